@@ -1,0 +1,93 @@
+/* qemb_hip.h -- C ABI of libqemb_hip.so: the MI355X (gfx950) per-fragment embedding solver that sits behind
+ * QuEmb's Frags / solver / int_transform seams (troyvvgroup/quemb).
+ *
+ * Conventions (reference precedent: shared/external/unrestricted_utils.py:142-160 -- caller-allocated
+ * numpy buffers handed to a C function as plain pointers):
+ *   - plain C types only; FP64; row-major; every HOST buffer (in and out) is allocated by the caller;
+ *   - device-resident state lives behind opaque handles with explicit *_free;
+ *   - every function returns 0 on success and <0 on failure; qemb_last_error() returns the message
+ *     (the reference's natives throw C++ exceptions mapped to Python -- _cpp/eri_sparse_DF.cpp:40-62 --
+ *     a C ABI returns a status instead and the Python shim raises);
+ *   - pair index ij = i(i+1)/2 + j, i >= j (shared/helper.py:260-276, _cpp/indexers.hpp:75-79);
+ *   - embedding orbitals are ordered fragment sites first, then bath (molbe/pfrag.py:489-491).
+ *   - There is NO CPU fallback: without a visible HIP device qemb_init() fails.
+ */
+#ifndef QEMB_HIP_H
+#define QEMB_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QEMB_OK 0
+#define QEMB_ERR_ARG (-1)
+#define QEMB_ERR_ALLOC (-2)
+#define QEMB_ERR_DEVICE (-3)
+#define QEMB_ERR_NOCONV (-4)
+#define QEMB_ERR_NUMERIC (-5)
+
+/* ---------------------------------------------------------------- library / device ------------- */
+int qemb_init(int device);                 /* select the GPU, create the library stream            */
+const char* qemb_last_error(void);
+const char* qemb_backend(void);            /* "hip-gfx950"                                         */
+int qemb_sync(void);
+int qemb_mem_info(size_t* free_bytes, size_t* total_bytes);
+
+/* raw device buffers (for callers that keep tensors resident, e.g. bench.py / multi-fragment sweeps) */
+int qemb_malloc(void** dptr, size_t bytes);
+int qemb_free(void* dptr);
+int qemb_h2d(void* dptr, const void* host, size_t bytes);
+int qemb_d2h(void* host, const void* dptr, size_t bytes);
+int qemb_d2d(void* dst, const void* src, size_t bytes);
+
+/* device-time laps measured with HIP events on the library stream (slot ids: see QEMB_TIMER_*) */
+#define QEMB_TIMER_LADDER 0
+#define QEMB_TIMER_RINGS 1
+#define QEMB_TIMER_ITER 2
+#define QEMB_TIMER_AO2MO 3
+#define QEMB_TIMER_SCF 4
+#define QEMB_TIMER_GEMM_ANY 5
+#define QEMB_TIMER_SCHMIDT 6
+#define QEMB_TIMER_DF 7
+int qemb_timer_begin(int slot);
+int qemb_timer_end(int slot);
+int qemb_timer_read(int slot, double* total_ms, int64_t* count);
+int qemb_timer_reset(int slot);
+
+/* ---------------------------------------------------------------- device-pointer primitives ---- */
+/* (the kernels the drivers below are composed of; exported so the parity tests can hit each one)    */
+
+/* C[b] = alpha*op(A[b])*op(B[b]) + beta*C[b] on v_mfma_f64_16x16x4_f64.
+ * a_kcontig: A(m,k)=A[m*lda+k] else A[k*lda+m];  b_kcontig: B(k,n)=B[n*ldb+k] else B[k*ldb+n].      */
+int qemb_op_gemm(int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t lda, int a_kcontig,
+                 int64_t strideA, const double* B, int64_t ldb, int b_kcontig, int64_t strideB, double beta,
+                 double* C, int64_t ldc, int64_t strideC, int64_t batch);
+int qemb_set_gemm_config(int cfg);         /* -1 = automatic tile choice; >=0 forces a tile config  */
+/* out[sum ik*so[k]] = alpha*in[sum ik*si[k]] + beta*out[...], 0<=ik<dim[k], 4 dims                  */
+int qemb_op_copy4(const int64_t dim[4], const double* in, const int64_t si[4], double* out,
+                  const int64_t so[4], double alpha, double beta);
+int qemb_op_outer4(const int64_t dim[4], const double* u, int64_t su0, int64_t su2, const double* v,
+                   int64_t sv1, int64_t sv3, double* out, const int64_t so[4], double alpha, double beta);
+int qemb_op_div_denom(double* x, int64_t d0, int64_t d1, int64_t d2, int64_t d3, const double* ea,
+                      const double* eb, const double* ec, const double* ed);
+int qemb_op_dot(int64_t n, const double* x, const double* y, double* out_dev);
+int qemb_op_absmax(int64_t n, const double* x, double* out_dev);
+int qemb_op_gemv_rows(int64_t rows, int64_t cols, const double* T, int64_t ldt, const double* x, double* y,
+                      double alpha, double beta);
+int qemb_op_contract_mid(int64_t outer, int64_t mid, int64_t inner, const double* T, const double* x,
+                         double* Y, int64_t ldy, double alpha, double beta);
+int qemb_op_unpack_s4(int64_t n, const double* s4, double* s1);
+int qemb_op_pack_s4(int64_t n, const double* s1, double* s4);
+int qemb_op_unpack_s8_to_s4(int64_t n, const double* s8, double* s4);
+int qemb_op_unpack_tril_rows(int64_t rows, int64_t n, const double* packed, double* full);
+int qemb_op_pack_tril_rows(int64_t rows, int64_t n, const double* full, double* packed);
+int qemb_op_jacobi_eigh(int64_t n, double* A, double* w, double* V, int* sweeps);
+int qemb_op_jacobi_svd(int64_t m, int64_t n, double* G, double* s, double* U, double* V, int* sweeps);
+int qemb_op_cholesky_lower(int64_t n, double* A);
+int qemb_op_tri_inverse_lower(int64_t n, const double* L, double* Linv);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QEMB_HIP_H */

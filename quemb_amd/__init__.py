@@ -1,0 +1,11 @@
+"""quemb_amd -- MI355X (gfx950) per-fragment embedding solver behind QuEmb's Frags / solver seams.
+
+Only the hot path of troyvvgroup/quemb is here: Schmidt decomposition, AO->fragment
+ERI transforms (dense + DF), fragment RHF, per-fragment CCSD, fragment energies and the density-matching
+residual.  All numerics run in hand-written HIP kernels inside ``libqemb_hip.so`` (C ABI in
+``include/qemb_hip.h``); this package is the thin Python host side mirroring the reference's names.
+There is no CPU fallback: importing is cheap, but the first call that needs the device raises if the
+library or a GPU is missing.
+"""
+
+__all__ = ["_lib"]

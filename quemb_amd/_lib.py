@@ -1,0 +1,151 @@
+"""ctypes binding of libqemb_hip.so (C ABI: include/qemb_hip.h).
+
+The reference binds its one native helper the same way -- ``ctypes`` + caller-allocated numpy buffers
+(shared/external/unrestricted_utils.py:142-160).  The library is built in-tree by ``__graft_entry__.build()``
+(``make -C quemb_amd/csrc``).  Nothing here falls back to the CPU: a missing library or device raises.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "libqemb_hip.so"
+
+c_dp = C.POINTER(C.c_double)
+c_i64 = C.c_int64
+c_vp = C.c_void_p
+
+
+class QembError(RuntimeError):
+    """Raised when a libqemb_hip call returns a non-zero status."""
+
+
+_lib = None
+_initialised_device = None
+
+
+def _declare(lib):
+    def f(name, restype, *argtypes):
+        fn = getattr(lib, name)
+        fn.restype = restype
+        fn.argtypes = list(argtypes)
+
+    I, D, P, V, L = C.c_int, C.c_double, c_vp, c_vp, c_i64
+    f("qemb_init", I, I)
+    f("qemb_last_error", C.c_char_p)
+    f("qemb_backend", C.c_char_p)
+    f("qemb_sync", I)
+    f("qemb_mem_info", I, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t))
+    f("qemb_malloc", I, C.POINTER(c_vp), C.c_size_t)
+    f("qemb_free", I, V)
+    f("qemb_h2d", I, V, V, C.c_size_t)
+    f("qemb_d2h", I, V, V, C.c_size_t)
+    f("qemb_d2d", I, V, V, C.c_size_t)
+    f("qemb_timer_begin", I, I)
+    f("qemb_timer_end", I, I)
+    f("qemb_timer_read", I, I, C.POINTER(D), C.POINTER(L))
+    f("qemb_timer_reset", I, I)
+    f("qemb_op_gemm", I, L, L, L, D, P, L, I, L, P, L, I, L, D, P, L, L, L)
+    f("qemb_set_gemm_config", I, I)
+    f("qemb_op_copy4", I, C.POINTER(L), P, C.POINTER(L), P, C.POINTER(L), D, D)
+    f("qemb_op_outer4", I, C.POINTER(L), P, L, L, P, L, L, P, C.POINTER(L), D, D)
+    f("qemb_op_div_denom", I, P, L, L, L, L, P, P, P, P)
+    f("qemb_op_dot", I, L, P, P, P)
+    f("qemb_op_absmax", I, L, P, P)
+    f("qemb_op_gemv_rows", I, L, L, P, L, P, P, D, D)
+    f("qemb_op_contract_mid", I, L, L, L, P, P, P, L, D, D)
+    f("qemb_op_unpack_s4", I, L, P, P)
+    f("qemb_op_pack_s4", I, L, P, P)
+    f("qemb_op_unpack_s8_to_s4", I, L, P, P)
+    f("qemb_op_unpack_tril_rows", I, L, L, P, P)
+    f("qemb_op_pack_tril_rows", I, L, L, P, P)
+    f("qemb_op_jacobi_eigh", I, L, P, P, P, C.POINTER(I))
+    f("qemb_op_jacobi_svd", I, L, L, P, P, P, P, C.POINTER(I))
+    f("qemb_op_cholesky_lower", I, L, P)
+    f("qemb_op_tri_inverse_lower", I, L, P, P)
+    # high-level entry points are declared lazily by the modules that use them (they may not exist in
+    # a partially built library during development)
+    return lib
+
+
+def load(path: os.PathLike | None = None):
+    """dlopen libqemb_hip.so (no device call is made)."""
+    global _lib
+    if _lib is None:
+        p = Path(path) if path else LIB_PATH
+        if not p.exists():
+            raise QembError(
+                f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(make -C quemb_amd/csrc). quemb_amd has no CPU fallback."
+            )
+        _lib = _declare(C.CDLL(str(p)))
+    return _lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().qemb_last_error().decode(errors="replace")
+        raise QembError(f"{what or 'libqemb_hip call'} failed (status {rc}): {msg}")
+
+
+def init(device: int | None = None):
+    """Select the GPU (LOCAL_RANK by default) and create the library stream."""
+    global _initialised_device
+    lib = load()
+    if device is None:
+        device = int(os.environ.get("LOCAL_RANK", "0"))
+    if _initialised_device != device:
+        check(lib.qemb_init(int(device)), "qemb_init")
+        _initialised_device = device
+    return lib
+
+
+class DeviceBuffer:
+    """A caller-owned FP64 device allocation (freed on __del__ / .free())."""
+
+    def __init__(self, nelem: int, lib=None):
+        self.lib = lib or init()
+        self.n = int(nelem)
+        p = c_vp()
+        check(self.lib.qemb_malloc(C.byref(p), max(self.n, 1) * 8), "qemb_malloc")
+        self.ptr = p.value
+
+    @classmethod
+    def from_numpy(cls, a: np.ndarray):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        b = cls(a.size)
+        b.upload(a)
+        return b
+
+    def upload(self, a: np.ndarray):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        assert a.size <= self.n
+        check(self.lib.qemb_h2d(self.ptr, a.ctypes.data, a.size * 8), "qemb_h2d")
+
+    def numpy(self, shape=None) -> np.ndarray:
+        out = np.empty(self.n, dtype=np.float64)
+        check(self.lib.qemb_d2h(out.ctypes.data, self.ptr, self.n * 8), "qemb_d2h")
+        return out if shape is None else out[: int(np.prod(shape))].reshape(shape)
+
+    def at(self, offset_elems: int) -> int:
+        return self.ptr + 8 * int(offset_elems)
+
+    def free(self):
+        if getattr(self, "ptr", None):
+            self.lib.qemb_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def i64x4(v):
+    return (c_i64 * 4)(*[int(x) for x in v])

@@ -1,0 +1,67 @@
+// api.cpp -- extern "C" surface of libqemb_hip.so (declared in include/qemb_hip.h).
+// Thin argument marshalling only; the work is in the drivers (ccsd.cpp, scf.cpp, ao2mo.cpp, schmidt.cpp)
+// and the device layer (dev_ops.h).
+#include <cstring>
+#include "../../include/qemb_hip.h"
+#include "dev_ops.h"
+
+using namespace qemb;
+namespace qemb { extern int g_gemm_force_cfg; }
+
+extern "C" {
+
+int qemb_init(int device) { return dev_init(device); }
+const char* qemb_last_error(void) { return last_error(); }
+const char* qemb_backend(void) { return dev_backend_name(); }
+int qemb_sync(void) { return dev_sync(); }
+int qemb_mem_info(size_t* f, size_t* t) { return dev_mem_info(f, t); }
+int qemb_malloc(void** p, size_t bytes) { return dev_alloc(p, bytes); }
+int qemb_free(void* p) { return dev_free(p); }
+int qemb_h2d(void* d, const void* h, size_t b) { return dev_h2d(d, h, b); }
+int qemb_d2h(void* h, const void* d, size_t b) { return dev_d2h(h, d, b); }
+int qemb_d2d(void* d, const void* s, size_t b) { return dev_d2d(d, s, b); }
+int qemb_timer_begin(int s) { return dev_timer_begin(s); }
+int qemb_timer_end(int s) { return dev_timer_end(s); }
+int qemb_timer_read(int s, double* ms, int64_t* c) { return dev_timer_read(s, ms, c); }
+int qemb_timer_reset(int s) { return dev_timer_reset(s); }
+
+int qemb_op_gemm(int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t lda, int a_kcontig,
+                 int64_t strideA, const double* B, int64_t ldb, int b_kcontig, int64_t strideB, double beta,
+                 double* C, int64_t ldc, int64_t strideC, int64_t batch) {
+  GemmDesc g{M, N, K, alpha, beta, A, lda, a_kcontig, strideA, B, ldb, b_kcontig, strideB, C, ldc, strideC, batch};
+  return dev_gemm(g);
+}
+int qemb_set_gemm_config(int cfg) { g_gemm_force_cfg = cfg; return QEMB_OK; }
+int qemb_op_copy4(const int64_t dim[4], const double* in, const int64_t si[4], double* out, const int64_t so[4],
+                  double alpha, double beta) {
+  Copy4Desc c{};
+  for (int k = 0; k < 4; ++k) { c.dim[k] = dim[k]; c.si[k] = si[k]; c.so[k] = so[k]; }
+  c.in = in; c.out = out; c.alpha = alpha; c.beta = beta;
+  return dev_copy4(c);
+}
+int qemb_op_outer4(const int64_t dim[4], const double* u, int64_t su0, int64_t su2, const double* v, int64_t sv1,
+                   int64_t sv3, double* out, const int64_t so[4], double alpha, double beta) {
+  Outer4Desc o{};
+  for (int k = 0; k < 4; ++k) { o.dim[k] = dim[k]; o.so[k] = so[k]; }
+  o.u = u; o.su0 = su0; o.su2 = su2; o.v = v; o.sv1 = sv1; o.sv3 = sv3; o.out = out; o.alpha = alpha; o.beta = beta;
+  return dev_outer4(o);
+}
+int qemb_op_div_denom(double* x, int64_t d0, int64_t d1, int64_t d2, int64_t d3, const double* ea, const double* eb,
+                      const double* ec, const double* ed) { return dev_div_denom(x, d0, d1, d2, d3, ea, eb, ec, ed); }
+int qemb_op_dot(int64_t n, const double* x, const double* y, double* o) { return dev_dot(n, x, y, o); }
+int qemb_op_absmax(int64_t n, const double* x, double* o) { return dev_absmax(n, x, o); }
+int qemb_op_gemv_rows(int64_t rows, int64_t cols, const double* T, int64_t ldt, const double* x, double* y, double alpha,
+                      double beta) { return dev_gemv_rows(rows, cols, T, ldt, x, y, alpha, beta); }
+int qemb_op_contract_mid(int64_t outer, int64_t mid, int64_t inner, const double* T, const double* x, double* Y,
+                         int64_t ldy, double alpha, double beta) { return dev_contract_mid(outer, mid, inner, T, x, Y, ldy, alpha, beta); }
+int qemb_op_unpack_s4(int64_t n, const double* s4, double* s1) { return dev_unpack_s4(n, s4, s1); }
+int qemb_op_pack_s4(int64_t n, const double* s1, double* s4) { return dev_pack_s4(n, s1, s4); }
+int qemb_op_unpack_s8_to_s4(int64_t n, const double* s8, double* s4) { return dev_unpack_s8_to_s4(n, s8, s4); }
+int qemb_op_unpack_tril_rows(int64_t rows, int64_t n, const double* p, double* f) { return dev_unpack_tril_rows(rows, n, p, f); }
+int qemb_op_pack_tril_rows(int64_t rows, int64_t n, const double* f, double* p) { return dev_pack_tril_rows(rows, n, f, p); }
+int qemb_op_jacobi_eigh(int64_t n, double* A, double* w, double* V, int* sweeps) { return dev_jacobi_eigh(n, A, w, V, sweeps); }
+int qemb_op_jacobi_svd(int64_t m, int64_t n, double* G, double* s, double* U, double* V, int* sweeps) { return dev_jacobi_svd(m, n, G, s, U, V, sweeps); }
+int qemb_op_cholesky_lower(int64_t n, double* A) { return dev_cholesky_lower(n, A); }
+int qemb_op_tri_inverse_lower(int64_t n, const double* L, double* Linv) { return dev_tri_inverse_lower(n, L, Linv); }
+
+}  // extern "C"

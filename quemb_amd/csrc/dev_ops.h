@@ -1,0 +1,132 @@
+// dev_ops.h -- the device-operation layer of libqemb_hip.
+//
+// Every driver in this directory (ccsd.cpp, scf.cpp, ao2mo.cpp, schmidt.cpp, api.cpp) is plain
+// C++ written against THIS interface only.  The product library links dev_ops_hip.hip (hand-written
+// gfx950 kernels).  tests/hostcheck/ links the same drivers against a slow scalar mock so that the
+// host logic can be exercised in a GPU-less container; that mock is test infrastructure and is never
+// part of libqemb_hip.so.
+//
+// Conventions: FP64 only, row-major, all pointers are DEVICE pointers unless the name says host,
+// sizes are int64_t.  Every function returns 0 on success, <0 on error (qemb::last_error() has text).
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include "../../include/qemb_hip.h"
+
+namespace qemb {
+
+// ---- error channel -------------------------------------------------------------------------
+void set_error(const std::string& msg);
+const char* last_error();
+
+// status codes: QEMB_OK / QEMB_ERR_* from the public header
+
+
+// ---- device / memory -----------------------------------------------------------------------
+int dev_init(int device);            // select device, create the library stream
+int dev_sync();                      // wait for the library stream
+int dev_alloc(void** p, size_t bytes);
+int dev_free(void* p);
+int dev_h2d(void* dst, const void* src_host, size_t bytes);
+int dev_d2h(void* dst_host, const void* src, size_t bytes);
+int dev_d2d(void* dst, const void* src, size_t bytes);
+int dev_fill(double* x, int64_t n, double value);
+int dev_mem_info(size_t* free_b, size_t* total_b);
+const char* dev_backend_name();      // "hip-gfx950" for the product, "hostcheck" for the mock
+
+// ---- timing (HIP events on the library stream) ------------------------------------------------
+// A "lap" accumulates elapsed device time of every region bracketed with the same slot id.
+int dev_timer_begin(int slot);
+int dev_timer_end(int slot);
+int dev_timer_read(int slot, double* total_ms, int64_t* count);   // syncs
+int dev_timer_reset(int slot);
+enum { TIMER_LADDER = 0, TIMER_RINGS = 1, TIMER_ITER = 2, TIMER_AO2MO = 3, TIMER_SCF = 4,
+       TIMER_GEMM_ANY = 5, TIMER_SCHMIDT = 6, TIMER_DF = 7, TIMER_NSLOTS = 16 };
+
+// ---- GEMM (FP64 MFMA) --------------------------------------------------------------------------
+// C[b] = alpha * op(A[b]) * op(B[b]) + beta * C[b],   b = 0..batch-1
+//   op(A) is M x K.  a_kcontig: A(m,k) = A[m*lda + k]   (row-major M x K);
+//                   !a_kcontig: A(m,k) = A[k*lda + m]   (stored K x M, i.e. "transposed")
+//   op(B) is K x N.  b_kcontig: B(k,n) = B[n*ldb + k]   (stored N x K, i.e. "transposed");
+//                   !b_kcontig: B(k,n) = B[k*ldb + n]   (row-major K x N)
+//   C is row-major M x N with leading dimension ldc.  Batch strides are in elements.
+struct GemmDesc {
+  int64_t M, N, K;
+  double alpha, beta;
+  const double* A; int64_t lda; int a_kcontig; int64_t strideA;
+  const double* B; int64_t ldb; int b_kcontig; int64_t strideB;
+  double* C; int64_t ldc; int64_t strideC;
+  int64_t batch;
+};
+int dev_gemm(const GemmDesc& g);
+
+// ---- strided tensor copy / add (up to 4 dims) -------------------------------------------------
+// out[i0*so[0]+i1*so[1]+i2*so[2]+i3*so[3]] = alpha * in[i0*si[0]+...+i3*si[3]] + beta * out[...]
+// for 0 <= ik < dim[k].  Covers permutations, block extraction/placement, axpby, scaling.
+// beta == 0 never reads out.
+struct Copy4Desc {
+  int64_t dim[4];
+  const double* in; int64_t si[4];
+  double* out; int64_t so[4];
+  double alpha, beta;
+};
+int dev_copy4(const Copy4Desc& c);
+
+// out[i0,i1,i2,i3] (strides so) = beta*out + alpha * u[i0*su0 + i2*su2] * v[i1*sv1 + i3*sv3]
+// (the t1 (x) t1 outer products of tau and the disconnected RDM pieces)
+struct Outer4Desc {
+  int64_t dim[4];
+  const double* u; int64_t su0, su2;
+  const double* v; int64_t sv1, sv3;
+  double* out; int64_t so[4];
+  double alpha, beta;
+};
+int dev_outer4(const Outer4Desc& c);
+
+// x[i0,i1,i2,i3] (contiguous, dims d0..d3) *= 1 / (ea[i0] + eb[i1] - ec[i2] - ed[i3])
+// (orbital-energy denominators; pass d1 = d3 = 1 with eb = ed = nullptr for t1)
+int dev_div_denom(double* x, int64_t d0, int64_t d1, int64_t d2, int64_t d3,
+                  const double* ea, const double* eb, const double* ec, const double* ed);
+
+// ---- reductions ---------------------------------------------------------------------------------
+// out_dev[0] = sum_i x[i]*y[i]   (deterministic two-stage reduction; out_dev is a device double)
+int dev_dot(int64_t n, const double* x, const double* y, double* out_dev);
+// out_dev[0] = max_i |x[i]|
+int dev_absmax(int64_t n, const double* x, double* out_dev);
+
+// ---- matrix-vector style contractions for J/K builds (HBM bound) -------------------------------
+// y[r] = alpha * sum_c T[r*ldt + c] * x[c] + beta*y[r]        r < rows, c < cols
+int dev_gemv_rows(int64_t rows, int64_t cols, const double* T, int64_t ldt, const double* x,
+                  double* y, double alpha, double beta);
+// Y[p*ldy + r] = alpha * sum_m x[m] * T[(p*mid + m)*inner + r] + beta*Y   p<outer, m<mid, r<inner
+int dev_contract_mid(int64_t outer, int64_t mid, int64_t inner, const double* T, const double* x,
+                     double* Y, int64_t ldy, double alpha, double beta);
+
+// ---- packed-pair index transforms ------------------------------------------------------------------
+// pair index ij = i(i+1)/2 + j, i >= j   (reference: shared/helper.py:260-276 ravel_symmetric)
+// s4 (npair x npair)  ->  s1 (n^4, [i,j,k,l])
+int dev_unpack_s4(int64_t n, const double* s4, double* s1);
+// s1 -> s4 (reads i>=j, k>=l elements)
+int dev_pack_s4(int64_t n, const double* s1, double* s4);
+// s8 (1-D npair(npair)) -> s4
+int dev_unpack_s8_to_s4(int64_t n, const double* s8, double* s4);
+// rows of a (rows x npair(n)) packed matrix -> (rows x n x n) full symmetric, and back
+int dev_unpack_tril_rows(int64_t rows, int64_t n, const double* packed, double* full);
+int dev_pack_tril_rows(int64_t rows, int64_t n, const double* full, double* packed);
+
+// ---- symmetric eigen / SVD by wavefront Jacobi (no MFMA) -----------------------------------------
+// A (n x n, symmetric, row-major, overwritten) -> eigenvalues w[n] ascending and eigenvectors in the
+// COLUMNS of V (n x n row-major).  sweeps_out (host int*) may be null.
+int dev_jacobi_eigh(int64_t n, double* A, double* w, double* V, int* sweeps_out);
+// One-sided Jacobi SVD of G (m x n row-major, m >= n), overwritten by U*diag(s) columns;
+// s[n] descending, V (n x n) right vectors in columns, U (m x n) left vectors in columns.
+int dev_jacobi_svd(int64_t m, int64_t n, double* G, double* s, double* U, double* V, int* sweeps_out);
+
+// ---- Cholesky / triangular inverse (DF metric) ---------------------------------------------------------
+// A (n x n SPD row-major) -> L lower triangular with A = L L^T (upper part zeroed), in place
+int dev_cholesky_lower(int64_t n, double* A);
+// Linv = L^{-1} (lower triangular, row-major n x n)
+int dev_tri_inverse_lower(int64_t n, const double* L, double* Linv);
+
+}  // namespace qemb

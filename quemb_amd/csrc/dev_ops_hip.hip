@@ -1,0 +1,515 @@
+// dev_ops_hip.hip -- gfx950 implementation of dev_ops.h (everything except the MFMA GEMM, which lives
+// in gemm_f64.hip, and the Jacobi / Cholesky kernels in linalg_f64.hip).
+//
+// These are the HBM-bound pieces of the hot path: tensor permutations between the GEMM-shaped CCSD
+// contractions, the tau / denominator / DIIS vector work (reference: PySCF ccsd.update_amps as driven by
+// molbe/solver.py:907), the J/K contractions of the fragment RHF (molbe/helper.py:64 dot_eri_dm) and the
+// packed-pair (s4/s8) <-> full index transforms (ao2mo.restore at helper.py:189, mbe.py:1155).
+// They are written for coalescing (16-byte lanes where the layout allows, LDS-tiled transposes when the
+// contiguous dimension changes) rather than reshaped into GEMMs.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+#include "dev_ops.h"
+#include "hip_common.h"
+
+namespace qemb {
+
+// ------------------------------------------------------------------------------------------------
+// error channel + device state
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+const char* last_error() { return g_err.c_str(); }
+
+static hipStream_t g_stream = nullptr;
+static int g_device = -1;
+static double* g_partials = nullptr;       // reduction scratch (NPART doubles)
+static constexpr int NPART = 2048;
+static double* g_ws = nullptr;             // growable workspace for contract_mid partials
+static size_t g_ws_bytes = 0;
+
+struct TimerSlot { hipEvent_t e0 = nullptr, e1 = nullptr; double total_ms = 0; int64_t count = 0;
+                   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending; };
+static TimerSlot g_timers[TIMER_NSLOTS];
+
+hipStream_t hip_stream() { return g_stream; }
+const char* dev_backend_name() { return "hip-gfx950"; }
+
+int dev_init(int device) {
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (ndev <= 0) { set_error("no HIP device visible: libqemb_hip has no CPU fallback"); return QEMB_ERR_DEVICE; }
+  if (device < 0 || device >= ndev) { set_error("dev_init: device index out of range"); return QEMB_ERR_ARG; }
+  if (g_stream && g_device == device) return QEMB_OK;
+  HIP_TRY(hipSetDevice(device));
+  if (g_stream) { (void)hipStreamDestroy(g_stream); g_stream = nullptr; g_partials = nullptr; g_ws = nullptr; g_ws_bytes = 0; }
+  HIP_TRY(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+  HIP_TRY(hipMalloc((void**)&g_partials, NPART * sizeof(double)));
+  g_device = device;
+  return QEMB_OK;
+}
+#define REQUIRE_INIT()                                                                          \
+  do { if (!g_stream) { set_error("libqemb_hip: call qemb_init(device) first"); return QEMB_ERR_DEVICE; } } while (0)
+
+int dev_sync() { REQUIRE_INIT(); HIP_TRY(hipStreamSynchronize(g_stream)); return QEMB_OK; }
+int dev_alloc(void** p, size_t bytes) {
+  REQUIRE_INIT();
+  if (bytes == 0) bytes = 16;
+  hipError_t e = hipMalloc(p, bytes);
+  if (e != hipSuccess) { set_error("hipMalloc of " + std::to_string(bytes) + " bytes failed: " + hipGetErrorString(e)); return QEMB_ERR_ALLOC; }
+  return QEMB_OK;
+}
+int dev_free(void* p) { if (p) { HIP_TRY(hipStreamSynchronize(g_stream)); HIP_TRY(hipFree(p)); } return QEMB_OK; }
+int dev_h2d(void* dst, const void* src, size_t bytes) {
+  REQUIRE_INIT();
+  HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, g_stream));
+  HIP_TRY(hipStreamSynchronize(g_stream));   // pageable host memory: keep the contract simple
+  return QEMB_OK;
+}
+int dev_d2h(void* dst, const void* src, size_t bytes) {
+  REQUIRE_INIT();
+  HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, g_stream));
+  HIP_TRY(hipStreamSynchronize(g_stream));
+  return QEMB_OK;
+}
+int dev_d2d(void* dst, const void* src, size_t bytes) {
+  REQUIRE_INIT();
+  HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, g_stream));
+  return QEMB_OK;
+}
+int dev_mem_info(size_t* free_b, size_t* total_b) { REQUIRE_INIT(); HIP_TRY(hipMemGetInfo(free_b, total_b)); return QEMB_OK; }
+
+static int ensure_ws(size_t bytes) {
+  if (bytes <= g_ws_bytes) return QEMB_OK;
+  if (g_ws) { HIP_TRY(hipStreamSynchronize(g_stream)); HIP_TRY(hipFree(g_ws)); g_ws = nullptr; g_ws_bytes = 0; }
+  hipError_t e = hipMalloc((void**)&g_ws, bytes);
+  if (e != hipSuccess) { set_error("workspace hipMalloc failed"); return QEMB_ERR_ALLOC; }
+  g_ws_bytes = bytes;
+  return QEMB_OK;
+}
+
+// ---- timers -----------------------------------------------------------------------------------
+int dev_timer_begin(int slot) {
+  REQUIRE_INIT();
+  if (slot < 0 || slot >= TIMER_NSLOTS) return QEMB_ERR_ARG;
+  TimerSlot& t = g_timers[slot];
+  hipEvent_t a, b;
+  HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b));
+  HIP_TRY(hipEventRecord(a, g_stream));
+  t.pending.emplace_back(a, b);
+  return QEMB_OK;
+}
+int dev_timer_end(int slot) {
+  REQUIRE_INIT();
+  if (slot < 0 || slot >= TIMER_NSLOTS) return QEMB_ERR_ARG;
+  TimerSlot& t = g_timers[slot];
+  if (t.pending.empty()) return QEMB_ERR_ARG;
+  HIP_TRY(hipEventRecord(t.pending.back().second, g_stream));
+  return QEMB_OK;
+}
+int dev_timer_read(int slot, double* total_ms, int64_t* count) {
+  REQUIRE_INIT();
+  if (slot < 0 || slot >= TIMER_NSLOTS) return QEMB_ERR_ARG;
+  TimerSlot& t = g_timers[slot];
+  HIP_TRY(hipStreamSynchronize(g_stream));
+  for (auto& pr : t.pending) {
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, pr.first, pr.second));
+    t.total_ms += ms; t.count += 1;
+    (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second);
+  }
+  t.pending.clear();
+  if (total_ms) *total_ms = t.total_ms;
+  if (count) *count = t.count;
+  return QEMB_OK;
+}
+int dev_timer_reset(int slot) {
+  double a; int64_t c;
+  int rc = dev_timer_read(slot, &a, &c);
+  if (rc) return rc;
+  g_timers[slot].total_ms = 0; g_timers[slot].count = 0;
+  return QEMB_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// fill
+// ------------------------------------------------------------------------------------------------
+__global__ void fill_kernel(double* x, long long n, double v) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) x[i] = v;
+}
+int dev_fill(double* x, int64_t n, double value) {
+  REQUIRE_INIT();
+  if (n <= 0) return QEMB_OK;
+  const int grid = (int)std::min<int64_t>((n + 255) / 256, 4096);
+  hipLaunchKernelGGL(fill_kernel, dim3(grid), dim3(256), 0, g_stream, x, (long long)n, value);
+  HIP_TRY(hipGetLastError());
+  return QEMB_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// strided 4-d copy/add.  Two kernels: "linear" (threads run along the dimension that is contiguous on
+// the input side -- also contiguous on the output side when no transpose is involved) and "transpose"
+// (32x32 LDS tile over the input-contiguous x output-contiguous pair of dimensions).
+// ------------------------------------------------------------------------------------------------
+struct Copy4K {
+  long long d0, d1, d2, d3;
+  long long si0, si1, si2, si3, so0, so1, so2, so3;
+  const double* in; double* out; double alpha, beta;
+};
+
+__global__ void __launch_bounds__(256) copy4_linear_kernel(Copy4K c) {
+  // x: combined (i2,i3) index, y: i1, z: i0 (both looped)
+  const long long n23 = c.d2 * c.d3;
+  for (long long i0 = blockIdx.z; i0 < c.d0; i0 += gridDim.z) {
+    for (long long i1 = blockIdx.y; i1 < c.d1; i1 += gridDim.y) {
+      const long long bi = i0 * c.si0 + i1 * c.si1, bo = i0 * c.so0 + i1 * c.so1;
+      for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n23;
+           t += (long long)gridDim.x * blockDim.x) {
+        const long long i2 = t / c.d3, i3 = t - i2 * c.d3;
+        const double v = c.alpha * c.in[bi + i2 * c.si2 + i3 * c.si3];
+        double* p = c.out + bo + i2 * c.so2 + i3 * c.so3;
+        *p = (c.beta != 0.0) ? v + c.beta * (*p) : v;
+      }
+    }
+  }
+}
+
+// dims canonicalised so that si3 == 1 (input contiguous along i3) and so2 == 1 (output contiguous along i2)
+__global__ void __launch_bounds__(256) copy4_transpose_kernel(Copy4K c, int tiles3) {
+  __shared__ double tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const long long t2 = blockIdx.x / tiles3, t3 = blockIdx.x % tiles3;
+  const long long base2 = t2 * 32, base3 = t3 * 32;
+  for (long long i0 = blockIdx.z; i0 < c.d0; i0 += gridDim.z) {
+    for (long long i1 = blockIdx.y; i1 < c.d1; i1 += gridDim.y) {
+      const long long bi = i0 * c.si0 + i1 * c.si1, bo = i0 * c.so0 + i1 * c.so1;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long long i2 = base2 + ty + 8 * r, i3 = base3 + tx;
+        if (i2 < c.d2 && i3 < c.d3) tile[ty + 8 * r][tx] = c.in[bi + i2 * c.si2 + i3 * c.si3];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long long i3 = base3 + ty + 8 * r, i2 = base2 + tx;
+        if (i2 < c.d2 && i3 < c.d3) {
+          const double v = c.alpha * tile[tx][ty + 8 * r];
+          double* p = c.out + bo + i2 * c.so2 + i3 * c.so3;
+          *p = (c.beta != 0.0) ? v + c.beta * (*p) : v;
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+int dev_copy4(const Copy4Desc& cd) {
+  REQUIRE_INIT();
+  for (int k = 0; k < 4; ++k) if (cd.dim[k] <= 0) return QEMB_OK;
+  if (!cd.in || !cd.out) { set_error("dev_copy4: null pointer"); return QEMB_ERR_ARG; }
+  // canonicalise the loop order: input-contiguous dim -> slot 3, output-contiguous dim -> slot 2
+  int order[4] = {0, 1, 2, 3};
+  int a = -1, b = -1;
+  for (int k = 3; k >= 0; --k) if (cd.si[k] == 1 && cd.dim[k] > 1) { a = k; break; }
+  for (int k = 3; k >= 0; --k) if (cd.so[k] == 1 && cd.dim[k] > 1) { b = k; break; }
+  bool transpose = (a >= 0 && b >= 0 && a != b && cd.dim[a] >= 8 && cd.dim[b] >= 8);
+  if (a < 0) a = 3;
+  {
+    std::vector<int> rest;
+    if (transpose) { for (int k = 0; k < 4; ++k) if (k != a && k != b) rest.push_back(k); order[0] = rest[0]; order[1] = rest[1]; order[2] = b; order[3] = a; }
+    else { for (int k = 0; k < 4; ++k) if (k != a) rest.push_back(k); order[0] = rest[0]; order[1] = rest[1]; order[2] = rest[2]; order[3] = a; }
+  }
+  Copy4K c;
+  long long d[4], si[4], so[4];
+  for (int k = 0; k < 4; ++k) { d[k] = cd.dim[order[k]]; si[k] = cd.si[order[k]]; so[k] = cd.so[order[k]]; }
+  c.d0 = d[0]; c.d1 = d[1]; c.d2 = d[2]; c.d3 = d[3];
+  c.si0 = si[0]; c.si1 = si[1]; c.si2 = si[2]; c.si3 = si[3];
+  c.so0 = so[0]; c.so1 = so[1]; c.so2 = so[2]; c.so3 = so[3];
+  c.in = cd.in; c.out = cd.out; c.alpha = cd.alpha; c.beta = cd.beta;
+  if (c.d2 * c.d3 >= (1LL << 40)) { set_error("dev_copy4: inner extent too large"); return QEMB_ERR_ARG; }
+  const unsigned gy = (unsigned)std::min<long long>(c.d1, 65535), gz = (unsigned)std::min<long long>(c.d0, 65535);
+  if (transpose) {
+    const long long tiles2 = (c.d2 + 31) / 32, tiles3 = (c.d3 + 31) / 32;
+    if (tiles2 * tiles3 > 0x7fffffffLL) { set_error("dev_copy4: too many tiles"); return QEMB_ERR_ARG; }
+    hipLaunchKernelGGL(copy4_transpose_kernel, dim3((unsigned)(tiles2 * tiles3), gy, gz), dim3(256), 0, g_stream, c, (int)tiles3);
+  } else {
+    const long long n23 = c.d2 * c.d3;
+    const unsigned gx = (unsigned)std::min<long long>((n23 + 255) / 256, 1 << 20);
+    hipLaunchKernelGGL(copy4_linear_kernel, dim3(gx, gy, gz), dim3(256), 0, g_stream, c);
+  }
+  HIP_TRY(hipGetLastError());
+  return QEMB_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// outer4 / denominators
+// ------------------------------------------------------------------------------------------------
+struct Outer4K {
+  long long d0, d1, d2, d3, su0, su2, sv1, sv3, so0, so1, so2, so3;
+  const double* u; const double* v; double* out; double alpha, beta;
+};
+__global__ void __launch_bounds__(256) outer4_kernel(Outer4K c) {
+  const long long n23 = c.d2 * c.d3;
+  for (long long i0 = blockIdx.z; i0 < c.d0; i0 += gridDim.z)
+    for (long long i1 = blockIdx.y; i1 < c.d1; i1 += gridDim.y)
+      for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n23; t += (long long)gridDim.x * blockDim.x) {
+        const long long i2 = t / c.d3, i3 = t - i2 * c.d3;
+        const double val = c.alpha * c.u[i0 * c.su0 + i2 * c.su2] * c.v[i1 * c.sv1 + i3 * c.sv3];
+        double* p = c.out + i0 * c.so0 + i1 * c.so1 + i2 * c.so2 + i3 * c.so3;
+        *p = (c.beta != 0.0) ? val + c.beta * (*p) : val;
+      }
+}
+int dev_outer4(const Outer4Desc& o) {
+  REQUIRE_INIT();
+  for (int k = 0; k < 4; ++k) if (o.dim[k] <= 0) return QEMB_OK;
+  Outer4K c{o.dim[0], o.dim[1], o.dim[2], o.dim[3], o.su0, o.su2, o.sv1, o.sv3, o.so[0], o.so[1], o.so[2], o.so[3], o.u, o.v, o.out, o.alpha, o.beta};
+  const long long n23 = c.d2 * c.d3;
+  const unsigned gx = (unsigned)std::min<long long>((n23 + 255) / 256, 1 << 20);
+  hipLaunchKernelGGL(outer4_kernel, dim3(gx, (unsigned)std::min<long long>(c.d1, 65535), (unsigned)std::min<long long>(c.d0, 65535)), dim3(256), 0, g_stream, c);
+  HIP_TRY(hipGetLastError());
+  return QEMB_OK;
+}
+
+__global__ void __launch_bounds__(256) div_denom_kernel(double* x, long long d0, long long d1, long long d2, long long d3,
+                                                        const double* ea, const double* eb, const double* ec, const double* ed) {
+  const long long n23 = d2 * d3;
+  for (long long i0 = blockIdx.z; i0 < d0; i0 += gridDim.z)
+    for (long long i1 = blockIdx.y; i1 < d1; i1 += gridDim.y) {
+      const double e01 = ea[i0] + (eb ? eb[i1] : 0.0);
+      double* row = x + (i0 * d1 + i1) * n23;
+      for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n23; t += (long long)gridDim.x * blockDim.x) {
+        const long long i2 = t / d3, i3 = t - i2 * d3;
+        row[t] = row[t] / (e01 - ec[i2] - (ed ? ed[i3] : 0.0));
+      }
+    }
+}
+int dev_div_denom(double* x, int64_t d0, int64_t d1, int64_t d2, int64_t d3, const double* ea, const double* eb, const double* ec, const double* ed) {
+  REQUIRE_INIT();
+  if (d0 <= 0 || d1 <= 0 || d2 <= 0 || d3 <= 0) return QEMB_OK;
+  const long long n23 = d2 * d3;
+  const unsigned gx = (unsigned)std::min<long long>((n23 + 255) / 256, 1 << 20);
+  hipLaunchKernelGGL(div_denom_kernel, dim3(gx, (unsigned)std::min<long long>(d1, 65535), (unsigned)std::min<long long>(d0, 65535)), dim3(256), 0, g_stream,
+                     x, (long long)d0, (long long)d1, (long long)d2, (long long)d3, ea, eb, ec, ed);
+  HIP_TRY(hipGetLastError());
+  return QEMB_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// reductions (deterministic: fixed grid, fixed tree)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
+  return v;
+}
+template <bool MAX>
+__device__ __forceinline__ double block_reduce(double v, double* sh) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  v = MAX ? wave_max(v) : wave_sum(v);
+  if (lane == 0) sh[w] = v;
+  __syncthreads();
+  double r = 0.0;
+  if (threadIdx.x == 0) { r = sh[0]; for (int k = 1; k < nw; ++k) r = MAX ? fmax(r, sh[k]) : r + sh[k]; }
+  __syncthreads();
+  return r;  // valid on thread 0
+}
+template <bool MAX>
+__global__ void __launch_bounds__(256) reduce_stage1(long long n, const double* x, const double* y, double* partial) {
+  __shared__ double sh[4];
+  double acc = 0.0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    acc = MAX ? fmax(acc, fabs(x[i])) : acc + x[i] * y[i];
+  const double r = block_reduce<MAX>(acc, sh);
+  if (threadIdx.x == 0) partial[blockIdx.x] = r;
+}
+template <bool MAX>
+__global__ void __launch_bounds__(256) reduce_stage2(int np, const double* partial, double* out) {
+  __shared__ double sh[4];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < np; i += blockDim.x) acc = MAX ? fmax(acc, partial[i]) : acc + partial[i];
+  const double r = block_reduce<MAX>(acc, sh);
+  if (threadIdx.x == 0) out[0] = r;
+}
+int dev_dot(int64_t n, const double* x, const double* y, double* out_dev) {
+  REQUIRE_INIT();
+  const int np = (int)std::max<int64_t>(1, std::min<int64_t>((n + 1023) / 1024, NPART));
+  hipLaunchKernelGGL(reduce_stage1<false>, dim3(np), dim3(256), 0, g_stream, (long long)n, x, y, g_partials);
+  hipLaunchKernelGGL(reduce_stage2<false>, dim3(1), dim3(256), 0, g_stream, np, g_partials, out_dev);
+  HIP_TRY(hipGetLastError());
+  return QEMB_OK;
+}
+int dev_absmax(int64_t n, const double* x, double* out_dev) {
+  REQUIRE_INIT();
+  const int np = (int)std::max<int64_t>(1, std::min<int64_t>((n + 1023) / 1024, NPART));
+  hipLaunchKernelGGL(reduce_stage1<true>, dim3(np), dim3(256), 0, g_stream, (long long)n, x, x, g_partials);
+  hipLaunchKernelGGL(reduce_stage2<true>, dim3(1), dim3(256), 0, g_stream, np, g_partials, out_dev);
+  HIP_TRY(hipGetLastError());
+  return QEMB_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// J/K style contractions
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) gemv_rows_kernel(long long rows, long long cols, const double* T, long long ldt,
+                                                        const double* x, double* y, double alpha, double beta) {
+  __shared__ double sh[4];
+  for (long long r = blockIdx.x; r < rows; r += gridDim.x) {
+    const double* row = T + r * ldt;
+    double acc = 0.0;
+    for (long long c = threadIdx.x; c < cols; c += blockDim.x) acc += row[c] * x[c];
+    const double s = block_reduce<false>(acc, sh);
+    if (threadIdx.x == 0) y[r] = (beta != 0.0) ? alpha * s + beta * y[r] : alpha * s;
+  }
+}
+int dev_gemv_rows(int64_t rows, int64_t cols, const double* T, int64_t ldt, const double* x, double* y, double alpha, double beta) {
+  REQUIRE_INIT();
+  if (rows <= 0) return QEMB_OK;
+  const unsigned grid = (unsigned)std::min<int64_t>(rows, 1 << 20);
+  hipLaunchKernelGGL(gemv_rows_kernel, dim3(grid), dim3(256), 0, g_stream, (long long)rows, (long long)cols, T, (long long)ldt, x, y, alpha, beta);
+  HIP_TRY(hipGetLastError());
+  return QEMB_OK;
+}
+
+// partial[p][chunk][r] = sum_{m in chunk} x[m] * T[p][m][r];  threads run along r (contiguous)
+__global__ void __launch_bounds__(256) contract_mid_stage1(long long mid, long long inner, int nchunk, const double* T,
+                                                           const double* x, double* partial) {
+  const long long p = blockIdx.y;
+  const int ch = blockIdx.x;
+  const long long m_per = (mid + nchunk - 1) / nchunk;
+  const long long m0 = ch * m_per, m1 = (m0 + m_per < mid) ? m0 + m_per : mid;
+  for (long long r = threadIdx.x; r < inner; r += blockDim.x) {
+    double acc = 0.0;
+    const double* base = T + (p * mid) * inner + r;
+    for (long long m = m0; m < m1; ++m) acc += x[m] * base[m * inner];
+    partial[(p * nchunk + ch) * inner + r] = acc;
+  }
+}
+__global__ void __launch_bounds__(256) contract_mid_stage2(long long outer, long long inner, int nchunk, const double* partial,
+                                                           double* Y, long long ldy, double alpha, double beta) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= outer * inner) return;
+  const long long p = t / inner, r = t - p * inner;
+  double acc = 0.0;
+  for (int ch = 0; ch < nchunk; ++ch) acc += partial[(p * nchunk + ch) * inner + r];
+  double* y = Y + p * ldy + r;
+  *y = (beta != 0.0) ? alpha * acc + beta * (*y) : alpha * acc;
+}
+int dev_contract_mid(int64_t outer, int64_t mid, int64_t inner, const double* T, const double* x, double* Y, int64_t ldy, double alpha, double beta) {
+  REQUIRE_INIT();
+  if (outer <= 0 || inner <= 0) return QEMB_OK;
+  if (outer > 65535) { set_error("dev_contract_mid: outer too large"); return QEMB_ERR_ARG; }
+  int nchunk = (int)std::max<int64_t>(1, std::min<int64_t>(mid / 64, std::max<int64_t>(1, 4096 / outer)));
+  int rc = ensure_ws((size_t)outer * nchunk * inner * sizeof(double));
+  if (rc) return rc;
+  hipLaunchKernelGGL(contract_mid_stage1, dim3(nchunk, (unsigned)outer), dim3(256), 0, g_stream, (long long)mid, (long long)inner, nchunk, T, x, g_ws);
+  const long long tot = outer * inner;
+  hipLaunchKernelGGL(contract_mid_stage2, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, g_stream, (long long)outer, (long long)inner, nchunk, g_ws, Y, (long long)ldy, alpha, beta);
+  HIP_TRY(hipGetLastError());
+  return QEMB_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// packed-pair transforms.  pair(i,j) = i(i+1)/2 + j, i >= j  (reference shared/helper.py:260-276)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ long long pair_idx(long long i, long long j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
+
+// s1[i,j,k,l] = s4[pair(i,j), pair(k,l)];  one block row per (i,j), threads along (k,l)
+__global__ void __launch_bounds__(256) unpack_s4_kernel(long long n, const double* s4, double* s1) {
+  const long long np = n * (n + 1) / 2, n2 = n * n;
+  for (long long ij = blockIdx.x; ij < n2; ij += gridDim.x) {
+    const long long i = ij / n, j = ij - i * n;
+    const double* src = s4 + pair_idx(i, j) * np;
+    double* dst = s1 + ij * n2;
+    for (long long kl = threadIdx.x; kl < n2; kl += blockDim.x) {
+      const long long k = kl / n, l = kl - k * n;
+      dst[kl] = src[pair_idx(k, l)];
+    }
+  }
+}
+int dev_unpack_s4(int64_t n, const double* s4, double* s1) {
+  REQUIRE_INIT();
+  hipLaunchKernelGGL(unpack_s4_kernel, dim3((unsigned)std::min<int64_t>(n * n, 1 << 20)), dim3(256), 0, g_stream, (long long)n, s4, s1);
+  HIP_TRY(hipGetLastError());
+  return QEMB_OK;
+}
+__global__ void __launch_bounds__(256) pack_s4_kernel(long long n, const double* s1, double* s4) {
+  const long long np = n * (n + 1) / 2, n2 = n * n;
+  for (long long ij = blockIdx.x; ij < np; ij += gridDim.x) {
+    // unravel ij -> (i,j), i >= j
+    long long i = (long long)((sqrt(8.0 * (double)ij + 1.0) - 1.0) * 0.5);
+    while (i * (i + 1) / 2 > ij) --i;
+    while ((i + 1) * (i + 2) / 2 <= ij) ++i;
+    const long long j = ij - i * (i + 1) / 2;
+    const double* src = s1 + (i * n + j) * n2;
+    double* dst = s4 + ij * np;
+    for (long long kl = threadIdx.x; kl < np; kl += blockDim.x) {
+      long long k = (long long)((sqrt(8.0 * (double)kl + 1.0) - 1.0) * 0.5);
+      while (k * (k + 1) / 2 > kl) --k;
+      while ((k + 1) * (k + 2) / 2 <= kl) ++k;
+      const long long l = kl - k * (k + 1) / 2;
+      dst[kl] = src[k * n + l];
+    }
+  }
+}
+int dev_pack_s4(int64_t n, const double* s1, double* s4) {
+  REQUIRE_INIT();
+  const int64_t np = n * (n + 1) / 2;
+  hipLaunchKernelGGL(pack_s4_kernel, dim3((unsigned)std::min<int64_t>(np, 1 << 20)), dim3(256), 0, g_stream, (long long)n, s1, s4);
+  HIP_TRY(hipGetLastError());
+  return QEMB_OK;
+}
+__global__ void __launch_bounds__(256) unpack_s8_kernel(long long np, const double* s8, double* s4) {
+  for (long long r = blockIdx.x; r < np; r += gridDim.x)
+    for (long long c = threadIdx.x; c < np; c += blockDim.x) s4[r * np + c] = s8[pair_idx(r, c)];
+}
+int dev_unpack_s8_to_s4(int64_t n, const double* s8, double* s4) {
+  REQUIRE_INIT();
+  const int64_t np = n * (n + 1) / 2;
+  hipLaunchKernelGGL(unpack_s8_kernel, dim3((unsigned)std::min<int64_t>(np, 1 << 20)), dim3(256), 0, g_stream, (long long)np, s8, s4);
+  HIP_TRY(hipGetLastError());
+  return QEMB_OK;
+}
+__global__ void __launch_bounds__(256) unpack_tril_rows_kernel(long long rows, long long n, const double* packed, double* full) {
+  const long long np = n * (n + 1) / 2, n2 = n * n;
+  for (long long r = blockIdx.x; r < rows; r += gridDim.x)
+    for (long long kl = threadIdx.x; kl < n2; kl += blockDim.x) {
+      const long long k = kl / n, l = kl - k * n;
+      full[r * n2 + kl] = packed[r * np + pair_idx(k, l)];
+    }
+}
+int dev_unpack_tril_rows(int64_t rows, int64_t n, const double* packed, double* full) {
+  REQUIRE_INIT();
+  if (rows <= 0) return QEMB_OK;
+  hipLaunchKernelGGL(unpack_tril_rows_kernel, dim3((unsigned)std::min<int64_t>(rows, 1 << 20)), dim3(256), 0, g_stream, (long long)rows, (long long)n, packed, full);
+  HIP_TRY(hipGetLastError());
+  return QEMB_OK;
+}
+__global__ void __launch_bounds__(256) pack_tril_rows_kernel(long long rows, long long n, const double* full, double* packed) {
+  const long long np = n * (n + 1) / 2, n2 = n * n;
+  for (long long r = blockIdx.x; r < rows; r += gridDim.x)
+    for (long long kl = threadIdx.x; kl < n2; kl += blockDim.x) {
+      const long long k = kl / n, l = kl - k * n;
+      if (k >= l) packed[r * np + k * (k + 1) / 2 + l] = full[r * n2 + kl];
+    }
+}
+int dev_pack_tril_rows(int64_t rows, int64_t n, const double* full, double* packed) {
+  REQUIRE_INIT();
+  if (rows <= 0) return QEMB_OK;
+  hipLaunchKernelGGL(pack_tril_rows_kernel, dim3((unsigned)std::min<int64_t>(rows, 1 << 20)), dim3(256), 0, g_stream, (long long)rows, (long long)n, full, packed);
+  HIP_TRY(hipGetLastError());
+  return QEMB_OK;
+}
+
+}  // namespace qemb

@@ -1,0 +1,298 @@
+// gemm_f64.hip -- hand-written FP64 GEMM for gfx950 (MI355X, CDNA4) on v_mfma_f64_16x16x4_f64.
+//
+// This one kernel family carries every O(N^5)/O(N^6) contraction of the hot path: the CCSD
+// pp-ladder  t2new[ij,ab] += tau[ij,cd] * W[ab,cd]  (reference: molbe/solver.py:907 ->
+// PySCF ccsd.update_amps/_add_vvvv), the ph rings, the embedding->MO quarter transforms
+// (solver.py:900), the AO->embedding transforms (mbe.py:1038, eri_onthefly.py:133-143) and the
+// DF fit/contract (eri_sparse_DF.cpp:611-621).
+//
+// Design (MI355X-first, see DESIGN.md "GEMM"):
+//  * wave64; each wave owns a (16*WM) x (16*WN) output sub-tile = WM*WN MFMA accumulators of 4 f64.
+//    f64 MFMA on gfx950 issues once per 64 cycles per SIMD (78.6 TF chip peak == the FP64 vector peak),
+//    so the operand traffic per MFMA is tiny; what matters is never starving the matrix pipe:
+//    register-prefetched global loads for tile t+1 are issued before the MFMAs of tile t (T14 split),
+//    LDS is double buffered, one barrier per K-tile.
+//  * LDS images are chosen per operand storage order so that BOTH the 16-byte staging writes and the
+//    ds_read_b64 fragment reads are bank-conflict free:
+//      K-contiguous operand  -> image [row][BK+2]   (row stride 2*(BK+2) dwords: 36 for BK=16;
+//                               rows*36 mod 64 are 16 distinct multiples of 4, +{0,2} for the 2 k's
+//                               of a 32-lane group)
+//      M/N-contiguous operand-> image [k][BMN+pad], (BMN+pad) == 16 (mod 32) so that the two k rows
+//                               read by a 32-lane group sit in opposite halves of the 64 banks.
+//  * f64 MFMA lane maps (guide cdna_hip_programming.md §3):  A: lane l holds A[row=l&15][k=l>>4];
+//    B: lane l holds B[k=l>>4][col=l&15];  D: reg r of lane l is D[row=(l>>4)+4r][col=l&15].
+//  * blockIdx -> tile map is XCD aware: the 8 XCDs (private L2 each) get contiguous chunks of the
+//    logical tile order, m-tiles fastest, so the m-tiles that share one streamed B panel (W_vvvv for
+//    the ladder: 12.8 GB) run on one XCD at the same time and the panel is fetched from HBM once.
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include "dev_ops.h"
+#include "hip_common.h"
+
+namespace qemb {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+struct GemmKArgs {
+  const double* A; const double* B; double* C;
+  long long lda, ldb, ldc, strideA, strideB, strideC;
+  int M, N, K;
+  int tiles_m, tiles_n;
+  double alpha, beta;
+};
+
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  // bijective XCD-contiguous remap (guide §5 "XCD swizzle must be bijective")
+  const int q = nwg >> 3, r = nwg & 7;
+  const int xcd = bid & 7, k = bid >> 3;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + k;
+}
+
+template <int BMN, int BK, bool KCONTIG>
+struct LdsImage {
+  static constexpr int PADK = 2;
+  static constexpr int PADMN = (16 - (BMN % 32) + 32) % 32;
+  static constexpr int LDK = BK + PADK;      // row stride (doubles) of the K-contiguous image
+  static constexpr int LDMN = BMN + PADMN;   // row stride (doubles) of the M/N-contiguous image
+  static constexpr int SIZE = KCONTIG ? BMN * LDK : BK * LDMN;
+  __device__ static __forceinline__ int off(int mn, int k) {
+    return KCONTIG ? mn * LDK + k : k * LDMN + mn;
+  }
+};
+
+// Stage one operand tile global -> registers (zero filled outside the matrix).
+template <int BMN, int BK, bool KCONTIG, int VEC, int T, int NCH>
+__device__ __forceinline__ void stage_load(double (&reg)[NCH][VEC], const double* __restrict__ P,
+                                           long long ld, int mn0, int k0, int MN, int K, int tid) {
+  constexpr int CPR = (KCONTIG ? BK : BMN) / VEC;  // chunks per contiguous row of the tile
+  constexpr int TOTAL = BMN * BK / VEC;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int chunk = tid + c * T;
+    if ((TOTAL % T != 0) && chunk >= TOTAL) { reg[c][0] = 0.0; reg[c][VEC - 1] = 0.0; continue; }
+    const int r = chunk / CPR;             // K-contig: tile row (m/n) ; else: tile k
+    const int cc = (chunk % CPR) * VEC;    // offset along the contiguous dim
+    const int mn = KCONTIG ? r : cc;
+    const int k = KCONTIG ? cc : r;
+    const int gmn = mn0 + mn, gk = k0 + k;
+    const long long g = KCONTIG ? (long long)gmn * ld + gk : (long long)gk * ld + gmn;
+    if constexpr (VEC == 2) {
+      // dispatch guarantees even extents/ld/alignment, so a chunk is entirely in or out
+      const bool ok = (gmn < MN) && (gk < K);
+      d2 v = {0.0, 0.0};
+      if (ok) v = *reinterpret_cast<const d2*>(P + g);
+      reg[c][0] = v[0];
+      reg[c][VEC - 1] = v[1];
+    } else {
+      const bool ok = (gmn < MN) && (gk < K);
+      reg[c][0] = ok ? P[g] : 0.0;
+    }
+  }
+}
+
+template <int BMN, int BK, bool KCONTIG, int VEC, int T, int NCH>
+__device__ __forceinline__ void stage_store(const double (&reg)[NCH][VEC], double* __restrict__ S,
+                                            int tid) {
+  using Img = LdsImage<BMN, BK, KCONTIG>;
+  constexpr int CPR = (KCONTIG ? BK : BMN) / VEC;
+  constexpr int TOTAL = BMN * BK / VEC;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int chunk = tid + c * T;
+    if ((TOTAL % T != 0) && chunk >= TOTAL) continue;
+    const int r = chunk / CPR;
+    const int cc = (chunk % CPR) * VEC;
+    const int mn = KCONTIG ? r : cc;
+    const int k = KCONTIG ? cc : r;
+    double* dst = S + Img::off(mn, k);
+    if constexpr (VEC == 2) {
+      d2 v = {reg[c][0], reg[c][VEC - 1]};
+      *reinterpret_cast<d2*>(dst) = v;
+    } else {
+      dst[0] = reg[c][0];
+    }
+  }
+}
+
+template <int WM, int WN, int WAVES_M, int WAVES_N, int BK, bool A_KC, bool B_KC, int VEC>
+__global__ void __launch_bounds__(WAVES_M* WAVES_N * 64, (WM * WN <= 16) ? 2 : 1)
+    dgemm_mfma_kernel(GemmKArgs g) {
+  constexpr int BM = WM * 16 * WAVES_M;
+  constexpr int BN = WN * 16 * WAVES_N;
+  constexpr int T = WAVES_M * WAVES_N * 64;
+  using ImgA = LdsImage<BM, BK, A_KC>;
+  using ImgB = LdsImage<BN, BK, B_KC>;
+  constexpr int NCH_A = (BM * BK / VEC + T - 1) / T;
+  constexpr int NCH_B = (BN * BK / VEC + T - 1) / T;
+  static_assert(BK % 4 == 0, "BK must be a multiple of the MFMA K (4)");
+
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* sA0 = smem;
+  double* sB0 = sA0 + ImgA::SIZE;
+  double* sA1 = sB0 + ImgB::SIZE;
+  double* sB1 = sA1 + ImgA::SIZE;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+  const int ntiles = g.tiles_m * g.tiles_n;
+  const int L = xcd_remap(blockIdx.x, ntiles);
+  const int tm = L % g.tiles_m, tn = L / g.tiles_m;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const long long bz = blockIdx.y;
+  const double* __restrict__ A = g.A + bz * g.strideA;
+  const double* __restrict__ B = g.B + bz * g.strideB;
+  double* __restrict__ C = g.C + bz * g.strideC;
+
+  d4 acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
+
+  double ra[NCH_A][VEC], rb[NCH_B][VEC];
+  const int nk = (g.K + BK - 1) / BK;
+
+  // prologue: tile 0 -> LDS buffer 0
+  stage_load<BM, BK, A_KC, VEC, T, NCH_A>(ra, A, g.lda, m0, 0, g.M, g.K, tid);
+  stage_load<BN, BK, B_KC, VEC, T, NCH_B>(rb, B, g.ldb, n0, 0, g.N, g.K, tid);
+  stage_store<BM, BK, A_KC, VEC, T, NCH_A>(ra, sA0, tid);
+  stage_store<BN, BK, B_KC, VEC, T, NCH_B>(rb, sB0, tid);
+  __syncthreads();
+
+  const int fr = lane & 15, fk = lane >> 4;
+  for (int kt = 0; kt < nk; ++kt) {
+    const double* sA = (kt & 1) ? sA1 : sA0;
+    const double* sB = (kt & 1) ? sB1 : sB0;
+    double* nA = (kt & 1) ? sA0 : sA1;
+    double* nB = (kt & 1) ? sB0 : sB1;
+    const bool more = (kt + 1 < nk);
+    if (more) {  // issue next tile's global loads before this tile's MFMAs (latency hides under them)
+      stage_load<BM, BK, A_KC, VEC, T, NCH_A>(ra, A, g.lda, m0, (kt + 1) * BK, g.M, g.K, tid);
+      stage_load<BN, BK, B_KC, VEC, T, NCH_B>(rb, B, g.ldb, n0, (kt + 1) * BK, g.N, g.K, tid);
+    }
+#pragma unroll
+    for (int ks = 0; ks < BK / 4; ++ks) {
+      const int kk = ks * 4 + fk;
+      double a[WM], b[WN];
+#pragma unroll
+      for (int i = 0; i < WM; ++i) a[i] = sA[ImgA::off((wm * WM + i) * 16 + fr, kk)];
+#pragma unroll
+      for (int j = 0; j < WN; ++j) b[j] = sB[ImgB::off((wn * WN + j) * 16 + fr, kk)];
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) {
+      stage_store<BM, BK, A_KC, VEC, T, NCH_A>(ra, nA, tid);
+      stage_store<BN, BK, B_KC, VEC, T, NCH_B>(rb, nB, tid);
+    }
+    __syncthreads();
+  }
+
+  // epilogue: D reg r of lane l -> row (l>>4)+4r, col l&15 of the 16x16 tile
+  const double alpha = g.alpha, beta = g.beta;
+#pragma unroll
+  for (int i = 0; i < WM; ++i) {
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      const int col = n0 + (wn * WN + j) * 16 + fr;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + (wm * WM + i) * 16 + fk + 4 * r;
+        if (row < g.M && col < g.N) {
+          double* p = C + (long long)row * g.ldc + col;
+          double v = alpha * acc[i][j][r];
+          if (beta != 0.0) v += beta * (*p);
+          *p = v;
+        }
+      }
+    }
+  }
+}
+
+template <int WM, int WN, int WAVES_M, int WAVES_N, int BK, bool A_KC, bool B_KC, int VEC>
+static int launch_cfg(const GemmDesc& d, hipStream_t s) {
+  constexpr int BM = WM * 16 * WAVES_M, BN = WN * 16 * WAVES_N;
+  using ImgA = LdsImage<BM, BK, A_KC>;
+  using ImgB = LdsImage<BN, BK, B_KC>;
+  GemmKArgs g;
+  g.A = d.A; g.B = d.B; g.C = d.C;
+  g.lda = d.lda; g.ldb = d.ldb; g.ldc = d.ldc;
+  g.strideA = d.strideA; g.strideB = d.strideB; g.strideC = d.strideC;
+  g.M = (int)d.M; g.N = (int)d.N; g.K = (int)d.K;
+  g.tiles_m = (int)((d.M + BM - 1) / BM);
+  g.tiles_n = (int)((d.N + BN - 1) / BN);
+  g.alpha = d.alpha; g.beta = d.beta;
+  const size_t lds = 2 * (size_t)(ImgA::SIZE + ImgB::SIZE) * sizeof(double);
+  auto kern = dgemm_mfma_kernel<WM, WN, WAVES_M, WAVES_N, BK, A_KC, B_KC, VEC>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  dim3 grid((unsigned)(g.tiles_m * g.tiles_n), (unsigned)d.batch, 1);
+  dim3 block(WAVES_M * WAVES_N * 64, 1, 1);
+  hipLaunchKernelGGL(kern, grid, block, lds, s, g);
+  HIP_TRY(hipGetLastError());
+  return QEMB_OK;
+}
+
+template <int WM, int WN, int WAVES_M, int WAVES_N, int BK>
+static int launch_layout(const GemmDesc& d, hipStream_t s, bool vec2) {
+  const bool a = d.a_kcontig != 0, b = d.b_kcontig != 0;
+#define QEMB_GEMM_CASE(AK, BKC)                                                                \
+  if (a == AK && b == BKC)                                                                      \
+    return vec2 ? launch_cfg<WM, WN, WAVES_M, WAVES_N, BK, AK, BKC, 2>(d, s)                     \
+                : launch_cfg<WM, WN, WAVES_M, WAVES_N, BK, AK, BKC, 1>(d, s);
+  QEMB_GEMM_CASE(true, true)
+  QEMB_GEMM_CASE(true, false)
+  QEMB_GEMM_CASE(false, true)
+  QEMB_GEMM_CASE(false, false)
+#undef QEMB_GEMM_CASE
+  return QEMB_ERR_ARG;
+}
+
+static bool operand_vec2_ok(const double* p, int64_t ld, int64_t stride, int64_t contig_extent) {
+  return ((reinterpret_cast<uintptr_t>(p) & 15) == 0) && (ld % 2 == 0) && (stride % 2 == 0) &&
+         (contig_extent % 2 == 0);
+}
+
+int g_gemm_force_cfg = -1;  // test / tuning hook (qemb_set_gemm_config)
+
+int dev_gemm(const GemmDesc& d) {
+  if (d.M <= 0 || d.N <= 0 || d.batch <= 0) return QEMB_OK;
+  if (d.K < 0 || !d.A || !d.B || !d.C) { set_error("dev_gemm: bad arguments"); return QEMB_ERR_ARG; }
+  if (d.M > 0x3fffffff || d.N > 0x3fffffff || d.K > 0x3fffffff) {
+    set_error("dev_gemm: dimension too large"); return QEMB_ERR_ARG;
+  }
+  hipStream_t s = hip_stream();
+  const bool vec2 = operand_vec2_ok(d.A, d.lda, d.strideA, d.a_kcontig ? d.K : d.M) &&
+                    operand_vec2_ok(d.B, d.ldb, d.strideB, d.b_kcontig ? d.K : d.N);
+  // tile choice: biggest tile that still gives the 256 CUs >= ~2 workgroups each; small problems
+  // fall to 64x64 / 32x32 tiles so the grid is not a handful of blocks.
+  const int64_t t128 = ((d.M + 127) / 128) * ((d.N + 127) / 128) * d.batch;
+  const int64_t t64 = ((d.M + 63) / 64) * ((d.N + 63) / 64) * d.batch;
+  int cfg;
+  if (t128 >= 384) cfg = 0;
+  else if (t64 >= 256) cfg = 1;
+  else cfg = 2;
+  if (g_gemm_force_cfg >= 0) cfg = g_gemm_force_cfg;
+  switch (cfg) {
+    case 0: return launch_layout<4, 4, 2, 2, 16>(d, s, vec2);   // 128 x 128, 4 waves
+    case 1: return launch_layout<2, 2, 2, 2, 16>(d, s, vec2);   //  64 x  64, 4 waves
+    case 2: return launch_layout<1, 1, 2, 2, 32>(d, s, vec2);   //  32 x  32, 4 waves
+    case 3: return launch_layout<5, 4, 1, 4, 16>(d, s, vec2);   //  80 x 256, 4 waves (M = 400 = 5*80)
+    case 4: return launch_layout<4, 4, 2, 4, 16>(d, s, vec2);   // 128 x 256, 8 waves
+    default: set_error("dev_gemm: unknown tile config"); return QEMB_ERR_ARG;
+  }
+}
+
+}  // namespace qemb

@@ -1,0 +1,411 @@
+// linalg_f64.hip -- wavefront Jacobi eigen / SVD and small dense factorizations for gfx950.
+//
+// Schmidt decomposition (reference: molbe/pfrag.py:403-494 `eigh(Denv)`; kbe/solver.py:9-46 `svd`) and the
+// Fock diagonalisations of the fragment RHF (molbe/helper.py:73-151) are eigenproblems with no GEMM shape:
+// they run as one-sided (Hestenes) Jacobi sweeps.  A "round" applies n/2 independent plane rotations
+// (round-robin tournament ordering), one workgroup per vector pair; within a workgroup every wave streams
+// its slice of the two vectors (coalesced), the three Gram entries are reduced across the wave64s, and the
+// rotated vectors are written back.  No MFMA -- the work is dot products and axpys out of L2.
+//
+// Symmetric eigenproblems are solved as the SVD of the shifted matrix A + sigma*I (sigma from Gershgorin,
+// so the shifted matrix is positive definite and singular vectors == eigenvectors even when A has +/- pairs).
+//
+// Also here: blocked Cholesky and triangular inverse for the DF metric (reference: eri_onthefly.py:108,141;
+// _cpp/eri_sparse_DF.cpp:611-621), built from a 32x32 LDS diagonal-block kernel plus the MFMA GEMM.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <numeric>
+#include <vector>
+#include "dev_ops.h"
+#include "hip_common.h"
+
+namespace qemb {
+
+// ------------------------------------------------------------------------------------------------
+// Jacobi core: orthogonalise the rows of W (nvec x len, ld = ldw), accumulate rotations in Vt (nvec x nvec)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wsum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// round-robin pairing (circle method): np players (even), round r in [0, np-1), slot k in [0, np/2)
+__device__ __forceinline__ void rr_pair(int np, int r, int k, int& p, int& q) {
+  const int m = np - 1;
+  if (k == 0) { p = m; q = r; }
+  else { p = (r + k) % m; q = (r - k + m) % m; }
+  if (p > q) { const int t = p; p = q; q = t; }
+}
+
+__global__ void __launch_bounds__(256) jacobi_round_kernel(double* W, long long ldw, long long len, double* Vt, int nvec, int np,
+                                                           int round, double tol, double floor2, unsigned long long* offmax_bits) {
+  __shared__ double sh[3][4];
+  __shared__ double cs[2];
+  int p, q;
+  rr_pair(np, round, blockIdx.x, p, q);
+  if (q >= nvec) return;  // phantom player of an odd tournament
+  double* wp = W + (long long)p * ldw;
+  double* wq = W + (long long)q * ldw;
+  double a = 0.0, b = 0.0, g = 0.0;
+  for (long long i = threadIdx.x; i < len; i += blockDim.x) {
+    const double x = wp[i], y = wq[i];
+    a += x * x; b += y * y; g += x * y;
+  }
+  a = wsum(a); b = wsum(b); g = wsum(g);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) { sh[0][w] = a; sh[1][w] = b; sh[2][w] = g; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double A = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
+    const double B = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
+    const double G = sh[2][0] + sh[2][1] + sh[2][2] + sh[2][3];
+    double c = 1.0, s = 0.0;
+    if (A > floor2 && B > floor2) {
+      const double rel = fabs(G) / sqrt(A * B);
+      if (rel > tol) {
+        const double zeta = (B - A) / (2.0 * G);
+        const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+        c = 1.0 / sqrt(1.0 + t * t);
+        s = c * t;
+        atomicMax(offmax_bits, (unsigned long long)__double_as_longlong(rel));
+      }
+    }
+    cs[0] = c; cs[1] = s;
+  }
+  __syncthreads();
+  const double c = cs[0], s = cs[1];
+  if (s == 0.0) return;
+  for (long long i = threadIdx.x; i < len; i += blockDim.x) {
+    const double x = wp[i], y = wq[i];
+    wp[i] = c * x - s * y;
+    wq[i] = s * x + c * y;
+  }
+  if (Vt) {
+    double* vp = Vt + (long long)p * nvec;
+    double* vq = Vt + (long long)q * nvec;
+    for (int i = threadIdx.x; i < nvec; i += blockDim.x) {
+      const double x = vp[i], y = vq[i];
+      vp[i] = c * x - s * y;
+      vq[i] = s * x + c * y;
+    }
+  }
+}
+
+// out[i] = sum_k X[i*ldx+k] * Y[i*ldy+k]
+__global__ void __launch_bounds__(256) rowdot_kernel(int nrow, long long len, const double* X, long long ldx, const double* Y, long long ldy, double* out) {
+  __shared__ double sh[4];
+  const int i = blockIdx.x;
+  double acc = 0.0;
+  for (long long k = threadIdx.x; k < len; k += blockDim.x) acc += X[i * ldx + k] * Y[i * ldy + k];
+  acc = wsum(acc);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[i] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+// out[i] = sum_k |X[i*ld+k]|
+__global__ void __launch_bounds__(256) rowabssum_kernel(int nrow, long long len, const double* X, long long ld, double* out) {
+  __shared__ double sh[4];
+  const int i = blockIdx.x;
+  double acc = 0.0;
+  for (long long k = threadIdx.x; k < len; k += blockDim.x) acc += fabs(X[i * ld + k]);
+  acc = wsum(acc);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[i] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+__global__ void add_diag_kernel(int n, double* A, long long ld, double s) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) A[(long long)i * ld + i] += s;
+}
+__global__ void set_identity_kernel(int n, double* A) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < (long long)n * n) A[t] = ((t / n) == (t % n)) ? 1.0 : 0.0;
+}
+// out[c*ldo + i] = scale[i] * in[perm[i]*ldi + c]   (gather rows by perm, scale, write TRANSPOSED: vectors -> columns)
+__global__ void __launch_bounds__(256) gather_rows_to_cols_kernel(int nrow, long long len, const double* in, long long ldi, const int* perm,
+                                                                  const double* scale, double* out, long long ldo) {
+  const int i = blockIdx.y;
+  const double sc = scale ? scale[i] : 1.0;
+  const double* src = in + (long long)perm[i] * ldi;
+  for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < len; c += (long long)gridDim.x * blockDim.x)
+    out[c * ldo + i] = sc * src[c];
+}
+
+static int jacobi_rows(int nvec, int64_t len, double* W, int64_t ldw, double* Vt, double floor2, int* sweeps_out) {
+  hipStream_t s = hip_stream();
+  if (nvec < 2) { if (sweeps_out) *sweeps_out = 0; return QEMB_OK; }
+  const int np = (nvec % 2 == 0) ? nvec : nvec + 1;
+  unsigned long long* d_off = nullptr;
+  HIP_TRY(hipMalloc((void**)&d_off, sizeof(unsigned long long)));
+  const double tol = std::max(1.0e-15, std::sqrt((double)len) * 2.22e-16);   // LAPACK dgesvj-style
+  const int max_sweeps = 40;
+  int sweep = 0;
+  bool conv = false;
+  for (; sweep < max_sweeps; ++sweep) {
+    HIP_TRY(hipMemsetAsync(d_off, 0, sizeof(unsigned long long), s));
+    for (int r = 0; r < np - 1; ++r)
+      hipLaunchKernelGGL(jacobi_round_kernel, dim3(np / 2), dim3(256), 0, s, W, (long long)ldw, (long long)len, Vt, nvec, np, r, tol, floor2, d_off);
+    HIP_TRY(hipGetLastError());
+    unsigned long long bits = 0;
+    HIP_TRY(hipMemcpyAsync(&bits, d_off, sizeof(bits), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (bits == 0ULL) { conv = true; ++sweep; break; }   // a full sweep without a single rotation
+  }
+  (void)hipFree(d_off);
+  if (sweeps_out) *sweeps_out = sweep;
+  if (!conv) { set_error("Jacobi sweeps did not converge in 40 sweeps"); return QEMB_ERR_NOCONV; }
+  return QEMB_OK;
+}
+
+int dev_jacobi_eigh(int64_t n64, double* A, double* w, double* V, int* sweeps_out) {
+  hipStream_t s = hip_stream();
+  if (!s) { set_error("libqemb_hip: call qemb_init(device) first"); return QEMB_ERR_DEVICE; }
+  const int n = (int)n64;
+  if (n <= 0) return QEMB_OK;
+  double *Vt = nullptr, *tmp = nullptr; int* d_perm = nullptr;
+  HIP_TRY(hipMalloc((void**)&Vt, sizeof(double) * (size_t)n * n));
+  HIP_TRY(hipMalloc((void**)&tmp, sizeof(double) * (size_t)n));
+  HIP_TRY(hipMalloc((void**)&d_perm, sizeof(int) * (size_t)n));
+  // Gershgorin shift
+  hipLaunchKernelGGL(rowabssum_kernel, dim3(n), dim3(256), 0, s, n, (long long)n, A, (long long)n, tmp);
+  std::vector<double> h(n);
+  HIP_TRY(hipMemcpyAsync(h.data(), tmp, sizeof(double) * n, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  double gersh = 0.0;
+  for (double x : h) gersh = std::max(gersh, x);
+  const double sigma = 1.0625 * gersh + 1.0e-300;
+  hipLaunchKernelGGL(add_diag_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, A, (long long)n, sigma);
+  hipLaunchKernelGGL(set_identity_kernel, dim3((unsigned)(((long long)n * n + 255) / 256)), dim3(256), 0, s, n, Vt);
+  int rc = jacobi_rows(n, n, A, n, Vt, 0.0, sweeps_out);
+  if (rc == QEMB_OK) {
+    // Rayleigh quotients lambda_i + sigma = W_i . Vt_i
+    hipLaunchKernelGGL(rowdot_kernel, dim3(n), dim3(256), 0, s, n, (long long)n, A, (long long)n, Vt, (long long)n, tmp);
+    HIP_TRY(hipMemcpyAsync(h.data(), tmp, sizeof(double) * n, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    std::vector<int> perm(n);
+    std::iota(perm.begin(), perm.end(), 0);
+    std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return h[a] < h[b]; });
+    std::vector<double> ws(n);
+    for (int i = 0; i < n; ++i) ws[i] = h[perm[i]] - sigma;
+    HIP_TRY(hipMemcpyAsync(w, ws.data(), sizeof(double) * n, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_perm, perm.data(), sizeof(int) * n, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(gather_rows_to_cols_kernel, dim3((n + 255) / 256, n), dim3(256), 0, s, n, (long long)n, Vt, (long long)n, d_perm, (const double*)nullptr, V, (long long)n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s));
+  }
+  (void)hipFree(Vt); (void)hipFree(tmp); (void)hipFree(d_perm);
+  return rc;
+}
+
+int dev_jacobi_svd(int64_t m64, int64_t n64, double* G, double* sv, double* U, double* V, int* sweeps_out) {
+  hipStream_t s = hip_stream();
+  if (!s) { set_error("libqemb_hip: call qemb_init(device) first"); return QEMB_ERR_DEVICE; }
+  const int n = (int)n64; const long long m = m64;
+  if (n <= 0 || m <= 0) return QEMB_OK;
+  if (m < n) { set_error("dev_jacobi_svd: need m >= n"); return QEMB_ERR_ARG; }
+  double *Wt = nullptr, *Vt = nullptr, *tmp = nullptr; int* d_perm = nullptr;
+  HIP_TRY(hipMalloc((void**)&Wt, sizeof(double) * (size_t)n * m));
+  HIP_TRY(hipMalloc((void**)&Vt, sizeof(double) * (size_t)n * n));
+  HIP_TRY(hipMalloc((void**)&tmp, sizeof(double) * (size_t)n));
+  HIP_TRY(hipMalloc((void**)&d_perm, sizeof(int) * (size_t)n));
+  // Wt = G^T (n x m): columns of G become contiguous rows
+  Copy4Desc c{};
+  c.dim[0] = 1; c.dim[1] = 1; c.dim[2] = n; c.dim[3] = m;
+  c.in = G; c.si[0] = 0; c.si[1] = 0; c.si[2] = 1; c.si[3] = n;
+  c.out = Wt; c.so[0] = 0; c.so[1] = 0; c.so[2] = m; c.so[3] = 1;
+  c.alpha = 1.0; c.beta = 0.0;
+  int rc = dev_copy4(c);
+  if (rc == QEMB_OK) {
+    hipLaunchKernelGGL(set_identity_kernel, dim3((unsigned)(((long long)n * n + 255) / 256)), dim3(256), 0, s, n, Vt);
+    // scale for the "zero vector" floor: ||G||_F^2
+    hipLaunchKernelGGL(rowdot_kernel, dim3(n), dim3(256), 0, s, n, m, Wt, m, Wt, m, tmp);
+    std::vector<double> h(n);
+    HIP_TRY(hipMemcpyAsync(h.data(), tmp, sizeof(double) * n, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    double fro2 = 0.0;
+    for (double x : h) fro2 += x;
+    const double floor2 = fro2 * 1.0e-30;   // vectors below 1e-15 * ||G||_F are numerically zero
+    rc = jacobi_rows(n, m, Wt, m, Vt, floor2, sweeps_out);
+    if (rc == QEMB_OK) {
+      hipLaunchKernelGGL(rowdot_kernel, dim3(n), dim3(256), 0, s, n, m, Wt, m, Wt, m, tmp);
+      HIP_TRY(hipMemcpyAsync(h.data(), tmp, sizeof(double) * n, hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipStreamSynchronize(s));
+      std::vector<int> perm(n);
+      std::iota(perm.begin(), perm.end(), 0);
+      std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return h[a] > h[b]; });
+      std::vector<double> ss(n), inv(n);
+      for (int i = 0; i < n; ++i) {
+        ss[i] = std::sqrt(std::max(h[perm[i]], 0.0));
+        inv[i] = (h[perm[i]] > floor2) ? 1.0 / ss[i] : 0.0;
+      }
+      HIP_TRY(hipMemcpyAsync(sv, ss.data(), sizeof(double) * n, hipMemcpyHostToDevice, s));
+      HIP_TRY(hipMemcpyAsync(tmp, inv.data(), sizeof(double) * n, hipMemcpyHostToDevice, s));
+      HIP_TRY(hipMemcpyAsync(d_perm, perm.data(), sizeof(int) * n, hipMemcpyHostToDevice, s));
+      if (U) hipLaunchKernelGGL(gather_rows_to_cols_kernel, dim3((unsigned)std::min<long long>((m + 255) / 256, 65535), n), dim3(256), 0, s, n, m, Wt, m, d_perm, tmp, U, (long long)n);
+      if (V) hipLaunchKernelGGL(gather_rows_to_cols_kernel, dim3((n + 255) / 256, n), dim3(256), 0, s, n, (long long)n, Vt, (long long)n, d_perm, (const double*)nullptr, V, (long long)n);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipStreamSynchronize(s));
+    }
+  }
+  (void)hipFree(Wt); (void)hipFree(Vt); (void)hipFree(tmp); (void)hipFree(d_perm);
+  return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Cholesky / triangular inverse
+// ------------------------------------------------------------------------------------------------
+constexpr int NB = 32;
+
+// Factor the nb x nb diagonal block at A (ld) in place (lower), write its inverse to Dinv (NB x NB, ld NB).
+// Also used with factor=false to only invert an existing lower-triangular block.
+__global__ void __launch_bounds__(256) diag_block_kernel(double* A, long long ld, int nb, double* Dinv, int factor, int* fail) {
+  __shared__ double a[NB][NB + 1];
+  __shared__ double inv[NB][NB + 1];
+  __shared__ int bad;
+  const int tid = threadIdx.x;
+  if (tid == 0) bad = 0;
+  for (int t = tid; t < NB * NB; t += 256) {
+    const int i = t / NB, j = t % NB;
+    a[i][j] = (i < nb && j < nb && j <= i) ? A[(long long)i * ld + j] : ((i == j) ? 1.0 : 0.0);
+    inv[i][j] = 0.0;
+  }
+  __syncthreads();
+  if (factor) {
+    for (int k = 0; k < nb; ++k) {
+      if (tid == 0) {
+        const double d = a[k][k];
+        if (!(d > 0.0)) { bad = 1; a[k][k] = 1.0; } else a[k][k] = sqrt(d);
+      }
+      __syncthreads();
+      const double dk = a[k][k];
+      for (int i = k + 1 + tid; i < nb; i += 256) a[i][k] /= dk;
+      __syncthreads();
+      for (int t = tid; t < NB * NB; t += 256) {
+        const int i = t / NB, j = t % NB;
+        if (i > k && j > k && j <= i && i < nb) a[i][j] -= a[i][k] * a[j][k];
+      }
+      __syncthreads();
+    }
+    for (int t = tid; t < NB * NB; t += 256) {
+      const int i = t / NB, j = t % NB;
+      if (i < nb && j < nb) A[(long long)i * ld + j] = (j <= i) ? a[i][j] : 0.0;
+    }
+  }
+  __syncthreads();
+  if (tid < nb) {   // column tid of the inverse by forward substitution
+    const int j = tid;
+    inv[j][j] = 1.0 / a[j][j];
+    for (int i = j + 1; i < nb; ++i) {
+      double acc = 0.0;
+      for (int k = j; k < i; ++k) acc += a[i][k] * inv[k][j];
+      inv[i][j] = -acc / a[i][i];
+    }
+  }
+  __syncthreads();
+  for (int t = tid; t < NB * NB; t += 256) Dinv[t] = inv[t / NB][t % NB];
+  if (tid == 0 && bad && fail) *fail = 1;
+}
+__global__ void zero_upper_kernel(int n, double* A) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < (long long)n * n) { const long long i = t / n, j = t % n; if (j > i) A[t] = 0.0; }
+}
+
+int dev_cholesky_lower(int64_t n64, double* A) {
+  hipStream_t s = hip_stream();
+  if (!s) { set_error("libqemb_hip: call qemb_init(device) first"); return QEMB_ERR_DEVICE; }
+  const int n = (int)n64;
+  if (n <= 0) return QEMB_OK;
+  double *Dinv = nullptr, *panel = nullptr; int* d_fail = nullptr;
+  HIP_TRY(hipMalloc((void**)&Dinv, sizeof(double) * NB * NB));
+  HIP_TRY(hipMalloc((void**)&panel, sizeof(double) * (size_t)n * NB));
+  HIP_TRY(hipMalloc((void**)&d_fail, sizeof(int)));
+  HIP_TRY(hipMemsetAsync(d_fail, 0, sizeof(int), s));
+  int rc = QEMB_OK;
+  for (int k0 = 0; k0 < n && rc == QEMB_OK; k0 += NB) {
+    const int nb = std::min(NB, n - k0);
+    double* Akk = A + (long long)k0 * n + k0;
+    hipLaunchKernelGGL(diag_block_kernel, dim3(1), dim3(256), 0, s, Akk, (long long)n, nb, Dinv, 1, d_fail);
+    const int rest = n - k0 - nb;
+    if (rest > 0) {
+      double* A21 = A + (long long)(k0 + nb) * n + k0;
+      // panel = A21 * L11^{-T}:  B(k,j) = Dinv[j][k]  -> stored N x K  (b_kcontig)
+      GemmDesc g{};
+      g.M = rest; g.N = nb; g.K = nb; g.alpha = 1.0; g.beta = 0.0;
+      g.A = A21; g.lda = n; g.a_kcontig = 1; g.strideA = 0;
+      g.B = Dinv; g.ldb = NB; g.b_kcontig = 1; g.strideB = 0;
+      g.C = panel; g.ldc = NB; g.strideC = 0; g.batch = 1;
+      rc = dev_gemm(g);
+      if (rc) break;
+      Copy4Desc c{};
+      c.dim[0] = 1; c.dim[1] = 1; c.dim[2] = rest; c.dim[3] = nb;
+      c.in = panel; c.si[0] = 0; c.si[1] = 0; c.si[2] = NB; c.si[3] = 1;
+      c.out = A21; c.so[0] = 0; c.so[1] = 0; c.so[2] = n; c.so[3] = 1; c.alpha = 1.0; c.beta = 0.0;
+      rc = dev_copy4(c);
+      if (rc) break;
+      // A22 -= L21 L21^T
+      double* A22 = A + (long long)(k0 + nb) * n + (k0 + nb);
+      GemmDesc u{};
+      u.M = rest; u.N = rest; u.K = nb; u.alpha = -1.0; u.beta = 1.0;
+      u.A = panel; u.lda = NB; u.a_kcontig = 1; u.strideA = 0;
+      u.B = panel; u.ldb = NB; u.b_kcontig = 1; u.strideB = 0;
+      u.C = A22; u.ldc = n; u.strideC = 0; u.batch = 1;
+      rc = dev_gemm(u);
+    }
+  }
+  if (rc == QEMB_OK) {
+    hipLaunchKernelGGL(zero_upper_kernel, dim3((unsigned)(((long long)n * n + 255) / 256)), dim3(256), 0, s, n, A);
+    int fail = 0;
+    HIP_TRY(hipMemcpyAsync(&fail, d_fail, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (fail) { set_error("Cholesky: matrix is not positive definite"); rc = QEMB_ERR_NUMERIC; }
+  }
+  (void)hipFree(Dinv); (void)hipFree(panel); (void)hipFree(d_fail);
+  return rc;
+}
+
+int dev_tri_inverse_lower(int64_t n64, const double* L, double* X) {
+  hipStream_t s = hip_stream();
+  if (!s) { set_error("libqemb_hip: call qemb_init(device) first"); return QEMB_ERR_DEVICE; }
+  const int n = (int)n64;
+  if (n <= 0) return QEMB_OK;
+  double *Dinv = nullptr, *T = nullptr, *Lc = nullptr;
+  HIP_TRY(hipMalloc((void**)&Dinv, sizeof(double) * NB * NB));
+  HIP_TRY(hipMalloc((void**)&T, sizeof(double) * (size_t)NB * n));
+  HIP_TRY(hipMalloc((void**)&Lc, sizeof(double) * (size_t)n * n));   // diag_block_kernel takes non-const
+  HIP_TRY(hipMemcpyAsync(Lc, L, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToDevice, s));
+  int rc = dev_fill(X, (int64_t)n * n, 0.0);
+  for (int i0 = 0; i0 < n && rc == QEMB_OK; i0 += NB) {
+    const int nb = std::min(NB, n - i0);
+    hipLaunchKernelGGL(diag_block_kernel, dim3(1), dim3(256), 0, s, Lc + (long long)i0 * n + i0, (long long)n, nb, Dinv, 0, (int*)nullptr);
+    // X[i,i] = Dinv
+    Copy4Desc c{};
+    c.dim[0] = 1; c.dim[1] = 1; c.dim[2] = nb; c.dim[3] = nb;
+    c.in = Dinv; c.si[0] = 0; c.si[1] = 0; c.si[2] = NB; c.si[3] = 1;
+    c.out = X + (long long)i0 * n + i0; c.so[0] = 0; c.so[1] = 0; c.so[2] = n; c.so[3] = 1; c.alpha = 1.0; c.beta = 0.0;
+    rc = dev_copy4(c);
+    if (rc || i0 == 0) continue;
+    // T (nb x i0) = L[i, 0:i0] * X[0:i0, 0:i0]
+    GemmDesc g{};
+    g.M = nb; g.N = i0; g.K = i0; g.alpha = 1.0; g.beta = 0.0;
+    g.A = Lc + (long long)i0 * n; g.lda = n; g.a_kcontig = 1; g.strideA = 0;
+    g.B = X; g.ldb = n; g.b_kcontig = 0; g.strideB = 0;
+    g.C = T; g.ldc = n; g.strideC = 0; g.batch = 1;
+    rc = dev_gemm(g);
+    if (rc) break;
+    // X[i, 0:i0] = -Dinv * T
+    GemmDesc h{};
+    h.M = nb; h.N = i0; h.K = nb; h.alpha = -1.0; h.beta = 0.0;
+    h.A = Dinv; h.lda = NB; h.a_kcontig = 1; h.strideA = 0;
+    h.B = T; h.ldb = n; h.b_kcontig = 0; h.strideB = 0;
+    h.C = X + (long long)i0 * n; h.ldc = n; h.strideC = 0; h.batch = 1;
+    rc = dev_gemm(h);
+  }
+  HIP_TRY(hipStreamSynchronize(s));
+  (void)hipFree(Dinv); (void)hipFree(T); (void)hipFree(Lc);
+  return rc;
+}
+
+}  // namespace qemb

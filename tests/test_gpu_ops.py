@@ -1,0 +1,248 @@
+"""-m gpu: every device primitive of libqemb_hip (through the C ABI) against numpy on seeded inputs."""
+
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from quemb_amd import _lib
+from quemb_amd._lib import DeviceBuffer, check, i64x4
+
+pytestmark = pytest.mark.gpu
+
+
+def _gemm(lib, A, B, Cm, alpha, beta, a_kc, b_kc, batch=1, cfg=-1):
+    """A: (batch, M, K) logical; B: (batch, K, N) logical.  Storage chosen by a_kc / b_kc."""
+    bsz, M, K = A.shape
+    N = B.shape[2]
+    As = A if a_kc else A.transpose(0, 2, 1)
+    Bs = B.transpose(0, 2, 1) if b_kc else B
+    As = np.ascontiguousarray(As)
+    Bs = np.ascontiguousarray(Bs)
+    dA, dB, dC = DeviceBuffer.from_numpy(As), DeviceBuffer.from_numpy(Bs), DeviceBuffer.from_numpy(Cm)
+    lda = K if a_kc else M
+    ldb = K if b_kc else N
+    lib.qemb_set_gemm_config(cfg)
+    check(lib.qemb_op_gemm(M, N, K, alpha, dA.ptr, lda, int(a_kc), M * K, dB.ptr, ldb, int(b_kc), K * N, beta,
+                           dC.ptr, N, M * N, bsz), "gemm")
+    lib.qemb_set_gemm_config(-1)
+    return dC.numpy(Cm.shape)
+
+
+@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 3, 4])
+@pytest.mark.parametrize("a_kc,b_kc", [(1, 1), (1, 0), (0, 1), (0, 0)])
+@pytest.mark.parametrize("shape", [(128, 128, 64), (400, 300, 200), (37, 53, 29), (441, 441, 441), (1, 220, 96), (130, 258, 18)])
+def test_gemm_matches_numpy(qlib, cfg, a_kc, b_kc, shape):
+    M, N, K = shape
+    rng = np.random.default_rng(1234 + M + 7 * N + 13 * K)
+    A = rng.standard_normal((2, M, K))
+    B = rng.standard_normal((2, K, N))
+    C0 = rng.standard_normal((2, M, N))
+    alpha, beta = 0.75, -0.5
+    got = _gemm(qlib, A, B, C0, alpha, beta, a_kc, b_kc, cfg=cfg)
+    ref = alpha * np.einsum("bmk,bkn->bmn", A, B) + beta * C0
+    err = np.abs(got - ref).max()
+    assert err < 1e-11 * max(1.0, K), (shape, cfg, a_kc, b_kc, err)
+
+
+def test_gemm_identity_asymmetric(qlib):
+    """A = I with an asymmetric B catches swapped C-layout maps (guide section 3)."""
+    n = 64
+    A = np.eye(n)[None]
+    B = (np.arange(n * n, dtype=np.float64).reshape(n, n) * 1.0)[None]
+    got = _gemm(qlib, A, B, np.zeros((1, n, n)), 1.0, 0.0, 1, 0)
+    assert np.array_equal(got[0], B[0])
+
+
+def test_gemm_beta_zero_ignores_nan(qlib):
+    rng = np.random.default_rng(5)
+    A = rng.standard_normal((1, 70, 40)); B = rng.standard_normal((1, 40, 90))
+    C0 = np.full((1, 70, 90), np.nan)
+    got = _gemm(qlib, A, B, C0, 1.0, 0.0, 1, 1)
+    assert np.allclose(got, A @ B, atol=1e-12)
+
+
+@pytest.mark.parametrize("perm", [(0, 1, 2, 3), (0, 2, 1, 3), (1, 0, 3, 2), (3, 2, 1, 0), (2, 3, 0, 1), (0, 1, 3, 2), (1, 3, 0, 2)])
+def test_copy4_permutations(qlib, perm):
+    rng = np.random.default_rng(7)
+    dims = (6, 9, 33, 41)
+    x = rng.standard_normal(dims)
+    out0 = rng.standard_normal(tuple(dims[p] for p in perm))
+    alpha, beta = 1.5, 0.25
+    ref = alpha * x.transpose(perm) + beta * out0
+    # loop over the INPUT dims; output strides follow the permuted layout
+    out_shape = ref.shape
+    ostr = np.zeros(4, dtype=np.int64)
+    st = np.array([int(np.prod(out_shape[k + 1:])) for k in range(4)])
+    for k, p in enumerate(perm):
+        ostr[p] = st[k]
+    istr = [int(np.prod(dims[k + 1:])) for k in range(4)]
+    dx, do = DeviceBuffer.from_numpy(x), DeviceBuffer.from_numpy(out0)
+    check(qlib.qemb_op_copy4(i64x4(dims), dx.ptr, i64x4(istr), do.ptr, i64x4(ostr), alpha, beta))
+    got = do.numpy(out_shape)
+    assert np.allclose(got, ref, atol=1e-14)
+
+
+def test_copy4_block_extract(qlib):
+    rng = np.random.default_rng(8)
+    n, o = 11, 4
+    v = n - o
+    M = rng.standard_normal((n, n, n, n))
+    dM = DeviceBuffer.from_numpy(M)
+    dO = DeviceBuffer(o * v * o * v)
+    s = [n ** 3, n ** 2, n, 1]
+    off = o * n * n + o  # [i, o+a, j, o+b]
+    check(qlib.qemb_op_copy4(i64x4((o, v, o, v)), dM.at(off), i64x4(s), dO.ptr, i64x4((v * o * v, o * v, v, 1)), 1.0, 0.0))
+    assert np.array_equal(dO.numpy((o, v, o, v)), M[:o, o:, :o, o:])
+
+
+def test_outer4_and_denominators(qlib):
+    rng = np.random.default_rng(9)
+    o, v = 5, 7
+    t1 = rng.standard_normal((o, v)); t2 = rng.standard_normal((o, o, v, v))
+    d1, d2 = DeviceBuffer.from_numpy(t1), DeviceBuffer.from_numpy(t2)
+    check(qlib.qemb_op_outer4(i64x4((o, o, v, v)), d1.ptr, v, 1, d1.ptr, v, 1, d2.ptr, i64x4((o * v * v, v * v, v, 1)), 1.0, 1.0))
+    tau = t2 + np.einsum("ia,jb->ijab", t1, t1)
+    assert np.allclose(d2.numpy(t2.shape), tau, atol=1e-14)
+    eo = np.sort(rng.standard_normal(o)) - 3; ev = np.sort(rng.standard_normal(v)) + 3
+    deo, dev = DeviceBuffer.from_numpy(eo), DeviceBuffer.from_numpy(ev)
+    check(qlib.qemb_op_div_denom(d2.ptr, o, o, v, v, deo.ptr, deo.ptr, dev.ptr, dev.ptr))
+    den = eo[:, None, None, None] + eo[None, :, None, None] - ev[None, None, :, None] - ev[None, None, None, :]
+    assert np.allclose(d2.numpy(t2.shape), tau / den, rtol=1e-14)
+    check(qlib.qemb_op_div_denom(d1.ptr, o, 1, v, 1, deo.ptr, None, dev.ptr, None))
+    assert np.allclose(d1.numpy(t1.shape), t1 / (eo[:, None] - ev[None, :]), rtol=1e-14)
+
+
+def test_reductions(qlib):
+    rng = np.random.default_rng(10)
+    for n in (1, 1000, 1 << 20, 3_000_001):
+        x = rng.standard_normal(n); y = rng.standard_normal(n)
+        dx, dy, do = DeviceBuffer.from_numpy(x), DeviceBuffer.from_numpy(y), DeviceBuffer(2)
+        check(qlib.qemb_op_dot(n, dx.ptr, dy.ptr, do.ptr))
+        check(qlib.qemb_op_absmax(n, dx.ptr, do.at(1)))
+        r = do.numpy()
+        assert abs(r[0] - x @ y) < 1e-9 * max(1.0, np.sqrt(n))
+        assert r[1] == np.abs(x).max()
+        check(qlib.qemb_op_dot(n, dx.ptr, dy.ptr, do.ptr))
+        assert do.numpy()[0] == r[0], "reduction must be run-to-run deterministic"
+
+
+def test_gemv_and_contract_mid(qlib):
+    rng = np.random.default_rng(11)
+    n = 23
+    E = rng.standard_normal((n, n, n, n)); D = rng.standard_normal((n, n))
+    dE, dD = DeviceBuffer.from_numpy(E), DeviceBuffer.from_numpy(D)
+    dJ, dK = DeviceBuffer(n * n), DeviceBuffer(n * n)
+    check(qlib.qemb_op_gemv_rows(n * n, n * n, dE.ptr, n * n, dD.ptr, dJ.ptr, 1.0, 0.0))
+    assert np.allclose(dJ.numpy((n, n)), np.einsum("pqrs,rs->pq", E, D), atol=1e-11)
+    check(qlib.qemb_op_contract_mid(n, n * n, n, dE.ptr, dD.ptr, dK.ptr, n, 1.0, 0.0))
+    assert np.allclose(dK.numpy((n, n)), np.einsum("pqsr,qs->pr", E, D), atol=1e-11)
+
+
+def _sym_eri(n, rng):
+    B = rng.standard_normal((2 * n, n, n)); B = B + B.transpose(0, 2, 1)
+    return np.einsum("Ppq,Prs->pqrs", B, B)
+
+
+def test_pack_unpack(qlib):
+    rng = np.random.default_rng(12)
+    n = 9
+    npair = n * (n + 1) // 2
+    eri = _sym_eri(n, rng)
+    il = np.tril_indices(n)
+    s4 = eri[il][:, il[0], il[1]]
+    d4, d1 = DeviceBuffer.from_numpy(s4), DeviceBuffer(n ** 4)
+    check(qlib.qemb_op_unpack_s4(n, d4.ptr, d1.ptr))
+    assert np.array_equal(d1.numpy((n,) * 4), eri)
+    d4b = DeviceBuffer(npair * npair)
+    check(qlib.qemb_op_pack_s4(n, d1.ptr, d4b.ptr))
+    assert np.array_equal(d4b.numpy((npair, npair)), s4)
+    s8 = s4[np.tril_indices(npair)]
+    d8 = DeviceBuffer.from_numpy(s8)
+    check(qlib.qemb_op_unpack_s8_to_s4(n, d8.ptr, d4b.ptr))
+    assert np.array_equal(d4b.numpy((npair, npair)), s4)
+    rows = 5
+    P = rng.standard_normal((rows, npair))
+    dP, dF = DeviceBuffer.from_numpy(P), DeviceBuffer(rows * n * n)
+    check(qlib.qemb_op_unpack_tril_rows(rows, n, dP.ptr, dF.ptr))
+    F = dF.numpy((rows, n, n))
+    assert np.array_equal(F[:, il[0], il[1]], P) and np.array_equal(F, F.transpose(0, 2, 1))
+    dP2 = DeviceBuffer(rows * npair)
+    check(qlib.qemb_op_pack_tril_rows(rows, n, dF.ptr, dP2.ptr))
+    assert np.array_equal(dP2.numpy((rows, npair)), P)
+
+
+@pytest.mark.parametrize("n", [2, 7, 42, 131, 220])
+def test_jacobi_eigh(qlib, n):
+    rng = np.random.default_rng(13 + n)
+    A = rng.standard_normal((n, n)); A = A + A.T
+    if n >= 8:  # plant a +/- pair and a degenerate pair
+        Q = np.linalg.qr(rng.standard_normal((n, n)))[0]
+        w = rng.standard_normal(n); w[0], w[1] = 1.5, -1.5; w[2] = w[3] = 0.25
+        A = (Q * w) @ Q.T
+    dA, dw, dV = DeviceBuffer.from_numpy(A), DeviceBuffer(n), DeviceBuffer(n * n)
+    sw = C.c_int(0)
+    check(qlib.qemb_op_jacobi_eigh(n, dA.ptr, dw.ptr, dV.ptr, C.byref(sw)))
+    w, V = dw.numpy(), dV.numpy((n, n))
+    wr = np.linalg.eigvalsh(A)
+    scale = np.abs(wr).max()
+    assert np.abs(w - wr).max() < 1e-12 * scale
+    assert np.abs(V.T @ V - np.eye(n)).max() < 1e-12
+    assert np.abs(A @ V - V * w).max() < 1e-11 * scale
+
+
+def test_jacobi_eigh_projector_spectrum(qlib):
+    """The Schmidt case: environment block of an idempotent 1-RDM (eigenvalues 0, 1 and a few in between)."""
+    rng = np.random.default_rng(14)
+    N, nocc, nf = 60, 20, 6
+    Cm = np.linalg.qr(rng.standard_normal((N, N)))[0][:, :nocc]
+    D = Cm @ Cm.T
+    Denv = D[nf:, nf:]
+    n = N - nf
+    dA, dw, dV = DeviceBuffer.from_numpy(Denv), DeviceBuffer(n), DeviceBuffer(n * n)
+    check(qlib.qemb_op_jacobi_eigh(n, dA.ptr, dw.ptr, dV.ptr, None))
+    w, V = dw.numpy(), dV.numpy((n, n))
+    wr, Vr = np.linalg.eigh(Denv)
+    assert np.abs(w - wr).max() < 1e-13
+    sel = (np.abs(w) > 1e-10) & (np.abs(w) < 1 - 1e-10)
+    selr = (np.abs(wr) > 1e-10) & (np.abs(wr) < 1 - 1e-10)
+    assert sel.sum() == selr.sum() == nf
+    Pg, Pr = V[:, sel] @ V[:, sel].T, Vr[:, selr] @ Vr[:, selr].T
+    assert np.abs(Pg - Pr).max() < 1e-11
+
+
+@pytest.mark.parametrize("m,n", [(50, 6), (300, 22), (40, 40)])
+def test_jacobi_svd(qlib, m, n):
+    rng = np.random.default_rng(15 + m)
+    G = rng.standard_normal((m, n))
+    if n >= 6:
+        G[:, 1] = G[:, 0]  # rank deficient: one exact zero singular value
+    dG, ds, dU, dV = DeviceBuffer.from_numpy(G), DeviceBuffer(n), DeviceBuffer(m * n), DeviceBuffer(n * n)
+    check(qlib.qemb_op_jacobi_svd(m, n, dG.ptr, ds.ptr, dU.ptr, dV.ptr, None))
+    s, U, V = ds.numpy(), dU.numpy((m, n)), dV.numpy((n, n))
+    sr = np.linalg.svd(G, compute_uv=False)
+    assert np.abs(s - sr).max() < 1e-12 * sr.max()
+    assert np.abs((U * s) @ V.T - G).max() < 1e-12 * sr.max()
+    r = int((sr > 1e-10 * sr.max()).sum())
+    assert np.abs(U[:, :r].T @ U[:, :r] - np.eye(r)).max() < 1e-12
+
+
+@pytest.mark.parametrize("n", [5, 32, 77, 300])
+def test_cholesky_and_tri_inverse(qlib, n):
+    rng = np.random.default_rng(16 + n)
+    X = rng.standard_normal((n, n)); A = X @ X.T + n * np.eye(n)
+    dA, dI = DeviceBuffer.from_numpy(A), DeviceBuffer(n * n)
+    check(qlib.qemb_op_cholesky_lower(n, dA.ptr))
+    L = dA.numpy((n, n))
+    Lr = np.linalg.cholesky(A)
+    assert np.abs(L - Lr).max() < 1e-11 * np.abs(Lr).max()
+    check(qlib.qemb_op_tri_inverse_lower(n, dA.ptr, dI.ptr))
+    Li = dI.numpy((n, n))
+    assert np.abs(Li @ L - np.eye(n)).max() < 1e-11
+    assert np.abs(np.triu(Li, 1)).max() == 0.0
+
+
+def test_cholesky_rejects_indefinite(qlib):
+    A = np.eye(8); A[3, 3] = -1.0
+    dA = DeviceBuffer.from_numpy(A)
+    assert qlib.qemb_op_cholesky_lower(8, dA.ptr) == -5
