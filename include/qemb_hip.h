@@ -87,6 +87,57 @@ int qemb_op_jacobi_svd(int64_t m, int64_t n, double* G, double* s, double* U, do
 int qemb_op_cholesky_lower(int64_t n, double* A);
 int qemb_op_tri_inverse_lower(int64_t n, const double* L, double* Linv);
 
+/* ---------------------------------------------------------------- fragment solver (hot path) ----- */
+/* Replaces, per fragment, the body of be_func's loop -- molbe/solver.py:301-547 -- and its worker twin
+ * run_solver(h1, dm0, ..., nao, nocc, n_frag, weight_and_relAO_per_center, TA, h1_e, solver, eri_file,
+ * veff, veff0, ...) -> (e_f, mo_coeff, rdm1, rdm2s, rdm1_tmp), molbe/be_parallel.py:40-60, :301-307:
+ * fragment RHF (helper.py:73-151) -> solve_ccsd (solver.py:829-946) -> rdm1 back-rotation (solver.py:496-505)
+ * -> get_frag_energy (helper.py:220-339).  The 2-RDM is never materialised: its contraction with the
+ * fragment ERIs is evaluated from t1/t2 directly (identical result).                      */
+typedef struct {
+  double cc_conv_tol;        /* |dE_corr|          default 1e-10 (PySCF 1e-7)                      */
+  double cc_conv_tol_normt;  /* |dt|               default 1e-8  (PySCF 1e-5)                      */
+  int cc_max_cycle;          /*                    default 100   (PySCF 50)                        */
+  int cc_diis_space;         /*                    default 6     (PySCF 6)                         */
+  double scf_conv_tol;       /* |dE_scf|           default 1e-11 (PySCF 1e-9)                      */
+  double scf_conv_tol_grad;  /* ||FD-DF||          default 1e-7                                    */
+  int scf_max_cycle;         /*                    default 50    (molbe/helper.py:118)             */
+  int scf_diis_space;        /*                    default 8                                       */
+  int warm_start;            /* reuse t1/t2 of the previous sweep as the CCSD guess (default 0)      */
+  int verbose;
+} qemb_solver_opts;
+void qemb_default_opts(qemb_solver_opts* opts);
+
+typedef void* qemb_frag_t;   /* opaque: one fragment with its ERIs resident in HBM                   */
+int qemb_frag_create(int n, int n_f, qemb_frag_t* out);
+int qemb_frag_free(qemb_frag_t f);
+/* fragment ERIs, 4-fold packed (npair(n) x npair(n)): the dataset "f{I}" of eri_file.h5 (mbe.py:1039) */
+int qemb_frag_set_eri_s4(qemb_frag_t f, const double* eri_s4_host);
+int qemb_frag_set_eri_s4_dev(qemb_frag_t f, const double* eri_s4_dev);
+int qemb_frag_get_eri_s4(qemb_frag_t f, double* eri_s4_host);
+/* h1 = TA^T hcore TA, veff0 = TA^T V_hf TA, veff (may be NULL), centre weight and indices
+ * (Frags.weight_and_relAO_per_center, pfrag.py:100)                                                  */
+int qemb_frag_set_energy_data(qemb_frag_t f, const double* h1, const double* veff0, const double* veff,
+                              double weight, const int* centers, int ncenter);
+/* J[p,q] = (pq|rs) P[r,s], K[p,r] = (pq|rs) P[q,s] from the resident ERIs (helper.py:64 dot_eri_dm)   */
+int qemb_frag_jk(qemb_frag_t f, const double* P, double* J, double* K);
+/* one fragment of the sweep.  h = fock + heff (n x n); dm0 n x n or NULL; eeval: also fragment energies.
+ * outputs (any may be NULL): mo_coeff n*n, mo_energy n, rdm1_emb n*n (= C rdm1 C^T / 2, Frags._rdm1),
+ * rdm1_mo n*n (Frags.rdm1__), t1 o*v, t2 o*o*v*v, e_frag[3] = [e1,e2,ec], scalars.                     */
+int qemb_frag_solve(qemb_frag_t f, int nsocc, const double* h, const double* dm0, const qemb_solver_opts* opts,
+                    int eeval, double* mo_coeff, double* mo_energy, double* rdm1_emb, double* rdm1_mo, double* t1,
+                    double* t2, double* e_frag, double* e_corr_mo, double* e_scf, double* ebe_hf, int* n_iter,
+                    int* scf_cycles);
+/* stateless one-call form (host buffers in, host buffers out) */
+int qemb_ccsd_solve(int n, int nsocc, int n_f, const double* h, const double* eri_s4, const double* dm0,
+                    const qemb_solver_opts* opts, const double* h1, const double* veff0, double weight,
+                    const int* centers, int ncenter, double* mo_coeff, double* mo_energy, double* t1, double* t2,
+                    double* rdm1_emb, double* e_frag, double* e_corr_mo, int* n_iter);
+/* measurement hooks: set up SCF + integrals once, then run/timed single CCSD iterations                */
+int qemb_frag_prepare_ccsd(qemb_frag_t f, int nsocc, const double* h, const double* dm0, const qemb_solver_opts* opts);
+int qemb_frag_ccsd_iterate(qemb_frag_t f, int niter, double* e_corr, double* normt);
+int qemb_frag_ccsd_reset(qemb_frag_t f);
+
 #ifdef __cplusplus
 }
 #endif

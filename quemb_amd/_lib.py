@@ -25,6 +25,13 @@ class QembError(RuntimeError):
     """Raised when a libqemb_hip call returns a non-zero status."""
 
 
+class SolverOpts(C.Structure):
+    """qemb_solver_opts (include/qemb_hip.h)."""
+    _fields_ = [("cc_conv_tol", C.c_double), ("cc_conv_tol_normt", C.c_double), ("cc_max_cycle", C.c_int),
+                ("cc_diis_space", C.c_int), ("scf_conv_tol", C.c_double), ("scf_conv_tol_grad", C.c_double),
+                ("scf_max_cycle", C.c_int), ("scf_diis_space", C.c_int), ("warm_start", C.c_int), ("verbose", C.c_int)]
+
+
 _lib = None
 _initialised_device = None
 
@@ -68,8 +75,23 @@ def _declare(lib):
     f("qemb_op_jacobi_svd", I, L, L, P, P, P, P, C.POINTER(I))
     f("qemb_op_cholesky_lower", I, L, P)
     f("qemb_op_tri_inverse_lower", I, L, P, P)
-    # high-level entry points are declared lazily by the modules that use them (they may not exist in
-    # a partially built library during development)
+    # ---- fragment solver
+    OP = C.POINTER(SolverOpts)
+    IP = C.POINTER(I)
+    DP = C.POINTER(D)
+    f("qemb_default_opts", None, OP)
+    f("qemb_frag_create", I, I, I, C.POINTER(c_vp))
+    f("qemb_frag_free", I, V)
+    f("qemb_frag_set_eri_s4", I, V, P)
+    f("qemb_frag_set_eri_s4_dev", I, V, P)
+    f("qemb_frag_get_eri_s4", I, V, P)
+    f("qemb_frag_set_energy_data", I, V, P, P, P, D, IP, I)
+    f("qemb_frag_jk", I, V, P, P, P)
+    f("qemb_frag_solve", I, V, I, P, P, OP, I, P, P, P, P, P, P, P, DP, DP, DP, IP, IP)
+    f("qemb_ccsd_solve", I, I, I, I, P, P, P, OP, P, P, D, IP, I, P, P, P, P, P, P, DP, IP)
+    f("qemb_frag_prepare_ccsd", I, V, I, P, P, OP)
+    f("qemb_frag_ccsd_iterate", I, V, I, DP, DP)
+    f("qemb_frag_ccsd_reset", I, V)
     return lib
 
 
@@ -87,9 +109,14 @@ def load(path: os.PathLike | None = None):
     return _lib
 
 
-def check(rc: int, what: str = ""):
+def declare(cdll):
+    """Attach the C-ABI prototypes to an already opened library (used by tests/hostcheck too)."""
+    return _declare(cdll)
+
+
+def check(rc: int, what: str = "", lib=None):
     if rc != 0:
-        msg = load().qemb_last_error().decode(errors="replace")
+        msg = (lib or load()).qemb_last_error().decode(errors="replace")
         raise QembError(f"{what or 'libqemb_hip call'} failed (status {rc}): {msg}")
 
 

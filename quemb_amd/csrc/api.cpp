@@ -4,6 +4,7 @@
 #include <cstring>
 #include "../../include/qemb_hip.h"
 #include "dev_ops.h"
+#include "fragment.h"
 
 using namespace qemb;
 namespace qemb { extern int g_gemm_force_cfg; }
@@ -63,5 +64,88 @@ int qemb_op_jacobi_eigh(int64_t n, double* A, double* w, double* V, int* sweeps)
 int qemb_op_jacobi_svd(int64_t m, int64_t n, double* G, double* s, double* U, double* V, int* sweeps) { return dev_jacobi_svd(m, n, G, s, U, V, sweeps); }
 int qemb_op_cholesky_lower(int64_t n, double* A) { return dev_cholesky_lower(n, A); }
 int qemb_op_tri_inverse_lower(int64_t n, const double* L, double* Linv) { return dev_tri_inverse_lower(n, L, Linv); }
+
+// ---------------------------------------------------------------- fragment solver ----------------
+void qemb_default_opts(qemb_solver_opts* o) {
+  CcsdOptions c; ScfOptions s;
+  o->cc_conv_tol = c.conv_tol; o->cc_conv_tol_normt = c.conv_tol_normt; o->cc_max_cycle = c.max_cycle; o->cc_diis_space = c.diis_space;
+  o->scf_conv_tol = s.conv_tol; o->scf_conv_tol_grad = s.conv_tol_grad; o->scf_max_cycle = s.max_cycle; o->scf_diis_space = s.diis_space;
+  o->warm_start = 0; o->verbose = 0;
+}
+static FragmentOptions to_opts(const qemb_solver_opts* o) {
+  FragmentOptions f;
+  if (o) {
+    f.cc.conv_tol = o->cc_conv_tol; f.cc.conv_tol_normt = o->cc_conv_tol_normt; f.cc.max_cycle = o->cc_max_cycle;
+    f.cc.diis_space = o->cc_diis_space; f.cc.verbose = o->verbose;
+    f.scf.conv_tol = o->scf_conv_tol; f.scf.conv_tol_grad = o->scf_conv_tol_grad; f.scf.max_cycle = o->scf_max_cycle;
+    f.scf.diis_space = o->scf_diis_space; f.scf.verbose = o->verbose;
+    f.warm_start = o->warm_start;
+  }
+  return f;
+}
+#define FRAG(f) (reinterpret_cast<Fragment*>(f))
+#define CHECK_FRAG(f) do { if (!(f)) { set_error("null fragment handle"); return QEMB_ERR_ARG; } } while (0)
+
+int qemb_frag_create(int n, int n_f, qemb_frag_t* out) {
+  if (n <= 0 || n_f < 0 || n_f > n || !out) { set_error("qemb_frag_create: bad arguments"); return QEMB_ERR_ARG; }
+  *out = new Fragment(n, n_f);
+  return QEMB_OK;
+}
+int qemb_frag_free(qemb_frag_t f) { delete FRAG(f); return QEMB_OK; }
+int qemb_frag_set_eri_s4(qemb_frag_t f, const double* s4) { CHECK_FRAG(f); return FRAG(f)->set_eri_s4_host(s4); }
+int qemb_frag_set_eri_s4_dev(qemb_frag_t f, const double* s4) { CHECK_FRAG(f); return FRAG(f)->set_eri_s4_dev(s4); }
+int qemb_frag_get_eri_s4(qemb_frag_t f, double* s4) {
+  CHECK_FRAG(f);
+  const int64_t n = FRAG(f)->n(), np = n * (n + 1) / 2;
+  if (!FRAG(f)->eri_s4()) { set_error("fragment has no ERIs"); return QEMB_ERR_ARG; }
+  return dev_d2h(s4, FRAG(f)->eri_s4(), sizeof(double) * np * np);
+}
+int qemb_frag_set_energy_data(qemb_frag_t f, const double* h1, const double* veff0, const double* veff, double weight,
+                              const int* centers, int ncenter) {
+  CHECK_FRAG(f);
+  for (int i = 0; i < ncenter; ++i) if (centers[i] < 0 || centers[i] >= FRAG(f)->nf()) { set_error("centre index outside the fragment sites"); return QEMB_ERR_ARG; }
+  FRAG(f)->set_energy_data(h1, veff0, veff, weight, centers, ncenter);
+  return QEMB_OK;
+}
+int qemb_frag_jk(qemb_frag_t f, const double* P, double* J, double* K) { CHECK_FRAG(f); return FRAG(f)->hf_veff_from_dm(P, J, K); }
+int qemb_frag_solve(qemb_frag_t f, int nsocc, const double* h, const double* dm0, const qemb_solver_opts* opts, int eeval,
+                    double* mo_coeff, double* mo_energy, double* rdm1_emb, double* rdm1_mo, double* t1, double* t2,
+                    double* e_frag, double* e_corr_mo, double* e_scf, double* ebe_hf, int* n_iter, int* scf_cycles) {
+  CHECK_FRAG(f);
+  if (!h) { set_error("qemb_frag_solve: h is NULL"); return QEMB_ERR_ARG; }
+  FragmentResult r;
+  int rc = FRAG(f)->solve(nsocc, h, dm0, to_opts(opts), eeval, &r, mo_coeff, mo_energy, rdm1_emb, rdm1_mo, t1, t2);
+  if (n_iter) *n_iter = r.n_iter;
+  if (scf_cycles) *scf_cycles = r.scf_cycles;
+  if (rc) return rc;
+  if (e_frag) { e_frag[0] = r.e_frag[0]; e_frag[1] = r.e_frag[1]; e_frag[2] = r.e_frag[2]; }
+  if (e_corr_mo) *e_corr_mo = r.e_corr_mo;
+  if (e_scf) *e_scf = r.e_scf;
+  if (ebe_hf) *ebe_hf = r.ebe_hf;
+  return QEMB_OK;
+}
+int qemb_ccsd_solve(int n, int nsocc, int n_f, const double* h, const double* eri_s4, const double* dm0,
+                    const qemb_solver_opts* opts, const double* h1, const double* veff0, double weight, const int* centers,
+                    int ncenter, double* mo_coeff, double* mo_energy, double* t1, double* t2, double* rdm1_emb, double* e_frag,
+                    double* e_corr_mo, int* n_iter) {
+  if (n <= 0 || n_f < 0 || n_f > n || !eri_s4) { set_error("qemb_ccsd_solve: bad arguments"); return QEMB_ERR_ARG; }
+  Fragment fr(n, n_f);
+  int rc = fr.set_eri_s4_host(eri_s4);
+  if (rc) return rc;
+  const int eeval = (h1 && veff0 && e_frag) ? 1 : 0;
+  if (eeval) fr.set_energy_data(h1, veff0, nullptr, weight, centers, ncenter);
+  FragmentResult r;
+  rc = fr.solve(nsocc, h, dm0, to_opts(opts), eeval, &r, mo_coeff, mo_energy, rdm1_emb, nullptr, t1, t2);
+  if (n_iter) *n_iter = r.n_iter;
+  if (rc) return rc;
+  if (e_frag && eeval) { e_frag[0] = r.e_frag[0]; e_frag[1] = r.e_frag[1]; e_frag[2] = r.e_frag[2]; }
+  if (e_corr_mo) *e_corr_mo = r.e_corr_mo;
+  return QEMB_OK;
+}
+int qemb_frag_prepare_ccsd(qemb_frag_t f, int nsocc, const double* h, const double* dm0, const qemb_solver_opts* opts) {
+  CHECK_FRAG(f); return FRAG(f)->prepare_ccsd(nsocc, h, dm0, to_opts(opts));
+}
+int qemb_frag_ccsd_iterate(qemb_frag_t f, int niter, double* e, double* nt) { CHECK_FRAG(f); return FRAG(f)->ccsd_iterate(niter, e, nt); }
+int qemb_frag_ccsd_reset(qemb_frag_t f) { CHECK_FRAG(f); return FRAG(f)->ccsd_reset(); }
 
 }  // extern "C"

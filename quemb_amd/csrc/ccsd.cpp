@@ -1,0 +1,341 @@
+// ccsd.cpp -- RCCSD amplitude equations as GEMM-shaped device contractions.
+//
+// Reference behaviour: molbe/solver.py:829-946 (`solve_ccsd`): PySCF `cc.CCSD(mf)`, `eris = mycc.ao2mo()`
+// (:900), `eris.fock = diag(mo_energy)` (:901-902), `mycc.kernel(eris)` (:907).  The equations are PySCF's
+// cc/rccsd.py `update_amps` + cc/rintermediates.py as restated in SURVEY.md Appendix A and in
+// oracle/qemb_oracle/ccsd.py; here every O(N^5)/O(N^6) term is factorised into dev_gemm calls (FP64 MFMA)
+// and the index shuffles between them into dev_copy4 passes.  With the forced-diagonal Fock f_ov = 0 and
+// f_oo / f_vv cancel against the orbital-energy shift, so those terms are dropped analytically.
+//
+// Layout conventions (all contiguous, row-major):
+//   t1[i,a]; t2[i,j,a,b]; tau = t2 + t1 (x) t1
+//   T [k,c,j,b] = t2[k,j,c,b]   ("ph layout", matrix (kc) x (jb))      Tp[k,c,j,b] = t2[k,j,b,c]
+//   W1[(ia),(kc)] = Wvoov[a,k,i,c]     W2[(ia),(kc)] = Wvovo[a,k,c,i]
+//   Vl[a,b,c,d] = (ac|bd): the pp-ladder is the NT GEMM  t2new[(ij),(ab)] += tau[(ij),(cd)] * Vl[(ab),(cd)]
+//   U accumulates every term that enters t2new as P(X) = X_ijab + X_jiba; it is symmetrised once.
+#include "ccsd.h"
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+
+namespace qemb {
+
+// ------------------------------------------------------------------------------------------------------------
+// embedding -> MO transformation: four quarter transforms, each  Out[s',(pqr)] = sum_s C[s,s'] In[(pqr),s]
+// (TN GEMM, M = n, N = n^3, K = n).  The index order cycles, so after four steps the layout is [p',q',r',s'].
+// After step three the tensor is [q',r',s',P] with P still in the embedding basis: exactly the 3/4-transformed
+// integrals (P q'|r' s') that the fragment-projected energy of get_frag_energy (helper.py:307-321) needs.
+// ------------------------------------------------------------------------------------------------------------
+int mo_transform(int n, int o, int nf, double* X0, double* X1, const double* C, MoIntegrals& out) {
+  const int v = n - o;
+  const int64_t n3 = (int64_t)n * n * n;
+  out.n = n; out.o = o; out.v = v; out.nf = nf;
+  double* src = X0; double* dst = X1;
+  QTRY(dev_timer_begin(TIMER_AO2MO));
+  for (int step = 0; step < 4; ++step) {
+    QTRY(gemm(n, n3, n, 1.0, C, n, false, src, n, true, 0.0, dst, n3));
+    std::swap(src, dst);
+    if (step == 2 && nf > 0) {   // src = [q',r',s',P]
+      QTRY(out.A1.alloc((int64_t)v * o * v * nf));
+      QTRY(out.A2.alloc((int64_t)o * o * v * nf));
+      QTRY(extract4(out.A1, src, n, n, n, o, 0, o, 0, v, o, v, nf));
+      QTRY(extract4(out.A2, src, n, n, n, 0, 0, o, 0, o, o, v, nf));
+    }
+  }
+  const double* M = src;   // [p',q',r',s']
+  QTRY(out.oooo.alloc((int64_t)o * o * o * o));
+  QTRY(out.ovoo.alloc((int64_t)o * v * o * o));
+  QTRY(out.ovov.alloc((int64_t)o * v * o * v));
+  QTRY(out.oovv.alloc((int64_t)o * o * v * v));
+  QTRY(out.ovvo.alloc((int64_t)o * v * v * o));
+  QTRY(out.ovvv.alloc((int64_t)o * v * v * v));
+  QTRY(out.Vl.alloc((int64_t)v * v * v * v));
+  QTRY(extract4(out.oooo, M, n, n, n, 0, 0, 0, 0, o, o, o, o));
+  QTRY(extract4(out.ovoo, M, n, n, n, 0, o, 0, 0, o, v, o, o));
+  QTRY(extract4(out.ovov, M, n, n, n, 0, o, 0, o, o, v, o, v));
+  QTRY(extract4(out.oovv, M, n, n, n, 0, 0, o, o, o, o, v, v));
+  QTRY(extract4(out.ovvo, M, n, n, n, 0, o, o, 0, o, v, v, o));
+  QTRY(extract4(out.ovvv, M, n, n, n, 0, o, o, o, o, v, v, v));
+  {  // Vl[a,b,c,d] = M[o+a, o+c, o+b, o+d]: loop over the source order (a,c,b,d)
+    Copy4Desc c{};
+    const int64_t n1 = n, n2 = (int64_t)n * n, n3s = (int64_t)n * n * n;
+    c.dim[0] = v; c.dim[1] = v; c.dim[2] = v; c.dim[3] = v;
+    c.in = M + o * n3s + o * n2 + o * n1 + o;
+    c.si[0] = n3s; c.si[1] = n2; c.si[2] = n1; c.si[3] = 1;
+    c.out = out.Vl;
+    c.so[0] = (int64_t)v * v * v;  // a
+    c.so[1] = v;                   // c
+    c.so[2] = (int64_t)v * v;      // b
+    c.so[3] = 1;                   // d
+    c.alpha = 1.0; c.beta = 0.0;
+    QTRY(dev_copy4(c));
+  }
+  QTRY(dev_timer_end(TIMER_AO2MO));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+int CcsdSolver::setup(MoIntegrals&& ints, const double* mo_energy_dev) {
+  I_ = std::move(ints);
+  o_ = I_.o; v_ = I_.v; nf_ = I_.nf;
+  const int64_t o = o_, v = v_, nov = o * v, oo = o * o, vv = v * v, N2 = oo * vv;
+  QTRY(eo_.alloc(o)); QTRY(ev_.alloc(v));
+  QTRY(dev_d2d(eo_, mo_energy_dev, sizeof(double) * o));
+  QTRY(dev_d2d(ev_, mo_energy_dev + o, sizeof(double) * v));
+  // ---- constant tensors derived from the integral blocks
+  QTRY(ovov_t_.alloc(nov * nov)); QTRY(Lovov_.alloc(nov * nov)); QTRY(Loovv_.alloc(N2)); QTRY(OVoovv_.alloc(N2));
+  QTRY(Lovoo_.alloc(o * v * oo)); QTRY(W1base_.alloc(N2)); QTRY(W2base_.alloc(N2)); QTRY(Lph1_.alloc(N2));
+  QTRY(OVl_.alloc(o * v * vv)); QTRY(oooo_p_.alloc(oo * oo));
+  QTRY(perm4(ovov_t_, I_.ovov, o, v, o, v, 0, 3, 2, 1));                 // ovov_t[k,c,l,d] = ovov[k,d,l,c]
+  QTRY(dcopy(nov * nov, I_.ovov, Lovov_));
+  QTRY(axpby(nov * nov, -1.0, ovov_t_, 2.0, Lovov_));                    // Lovov = 2 ovov - ovov_t
+  QTRY(perm4(Loovv_, Lovov_, o, v, o, v, 0, 2, 1, 3));                   // Loovv[k,l,c,d] = Lovov[k,c,l,d]
+  QTRY(perm4(OVoovv_, I_.ovov, o, v, o, v, 0, 2, 1, 3));                 // OVoovv[k,l,c,d] = ovov[k,c,l,d]
+  QTRY(perm4(Lovoo_, I_.ovoo, o, v, o, o, 2, 1, 0, 3, -1.0, 0.0));       // -ovoo[k,c,l,i] at [l,c,k,i]
+  QTRY(axpby(o * v * oo, 2.0, I_.ovoo, 1.0, Lovoo_));                    // Lovoo[l,c,k,i] = 2 ovoo[lcki] - ovoo[kcli]
+  QTRY(perm4(W1base_, I_.ovvo, o, v, v, o, 3, 2, 0, 1));                 // W1base[i,a,k,c] = ovvo[k,c,a,i]
+  QTRY(perm4(W2base_, I_.oovv, o, o, v, v, 1, 2, 0, 3));                 // W2base[i,a,k,c] = oovv[k,i,a,c]
+  QTRY(dcopy(N2, W2base_, Lph1_));
+  QTRY(axpby(N2, 2.0, W1base_, -1.0, Lph1_));                            // Lph1 = 2 W1base - W2base
+  QTRY(perm4(OVl_, I_.ovvv, o, v, v, v, 0, 2, 3, 1));                    // OVl[k,a,c,d] = ovvv[k,d,a,c]
+  QTRY(perm4(oooo_p_, I_.oooo, o, o, o, o, 0, 2, 1, 3));                 // oooo_p[k,l,i,j] = oooo[k,i,l,j]
+  // ovvo / oovv are no longer needed once W1base / W2base exist
+  I_.ovvo.release(); I_.oovv.release();
+  // ---- amplitudes and work space
+  const int64_t na = nov + N2;
+  QTRY(amp_.alloc(na)); QTRY(ampn_.alloc(na)); QTRY(diff_.alloc(na));
+  for (DBuf* b : {&tau_, &T_, &Tp_, &S_, &W1_, &W2_, &W12_, &R_, &U_}) QTRY(b->alloc(N2));
+  const int64_t NG = std::max<int64_t>(N2, oo * o * v);   // scratch also holds (o,o,v,o)-shaped temporaries
+  QTRY(G1_.alloc(NG)); QTRY(G2_.alloc(NG));
+  QTRY(Foo_.alloc(oo)); QTRY(Fvv_.alloc(vv)); QTRY(Fov_.alloc(nov)); QTRY(Z_.alloc(oo)); QTRY(Y_.alloc(vv));
+  QTRY(Ytmp_.alloc(vv)); QTRY(Loo_.alloc(oo)); QTRY(Lvv_.alloc(vv)); QTRY(Q_.alloc(oo)); QTRY(Wo_.alloc(oo * oo));
+  QTRY(O1_.alloc(oo * oo)); QTRY(X_.alloc(oo * nov)); QTRY(scal_.alloc(8));
+  first_ = true;
+  return 0;
+}
+
+int CcsdSolver::make_tau(const double* t1, const double* t2, double* tau) {
+  const int64_t o = o_, v = v_;
+  QTRY(dcopy(o * o * v * v, t2, tau));
+  Outer4Desc d{};
+  d.dim[0] = o; d.dim[1] = o; d.dim[2] = v; d.dim[3] = v;
+  d.u = t1; d.su0 = v; d.su2 = 1; d.v = t1; d.sv1 = v; d.sv3 = 1;
+  d.out = tau; d.so[0] = o * v * v; d.so[1] = v * v; d.so[2] = v; d.so[3] = 1;
+  d.alpha = 1.0; d.beta = 1.0;
+  return dev_outer4(d);
+}
+
+int CcsdSolver::energy(const double* t1, const double* t2, double* e) {
+  // E = sum (2 ovov[iajb] - ovov[ibja]) tau[ijab] = <Loovv, tau>   (f_ov = 0)
+  QTRY(make_tau(t1, t2, tau_));
+  QTRY(dev_dot((int64_t)o_ * o_ * v_ * v_, Loovv_, tau_, scal_));
+  QTRY(dev_d2h(e, scal_, sizeof(double)));
+  return 0;
+}
+
+int CcsdSolver::init_amps() {
+  const int64_t o = o_, v = v_;
+  QTRY(dev_fill(t1(), o * v, 0.0));                                      // t1 = f_ov / e_ia = 0
+  QTRY(dcopy(o * o * v * v, OVoovv_, t2()));                             // t2 = ovov[i,a,j,b] / e_ijab
+  QTRY(dev_div_denom(t2(), o, o, v, v, eo_, eo_, ev_, ev_));
+  first_ = true;
+  diis_.clear();
+  return energy(t1(), t2(), &ecc_);
+}
+
+int CcsdSolver::set_amps(const double* t1d, const double* t2d) {
+  QTRY(dev_d2d(t1(), t1d, sizeof(double) * o_ * v_));
+  QTRY(dev_d2d(t2(), t2d, sizeof(double) * (int64_t)o_ * o_ * v_ * v_));
+  first_ = true;
+  diis_.clear();
+  return energy(t1(), t2(), &ecc_);
+}
+
+int CcsdSolver::update_amps(double* t1n, double* t2n) {
+  const int64_t o = o_, v = v_, nov = o * v, oo = o * o, vv = v * v, N2 = oo * vv;
+  const double* t1 = this->t1();
+  const double* t2 = this->t2();
+  // ---- amplitude layouts
+  QTRY(make_tau(t1, t2, tau_));
+  QTRY(perm4(T_, t2, o, o, v, v, 0, 2, 1, 3));          // T [k,c,j,b] = t2[k,j,c,b]
+  QTRY(perm4(Tp_, t2, o, o, v, v, 0, 3, 1, 2));         // Tp[k,c,j,b] = t2[k,j,b,c]
+
+  // ---- one- and two-index intermediates (energy-shifted: Foo - eps, Fvv - eps, ...)
+  QTRY(gemm_nt(o, o, o * vv, 1.0, Loovv_, tau_, 0.0, Foo_));                       // Foo'[k,i]
+  QTRY(gemm_tn(v, v, oo * v, -1.0, tau_, Loovv_, 0.0, Fvv_));                      // Fvv'[a,c]
+  QTRY(dev_gemv_rows(nov, nov, Lovov_, nov, t1, Fov_, 1.0, 0.0));                  // Fov[k,c]
+  QTRY(dev_contract_mid(1, nov, oo, Lovoo_, t1, Z_, oo, 1.0, 0.0));                // Z[k,i]
+  QTRY(dev_contract_mid(1, nov, vv, I_.ovvv, t1, Y_, vv, 2.0, 0.0));               // Y[a,c] = 2 ovvv[kdac] t1[kd]
+  for (int64_t k = 0; k < o; ++k)                                                  // Ytmp[c,a] = ovvv[kcad] t1[kd]
+    QTRY(dev_gemv_rows(vv, v, I_.ovvv.p + k * v * vv, v, t1 + k * v, Ytmp_, 1.0, k == 0 ? 0.0 : 1.0));
+  QTRY(perm4(Y_, Ytmp_, 1, 1, v, v, 0, 1, 3, 2, -1.0, 1.0));                       // Y[a,c] -= Ytmp[c,a]
+  QTRY(dcopy(oo, Foo_, Loo_)); QTRY(axpby(oo, 1.0, Z_, 1.0, Loo_));                // Loo' = Foo' + Z
+  QTRY(dcopy(vv, Fvv_, Lvv_)); QTRY(axpby(vv, 1.0, Y_, 1.0, Lvv_));                // Lvv' = Fvv' + Y
+
+  // ---- T1 equation
+  QTRY(gemm_nt(o, v, v, 1.0, t1, Lvv_, 0.0, t1n));                                 // (Fvv'+Y)_ac t1[ic]
+  QTRY(gemm_tn(o, v, o, -1.0, Loo_, t1, 1.0, t1n));                                // -(Foo'+Z)_ki t1[ka]
+  QTRY(gemm_nt(o, o, v, 1.0, t1, Fov_, 0.0, Q_));                                  // Q[i,k] = t1[ic] Fov[kc]
+  QTRY(gemm_nn(o, v, o, 1.0, Q_, t1, 1.0, t1n));                                   // Fov_kc t1[ic] t1[ka]
+  QTRY(dcopy(N2, T_, S_)); QTRY(axpby(N2, -1.0, Tp_, 2.0, S_));                    // Theta_ph = 2T - Tp
+  QTRY(dev_gemv_rows(nov, nov, S_, nov, Fov_, t1n, 1.0, 1.0));                     // Fov_kc (2 t2[kica] - t2[ikca])
+  QTRY(dev_gemv_rows(nov, nov, Lph1_, nov, t1, t1n, 1.0, 1.0));                    // (2 ovvo[kcai] - oovv[kiac]) t1[kc]
+  QTRY(perm4(S_, t2, o, o, v, v, 0, 1, 3, 2, 2.0, 0.0)); QTRY(axpby(N2, -1.0, t2, 1.0, S_));  // Th[i,k,d,c] = 2 t2[ikcd] - t2[ikdc]
+  QTRY(gemm_nn(o, v, o * vv, 1.0, S_, I_.ovvv, 1.0, t1n));                         // (2 ovvv[kdac] - ovvv[kcad]) t2[ikcd]
+  QTRY(gemm_tn(o, v, o * v * o, -1.0, Lovoo_, T_, 1.0, t1n));                      // -(2 ovoo[lcki] - ovoo[kcli]) t2[klac]
+
+  // ---- T2 equation: direct (unsymmetrised) part
+  QTRY(dcopy(N2, OVoovv_, t2n));                                                   // ovov[i,a,j,b]
+  // Woooo[k,l,i,j]
+  QTRY(dcopy(oo * oo, oooo_p_, Wo_));
+  QTRY(gemm_nt(oo, oo, vv, 1.0, OVoovv_, tau_, 1.0, Wo_));                         // ovov[kcld] tau[ijcd]
+  QTRY(gemm(o, oo, v, 1.0, t1, v, true, I_.ovoo, oo, false, 0.0, O1_, oo, o, 0, v * oo, o * oo));   // O1[l,j,k,i]
+  QTRY(perm4(Wo_, O1_, o, o, o, o, 2, 0, 3, 1, 1.0, 1.0));                         // + ovoo[lcki] t1[jc]
+  QTRY(perm4(Wo_, O1_, o, o, o, o, 0, 2, 1, 3, 1.0, 1.0));                         // + ovoo[kclj] t1[ic]
+  QTRY(gemm_tn(oo, vv, oo, 1.0, Wo_, tau_, 1.0, t2n));                             // Woooo[klij] tau[klab]
+  // pp-ladder (the dominant kernel): tau[(ij),(cd)] * Vl[(ab),(cd)]^T
+  QTRY(dev_timer_begin(TIMER_LADDER));
+  QTRY(gemm_nt(oo, vv, vv, 1.0, tau_, I_.Vl, 1.0, t2n));
+  QTRY(dev_timer_end(TIMER_LADDER));
+
+  // ---- T2 equation: terms that enter as P(X) accumulate in U
+  QTRY(gemm(v, v, v, 1.0, Lvv_, v, true, t2, v, false, 0.0, U_, v, oo, 0, vv, vv));   // Lvv'[a,c] t2[ijcb]
+  QTRY(gemm_tn(o, o * vv, o, -1.0, Loo_, t2, 1.0, U_));                            // -Loo'[k,i] t2[kjab]
+  //   t1-dressing of Wvvvv folded on the tau side: -t1[kb] (tau[ijcd] ovvv[kdac])
+  QTRY(gemm_nt(oo, nov, vv, 1.0, tau_, OVl_, 0.0, X_));                            // X[i,j,k,a]
+  QTRY(gemm(v, v, o, -1.0, X_, v, false, t1, v, false, 1.0, U_, v, oo, nov, 0, vv));
+  //   X1 = (ovvv[iacb] - oovv[kibc] t1[ka]) t1[jc]
+  QTRY(gemm_nt(o, o * vv, v, 1.0, t1, I_.ovvv, 0.0, G1_));                         // G1[j,i,a,b] = t1[jc] ovvv[i,a,b,c]
+  QTRY(perm4(U_, G1_, o, o, v, v, 1, 0, 2, 3, 1.0, 1.0));
+  {  // oovv[k,i,b,c] = W2base[i,b,k,c]: G2[k,i,b,j] = oovv[(kib),c] t1[jc] needs the oovv layout -> rebuild it
+    QTRY(perm4(G1_, W2base_, o, v, o, v, 2, 0, 1, 3));                             // G1 = oovv[k,i,b,c]
+    QTRY(gemm_nt(oo * v, o, v, 1.0, G1_, t1, 0.0, G2_));                           // G2[k,i,b,j]
+    QTRY(gemm_tn(v, o * v * o, o, 1.0, t1, G2_, 0.0, G1_));                        // G1[a,i,b,j] = t1[ka] G2[k,i,b,j]
+    QTRY(perm4(U_, G1_, v, o, v, o, 1, 3, 0, 2, -1.0, 1.0));
+  }
+  //   X2 = (ovvo[kcai] t1[jc] + ovoo[iajk]) t1[kb]   (enters with a minus sign)
+  QTRY(gemm_nn(o * v * o, v, o, 1.0, I_.ovoo, t1, 0.0, G1_));                      // G1[i,a,j,b] = ovoo[i,a,j,k] t1[kb]
+  QTRY(perm4(U_, G1_, o, v, o, v, 0, 2, 1, 3, -1.0, 1.0));
+  {  // ovvo[k,c,a,i] = W1base[i,a,k,c]
+    QTRY(perm4(G1_, W1base_, o, v, o, v, 2, 3, 1, 0));                             // G1 = ovvo[k,c,a,i]
+    QTRY(gemm(o, v * o, v, 1.0, t1, v, true, G1_, v * o, false, 0.0, G2_, v * o, o, 0, v * v * o, o * v * o));  // G2[k,j,a,i]
+    QTRY(gemm_tn(o * v * o, v, o, 1.0, G2_, t1, 0.0, G1_));                        // G1[j,a,i,b] = G2[k,(jai)] t1[kb]
+    QTRY(perm4(U_, G1_, o, v, o, v, 2, 0, 1, 3, -1.0, 1.0));
+  }
+  // ---- ph rings
+  QTRY(dev_timer_begin(TIMER_RINGS));
+  //   W1[(ia),(kc)] = Wvoov[a,k,i,c]
+  QTRY(dcopy(N2, W1base_, W1_));
+  QTRY(gemm_nt(o * vv, o, v, 1.0, I_.ovvv, t1, 0.0, G1_));                         // G1[k,c,a,i] = ovvv[kcad] t1[id]
+  QTRY(perm4(W1_, G1_, o, v, v, o, 3, 2, 0, 1, 1.0, 1.0));
+  QTRY(gemm(o, v, o, 1.0, I_.ovoo, o, false, t1, v, false, 0.0, G1_, v, nov, oo, 0, nov));   // G1[k,c,i,a] = ovoo[kcli] t1[la]
+  QTRY(perm4(W1_, G1_, o, v, o, v, 2, 3, 0, 1, -1.0, 1.0));
+  //   S = T - Tp/2 - t1[id] t1[la]   at [(ia),(ld)]
+  QTRY(dcopy(N2, T_, S_)); QTRY(axpby(N2, -0.5, Tp_, 1.0, S_));
+  {
+    Outer4Desc d{};   // loop (i,l,d,a): u = t1[i,d], v = t1[l,a]; out S[i,a,l,d]
+    d.dim[0] = o; d.dim[1] = o; d.dim[2] = v; d.dim[3] = v;
+    d.u = t1; d.su0 = v; d.su2 = 1; d.v = t1; d.sv1 = v; d.sv3 = 1;
+    d.out = S_; d.so[0] = v * o * v; d.so[1] = v; d.so[2] = 1; d.so[3] = o * v;
+    d.alpha = -1.0; d.beta = 1.0;
+    QTRY(dev_outer4(d));
+  }
+  QTRY(gemm_nn(nov, nov, nov, 1.0, S_, I_.ovov, 1.0, W1_));
+  QTRY(gemm_nn(nov, nov, nov, -0.5, T_, ovov_t_, 1.0, W1_));
+  //   W2[(ia),(kc)] = Wvovo[a,k,c,i]
+  QTRY(dcopy(N2, W2base_, W2_));
+  QTRY(gemm(o, vv, v, 1.0, t1, v, true, I_.ovvv, vv, false, 0.0, G1_, vv, o, 0, v * vv, o * vv));   // G1[k,i,a,c] = t1[id] ovvv[kdac]
+  QTRY(perm4(W2_, G1_, o, o, v, v, 1, 2, 0, 3, 1.0, 1.0));
+  QTRY(gemm_tn(v, v * oo, o, 1.0, t1, I_.ovoo, 0.0, G1_));                         // G1[a,c,k,i] = t1[la] ovoo[lcki]
+  QTRY(perm4(W2_, G1_, v, v, o, o, 3, 0, 2, 1, -1.0, 1.0));
+  //   S = Tp/2 + t1[id] t1[la]
+  QTRY(dev_fill(S_, N2, 0.0)); QTRY(axpby(N2, 0.5, Tp_, 0.0, S_));
+  {
+    Outer4Desc d{};
+    d.dim[0] = o; d.dim[1] = o; d.dim[2] = v; d.dim[3] = v;
+    d.u = t1; d.su0 = v; d.su2 = 1; d.v = t1; d.sv1 = v; d.sv3 = 1;
+    d.out = S_; d.so[0] = v * o * v; d.so[1] = v; d.so[2] = 1; d.so[3] = o * v;
+    d.alpha = 1.0; d.beta = 1.0;
+    QTRY(dev_outer4(d));
+  }
+  QTRY(gemm_nn(nov, nov, nov, -1.0, S_, ovov_t_, 1.0, W2_));
+  //   contributions to U
+  QTRY(dcopy(N2, W1_, W12_)); QTRY(axpby(N2, -1.0, W2_, 2.0, W12_));               // 2 W1 - W2
+  QTRY(gemm_nn(nov, nov, nov, 1.0, W12_, T_, 0.0, R_));                            // (2 Wvoov - Wvovo) t2[kjcb]
+  QTRY(gemm_nn(nov, nov, nov, -1.0, W1_, Tp_, 1.0, R_));                           // - Wvoov t2[kjbc]
+  QTRY(perm4(U_, R_, o, v, o, v, 0, 2, 1, 3, 1.0, 1.0));                           // R[i,a,j,b] -> U[i,j,a,b]
+  QTRY(gemm_nn(nov, nov, nov, 1.0, W2_, Tp_, 0.0, R_));                            // Wvovo[bkci] t2[kjac] at R[i,b,j,a]
+  QTRY(perm4(U_, R_, o, v, o, v, 0, 2, 3, 1, -1.0, 1.0));
+  QTRY(dev_timer_end(TIMER_RINGS));
+
+  // ---- symmetrise and divide
+  QTRY(axpby(N2, 1.0, U_, 1.0, t2n));
+  QTRY(perm4(t2n, U_, o, o, v, v, 1, 0, 3, 2, 1.0, 1.0));
+  QTRY(dev_div_denom(t1n, o, 1, v, 1, eo_, nullptr, ev_, nullptr));
+  QTRY(dev_div_denom(t2n, o, o, v, v, eo_, eo_, ev_, ev_));
+  return 0;
+}
+
+int CcsdSolver::iterate(double* e_corr, double* normt) {
+  const int64_t na = n_amp();
+  QTRY(dev_timer_begin(TIMER_ITER));
+  QTRY(update_amps(ampn_.p, ampn_.p + (int64_t)o_ * v_));
+  // diff = t_new - t (also the DIIS error vector: trial minus previously returned vector)
+  QTRY(dcopy(na, ampn_, diff_)); QTRY(axpby(na, -1.0, amp_, 1.0, diff_));
+  QTRY(dev_dot(na, diff_, diff_, scal_.p + 1));
+  QTRY(dcopy(na, ampn_, amp_));
+  if (!first_ && !diis_.empty()) QTRY(diis_[0].extrapolate(amp_, diff_));
+  first_ = false;
+  double nn = 0.0;
+  QTRY(dev_d2h(&nn, scal_.p + 1, sizeof(double)));
+  *normt = std::sqrt(nn);
+  QTRY(energy(t1(), t2(), &ecc_));
+  *e_corr = ecc_;
+  QTRY(dev_timer_end(TIMER_ITER));
+  return 0;
+}
+
+int CcsdSolver::kernel(const CcsdOptions& opt, double* e_corr, int* n_iter, bool* converged) {
+  diis_.clear();
+  if (opt.diis_space > 1) {
+    diis_.emplace_back(opt.diis_space, n_amp());
+    QTRY(diis_[0].init());
+  }
+  double eold = ecc_, e = ecc_, normt = 0.0;
+  *converged = false;
+  int it = 0;
+  for (it = 1; it <= opt.max_cycle; ++it) {
+    QTRY(iterate(&e, &normt));
+    if (opt.verbose > 0) std::fprintf(stderr, "[qemb ccsd] cycle %3d  E(corr) = %.12f  dE = %.3e  |dt| = %.3e\n", it, e, e - eold, normt);
+    if (!std::isfinite(e)) { set_error("CCSD diverged (non-finite energy)"); return QEMB_ERR_NUMERIC; }
+    if (std::fabs(e - eold) < opt.conv_tol && normt < opt.conv_tol_normt) { *converged = true; break; }
+    eold = e;
+  }
+  *e_corr = e;
+  *n_iter = it > opt.max_cycle ? opt.max_cycle : it;
+  diis_.clear();
+  return 0;
+}
+
+// Z1[i,P] = sum_{ajb} G[i,a,j,b] (Pa|jb),  Z2[a,P] = sum_{ijb} G[i,a,j,b] (Pi|jb),  G = 2 tau[ijab] - tau[jiab]
+// (the contracted form of make_rdm2_urlx(with_dm1=False) + the 'ijkl,pi,qj,rk,sl' rotation of helper.py:307)
+int CcsdSolver::energy_intermediates(std::vector<double>& Z1, std::vector<double>& Z2) {
+  const int64_t o = o_, v = v_, nf = nf_, N2 = o * o * v * v;
+  Z1.assign((size_t)(o * nf), 0.0); Z2.assign((size_t)(v * nf), 0.0);
+  if (nf <= 0) return 0;
+  QTRY(make_tau(t1(), t2(), tau_));
+  QTRY(perm4(S_, tau_, o, o, v, v, 0, 2, 1, 3, 2.0, 0.0));     // 2 tau[ijab] at [i,a,j,b]
+  QTRY(perm4(S_, tau_, o, o, v, v, 1, 2, 0, 3, -1.0, 1.0));    // - tau[jiab]: out[i,a,j,b] = in[j,i,a,b]
+  DBuf z1, z2, a2p;
+  QTRY(z1.alloc(o * nf)); QTRY(z2.alloc(v * nf)); QTRY(a2p.alloc(o * o * v * nf));
+  QTRY(gemm_nn(o, nf, v * o * v, 1.0, S_, I_.A1, 0.0, z1));    // Z1[i,P] = G[i,(ajb)] A1[(ajb),P]
+  // Z2[a,P] = sum_{(jbi)} G[(jbi),a] A2p[(jbi),P],  A2p[j,b,i,P] = A2[i,j,b,P]
+  QTRY(perm4(a2p, I_.A2, o, o, v, nf, 1, 2, 0, 3));
+  QTRY(gemm_tn(v, nf, o * v * o, 1.0, S_, a2p, 0.0, z2));
+  QTRY(dev_d2h(Z1.data(), z1, sizeof(double) * o * nf));
+  QTRY(dev_d2h(Z2.data(), z2, sizeof(double) * v * nf));
+  (void)N2;
+  return 0;
+}
+
+}  // namespace qemb

@@ -1,0 +1,65 @@
+// ccsd.h -- device-resident RCCSD for one embedded fragment (row a8 of SURVEY.md section 8) plus the
+// embedding->MO integral transformation that feeds it and the contracted RDM/energy pieces (a9-a11).
+#pragma once
+#include <cstdint>
+#include <vector>
+#include "dev_ops.h"
+#include "tensor_utils.h"
+
+namespace qemb {
+
+struct CcsdOptions {
+  double conv_tol = 1e-10;        // |dE|      (PySCF default 1e-7; tighter here)
+  double conv_tol_normt = 1e-8;   // |dt|      (PySCF default 1e-5)
+  int max_cycle = 100;            //           (PySCF default 50)
+  int diis_space = 6;
+  int verbose = 0;
+};
+
+// MO-basis integral blocks, chemists' notation, all device resident and contiguous.
+struct MoIntegrals {
+  int n = 0, o = 0, v = 0, nf = 0;
+  DBuf oooo, ovoo, ovov, oovv, ovvo, ovvv;
+  DBuf Vl;          // Vl[a,b,c,d] = (ac|bd)   (the pp-ladder operand, K-contiguous in (c,d))
+  DBuf A1, A2;      // A1[a,j,b,P] = (P a|j b), A2[i,j,b,P] = (P i|j b), P < nf in the EMBEDDING basis
+};
+
+// eri_s1: (n^4) embedding-basis ERIs [p,q,r,s] on the device -- OVERWRITTEN (used as ping-pong buffer);
+// work: second n^4 device buffer; C: n x n MO coefficients (columns) on the device.
+int mo_transform(int n, int o, int nf, double* eri_s1, double* work, const double* C, MoIntegrals& out);
+
+class CcsdSolver {
+ public:
+  int setup(MoIntegrals&& ints, const double* mo_energy_dev);
+  int init_amps();                                  // MP2 guess (t1 = 0 for the diagonal Fock)
+  int set_amps(const double* t1_dev, const double* t2_dev);   // warm start
+  int iterate(double* e_corr, double* normt);       // one update_amps + DIIS + energy
+  int kernel(const CcsdOptions& opt, double* e_corr, int* n_iter, bool* converged);
+  // energy pieces of get_frag_energy that need t1,t2: Z1[i,P], Z2[a,P] (host outputs o*nf and v*nf)
+  int energy_intermediates(std::vector<double>& Z1, std::vector<double>& Z2);
+  double* t1() { return amp_.p; }
+  double* t2() { return amp_.p + (int64_t)o_ * v_; }
+  int o() const { return o_; }
+  int v() const { return v_; }
+  int64_t n_amp() const { return (int64_t)o_ * v_ + (int64_t)o_ * o_ * v_ * v_; }
+
+ private:
+  int update_amps(double* t1n, double* t2n);
+  int energy(const double* t1, const double* t2, double* e);
+  int make_tau(const double* t1, const double* t2, double* tau);
+
+  int o_ = 0, v_ = 0, nf_ = 0;
+  MoIntegrals I_;
+  DBuf eo_, ev_;
+  // derived constant tensors
+  DBuf ovov_t_, Lovov_, Loovv_, OVoovv_, Lovoo_, W1base_, W2base_, Lph1_, OVl_, oooo_p_;
+  // amplitudes (t1 then t2, one contiguous vector) and per-iteration work space
+  DBuf amp_, ampn_, diff_;
+  DBuf tau_, T_, Tp_, S_, W1_, W2_, W12_, R_, U_, G1_, G2_;
+  DBuf Foo_, Fvv_, Fov_, Z_, Y_, Ytmp_, Loo_, Lvv_, Q_, Wo_, O1_, X_, scal_;
+  std::vector<DeviceDIIS> diis_;
+  bool first_ = true;
+  double ecc_ = 0.0;
+};
+
+}  // namespace qemb

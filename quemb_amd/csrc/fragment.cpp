@@ -1,0 +1,193 @@
+// fragment.cpp -- the per-fragment pipeline on the device:
+//   fragment RHF (helper.py:73-151) -> embedding->MO integrals (solver.py:900) -> RCCSD (solver.py:907)
+//   -> unrelaxed 1-RDM (ccsd_rdm.py:10-20) back-rotated (solver.py:496-505) -> fragment energy (helper.py:220-339)
+// with the fragment ERIs resident in HBM between sweeps (the reference re-reads them from HDF5 every call:
+// helper.py:182-189, :303-304).
+#include "fragment.h"
+#include <cmath>
+#include <cstring>
+
+namespace qemb {
+
+static inline int64_t npair(int64_t n) { return n * (n + 1) / 2; }
+
+int Fragment::set_eri_s4_host(const double* s4) {
+  const int64_t np = npair(n_);
+  QTRY(eri_s4_.alloc(np * np));
+  return dev_h2d(eri_s4_, s4, sizeof(double) * np * np);
+}
+int Fragment::set_eri_s4_dev(const double* s4_dev) {
+  const int64_t np = npair(n_);
+  QTRY(eri_s4_.alloc(np * np));
+  return dev_d2d(eri_s4_, s4_dev, sizeof(double) * np * np);
+}
+void Fragment::set_energy_data(const double* h1, const double* veff0, const double* veff, double weight, const int* centers, int ncen) {
+  const size_t n2 = (size_t)n_ * n_;
+  if (h1) h1_.assign(h1, h1 + n2);
+  if (veff0) veff0_.assign(veff0, veff0 + n2);
+  if (veff) veff_.assign(veff, veff + n2);
+  weight_ = weight;
+  centers_.assign(centers, centers + ncen);
+}
+
+int Fragment::run_scf(int o, const double* h, const double* dm0, const ScfOptions& opt, double* X0, ScfResult* sres) {
+  const int64_t n2 = (int64_t)n_ * n_;
+  o_ = o;
+  QTRY(C_.alloc(n2)); QTRY(eps_.alloc(n_)); QTRY(dm_.alloc(n2)); QTRY(J_.alloc(n2)); QTRY(K_.alloc(n2));
+  DBuf hd;
+  QTRY(hd.alloc(n2));
+  QTRY(dev_h2d(hd, h, sizeof(double) * n2));
+  if (dm0) {
+    QTRY(dev_h2d(dm_, dm0, sizeof(double) * n2));
+  } else {   // core guess
+    DBuf tmp; QTRY(tmp.alloc(n2)); QTRY(dcopy(n2, hd, tmp));
+    QTRY(dev_jacobi_eigh(n_, tmp, eps_, C_, nullptr));
+    QTRY(gemm(n_, n_, o, 2.0, C_, n_, true, C_, n_, true, 0.0, dm_, n_));
+  }
+  return rhf_device(n_, o, hd, X0, dm_, opt, C_, eps_, J_, K_, sres);
+}
+
+int Fragment::hf_veff_from_dm(const double* P_host, double* J_host, double* K_host) {
+  if (!eri_s4_.p) { set_error("Fragment: ERIs not set"); return QEMB_ERR_ARG; }
+  const int64_t n2 = (int64_t)n_ * n_;
+  DBuf X0, P, J, K;
+  QTRY(X0.alloc(n2 * n2)); QTRY(P.alloc(n2)); QTRY(J.alloc(n2)); QTRY(K.alloc(n2));
+  QTRY(dev_unpack_s4(n_, eri_s4_, X0));
+  QTRY(dev_h2d(P, P_host, sizeof(double) * n2));
+  QTRY(build_jk(n_, X0, P, J, K));
+  QTRY(dev_d2h(J_host, J, sizeof(double) * n2));
+  QTRY(dev_d2h(K_host, K, sizeof(double) * n2));
+  return 0;
+}
+
+int Fragment::prepare_ccsd(int o, const double* h, const double* dm0, const FragmentOptions& opt) {
+  if (!eri_s4_.p) { set_error("Fragment: ERIs not set"); return QEMB_ERR_ARG; }
+  if (o <= 0 || o >= n_) { set_error("Fragment: need 0 < nsocc < n"); return QEMB_ERR_ARG; }
+  const int64_t n2 = (int64_t)n_ * n_;
+  cc_.reset();
+  DBuf X0, X1;
+  QTRY(X0.alloc(n2 * n2));
+  QTRY(dev_unpack_s4(n_, eri_s4_, X0));
+  ScfResult sres;
+  QTRY(run_scf(o, h, dm0, opt.scf, X0, &sres));
+  if (!sres.converged) { set_error("fragment SCF did not converge (also not with level shift 0.2)"); return QEMB_ERR_NOCONV; }
+  QTRY(X1.alloc(n2 * n2));
+  MoIntegrals ints;
+  QTRY(mo_transform(n_, o, nf_, X0, X1, C_, ints));
+  X0.release(); X1.release();
+  cc_.reset(new CcsdSolver());
+  QTRY(cc_->setup(std::move(ints), eps_));
+  return cc_->init_amps();
+}
+int Fragment::ccsd_reset() { if (!cc_) { set_error("Fragment: prepare_ccsd first"); return QEMB_ERR_ARG; } return cc_->init_amps(); }
+int Fragment::ccsd_iterate(int niter, double* e_corr, double* normt) {
+  if (!cc_) { set_error("Fragment: prepare_ccsd first"); return QEMB_ERR_ARG; }
+  for (int i = 0; i < niter; ++i) QTRY(cc_->iterate(e_corr, normt));
+  return 0;
+}
+
+int Fragment::solve(int o, const double* h, const double* dm0, const FragmentOptions& opt, int eeval, FragmentResult* res,
+                    double* mo_coeff, double* mo_energy, double* rdm1_emb, double* rdm1_mo, double* t1_out, double* t2_out) {
+  if (!eri_s4_.p) { set_error("Fragment: ERIs not set"); return QEMB_ERR_ARG; }
+  if (o <= 0 || o >= n_) { set_error("Fragment: need 0 < nsocc < n"); return QEMB_ERR_ARG; }
+  const int n = n_, v = n - o;
+  const int64_t n2 = (int64_t)n * n;
+  cc_.reset();
+  // ---- fragment RHF on the full n^4 tensor (kept for the MO transformation)
+  DBuf X0, X1;
+  QTRY(X0.alloc(n2 * n2));
+  QTRY(dev_unpack_s4(n, eri_s4_, X0));
+  ScfResult sres;
+  QTRY(run_scf(o, h, dm0, opt.scf, X0, &sres));
+  res->scf_converged = sres.converged; res->scf_cycles = sres.cycles; res->e_scf = sres.e_tot;
+  if (!sres.converged) { set_error("fragment SCF did not converge (also not with level shift 0.2)"); return QEMB_ERR_NOCONV; }
+  std::vector<double> C((size_t)n2), eps((size_t)n), J((size_t)n2), K((size_t)n2);
+  QTRY(dev_d2h(C.data(), C_, sizeof(double) * n2));
+  QTRY(dev_d2h(eps.data(), eps_, sizeof(double) * n));
+  // ---- integrals + CCSD
+  QTRY(X1.alloc(n2 * n2));
+  MoIntegrals ints;
+  QTRY(mo_transform(n, o, eeval ? nf_ : 0, X0, X1, C_, ints));
+  X0.release(); X1.release();
+  cc_.reset(new CcsdSolver());
+  QTRY(cc_->setup(std::move(ints), eps_));
+  if (opt.warm_start && t_prev_.p && t_prev_o_ == o) {
+    QTRY(cc_->set_amps(t_prev_.p, t_prev_.p + (int64_t)o * v));
+  } else {
+    QTRY(cc_->init_amps());
+  }
+  bool conv = false;
+  QTRY(cc_->kernel(opt.cc, &res->e_corr_mo, &res->n_iter, &conv));
+  res->ccsd_converged = conv;
+  if (!conv) { set_error("CCSD did not converge in max_cycle iterations"); return QEMB_ERR_NOCONV; }
+  // ---- amplitudes to the host as requested; unrelaxed 1-RDM (depends on t1 only)
+  std::vector<double> t1((size_t)o * v);
+  QTRY(dev_d2h(t1.data(), cc_->t1(), sizeof(double) * o * v));
+  if (t1_out) std::memcpy(t1_out, t1.data(), sizeof(double) * o * v);
+  if (t2_out) QTRY(dev_d2h(t2_out, cc_->t2(), sizeof(double) * (int64_t)o * o * v * v));
+  // rdm1_mo = [[2 I, t1], [t1^T, 0]]  (shared/external/ccsd_rdm.py:10-20)
+  if (rdm1_mo) {
+    std::memset(rdm1_mo, 0, sizeof(double) * n2);
+    for (int i = 0; i < o; ++i) rdm1_mo[(size_t)i * n + i] = 2.0;
+    for (int i = 0; i < o; ++i) for (int a = 0; a < v; ++a) { rdm1_mo[(size_t)i * n + o + a] = t1[(size_t)i * v + a]; rdm1_mo[(size_t)(o + a) * n + i] = t1[(size_t)i * v + a]; }
+  }
+  // rdm_emb = C rdm1 C^T / 2 = Co Co^T + (Co t1 Cv^T + Cv t1^T Co^T)/2   (solver.py:496-505)
+  std::vector<double> rdm((size_t)n2, 0.0), hfdm((size_t)n2, 0.0), X((size_t)n * v, 0.0);
+  for (int p = 0; p < n; ++p) for (int q = 0; q < n; ++q) { double s = 0; for (int i = 0; i < o; ++i) s += C[(size_t)p * n + i] * C[(size_t)q * n + i]; hfdm[(size_t)p * n + q] = s; }
+  for (int p = 0; p < n; ++p) for (int a = 0; a < v; ++a) { double s = 0; for (int i = 0; i < o; ++i) s += C[(size_t)p * n + i] * t1[(size_t)i * v + a]; X[(size_t)p * v + a] = s; }
+  for (int p = 0; p < n; ++p) for (int q = 0; q < n; ++q) { double s = 0; for (int a = 0; a < v; ++a) s += X[(size_t)p * v + a] * C[(size_t)q * n + o + a]; rdm[(size_t)p * n + q] = s; }
+  for (int p = 0; p < n; ++p) for (int q = 0; q <= p; ++q) {
+    const double sym = 0.5 * (rdm[(size_t)p * n + q] + rdm[(size_t)q * n + p]);
+    rdm[(size_t)p * n + q] = rdm[(size_t)q * n + p] = hfdm[(size_t)p * n + q] + sym;
+  }
+  if (rdm1_emb) std::memcpy(rdm1_emb, rdm.data(), sizeof(double) * n2);
+  if (mo_coeff) std::memcpy(mo_coeff, C.data(), sizeof(double) * n2);
+  if (mo_energy) std::memcpy(mo_energy, eps.data(), sizeof(double) * n);
+  // ---- energies
+  if (eeval) {
+    if (h1_.empty() || veff0_.empty()) { set_error("Fragment: set_energy_data(h1, veff0, ...) before an energy evaluation"); return QEMB_ERR_ARG; }
+    std::vector<double> Z1, Z2;
+    QTRY(cc_->energy_intermediates(Z1, Z2));
+    std::vector<double> e1((size_t)nf_, 0.0), e2((size_t)nf_, 0.0), ec((size_t)nf_, 0.0);
+    for (int P = 0; P < nf_; ++P) {
+      double s1 = 0, sc = 0;
+      for (int Q = 0; Q < n; ++Q) {
+        const double d = 2.0 * (rdm[(size_t)P * n + Q] - hfdm[(size_t)P * n + Q]);   // helper.py:286
+        s1 += h1_[(size_t)P * n + Q] * d; sc += veff0_[(size_t)P * n + Q] * d;
+      }
+      e1[P] = s1; ec[P] = sc;
+      double s2 = 0;
+      for (int i = 0; i < o; ++i) s2 += C[(size_t)P * n + i] * Z1[(size_t)i * nf_ + P];
+      for (int a = 0; a < v; ++a) s2 += C[(size_t)P * n + o + a] * Z2[(size_t)a * nf_ + P];
+      e2[P] = 0.5 * s2;
+    }
+    res->e_frag[0] = res->e_frag[1] = res->e_frag[2] = 0.0;
+    for (int c : centers_) { res->e_frag[0] += weight_ * e1[c]; res->e_frag[1] += weight_ * e2[c]; res->e_frag[2] += weight_ * ec[c]; }
+    // update_ebe_hf (pfrag.py:327-400) with D = Co Co^T: e2_i = sum_j D_ij (2 J_ij - K_ij), J/K of D = J,K(dm)/2
+    if (!veff_.empty()) {
+      QTRY(dev_d2h(J.data(), J_, sizeof(double) * n2));
+      QTRY(dev_d2h(K.data(), K_, sizeof(double) * n2));
+      double ehf = 0.0;
+      for (int c : centers_) {
+        double a = 0;
+        for (int Q = 0; Q < n; ++Q) {
+          const double D = hfdm[(size_t)c * n + Q];
+          a += 2.0 * h1_[(size_t)c * n + Q] * D + veff_[(size_t)c * n + Q] * D + D * (J[(size_t)c * n + Q] - 0.5 * K[(size_t)c * n + Q]);
+        }
+        ehf += weight_ * a;
+      }
+      res->ebe_hf = ehf;
+    }
+  }
+  // ---- keep amplitudes for a warm start of the next sweep
+  if (opt.keep_amplitudes || opt.warm_start) {
+    const int64_t na = cc_->n_amp();
+    QTRY(t_prev_.alloc(na));
+    QTRY(dcopy(na, cc_->t1(), t_prev_));
+    t_prev_o_ = o;
+  }
+  cc_.reset();
+  return 0;
+}
+
+}  // namespace qemb

@@ -1,0 +1,66 @@
+// fragment.h -- one embedded fragment resident on the device and the body of the fragment sweep
+// (be_func's loop body, molbe/solver.py:301-547 == run_solver, molbe/be_parallel.py:40-307).
+#pragma once
+#include <cstdint>
+#include <memory>
+#include <vector>
+#include "ccsd.h"
+#include "scf.h"
+
+namespace qemb {
+
+struct FragmentOptions {
+  CcsdOptions cc;
+  ScfOptions scf;
+  int warm_start = 0;      // reuse converged t1/t2 of the previous solve as the CCSD guess (reference restarts from MP2)
+  int keep_amplitudes = 1; // keep t1/t2 resident after the solve
+};
+
+struct FragmentResult {
+  int n_iter = 0;
+  int scf_cycles = 0;
+  int ccsd_converged = 0, scf_converged = 0;
+  double e_corr_mo = 0.0;      // CCSD correlation energy of the embedding problem
+  double e_scf = 0.0;          // fragment RHF energy (electronic, of h = fock + heff)
+  double e_frag[3] = {0, 0, 0};   // [e1, e2, ec] weighted centre sums (get_frag_energy, helper.py:333-339)
+  double ebe_hf = 0.0;         // update_ebe_hf (pfrag.py:327-400) evaluated with the SCF orbitals of this solve
+};
+
+class Fragment {
+ public:
+  Fragment(int n, int nf) : n_(n), nf_(nf) {}
+  int n() const { return n_; }
+  int nf() const { return nf_; }
+  int o() const { return o_; }
+  // ERIs: 4-fold packed (npair x npair), the layout of dataset "f{I}" (mbe.py:1039)
+  int set_eri_s4_host(const double* s4);
+  int set_eri_s4_dev(const double* s4_dev);     // device-to-device copy
+  double* eri_s4() { return eri_s4_.p; }
+  // static data for the energies: h1, veff0 (n x n host), centre weight/indices
+  void set_energy_data(const double* h1, const double* veff0, const double* veff, double weight, const int* centers, int ncen);
+  // The sweep body.  h = fock + heff (n x n host), dm0 (n x n host, may be null -> core guess).
+  // Outputs (host, nullable): mo_coeff n*n, mo_energy n, rdm1_emb n*n (= C rdm1 C^T / 2), rdm1_mo n*n, t1 o*v, t2 o*o*v*v.
+  int solve(int o, const double* h, const double* dm0, const FragmentOptions& opt, int eeval, FragmentResult* res,
+            double* mo_coeff, double* mo_energy, double* rdm1_emb, double* rdm1_mo, double* t1, double* t2);
+  // Bench hooks: set up the CCSD problem once (SCF + transform), then time single iterations.
+  int prepare_ccsd(int o, const double* h, const double* dm0, const FragmentOptions& opt);
+  int ccsd_iterate(int niter, double* e_corr, double* normt);
+  int ccsd_reset();                              // back to the MP2 guess
+  // J/K based pieces that do not need a correlated solve (row a6 / a15)
+  int hf_veff_from_dm(const double* P_host, double* J_host, double* K_host);   // J,K of an n x n density
+
+ private:
+  int run_scf(int o, const double* h, const double* dm0, const ScfOptions& opt, double* X0, ScfResult* sres);
+  int n_, nf_, o_ = -1;
+  DBuf eri_s4_;
+  std::vector<double> h1_, veff0_, veff_;
+  double weight_ = 1.0;
+  std::vector<int> centers_;
+  // state of the last solve
+  DBuf C_, eps_, dm_, J_, K_;
+  std::unique_ptr<CcsdSolver> cc_;
+  DBuf t_prev_;   // warm-start amplitudes (t1 then t2)
+  int t_prev_o_ = -1;
+};
+
+}  // namespace qemb

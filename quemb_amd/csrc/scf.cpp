@@ -1,0 +1,98 @@
+// scf.cpp -- fragment RHF in the orthonormal embedding basis, entirely on the device.
+//
+// Reference behaviour: molbe/helper.py:73-151 `get_scfObj` (PySCF `scf.RHF` with custom hcore = fock + heff,
+// S = I, `_eri` = fragment ERIs, nelec = 2*nsocc, `dm0`, max_cycle 50, DIIS; level-shift retry :128-149) and
+// molbe/helper.py:28-69 `get_veff` (J/K through `scf.hf.dot_eri_dm` :64).  The J/K contractions stream the
+// n^4 tensor once each (HBM bound); the Fock eigenproblem goes through the wavefront Jacobi solver.
+#include "scf.h"
+#include <cmath>
+#include <cstdio>
+#include <vector>
+
+namespace qemb {
+
+int build_jk(int n, const double* eri, const double* dm, double* J, double* K) {
+  const int64_t n2 = (int64_t)n * n;
+  if (J) QTRY(dev_gemv_rows(n2, n2, eri, n2, dm, J, 1.0, 0.0));
+  // K[p,r] = sum_{q,s} D[q,s] (pq|sr): treat eri as [p][(q,s)][r]
+  if (K) QTRY(dev_contract_mid(n, n2, n, eri, dm, K, n, 1.0, 0.0));
+  return 0;
+}
+
+static int density_from_mos(int n, int o, const double* C, double* dm) {
+  // dm = 2 C_occ C_occ^T : A(m,k) = C[m*n + k] (k < o), B(k,nn) = C[nn*n + k]
+  return gemm(n, n, o, 2.0, C, n, true, C, n, true, 0.0, dm, n);
+}
+
+static int rhf_loop(int n, int o, const double* h, const double* eri, double* dm, const ScfOptions& opt, double* C,
+                    double* eps, double* J, double* K, ScfResult* res) {
+  const int64_t n2 = (int64_t)n * n;
+  DBuf F, Fd, err, tmp, scal, hpf;
+  QTRY(F.alloc(n2)); QTRY(Fd.alloc(n2)); QTRY(err.alloc(n2)); QTRY(tmp.alloc(n2)); QTRY(scal.alloc(4)); QTRY(hpf.alloc(n2));
+  DeviceDIIS diis(opt.diis_space, n2);
+  QTRY(diis.init());
+  double e_old = 0.0;
+  res->converged = false;
+  int cyc = 0;
+  for (cyc = 0; cyc < opt.max_cycle; ++cyc) {
+    QTRY(build_jk(n, eri, dm, J, K));
+    QTRY(dcopy(n2, h, F)); QTRY(axpby(n2, 1.0, J, 1.0, F)); QTRY(axpby(n2, -0.5, K, 1.0, F));
+    QTRY(dcopy(n2, h, hpf)); QTRY(axpby(n2, 1.0, F, 1.0, hpf));
+    QTRY(dev_dot(n2, hpf, dm, scal));                                   // 2 E = <h + F, D>
+    QTRY(gemm_nn(n, n, n, 1.0, F, dm, 0.0, err));                       // FD - DF   (S = I)
+    QTRY(gemm_nn(n, n, n, -1.0, dm, F, 1.0, err));
+    QTRY(dev_dot(n2, err, err, scal.p + 1));
+    double hs[2];
+    QTRY(dev_d2h(hs, scal, sizeof(double) * 2));
+    const double e_tot = 0.5 * hs[0], gnorm = std::sqrt(hs[1]);
+    if (opt.verbose > 0) std::fprintf(stderr, "[qemb scf] cycle %2d  E = %.12f  dE = %.3e  |FD-DF| = %.3e\n", cyc, e_tot, e_tot - e_old, gnorm);
+    res->e_tot = e_tot;
+    if (!std::isfinite(e_tot)) { set_error("fragment SCF diverged"); return QEMB_ERR_NUMERIC; }
+    if (cyc > 0 && std::fabs(e_tot - e_old) < opt.conv_tol && gnorm < opt.conv_tol_grad) { res->converged = true; break; }
+    e_old = e_tot;
+    QTRY(dcopy(n2, F, Fd));
+    QTRY(diis.extrapolate(Fd, err));
+    if (opt.level_shift != 0.0) {                                        // F += shift * (I - D/2)
+      QTRY(axpby(n2, -0.5 * opt.level_shift, dm, 1.0, Fd));
+      std::vector<double> ident((size_t)n2, 0.0);
+      for (int i = 0; i < n; ++i) ident[(size_t)i * n + i] = opt.level_shift;
+      QTRY(dev_h2d(tmp, ident.data(), sizeof(double) * n2));
+      QTRY(axpby(n2, 1.0, tmp, 1.0, Fd));
+    }
+    QTRY(dev_jacobi_eigh(n, Fd, eps, C, nullptr));
+    QTRY(density_from_mos(n, o, C, dm));
+  }
+  res->cycles = cyc + (res->converged ? 1 : 0);
+  // canonical orbitals of the Fock matrix of the final density (PySCF does the same extra diagonalisation)
+  QTRY(build_jk(n, eri, dm, J, K));
+  QTRY(dcopy(n2, h, F)); QTRY(axpby(n2, 1.0, J, 1.0, F)); QTRY(axpby(n2, -0.5, K, 1.0, F));
+  QTRY(dcopy(n2, F, Fd));
+  QTRY(dev_jacobi_eigh(n, Fd, eps, C, nullptr));
+  QTRY(density_from_mos(n, o, C, dm));
+  return 0;
+}
+
+int rhf_device(int n, int o, const double* h, const double* eri, double* dm, const ScfOptions& opt, double* C, double* eps,
+               double* J_out, double* K_out, ScfResult* res) {
+  if (n <= 0 || o <= 0 || o > n) { set_error("rhf_device: bad dimensions"); return QEMB_ERR_ARG; }
+  const int64_t n2 = (int64_t)n * n;
+  DBuf Jb, Kb;
+  double* J = J_out; double* K = K_out;
+  if (!J) { QTRY(Jb.alloc(n2)); J = Jb; }
+  if (!K) { QTRY(Kb.alloc(n2)); K = Kb; }
+  QTRY(dev_timer_begin(TIMER_SCF));
+  DBuf dm_start;
+  QTRY(dm_start.alloc(n2)); QTRY(dcopy(n2, dm, dm_start));
+  QTRY(rhf_loop(n, o, h, eri, dm, opt, C, eps, J, K, res));
+  if (!res->converged) {
+    // molbe/helper.py:128-149: retry with level_shift = 0.2 and a 25-vector DIIS space
+    ScfOptions o2 = opt;
+    o2.level_shift = 0.2; o2.diis_space = 25;
+    QTRY(dcopy(n2, dm_start, dm));
+    QTRY(rhf_loop(n, o, h, eri, dm, o2, C, eps, J, K, res));
+  }
+  QTRY(dev_timer_end(TIMER_SCF));
+  return 0;
+}
+
+}  // namespace qemb

@@ -1,0 +1,187 @@
+// tensor_utils.h -- small host-side helpers shared by the drivers: RAII device buffers, tensor
+// permutation / block extraction on top of dev_copy4, GEMM shorthands, and a device-resident DIIS.
+// Plain C++ over dev_ops.h (no HIP here).
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "dev_ops.h"
+
+namespace qemb {
+
+#define QTRY(expr)              \
+  do {                          \
+    int _rc = (expr);           \
+    if (_rc != 0) return _rc;   \
+  } while (0)
+
+struct DBuf {
+  double* p = nullptr;
+  int64_t n = 0;
+  DBuf() = default;
+  DBuf(const DBuf&) = delete;
+  DBuf& operator=(const DBuf&) = delete;
+  DBuf(DBuf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+  DBuf& operator=(DBuf&& o) noexcept { if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; } return *this; }
+  ~DBuf() { release(); }
+  int alloc(int64_t nelem) {
+    release();
+    void* q = nullptr;
+    int rc = dev_alloc(&q, (size_t)(nelem > 0 ? nelem : 1) * sizeof(double));
+    if (rc) return rc;
+    p = (double*)q; n = nelem;
+    return 0;
+  }
+  void release() { if (p) { dev_free(p); p = nullptr; n = 0; } }
+  operator double*() const { return p; }
+};
+
+// y = alpha*x + beta*y over n contiguous elements
+inline int axpby(int64_t n, double alpha, const double* x, double beta, double* y) {
+  const int64_t C = 1 << 20;
+  int64_t done = 0;
+  while (done < n) {
+    const int64_t left = n - done;
+    Copy4Desc c{};
+    if (left >= C) {
+      int64_t rows = left / C;
+      if (rows > (1 << 10)) rows = 1 << 10;
+      c.dim[0] = 1; c.dim[1] = 1; c.dim[2] = rows; c.dim[3] = C;
+    } else {
+      c.dim[0] = 1; c.dim[1] = 1; c.dim[2] = 1; c.dim[3] = left;
+    }
+    c.in = x + done; c.out = y + done;
+    c.si[0] = c.si[1] = 0; c.si[2] = c.dim[3]; c.si[3] = 1;
+    c.so[0] = c.so[1] = 0; c.so[2] = c.dim[3]; c.so[3] = 1;
+    c.alpha = alpha; c.beta = beta;
+    QTRY(dev_copy4(c));
+    done += c.dim[2] * c.dim[3];
+  }
+  return 0;
+}
+inline int dcopy(int64_t n, const double* x, double* y) { return axpby(n, 1.0, x, 0.0, y); }
+
+// dst (contiguous, dims d[perm[0..3]]) = alpha * transpose(src, perm) + beta * dst;  src contiguous dims d
+inline int perm4(double* dst, const double* src, int64_t d0, int64_t d1, int64_t d2, int64_t d3, int p0, int p1, int p2,
+                 int p3, double alpha = 1.0, double beta = 0.0) {
+  const int64_t d[4] = {d0, d1, d2, d3};
+  const int perm[4] = {p0, p1, p2, p3};
+  int64_t od[4], ostr[4];
+  for (int k = 0; k < 4; ++k) od[k] = d[perm[k]];
+  ostr[3] = 1; ostr[2] = od[3]; ostr[1] = od[3] * od[2]; ostr[0] = od[3] * od[2] * od[1];
+  Copy4Desc c{};
+  c.in = src; c.out = dst; c.alpha = alpha; c.beta = beta;
+  c.si[3] = 1; c.si[2] = d[3]; c.si[1] = d[3] * d[2]; c.si[0] = d[3] * d[2] * d[1];
+  for (int k = 0; k < 4; ++k) { c.dim[k] = d[k]; }
+  for (int k = 0; k < 4; ++k) c.so[perm[k]] = ostr[k];
+  return dev_copy4(c);
+}
+
+// dst (contiguous s0 x s1 x s2 x s3) = src[o0:o0+s0, o1:o1+s1, o2:.., o3:..] of a contiguous n0 x n1 x n2 x n3 tensor
+inline int extract4(double* dst, const double* src, int64_t n1, int64_t n2, int64_t n3, int64_t o0, int64_t o1, int64_t o2,
+                    int64_t o3, int64_t s0, int64_t s1, int64_t s2, int64_t s3) {
+  Copy4Desc c{};
+  c.dim[0] = s0; c.dim[1] = s1; c.dim[2] = s2; c.dim[3] = s3;
+  c.si[3] = 1; c.si[2] = n3; c.si[1] = n3 * n2; c.si[0] = n3 * n2 * n1;
+  c.in = src + o0 * c.si[0] + o1 * c.si[1] + o2 * c.si[2] + o3;
+  c.so[3] = 1; c.so[2] = s3; c.so[1] = s3 * s2; c.so[0] = s3 * s2 * s1;
+  c.out = dst; c.alpha = 1.0; c.beta = 0.0;
+  return dev_copy4(c);
+}
+
+// C(MxN, ldc) = alpha * A * B + beta * C with explicit storage flags (see dev_ops.h GemmDesc)
+inline int gemm(int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t lda, bool a_kc, const double* B,
+                int64_t ldb, bool b_kc, double beta, double* C, int64_t ldc, int64_t batch = 1, int64_t sA = 0,
+                int64_t sB = 0, int64_t sC = 0) {
+  GemmDesc g{};
+  g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.beta = beta;
+  g.A = A; g.lda = lda; g.a_kcontig = a_kc ? 1 : 0; g.strideA = sA;
+  g.B = B; g.ldb = ldb; g.b_kcontig = b_kc ? 1 : 0; g.strideB = sB;
+  g.C = C; g.ldc = ldc; g.strideC = sC; g.batch = batch;
+  return dev_gemm(g);
+}
+// row-major conveniences: A is (M x K) or, transposed, stored (K x M); B is (K x N) or stored (N x K)
+inline int gemm_nn(int64_t M, int64_t N, int64_t K, double al, const double* A, const double* B, double be, double* C) {
+  return gemm(M, N, K, al, A, K, true, B, N, false, be, C, N);
+}
+inline int gemm_nt(int64_t M, int64_t N, int64_t K, double al, const double* A, const double* B, double be, double* C) {
+  return gemm(M, N, K, al, A, K, true, B, K, true, be, C, N);
+}
+inline int gemm_tn(int64_t M, int64_t N, int64_t K, double al, const double* A, const double* B, double be, double* C) {
+  return gemm(M, N, K, al, A, M, false, B, N, false, be, C, N);
+}
+
+// small dense solve (Gaussian elimination with partial pivoting) for the DIIS equations, host side
+inline bool solve_dense(int n, std::vector<double>& A, std::vector<double>& b) {
+  for (int k = 0; k < n; ++k) {
+    int piv = k; double best = std::fabs(A[k * n + k]);
+    for (int i = k + 1; i < n; ++i) if (std::fabs(A[i * n + k]) > best) { best = std::fabs(A[i * n + k]); piv = i; }
+    if (best < 1e-300) return false;
+    if (piv != k) { for (int j = 0; j < n; ++j) std::swap(A[k * n + j], A[piv * n + j]); std::swap(b[k], b[piv]); }
+    for (int i = k + 1; i < n; ++i) {
+      const double f = A[i * n + k] / A[k * n + k];
+      if (f == 0.0) continue;
+      for (int j = k; j < n; ++j) A[i * n + j] -= f * A[k * n + j];
+      b[i] -= f * b[k];
+    }
+  }
+  for (int k = n - 1; k >= 0; --k) {
+    double s = b[k];
+    for (int j = k + 1; j < n; ++j) s -= A[k * n + j] * b[j];
+    b[k] = s / A[k * n + k];
+  }
+  return true;
+}
+
+// Device-resident DIIS over vectors of length n.  Error vectors are supplied by the caller.
+// (CCSD: error = trial - previously returned vector, PySCF lib.diis.DIIS semantics; SCF: FD - DF.)
+class DeviceDIIS {
+ public:
+  DeviceDIIS(int space, int64_t n) : space_(space), n_(n) {}
+  int init() {
+    xs_.resize(space_); es_.resize(space_);
+    for (int i = 0; i < space_; ++i) { QTRY(xs_[i].alloc(n_)); QTRY(es_[i].alloc(n_)); }
+    QTRY(scal_.alloc(space_ + 1));
+    B_.assign((size_t)space_ * space_, 0.0);
+    return 0;
+  }
+  int size() const { return count_ < space_ ? count_ : space_; }
+  // push (x, e) and overwrite x with the extrapolated vector
+  int extrapolate(double* x, const double* e) {
+    const int slot = count_ % space_;
+    QTRY(dcopy(n_, x, xs_[slot]));
+    QTRY(dcopy(n_, e, es_[slot]));
+    ++count_;
+    const int m = size();
+    // refresh row/column `slot` of the Gram matrix
+    for (int j = 0; j < m; ++j) QTRY(dev_dot(n_, es_[slot], es_[j], scal_.p + j));
+    std::vector<double> row(m);
+    QTRY(dev_d2h(row.data(), scal_.p, sizeof(double) * m));
+    for (int j = 0; j < m; ++j) { B_[(size_t)slot * space_ + j] = row[j]; B_[(size_t)j * space_ + slot] = row[j]; }
+    if (m < 2) return 0;
+    std::vector<double> A((size_t)(m + 1) * (m + 1), 0.0), rhs(m + 1, 0.0);
+    double scale = 0.0;
+    for (int i = 0; i < m; ++i) scale = std::fmax(scale, B_[(size_t)i * space_ + i]);
+    if (scale <= 0.0) return 0;
+    for (int i = 0; i < m; ++i) {
+      for (int j = 0; j < m; ++j) A[(size_t)(i + 1) * (m + 1) + (j + 1)] = B_[(size_t)i * space_ + j] / scale;
+      A[i + 1] = 1.0; A[(size_t)(i + 1) * (m + 1)] = 1.0;
+    }
+    rhs[0] = 1.0;
+    if (!solve_dense(m + 1, A, rhs)) return 0;   // singular: keep the un-extrapolated vector
+    for (int i = 0; i < m; ++i) if (!std::isfinite(rhs[i + 1])) return 0;
+    for (int i = 0; i < m; ++i) QTRY(axpby(n_, rhs[i + 1], xs_[i], i == 0 ? 0.0 : 1.0, x));
+    return 0;
+  }
+  void reset() { count_ = 0; }
+
+ private:
+  int space_; int64_t n_; int count_ = 0;
+  std::vector<DBuf> xs_, es_;
+  DBuf scal_;
+  std::vector<double> B_;
+};
+
+}  // namespace qemb

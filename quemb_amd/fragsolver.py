@@ -1,0 +1,117 @@
+"""Python handle on one device-resident fragment (C ABI qemb_frag_* in include/qemb_hip.h).
+
+This is the object `quemb_amd.pfrag.Frags` keeps in place of the reference's HDF5 dataset name + PySCF
+objects: fragment ERIs stay in HBM between sweeps (the reference re-reads `eri_file.h5` every call --
+molbe/helper.py:182-189, :303-304) and one `solve()` is the body of be_func's loop (molbe/solver.py:301-547).
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import SolverOpts, c_vp, check
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data
+
+
+def default_opts(lib=None, **kw) -> SolverOpts:
+    lib = lib or _lib.init()
+    o = SolverOpts()
+    lib.qemb_default_opts(C.byref(o))
+    for k, v in kw.items():
+        if not hasattr(o, k):
+            raise TypeError(f"unknown solver option {k!r}")
+        setattr(o, k, v)
+    return o
+
+
+class DeviceFragment:
+    def __init__(self, n: int, n_f: int, lib=None):
+        self.lib = lib or _lib.init()
+        self.n, self.n_f = int(n), int(n_f)
+        h = c_vp()
+        check(self.lib.qemb_frag_create(self.n, self.n_f, C.byref(h)), "qemb_frag_create", self.lib)
+        self.h = h
+
+    # ---- data --------------------------------------------------------------------------------
+    def set_eri_s4(self, eri_s4: np.ndarray):
+        npair = self.n * (self.n + 1) // 2
+        a = np.ascontiguousarray(eri_s4, dtype=np.float64)
+        if a.shape != (npair, npair):
+            raise ValueError(f"fragment ERIs must be 4-fold packed ({npair},{npair}), got {a.shape}")
+        check(self.lib.qemb_frag_set_eri_s4(self.h, a.ctypes.data), "qemb_frag_set_eri_s4", self.lib)
+
+    def set_eri_s4_dev(self, dev_ptr: int):
+        check(self.lib.qemb_frag_set_eri_s4_dev(self.h, dev_ptr), "qemb_frag_set_eri_s4_dev", self.lib)
+
+    def get_eri_s4(self) -> np.ndarray:
+        npair = self.n * (self.n + 1) // 2
+        out = np.empty((npair, npair))
+        check(self.lib.qemb_frag_get_eri_s4(self.h, out.ctypes.data), "qemb_frag_get_eri_s4", self.lib)
+        return out
+
+    def set_energy_data(self, h1, veff0, veff, weight, centers):
+        h1 = np.ascontiguousarray(h1, dtype=np.float64)
+        veff0 = np.ascontiguousarray(veff0, dtype=np.float64)
+        veff = None if veff is None else np.ascontiguousarray(veff, dtype=np.float64)
+        cen = np.ascontiguousarray(centers, dtype=np.int32)
+        check(self.lib.qemb_frag_set_energy_data(self.h, h1.ctypes.data, veff0.ctypes.data, _p(veff), float(weight),
+                                                 cen.ctypes.data_as(C.POINTER(C.c_int)), len(cen)), "qemb_frag_set_energy_data", self.lib)
+
+    def jk(self, P):
+        P = np.ascontiguousarray(P, dtype=np.float64)
+        J = np.empty((self.n, self.n)); K = np.empty((self.n, self.n))
+        check(self.lib.qemb_frag_jk(self.h, P.ctypes.data, J.ctypes.data, K.ctypes.data), "qemb_frag_jk", self.lib)
+        return J, K
+
+    # ---- the sweep body -------------------------------------------------------------------------
+    def solve(self, nsocc, h, dm0=None, opts: SolverOpts | None = None, eeval=True, want_t2=False):
+        n, o = self.n, int(nsocc)
+        v = n - o
+        h = np.ascontiguousarray(h, dtype=np.float64)
+        dm0 = None if dm0 is None else np.ascontiguousarray(dm0, dtype=np.float64)
+        opts = opts or default_opts(self.lib)
+        out = dict(mo_coeff=np.empty((n, n)), mo_energy=np.empty(n), rdm1_emb=np.empty((n, n)), rdm1_mo=np.empty((n, n)),
+                   t1=np.empty((o, v)), t2=np.empty((o, o, v, v)) if want_t2 else None)
+        e_frag = np.zeros(3)
+        ecorr, escf, ebehf = C.c_double(), C.c_double(), C.c_double()
+        nit, ncyc = C.c_int(), C.c_int()
+        check(self.lib.qemb_frag_solve(self.h, o, h.ctypes.data, _p(dm0), C.byref(opts), int(bool(eeval)),
+                                       out["mo_coeff"].ctypes.data, out["mo_energy"].ctypes.data, out["rdm1_emb"].ctypes.data,
+                                       out["rdm1_mo"].ctypes.data, out["t1"].ctypes.data, _p(out["t2"]), e_frag.ctypes.data,
+                                       C.byref(ecorr), C.byref(escf), C.byref(ebehf), C.byref(nit), C.byref(ncyc)),
+              "qemb_frag_solve", self.lib)
+        out.update(e_frag=e_frag, e_corr_mo=ecorr.value, e_scf=escf.value, ebe_hf=ebehf.value, n_iter=nit.value,
+                   scf_cycles=ncyc.value)
+        return out
+
+    # ---- measurement hooks ---------------------------------------------------------------------------
+    def prepare_ccsd(self, nsocc, h, dm0=None, opts=None):
+        h = np.ascontiguousarray(h, dtype=np.float64)
+        dm0 = None if dm0 is None else np.ascontiguousarray(dm0, dtype=np.float64)
+        opts = opts or default_opts(self.lib)
+        check(self.lib.qemb_frag_prepare_ccsd(self.h, int(nsocc), h.ctypes.data, _p(dm0), C.byref(opts)), "qemb_frag_prepare_ccsd", self.lib)
+
+    def ccsd_iterate(self, niter=1):
+        e, nt = C.c_double(), C.c_double()
+        check(self.lib.qemb_frag_ccsd_iterate(self.h, int(niter), C.byref(e), C.byref(nt)), "qemb_frag_ccsd_iterate", self.lib)
+        return e.value, nt.value
+
+    def ccsd_reset(self):
+        check(self.lib.qemb_frag_ccsd_reset(self.h), "qemb_frag_ccsd_reset", self.lib)
+
+    def free(self):
+        if getattr(self, "h", None):
+            self.lib.qemb_frag_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

@@ -1,0 +1,189 @@
+// dev_ops_cpu.cpp -- TEST-ONLY scalar mock of quemb_amd/csrc/dev_ops.h.
+//
+// Purpose: let the GPU-less build container exercise the HOST LOGIC of the drivers (ccsd.cpp, scf.cpp,
+// ao2mo.cpp, schmidt.cpp, fragment.cpp: the GEMM factorisation of the CCSD equations, index permutations,
+// DIIS, convergence control) against the oracle.  "Device" memory is plain host memory here.
+// This file is linked ONLY into tests/hostcheck/libqemb_hostcheck.so by tests/hostcheck/build.py; it is never
+// part of libqemb_hip.so, never imported by quemb_amd, and proves nothing about the HIP kernels (those are
+// checked on the GPU by tests/test_gpu_*.py).
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+#include "dev_ops.h"
+
+namespace qemb {
+
+static thread_local std::string g_err;
+void set_error(const std::string& m) { g_err = m; }
+const char* last_error() { return g_err.c_str(); }
+const char* dev_backend_name() { return "hostcheck"; }
+int g_gemm_force_cfg = -1;
+
+int dev_init(int) { return 0; }
+int dev_sync() { return 0; }
+int dev_alloc(void** p, size_t bytes) { *p = std::malloc(bytes ? bytes : 16); if (!*p) { set_error("malloc failed"); return QEMB_ERR_ALLOC; } return 0; }
+int dev_free(void* p) { std::free(p); return 0; }
+int dev_h2d(void* d, const void* s, size_t b) { std::memcpy(d, s, b); return 0; }
+int dev_d2h(void* d, const void* s, size_t b) { std::memcpy(d, s, b); return 0; }
+int dev_d2d(void* d, const void* s, size_t b) { std::memmove(d, s, b); return 0; }
+int dev_fill(double* x, int64_t n, double v) { std::fill(x, x + n, v); return 0; }
+int dev_mem_info(size_t* f, size_t* t) { *f = *t = (size_t)1 << 34; return 0; }
+
+static double g_tot[TIMER_NSLOTS]; static int64_t g_cnt[TIMER_NSLOTS];
+static std::chrono::steady_clock::time_point g_t0[TIMER_NSLOTS];
+int dev_timer_begin(int s) { g_t0[s] = std::chrono::steady_clock::now(); return 0; }
+int dev_timer_end(int s) { g_tot[s] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - g_t0[s]).count(); g_cnt[s]++; return 0; }
+int dev_timer_read(int s, double* ms, int64_t* c) { if (ms) *ms = g_tot[s]; if (c) *c = g_cnt[s]; return 0; }
+int dev_timer_reset(int s) { g_tot[s] = 0; g_cnt[s] = 0; return 0; }
+
+int dev_gemm(const GemmDesc& g) {
+  for (int64_t b = 0; b < g.batch; ++b) {
+    const double* A = g.A + b * g.strideA; const double* B = g.B + b * g.strideB; double* C = g.C + b * g.strideC;
+    // pack to contiguous row-major A(MxK), B(KxN) for a cache-friendly triple loop
+    std::vector<double> a((size_t)g.M * g.K), bb((size_t)g.K * g.N);
+    for (int64_t m = 0; m < g.M; ++m) for (int64_t k = 0; k < g.K; ++k) a[m * g.K + k] = g.a_kcontig ? A[m * g.lda + k] : A[k * g.lda + m];
+    for (int64_t k = 0; k < g.K; ++k) for (int64_t n = 0; n < g.N; ++n) bb[k * g.N + n] = g.b_kcontig ? B[n * g.ldb + k] : B[k * g.ldb + n];
+    std::vector<double> row((size_t)g.N);
+    for (int64_t m = 0; m < g.M; ++m) {
+      std::fill(row.begin(), row.end(), 0.0);
+      for (int64_t k = 0; k < g.K; ++k) { const double x = a[m * g.K + k]; const double* br = &bb[k * g.N]; for (int64_t n = 0; n < g.N; ++n) row[n] += x * br[n]; }
+      for (int64_t n = 0; n < g.N; ++n) { double* c = C + m * g.ldc + n; *c = (g.beta != 0.0) ? g.alpha * row[n] + g.beta * (*c) : g.alpha * row[n]; }
+    }
+  }
+  return 0;
+}
+
+int dev_copy4(const Copy4Desc& c) {
+  for (int64_t i0 = 0; i0 < c.dim[0]; ++i0) for (int64_t i1 = 0; i1 < c.dim[1]; ++i1) for (int64_t i2 = 0; i2 < c.dim[2]; ++i2) for (int64_t i3 = 0; i3 < c.dim[3]; ++i3) {
+    const double v = c.alpha * c.in[i0 * c.si[0] + i1 * c.si[1] + i2 * c.si[2] + i3 * c.si[3]];
+    double* p = c.out + i0 * c.so[0] + i1 * c.so[1] + i2 * c.so[2] + i3 * c.so[3];
+    *p = (c.beta != 0.0) ? v + c.beta * (*p) : v;
+  }
+  return 0;
+}
+int dev_outer4(const Outer4Desc& c) {
+  for (int64_t i0 = 0; i0 < c.dim[0]; ++i0) for (int64_t i1 = 0; i1 < c.dim[1]; ++i1) for (int64_t i2 = 0; i2 < c.dim[2]; ++i2) for (int64_t i3 = 0; i3 < c.dim[3]; ++i3) {
+    const double v = c.alpha * c.u[i0 * c.su0 + i2 * c.su2] * c.v[i1 * c.sv1 + i3 * c.sv3];
+    double* p = c.out + i0 * c.so[0] + i1 * c.so[1] + i2 * c.so[2] + i3 * c.so[3];
+    *p = (c.beta != 0.0) ? v + c.beta * (*p) : v;
+  }
+  return 0;
+}
+int dev_div_denom(double* x, int64_t d0, int64_t d1, int64_t d2, int64_t d3, const double* ea, const double* eb, const double* ec, const double* ed) {
+  for (int64_t i0 = 0; i0 < d0; ++i0) for (int64_t i1 = 0; i1 < d1; ++i1) for (int64_t i2 = 0; i2 < d2; ++i2) for (int64_t i3 = 0; i3 < d3; ++i3)
+    x[((i0 * d1 + i1) * d2 + i2) * d3 + i3] /= (ea[i0] + (eb ? eb[i1] : 0.0) - ec[i2] - (ed ? ed[i3] : 0.0));
+  return 0;
+}
+int dev_dot(int64_t n, const double* x, const double* y, double* o) { long double s = 0; for (int64_t i = 0; i < n; ++i) s += (long double)x[i] * y[i]; *o = (double)s; return 0; }
+int dev_absmax(int64_t n, const double* x, double* o) { double m = 0; for (int64_t i = 0; i < n; ++i) m = std::max(m, std::fabs(x[i])); *o = m; return 0; }
+int dev_gemv_rows(int64_t rows, int64_t cols, const double* T, int64_t ldt, const double* x, double* y, double alpha, double beta) {
+  for (int64_t r = 0; r < rows; ++r) { double s = 0; for (int64_t c = 0; c < cols; ++c) s += T[r * ldt + c] * x[c]; y[r] = (beta != 0.0) ? alpha * s + beta * y[r] : alpha * s; }
+  return 0;
+}
+int dev_contract_mid(int64_t outer, int64_t mid, int64_t inner, const double* T, const double* x, double* Y, int64_t ldy, double alpha, double beta) {
+  std::vector<double> acc((size_t)inner);
+  for (int64_t p = 0; p < outer; ++p) {
+    std::fill(acc.begin(), acc.end(), 0.0);
+    for (int64_t m = 0; m < mid; ++m) { const double xm = x[m]; const double* t = T + (p * mid + m) * inner; for (int64_t r = 0; r < inner; ++r) acc[r] += xm * t[r]; }
+    for (int64_t r = 0; r < inner; ++r) { double* y = Y + p * ldy + r; *y = (beta != 0.0) ? alpha * acc[r] + beta * (*y) : alpha * acc[r]; }
+  }
+  return 0;
+}
+static inline int64_t pidx(int64_t i, int64_t j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
+int dev_unpack_s4(int64_t n, const double* s4, double* s1) {
+  const int64_t np = n * (n + 1) / 2;
+  for (int64_t i = 0; i < n; ++i) for (int64_t j = 0; j < n; ++j) for (int64_t k = 0; k < n; ++k) for (int64_t l = 0; l < n; ++l)
+    s1[((i * n + j) * n + k) * n + l] = s4[pidx(i, j) * np + pidx(k, l)];
+  return 0;
+}
+int dev_pack_s4(int64_t n, const double* s1, double* s4) {
+  const int64_t np = n * (n + 1) / 2;
+  for (int64_t i = 0; i < n; ++i) for (int64_t j = 0; j <= i; ++j) for (int64_t k = 0; k < n; ++k) for (int64_t l = 0; l <= k; ++l)
+    s4[pidx(i, j) * np + pidx(k, l)] = s1[((i * n + j) * n + k) * n + l];
+  return 0;
+}
+int dev_unpack_s8_to_s4(int64_t n, const double* s8, double* s4) {
+  const int64_t np = n * (n + 1) / 2;
+  for (int64_t r = 0; r < np; ++r) for (int64_t c = 0; c < np; ++c) s4[r * np + c] = s8[pidx(r, c)];
+  return 0;
+}
+int dev_unpack_tril_rows(int64_t rows, int64_t n, const double* p, double* f) {
+  const int64_t np = n * (n + 1) / 2;
+  for (int64_t r = 0; r < rows; ++r) for (int64_t k = 0; k < n; ++k) for (int64_t l = 0; l < n; ++l) f[(r * n + k) * n + l] = p[r * np + pidx(k, l)];
+  return 0;
+}
+int dev_pack_tril_rows(int64_t rows, int64_t n, const double* f, double* p) {
+  const int64_t np = n * (n + 1) / 2;
+  for (int64_t r = 0; r < rows; ++r) for (int64_t k = 0; k < n; ++k) for (int64_t l = 0; l <= k; ++l) p[r * np + pidx(k, l)] = f[(r * n + k) * n + l];
+  return 0;
+}
+
+// cyclic two-sided Jacobi (independent of the product's one-sided formulation)
+int dev_jacobi_eigh(int64_t n64, double* A, double* w, double* V, int* sweeps_out) {
+  const int n = (int)n64;
+  std::vector<double> a(A, A + (size_t)n * n), v((size_t)n * n, 0.0);
+  for (int i = 0; i < n; ++i) v[(size_t)i * n + i] = 1.0;
+  int sweep = 0;
+  for (; sweep < 60; ++sweep) {
+    double off = 0, diag = 0;
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) (i == j ? diag : off) += a[(size_t)i * n + j] * a[(size_t)i * n + j];
+    if (off <= 1e-30 * std::max(diag, 1e-300)) break;
+    for (int p = 0; p < n; ++p) for (int q = p + 1; q < n; ++q) {
+      const double apq = a[(size_t)p * n + q];
+      if (std::fabs(apq) < 1e-300) continue;
+      const double th = (a[(size_t)q * n + q] - a[(size_t)p * n + p]) / (2 * apq);
+      const double t = (th >= 0 ? 1.0 : -1.0) / (std::fabs(th) + std::sqrt(1 + th * th));
+      const double c = 1 / std::sqrt(1 + t * t), s = c * t;
+      for (int k = 0; k < n; ++k) { const double x = a[(size_t)k * n + p], y = a[(size_t)k * n + q]; a[(size_t)k * n + p] = c * x - s * y; a[(size_t)k * n + q] = s * x + c * y; }
+      for (int k = 0; k < n; ++k) { const double x = a[(size_t)p * n + k], y = a[(size_t)q * n + k]; a[(size_t)p * n + k] = c * x - s * y; a[(size_t)q * n + k] = s * x + c * y; }
+      for (int k = 0; k < n; ++k) { const double x = v[(size_t)k * n + p], y = v[(size_t)k * n + q]; v[(size_t)k * n + p] = c * x - s * y; v[(size_t)k * n + q] = s * x + c * y; }
+    }
+  }
+  std::vector<int> perm(n); std::iota(perm.begin(), perm.end(), 0);
+  std::stable_sort(perm.begin(), perm.end(), [&](int x, int y) { return a[(size_t)x * n + x] < a[(size_t)y * n + y]; });
+  for (int i = 0; i < n; ++i) { w[i] = a[(size_t)perm[i] * n + perm[i]]; for (int k = 0; k < n; ++k) V[(size_t)k * n + i] = v[(size_t)k * n + perm[i]]; }
+  if (sweeps_out) *sweeps_out = sweep;
+  return 0;
+}
+int dev_jacobi_svd(int64_t m64, int64_t n64, double* G, double* s, double* U, double* V, int* sweeps_out) {
+  // via eigh of G^T G (adequate for a mock; the product does a genuine one-sided Jacobi)
+  const int m = (int)m64, n = (int)n64;
+  std::vector<double> gtg((size_t)n * n, 0.0), w(n), vv((size_t)n * n);
+  for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) { double t = 0; for (int k = 0; k < m; ++k) t += G[(size_t)k * n + i] * G[(size_t)k * n + j]; gtg[(size_t)i * n + j] = t; }
+  dev_jacobi_eigh(n, gtg.data(), w.data(), vv.data(), sweeps_out);
+  for (int i = 0; i < n; ++i) {           // descending
+    const int src = n - 1 - i;
+    s[i] = std::sqrt(std::max(w[src], 0.0));
+    for (int k = 0; k < n; ++k) if (V) V[(size_t)k * n + i] = vv[(size_t)k * n + src];
+    for (int k = 0; k < m; ++k) { double t = 0; for (int j = 0; j < n; ++j) t += G[(size_t)k * n + j] * vv[(size_t)j * n + src]; if (U) U[(size_t)k * n + i] = (s[i] > 1e-150) ? t / s[i] : 0.0; }
+  }
+  return 0;
+}
+int dev_cholesky_lower(int64_t n64, double* A) {
+  const int n = (int)n64;
+  for (int j = 0; j < n; ++j) {
+    double d = A[(size_t)j * n + j];
+    for (int k = 0; k < j; ++k) d -= A[(size_t)j * n + k] * A[(size_t)j * n + k];
+    if (!(d > 0)) { set_error("Cholesky: matrix is not positive definite"); return QEMB_ERR_NUMERIC; }
+    A[(size_t)j * n + j] = std::sqrt(d);
+    for (int i = j + 1; i < n; ++i) { double t = A[(size_t)i * n + j]; for (int k = 0; k < j; ++k) t -= A[(size_t)i * n + k] * A[(size_t)j * n + k]; A[(size_t)i * n + j] = t / A[(size_t)j * n + j]; }
+    for (int k = j + 1; k < n; ++k) A[(size_t)j * n + k] = 0.0;
+  }
+  return 0;
+}
+int dev_tri_inverse_lower(int64_t n64, const double* L, double* X) {
+  const int n = (int)n64;
+  std::fill(X, X + (size_t)n * n, 0.0);
+  for (int j = 0; j < n; ++j) {
+    X[(size_t)j * n + j] = 1.0 / L[(size_t)j * n + j];
+    for (int i = j + 1; i < n; ++i) { double t = 0; for (int k = j; k < i; ++k) t += L[(size_t)i * n + k] * X[(size_t)k * n + j]; X[(size_t)i * n + j] = -t / L[(size_t)i * n + i]; }
+  }
+  return 0;
+}
+
+}  // namespace qemb

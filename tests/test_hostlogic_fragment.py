@@ -1,0 +1,113 @@
+"""CPU: HOST LOGIC of the drivers (GEMM factorisation of RCCSD, MO transform, SCF loop, energy contraction)
+against the oracle, by linking the product's driver sources to the scalar mock device layer
+(tests/hostcheck).  The HIP kernels themselves are covered by the -m gpu tests."""
+import ctypes as C
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from helpers import synthetic_fragment
+from qemb_oracle import be, ccsd, eri, rdm, scf
+
+sys.path.insert(0, str(Path(__file__).resolve().parent / "hostcheck"))
+
+
+@pytest.fixture(scope="module")
+def hlib():
+    import build as hc_build
+    from quemb_amd import _lib
+    lib = _lib.declare(C.CDLL(str(hc_build.build())))
+    assert lib.qemb_backend() == b"hostcheck"
+    return lib
+
+
+def _problem(n, o, nf, seed):
+    h, e1 = synthetic_fragment(n, o, seed)
+    rng = np.random.default_rng(seed + 1)
+    h1 = rng.standard_normal((n, n)); h1 = h1 + h1.T
+    veff0 = rng.standard_normal((n, n)); veff0 = veff0 + veff0.T
+    veff = rng.standard_normal((n, n)); veff = veff + veff.T
+    return h, e1, h1, veff0, veff
+
+
+@pytest.mark.parametrize("n,o,nf,cen", [(6, 2, 3, [0, 1]), (8, 3, 3, [1]), (7, 4, 2, [0])])
+def test_fragment_solve_matches_oracle(hlib, n, o, nf, cen):
+    from quemb_amd.fragsolver import DeviceFragment, default_opts
+    h, e1, h1, veff0, veff = _problem(n, o, nf, 40 + n)
+    s4 = eri.pack_s4(e1)
+    fr = DeviceFragment(n, nf, lib=hlib)
+    fr.set_eri_s4(s4)
+    fr.set_energy_data(h1, veff0, veff, 0.75, cen)
+    opts = default_opts(hlib, cc_conv_tol=1e-13, cc_conv_tol_normt=1e-11, scf_conv_tol=1e-13, scf_conv_tol_grad=1e-9)
+    out = fr.solve(o, h, opts=opts, eeval=True, want_t2=True)
+    # oracle
+    mf = scf.rhf(h, e1, o, conv_tol=1e-13, conv_tol_grad=1e-9)
+    t1, t2, ecc, nit = ccsd.solve_ccsd(h, e1, o, mf["mo_coeff"], mf["mo_energy"], conv_tol=1e-13, conv_tol_normt=1e-11)
+    assert abs(out["e_scf"] - mf["e_tot"]) < 1e-10
+    assert np.abs(out["mo_energy"] - mf["mo_energy"]).max() < 1e-8
+    assert abs(out["e_corr_mo"] - ecc) < 1e-10, (out["e_corr_mo"], ecc)
+    r1 = rdm.make_rdm1_ccsd_t1(t1)
+    rdm_emb = mf["mo_coeff"] @ r1 @ mf["mo_coeff"].T * 0.5
+    assert np.abs(out["rdm1_emb"] - rdm_emb).max() < 1e-8
+    r2 = rdm.make_rdm2_urlx(t1, t2, with_dm1=False)
+    TA = np.zeros((n + 2, n))
+    e_ref = be.get_frag_energy(mf["mo_coeff"], o, nf, (0.75, cen), TA, h1, r1, r2, s4, veff0, None, True)
+    assert np.allclose(out["e_frag"], e_ref, atol=1e-9), (out["e_frag"], e_ref)
+    # HF fragment energy (update_ebe_hf) with the same orbitals
+    f = be.Frag(list(range(nf)), 0, [], [], [], [], (0.75, cen))
+    f.h1, f.veff, f.TA, f._mo_coeffs, f.nsocc, f.eri_s4 = h1, veff, TA, mf["mo_coeff"], o, s4
+    assert abs(out["ebe_hf"] - be.update_ebe_hf(f)) < 1e-9
+    # amplitudes up to the MO phase convention: compare through phase-invariant contractions
+    C_g, C_o = out["mo_coeff"], mf["mo_coeff"]
+    t1_emb_g = C_g[:, :o] @ out["t1"] @ C_g[:, o:].T
+    t1_emb_o = C_o[:, :o] @ t1 @ C_o[:, o:].T
+    assert np.abs(t1_emb_g - t1_emb_o).max() < 1e-8
+    # J/K entry point
+    P = np.random.default_rng(1).standard_normal((n, n)); P = P + P.T
+    J, K = fr.jk(P)
+    Jr, Kr = scf.get_jk(e1, P)
+    assert np.abs(J - Jr).max() < 1e-11 and np.abs(K - Kr).max() < 1e-11
+
+
+def test_single_update_amps_matches_oracle(hlib):
+    """One un-extrapolated amplitude update from the MP2 guess, then DIIS-free convergence to the same energy."""
+    from quemb_amd.fragsolver import DeviceFragment, default_opts
+    n, o, nf = 7, 3, 2
+    h, e1, *_ = _problem(n, o, nf, 99)
+    fr = DeviceFragment(n, nf, lib=hlib)
+    fr.set_eri_s4(eri.pack_s4(e1))
+    opts = default_opts(hlib, scf_conv_tol=1e-13, scf_conv_tol_grad=1e-9)
+    fr.prepare_ccsd(o, h, opts=opts)
+    mf = scf.rhf(h, e1, o, conv_tol=1e-13, conv_tol_grad=1e-9)
+    eris = ccsd.Eris(e1, mf["mo_coeff"], o, mo_energy=mf["mo_energy"])
+    t1, t2 = ccsd.init_amps(eris)
+    for it in range(3):   # first iterations carry no DIIS extrapolation difference only at it == 0
+        e_g, nt_g = fr.ccsd_iterate(1)
+        t1n, t2n = ccsd.update_amps(t1, t2, eris)
+        if it == 0:
+            e_o = ccsd.energy(t1n, t2n, eris)
+            nt_o = np.sqrt(np.linalg.norm(t1n - t1) ** 2 + np.linalg.norm(t2n - t2) ** 2)
+            assert abs(e_g - e_o) < 1e-12 and abs(nt_g - nt_o) < 1e-12
+        t1, t2 = t1n, t2n
+
+
+def test_warm_start_and_errors(hlib):
+    from quemb_amd._lib import QembError
+    from quemb_amd.fragsolver import DeviceFragment, default_opts
+    n, o, nf = 6, 2, 2
+    h, e1, h1, veff0, veff = _problem(n, o, nf, 5)
+    fr = DeviceFragment(n, nf, lib=hlib)
+    with pytest.raises(QembError):
+        fr.solve(o, h)                       # ERIs not set
+    fr.set_eri_s4(eri.pack_s4(e1))
+    with pytest.raises(QembError):
+        fr.solve(o, h, eeval=True)           # energy data not set
+    with pytest.raises(ValueError):
+        fr.set_eri_s4(np.zeros((3, 3)))
+    a = fr.solve(o, h, eeval=False)
+    b = fr.solve(o, h, opts=default_opts(hlib, warm_start=1), eeval=False)
+    assert abs(a["e_corr_mo"] - b["e_corr_mo"]) < 1e-9 and b["n_iter"] <= 3
+    with pytest.raises(QembError):
+        fr.solve(o, h, opts=default_opts(hlib, cc_max_cycle=1), eeval=False)   # non-convergence is an error
