@@ -1,0 +1,60 @@
+"""Time one synthetic fragment (SURVEY 8d family) through the device pipeline; print per-phase device times."""
+import ctypes as C
+import json
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, ".")
+from quemb_amd import _lib
+from quemb_amd._lib import DeviceBuffer, check
+from quemb_amd.fragsolver import DeviceFragment, default_opts
+
+
+def synthetic_on_device(lib, n, seed, naux=None, scale=0.06, gap=2.0):
+    """h (host) and the s4-packed ERIs built ON THE DEVICE from the DF factor (B^T B over packed pairs)."""
+    rng = np.random.default_rng(seed)
+    naux = naux or 3 * n
+    B = scale * rng.standard_normal((naux, n, n))
+    B = 0.5 * (B + B.transpose(0, 2, 1))
+    il = np.tril_indices(n)
+    Bp = np.ascontiguousarray(B[:, il[0], il[1]])          # (naux, npair)
+    npair = Bp.shape[1]
+    dB = DeviceBuffer.from_numpy(Bp)
+    d4 = DeviceBuffer(npair * npair)
+    check(lib.qemb_op_gemm(npair, npair, naux, 1.0, dB.ptr, npair, 0, 0, dB.ptr, npair, 0, 0, 0.0, d4.ptr, npair, 0, 1))
+    A = rng.standard_normal((n, n))
+    h = np.diag(gap * np.arange(n)) + 0.3 * 0.5 * (A + A.T)
+    return h, d4
+
+
+def timers(lib):
+    out = {}
+    for name, slot in dict(ladder=0, rings=1, iter=2, ao2mo=3, scf=4).items():
+        ms = C.c_double(); cnt = C.c_int64()
+        lib.qemb_timer_read(slot, C.byref(ms), C.byref(cnt))
+        out[name] = dict(ms=ms.value, count=cnt.value)
+    return out
+
+
+if __name__ == "__main__":
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 220
+    o = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+    lib = _lib.init(0)
+    t0 = time.time()
+    h, d4 = synthetic_on_device(lib, n, 20260803)
+    fr = DeviceFragment(n, min(22, n // 2))
+    fr.set_eri_s4_dev(d4.ptr); d4.free()
+    lib.qemb_sync(); print("setup s", time.time() - t0, flush=True)
+    for s in range(8): lib.qemb_timer_reset(s)
+    t0 = time.time()
+    out = fr.solve(o, h, opts=default_opts(verbose=int(len(sys.argv) > 3)), eeval=False)
+    lib.qemb_sync(); wall = time.time() - t0
+    v = n - o
+    tm = timers(lib)
+    lad = tm["ladder"]["ms"] / max(tm["ladder"]["count"], 1)
+    res = dict(n=n, o=o, wall_s=wall, n_iter=out["n_iter"], scf_cycles=out["scf_cycles"], e_corr=out["e_corr_mo"], timers=tm,
+               ladder_ms=lad, ladder_tflops=2.0 * o * o * v ** 4 / (lad * 1e-3) / 1e12 if lad else None,
+               iter_ms=tm["iter"]["ms"] / max(tm["iter"]["count"], 1))
+    print(json.dumps(res), flush=True)
