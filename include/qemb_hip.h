@@ -128,6 +128,15 @@ int qemb_frag_solve(qemb_frag_t f, int nsocc, const double* h, const double* dm0
                     int eeval, double* mo_coeff, double* mo_energy, double* rdm1_emb, double* rdm1_mo, double* t1,
                     double* t2, double* e_frag, double* e_corr_mo, double* e_scf, double* ebe_hf, int* n_iter,
                     int* scf_cycles);
+/* fragment RHF only: get_scfObj(fock + heff, eri, nocc, dm0) of molbe/helper.py:73-151 as used by
+ * Frags.scf(fs=True) at initialisation (mbe.py:1160).  J, K: of the converged density (nullable).        */
+int qemb_frag_scf(qemb_frag_t f, int nsocc, const double* h, const double* dm0, const qemb_solver_opts* opts,
+                  double* mo_coeff, double* mo_energy, double* J, double* K, double* e_scf, int* converged, int* cycles);
+/* CPHF density response to npot one-body perturbations (npot x n x n) -> dPs (npot x n x n): the work inside
+ * hfres_func / cphf_kernel_batch (shared/external/optqn.py:456-466, cphf_utils.py:55-81) that builds the
+ * initial Jacobian of the quasi-Newton density matching.                                                 */
+int qemb_frag_cphf(qemb_frag_t f, int nsocc, const double* h, const double* dm0, const qemb_solver_opts* opts,
+                   const double* vpots, int npot, double* dPs);
 /* stateless one-call form (host buffers in, host buffers out) */
 int qemb_ccsd_solve(int n, int nsocc, int n_f, const double* h, const double* eri_s4, const double* dm0,
                     const qemb_solver_opts* opts, const double* h1, const double* veff0, double weight,
@@ -137,6 +146,44 @@ int qemb_ccsd_solve(int n, int nsocc, int n_f, const double* h, const double* er
 int qemb_frag_prepare_ccsd(qemb_frag_t f, int nsocc, const double* h, const double* dm0, const qemb_solver_opts* opts);
 int qemb_frag_ccsd_iterate(qemb_frag_t f, int niter, double* e_corr, double* normt);
 int qemb_frag_ccsd_reset(qemb_frag_t f);
+
+/* ---------------------------------------------------------------- AO -> fragment ERI transforms -- */
+/* Dense: replaces `ao2mo.incore.full(eri_, TA, compact=True)` of BE._eri_transform "in-core"
+ * (molbe/mbe.py:1035-1039).  The AO tensor is uploaded once per system and stays resident.            */
+typedef void* qemb_aoeri_t;
+int qemb_aoeri_upload(int N, const double* eri, int sym /* 8, 4 or 1 */, qemb_aoeri_t* out);
+int qemb_aoeri_free(qemb_aoeri_t ao);
+/* TA: N x n (host).  Result 4-fold packed (npair(n) x npair(n)) to out_s4_host (nullable) and/or
+ * straight into a fragment handle (nullable) -- the HDF5 dataset "f{I}" hand-off without the disk.     */
+int qemb_ao2mo_dense(qemb_aoeri_t ao, const double* TA, int n, double* out_s4_host, qemb_frag_t frag);
+
+/* Density fitted: replaces integral_direct_DF (molbe/eri_onthefly.py:45-145, "int-direct-DF") and the
+ * transform_integral / transform_integral_cuda pair injected into _run_sparse_df_driver
+ * (molbe/eri_sparse_DF.py:535-556, :677-678, :701-702; C++ _cpp/eri_sparse_DF.cpp:724-751).
+ * qemb_df_create factors (P|Q) on the device (eri_onthefly.py:108); qemb_lpq_upload takes an existing
+ * lower Cholesky factor instead (the `build_lowtri_PQ` seam / GPU_MatrixHandle, eri_sparse_DF.cpp:64-107). */
+typedef void* qemb_df_t;
+int qemb_df_create(int naux, const double* j2c, qemb_df_t* out);
+int qemb_lpq_upload(const double* L_PQ, int naux, qemb_df_t* out);
+int qemb_df_free(qemb_df_t df);
+/* 3-index integrals: layout 0 = (N,N,naux) "pqL" as getints3c returns them (eri_onthefly.py:85),
+ * 1 = (naux,N,N), 2 = (naux, npair(N)) unique pairs mu >= nu (SemiSparseSym3DTensor without screening) */
+int qemb_df_set_ints(qemb_df_t df, int N, const double* ints, int layout);
+int qemb_df_transform(qemb_df_t df, const double* TA, int n, double* out_s4_host, qemb_frag_t frag);
+
+/* ---------------------------------------------------------------- Schmidt decomposition ---------- */
+/* schmidt_decomposition(mo_coeff, nocc, AO_in_frag, thr_bath) -> (TA_lo_eo, n_f, n_b), molbe/pfrag.py:403-411.
+ * lmo: N x nmo row-major; TA_lo_eo: caller buffer N x ld (ld >= n_f + n_b; 2*n_f always suffices).      */
+int qemb_schmidt(const double* lmo, int N, int nmo, int nocc, const int64_t* frag_idx, int n_f, double thr,
+                 double* TA_lo_eo, int ld, int* n_b, int* sweeps);
+/* schmidt_decomp_svd(rdm, Frag_sites, thr_bath) -> TA, kbe/solver.py:9 (real part)                     */
+int qemb_schmidt_svd(const double* rdm, int N, const int64_t* frag_idx, int n_f, double thr, double* TA, int ld,
+                     int* n_b, int* sweeps);
+/* Frags.get_nsocc (molbe/pfrag.py:208-239): Cproj = TA^T S C_occ (n x nocc) -> P (n x n, nullable),
+ * nsocc, initial fragment MOs (n x n)                                                                  */
+int qemb_nsocc_guess(const double* Cproj, int n, int nocc, double* P, int* nsocc, double* mo_coeffs);
+/* plain host-in/host-out matrix product on the device: C(MxN) = op(A) op(B) (convenience for TA = W @ TA_lo_eo) */
+int qemb_matmul(int64_t M, int64_t N, int64_t K, const double* A, int transA, const double* B, int transB, double* C);
 
 #ifdef __cplusplus
 }

@@ -88,10 +88,26 @@ def _declare(lib):
     f("qemb_frag_set_energy_data", I, V, P, P, P, D, IP, I)
     f("qemb_frag_jk", I, V, P, P, P)
     f("qemb_frag_solve", I, V, I, P, P, OP, I, P, P, P, P, P, P, P, DP, DP, DP, IP, IP)
+    f("qemb_frag_scf", I, V, I, P, P, OP, P, P, P, P, DP, IP, IP)
+    f("qemb_frag_cphf", I, V, I, P, P, OP, P, I, P)
     f("qemb_ccsd_solve", I, I, I, I, P, P, P, OP, P, P, D, IP, I, P, P, P, P, P, P, DP, IP)
     f("qemb_frag_prepare_ccsd", I, V, I, P, P, OP)
     f("qemb_frag_ccsd_iterate", I, V, I, DP, DP)
     f("qemb_frag_ccsd_reset", I, V)
+    # ---- ERI transforms / Schmidt
+    LP = C.POINTER(L)
+    f("qemb_aoeri_upload", I, I, P, I, C.POINTER(c_vp))
+    f("qemb_aoeri_free", I, V)
+    f("qemb_ao2mo_dense", I, V, P, I, P, V)
+    f("qemb_df_create", I, I, P, C.POINTER(c_vp))
+    f("qemb_lpq_upload", I, P, I, C.POINTER(c_vp))
+    f("qemb_df_free", I, V)
+    f("qemb_df_set_ints", I, V, I, P, I)
+    f("qemb_df_transform", I, V, P, I, P, V)
+    f("qemb_schmidt", I, P, I, I, I, LP, I, D, P, I, IP, IP)
+    f("qemb_schmidt_svd", I, P, I, LP, I, D, P, I, IP, IP)
+    f("qemb_nsocc_guess", I, P, I, I, P, IP, P)
+    f("qemb_matmul", I, L, L, L, P, I, P, I, P)
     return lib
 
 

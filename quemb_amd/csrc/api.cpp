@@ -5,9 +5,17 @@
 #include "../../include/qemb_hip.h"
 #include "dev_ops.h"
 #include "fragment.h"
+#include "ao2mo.h"
 
 using namespace qemb;
-namespace qemb { extern int g_gemm_force_cfg; }
+namespace qemb {
+extern int g_gemm_force_cfg;
+int schmidt_eigh(const double* lmo, int N, int nmo, int nocc, const int64_t* frag, int n_f, double thr, double* TA_out,
+                 int ld_out, int* n_b_out, int* sweeps_out);
+int schmidt_svd(const double* rdm, int N, const int64_t* frag_in, int n_f, double thr, double* TA_out, int ld_out, int* n_b_out,
+                int* sweeps_out);
+int nsocc_guess(const double* Cproj, int n, int nocc, double* P_out, int* nsocc, double* mo_out);
+}
 
 extern "C" {
 
@@ -124,6 +132,24 @@ int qemb_frag_solve(qemb_frag_t f, int nsocc, const double* h, const double* dm0
   if (ebe_hf) *ebe_hf = r.ebe_hf;
   return QEMB_OK;
 }
+int qemb_frag_scf(qemb_frag_t f, int nsocc, const double* h, const double* dm0, const qemb_solver_opts* opts, double* mo_coeff,
+                  double* mo_energy, double* J, double* K, double* e_scf, int* converged, int* cycles) {
+  CHECK_FRAG(f);
+  if (!h) { set_error("qemb_frag_scf: h is NULL"); return QEMB_ERR_ARG; }
+  ScfResult r;
+  int rc = FRAG(f)->scf_only(nsocc, h, dm0, to_opts(opts).scf, mo_coeff, mo_energy, J, K, &r);
+  if (rc) return rc;
+  if (e_scf) *e_scf = r.e_tot;
+  if (converged) *converged = r.converged ? 1 : 0;
+  if (cycles) *cycles = r.cycles;
+  return QEMB_OK;
+}
+int qemb_frag_cphf(qemb_frag_t f, int nsocc, const double* h, const double* dm0, const qemb_solver_opts* opts, const double* vpots,
+                   int npot, double* dPs) {
+  CHECK_FRAG(f);
+  if (!h || !vpots || !dPs) { set_error("qemb_frag_cphf: null argument"); return QEMB_ERR_ARG; }
+  return FRAG(f)->cphf_response(nsocc, h, dm0, to_opts(opts).scf, vpots, npot, dPs);
+}
 int qemb_ccsd_solve(int n, int nsocc, int n_f, const double* h, const double* eri_s4, const double* dm0,
                     const qemb_solver_opts* opts, const double* h1, const double* veff0, double weight, const int* centers,
                     int ncenter, double* mo_coeff, double* mo_energy, double* t1, double* t2, double* rdm1_emb, double* e_frag,
@@ -147,5 +173,99 @@ int qemb_frag_prepare_ccsd(qemb_frag_t f, int nsocc, const double* h, const doub
 }
 int qemb_frag_ccsd_iterate(qemb_frag_t f, int niter, double* e, double* nt) { CHECK_FRAG(f); return FRAG(f)->ccsd_iterate(niter, e, nt); }
 int qemb_frag_ccsd_reset(qemb_frag_t f) { CHECK_FRAG(f); return FRAG(f)->ccsd_reset(); }
+
+// ---------------------------------------------------------------- ERI transforms ------------------
+static int deliver_s4(const DBuf& s4, int n, double* out_host, qemb_frag_t frag) {
+  const int64_t np = (int64_t)n * (n + 1) / 2;
+  if (out_host) { int rc = dev_d2h(out_host, s4, sizeof(double) * np * np); if (rc) return rc; }
+  if (frag) {
+    if (FRAG(frag)->n() != n) { set_error("fragment handle has a different n"); return QEMB_ERR_ARG; }
+    return FRAG(frag)->set_eri_s4_dev(s4);
+  }
+  return QEMB_OK;
+}
+int qemb_aoeri_upload(int N, const double* eri, int sym, qemb_aoeri_t* out) {
+  if (N <= 0 || !eri || !out) { set_error("qemb_aoeri_upload: bad arguments"); return QEMB_ERR_ARG; }
+  AoEri* a = new AoEri();
+  int rc = a->upload(N, eri, sym);
+  if (rc) { delete a; return rc; }
+  *out = a;
+  return QEMB_OK;
+}
+int qemb_aoeri_free(qemb_aoeri_t ao) { delete reinterpret_cast<AoEri*>(ao); return QEMB_OK; }
+int qemb_ao2mo_dense(qemb_aoeri_t ao, const double* TA, int n, double* out_s4_host, qemb_frag_t frag) {
+  if (!ao || !TA) { set_error("qemb_ao2mo_dense: null argument"); return QEMB_ERR_ARG; }
+  AoEri* a = reinterpret_cast<AoEri*>(ao);
+  DBuf dTA, s4;
+  int rc;
+  if ((rc = dTA.alloc((int64_t)a->N * n))) return rc;
+  if ((rc = dev_h2d(dTA, TA, sizeof(double) * a->N * n))) return rc;
+  if ((rc = s4.alloc(((int64_t)n * (n + 1) / 2) * ((int64_t)n * (n + 1) / 2)))) return rc;
+  if ((rc = ao2mo_dense(*a, dTA, n, s4))) return rc;
+  return deliver_s4(s4, n, out_s4_host, frag);
+}
+int qemb_df_create(int naux, const double* j2c, qemb_df_t* out) {
+  if (naux <= 0 || !j2c || !out) { set_error("qemb_df_create: bad arguments"); return QEMB_ERR_ARG; }
+  DfContext* d = new DfContext();
+  int rc = d->set_metric(naux, j2c);
+  if (rc) { delete d; return rc; }
+  *out = d;
+  return QEMB_OK;
+}
+int qemb_lpq_upload(const double* L, int naux, qemb_df_t* out) {
+  if (naux <= 0 || !L || !out) { set_error("qemb_lpq_upload: bad arguments"); return QEMB_ERR_ARG; }
+  DfContext* d = new DfContext();
+  int rc = d->set_cholesky_factor(naux, L);
+  if (rc) { delete d; return rc; }
+  *out = d;
+  return QEMB_OK;
+}
+int qemb_df_free(qemb_df_t df) { delete reinterpret_cast<DfContext*>(df); return QEMB_OK; }
+int qemb_df_set_ints(qemb_df_t df, int N, const double* ints, int layout) {
+  if (!df || !ints || N <= 0) { set_error("qemb_df_set_ints: bad arguments"); return QEMB_ERR_ARG; }
+  DfContext* d = reinterpret_cast<DfContext*>(df);
+  if (layout == 0) return d->set_ints_pqL(N, ints);
+  if (layout == 1) return d->set_ints_Lpq(N, ints);
+  if (layout == 2) return d->set_ints_packed(N, ints);
+  set_error("qemb_df_set_ints: layout must be 0, 1 or 2");
+  return QEMB_ERR_ARG;
+}
+int qemb_df_transform(qemb_df_t df, const double* TA, int n, double* out_s4_host, qemb_frag_t frag) {
+  if (!df || !TA) { set_error("qemb_df_transform: null argument"); return QEMB_ERR_ARG; }
+  DfContext* d = reinterpret_cast<DfContext*>(df);
+  DBuf dTA, s4;
+  int rc;
+  if ((rc = dTA.alloc((int64_t)d->N * n))) return rc;
+  if ((rc = dev_h2d(dTA, TA, sizeof(double) * d->N * n))) return rc;
+  if ((rc = s4.alloc(((int64_t)n * (n + 1) / 2) * ((int64_t)n * (n + 1) / 2)))) return rc;
+  if ((rc = d->transform(dTA, n, s4))) return rc;
+  return deliver_s4(s4, n, out_s4_host, frag);
+}
+
+// ---------------------------------------------------------------- Schmidt ---------------------------
+int qemb_schmidt(const double* lmo, int N, int nmo, int nocc, const int64_t* frag_idx, int n_f, double thr, double* TA, int ld,
+                 int* n_b, int* sweeps) {
+  if (!lmo || !frag_idx || !TA || !n_b) { set_error("qemb_schmidt: null argument"); return QEMB_ERR_ARG; }
+  return schmidt_eigh(lmo, N, nmo, nocc, frag_idx, n_f, thr, TA, ld, n_b, sweeps);
+}
+int qemb_schmidt_svd(const double* rdm, int N, const int64_t* frag_idx, int n_f, double thr, double* TA, int ld, int* n_b,
+                     int* sweeps) {
+  if (!rdm || !frag_idx || !TA || !n_b) { set_error("qemb_schmidt_svd: null argument"); return QEMB_ERR_ARG; }
+  return schmidt_svd(rdm, N, frag_idx, n_f, thr, TA, ld, n_b, sweeps);
+}
+int qemb_nsocc_guess(const double* Cproj, int n, int nocc, double* P, int* nsocc, double* mo) {
+  if (!Cproj || !nsocc || !mo) { set_error("qemb_nsocc_guess: null argument"); return QEMB_ERR_ARG; }
+  return nsocc_guess(Cproj, n, nocc, P, nsocc, mo);
+}
+int qemb_matmul(int64_t M, int64_t N, int64_t K, const double* A, int transA, const double* B, int transB, double* C) {
+  DBuf dA, dB, dC;
+  int rc;
+  if ((rc = dA.alloc(M * K)) || (rc = dB.alloc(K * N)) || (rc = dC.alloc(M * N))) return rc;
+  if ((rc = dev_h2d(dA, A, sizeof(double) * M * K)) || (rc = dev_h2d(dB, B, sizeof(double) * K * N))) return rc;
+  // transA: A is stored K x M;  transB: B is stored N x K
+  rc = gemm(M, N, K, 1.0, dA, transA ? M : K, !transA, dB, transB ? K : N, transB != 0, 0.0, dC, N);
+  if (rc) return rc;
+  return dev_d2h(C, dC, sizeof(double) * M * N);
+}
 
 }  // extern "C"

@@ -60,6 +60,90 @@ int Fragment::hf_veff_from_dm(const double* P_host, double* J_host, double* K_ho
   return 0;
 }
 
+int Fragment::scf_only(int o, const double* h, const double* dm0, const ScfOptions& opt, double* mo_coeff, double* mo_energy,
+                       double* J_host, double* K_host, ScfResult* sres) {
+  if (!eri_s4_.p) { set_error("Fragment: ERIs not set"); return QEMB_ERR_ARG; }
+  if (o <= 0 || o > n_) { set_error("Fragment: need 0 < nsocc <= n"); return QEMB_ERR_ARG; }
+  const int64_t n2 = (int64_t)n_ * n_;
+  DBuf X0;
+  QTRY(X0.alloc(n2 * n2));
+  QTRY(dev_unpack_s4(n_, eri_s4_, X0));
+  QTRY(run_scf(o, h, dm0, opt, X0, sres));
+  if (mo_coeff) QTRY(dev_d2h(mo_coeff, C_, sizeof(double) * n2));
+  if (mo_energy) QTRY(dev_d2h(mo_energy, eps_, sizeof(double) * n_));
+  if (J_host) QTRY(dev_d2h(J_host, J_, sizeof(double) * n2));
+  if (K_host) QTRY(dev_d2h(K_host, K_, sizeof(double) * n2));
+  return 0;
+}
+
+// Coupled-perturbed HF (shared/external/cphf_utils.py:12-81, used by the HF Jacobian of the QN optimiser,
+// shared/external/optqn.py:456-466):  A = 4 (ia|jb) - (ib|ja) - (ij|ab) - diag(e_i - e_a)  (:27-32),
+// B0_p = Co^T v_p Cv (:37-41), u_p = A^-1 B0_p (:70), dP_p = -(Co u_p Cv^T + transpose) (:75-81).
+// A is the (positive definite) RHF orbital Hessian, so the solve is Cholesky + triangular inverse + two GEMMs.
+int Fragment::cphf_response(int o, const double* h, const double* dm0, const ScfOptions& opt, const double* vpots, int npot,
+                            double* dPs) {
+  if (!eri_s4_.p) { set_error("Fragment: ERIs not set"); return QEMB_ERR_ARG; }
+  if (o <= 0 || o >= n_ || npot <= 0) { set_error("cphf_response: bad arguments"); return QEMB_ERR_ARG; }
+  const int n = n_, v = n - o;
+  const int64_t n2 = (int64_t)n * n, nov = (int64_t)o * v;
+  DBuf X0, X1;
+  QTRY(X0.alloc(n2 * n2));
+  QTRY(dev_unpack_s4(n, eri_s4_, X0));
+  ScfResult sres;
+  QTRY(run_scf(o, h, dm0, opt, X0, &sres));
+  if (!sres.converged) { set_error("cphf_response: fragment SCF did not converge"); return QEMB_ERR_NOCONV; }
+  std::vector<double> C((size_t)n2), eps((size_t)n);
+  QTRY(dev_d2h(C.data(), C_, sizeof(double) * n2));
+  QTRY(dev_d2h(eps.data(), eps_, sizeof(double) * n));
+  QTRY(X1.alloc(n2 * n2));
+  MoIntegrals ints;
+  QTRY(mo_transform(n, o, 0, X0, X1, C_, ints));
+  X0.release(); X1.release();
+  DBuf A, L, Linv, d;
+  QTRY(A.alloc(nov * nov)); QTRY(d.alloc(nov));
+  QTRY(dcopy(nov * nov, ints.ovov, A));
+  QTRY(axpby(nov * nov, 0.0, A, 4.0, A));                                              // 4 (ia|jb)
+  QTRY(perm4(A, ints.ovov, o, v, o, v, 0, 3, 2, 1, -1.0, 1.0));                         // - (ib|ja)
+  QTRY(perm4(A, ints.oovv, o, o, v, v, 0, 2, 1, 3, -1.0, 1.0));                         // - (ij|ab)
+  std::vector<double> den((size_t)nov);
+  for (int i = 0; i < o; ++i) for (int a = 0; a < v; ++a) den[(size_t)i * v + a] = eps[(size_t)o + a] - eps[(size_t)i];
+  QTRY(dev_h2d(d, den.data(), sizeof(double) * nov));
+  {
+    Copy4Desc c{};
+    c.dim[0] = 1; c.dim[1] = 1; c.dim[2] = 1; c.dim[3] = nov;
+    c.in = d; c.si[3] = 1; c.out = A; c.so[3] = nov + 1; c.alpha = 1.0; c.beta = 1.0;
+    QTRY(dev_copy4(c));                                                               // - diag(e_i - e_a)
+  }
+  ints = MoIntegrals();
+  QTRY(dev_cholesky_lower(nov, A));
+  QTRY(Linv.alloc(nov * nov));
+  QTRY(dev_tri_inverse_lower(nov, A, Linv));
+  A.release();
+  // right-hand sides B0[(ia), p]
+  std::vector<double> B0((size_t)nov * npot), tmp((size_t)o * n);
+  for (int p = 0; p < npot; ++p) {
+    const double* vp = vpots + (size_t)p * n2;
+    for (int i = 0; i < o; ++i) for (int q = 0; q < n; ++q) { double s = 0; for (int r = 0; r < n; ++r) s += C[(size_t)r * n + i] * vp[(size_t)r * n + q]; tmp[(size_t)i * n + q] = s; }
+    for (int i = 0; i < o; ++i) for (int a = 0; a < v; ++a) { double s = 0; for (int q = 0; q < n; ++q) s += tmp[(size_t)i * n + q] * C[(size_t)q * n + o + a]; B0[((size_t)i * v + a) * npot + p] = s; }
+  }
+  DBuf dB, dY, dU;
+  QTRY(dB.alloc(nov * npot)); QTRY(dY.alloc(nov * npot)); QTRY(dU.alloc(nov * npot));
+  QTRY(dev_h2d(dB, B0.data(), sizeof(double) * nov * npot));
+  QTRY(gemm_nn(nov, npot, nov, 1.0, Linv, dB, 0.0, dY));                                // y = L^-1 B0
+  QTRY(gemm_tn(nov, npot, nov, 1.0, Linv, dY, 0.0, dU));                                // u = L^-T y
+  std::vector<double> U((size_t)nov * npot);
+  QTRY(dev_d2h(U.data(), dU, sizeof(double) * nov * npot));
+  std::vector<double> X((size_t)n * v);
+  for (int p = 0; p < npot; ++p) {
+    double* dP = dPs + (size_t)p * n2;
+    for (int r = 0; r < n; ++r) for (int a = 0; a < v; ++a) { double s = 0; for (int i = 0; i < o; ++i) s += C[(size_t)r * n + i] * U[((size_t)i * v + a) * npot + p]; X[(size_t)r * v + a] = s; }
+    for (int r = 0; r < n; ++r) for (int q = 0; q < n; ++q) { double s = 0; for (int a = 0; a < v; ++a) s += X[(size_t)r * v + a] * C[(size_t)q * n + o + a]; dP[(size_t)r * n + q] = -s; }
+    for (int r = 0; r < n; ++r) for (int q = 0; q < r; ++q) { const double t = dP[(size_t)r * n + q] + dP[(size_t)q * n + r]; dP[(size_t)r * n + q] = dP[(size_t)q * n + r] = t; }
+    for (int r = 0; r < n; ++r) dP[(size_t)r * n + r] *= 2.0;
+  }
+  return 0;
+}
+
 int Fragment::prepare_ccsd(int o, const double* h, const double* dm0, const FragmentOptions& opt) {
   if (!eri_s4_.p) { set_error("Fragment: ERIs not set"); return QEMB_ERR_ARG; }
   if (o <= 0 || o >= n_) { set_error("Fragment: need 0 < nsocc < n"); return QEMB_ERR_ARG; }

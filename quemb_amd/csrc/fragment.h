@@ -46,6 +46,12 @@ class Fragment {
   int prepare_ccsd(int o, const double* h, const double* dm0, const FragmentOptions& opt);
   int ccsd_iterate(int niter, double* e_corr, double* normt);
   int ccsd_reset();                              // back to the MP2 guess
+  // fragment RHF only (Frags.scf(fs=True), mbe.py:1160): outputs host n*n / n / n*n / n*n, nullable
+  int scf_only(int o, const double* h, const double* dm0, const ScfOptions& opt, double* mo_coeff, double* mo_energy,
+               double* J_host, double* K_host, ScfResult* sres);
+  // CPHF response of the fragment RHF density to npot one-body perturbations v_p (n x n each, host):
+  // dP_p = d(P)/d(lambda_p), P the spin-summed... see fragment.cpp.  dPs: npot x n x n (host).
+  int cphf_response(int o, const double* h, const double* dm0, const ScfOptions& opt, const double* vpots, int npot, double* dPs);
   // J/K based pieces that do not need a correlated solve (row a6 / a15)
   int hf_veff_from_dm(const double* P_host, double* J_host, double* K_host);   // J,K of an n x n density
 

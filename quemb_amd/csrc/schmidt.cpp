@@ -1,0 +1,110 @@
+// schmidt.cpp -- Schmidt decomposition of the HF 1-RDM (rows a1, a1', a2 of SURVEY.md section 8).
+//
+// Reference: molbe/pfrag.py:403-494 `schmidt_decomposition` (eigh of the environment block of D = C_occ C_occ^T,
+// bath = eigenvectors with thr < |lambda| < 1 - thr, TA = [I_frag (+) Evec_bath]); kbe/solver.py:9-46
+// `schmidt_decomp_svd` (SVD of D[env, frag], bath = left vectors with sigma >= thr); molbe/pfrag.py:208-239
+// `get_nsocc`.  The O(N_env^3) / O(N_env n_f^2) eigen/SVD work runs as wavefront Jacobi sweeps on the device
+// (linalg_f64.hip); the index bookkeeping (which rows are environment, which eigenvalues are bath) is host logic
+// exactly as in the reference.
+#include <algorithm>
+#include <cmath>
+#include <vector>
+#include "dev_ops.h"
+#include "tensor_utils.h"
+
+namespace qemb {
+
+// lmo: N x nmo row-major (host); AO_in_frag: n_f indices.  TA_out: N x (n_f + n_b) row-major written into a buffer
+// with leading dimension ld_out >= n_f + n_b (caller gives N x ld_out).  Returns n_b.
+int schmidt_eigh(const double* lmo, int N, int nmo, int nocc, const int64_t* frag, int n_f, double thr, double* TA_out,
+                 int ld_out, int* n_b_out, int* sweeps_out) {
+  if (N <= 0 || nocc <= 0 || nocc > nmo || n_f <= 0 || n_f >= N) { set_error("schmidt: bad dimensions"); return QEMB_ERR_ARG; }
+  std::vector<char> isfrag((size_t)N, 0);
+  for (int k = 0; k < n_f; ++k) {
+    if (frag[k] < 0 || frag[k] >= N || isfrag[(size_t)frag[k]]) { set_error("schmidt: bad fragment index list"); return QEMB_ERR_ARG; }
+    isfrag[(size_t)frag[k]] = 1;
+  }
+  std::vector<int> env;
+  for (int i = 0; i < N; ++i) if (!isfrag[(size_t)i]) env.push_back(i);
+  const int ne = (int)env.size();
+  // C_env = rows of the occupied LMO block that belong to the environment; Denv = C_env C_env^T  (pfrag.py:448-465)
+  std::vector<double> cenv((size_t)ne * nocc);
+  for (int r = 0; r < ne; ++r) for (int k = 0; k < nocc; ++k) cenv[(size_t)r * nocc + k] = lmo[(size_t)env[(size_t)r] * nmo + k];
+  DBuf dC, dD, dw, dV;
+  QTRY(dC.alloc((int64_t)ne * nocc)); QTRY(dD.alloc((int64_t)ne * ne)); QTRY(dw.alloc(ne)); QTRY(dV.alloc((int64_t)ne * ne));
+  QTRY(dev_h2d(dC, cenv.data(), sizeof(double) * ne * nocc));
+  QTRY(dev_timer_begin(TIMER_SCHMIDT));
+  QTRY(gemm_nt(ne, ne, nocc, 1.0, dC, dC, 0.0, dD));
+  QTRY(dev_jacobi_eigh(ne, dD, dw, dV, sweeps_out));                       // pfrag.py:468
+  QTRY(dev_timer_end(TIMER_SCHMIDT));
+  std::vector<double> w((size_t)ne), V((size_t)ne * ne);
+  QTRY(dev_d2h(w.data(), dw, sizeof(double) * ne));
+  QTRY(dev_d2h(V.data(), dV, sizeof(double) * ne * ne));
+  std::vector<int> bidx;
+  for (int i = 0; i < ne; ++i) if (thr < std::fabs(w[(size_t)i]) && std::fabs(w[(size_t)i]) < 1.0 - thr) bidx.push_back(i);   // :484-486
+  const int nb = (int)bidx.size();
+  *n_b_out = nb;
+  if (n_f + nb > ld_out) { set_error("schmidt: output buffer too narrow for n_f + n_b columns"); return QEMB_ERR_ARG; }
+  for (int i = 0; i < N; ++i) for (int c = 0; c < ld_out; ++c) TA_out[(size_t)i * ld_out + c] = 0.0;
+  for (int k = 0; k < n_f; ++k) TA_out[(size_t)frag[k] * ld_out + k] = 1.0;                                                 // :490
+  for (int r = 0; r < ne; ++r) for (int b = 0; b < nb; ++b) TA_out[(size_t)env[(size_t)r] * ld_out + n_f + b] = V[(size_t)r * ne + bidx[(size_t)b]];   // :491
+  return 0;
+}
+
+// rdm: N x N (host, real).  kbe/solver.py:9-46.
+int schmidt_svd(const double* rdm, int N, const int64_t* frag_in, int n_f, double thr, double* TA_out, int ld_out, int* n_b_out,
+                int* sweeps_out) {
+  if (N <= 0 || n_f <= 0 || n_f >= N) { set_error("schmidt_svd: bad dimensions"); return QEMB_ERR_ARG; }
+  std::vector<int> frag((size_t)n_f);
+  std::vector<char> isfrag((size_t)N, 0);
+  for (int k = 0; k < n_f; ++k) {
+    int64_t f = frag_in[k] >= 0 ? frag_in[k] : N + frag_in[k];                                                              // :32
+    if (f < 0 || f >= N || isfrag[(size_t)f]) { set_error("schmidt_svd: bad fragment index list"); return QEMB_ERR_ARG; }
+    frag[(size_t)k] = (int)f; isfrag[(size_t)f] = 1;
+  }
+  std::vector<int> env;
+  for (int i = 0; i < N; ++i) if (!isfrag[(size_t)i]) env.push_back(i);
+  const int ne = (int)env.size();
+  if (ne < n_f) { set_error("schmidt_svd: environment smaller than the fragment"); return QEMB_ERR_ARG; }
+  std::vector<double> G((size_t)ne * n_f);
+  for (int r = 0; r < ne; ++r) for (int k = 0; k < n_f; ++k) G[(size_t)r * n_f + k] = rdm[(size_t)env[(size_t)r] * N + frag[(size_t)k]];    // :37
+  DBuf dG, ds, dU;
+  QTRY(dG.alloc((int64_t)ne * n_f)); QTRY(ds.alloc(n_f)); QTRY(dU.alloc((int64_t)ne * n_f));
+  QTRY(dev_h2d(dG, G.data(), sizeof(double) * ne * n_f));
+  QTRY(dev_timer_begin(TIMER_SCHMIDT));
+  QTRY(dev_jacobi_svd(ne, n_f, dG, ds, dU, nullptr, sweeps_out));                                                           // :38
+  QTRY(dev_timer_end(TIMER_SCHMIDT));
+  std::vector<double> s((size_t)n_f), U((size_t)ne * n_f);
+  QTRY(dev_d2h(s.data(), ds, sizeof(double) * n_f));
+  QTRY(dev_d2h(U.data(), dU, sizeof(double) * ne * n_f));
+  int nb = 0;
+  for (int k = 0; k < n_f; ++k) if (s[(size_t)k] >= thr) ++nb;                                                               // :40
+  *n_b_out = nb;
+  if (n_f + nb > ld_out) { set_error("schmidt_svd: output buffer too narrow"); return QEMB_ERR_ARG; }
+  for (int i = 0; i < N; ++i) for (int c = 0; c < ld_out; ++c) TA_out[(size_t)i * ld_out + c] = 0.0;
+  for (int k = 0; k < n_f; ++k) TA_out[(size_t)frag[(size_t)k] * ld_out + k] = 1.0;
+  for (int r = 0; r < ne; ++r) for (int b = 0; b < nb; ++b) TA_out[(size_t)env[(size_t)r] * ld_out + n_f + b] = U[(size_t)r * n_f + b];
+  return 0;
+}
+
+// C_ (n x nocc host) -> P_ = C_ C_^T (n x n), nsocc = round(tr P_), mo = eigenvectors of P_ by DEscending
+// eigenvalue (= left singular vectors of C_, pfrag.py:228-239).
+int nsocc_guess(const double* Cproj, int n, int nocc, double* P_out, int* nsocc, double* mo_out) {
+  DBuf dC, dP, dw, dV;
+  QTRY(dC.alloc((int64_t)n * nocc)); QTRY(dP.alloc((int64_t)n * n)); QTRY(dw.alloc(n)); QTRY(dV.alloc((int64_t)n * n));
+  QTRY(dev_h2d(dC, Cproj, sizeof(double) * n * nocc));
+  QTRY(gemm_nt(n, n, nocc, 1.0, dC, dC, 0.0, dP));
+  std::vector<double> P((size_t)n * n);
+  QTRY(dev_d2h(P.data(), dP, sizeof(double) * n * n));
+  double tr = 0.0;
+  for (int i = 0; i < n; ++i) tr += P[(size_t)i * n + i];
+  *nsocc = (int)std::lround(tr);
+  if (P_out) std::copy(P.begin(), P.end(), P_out);
+  QTRY(dev_jacobi_eigh(n, dP, dw, dV, nullptr));
+  std::vector<double> V((size_t)n * n);
+  QTRY(dev_d2h(V.data(), dV, sizeof(double) * n * n));
+  for (int r = 0; r < n; ++r) for (int c = 0; c < n; ++c) mo_out[(size_t)r * n + c] = V[(size_t)r * n + (n - 1 - c)];
+  return 0;
+}
+
+}  // namespace qemb

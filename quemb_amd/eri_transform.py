@@ -1,0 +1,184 @@
+"""AO -> fragment ERI transforms and Schmidt decomposition on the device (C ABI qemb_aoeri_*, qemb_df_*,
+qemb_schmidt*).  Host mirror of the reference seams:
+
+* `ao2mo.incore.full(eri_, TA, compact=True)`            molbe/mbe.py:1038            -> AOEri.transform
+* `integral_direct_DF(mf, Fobjs, file_eri, auxbasis)`     molbe/eri_onthefly.py:45     -> DFContext.transform
+* `transform_integral[_cuda](P_mu_nu, TA, S_abs, L_PQ, e)` molbe/eri_sparse_DF.py:677-702 -> DFContext (packed ints)
+* `schmidt_decomposition(mo_coeff, nocc, AO_in_frag, ...)` molbe/pfrag.py:403           -> schmidt_decomposition
+* `schmidt_decomp_svd(rdm, Frag_sites, thr_bath)`          kbe/solver.py:9              -> schmidt_decomp_svd
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import c_vp, check
+
+#: new `int_transform` literals next to the reference's IntTransforms (molbe/mbe.py:63-71)
+HIP_INT_TRANSFORMS = ("in-core-hip", "int-direct-DF-hip", "sparse-DF-hip")
+
+
+def _arr(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def matmul(A, B, transA=False, transB=False, lib=None):
+    """op(A) @ op(B) on the device (FP64 MFMA GEMM), host arrays in and out."""
+    lib = lib or _lib.init()
+    A, B = _arr(A), _arr(B)
+    M, K = (A.shape[1], A.shape[0]) if transA else A.shape
+    K2, N = (B.shape[1], B.shape[0]) if transB else B.shape
+    if K != K2:
+        raise ValueError(f"matmul: inner dimensions differ ({K} vs {K2})")
+    out = np.empty((M, N))
+    check(lib.qemb_matmul(M, N, K, A.ctypes.data, int(transA), B.ctypes.data, int(transB), out.ctypes.data), "qemb_matmul", lib)
+    return out
+
+
+class AOEri:
+    """AO-basis ERIs resident on the device (uploaded once per system, shared by all fragments)."""
+
+    def __init__(self, eri, nao: int, lib=None):
+        self.lib = lib or _lib.init()
+        eri = _arr(eri)
+        npair = nao * (nao + 1) // 2
+        if eri.ndim == 4 or eri.size == nao ** 4:
+            sym = 1
+        elif eri.size == npair * npair:
+            sym = 4
+        elif eri.size == npair * (npair + 1) // 2:
+            sym = 8
+        else:
+            raise ValueError("AOEri: ERIs must be s1 (N^4), s4 (npair x npair) or s8 (1-D npair(npair))")
+        self.nao = int(nao)
+        h = c_vp()
+        check(self.lib.qemb_aoeri_upload(self.nao, eri.ctypes.data, sym, C.byref(h)), "qemb_aoeri_upload", self.lib)
+        self.h = h
+
+    def transform(self, TA, frag=None, want_host=True):
+        """(ij|kl) in the fragment embedding basis, 4-fold packed; optionally stored straight into `frag`."""
+        TA = _arr(TA)
+        if TA.shape[0] != self.nao:
+            raise ValueError("AOEri.transform: TA has the wrong number of rows")
+        n = TA.shape[1]
+        npair = n * (n + 1) // 2
+        out = np.empty((npair, npair)) if want_host else None
+        check(self.lib.qemb_ao2mo_dense(self.h, TA.ctypes.data, n, None if out is None else out.ctypes.data,
+                                        None if frag is None else frag.h), "qemb_ao2mo_dense", self.lib)
+        return out
+
+    def free(self):
+        if getattr(self, "h", None):
+            self.lib.qemb_aoeri_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class DFContext:
+    """Density-fitting context: metric factor and (P|mu nu) resident on the device."""
+
+    def __init__(self, j2c=None, L_PQ=None, lib=None):
+        self.lib = lib or _lib.init()
+        h = c_vp()
+        if (j2c is None) == (L_PQ is None):
+            raise ValueError("DFContext: give exactly one of j2c (metric) or L_PQ (its lower Cholesky factor)")
+        if j2c is not None:
+            j2c = _arr(j2c)
+            self.naux = j2c.shape[0]
+            check(self.lib.qemb_df_create(self.naux, j2c.ctypes.data, C.byref(h)), "qemb_df_create", self.lib)
+        else:
+            L_PQ = _arr(L_PQ)
+            self.naux = L_PQ.shape[0]
+            check(self.lib.qemb_lpq_upload(L_PQ.ctypes.data, self.naux, C.byref(h)), "qemb_lpq_upload", self.lib)
+        self.h = h
+        self.nao = None
+
+    def set_ints(self, ints, nao: int, layout: str = "pqL"):
+        """layout: 'pqL' (N,N,naux) as getints3c returns, 'Lpq' (naux,N,N), 'packed' (naux, npair(N))."""
+        code = {"pqL": 0, "Lpq": 1, "packed": 2}[layout]
+        ints = _arr(ints)
+        npair = nao * (nao + 1) // 2
+        want = {0: nao * nao * self.naux, 1: nao * nao * self.naux, 2: self.naux * npair}[code]
+        if ints.size != want:
+            raise ValueError("DFContext.set_ints: array size does not match layout")
+        check(self.lib.qemb_df_set_ints(self.h, int(nao), ints.ctypes.data, code), "qemb_df_set_ints", self.lib)
+        self.nao = int(nao)
+
+    def transform(self, TA, frag=None, want_host=True):
+        TA = _arr(TA)
+        if self.nao is None or TA.shape[0] != self.nao:
+            raise ValueError("DFContext.transform: set_ints first / TA has the wrong number of rows")
+        n = TA.shape[1]
+        npair = n * (n + 1) // 2
+        out = np.empty((npair, npair)) if want_host else None
+        check(self.lib.qemb_df_transform(self.h, TA.ctypes.data, n, None if out is None else out.ctypes.data,
+                                         None if frag is None else frag.h), "qemb_df_transform", self.lib)
+        return out
+
+    def free(self):
+        if getattr(self, "h", None):
+            self.lib.qemb_df_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def schmidt_decomposition(mo_coeff, nocc, AO_in_frag, thr_bath=1.0e-10, cinv=None, rdm=None, norb=None, lib=None):
+    """Same signature / return as molbe/pfrag.py:403-411: (TA_lo_eo, n_f, n_b).  The `cinv`, `rdm` and `norb`
+    variants of the reference are only reached from UBE (out of scope) and raise here."""
+    if cinv is not None or rdm is not None or norb is not None:
+        raise NotImplementedError("schmidt_decomposition: cinv / rdm / norb variants (UBE) are outside the hot path")
+    lib = lib or _lib.init()
+    C_ = _arr(mo_coeff)
+    N, nmo = C_.shape
+    frag = np.ascontiguousarray(AO_in_frag, dtype=np.int64)
+    nf = len(frag)
+    ld = min(N, 2 * nf + 2)
+    while True:
+        TA = np.empty((N, ld))
+        nb, sw = C.c_int(), C.c_int()
+        rc = lib.qemb_schmidt(C_.ctypes.data, N, nmo, int(nocc), frag.ctypes.data_as(C.POINTER(C.c_int64)), nf, float(thr_bath),
+                              TA.ctypes.data, ld, C.byref(nb), C.byref(sw))
+        if rc == -1 and b"too narrow" in lib.qemb_last_error() and ld < N:
+            ld = N          # more bath orbitals than fragment orbitals (non-idempotent input): retry with full width
+            continue
+        check(rc, "qemb_schmidt", lib)
+        break
+    return np.ascontiguousarray(TA[:, : nf + nb.value]), nf, nb.value
+
+
+def schmidt_decomp_svd(rdm, Frag_sites, thr_bath=1.0e-10, lib=None):
+    """kbe/solver.py:9-46 (returns the real TA; the reference's complex128 container holds real content)."""
+    lib = lib or _lib.init()
+    D = _arr(np.real(rdm))
+    N = D.shape[0]
+    frag = np.ascontiguousarray(Frag_sites, dtype=np.int64)
+    nf = len(frag)
+    TA = np.empty((N, 2 * nf))
+    nb, sw = C.c_int(), C.c_int()
+    check(lib.qemb_schmidt_svd(D.ctypes.data, N, frag.ctypes.data_as(C.POINTER(C.c_int64)), nf, float(thr_bath), TA.ctypes.data,
+                               2 * nf, C.byref(nb), C.byref(sw)), "qemb_schmidt_svd", lib)
+    return np.ascontiguousarray(TA[:, : nf + nb.value])
+
+
+def nsocc_guess(Cproj, lib=None):
+    """Frags.get_nsocc core (molbe/pfrag.py:228-239): returns (P_, nsocc, mo_coeffs)."""
+    lib = lib or _lib.init()
+    Cp = _arr(Cproj)
+    n, nocc = Cp.shape
+    P = np.empty((n, n)); mo = np.empty((n, n))
+    ns = C.c_int()
+    check(lib.qemb_nsocc_guess(Cp.ctypes.data, n, nocc, P.ctypes.data, C.byref(ns), mo.ctypes.data), "qemb_nsocc_guess", lib)
+    return P, ns.value, mo

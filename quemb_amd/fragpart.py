@@ -1,0 +1,56 @@
+"""FragPart -- the index lists a fragmentation produces (molbe/autofrag.py:38-130), as plain data.
+
+Fragmentation itself (autogen / chemgen / graphgen) is upstream of the hot path and stays in QuEmb; this class
+only carries its OUTPUT.  Any object with the same attribute names (e.g. the reference's own FragPart) is
+accepted by `quemb_amd.mbe.BE`.
+"""
+
+from __future__ import annotations
+
+import json
+from dataclasses import dataclass, field
+from pathlib import Path
+
+
+@dataclass
+class FragPart:
+    AO_per_frag: list
+    AO_per_edge_per_frag: list
+    ref_frag_idx_per_edge_per_frag: list
+    relAO_per_origin_per_frag: list
+    weight_and_relAO_per_center_per_frag: list
+    relAO_per_edge_per_frag: list = field(default_factory=list)
+    relAO_in_ref_per_edge_per_frag: list = field(default_factory=list)
+    n_BE: int = 2
+    frozen_core: bool = False
+    iao_valence_basis: object = None
+    iao_valence_only: bool = False
+
+    def __post_init__(self):
+        AO = self.AO_per_frag
+        if not self.relAO_per_edge_per_frag:
+            # position of every edge AO inside its own fragment (autofrag.py:554-620)
+            self.relAO_per_edge_per_frag = [[[AO[i].index(a) for a in e] for e in self.AO_per_edge_per_frag[i]] for i in range(len(AO))]
+        if not self.relAO_in_ref_per_edge_per_frag:
+            # position of the same AOs inside the fragment where they are centre sites (autofrag.py:652-698)
+            self.relAO_in_ref_per_edge_per_frag = [
+                [[AO[r].index(a) for a in e] for e, r in zip(self.AO_per_edge_per_frag[i], self.ref_frag_idx_per_edge_per_frag[i])]
+                for i in range(len(AO))]
+        self.weight_and_relAO_per_center_per_frag = [(float(w), list(c)) for w, c in self.weight_and_relAO_per_center_per_frag]
+
+    @property
+    def n_frag(self):
+        return len(self.AO_per_frag)
+
+    def all_centers_are_origins(self):
+        return all(sorted(c) == sorted(o) for (_, c), o in zip(self.weight_and_relAO_per_center_per_frag, self.relAO_per_origin_per_frag))
+
+    @classmethod
+    def from_json(cls, path, key, n_BE=2):
+        d = json.loads(Path(path).read_text())[key]
+        return cls(AO_per_frag=d["AO_per_frag"], AO_per_edge_per_frag=d["AO_per_edge_per_frag"],
+                   ref_frag_idx_per_edge_per_frag=d["ref_frag_idx_per_edge_per_frag"],
+                   relAO_per_origin_per_frag=d["relAO_per_origin_per_frag"],
+                   weight_and_relAO_per_center_per_frag=d["weight_and_relAO_per_center_per_frag"],
+                   relAO_per_edge_per_frag=d.get("relAO_per_edge_per_frag", []),
+                   relAO_in_ref_per_edge_per_frag=d.get("relAO_in_ref_per_edge_per_frag", []), n_BE=n_BE)

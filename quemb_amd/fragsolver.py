@@ -90,6 +90,30 @@ class DeviceFragment:
                    scf_cycles=ncyc.value)
         return out
 
+    def scf(self, nsocc, h, dm0=None, opts=None):
+        """Fragment RHF only (Frags.scf(fs=True)); returns dict(mo_coeff, mo_energy, J, K, e_scf, converged, cycles)."""
+        n = self.n
+        h = np.ascontiguousarray(h, dtype=np.float64)
+        dm0 = None if dm0 is None else np.ascontiguousarray(dm0, dtype=np.float64)
+        opts = opts or default_opts(self.lib)
+        mo = np.empty((n, n)); eps = np.empty(n); J = np.empty((n, n)); K = np.empty((n, n))
+        e = C.c_double(); conv = C.c_int(); cyc = C.c_int()
+        check(self.lib.qemb_frag_scf(self.h, int(nsocc), h.ctypes.data, _p(dm0), C.byref(opts), mo.ctypes.data, eps.ctypes.data,
+                                     J.ctypes.data, K.ctypes.data, C.byref(e), C.byref(conv), C.byref(cyc)), "qemb_frag_scf", self.lib)
+        return dict(mo_coeff=mo, mo_energy=eps, J=J, K=K, e_scf=e.value, converged=bool(conv.value), cycles=cyc.value)
+
+    def cphf(self, nsocc, h, vpots, dm0=None, opts=None):
+        """Density responses dP_p (npot, n, n) to the one-body perturbations vpots (npot, n, n)."""
+        n = self.n
+        h = np.ascontiguousarray(h, dtype=np.float64)
+        v = np.ascontiguousarray(vpots, dtype=np.float64).reshape(-1, n, n)
+        dm0 = None if dm0 is None else np.ascontiguousarray(dm0, dtype=np.float64)
+        opts = opts or default_opts(self.lib)
+        out = np.empty_like(v)
+        check(self.lib.qemb_frag_cphf(self.h, int(nsocc), h.ctypes.data, _p(dm0), C.byref(opts), v.ctypes.data, v.shape[0],
+                                      out.ctypes.data), "qemb_frag_cphf", self.lib)
+        return out
+
     # ---- measurement hooks ---------------------------------------------------------------------------
     def prepare_ccsd(self, nsocc, h, dm0=None, opts=None):
         h = np.ascontiguousarray(h, dtype=np.float64)

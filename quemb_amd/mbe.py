@@ -1,0 +1,193 @@
+"""BE -- host mirror of the molecular bootstrap-embedding driver (molbe/mbe.py:149) over the device hot path.
+
+`BE(mf, fobj)` accepts any mean-field object exposing the PySCF attributes the reference reads
+(mbe.py:361-373): mo_energy, mo_coeff, e_tot, _eri, mol.nelectron, energy_nuc(), get_hcore(), get_ovlp(),
+make_rdm1(), get_veff() -- a real `pyscf.scf.RHF` or `quemb_amd.integrals.RHF`.  What runs where:
+  host (NumPy, once per system, out of scope per SURVEY 2): Loewdin localisation W = S^-1/2 (mbe.py:1395-1398);
+  device (libqemb_hip): Schmidt decomposition, AO->fragment ERI transform, fragment Fock / SCF, CCSD, energies.
+Only lo_method="lowdin", restricted, no frozen core are mirrored (the configurations of SURVEY section 8).
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+from . import eri_transform as et
+from .be_parallel import be_func_parallel, fragment_cost, partition_fragments, world, all_reduce_sum
+from .fragsolver import default_opts
+from .pfrag import Frags
+from .solver import ErrorMap, be_func
+
+
+def initialize_pot(n_frag, relAO_per_edge):
+    """molbe/mbe.py:1614-1650: one zero per unique edge-AO pair (j <= k) of every fragment + the chemical potential."""
+    n = 0
+    if relAO_per_edge:
+        for I in range(n_frag):
+            for e in relAO_per_edge[I]:
+                n += len(e) * (len(e) + 1) // 2
+    return [0.0] * (n + 1)
+
+
+class BE:
+    def __init__(self, mf, fobj, *, lo_method="lowdin", thr_bath=1.0e-10, int_transform="in-core-hip", auxbasis=None,
+                 df_ints=None, nproc=1, ompnum=1, initialize_fragment_idx=None, solver_opts=None, lib=None, distribute=True,
+                 eri_file=None, scratch_dir=None, restart=False):
+        if lo_method != "lowdin":
+            raise NotImplementedError("only lo_method='lowdin' is mirrored (localisation is upstream of the hot path)")
+        if getattr(fobj, "frozen_core", False):
+            raise NotImplementedError("frozen core is not mirrored")
+        if restart:
+            raise NotImplementedError("restart files are outside the hot path")
+        self.mf, self.fobj, self.lib = mf, fobj, lib
+        self.thr_bath = thr_bath
+        self.int_transform = int_transform
+        self.opts = solver_opts
+        self.unrestricted = False
+        self.ebe_hf = 0.0
+        self.ebe_tot = 0.0
+        self.mo_energy = mf.mo_energy
+        self.Nocc = mf.mol.nelectron // 2
+        self.enuc = float(mf.energy_nuc())
+        self.hcore = np.asarray(mf.get_hcore())
+        self.S = np.asarray(mf.get_ovlp())
+        self.C = np.array(mf.mo_coeff)
+        self.hf_dm = np.asarray(mf.make_rdm1())
+        self.hf_veff = np.asarray(mf.get_veff())
+        self.hf_etot = float(mf.e_tot)
+        self.E_core = 0.0
+        self.ncore = 0
+        self.pot = initialize_pot(fobj.n_frag, fobj.relAO_per_edge_per_frag)
+        self.Fobjs: list[Frags] = []
+        self.stats = {}
+        # fragment ownership over ranks (all fragments on this rank when not distributed)
+        self.rank, self.world = world() if distribute else (0, 1)
+        self.localize()
+        self._df_ints = df_ints
+        self.initialize(getattr(mf, "_eri", None), initialize_fragment_idx)
+
+    # ------------------------------------------------------------------ localisation (host; mbe.py:1395-1449)
+    def localize(self):
+        es_, vs_ = np.linalg.eigh(self.S)
+        edx = es_ > 1.0e-15
+        self.W = (vs_[:, edx] / np.sqrt(es_[edx])) @ vs_[:, edx].T
+        self.lmo_coeff = self.W.T @ self.S @ self.C
+
+    # ------------------------------------------------------------------ initialisation (mbe.py:1183-1237)
+    def initialize(self, eri_, initialize_fragment_idx=None):
+        fo = self.fobj
+        for I in range(fo.n_frag):
+            f = Frags(fo.AO_per_frag[I], I, fo.AO_per_edge_per_frag[I], fo.ref_frag_idx_per_edge_per_frag[I],
+                      fo.relAO_per_edge_per_frag[I], fo.relAO_in_ref_per_edge_per_frag[I],
+                      fo.weight_and_relAO_per_center_per_frag[I], fo.relAO_per_origin_per_frag[I], lib=self.lib)
+            self.Fobjs.append(f)
+        couti = 0
+        for f in self.Fobjs:
+            f.udim = couti
+            couti = f.set_udim(couti)
+        self.emap = ErrorMap(self.Fobjs) if fo.n_BE != 1 and any(fo.relAO_per_edge_per_frag) else None
+        # Schmidt decomposition of every fragment this rank may own (cheap; sizes decide the partition)
+        for f in self.Fobjs:
+            f.sd(self.W, self.lmo_coeff, self.Nocc, thr_bath=self.thr_bath)
+            f.get_nsocc(self.S, self.C, self.Nocc)
+        costs = [fragment_cost(f.nao, f.nsocc) for f in self.Fobjs]
+        self.owner = partition_fragments(costs, self.world)
+        if initialize_fragment_idx is None:
+            initialize_fragment_idx = [i for i in range(fo.n_frag) if self.owner[i] == self.rank]
+        self.my_frags = list(initialize_fragment_idx)
+        self._eri_transform(eri_, self.my_frags)
+        self._initialize_fragments(self.my_frags)
+
+    def _eri_transform(self, eri_, idx):
+        """BE._eri_transform (mbe.py:1004-1113) with the device literals of eri_transform.HIP_INT_TRANSFORMS."""
+        it = self.int_transform
+        if it in ("in-core-hip", "in-core"):
+            if eri_ is None:
+                raise ValueError("ERIs have to be available in memory.")      # mbe.py:1036
+            ao = et.AOEri(eri_, self.S.shape[0], lib=self.lib)
+            for I in idx:
+                ao.transform(self.Fobjs[I].TA, frag=self.Fobjs[I].dev, want_host=False)
+            ao.free()
+        elif it in ("int-direct-DF-hip", "sparse-DF-hip"):
+            if self._df_ints is None:
+                raise ValueError("df_ints=(ints, j2c, layout) has to be given for a DF transform")
+            ints, j2c, layout = self._df_ints
+            df = et.DFContext(j2c=j2c, lib=self.lib)
+            df.set_ints(ints, self.S.shape[0], layout)
+            for I in idx:
+                df.transform(self.Fobjs[I].TA, frag=self.Fobjs[I].dev, want_host=False)
+            df.free()
+        else:
+            raise ValueError(f"int_transform {it!r} is not one of {et.HIP_INT_TRANSFORMS}")
+
+    def _initialize_fragments(self, idx):
+        """mbe.py:1116-1180: h1, Fock, fragment SCF, dm0, fragment HF energies, HF-in-HF check."""
+        E_hf = 0.0
+        for I in idx:
+            f = self.Fobjs[I]
+            f.h1 = f.TA.T @ self.hcore @ f.TA
+            f.cons_fock(self.hf_veff, self.S, self.hf_dm)
+            f.heff = np.zeros_like(f.h1)
+            f.scf(fs=True, opts=self.opts)
+            f.dm0 = 2.0 * f._mo_coeffs[:, : f.nsocc] @ f._mo_coeffs[:, : f.nsocc].T
+            f.update_ebe_hf()
+            E_hf += f.ebe_hf
+        buf = np.array([E_hf])
+        if self.world > 1:
+            all_reduce_sum(buf)
+        self.ebe_hf = float(buf[0]) + self.enuc + self.E_core
+        self.hf_err = self.hf_etot - self.ebe_hf
+        if self.rank == 0:
+            print(f"HF-in-HF error                 :  {self.hf_err:>.4e} Ha", flush=True)
+
+    # ------------------------------------------------------------------ sweeps
+    def _sweep(self, pot, **kw):
+        if self.world > 1:
+            return be_func_parallel(pot, self.Fobjs, self.Nocc, "CCSD", self.enuc, owner=self.owner, opts=self.opts,
+                                    stats=self.stats, emap=self.emap, **kw)
+        return be_func(pot, self.Fobjs, self.Nocc, "CCSD", self.enuc, opts=self.opts, stats=self.stats, **kw)
+
+    def oneshot(self, solver="CCSD", use_cumulant=True, nproc=1, ompnum=1, solver_args=None):
+        """mbe.py:1240-1310."""
+        if solver != "CCSD":
+            raise ValueError("Solver not implemented")
+        rets = self._sweep(None, eeval=True, use_cumulant=use_cumulant, return_vec=False)
+        self.ebe_tot = rets[0] + self.ebe_hf
+        self.e_corr = rets[0]
+        self.e_components = rets[1]
+        if self.rank == 0:
+            print(f"One-shot BE  E_corr = {rets[0]:.12f}  Tr(F del g) = {rets[1][0] + rets[1][2]:.10f}  Tr(V K) = {rets[1][1]:.10f}"
+                  f"  E_tot = {self.ebe_tot:.10f}", flush=True)
+        return rets
+
+    def optimize(self, solver="CCSD", method="QN", only_chem=False, use_cumulant=True, conv_tol=1.0e-6, relax_density=False,
+                 jac_solver="HF", nproc=1, ompnum=1, max_iter=500, trust_region=False, step_size=1e-6, solver_args=None):
+        """mbe.py:841-977."""
+        from .opt import BEOPT
+        from .jacobian import get_be_error_jacobian
+        if solver != "CCSD":
+            raise ValueError("Solver not implemented")
+        if method != "QN":
+            raise ValueError("This optimization method for BE is not supported")
+        if not only_chem:
+            pot = self.pot
+            if self.fobj.n_BE == 1:
+                raise ValueError("BE1 only works with chemical potential optimization. Set only_chem=True")
+        else:
+            pot = [0.0]
+        be_ = BEOPT(pot, self.Fobjs, self.Nocc, self.enuc, solver=solver, only_chem=only_chem, use_cumulant=use_cumulant,
+                    max_space=max_iter, conv_tol=conv_tol, relax_density=relax_density, ebe_hf=self.ebe_hf,
+                    sweep=self._sweep, verbose=self.rank == 0)
+        J0 = get_be_error_jacobian(self.fobj.n_frag, self.Fobjs, jac_solver=jac_solver, owner=self.owner, rank=self.rank,
+                                   world=self.world, opts=self.opts)
+        if only_chem:
+            J0 = J0[-1:, -1:]
+        be_.optimize(method, J0=J0, trust_region=trust_region)
+        self.pot = list(be_.pot)
+        self.ebe_tot = be_.Ebe[0] + self.ebe_hf
+        self.e_corr = be_.Ebe[0]
+        self.e_components = be_.Ebe[1]
+        self.beopt = be_
+        if self.rank == 0:
+            print(f"BE optimised  E_corr = {be_.Ebe[0]:.12f}  E_tot = {self.ebe_tot:.10f}  iterations = {be_.iter}", flush=True)
+        return be_

@@ -1,0 +1,132 @@
+"""be_func / solve_error / solve_ccsd -- host mirror of molbe/solver.py over the device fragment solver.
+
+`be_func` keeps the reference's signature (molbe/solver.py:244-257) for solver == "CCSD"; every other solver
+string of the reference (MP2, FCI, SCI, DMRG, ...) is a different code path of QuEmb that this package does
+not replace and raises ValueError("Solver not implemented") exactly like the reference's final else (:490-491).
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+from .fragsolver import DeviceFragment, default_opts
+
+
+class ErrorMap:
+    """Static index map of solve_error (molbe/solver.py:683-778): which (fragment, row, col) of the fragment 1-RDMs
+    feed each slot of err_edge / err_cen.  Built once; evaluating the residual is then two gathers -- and in the
+    multi-GPU sweep the same map tells each rank which slots of the all-reduce buffer it owns."""
+
+    def __init__(self, Fobjs):
+        ef, er, ec = [], [], []
+        cf, cr, cc = [], [], []
+        cenf, ceni = [], []
+        for fidx, f in enumerate(Fobjs):
+            for edge in f.relAO_per_edge:
+                for j in range(len(edge)):
+                    for k in range(j, len(edge)):
+                        ef.append(fidx); er.append(edge[j]); ec.append(edge[k])
+            for i in f.weight_and_relAO_per_center[1]:
+                cenf.append(fidx); ceni.append(i)
+        for f in Fobjs:
+            for cidx, cens in enumerate(f.relAO_in_ref_per_edge):
+                ref = f.ref_frag_idx_per_edge[cidx]
+                for j in range(len(cens)):
+                    for k in range(j, len(cens)):
+                        cf.append(ref); cr.append(cens[j]); cc.append(cens[k])
+        self.edge = (np.array(ef, dtype=int), np.array(er, dtype=int), np.array(ec, dtype=int))
+        self.cen = (np.array(cf, dtype=int), np.array(cr, dtype=int), np.array(cc, dtype=int))
+        self.diag = (np.array(cenf, dtype=int), np.array(ceni, dtype=int))
+        if len(self.edge[0]) != len(self.cen[0]):
+            raise ValueError("edge / centre matching lists have different lengths")
+        self.n_match = len(self.edge[0])
+
+    def fill(self, Fobjs, owned, edge_vals, cen_vals):
+        """Add the contributions of the fragments in `owned` to the (zero-initialised) buffers; returns the
+        centre-diagonal partial sum (the chemical-potential condition)."""
+        owned = set(owned)
+        tr = 0.0
+        f, r, c = self.edge
+        for s in range(self.n_match):
+            if f[s] in owned:
+                edge_vals[s] += Fobjs[f[s]]._rdm1[r[s], c[s]]
+        f, r, c = self.cen
+        for s in range(self.n_match):
+            if f[s] in owned:
+                cen_vals[s] += Fobjs[f[s]]._rdm1[r[s], c[s]]
+        f, i = self.diag
+        for s in range(len(f)):
+            if f[s] in owned:
+                tr += Fobjs[f[s]]._rdm1[i[s], i[s]]
+        return tr
+
+
+def solve_error(Fobjs, Nocc, only_chem=False, rdm1_list=None):
+    """molbe/solver.py:683-778: (norm, err_vec).  err_vec = [edge elements ..., sum centre diag / nkpt] -
+    [centre elements read from the reference fragments ..., Nocc]; norm = sqrt(mean(err^2))."""
+    if rdm1_list is not None:
+        class _V:  # lightweight view so that ErrorMap can index `._rdm1`
+            def __init__(self, f, r):
+                self.__dict__.update(f.__dict__); self._rdm1 = r
+        Fobjs = [_V(f, r) for f, r in zip(Fobjs, rdm1_list)]
+    emap = ErrorMap(Fobjs)
+    edge = np.zeros(emap.n_match); cen = np.zeros(emap.n_match)
+    tr = emap.fill(Fobjs, range(len(Fobjs)), edge, cen) / Fobjs[0].unitcell_nkpt
+    if only_chem:
+        err = tr - Nocc
+        return abs(err), np.asarray([err])
+    err_vec = np.append(edge, tr) - np.append(cen, Nocc)
+    return float(np.mean(err_vec * err_vec) ** 0.5), err_vec
+
+
+def solve_ccsd(h, eri_s4, nsocc, dm0=None, *, n_frag=0, rdm_return=False, rdm2_return=False, relax=False, use_cumulant=True,
+               opts=None, lib=None):
+    """Device counterpart of solve_ccsd (molbe/solver.py:829-946).  The reference takes a PySCF mean-field object;
+    here the fragment RHF is part of the device call, so the inputs are what `get_scfObj` would have been given:
+    h = fock + heff, the 4-fold packed fragment ERIs, nsocc and dm0.
+    Returns (t1, t2) or (t1, t2, rdm1_mo, mo_coeff) with rdm_return.  The dense 2-RDM is never formed on the device
+    (rdm2_return raises): its only consumer, get_frag_energy, is evaluated in contracted form by `Frags.solve`."""
+    if relax:
+        raise NotImplementedError("relaxed CCSD densities (Lambda equations) are a 'next' row (SURVEY 8f.3)")
+    if rdm2_return:
+        raise NotImplementedError("the n^4 2-RDM is not materialised; use Frags.solve(eeval=True) for energies")
+    n = h.shape[0]
+    fr = DeviceFragment(n, n_frag, lib=lib)
+    fr.set_eri_s4(eri_s4)
+    out = fr.solve(nsocc, h, dm0, opts=opts, eeval=False, want_t2=True)
+    fr.free()
+    if rdm_return:
+        return out["t1"], out["t2"], out["rdm1_mo"], out["mo_coeff"]
+    return out["t1"], out["t2"]
+
+
+def be_func(pot, Fobjs, Nocc, solver, enuc, solver_args=None, scratch_dir=None, only_chem=False, eeval=False,
+            relax_density=False, return_vec=False, use_cumulant=True, *, opts=None, stats=None):
+    """molbe/solver.py:244-562 for solver == 'CCSD'.  `opts` (qemb_solver_opts) and `stats` (dict collecting
+    per-sweep counters) are additions; everything else has the reference's meaning."""
+    if solver != "CCSD":
+        raise ValueError("Solver not implemented")
+    if relax_density:
+        raise NotImplementedError("relax_density=True needs the CCSD Lambda equations (SURVEY 8f.3)")
+    total_e = [0.0, 0.0, 0.0]
+    n_iter = 0
+    for fobj in Fobjs:
+        if pot is not None:
+            fobj.update_heff(pot, only_chem=only_chem)
+        assert fobj.fock is not None and fobj.heff is not None
+        out = fobj.solve(opts=opts, eeval=eeval, use_cumulant=use_cumulant)
+        n_iter += out["n_iter"]
+        if eeval:
+            total_e = [a + b for a, b in zip(total_e, out["e_frag"])]
+    if stats is not None:
+        stats["ccsd_iterations"] = stats.get("ccsd_iterations", 0) + n_iter
+        stats["fragments"] = stats.get("fragments", 0) + len(Fobjs)
+    Ecorr = sum(total_e)
+    if eeval and not return_vec:
+        return (Ecorr, total_e)
+    ernorm, ervec = solve_error(Fobjs, Nocc, only_chem=only_chem)
+    if eeval:
+        return (ernorm, ervec, [Ecorr, total_e])
+    if return_vec:
+        return (ernorm, ervec, None)
+    return ernorm
