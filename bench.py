@@ -1,0 +1,250 @@
+#!/usr/bin/env python
+"""bench.py -- fragment-sweep throughput of the MI355X hot path.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (BASELINE.json configs[2], the one the metric's n_occ/n_virt and the 1/2/4/8-GPU scaling are quoted on;
+configs[1] -- octane BE2 -- is a parity case in tests/): F synthetic fragments PER GPU (weak scaling), each
+n = 220 embedding orbitals, n_occ = 20, n_virt = 200, DF-factorised 8-fold-symmetric ERIs (SURVEY.md 8d family,
+seed 20260803 + global fragment index; ERI scale 0.03), ERIs resident in HBM before timing.
+
+One STEP = one be_func sweep (one objective evaluation of the density-matching loop, molbe/solver.py:244) over the
+rank's fragments: per fragment  fragment RHF -> embedding->MO integral transform -> RCCSD to convergence ->
+1-RDM -> fragment energy;  then ONE all-reduce (RCCL) of the residual/energy buffer.  Nothing is cached between
+steps (amplitudes restart from MP2 exactly like the reference).
+value = CCSD iterations completed by all ranks in the K timed steps / wall time (max over ranks).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+PEAK_FP64_MFMA_TFLOPS = 78.6     # MI355X FP64 matrix peak (AMD spec; == the FP64 vector peak). The MI355X guide
+                                 # lists no f64 row; see DESIGN.md "Roofline".
+SEED0 = 20260803
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--frags-per-gpu", type=int, default=8)
+    ap.add_argument("--n", type=int, default=220)
+    ap.add_argument("--nocc", type=int, default=20)
+    ap.add_argument("--scale", type=float, default=0.03)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-iters", type=int, default=1)
+    return ap.parse_args()
+
+
+def make_fragment(lib, n, nf, seed, scale):
+    """Synthetic fragment: h on the host, ERIs built on the device from the DF factor and left resident."""
+    from quemb_amd._lib import DeviceBuffer, check
+    from quemb_amd.fragsolver import DeviceFragment
+    rng = np.random.default_rng(seed)
+    naux = 3 * n
+    B = scale * rng.standard_normal((naux, n, n))
+    B = 0.5 * (B + B.transpose(0, 2, 1))
+    il = np.tril_indices(n)
+    Bp = np.ascontiguousarray(B[:, il[0], il[1]])
+    npair = Bp.shape[1]
+    dB = DeviceBuffer.from_numpy(Bp)
+    d4 = DeviceBuffer(npair * npair)
+    check(lib.qemb_op_gemm(npair, npair, naux, 1.0, dB.ptr, npair, 0, 0, dB.ptr, npair, 0, 0, 0.0, d4.ptr, npair, 0, 1))
+    A = rng.standard_normal((n, n))
+    h = np.diag(2.0 * np.arange(n)) + 0.3 * 0.5 * (A + A.T)
+    fr = DeviceFragment(n, nf)
+    fr.set_eri_s4_dev(d4.ptr)
+    dB.free(); d4.free()
+    V = rng.standard_normal((n, n)); veff0 = 0.05 * (V + V.T)
+    fr.set_energy_data(h, veff0, None, 1.0, list(range(nf)))
+    return fr, h, B
+
+
+def read_timer(lib, slot):
+    ms = C.c_double(); cnt = C.c_int64()
+    lib.qemb_timer_read(slot, C.byref(ms), C.byref(cnt))
+    return ms.value, cnt.value
+
+
+def cpu_baseline(n, o, scale, iters):
+    """The oracle ('port') on the host cores: one fragment of the same family, integrals assembled from its DF
+    factor, `iters` full RCCSD amplitude updates at (n_occ, n_virt) = (o, n - o)."""
+    sys.path.insert(0, str(ROOT / "oracle"))
+    from qemb_oracle import ccsd_lean
+    rng = np.random.default_rng(SEED0)
+    naux = 3 * n
+    B = scale * rng.standard_normal((naux, n, n)); B = 0.5 * (B + B.transpose(0, 2, 1))
+    A = rng.standard_normal((n, n)); h = np.diag(2.0 * np.arange(n)) + 0.3 * 0.5 * (A + A.T)
+    # RHF through the DF factor (cheap), canonical MOs
+    w, c = np.linalg.eigh(h); dm = 2 * c[:, :o] @ c[:, :o].T
+    Bf = B.reshape(naux, -1)
+    fs, es = [], []
+    for _ in range(50):
+        J = (Bf.T @ (Bf @ dm.ravel())).reshape(n, n)
+        BD = B @ dm
+        K = np.tensordot(BD, B, axes=([0, 2], [0, 2]))
+        F = h + J - 0.5 * K
+        err = F @ dm - dm @ F
+        if np.linalg.norm(err) < 1e-8:
+            break
+        fs.append(F); es.append(err); fs, es = fs[-8:], es[-8:]
+        m = len(fs)
+        if m > 1:
+            Bm = np.zeros((m + 1, m + 1)); Bm[-1, :] = Bm[:, -1] = 1; Bm[-1, -1] = 0
+            for i in range(m):
+                for j in range(m):
+                    Bm[i, j] = np.vdot(es[i], es[j])
+            rhs = np.zeros(m + 1); rhs[-1] = 1
+            F = sum(a * b for a, b in zip(np.linalg.solve(Bm, rhs)[:m], fs))
+        w, c = np.linalg.eigh(F); dm = 2 * c[:, :o] @ c[:, :o].T
+    Bmo = np.einsum("Ppq,pi->Piq", B, c, optimize=True)
+    Bmo = np.einsum("Piq,qj->Pij", Bmo, c, optimize=True)
+    t0 = time.perf_counter()
+    er = ccsd_lean.LeanEris(Bmo, o, w)
+    t_setup = time.perf_counter() - t0
+    eo, ev = w[:o], w[o:]
+    eia = eo[:, None] - ev[None, :]
+    t1 = np.zeros((o, n - o)); t2 = er.ovov.transpose(0, 2, 1, 3) / (eia[:, None, :, None] + eia[None, :, None, :])
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        t1, t2 = ccsd_lean.update_amps(t1, t2, er)
+    dt = (time.perf_counter() - t0) / iters
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
+    return dict(value=1.0 / dt, unit="CCSD iterations/s", cores=cores, kind="port",
+                sample=f"1 fragment of the same family (n_occ={o}, n_virt={n - o}), integrals from its DF factor "
+                       f"({t_setup:.1f} s, untimed), {iters} full RCCSD amplitude update(s) by oracle/qemb_oracle/ccsd_lean.py "
+                       f"(NumPy/BLAS, all host threads)", s_per_iteration=dt)
+
+
+def parity_probe():
+    """corr-E error vs the oracle on a small fragment of the same family (the metric's second half)."""
+    sys.path.insert(0, str(ROOT / "oracle")); sys.path.insert(0, str(ROOT / "tests"))
+    from helpers import synthetic_fragment
+    from qemb_oracle import ccsd, eri, scf
+    from quemb_amd.fragsolver import DeviceFragment, default_opts
+    n, o = 26, 6
+    h, e1 = synthetic_fragment(n, o, SEED0)
+    fr = DeviceFragment(n, 6); fr.set_eri_s4(eri.pack_s4(e1))
+    out = fr.solve(o, h, opts=default_opts(), eeval=False)
+    mf = scf.rhf(h, e1, o)
+    _, _, ecc, _ = ccsd.solve_ccsd(h, e1, o, mf["mo_coeff"], mf["mo_energy"])
+    fr.free()
+    return abs(out["e_corr_mo"] - ecc)
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); lrank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(lrank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", lrank))
+    from quemb_amd import _lib
+    from quemb_amd.fragsolver import default_opts
+    lib = _lib.init(lrank)
+    n, o, F = args.n, args.nocc, args.frags_per_gpu
+    v = n - o
+    nf = min(22, n // 2)
+    opts = default_opts()
+
+    # ---- set-up (untimed): fragments resident in HBM, initial fragment SCF for dm0 (BE.initialize does the same)
+    frs = []
+    for i in range(F):
+        fr, h, _ = make_fragment(lib, n, nf, SEED0 + rank * F + i, args.scale)
+        r = fr.scf(o, h, None, opts=opts)
+        dm0 = 2.0 * r["mo_coeff"][:, :o] @ r["mo_coeff"][:, :o].T
+        frs.append((fr, h, dm0))
+    sync = torch.cuda.synchronize if torch.cuda.is_available() else (lambda: None)
+
+    buf_t = torch.zeros(8, dtype=torch.float64, device=torch.device("cuda", lrank)) if world > 1 else None
+
+    def sweep():
+        acc = np.zeros(8)
+        for fr, h, dm0 in frs:
+            out = fr.solve(o, h, dm0, opts=opts, eeval=True)
+            acc[0] += out["n_iter"]; acc[1:4] += out["e_frag"]; acc[4] += np.trace(out["rdm1_emb"][:nf, :nf]); acc[5] += out["e_corr_mo"]; acc[6] += 1
+        if world > 1:      # the one exchange of a sweep: residual/energy buffer, RCCL sum-all-reduce
+            buf_t.copy_(torch.from_numpy(acc))
+            dist.all_reduce(buf_t, op=dist.ReduceOp.SUM)
+            acc = buf_t.cpu().numpy()
+        return acc
+
+    for _ in range(args.warmup):
+        sweep()
+    for s in range(8):
+        lib.qemb_timer_reset(s)
+    if world > 1:
+        dist.barrier()
+    lib.qemb_sync(); sync()
+    t0 = time.perf_counter()
+    tot = np.zeros(8)
+    for _ in range(args.steps):
+        tot += sweep()
+    lib.qemb_sync(); sync()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=torch.device("cuda", lrank))
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    else:
+        pass
+    # `tot` is already summed over ranks inside sweep() when world > 1
+    n_iter_total = float(tot[0]); n_frag_total = float(tot[6])
+
+    if rank == 0:
+        lad_ms, lad_cnt = read_timer(lib, 0)
+        it_ms, it_cnt = read_timer(lib, 2)
+        ao_ms, ao_cnt = read_timer(lib, 3)
+        scf_ms, scf_cnt = read_timer(lib, 4)
+        ring_ms, ring_cnt = read_timer(lib, 1)
+        lad_avg = lad_ms / max(lad_cnt, 1) * 1e-3
+        flop_ladder = 2.0 * o * o * float(v) ** 4
+        achieved = flop_ladder / lad_avg / 1e12 if lad_avg > 0 else 0.0
+        res = {
+            "metric": "fragment CCSD iters/sec (full BE sweep over synthetic n_occ=20 n_virt=200 fragments); corr-E error vs oracle in parity_max_abs_err_Eh",
+            "value": n_iter_total / dt, "unit": "CCSD iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[2]: synthetic fragment sweep, {F} fragments per GPU ({F * world} total), "
+                                   f"n_occ={o} n_virt={v} (n={n}), DF-factorised ERIs naux={3 * n} scale={args.scale}, "
+                                   "one be_func sweep per step (fragment RHF + MO transform + RCCSD to |dE|<1e-10 + energies + 1 all-reduce)",
+                       "fragments_per_gpu": F, "n_occ": o, "n_virt": v, "parallelism": f"fragments sharded over {world} GPU(s), 1 RCCL all-reduce per sweep"},
+            "fragments_per_s": n_frag_total / dt,
+            "ccsd_iterations_per_fragment": n_iter_total / max(n_frag_total, 1),
+            "mean_e_corr_per_fragment": float(tot[5]) / max(n_frag_total, 1),
+            "roofline": {"bound": "mfma", "kernel": "dgemm_mfma_kernel (pp-ladder tau[ij,cd] x W[ab,cd], M=o^2 N=v^2 K=v^2)",
+                         "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_MFMA_TFLOPS,
+                         "traffic": None, "avg_launch_ms": lad_avg * 1e3, "launches": lad_cnt, "flop_per_launch": flop_ladder},
+            "device_time_ms_rank0": {"ccsd_iteration_avg": it_ms / max(it_cnt, 1), "ccsd_iterations": it_cnt, "rings_avg": ring_ms / max(ring_cnt, 1),
+                                     "mo_transform_avg": ao_ms / max(ao_cnt, 1), "fragment_scf_avg": scf_ms / max(scf_cnt, 1)},
+        }
+        if world == 1:
+            try:
+                res["parity_max_abs_err_Eh"] = parity_probe()
+            except Exception as e:  # noqa: BLE001
+                res["parity_max_abs_err_Eh"] = f"probe failed: {e}"
+            if not args.no_cpu_baseline:
+                res["cpu_baseline"] = cpu_baseline(n, o, args.scale, args.cpu_iters)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

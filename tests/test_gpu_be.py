@@ -1,0 +1,121 @@
+"""-m gpu: ERI transforms, Schmidt decomposition and the whole BE driver on the MI355X against the oracle and the
+reference's end-to-end golden energies (H8 and octane, STO-3G)."""
+import numpy as np
+import pytest
+
+from helpers import GOLDEN
+from qemb_oracle import eri as oeri
+from quemb_amd import eri_transform as et
+
+pytestmark = pytest.mark.gpu
+
+
+def test_dense_transform_matches_oracle(qlib):
+    rng = np.random.default_rng(50)
+    N, n = 26, 11
+    Bm = rng.standard_normal((40, N, N)); Bm = Bm + Bm.transpose(0, 2, 1)
+    e1 = np.einsum("Ppq,Prs->pqrs", Bm, Bm)
+    TA = np.linalg.qr(rng.standard_normal((N, N)))[0][:, :n]
+    ref = oeri.ao2mo_full(e1, TA)
+    for arr in (e1, oeri.pack_s4(e1), oeri.pack_s8(e1)):
+        ao = et.AOEri(arr, N)
+        got = ao.transform(TA)
+        assert np.abs(got - ref).max() < 1e-11 * np.abs(ref).max()
+
+
+def test_df_transform_matches_oracle_and_dense(qlib):
+    rng = np.random.default_rng(51)
+    N, n, naux = 20, 9, 260
+    L = rng.standard_normal((naux, N, N)); L = L + L.transpose(0, 2, 1)
+    A = rng.standard_normal((naux, naux)); j2c = A @ A.T + naux * np.eye(naux)
+    pqL = np.ascontiguousarray(L.transpose(1, 2, 0))
+    TA = np.linalg.qr(rng.standard_normal((N, N)))[0][:, :n]
+    ref = oeri.integral_direct_DF(pqL, j2c, TA)
+    il = np.tril_indices(N)
+    for layout, ints in [("pqL", pqL), ("Lpq", L), ("packed", np.ascontiguousarray(L[:, il[0], il[1]]))]:
+        df = et.DFContext(j2c=j2c); df.set_ints(ints, N, layout)
+        assert np.abs(df.transform(TA) - ref).max() < 1e-10 * np.abs(ref).max()
+    df = et.DFContext(L_PQ=np.linalg.cholesky(j2c)); df.set_ints(L, N, "Lpq")
+    assert np.abs(df.transform(TA) - ref).max() < 1e-10 * np.abs(ref).max()
+    with pytest.raises(Exception):
+        et.DFContext(j2c=-np.eye(4))          # not positive definite -> error, like scipy.linalg.cholesky
+
+
+def test_schmidt_matches_reference_goldens(qlib):
+    g = np.load(GOLDEN / "schmidt.npz")
+    for case in range(4):
+        Cm, nocc, frag = g[f"C{case}"], int(g[f"nocc{case}"]), list(g[f"frag{case}"])
+        TA, nf, nb = et.schmidt_decomposition(Cm, nocc, frag)
+        ref = g[f"TA{case}"]
+        assert (nf, nb) == tuple(g[f"nfnb{case}"]) and TA.shape == ref.shape
+        assert np.array_equal(TA[:, :nf], ref[:, :nf])
+        assert np.abs(TA @ TA.T - ref @ ref.T).max() < 1e-10
+        assert np.abs(TA.T @ TA - np.eye(nf + nb)).max() < 1e-11
+        D = Cm[:, :nocc] @ Cm[:, :nocc].T
+        TAs = et.schmidt_decomp_svd(D, frag)
+        assert np.abs(TAs @ TAs.T - g[f"TAsvd{case}"] @ g[f"TAsvd{case}"].T).max() < 1e-9
+
+
+def test_schmidt_large_environment(qlib):
+    """N_lo = 600: eigh of a 578 x 578 projector block by Jacobi sweeps; compared with LAPACK through projectors."""
+    rng = np.random.default_rng(52)
+    N, nocc = 600, 150
+    frag = list(range(100, 122))
+    Cm = np.linalg.qr(rng.standard_normal((N, N)))[0]
+    TA, nf, nb = et.schmidt_decomposition(Cm, nocc, frag)
+    from qemb_oracle import schmidt as os_
+    ref, _, nbr = os_.schmidt_decomposition(Cm, nocc, frag)
+    assert nb == nbr == 22
+    assert np.abs(TA @ TA.T - ref @ ref.T).max() < 1e-9
+    D = Cm[:, :nocc] @ Cm[:, :nocc].T
+    assert abs(np.trace(TA.T @ D @ TA) - round(np.trace(TA.T @ D @ TA))) < 1e-9     # integer electron pairs in the embedding
+
+
+def _be(which, **kw):
+    from quemb_amd.fragpart import FragPart
+    from quemb_amd.integrals import RHF, Mole
+    from quemb_amd.mbe import BE
+    if which == "h8":
+        mol = Mole([["H", (0.0, 0.0, float(i))] for i in range(8)]); key = "test_autogen_h_linear_be2"
+    else:
+        mol = Mole(GOLDEN / "octane.xyz"); key = "test_autogen_octane_be2"
+    mf = RHF(mol); mf.kernel()
+    return mf, BE(mf, FragPart.from_json(GOLDEN / "fragmentation.json", key), distribute=False, **kw)
+
+
+def test_h8_oneshot_golden(qlib):
+    mf, be = _be("h8")
+    assert abs(be.hf_err) < 1e-8
+    e, _ = be.oneshot()
+    assert abs(e - (-0.13198886164212092)) < 3e-7      # tests/_expected_data_for_fragmentation_test.py:983 (PySCF conv_tol 1e-7)
+
+
+def test_octane_hf_oneshot_and_density_matching_goldens(qlib):
+    mf, be = _be("octane")
+    assert abs(mf.e_tot - (-309.7847696458918)) < 5e-8          # tests/molbe_octane_test.py:32-36 (E_HF)
+    assert abs(be.ebe_hf - (-309.7847696458918)) < 5e-8         # HF-in-HF
+    e, _ = be.oneshot()
+    assert abs(e - (-0.5499456086311243)) < 5e-7                # tests/_expected_data_for_fragmentation_test.py:984
+    opt = be.optimize(solver="CCSD", only_chem=False)           # reference defaults: conv_tol 1e-6, QN, HF Jacobian
+    assert opt.err < 1e-6
+    # tests/molbe_octane_test.py:32-36: E_corr = -0.5499514850769742, E_tot = -310.3347211309688 (np.isclose, rtol 1e-5)
+    assert abs(be.e_corr - (-0.5499514850769742)) < 5e-6
+    assert abs(be.ebe_tot - (-310.3347211309688)) < 5e-6
+
+
+def test_h8_df_transform_path(qlib):
+    """int-direct-DF-hip with a (numerically) complete auxiliary set reproduces the in-core result."""
+    from quemb_amd.fragpart import FragPart
+    from quemb_amd.integrals import RHF, Mole
+    from quemb_amd.mbe import BE
+    mol = Mole([["H", (0.0, 0.0, float(i))] for i in range(8)])
+    mf = RHF(mol); mf.kernel()
+    N = mol.nao
+    e1 = mf._eri
+    il = np.tril_indices(N)
+    j2c = oeri.pack_s4(e1) + 1e-10 * np.eye(N * (N + 1) // 2)      # AO pairs as the auxiliary set
+    pqL = np.zeros((N, N, j2c.shape[0])); pqL[il[0], il[1], :] = oeri.pack_s4(e1); pqL[il[1], il[0], :] = oeri.pack_s4(e1)
+    fobj = FragPart.from_json(GOLDEN / "fragmentation.json", "test_autogen_h_linear_be2")
+    be_df = BE(mf, fobj, int_transform="int-direct-DF-hip", df_ints=(pqL, j2c, "pqL"), distribute=False)
+    be_in = BE(mf, fobj, distribute=False)
+    assert abs(be_df.oneshot()[0] - be_in.oneshot()[0]) < 1e-6

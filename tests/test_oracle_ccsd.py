@@ -137,3 +137,22 @@ def test_rhf_is_a_fixed_point():
     C, F = mf["mo_coeff"], mf["fock"]
     assert np.abs(C.T @ F @ C - np.diag(mf["mo_energy"])).max() < 1e-9
     assert np.abs(C.T @ C - np.eye(8)).max() < 1e-12
+
+
+def test_lean_update_matches_reference_form():
+    """ccsd_lean.update_amps (bench cpu_baseline) == ccsd.update_amps on a DF-factorised fragment."""
+    from qemb_oracle import ccsd_lean
+    n, o = 9, 3
+    rng = np.random.default_rng(21)
+    B = 0.1 * rng.standard_normal((20, n, n)); B = 0.5 * (B + B.transpose(0, 2, 1))
+    e1 = np.einsum("Ppq,Prs->pqrs", B, B)
+    A = rng.standard_normal((n, n)); h = np.diag(2.0 * np.arange(n)) + 0.15 * (A + A.T)
+    mf = scf.rhf(h, e1, o)
+    C = mf["mo_coeff"]
+    eris = ccsd.Eris(e1, C, o, mo_energy=mf["mo_energy"])
+    lean = ccsd_lean.LeanEris(np.einsum("Ppq,pi,qj->Pij", B, C, C), o, mf["mo_energy"])
+    t1, t2 = ccsd.init_amps(eris)
+    t1 = t1 + 0.01 * rng.standard_normal(t1.shape)           # exercise the t1 terms
+    a1, a2 = ccsd.update_amps(t1, t2, eris)
+    b1, b2 = ccsd_lean.update_amps(t1, t2, lean)
+    assert np.abs(a1 - b1).max() < 1e-12 and np.abs(a2 - b2).max() < 1e-12

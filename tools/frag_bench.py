@@ -12,10 +12,11 @@ from quemb_amd._lib import DeviceBuffer, check
 from quemb_amd.fragsolver import DeviceFragment, default_opts
 
 
-def synthetic_on_device(lib, n, seed, naux=None, scale=0.06, gap=2.0):
+def synthetic_on_device(lib, n, seed, naux=None, scale=None, gap=2.0):
     """h (host) and the s4-packed ERIs built ON THE DEVICE from the DF factor (B^T B over packed pairs)."""
     rng = np.random.default_rng(seed)
     naux = naux or 3 * n
+    scale = 0.06 * min(1.0, (55.0 / n) ** 0.5) if scale is None else scale
     B = scale * rng.standard_normal((naux, n, n))
     B = 0.5 * (B + B.transpose(0, 2, 1))
     il = np.tril_indices(n)
