@@ -33,6 +33,15 @@ PEAK_FP64_MFMA_TFLOPS = 78.6     # MI355X FP64 matrix peak (AMD spec; == the FP6
 SEED0 = 20260803
 
 
+T_START = time.perf_counter()
+
+
+def log(msg):
+    """progress on stderr (the JSON line is the only thing on stdout)"""
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench {time.perf_counter() - T_START:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -44,6 +53,8 @@ def parse():
     ap.add_argument("--scale", type=float, default=0.03)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=1)
+    ap.add_argument("--cpu-worker", type=str, default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-threads", type=int, default=16, help="BLAS threads of the CPU baseline (the box's CPU share of one GPU)")
     return ap.parse_args()
 
 
@@ -77,54 +88,60 @@ def read_timer(lib, slot):
     return ms.value, cnt.value
 
 
-def cpu_baseline(n, o, scale, iters):
-    """The oracle ('port') on the host cores: one fragment of the same family, integrals assembled from its DF
-    factor, `iters` full RCCSD amplitude updates at (n_occ, n_virt) = (o, n - o)."""
+def cpu_baseline(fr, h, dm0, o, opts, iters, threads, timeout_s=300):
+    """The oracle ('port') on the host cores, timed on a bounded sample of the SAME workload: fragment 0 of this rank,
+    its MO integrals exported from the device (so no CPU time goes into re-deriving inputs), `iters` full RCCSD
+    amplitude updates (oracle/qemb_oracle/ccsd_lean.py, NumPy/BLAS) starting from the MP2 guess.  Runs in a child
+    process with the BLAS thread count pinned through the environment and a hard timeout."""
+    import shutil
+    import subprocess
+    import tempfile
+    n = fr.n
+    v = n - o
+    fr.prepare_ccsd(o, h, dm0, opts=opts)
+    shapes = dict(oooo=(o, o, o, o), ovoo=(o, v, o, o), ovov=(o, v, o, v), ovvv=(o, v, v, v), Vl=(v, v, v, v),
+                  W1base=(o, v, o, v), W2base=(o, v, o, v), eo=(o,), ev=(v,))
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    d = tempfile.mkdtemp(prefix="qemb_bench_", dir=base)
+    try:
+        for name, shp in shapes.items():
+            np.save(os.path.join(d, name + ".npy"), fr.ccsd_export(name, shp))
+        log(f"cpu_baseline: integrals exported to {d}; running {iters} amplitude update(s) on {threads} threads")
+        env = dict(os.environ, OMP_NUM_THREADS=str(threads), OPENBLAS_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads))
+        p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--cpu-worker", d, "--cpu-iters", str(iters), "--nocc", str(o)],
+                           env=env, capture_output=True, text=True, timeout=timeout_s)
+        if p.returncode != 0:
+            return dict(value=None, unit="CCSD iterations/s", cores=threads, kind="port", sample=f"worker failed: {p.stderr[-400:]}")
+        r = json.loads(p.stdout.strip().splitlines()[-1])
+        return dict(value=1.0 / r["s_per_iteration"], unit="CCSD iterations/s", cores=threads, kind="port",
+                    sample=f"fragment 0 of the timed workload (n_occ={o}, n_virt={v}); MO integrals exported from the device; "
+                           f"{iters} full RCCSD amplitude update(s) from the MP2 guess by oracle/qemb_oracle/ccsd_lean.py (NumPy/BLAS, {threads} threads)",
+                    s_per_iteration=r["s_per_iteration"], e_corr_after_sample=r["e_corr"])
+    except subprocess.TimeoutExpired:
+        return dict(value=None, unit="CCSD iterations/s", cores=threads, kind="port", sample=f"worker exceeded {timeout_s} s")
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def cpu_worker(d, o, iters):
+    """child process of cpu_baseline: load the exported blocks, time the oracle's amplitude update."""
     sys.path.insert(0, str(ROOT / "oracle"))
     from qemb_oracle import ccsd_lean
-    rng = np.random.default_rng(SEED0)
-    naux = 3 * n
-    B = scale * rng.standard_normal((naux, n, n)); B = 0.5 * (B + B.transpose(0, 2, 1))
-    A = rng.standard_normal((n, n)); h = np.diag(2.0 * np.arange(n)) + 0.3 * 0.5 * (A + A.T)
-    # RHF through the DF factor (cheap), canonical MOs
-    w, c = np.linalg.eigh(h); dm = 2 * c[:, :o] @ c[:, :o].T
-    Bf = B.reshape(naux, -1)
-    fs, es = [], []
-    for _ in range(50):
-        J = (Bf.T @ (Bf @ dm.ravel())).reshape(n, n)
-        BD = B @ dm
-        K = np.tensordot(BD, B, axes=([0, 2], [0, 2]))
-        F = h + J - 0.5 * K
-        err = F @ dm - dm @ F
-        if np.linalg.norm(err) < 1e-8:
-            break
-        fs.append(F); es.append(err); fs, es = fs[-8:], es[-8:]
-        m = len(fs)
-        if m > 1:
-            Bm = np.zeros((m + 1, m + 1)); Bm[-1, :] = Bm[:, -1] = 1; Bm[-1, -1] = 0
-            for i in range(m):
-                for j in range(m):
-                    Bm[i, j] = np.vdot(es[i], es[j])
-            rhs = np.zeros(m + 1); rhs[-1] = 1
-            F = sum(a * b for a, b in zip(np.linalg.solve(Bm, rhs)[:m], fs))
-        w, c = np.linalg.eigh(F); dm = 2 * c[:, :o] @ c[:, :o].T
-    Bmo = np.einsum("Ppq,pi->Piq", B, c, optimize=True)
-    Bmo = np.einsum("Piq,qj->Pij", Bmo, c, optimize=True)
-    t0 = time.perf_counter()
-    er = ccsd_lean.LeanEris(Bmo, o, w)
-    t_setup = time.perf_counter() - t0
-    eo, ev = w[:o], w[o:]
+    ld = lambda nm: np.load(os.path.join(d, nm + ".npy"))
+    eo, ev = ld("eo"), ld("ev")
+    W1, W2 = ld("W1base"), ld("W2base")
+    ovvo = np.ascontiguousarray(W1.transpose(2, 3, 1, 0))     # ovvo[k,c,a,i] = W1base[i,a,k,c]
+    oovv = np.ascontiguousarray(W2.transpose(2, 0, 1, 3))     # oovv[k,i,a,c] = W2base[i,a,k,c]
+    er = ccsd_lean.LeanEris.from_blocks(o, np.concatenate([eo, ev]), ld("oooo"), ld("ovoo"), ld("ovov"), oovv, ovvo, ld("ovvv"), ld("Vl"))
     eia = eo[:, None] - ev[None, :]
-    t1 = np.zeros((o, n - o)); t2 = er.ovov.transpose(0, 2, 1, 3) / (eia[:, None, :, None] + eia[None, :, None, :])
+    t1 = np.zeros((o, len(ev))); t2 = er.ovov.transpose(0, 2, 1, 3) / (eia[:, None, :, None] + eia[None, :, None, :])
     t0 = time.perf_counter()
     for _ in range(iters):
         t1, t2 = ccsd_lean.update_amps(t1, t2, er)
     dt = (time.perf_counter() - t0) / iters
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
-    return dict(value=1.0 / dt, unit="CCSD iterations/s", cores=cores, kind="port",
-                sample=f"1 fragment of the same family (n_occ={o}, n_virt={n - o}), integrals from its DF factor "
-                       f"({t_setup:.1f} s, untimed), {iters} full RCCSD amplitude update(s) by oracle/qemb_oracle/ccsd_lean.py "
-                       f"(NumPy/BLAS, all host threads)", s_per_iteration=dt)
+    tau = t2 + np.einsum("ia,jb->ijab", t1, t1)
+    e = float(np.sum((2 * er.ovov.transpose(0, 2, 1, 3) - er.ovov.transpose(0, 2, 3, 1)) * tau))
+    print(json.dumps(dict(s_per_iteration=dt, e_corr=e)), flush=True)
 
 
 def parity_probe():
@@ -145,6 +162,8 @@ def parity_probe():
 
 def main():
     args = parse()
+    if args.cpu_worker:
+        return cpu_worker(args.cpu_worker, args.nocc, args.cpu_iters)
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); lrank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     dist = None
@@ -162,6 +181,7 @@ def main():
 
     # ---- set-up (untimed): fragments resident in HBM, initial fragment SCF for dm0 (BE.initialize does the same)
     frs = []
+    log(f"setting up {F} fragments per GPU (n={n}, n_occ={o})")
     for i in range(F):
         fr, h, _ = make_fragment(lib, n, nf, SEED0 + rank * F + i, args.scale)
         r = fr.scf(o, h, None, opts=opts)
@@ -182,8 +202,10 @@ def main():
             acc = buf_t.cpu().numpy()
         return acc
 
+    log("fragments resident; warm-up sweeps")
     for _ in range(args.warmup):
         sweep()
+    log("timed sweeps")
     for s in range(8):
         lib.qemb_timer_reset(s)
     if world > 1:
@@ -206,6 +228,7 @@ def main():
     # `tot` is already summed over ranks inside sweep() when world > 1
     n_iter_total = float(tot[0]); n_frag_total = float(tot[6])
 
+    log(f"timed region done: {dt:.2f} s for {args.steps} step(s)")
     if rank == 0:
         lad_ms, lad_cnt = read_timer(lib, 0)
         it_ms, it_cnt = read_timer(lib, 2)
@@ -234,12 +257,14 @@ def main():
                                      "mo_transform_avg": ao_ms / max(ao_cnt, 1), "fragment_scf_avg": scf_ms / max(scf_cnt, 1)},
         }
         if world == 1:
+            log("parity probe vs oracle")
             try:
                 res["parity_max_abs_err_Eh"] = parity_probe()
             except Exception as e:  # noqa: BLE001
                 res["parity_max_abs_err_Eh"] = f"probe failed: {e}"
             if not args.no_cpu_baseline:
-                res["cpu_baseline"] = cpu_baseline(n, o, args.scale, args.cpu_iters)
+                fr0, h0, dm00 = frs[0]
+                res["cpu_baseline"] = cpu_baseline(fr0, h0, dm00, o, opts, args.cpu_iters, args.cpu_threads)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

@@ -146,6 +146,9 @@ int qemb_ccsd_solve(int n, int nsocc, int n_f, const double* h, const double* er
 int qemb_frag_prepare_ccsd(qemb_frag_t f, int nsocc, const double* h, const double* dm0, const qemb_solver_opts* opts);
 int qemb_frag_ccsd_iterate(qemb_frag_t f, int niter, double* e_corr, double* normt);
 int qemb_frag_ccsd_reset(qemb_frag_t f);
+/* copy one MO-integral block of the prepared CCSD problem to the host: "oooo" "ovoo" "ovov" "ovvv" "Vl" (= (ac|bd) at
+ * [a,b,c,d]) "W1base" (= ovvo[k,c,a,i] at [i,a,k,c]) "W2base" (= oovv[k,i,a,c] at [i,a,k,c]) "eo" "ev"                     */
+int qemb_frag_ccsd_export(qemb_frag_t f, const char* name, double* host, int64_t nelem);
 
 /* ---------------------------------------------------------------- AO -> fragment ERI transforms -- */
 /* Dense: replaces `ao2mo.incore.full(eri_, TA, compact=True)` of BE._eri_transform "in-core"

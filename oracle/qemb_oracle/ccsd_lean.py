@@ -11,6 +11,15 @@ import numpy as np
 
 
 class LeanEris:
+    @classmethod
+    def from_blocks(cls, nocc, mo_energy, oooo, ovoo, ovov, oovv, ovvo, ovvv, Vl):
+        """Wrap already assembled MO blocks (e.g. exported from the device, bench.py)."""
+        self = cls.__new__(cls)
+        self.nocc, self.nmo = nocc, len(mo_energy)
+        self.mo_energy = np.asarray(mo_energy)
+        self.oooo, self.ovoo, self.ovov, self.oovv, self.ovvo, self.ovvv, self.Vl = oooo, ovoo, ovov, oovv, ovvo, ovvv, Vl
+        return self
+
     def __init__(self, B_mo, nocc, mo_energy):
         """B_mo: (naux, n, n) DF factor in the MO basis: (pq|rs) = sum_P B[P,p,q] B[P,r,s]."""
         o = nocc

@@ -94,6 +94,7 @@ def _declare(lib):
     f("qemb_frag_prepare_ccsd", I, V, I, P, P, OP)
     f("qemb_frag_ccsd_iterate", I, V, I, DP, DP)
     f("qemb_frag_ccsd_reset", I, V)
+    f("qemb_frag_ccsd_export", I, V, C.c_char_p, P, L)
     # ---- ERI transforms / Schmidt
     LP = C.POINTER(L)
     f("qemb_aoeri_upload", I, I, P, I, C.POINTER(c_vp))

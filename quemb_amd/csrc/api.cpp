@@ -172,6 +172,7 @@ int qemb_frag_prepare_ccsd(qemb_frag_t f, int nsocc, const double* h, const doub
   CHECK_FRAG(f); return FRAG(f)->prepare_ccsd(nsocc, h, dm0, to_opts(opts));
 }
 int qemb_frag_ccsd_iterate(qemb_frag_t f, int niter, double* e, double* nt) { CHECK_FRAG(f); return FRAG(f)->ccsd_iterate(niter, e, nt); }
+int qemb_frag_ccsd_export(qemb_frag_t f, const char* name, double* host, int64_t nelem) { CHECK_FRAG(f); return FRAG(f)->ccsd_export(name, host, nelem); }
 int qemb_frag_ccsd_reset(qemb_frag_t f) { CHECK_FRAG(f); return FRAG(f)->ccsd_reset(); }
 
 // ---------------------------------------------------------------- ERI transforms ------------------

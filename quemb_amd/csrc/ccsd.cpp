@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <string>
 
 namespace qemb {
 
@@ -315,6 +316,17 @@ int CcsdSolver::kernel(const CcsdOptions& opt, double* e_corr, int* n_iter, bool
   *n_iter = it > opt.max_cycle ? opt.max_cycle : it;
   diis_.clear();
   return 0;
+}
+
+int CcsdSolver::export_block(const char* name, double* host, int64_t nelem) {
+  const std::string nm(name ? name : "");
+  const DBuf* b = nullptr;
+  if (nm == "oooo") b = &I_.oooo; else if (nm == "ovoo") b = &I_.ovoo; else if (nm == "ovov") b = &I_.ovov;
+  else if (nm == "ovvv") b = &I_.ovvv; else if (nm == "Vl") b = &I_.Vl; else if (nm == "W1base") b = &W1base_;
+  else if (nm == "W2base") b = &W2base_; else if (nm == "eo") b = &eo_; else if (nm == "ev") b = &ev_;
+  if (!b || !b->p) { set_error("export_block: unknown block name"); return QEMB_ERR_ARG; }
+  if (nelem != b->n) { set_error("export_block: element count mismatch"); return QEMB_ERR_ARG; }
+  return dev_d2h(host, b->p, sizeof(double) * nelem);
 }
 
 // Z1[i,P] = sum_{ajb} G[i,a,j,b] (Pa|jb),  Z2[a,P] = sum_{ijb} G[i,a,j,b] (Pi|jb),  G = 2 tau[ijab] - tau[jiab]

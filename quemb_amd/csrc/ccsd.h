@@ -37,6 +37,8 @@ class CcsdSolver {
   int kernel(const CcsdOptions& opt, double* e_corr, int* n_iter, bool* converged);
   // energy pieces of get_frag_energy that need t1,t2: Z1[i,P], Z2[a,P] (host outputs o*nf and v*nf)
   int energy_intermediates(std::vector<double>& Z1, std::vector<double>& Z2);
+  // copy a named integral block to the host (measurement / debugging): oooo ovoo ovov ovvv Vl W1base W2base eo ev
+  int export_block(const char* name, double* host, int64_t nelem);
   double* t1() { return amp_.p; }
   double* t2() { return amp_.p + (int64_t)o_ * v_; }
   int o() const { return o_; }

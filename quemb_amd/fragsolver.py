@@ -126,6 +126,11 @@ class DeviceFragment:
         check(self.lib.qemb_frag_ccsd_iterate(self.h, int(niter), C.byref(e), C.byref(nt)), "qemb_frag_ccsd_iterate", self.lib)
         return e.value, nt.value
 
+    def ccsd_export(self, name: str, shape):
+        out = np.empty(shape)
+        check(self.lib.qemb_frag_ccsd_export(self.h, name.encode(), out.ctypes.data, out.size), "qemb_frag_ccsd_export", self.lib)
+        return out
+
     def ccsd_reset(self):
         check(self.lib.qemb_frag_ccsd_reset(self.h), "qemb_frag_ccsd_reset", self.lib)
 
