@@ -64,6 +64,9 @@ int qemb_op_gemm(int64_t M, int64_t N, int64_t K, double alpha, const double* A,
                  int64_t strideA, const double* B, int64_t ldb, int b_kcontig, int64_t strideB, double beta,
                  double* C, int64_t ldc, int64_t strideC, int64_t batch);
 int qemb_set_gemm_config(int cfg);         /* -1 = automatic tile choice; >=0 forces a tile config  */
+/* calibration: sustained v_mfma_f64_16x16x4_f64 rate of the chip, registers only (TFLOP/s)           */
+int qemb_mfma_f64_peak(int iters, int blocks_per_cu, double* tflops);
+int qemb_set_gemm_splitk(int enabled);     /* split-K for few-tile / long-K products (default on)   */
 /* out[sum ik*so[k]] = alpha*in[sum ik*si[k]] + beta*out[...], 0<=ik<dim[k], 4 dims                  */
 int qemb_op_copy4(const int64_t dim[4], const double* in, const int64_t si[4], double* out,
                   const int64_t so[4], double alpha, double beta);

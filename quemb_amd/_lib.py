@@ -59,6 +59,8 @@ def _declare(lib):
     f("qemb_timer_reset", I, I)
     f("qemb_op_gemm", I, L, L, L, D, P, L, I, L, P, L, I, L, D, P, L, L, L)
     f("qemb_set_gemm_config", I, I)
+    f("qemb_set_gemm_splitk", I, I)
+    f("qemb_mfma_f64_peak", I, I, I, C.POINTER(D))
     f("qemb_op_copy4", I, C.POINTER(L), P, C.POINTER(L), P, C.POINTER(L), D, D)
     f("qemb_op_outer4", I, C.POINTER(L), P, L, L, P, L, L, P, C.POINTER(L), D, D)
     f("qemb_op_div_denom", I, P, L, L, L, L, P, P, P, P)

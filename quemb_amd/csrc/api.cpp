@@ -9,7 +9,9 @@
 
 using namespace qemb;
 namespace qemb {
+int dev_mfma_f64_peak(int iters, int blocks_per_cu, double* tflops);
 extern int g_gemm_force_cfg;
+extern int g_gemm_splitk_enabled;
 int schmidt_eigh(const double* lmo, int N, int nmo, int nocc, const int64_t* frag, int n_f, double thr, double* TA_out,
                  int ld_out, int* n_b_out, int* sweeps_out);
 int schmidt_svd(const double* rdm, int N, const int64_t* frag_in, int n_f, double thr, double* TA_out, int ld_out, int* n_b_out,
@@ -41,6 +43,12 @@ int qemb_op_gemm(int64_t M, int64_t N, int64_t K, double alpha, const double* A,
   return dev_gemm(g);
 }
 int qemb_set_gemm_config(int cfg) { g_gemm_force_cfg = cfg; return QEMB_OK; }
+#ifndef QEMB_HOSTCHECK
+int qemb_mfma_f64_peak(int iters, int blocks_per_cu, double* tflops) { return dev_mfma_f64_peak(iters, blocks_per_cu, tflops); }
+#else
+int qemb_mfma_f64_peak(int, int, double*) { set_error("not available in the hostcheck build"); return QEMB_ERR_DEVICE; }
+#endif
+int qemb_set_gemm_splitk(int enabled) { g_gemm_splitk_enabled = enabled; return QEMB_OK; }
 int qemb_op_copy4(const int64_t dim[4], const double* in, const int64_t si[4], double* out, const int64_t so[4],
                   double alpha, double beta) {
   Copy4Desc c{};

@@ -32,6 +32,8 @@ static double* g_partials = nullptr;       // reduction scratch (NPART doubles)
 static constexpr int NPART = 2048;
 static double* g_ws = nullptr;             // growable workspace for contract_mid partials
 static size_t g_ws_bytes = 0;
+static double* g_gws = nullptr;            // split-K partial-sum workspace of the GEMM
+static size_t g_gws_bytes = 0;
 
 struct TimerSlot { hipEvent_t e0 = nullptr, e1 = nullptr; double total_ms = 0; int64_t count = 0;
                    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending; };
@@ -47,7 +49,7 @@ int dev_init(int device) {
   if (device < 0 || device >= ndev) { set_error("dev_init: device index out of range"); return QEMB_ERR_ARG; }
   if (g_stream && g_device == device) return QEMB_OK;
   HIP_TRY(hipSetDevice(device));
-  if (g_stream) { (void)hipStreamDestroy(g_stream); g_stream = nullptr; g_partials = nullptr; g_ws = nullptr; g_ws_bytes = 0; }
+  if (g_stream) { (void)hipStreamDestroy(g_stream); g_stream = nullptr; g_partials = nullptr; g_ws = nullptr; g_ws_bytes = 0; g_gws = nullptr; g_gws_bytes = 0; }
   HIP_TRY(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
   HIP_TRY(hipMalloc((void**)&g_partials, NPART * sizeof(double)));
   g_device = device;
@@ -83,6 +85,15 @@ int dev_d2d(void* dst, const void* src, size_t bytes) {
   return QEMB_OK;
 }
 int dev_mem_info(size_t* free_b, size_t* total_b) { REQUIRE_INIT(); HIP_TRY(hipMemGetInfo(free_b, total_b)); return QEMB_OK; }
+
+double* gemm_workspace(size_t bytes) {
+  if (bytes <= g_gws_bytes) return g_gws;
+  if (g_gws) { (void)hipStreamSynchronize(g_stream); (void)hipFree(g_gws); g_gws = nullptr; g_gws_bytes = 0; }
+  const size_t want = bytes < ((size_t)64 << 20) ? ((size_t)64 << 20) : bytes;
+  if (hipMalloc((void**)&g_gws, want) != hipSuccess) { set_error("split-K workspace hipMalloc failed"); return nullptr; }
+  g_gws_bytes = want;
+  return g_gws;
+}
 
 static int ensure_ws(size_t bytes) {
   if (bytes <= g_ws_bytes) return QEMB_OK;

@@ -34,11 +34,15 @@ namespace qemb {
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
 
+int g_gemm_force_cfg = -1;      // test / tuning hook (qemb_set_gemm_config)
+int g_gemm_splitk_enabled = 1;  // test hook
+
 struct GemmKArgs {
   const double* A; const double* B; double* C;
   long long lda, ldb, ldc, strideA, strideB, strideC;
   int M, N, K;
   int tiles_m, tiles_n;
+  int ksplit, kchunk;      // split-K: blockIdx.y = batch * ksplit + slice; slice s covers k in [s*kchunk, (s+1)*kchunk)
   double alpha, beta;
 };
 
@@ -144,10 +148,14 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64, (WM * WN <= 16) ? 2 : 1
   const int tm = L % g.tiles_m, tn = L / g.tiles_m;
   const int m0 = tm * BM, n0 = tn * BN;
 
-  const long long bz = blockIdx.y;
+  const long long bz = blockIdx.y / g.ksplit;
+  const int kslice = blockIdx.y % g.ksplit;
+  const int kbeg = kslice * g.kchunk;
+  const int kend = (kbeg + g.kchunk < g.K) ? kbeg + g.kchunk : g.K;
   const double* __restrict__ A = g.A + bz * g.strideA;
   const double* __restrict__ B = g.B + bz * g.strideB;
-  double* __restrict__ C = g.C + bz * g.strideC;
+  // with split-K every slice writes its own partial (C = workspace [batch][slice][M][N]); combined by splitk_reduce
+  double* __restrict__ C = g.C + (long long)blockIdx.y * g.strideC;
 
   d4 acc[WM][WN];
 #pragma unroll
@@ -156,11 +164,11 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64, (WM * WN <= 16) ? 2 : 1
     for (int j = 0; j < WN; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
 
   double ra[NCH_A][VEC], rb[NCH_B][VEC];
-  const int nk = (g.K + BK - 1) / BK;
+  const int nk = (kend - kbeg + BK - 1) / BK;
 
   // prologue: tile 0 -> LDS buffer 0
-  stage_load<BM, BK, A_KC, VEC, T, NCH_A>(ra, A, g.lda, m0, 0, g.M, g.K, tid);
-  stage_load<BN, BK, B_KC, VEC, T, NCH_B>(rb, B, g.ldb, n0, 0, g.N, g.K, tid);
+  stage_load<BM, BK, A_KC, VEC, T, NCH_A>(ra, A, g.lda, m0, kbeg, g.M, kend, tid);
+  stage_load<BN, BK, B_KC, VEC, T, NCH_B>(rb, B, g.ldb, n0, kbeg, g.N, kend, tid);
   stage_store<BM, BK, A_KC, VEC, T, NCH_A>(ra, sA0, tid);
   stage_store<BN, BK, B_KC, VEC, T, NCH_B>(rb, sB0, tid);
   __syncthreads();
@@ -173,8 +181,8 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64, (WM * WN <= 16) ? 2 : 1
     double* nB = (kt & 1) ? sB0 : sB1;
     const bool more = (kt + 1 < nk);
     if (more) {  // issue next tile's global loads before this tile's MFMAs (latency hides under them)
-      stage_load<BM, BK, A_KC, VEC, T, NCH_A>(ra, A, g.lda, m0, (kt + 1) * BK, g.M, g.K, tid);
-      stage_load<BN, BK, B_KC, VEC, T, NCH_B>(rb, B, g.ldb, n0, (kt + 1) * BK, g.N, g.K, tid);
+      stage_load<BM, BK, A_KC, VEC, T, NCH_A>(ra, A, g.lda, m0, kbeg + (kt + 1) * BK, g.M, kend, tid);
+      stage_load<BN, BK, B_KC, VEC, T, NCH_B>(rb, B, g.ldb, n0, kbeg + (kt + 1) * BK, g.N, kend, tid);
     }
 #pragma unroll
     for (int ks = 0; ks < BK / 4; ++ks) {
@@ -218,6 +226,24 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64, (WM * WN <= 16) ? 2 : 1
   }
 }
 
+// C[b][m][n] = alpha * sum_s ws[b][s][m][n] + beta * C   (fixed summation order: deterministic)
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(const double* __restrict__ ws, int S, long long M, long long N,
+                                                            double* __restrict__ C, long long ldc, long long strideC,
+                                                            double alpha, double beta) {
+  const long long mn = M * N;
+  const long long b = blockIdx.y;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < mn; t += (long long)gridDim.x * blockDim.x) {
+    double acc = 0.0;
+    const double* p = ws + b * S * mn + t;
+    for (int s = 0; s < S; ++s) acc += p[(long long)s * mn];
+    const long long m = t / N, n = t - m * N;
+    double* c = C + b * strideC + m * ldc + n;
+    *c = (beta != 0.0) ? alpha * acc + beta * (*c) : alpha * acc;
+  }
+}
+
+double* gemm_workspace(size_t bytes);   // dev_ops_hip.hip
+
 template <int WM, int WN, int WAVES_M, int WAVES_N, int BK, bool A_KC, bool B_KC, int VEC>
 static int launch_cfg(const GemmDesc& d, hipStream_t s) {
   constexpr int BM = WM * 16 * WAVES_M, BN = WN * 16 * WAVES_N;
@@ -231,6 +257,25 @@ static int launch_cfg(const GemmDesc& d, hipStream_t s) {
   g.tiles_m = (int)((d.M + BM - 1) / BM);
   g.tiles_n = (int)((d.N + BN - 1) / BN);
   g.alpha = d.alpha; g.beta = d.beta;
+  // split-K when the output has too few tiles to occupy 256 CUs but K is long (the o x v, o x o, v x v shaped
+  // CCSD intermediates contract over o*v^2 ... v^2 indices)
+  g.ksplit = 1; g.kchunk = g.K > 0 ? g.K : 1;
+  const long long tiles = (long long)g.tiles_m * g.tiles_n * d.batch;
+  if (g_gemm_splitk_enabled && tiles < 256 && d.K >= 1024) {
+    long long S = (768 + tiles - 1) / tiles;
+    if (S > d.K / 256) S = d.K / 256;
+    if (S > 1) {
+      long long chunk = (d.K + S - 1) / S;
+      chunk = (chunk + 31) / 32 * 32;
+      S = (d.K + chunk - 1) / chunk;
+      if (S > 1 && S * d.batch <= 65535) { g.ksplit = (int)S; g.kchunk = (int)chunk; }
+    }
+  }
+  if (g.ksplit > 1) {
+    double* ws = gemm_workspace(sizeof(double) * (size_t)d.batch * g.ksplit * d.M * d.N);
+    if (!ws) return QEMB_ERR_ALLOC;
+    g.C = ws; g.ldc = d.N; g.strideC = d.M * d.N; g.alpha = 1.0; g.beta = 0.0;
+  }
   const size_t lds = 2 * (size_t)(ImgA::SIZE + ImgB::SIZE) * sizeof(double);
   auto kern = dgemm_mfma_kernel<WM, WN, WAVES_M, WAVES_N, BK, A_KC, B_KC, VEC>;
   static bool attr_set = false;
@@ -238,9 +283,15 @@ static int launch_cfg(const GemmDesc& d, hipStream_t s) {
     HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  dim3 grid((unsigned)(g.tiles_m * g.tiles_n), (unsigned)d.batch, 1);
+  dim3 grid((unsigned)(g.tiles_m * g.tiles_n), (unsigned)(d.batch * g.ksplit), 1);
   dim3 block(WAVES_M * WAVES_N * 64, 1, 1);
   hipLaunchKernelGGL(kern, grid, block, lds, s, g);
+  if (g.ksplit > 1) {
+    const long long mn = d.M * d.N;
+    const unsigned gx = (unsigned)((mn + 255) / 256 < 2048 ? (mn + 255) / 256 : 2048);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(gx, (unsigned)d.batch), dim3(256), 0, s, (const double*)g.C, g.ksplit,
+                       (long long)d.M, (long long)d.N, d.C, (long long)d.ldc, (long long)d.strideC, d.alpha, d.beta);
+  }
   HIP_TRY(hipGetLastError());
   return QEMB_OK;
 }
@@ -265,7 +316,43 @@ static bool operand_vec2_ok(const double* p, int64_t ld, int64_t stride, int64_t
          (contig_extent % 2 == 0);
 }
 
-int g_gemm_force_cfg = -1;  // test / tuning hook (qemb_set_gemm_config)
+
+
+// ---- calibration: back-to-back v_mfma_f64_16x16x4_f64 issue rate of the whole chip (no memory traffic) --------
+__global__ void __launch_bounds__(256) mfma_f64_peak_kernel(double* out, int iters) {
+  d4 acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = d4{0.0, 0.0, 0.0, 0.0};
+  double a = 1.0 + 1e-9 * threadIdx.x, b = 1.0 - 1e-9 * threadIdx.x;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  if (s == 12345.678) out[0] = s;   // keep the accumulators live
+}
+int dev_mfma_f64_peak(int iters, int blocks_per_cu, double* tflops) {
+  hipStream_t s = hip_stream();
+  if (!s) { set_error("libqemb_hip: call qemb_init(device) first"); return QEMB_ERR_DEVICE; }
+  double* out = nullptr;
+  HIP_TRY(hipMalloc((void**)&out, 64));
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+  const int grid = 256 * blocks_per_cu;
+  hipLaunchKernelGGL(mfma_f64_peak_kernel, dim3(grid), dim3(256), 0, s, out, 64);   // warm-up
+  HIP_TRY(hipEventRecord(e0, s));
+  hipLaunchKernelGGL(mfma_f64_peak_kernel, dim3(grid), dim3(256), 0, s, out, iters);
+  HIP_TRY(hipEventRecord(e1, s));
+  HIP_TRY(hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+  const double flop = 2.0 * 16 * 16 * 4 * 8.0 * iters * 4.0 * grid;   // 8 MFMAs x 4 waves per block
+  *tflops = flop / (ms * 1e-3) / 1e12;
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(out);
+  return QEMB_OK;
+}
 
 int dev_gemm(const GemmDesc& d) {
   if (d.M <= 0 || d.N <= 0 || d.batch <= 0) return QEMB_OK;
@@ -291,6 +378,8 @@ int dev_gemm(const GemmDesc& d) {
     case 2: return launch_layout<1, 1, 2, 2, 32>(d, s, vec2);   //  32 x  32, 4 waves
     case 3: return launch_layout<5, 4, 1, 4, 16>(d, s, vec2);   //  80 x 256, 4 waves (M = 400 = 5*80)
     case 4: return launch_layout<4, 4, 2, 4, 16>(d, s, vec2);   // 128 x 256, 8 waves
+    case 5: return launch_layout<5, 2, 1, 4, 16>(d, s, vec2);   //  80 x 128, 4 waves
+    case 6: return launch_layout<5, 4, 1, 2, 16>(d, s, vec2);   //  80 x 128, 2 waves
     default: set_error("dev_gemm: unknown tile config"); return QEMB_ERR_ARG;
   }
 }

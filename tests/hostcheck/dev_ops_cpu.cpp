@@ -23,6 +23,7 @@ void set_error(const std::string& m) { g_err = m; }
 const char* last_error() { return g_err.c_str(); }
 const char* dev_backend_name() { return "hostcheck"; }
 int g_gemm_force_cfg = -1;
+int g_gemm_splitk_enabled = 1;
 
 int dev_init(int) { return 0; }
 int dev_sync() { return 0; }

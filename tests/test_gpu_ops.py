@@ -29,7 +29,7 @@ def _gemm(lib, A, B, Cm, alpha, beta, a_kc, b_kc, batch=1, cfg=-1):
     return dC.numpy(Cm.shape)
 
 
-@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 3, 4])
+@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize("a_kc,b_kc", [(1, 1), (1, 0), (0, 1), (0, 0)])
 @pytest.mark.parametrize("shape", [(128, 128, 64), (400, 300, 200), (37, 53, 29), (441, 441, 441), (1, 220, 96), (130, 258, 18)])
 def test_gemm_matches_numpy(qlib, cfg, a_kc, b_kc, shape):
@@ -246,3 +246,29 @@ def test_cholesky_rejects_indefinite(qlib):
     A = np.eye(8); A[3, 3] = -1.0
     dA = DeviceBuffer.from_numpy(A)
     assert qlib.qemb_op_cholesky_lower(8, dA.ptr) == -5
+
+
+@pytest.mark.parametrize("shape", [(20, 200, 80000), (20, 20, 50000), (200, 200, 8000), (400, 400, 40000), (20, 22, 80001)])
+@pytest.mark.parametrize("a_kc,b_kc", [(1, 1), (1, 0), (0, 0)])
+def test_gemm_split_k(qlib, shape, a_kc, b_kc):
+    """few output tiles + long K: the dispatcher splits K over workgroups and reduces deterministically."""
+    M, N, K = shape
+    rng = np.random.default_rng(M + N + K)
+    A = rng.standard_normal((1, M, K)); B = rng.standard_normal((1, K, N)); C0 = rng.standard_normal((1, M, N))
+    got = _gemm(qlib, A, B, C0, 0.5, 2.0, a_kc, b_kc)
+    ref = 0.5 * (A @ B) + 2.0 * C0
+    assert np.abs(got - ref).max() < 1e-12 * K
+    again = _gemm(qlib, A, B, C0, 0.5, 2.0, a_kc, b_kc)
+    assert np.array_equal(got, again)
+    qlib.qemb_set_gemm_splitk(0)
+    try:
+        plain = _gemm(qlib, A, B, C0, 0.5, 2.0, a_kc, b_kc)
+    finally:
+        qlib.qemb_set_gemm_splitk(1)
+    assert np.abs(got - plain).max() < 1e-12 * K
+
+
+def test_mfma_f64_peak_calibration(qlib):
+    t = C.c_double()
+    check(qlib.qemb_mfma_f64_peak(20000, 2, C.byref(t)))
+    assert 20.0 < t.value < 200.0
