@@ -36,7 +36,8 @@ int qemb_mem_info(size_t* free_bytes, size_t* total_bytes);
 
 /* raw device buffers (for callers that keep tensors resident, e.g. bench.py / multi-fragment sweeps) */
 int qemb_malloc(void** dptr, size_t bytes);
-int qemb_free(void* dptr);
+int qemb_free(void* dptr);                 /* parks the block for reuse (caching allocator)       */
+int qemb_trim(void);                       /* hand every parked block back to the driver          */
 int qemb_h2d(void* dptr, const void* host, size_t bytes);
 int qemb_d2h(void* host, const void* dptr, size_t bytes);
 int qemb_d2d(void* dst, const void* src, size_t bytes);

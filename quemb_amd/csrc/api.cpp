@@ -28,6 +28,7 @@ int qemb_sync(void) { return dev_sync(); }
 int qemb_mem_info(size_t* f, size_t* t) { return dev_mem_info(f, t); }
 int qemb_malloc(void** p, size_t bytes) { return dev_alloc(p, bytes); }
 int qemb_free(void* p) { return dev_free(p); }
+int qemb_trim(void) { return dev_trim(); }
 int qemb_h2d(void* d, const void* h, size_t b) { return dev_h2d(d, h, b); }
 int qemb_d2h(void* h, const void* d, size_t b) { return dev_d2h(h, d, b); }
 int qemb_d2d(void* d, const void* s, size_t b) { return dev_d2d(d, s, b); }

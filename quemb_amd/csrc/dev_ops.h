@@ -27,7 +27,8 @@ const char* last_error();
 int dev_init(int device);            // select device, create the library stream
 int dev_sync();                      // wait for the library stream
 int dev_alloc(void** p, size_t bytes);
-int dev_free(void* p);
+int dev_free(void* p);                // parks the block in a free list (see dev_trim)
+int dev_trim();                       // release every parked block back to the driver
 int dev_h2d(void* dst, const void* src_host, size_t bytes);
 int dev_d2h(void* dst_host, const void* src, size_t bytes);
 int dev_d2d(void* dst, const void* src, size_t bytes);

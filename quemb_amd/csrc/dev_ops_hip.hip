@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -59,14 +60,53 @@ int dev_init(int device) {
   do { if (!g_stream) { set_error("libqemb_hip: call qemb_init(device) first"); return QEMB_ERR_DEVICE; } } while (0)
 
 int dev_sync() { REQUIRE_INIT(); HIP_TRY(hipStreamSynchronize(g_stream)); return QEMB_OK; }
+// ---- caching allocator --------------------------------------------------------------------------------------
+// Every fragment solve allocates the same handful of multi-GB buffers (two n^4 ping-pong tensors, the v^4 ladder
+// operand, ...).  hipMalloc / hipFree of such blocks cost ~0.1 s each and hipFree synchronises the device, so
+// freed blocks are parked in an exact-size free list and handed back to the next request of that size.  All work
+// is on ONE stream, so reuse is stream-ordered and needs no synchronisation.  dev_trim() / an allocation failure
+// releases the parked blocks.
+static std::map<size_t, std::vector<void*>> g_pool;
+static std::map<void*, size_t> g_live;
+static size_t g_pool_bytes = 0;
+
+int dev_trim() {
+  if (!g_stream) return QEMB_OK;
+  HIP_TRY(hipStreamSynchronize(g_stream));
+  for (auto& kv : g_pool) for (void* q : kv.second) (void)hipFree(q);
+  g_pool.clear(); g_pool_bytes = 0;
+  return QEMB_OK;
+}
 int dev_alloc(void** p, size_t bytes) {
   REQUIRE_INIT();
   if (bytes == 0) bytes = 16;
+  bytes = (bytes + 255) / 256 * 256;
+  auto it = g_pool.find(bytes);
+  if (it != g_pool.end() && !it->second.empty()) {
+    *p = it->second.back(); it->second.pop_back(); g_pool_bytes -= bytes;
+    g_live[*p] = bytes;
+    return QEMB_OK;
+  }
   hipError_t e = hipMalloc(p, bytes);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    int rc = dev_trim();
+    if (rc) return rc;
+    e = hipMalloc(p, bytes);
+  }
   if (e != hipSuccess) { set_error("hipMalloc of " + std::to_string(bytes) + " bytes failed: " + hipGetErrorString(e)); return QEMB_ERR_ALLOC; }
+  g_live[*p] = bytes;
   return QEMB_OK;
 }
-int dev_free(void* p) { if (p) { HIP_TRY(hipStreamSynchronize(g_stream)); HIP_TRY(hipFree(p)); } return QEMB_OK; }
+int dev_free(void* p) {
+  if (!p) return QEMB_OK;
+  auto it = g_live.find(p);
+  if (it == g_live.end()) { HIP_TRY(hipStreamSynchronize(g_stream)); HIP_TRY(hipFree(p)); return QEMB_OK; }
+  const size_t bytes = it->second;
+  g_live.erase(it);
+  g_pool[bytes].push_back(p); g_pool_bytes += bytes;
+  return QEMB_OK;
+}
 int dev_h2d(void* dst, const void* src, size_t bytes) {
   REQUIRE_INIT();
   HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, g_stream));

@@ -380,6 +380,9 @@ int dev_gemm(const GemmDesc& d) {
     case 4: return launch_layout<4, 4, 2, 4, 16>(d, s, vec2);   // 128 x 256, 8 waves
     case 5: return launch_layout<5, 2, 1, 4, 16>(d, s, vec2);   //  80 x 128, 4 waves
     case 6: return launch_layout<5, 4, 1, 2, 16>(d, s, vec2);   //  80 x 128, 2 waves
+    case 7: return launch_layout<5, 1, 1, 4, 16>(d, s, vec2);   //  80 x  64, 4 waves
+    case 8: return launch_layout<5, 1, 1, 8, 16>(d, s, vec2);   //  80 x 128, 8 waves
+    case 9: return launch_layout<5, 2, 1, 8, 16>(d, s, vec2);   //  80 x 256, 8 waves
     default: set_error("dev_gemm: unknown tile config"); return QEMB_ERR_ARG;
   }
 }

@@ -29,6 +29,7 @@ int dev_init(int) { return 0; }
 int dev_sync() { return 0; }
 int dev_alloc(void** p, size_t bytes) { *p = std::malloc(bytes ? bytes : 16); if (!*p) { set_error("malloc failed"); return QEMB_ERR_ALLOC; } return 0; }
 int dev_free(void* p) { std::free(p); return 0; }
+int dev_trim() { return 0; }
 int dev_h2d(void* d, const void* s, size_t b) { std::memcpy(d, s, b); return 0; }
 int dev_d2h(void* d, const void* s, size_t b) { std::memcpy(d, s, b); return 0; }
 int dev_d2d(void* d, const void* s, size_t b) { std::memmove(d, s, b); return 0; }

@@ -29,7 +29,7 @@ def _gemm(lib, A, B, Cm, alpha, beta, a_kc, b_kc, batch=1, cfg=-1):
     return dC.numpy(Cm.shape)
 
 
-@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9])
 @pytest.mark.parametrize("a_kc,b_kc", [(1, 1), (1, 0), (0, 1), (0, 0)])
 @pytest.mark.parametrize("shape", [(128, 128, 64), (400, 300, 200), (37, 53, 29), (441, 441, 441), (1, 220, 96), (130, 258, 18)])
 def test_gemm_matches_numpy(qlib, cfg, a_kc, b_kc, shape):

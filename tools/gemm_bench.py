@@ -51,7 +51,7 @@ if __name__ == "__main__":
     for bpc in (1, 2, 4):
         t = C.c_double(); check(lib.qemb_mfma_f64_peak(40000, bpc, C.byref(t)))
         print(json.dumps(dict(tag="mfma_f64 register-only peak", blocks_per_cu=bpc, tflops=t.value)), flush=True)
-    for cfg in (0, 4, 1, 5, 6):
+    for cfg in (1, 5, 7, 8, 9):
         bench(o * o, v * v, v * v, 1, 1, cfg, tag="pp-ladder tau[ij,cd] W[ab,cd]")
     bench(o, v, o * v * v, 1, 0, -1, tag="t1 term: M=o N=v K=o v^2 (split-K)")
     bench(v, v, o * o * v, 0, 0, -1, tag="Fvv: M=v N=v K=o^2 v (split-K)")
