@@ -67,7 +67,8 @@ int qemb_op_gemm(int64_t M, int64_t N, int64_t K, double alpha, const double* A,
 int qemb_set_gemm_config(int cfg);         /* -1 = automatic tile choice; >=0 forces a tile config  */
 /* calibration: sustained v_mfma_f64_16x16x4_f64 rate of the chip, registers only (TFLOP/s)           */
 int qemb_mfma_f64_peak(int iters, int blocks_per_cu, double* tflops);
-int qemb_set_gemm_splitk(int enabled);     /* split-K for few-tile / long-K products (default on)   */
+int qemb_set_gemm_splitk(int enabled);
+int qemb_set_gemm_ksplit(int ksplit);      /* explicit split-K factor for qemb_op_gemm (0 = automatic) */     /* split-K for few-tile / long-K products (default on)   */
 /* out[sum ik*so[k]] = alpha*in[sum ik*si[k]] + beta*out[...], 0<=ik<dim[k], 4 dims                  */
 int qemb_op_copy4(const int64_t dim[4], const double* in, const int64_t si[4], double* out,
                   const int64_t so[4], double alpha, double beta);
@@ -75,6 +76,9 @@ int qemb_op_outer4(const int64_t dim[4], const double* u, int64_t su0, int64_t s
                    int64_t sv1, int64_t sv3, double* out, const int64_t so[4], double alpha, double beta);
 int qemb_op_div_denom(double* x, int64_t d0, int64_t d1, int64_t d2, int64_t d3, const double* ea,
                       const double* eb, const double* ec, const double* ed);
+/* out[p,:] = in[i*o+j,:] for pairs p = i(i+1)/2+j, i>=j;  t2[i,j,a,b] += R[p,a,b], t2[j,i,a,b] += R[p,b,a] (i != j) */
+int qemb_op_sym_pack_rows(int64_t o, int64_t ncols, const double* in, double* out);
+int qemb_op_sym_ladder_scatter(int64_t o, int64_t v, const double* R, double* t2);
 int qemb_op_dot(int64_t n, const double* x, const double* y, double* out_dev);
 int qemb_op_absmax(int64_t n, const double* x, double* out_dev);
 int qemb_op_gemv_rows(int64_t rows, int64_t cols, const double* T, int64_t ldt, const double* x, double* y,

@@ -61,6 +61,9 @@ def _declare(lib):
     f("qemb_op_gemm", I, L, L, L, D, P, L, I, L, P, L, I, L, D, P, L, L, L)
     f("qemb_set_gemm_config", I, I)
     f("qemb_set_gemm_splitk", I, I)
+    f("qemb_set_gemm_ksplit", I, I)
+    f("qemb_op_sym_pack_rows", I, L, L, P, P)
+    f("qemb_op_sym_ladder_scatter", I, L, L, P, P)
     f("qemb_mfma_f64_peak", I, I, I, C.POINTER(D))
     f("qemb_op_copy4", I, C.POINTER(L), P, C.POINTER(L), P, C.POINTER(L), D, D)
     f("qemb_op_outer4", I, C.POINTER(L), P, L, L, P, L, L, P, C.POINTER(L), D, D)

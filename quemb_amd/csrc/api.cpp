@@ -19,6 +19,8 @@ int schmidt_svd(const double* rdm, int N, const int64_t* frag_in, int n_f, doubl
 int nsocc_guess(const double* Cproj, int n, int nocc, double* P_out, int* nsocc, double* mo_out);
 }
 
+static int g_test_ksplit = 0;   // qemb_set_gemm_ksplit: split-K override of qemb_op_gemm (tests / tuning)
+
 extern "C" {
 
 int qemb_init(int device) { return dev_init(device); }
@@ -40,9 +42,11 @@ int qemb_timer_reset(int s) { return dev_timer_reset(s); }
 int qemb_op_gemm(int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t lda, int a_kcontig,
                  int64_t strideA, const double* B, int64_t ldb, int b_kcontig, int64_t strideB, double beta,
                  double* C, int64_t ldc, int64_t strideC, int64_t batch) {
-  GemmDesc g{M, N, K, alpha, beta, A, lda, a_kcontig, strideA, B, ldb, b_kcontig, strideB, C, ldc, strideC, batch};
+  GemmDesc g{M, N, K, alpha, beta, A, lda, a_kcontig, strideA, B, ldb, b_kcontig, strideB, C, ldc, strideC, batch, -1, g_test_ksplit};
   return dev_gemm(g);
 }
+static int g_test_ksplit_dummy = 0;
+int qemb_set_gemm_ksplit(int ks) { g_test_ksplit = ks; (void)g_test_ksplit_dummy; return QEMB_OK; }
 int qemb_set_gemm_config(int cfg) { g_gemm_force_cfg = cfg; return QEMB_OK; }
 #ifndef QEMB_HOSTCHECK
 int qemb_mfma_f64_peak(int iters, int blocks_per_cu, double* tflops) { return dev_mfma_f64_peak(iters, blocks_per_cu, tflops); }
@@ -66,6 +70,8 @@ int qemb_op_outer4(const int64_t dim[4], const double* u, int64_t su0, int64_t s
 }
 int qemb_op_div_denom(double* x, int64_t d0, int64_t d1, int64_t d2, int64_t d3, const double* ea, const double* eb,
                       const double* ec, const double* ed) { return dev_div_denom(x, d0, d1, d2, d3, ea, eb, ec, ed); }
+int qemb_op_sym_pack_rows(int64_t o, int64_t ncols, const double* in, double* out) { return dev_sym_pack_rows(o, ncols, in, out); }
+int qemb_op_sym_ladder_scatter(int64_t o, int64_t v, const double* R, double* t2) { return dev_sym_ladder_scatter(o, v, R, t2); }
 int qemb_op_dot(int64_t n, const double* x, const double* y, double* o) { return dev_dot(n, x, y, o); }
 int qemb_op_absmax(int64_t n, const double* x, double* o) { return dev_absmax(n, x, o); }
 int qemb_op_gemv_rows(int64_t rows, int64_t cols, const double* T, int64_t ldt, const double* x, double* y, double alpha,

@@ -111,6 +111,7 @@ int CcsdSolver::setup(MoIntegrals&& ints, const double* mo_energy_dev) {
   QTRY(Foo_.alloc(oo)); QTRY(Fvv_.alloc(vv)); QTRY(Fov_.alloc(nov)); QTRY(Z_.alloc(oo)); QTRY(Y_.alloc(vv));
   QTRY(Ytmp_.alloc(vv)); QTRY(Loo_.alloc(oo)); QTRY(Lvv_.alloc(vv)); QTRY(Q_.alloc(oo)); QTRY(Wo_.alloc(oo * oo));
   QTRY(O1_.alloc(oo * oo)); QTRY(X_.alloc(oo * nov)); QTRY(scal_.alloc(8));
+  QTRY(taup_.alloc(o * (o + 1) / 2 * vv)); QTRY(Rlad_.alloc(o * (o + 1) / 2 * vv));
   first_ = true;
   return 0;
 }
@@ -195,9 +196,23 @@ int CcsdSolver::update_amps(double* t1n, double* t2n) {
   QTRY(perm4(Wo_, O1_, o, o, o, o, 0, 2, 1, 3, 1.0, 1.0));                         // + ovoo[kclj] t1[ic]
   QTRY(gemm_tn(oo, vv, oo, 1.0, Wo_, tau_, 1.0, t2n));                             // Woooo[klij] tau[klab]
   // pp-ladder (the dominant kernel): tau[(ij),(cd)] * Vl[(ab),(cd)]^T
-  QTRY(dev_timer_begin(TIMER_LADDER));
-  QTRY(gemm_nt(oo, vv, vv, 1.0, tau_, I_.Vl, 1.0, t2n));
-  QTRY(dev_timer_end(TIMER_LADDER));
+  // Only the o(o+1)/2 rows i >= j are contracted (tau[j,i,c,d] = tau[i,j,d,c] and Vl[ba,dc] = Vl[ab,cd] give the
+  // (j,i) rows as the (a<->b)-transposed result), so the 12.8 GB operand Vl is streamed ONCE through a tile that
+  // holds every packed row (224 x 128, 8 waves) instead of once per 64/128-row tile of the dense o^2 x v^2 product.
+  {
+    const int64_t np = o * (o + 1) / 2;
+    QTRY(dev_sym_pack_rows(o, vv, tau_, taup_));
+    int cfg = -1, ks = 0;
+    if (np <= 224 && vv >= 4096) {
+      cfg = np <= 64 ? 12 : (np <= 112 ? 11 : 10);
+      const int64_t tiles = (vv + 127) / 128;
+      ks = (int)std::max<int64_t>(1, std::min<int64_t>(8, (1280 + tiles - 1) / tiles));   // ~5 workgroups per CU
+    }
+    QTRY(dev_timer_begin(TIMER_LADDER));
+    QTRY(gemm(np, vv, vv, 1.0, taup_, vv, true, I_.Vl, vv, true, 0.0, Rlad_, vv, 1, 0, 0, 0, cfg, ks));
+    QTRY(dev_timer_end(TIMER_LADDER));
+    QTRY(dev_sym_ladder_scatter(o, v, Rlad_, t2n));
+  }
 
   // ---- T2 equation: terms that enter as P(X) accumulate in U
   QTRY(gemm(v, v, v, 1.0, Lvv_, v, true, t2, v, false, 0.0, U_, v, oo, 0, vv, vv));   // Lvv'[a,c] t2[ijcb]

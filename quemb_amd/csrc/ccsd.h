@@ -58,6 +58,7 @@ class CcsdSolver {
   // amplitudes (t1 then t2, one contiguous vector) and per-iteration work space
   DBuf amp_, ampn_, diff_;
   DBuf tau_, T_, Tp_, S_, W1_, W2_, W12_, R_, U_, G1_, G2_;
+  DBuf taup_, Rlad_;
   DBuf Foo_, Fvv_, Fov_, Z_, Y_, Ytmp_, Loo_, Lvv_, Q_, Wo_, O1_, X_, scal_;
   std::vector<DeviceDIIS> diis_;
   bool first_ = true;

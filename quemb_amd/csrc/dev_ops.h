@@ -59,6 +59,8 @@ struct GemmDesc {
   const double* B; int64_t ldb; int b_kcontig; int64_t strideB;
   double* C; int64_t ldc; int64_t strideC;
   int64_t batch;
+  int cfg = -1;        // tile configuration override (-1: automatic)
+  int ksplit = 0;      // split-K override (0: automatic)
 };
 int dev_gemm(const GemmDesc& g);
 
@@ -89,6 +91,12 @@ int dev_outer4(const Outer4Desc& c);
 // (orbital-energy denominators; pass d1 = d3 = 1 with eb = ed = nullptr for t1)
 int dev_div_denom(double* x, int64_t d0, int64_t d1, int64_t d2, int64_t d3,
                   const double* ea, const double* eb, const double* ec, const double* ed);
+
+// ---- (i,j) <-> (j,i) symmetry of the doubles amplitudes: tau[j,i,d,c] = tau[i,j,c,d] --------------------------
+// out[p, c] = in[(i*o + j), c] for the o(o+1)/2 pairs p = i(i+1)/2 + j, i >= j   (rows of length ncols)
+int dev_sym_pack_rows(int64_t o, int64_t ncols, const double* in, double* out);
+// t2[i,j,a,b] += R[p,a,b] and, for i != j, t2[j,i,a,b] += R[p,b,a]   (R: npair(o) x v x v)
+int dev_sym_ladder_scatter(int64_t o, int64_t v, const double* R, double* t2);
 
 // ---- reductions ---------------------------------------------------------------------------------
 // out_dev[0] = sum_i x[i]*y[i]   (deterministic two-stage reduction; out_dev is a device double)

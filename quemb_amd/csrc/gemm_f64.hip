@@ -261,7 +261,12 @@ static int launch_cfg(const GemmDesc& d, hipStream_t s) {
   // CCSD intermediates contract over o*v^2 ... v^2 indices)
   g.ksplit = 1; g.kchunk = g.K > 0 ? g.K : 1;
   const long long tiles = (long long)g.tiles_m * g.tiles_n * d.batch;
-  if (g_gemm_splitk_enabled && tiles < 256 && d.K >= 1024) {
+  if (d.ksplit > 1) {
+    long long chunk = (d.K + d.ksplit - 1) / d.ksplit;
+    chunk = (chunk + 31) / 32 * 32;
+    const long long S = (d.K + chunk - 1) / chunk;
+    if (S > 1 && S * d.batch <= 65535) { g.ksplit = (int)S; g.kchunk = (int)chunk; }
+  } else if (g_gemm_splitk_enabled && tiles < 256 && d.K >= 1024) {
     long long S = (768 + tiles - 1) / tiles;
     if (S > d.K / 256) S = d.K / 256;
     if (S > 1) {
@@ -375,6 +380,7 @@ int dev_gemm(const GemmDesc& d) {
   if (t128 >= 384) cfg = (w128 > 1.08 * w64) ? 1 : 0;
   else if (t64 >= 256) cfg = 1;
   else cfg = 2;
+  if (d.cfg >= 0) cfg = d.cfg;
   if (g_gemm_force_cfg >= 0) cfg = g_gemm_force_cfg;
   switch (cfg) {
     case 0: return launch_layout<4, 4, 2, 2, 16>(d, s, vec2);   // 128 x 128, 4 waves
@@ -387,6 +393,9 @@ int dev_gemm(const GemmDesc& d) {
     case 7: return launch_layout<5, 1, 1, 4, 16>(d, s, vec2);   //  80 x  64, 4 waves
     case 8: return launch_layout<5, 1, 1, 8, 16>(d, s, vec2);   //  80 x 128, 8 waves
     case 9: return launch_layout<5, 2, 1, 8, 16>(d, s, vec2);   //  80 x 256, 8 waves
+    case 10: return launch_layout<14, 1, 1, 8, 16>(d, s, vec2); // 224 x 128, 8 waves: all packed (i>=j) rows of o = 20 in ONE tile
+    case 11: return launch_layout<7, 1, 1, 8, 16>(d, s, vec2);  // 112 x 128, 8 waves
+    case 12: return launch_layout<4, 1, 1, 8, 16>(d, s, vec2);  //  64 x 128, 8 waves
     default: set_error("dev_gemm: unknown tile config"); return QEMB_ERR_ARG;
   }
 }

@@ -94,12 +94,12 @@ inline int extract4(double* dst, const double* src, int64_t n1, int64_t n2, int6
 // C(MxN, ldc) = alpha * A * B + beta * C with explicit storage flags (see dev_ops.h GemmDesc)
 inline int gemm(int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t lda, bool a_kc, const double* B,
                 int64_t ldb, bool b_kc, double beta, double* C, int64_t ldc, int64_t batch = 1, int64_t sA = 0,
-                int64_t sB = 0, int64_t sC = 0) {
+                int64_t sB = 0, int64_t sC = 0, int cfg = -1, int ksplit = 0) {
   GemmDesc g{};
   g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.beta = beta;
   g.A = A; g.lda = lda; g.a_kcontig = a_kc ? 1 : 0; g.strideA = sA;
   g.B = B; g.ldb = ldb; g.b_kcontig = b_kc ? 1 : 0; g.strideB = sB;
-  g.C = C; g.ldc = ldc; g.strideC = sC; g.batch = batch;
+  g.C = C; g.ldc = ldc; g.strideC = sC; g.batch = batch; g.cfg = cfg; g.ksplit = ksplit;
   return dev_gemm(g);
 }
 // row-major conveniences: A is (M x K) or, transposed, stored (K x M); B is (K x N) or stored (N x K)

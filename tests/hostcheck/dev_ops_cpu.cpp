@@ -81,6 +81,20 @@ int dev_div_denom(double* x, int64_t d0, int64_t d1, int64_t d2, int64_t d3, con
     x[((i0 * d1 + i1) * d2 + i2) * d3 + i3] /= (ea[i0] + (eb ? eb[i1] : 0.0) - ec[i2] - (ed ? ed[i3] : 0.0));
   return 0;
 }
+int dev_sym_pack_rows(int64_t o, int64_t ncols, const double* in, double* out) {
+  for (int64_t i = 0; i < o; ++i) for (int64_t j = 0; j <= i; ++j) std::memcpy(out + (i * (i + 1) / 2 + j) * ncols, in + (i * o + j) * ncols, sizeof(double) * ncols);
+  return 0;
+}
+int dev_sym_ladder_scatter(int64_t o, int64_t v, const double* R, double* t2) {
+  for (int64_t i = 0; i < o; ++i) for (int64_t j = 0; j <= i; ++j) {
+    const double* Rp = R + (i * (i + 1) / 2 + j) * v * v;
+    for (int64_t a = 0; a < v; ++a) for (int64_t b = 0; b < v; ++b) {
+      t2[((i * o + j) * v + a) * v + b] += Rp[a * v + b];
+      if (i != j) t2[((j * o + i) * v + b) * v + a] += Rp[a * v + b];
+    }
+  }
+  return 0;
+}
 int dev_dot(int64_t n, const double* x, const double* y, double* o) { long double s = 0; for (int64_t i = 0; i < n; ++i) s += (long double)x[i] * y[i]; *o = (double)s; return 0; }
 int dev_absmax(int64_t n, const double* x, double* o) { double m = 0; for (int64_t i = 0; i < n; ++i) m = std::max(m, std::fabs(x[i])); *o = m; return 0; }
 int dev_gemv_rows(int64_t rows, int64_t cols, const double* T, int64_t ldt, const double* x, double* y, double alpha, double beta) {

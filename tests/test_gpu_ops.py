@@ -272,3 +272,37 @@ def test_mfma_f64_peak_calibration(qlib):
     t = C.c_double()
     check(qlib.qemb_mfma_f64_peak(20000, 2, C.byref(t)))
     assert 20.0 < t.value < 200.0
+
+
+def test_sym_pack_and_ladder_scatter(qlib):
+    rng = np.random.default_rng(77)
+    o, v = 7, 37
+    npair = o * (o + 1) // 2
+    tau = rng.standard_normal((o, o, v, v))
+    dt, dp = DeviceBuffer.from_numpy(tau), DeviceBuffer(npair * v * v)
+    check(qlib.qemb_op_sym_pack_rows(o, v * v, dt.ptr, dp.ptr))
+    il = np.tril_indices(o)
+    assert np.array_equal(dp.numpy((npair, v, v)), tau[il[0], il[1]])
+    R = rng.standard_normal((npair, v, v)); t2 = rng.standard_normal((o, o, v, v))
+    dR, d2 = DeviceBuffer.from_numpy(R), DeviceBuffer.from_numpy(t2)
+    check(qlib.qemb_op_sym_ladder_scatter(o, v, dR.ptr, d2.ptr))
+    ref = t2.copy()
+    for p, (i, j) in enumerate(zip(*il)):
+        ref[i, j] += R[p]
+        if i != j:
+            ref[j, i] += R[p].T
+    assert np.allclose(d2.numpy(t2.shape), ref, atol=1e-14)
+
+
+@pytest.mark.parametrize("cfg,M", [(10, 210), (11, 100), (12, 64), (10, 224)])
+@pytest.mark.parametrize("ks", [0, 3])
+def test_gemm_single_m_tile_configs(qlib, cfg, M, ks):
+    rng = np.random.default_rng(cfg + M)
+    N, K = 1000, 1536
+    A = rng.standard_normal((1, M, K)); B = rng.standard_normal((1, K, N)); C0 = rng.standard_normal((1, M, N))
+    qlib.qemb_set_gemm_ksplit(ks)
+    try:
+        got = _gemm(qlib, A, B, C0, 1.0, 0.0, 1, 1, cfg=cfg)
+    finally:
+        qlib.qemb_set_gemm_ksplit(0)
+    assert np.abs(got - A @ B).max() < 1e-10

@@ -51,8 +51,13 @@ if __name__ == "__main__":
     for bpc in (1, 2, 4):
         t = C.c_double(); check(lib.qemb_mfma_f64_peak(40000, bpc, C.byref(t)))
         print(json.dumps(dict(tag="mfma_f64 register-only peak", blocks_per_cu=bpc, tflops=t.value)), flush=True)
-    for cfg in (1, 5, 7, 8, 9):
-        bench(o * o, v * v, v * v, 1, 1, cfg, tag="pp-ladder tau[ij,cd] W[ab,cd]")
+    bench(o * o, v * v, v * v, 1, 1, 1, tag="pp-ladder dense tau[ij,cd] W[ab,cd]")
+    npair = o * (o + 1) // 2
+    for ks in (1, 2, 4, 5, 8):
+        lib.qemb_set_gemm_ksplit(ks)
+        r = bench(npair, v * v, v * v, 1, 1, 10, tag=f"pp-ladder packed i>=j rows (M={npair}), 224x128 tile, ksplit={ks}")
+        print(json.dumps(dict(dense_equivalent_tflops=2.0 * o * o * v ** 4 / (r["ms"] * 1e-3) / 1e12)), flush=True)
+    lib.qemb_set_gemm_ksplit(0)
     bench(o, v, o * v * v, 1, 0, -1, tag="t1 term: M=o N=v K=o v^2 (split-K)")
     bench(v, v, o * o * v, 0, 0, -1, tag="Fvv: M=v N=v K=o^2 v (split-K)")
     bench(o * o, o * o, v * v, 1, 1, -1, tag="Woooo: M=N=o^2 K=v^2 (split-K)")
