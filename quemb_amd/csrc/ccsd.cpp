@@ -205,8 +205,16 @@ int CcsdSolver::update_amps(double* t1n, double* t2n) {
     int cfg = -1, ks = 0;
     if (np <= 224 && vv >= 4096) {
       cfg = np <= 64 ? 12 : (np <= 112 ? 11 : 10);
+      // split K so that (N-tiles x slices) fills whole rounds of the 256 CUs (1 workgroup of 8 waves per CU):
+      // v = 200 -> 313 tiles, 4 slices = 1252 workgroups = 4.9 rounds (98 % of the last round used)
       const int64_t tiles = (vv + 127) / 128;
-      ks = (int)std::max<int64_t>(1, std::min<int64_t>(8, (1280 + tiles - 1) / tiles));   // ~5 workgroups per CU
+      double best = 0.0;
+      for (int c = 1; c <= 8; ++c) {
+        const int64_t units = tiles * c, rounds = (units + 255) / 256;
+        const double eff = (double)units / (double)(rounds * 256) - (c == 1 ? 0.0 : 0.002 * c);   // slabs cost a little
+        if (units >= 512 && eff > best + 1e-9) { best = eff; ks = c; }
+      }
+      if (ks == 0) ks = (int)std::max<int64_t>(1, std::min<int64_t>(8, (1024 + tiles - 1) / tiles));
     }
     QTRY(dev_timer_begin(TIMER_LADDER));
     QTRY(gemm(np, vv, vv, 1.0, taup_, vv, true, I_.Vl, vv, true, 0.0, Rlad_, vv, 1, 0, 0, 0, cfg, ks));
