@@ -236,8 +236,17 @@ def main():
         scf_ms, scf_cnt = read_timer(lib, 4)
         ring_ms, ring_cnt = read_timer(lib, 1)
         lad_avg = lad_ms / max(lad_cnt, 1) * 1e-3
-        flop_ladder = 2.0 * o * o * float(v) ** 4
+        npair_o = o * (o + 1) // 2
+        flop_ladder = 2.0 * npair_o * float(v) ** 4              # executed: only the i >= j rows are contracted
+        flop_dense = 2.0 * o * o * float(v) ** 4                 # SURVEY 8(d) dense-equivalent figure
         achieved = flop_ladder / lad_avg / 1e12 if lad_avg > 0 else 0.0
+        traffic = None                                           # HBM bytes per launch from the separate --pmc passes
+        pmc = ROOT / "profiles" / "r01_pmc_ladder.json"
+        if pmc.exists():
+            try:
+                traffic = json.loads(pmc.read_text()).get("hbm_bytes_per_launch")
+            except Exception:  # noqa: BLE001
+                traffic = None
         res = {
             "metric": "fragment CCSD iters/sec (full BE sweep over synthetic n_occ=20 n_virt=200 fragments); corr-E error vs oracle in parity_max_abs_err_Eh",
             "value": n_iter_total / dt, "unit": "CCSD iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -250,9 +259,11 @@ def main():
             "fragments_per_s": n_frag_total / dt,
             "ccsd_iterations_per_fragment": n_iter_total / max(n_frag_total, 1),
             "mean_e_corr_per_fragment": float(tot[5]) / max(n_frag_total, 1),
-            "roofline": {"bound": "mfma", "kernel": "dgemm_mfma_kernel (pp-ladder tau[ij,cd] x W[ab,cd], M=o^2 N=v^2 K=v^2)",
+            "roofline": {"bound": "mfma", "kernel": "dgemm_mfma_kernel<14,1,1,8,16> (pp-ladder tau[(i>=j),cd] x W[ab,cd]^T, M=npair(o) N=v^2 K=v^2, split-K + slab reduce)",
                          "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_MFMA_TFLOPS,
-                         "traffic": None, "avg_launch_ms": lad_avg * 1e3, "launches": lad_cnt, "flop_per_launch": flop_ladder},
+                         "traffic": traffic, "avg_launch_ms": lad_avg * 1e3, "launches": lad_cnt, "flop_per_launch": flop_ladder,
+                         "dense_equivalent_tflops": flop_dense / lad_avg / 1e12 if lad_avg > 0 else 0.0,
+                         "algorithmic_bytes_per_launch": 8.0 * (float(v) ** 4 + 2.0 * npair_o * v * v)},
             "device_time_ms_rank0": {"ccsd_iteration_avg": it_ms / max(it_cnt, 1), "ccsd_iterations": it_cnt, "rings_avg": ring_ms / max(ring_cnt, 1),
                                      "mo_transform_avg": ao_ms / max(ao_cnt, 1), "fragment_scf_avg": scf_ms / max(scf_cnt, 1)},
         }
