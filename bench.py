@@ -167,10 +167,17 @@ def main():
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); lrank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     dist = None
+    # QEMB_DIST_BACKEND=gloo + several ranks on one card is a rehearsal mode for 1-GPU boxes (RCCL refuses duplicate GPUs)
+    backend = os.environ.get("QEMB_DIST_BACKEND", "nccl")
+    ndev = max(torch.cuda.device_count(), 1)
+    lrank = lrank % ndev
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(lrank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", lrank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", lrank))
+        else:
+            dist.init_process_group(backend=backend)
     from quemb_amd import _lib
     from quemb_amd.fragsolver import default_opts
     lib = _lib.init(lrank)
@@ -189,7 +196,8 @@ def main():
         frs.append((fr, h, dm0))
     sync = torch.cuda.synchronize if torch.cuda.is_available() else (lambda: None)
 
-    buf_t = torch.zeros(8, dtype=torch.float64, device=torch.device("cuda", lrank)) if world > 1 else None
+    comm_dev = torch.device("cuda", lrank) if backend == "nccl" else torch.device("cpu")
+    buf_t = torch.zeros(8, dtype=torch.float64, device=comm_dev) if world > 1 else None
 
     def sweep():
         acc = np.zeros(8)
@@ -220,7 +228,7 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=torch.device("cuda", lrank))
+        tt = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     else:

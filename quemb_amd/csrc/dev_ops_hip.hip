@@ -525,7 +525,8 @@ int dev_contract_mid(int64_t outer, int64_t mid, int64_t inner, const double* T,
   REQUIRE_INIT();
   if (outer <= 0 || inner <= 0) return QEMB_OK;
   if (outer > 65535) { set_error("dev_contract_mid: outer too large"); return QEMB_ERR_ARG; }
-  int nchunk = (int)std::max<int64_t>(1, std::min<int64_t>(mid / 64, std::max<int64_t>(1, 4096 / outer)));
+  // enough (p, chunk) workgroups to cover the chip: ~2048 in total, at least 8 rows of T per chunk
+  int nchunk = (int)std::max<int64_t>(1, std::min<int64_t>(mid / 8, std::max<int64_t>(1, 2048 / outer)));
   int rc = ensure_ws((size_t)outer * nchunk * inner * sizeof(double));
   if (rc) return rc;
   hipLaunchKernelGGL(contract_mid_stage1, dim3(nchunk, (unsigned)outer), dim3(256), 0, g_stream, (long long)mid, (long long)inner, nchunk, T, x, g_ws);
