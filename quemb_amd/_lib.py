@@ -148,6 +148,8 @@ def init(device: int | None = None):
     global _initialised_device
     lib = load()
     if device is None:
+        if _initialised_device is not None:
+            return lib                      # keep the device chosen by an earlier explicit init()
         device = int(os.environ.get("LOCAL_RANK", "0"))
     if _initialised_device != device:
         check(lib.qemb_init(int(device)), "qemb_init")
