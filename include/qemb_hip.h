@@ -79,6 +79,13 @@ int qemb_op_div_denom(double* x, int64_t d0, int64_t d1, int64_t d2, int64_t d3,
 /* out[p,:] = in[i*o+j,:] for pairs p = i(i+1)/2+j, i>=j;  t2[i,j,a,b] += R[p,a,b], t2[j,i,a,b] += R[p,b,a] (i != j) */
 int qemb_op_sym_pack_rows(int64_t o, int64_t ncols, const double* in, double* out);
 int qemb_op_sym_ladder_scatter(int64_t o, int64_t v, const double* R, double* t2);
+/* (+/-) pair-packed pp-ladder helpers, P(x,y) = x(x+1)/2+y (x>=y), Q(x,y) = x(x-1)/2+y (x>y):
+ * Vp[P(ab),P(cd)] = (ac|bd)+(ad|bc), Vm[Q(ab),Q(cd)] = (ac|bd)-(ad|bc) from the n^4 MO tensor (virtuals offset o);
+ * Tp[P(ij),P(cd)] = w(tau_ijcd+tau_ijdc), w = 1/2 | 1/4 (c==d), Tm[Q(ij),Q(cd)] = (tau_ijcd-tau_ijdc)/2;
+ * scatter: t2[ijab] += Rp+Rm, t2[ijba] += Rp-Rm, t2[jiab] += Rp-Rm, t2[jiba] += Rp+Rm                         */
+int qemb_op_ladder_pack_vvvv(int64_t n, int64_t o, const double* M, double* Vp, int64_t ldp, double* Vm, int64_t ldm);
+int qemb_op_ladder_pack_tau(int64_t o, int64_t v, const double* tau, double* Tp, int64_t ldp, double* Tm, int64_t ldm);
+int qemb_op_ladder_scatter_pm(int64_t o, int64_t v, const double* Rp, int64_t ldp, const double* Rm, int64_t ldm, double* t2);
 int qemb_op_dot(int64_t n, const double* x, const double* y, double* out_dev);
 int qemb_op_absmax(int64_t n, const double* x, double* out_dev);
 int qemb_op_gemv_rows(int64_t rows, int64_t cols, const double* T, int64_t ldt, const double* x, double* y,

@@ -64,6 +64,9 @@ def _declare(lib):
     f("qemb_set_gemm_ksplit", I, I)
     f("qemb_op_sym_pack_rows", I, L, L, P, P)
     f("qemb_op_sym_ladder_scatter", I, L, L, P, P)
+    f("qemb_op_ladder_pack_vvvv", I, L, L, P, P, L, P, L)
+    f("qemb_op_ladder_pack_tau", I, L, L, P, P, L, P, L)
+    f("qemb_op_ladder_scatter_pm", I, L, L, P, L, P, L, P)
     f("qemb_mfma_f64_peak", I, I, I, C.POINTER(D))
     f("qemb_op_copy4", I, C.POINTER(L), P, C.POINTER(L), P, C.POINTER(L), D, D)
     f("qemb_op_outer4", I, C.POINTER(L), P, L, L, P, L, L, P, C.POINTER(L), D, D)

@@ -27,7 +27,7 @@ namespace qemb {
 // After step three the tensor is [q',r',s',P] with P still in the embedding basis: exactly the 3/4-transformed
 // integrals (P q'|r' s') that the fragment-projected energy of get_frag_energy (helper.py:307-321) needs.
 // ------------------------------------------------------------------------------------------------------------
-int mo_transform(int n, int o, int nf, double* X0, double* X1, const double* C, MoIntegrals& out) {
+int mo_transform(int n, int o, int nf, double* X0, double* X1, const double* C, MoIntegrals& out, bool build_Vl) {
   const int v = n - o;
   const int64_t n3 = (int64_t)n * n * n;
   out.n = n; out.o = o; out.v = v; out.nf = nf;
@@ -50,14 +50,22 @@ int mo_transform(int n, int o, int nf, double* X0, double* X1, const double* C, 
   QTRY(out.oovv.alloc((int64_t)o * o * v * v));
   QTRY(out.ovvo.alloc((int64_t)o * v * v * o));
   QTRY(out.ovvv.alloc((int64_t)o * v * v * v));
-  QTRY(out.Vl.alloc((int64_t)v * v * v * v));
   QTRY(extract4(out.oooo, M, n, n, n, 0, 0, 0, 0, o, o, o, o));
   QTRY(extract4(out.ovoo, M, n, n, n, 0, o, 0, 0, o, v, o, o));
   QTRY(extract4(out.ovov, M, n, n, n, 0, o, 0, o, o, v, o, v));
   QTRY(extract4(out.oovv, M, n, n, n, 0, 0, o, o, o, o, v, v));
   QTRY(extract4(out.ovvo, M, n, n, n, 0, o, o, 0, o, v, v, o));
   QTRY(extract4(out.ovvv, M, n, n, n, 0, o, o, o, o, v, v, v));
-  {  // Vl[a,b,c,d] = M[o+a, o+c, o+b, o+d]: loop over the source order (a,c,b,d)
+  {  // (+/-) pair-packed ladder operands (6.4 GB instead of the 12.8 GB dense v^4 block at v = 200)
+    const int64_t np = (int64_t)v * (v + 1) / 2, nm = (int64_t)v * (v - 1) / 2;
+    out.ldp = np + (np & 1); out.ldm = nm + (nm & 1);
+    if (out.ldm == 0) out.ldm = 2;
+    QTRY(out.Vp.alloc(np * out.ldp));
+    QTRY(out.Vm.alloc(std::max<int64_t>(nm, 1) * out.ldm));
+    QTRY(dev_ladder_pack_vvvv(n, o, M, out.Vp, out.ldp, out.Vm, out.ldm));
+  }
+  if (build_Vl) {  // Vl[a,b,c,d] = M[o+a, o+c, o+b, o+d]: loop over the source order (a,c,b,d)
+    QTRY(out.Vl.alloc((int64_t)v * v * v * v));
     Copy4Desc c{};
     const int64_t n1 = n, n2 = (int64_t)n * n, n3s = (int64_t)n * n * n;
     c.dim[0] = v; c.dim[1] = v; c.dim[2] = v; c.dim[3] = v;
@@ -111,7 +119,10 @@ int CcsdSolver::setup(MoIntegrals&& ints, const double* mo_energy_dev) {
   QTRY(Foo_.alloc(oo)); QTRY(Fvv_.alloc(vv)); QTRY(Fov_.alloc(nov)); QTRY(Z_.alloc(oo)); QTRY(Y_.alloc(vv));
   QTRY(Ytmp_.alloc(vv)); QTRY(Loo_.alloc(oo)); QTRY(Lvv_.alloc(vv)); QTRY(Q_.alloc(oo)); QTRY(Wo_.alloc(oo * oo));
   QTRY(O1_.alloc(oo * oo)); QTRY(X_.alloc(oo * nov)); QTRY(scal_.alloc(8));
-  QTRY(taup_.alloc(o * (o + 1) / 2 * vv)); QTRY(Rlad_.alloc(o * (o + 1) / 2 * vv));
+  {
+    const int64_t npo = o * (o + 1) / 2, nmo = std::max<int64_t>(o * (o - 1) / 2, 1);
+    QTRY(LTp_.alloc(npo * I_.ldp)); QTRY(LRp_.alloc(npo * I_.ldp)); QTRY(LTm_.alloc(nmo * I_.ldm)); QTRY(LRm_.alloc(nmo * I_.ldm));
+  }
   first_ = true;
   return 0;
 }
@@ -195,31 +206,40 @@ int CcsdSolver::update_amps(double* t1n, double* t2n) {
   QTRY(perm4(Wo_, O1_, o, o, o, o, 2, 0, 3, 1, 1.0, 1.0));                         // + ovoo[lcki] t1[jc]
   QTRY(perm4(Wo_, O1_, o, o, o, o, 0, 2, 1, 3, 1.0, 1.0));                         // + ovoo[kclj] t1[ic]
   QTRY(gemm_tn(oo, vv, oo, 1.0, Wo_, tau_, 1.0, t2n));                             // Woooo[klij] tau[klab]
-  // pp-ladder (the dominant kernel): tau[(ij),(cd)] * Vl[(ab),(cd)]^T
-  // Only the o(o+1)/2 rows i >= j are contracted (tau[j,i,c,d] = tau[i,j,d,c] and Vl[ba,dc] = Vl[ab,cd] give the
-  // (j,i) rows as the (a<->b)-transposed result), so the 12.8 GB operand Vl is streamed ONCE through a tile that
-  // holds every packed row (224 x 128, 8 waves) instead of once per 64/128-row tile of the dense o^2 x v^2 product.
+  // pp-ladder (the dominant kernel)
+  // R_ijab = sum_cd (ac|bd) tau_ijcd through pair-packed symmetric / antisymmetric combinations:
+  //   R = R+ + R-,  R+[P(ij),P(ab)] = sum_{c>=d} Vp[P(ab),P(cd)] Tp[P(ij),P(cd)],  R-[Q(ij),Q(ab)] = sum_{c>d} Vm Tm,
+  // using tau[j,i,d,c] = tau[i,j,c,d] and (ac|bd) = (bd|ac): only i >= j rows, a >= b columns and c >= d contractions
+  // are computed -- 2 npair(o) npair(v)^2 + 2 npair'(o) npair'(v)^2 flops = 1/4 of the dense 2 o^2 v^4 -- and the
+  // operands Vp, Vm (6.4 GB together at v = 200) are each streamed ONCE through a tile that holds every packed (ij) row
+  // (224 x 128, 8 waves), K split over workgroups to fill whole rounds of the 256 CUs.
   {
-    const int64_t np = o * (o + 1) / 2;
-    QTRY(dev_sym_pack_rows(o, vv, tau_, taup_));
-    int cfg = -1, ks = 0;
-    if (np <= 224 && vv >= 4096) {
-      cfg = np <= 64 ? 12 : (np <= 112 ? 11 : 10);
-      // split K so that (N-tiles x slices) fills whole rounds of the 256 CUs (1 workgroup of 8 waves per CU):
-      // v = 200 -> 313 tiles, 4 slices = 1252 workgroups = 4.9 rounds (98 % of the last round used)
-      const int64_t tiles = (vv + 127) / 128;
+    const int64_t npo = o * (o + 1) / 2, nmo = o * (o - 1) / 2, npv = v * (v + 1) / 2, nmv = v * (v - 1) / 2;
+    const int64_t ldp = I_.ldp, ldm = I_.ldm;
+    QTRY(dev_ladder_pack_tau(o, v, tau_, LTp_, ldp, LTm_, ldm));
+    auto pick = [](int64_t rows, int64_t cols, int& cfg, int& ks) {
+      cfg = -1; ks = 0;
+      if (rows > 224 || cols < 2048) return;
+      cfg = rows <= 64 ? 12 : (rows <= 112 ? 11 : 10);
+      const int64_t tiles = (cols + 127) / 128;
       double best = 0.0;
       for (int c = 1; c <= 8; ++c) {
         const int64_t units = tiles * c, rounds = (units + 255) / 256;
-        const double eff = (double)units / (double)(rounds * 256) - (c == 1 ? 0.0 : 0.002 * c);   // slabs cost a little
+        const double eff = (double)units / (double)(rounds * 256) - (c == 1 ? 0.0 : 0.002 * c);
         if (units >= 512 && eff > best + 1e-9) { best = eff; ks = c; }
       }
       if (ks == 0) ks = (int)std::max<int64_t>(1, std::min<int64_t>(8, (1024 + tiles - 1) / tiles));
-    }
+    };
+    int cfg, ks;
     QTRY(dev_timer_begin(TIMER_LADDER));
-    QTRY(gemm(np, vv, vv, 1.0, taup_, vv, true, I_.Vl, vv, true, 0.0, Rlad_, vv, 1, 0, 0, 0, cfg, ks));
+    pick(npo, npv, cfg, ks);
+    QTRY(gemm(npo, npv, ldp, 1.0, LTp_, ldp, true, I_.Vp, ldp, true, 0.0, LRp_, ldp, 1, 0, 0, 0, cfg, ks));
+    if (nmo > 0 && nmv > 0) {
+      pick(nmo, nmv, cfg, ks);
+      QTRY(gemm(nmo, nmv, ldm, 1.0, LTm_, ldm, true, I_.Vm, ldm, true, 0.0, LRm_, ldm, 1, 0, 0, 0, cfg, ks));
+    }
     QTRY(dev_timer_end(TIMER_LADDER));
-    QTRY(dev_sym_ladder_scatter(o, v, Rlad_, t2n));
+    QTRY(dev_ladder_scatter_pm(o, v, LRp_, ldp, LRm_, ldm, t2n));
   }
 
   // ---- T2 equation: terms that enter as P(X) accumulate in U
@@ -345,7 +365,7 @@ int CcsdSolver::export_block(const char* name, double* host, int64_t nelem) {
   const std::string nm(name ? name : "");
   const DBuf* b = nullptr;
   if (nm == "oooo") b = &I_.oooo; else if (nm == "ovoo") b = &I_.ovoo; else if (nm == "ovov") b = &I_.ovov;
-  else if (nm == "ovvv") b = &I_.ovvv; else if (nm == "Vl") b = &I_.Vl; else if (nm == "W1base") b = &W1base_;
+  else if (nm == "ovvv") b = &I_.ovvv; else if (nm == "Vl") b = &I_.Vl; else if (nm == "Vp") b = &I_.Vp; else if (nm == "Vm") b = &I_.Vm; else if (nm == "W1base") b = &W1base_;
   else if (nm == "W2base") b = &W2base_; else if (nm == "eo") b = &eo_; else if (nm == "ev") b = &ev_;
   if (!b || !b->p) { set_error("export_block: unknown block name"); return QEMB_ERR_ARG; }
   if (nelem != b->n) { set_error("export_block: element count mismatch"); return QEMB_ERR_ARG; }

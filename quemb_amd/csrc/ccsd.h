@@ -20,13 +20,16 @@ struct CcsdOptions {
 struct MoIntegrals {
   int n = 0, o = 0, v = 0, nf = 0;
   DBuf oooo, ovoo, ovov, oovv, ovvo, ovvv;
-  DBuf Vl;          // Vl[a,b,c,d] = (ac|bd)   (the pp-ladder operand, K-contiguous in (c,d))
+  DBuf Vl;          // Vl[a,b,c,d] = (ac|bd)   (dense ladder operand; only built on request: export / measurement)
+  // (+/-) packed ladder operands: Vp[P(a,b),P(c,d)] = (ac|bd)+(ad|bc), Vm[Q(a,b),Q(c,d)] = (ac|bd)-(ad|bc)
+  DBuf Vp, Vm;
+  int64_t ldp = 0, ldm = 0;
   DBuf A1, A2;      // A1[a,j,b,P] = (P a|j b), A2[i,j,b,P] = (P i|j b), P < nf in the EMBEDDING basis
 };
 
 // eri_s1: (n^4) embedding-basis ERIs [p,q,r,s] on the device -- OVERWRITTEN (used as ping-pong buffer);
 // work: second n^4 device buffer; C: n x n MO coefficients (columns) on the device.
-int mo_transform(int n, int o, int nf, double* eri_s1, double* work, const double* C, MoIntegrals& out);
+int mo_transform(int n, int o, int nf, double* eri_s1, double* work, const double* C, MoIntegrals& out, bool build_Vl = false);
 
 class CcsdSolver {
  public:
@@ -58,7 +61,7 @@ class CcsdSolver {
   // amplitudes (t1 then t2, one contiguous vector) and per-iteration work space
   DBuf amp_, ampn_, diff_;
   DBuf tau_, T_, Tp_, S_, W1_, W2_, W12_, R_, U_, G1_, G2_;
-  DBuf taup_, Rlad_;
+  DBuf LTp_, LTm_, LRp_, LRm_;   // (+/-) packed ladder: tau combinations and results
   DBuf Foo_, Fvv_, Fov_, Z_, Y_, Ytmp_, Loo_, Lvv_, Q_, Wo_, O1_, X_, scal_;
   std::vector<DeviceDIIS> diis_;
   bool first_ = true;

@@ -98,6 +98,17 @@ int dev_sym_pack_rows(int64_t o, int64_t ncols, const double* in, double* out);
 // t2[i,j,a,b] += R[p,a,b] and, for i != j, t2[j,i,a,b] += R[p,b,a]   (R: npair(o) x v x v)
 int dev_sym_ladder_scatter(int64_t o, int64_t v, const double* R, double* t2);
 
+// ---- (+/-) packed pp-ladder: R_ijab = sum_cd (ac|bd) tau_ijcd through symmetric / antisymmetric pair combinations ------
+// pairs: P(x,y) = x(x+1)/2 + y for x >= y ("plus" blocks), Q(x,y) = x(x-1)/2 + y for x > y ("minus" blocks).
+// Vp[P(a,b), P(c,d)] = (ac|bd) + (ad|bc),  Vm[Q(a,b), Q(c,d)] = (ac|bd) - (ad|bc)   from the MO tensor M[p,q,r,s] (n^4),
+// virtual indices offset by o; row strides ldp / ldm (>= number of pairs, padding columns are zero-filled).
+int dev_ladder_pack_vvvv(int64_t n, int64_t o, const double* M, double* Vp, int64_t ldp, double* Vm, int64_t ldm);
+// Tp[P(i,j), P(c,d)] = w_cd (tau_ijcd + tau_ijdc), w = 1/2 (c > d) or 1/4 (c == d);  Tm[Q(i,j), Q(c,d)] = (tau_ijcd - tau_ijdc)/2
+int dev_ladder_pack_tau(int64_t o, int64_t v, const double* tau, double* Tp, int64_t ldp, double* Tm, int64_t ldm);
+// with Rp[P(i,j), P(a,b)], Rm[Q(i,j), Q(a,b)]:  t2[i,j,a,b] += Rp + Rm, t2[i,j,b,a] += Rp - Rm, t2[j,i,a,b] += Rp - Rm,
+// t2[j,i,b,a] += Rp + Rm  (each distinct element once; Rm = 0 where i == j or a == b)
+int dev_ladder_scatter_pm(int64_t o, int64_t v, const double* Rp, int64_t ldp, const double* Rm, int64_t ldm, double* t2);
+
 // ---- reductions ---------------------------------------------------------------------------------
 // out_dev[0] = sum_i x[i]*y[i]   (deterministic two-stage reduction; out_dev is a device double)
 int dev_dot(int64_t n, const double* x, const double* y, double* out_dev);

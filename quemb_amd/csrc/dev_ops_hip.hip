@@ -416,6 +416,95 @@ int dev_sym_ladder_scatter(int64_t o, int64_t v, const double* R, double* t2) {
   return QEMB_OK;
 }
 
+// ---- (+/-) packed ladder ------------------------------------------------------------------------------------
+__device__ __forceinline__ void unpair_ge(long long p, long long& x, long long& y) {   // p = x(x+1)/2 + y, x >= y
+  x = (long long)((sqrt(8.0 * (double)p + 1.0) - 1.0) * 0.5);
+  while (x * (x + 1) / 2 > p) --x;
+  while ((x + 1) * (x + 2) / 2 <= p) ++x;
+  y = p - x * (x + 1) / 2;
+}
+// one block row per (a >= b); threads run over P(c,d).  Reads M[a,c,b,d] (d contiguous) and M[a,d,b,c].
+__global__ void __launch_bounds__(256) ladder_pack_vvvv_kernel(long long n, long long o, const double* __restrict__ M,
+                                                              double* __restrict__ Vp, long long ldp, double* __restrict__ Vm, long long ldm) {
+  const long long v = n - o, np = v * (v + 1) / 2;
+  for (long long ab = blockIdx.x; ab < np; ab += gridDim.x) {
+    long long a, b; unpair_ge(ab, a, b);
+    const double* Ma = M + ((o + a) * n) * n * n + (o + b) * n;      // M[o+a, :, o+b, :]
+    double* vp = Vp + ab * ldp;
+    double* vm = (a > b) ? Vm + (a * (a - 1) / 2 + b) * ldm : nullptr;
+    for (long long cd = threadIdx.x; cd < ldp; cd += blockDim.x) {
+      if (cd >= np) { vp[cd] = 0.0; continue; }
+      long long c, d; unpair_ge(cd, c, d);
+      const double x = Ma[(o + c) * n * n + (o + d)], y = Ma[(o + d) * n * n + (o + c)];
+      vp[cd] = x + y;
+      if (vm && c > d) vm[c * (c - 1) / 2 + d] = x - y;
+    }
+    if (vm) { const long long nm = v * (v - 1) / 2; for (long long q = nm + threadIdx.x; q < ldm; q += blockDim.x) vm[q] = 0.0; }
+  }
+}
+int dev_ladder_pack_vvvv(int64_t n, int64_t o, const double* M, double* Vp, int64_t ldp, double* Vm, int64_t ldm) {
+  REQUIRE_INIT();
+  const long long v = n - o, np = v * (v + 1) / 2;
+  if (np <= 0) return QEMB_OK;
+  hipLaunchKernelGGL(ladder_pack_vvvv_kernel, dim3((unsigned)std::min<long long>(np, 1 << 20)), dim3(256), 0, g_stream, (long long)n, (long long)o, M, Vp, (long long)ldp, Vm, (long long)ldm);
+  HIP_TRY(hipGetLastError());
+  return QEMB_OK;
+}
+__global__ void __launch_bounds__(256) ladder_pack_tau_kernel(long long o, long long v, const double* __restrict__ tau,
+                                                             double* __restrict__ Tp, long long ldp, double* __restrict__ Tm, long long ldm) {
+  const long long ij = blockIdx.x, np = v * (v + 1) / 2, nm = v * (v - 1) / 2;
+  long long i, j; unpair_ge(ij, i, j);
+  const double* t = tau + (i * o + j) * v * v;
+  double* tp = Tp + ij * ldp;
+  double* tm = (i > j) ? Tm + (i * (i - 1) / 2 + j) * ldm : nullptr;
+  for (long long cd = threadIdx.x; cd < ldp; cd += blockDim.x) {
+    if (cd >= np) { tp[cd] = 0.0; continue; }
+    long long c, d; unpair_ge(cd, c, d);
+    const double x = t[c * v + d], y = t[d * v + c];
+    tp[cd] = (c == d) ? 0.25 * (x + y) : 0.5 * (x + y);
+    if (tm && c > d) tm[c * (c - 1) / 2 + d] = 0.5 * (x - y);
+  }
+  if (tm) for (long long q = nm + threadIdx.x; q < ldm; q += blockDim.x) tm[q] = 0.0;
+}
+int dev_ladder_pack_tau(int64_t o, int64_t v, const double* tau, double* Tp, int64_t ldp, double* Tm, int64_t ldm) {
+  REQUIRE_INIT();
+  const long long npo = o * (o + 1) / 2;
+  if (npo <= 0 || v <= 0) return QEMB_OK;
+  hipLaunchKernelGGL(ladder_pack_tau_kernel, dim3((unsigned)npo), dim3(256), 0, g_stream, (long long)o, (long long)v, tau, Tp, (long long)ldp, Tm, (long long)ldm);
+  HIP_TRY(hipGetLastError());
+  return QEMB_OK;
+}
+// grid (v, npair(o)): block = (pair ij, row a); threads over b <= a.  Writes rows [i,j,a,:], [j,i,a,:] coalesced and
+// the transposed elements [i,j,b,a], [j,i,b,a] strided (L2-resident t2, 128 MB).
+__global__ void __launch_bounds__(256) ladder_scatter_pm_kernel(long long o, long long v, const double* __restrict__ Rp, long long ldp,
+                                                               const double* __restrict__ Rm, long long ldm, double* __restrict__ t2) {
+  const long long ij = blockIdx.y, a = blockIdx.x;
+  long long i, j; unpair_ge(ij, i, j);
+  const double* rp = Rp + ij * ldp + a * (a + 1) / 2;
+  const double* rm = (i > j && a > 0) ? Rm + (i * (i - 1) / 2 + j) * ldm + a * (a - 1) / 2 : nullptr;
+  double* tij = t2 + (i * o + j) * v * v;
+  double* tji = t2 + (j * o + i) * v * v;
+  for (long long b = threadIdx.x; b <= a; b += blockDim.x) {
+    const double p = rp[b];
+    const double m = (rm && b < a) ? rm[b] : 0.0;
+    tij[a * v + b] += p + m;
+    if (b != a) tij[b * v + a] += p - m;
+    if (i != j) {
+      tji[a * v + b] += p - m;
+      if (b != a) tji[b * v + a] += p + m;
+    }
+  }
+}
+int dev_ladder_scatter_pm(int64_t o, int64_t v, const double* Rp, int64_t ldp, const double* Rm, int64_t ldm, double* t2) {
+  REQUIRE_INIT();
+  const long long npo = o * (o + 1) / 2;
+  if (npo <= 0 || v <= 0) return QEMB_OK;
+  if (npo > 65535) { set_error("dev_ladder_scatter_pm: too many pairs"); return QEMB_ERR_ARG; }
+  hipLaunchKernelGGL(ladder_scatter_pm_kernel, dim3((unsigned)v, (unsigned)npo), dim3(256), 0, g_stream, (long long)o, (long long)v, Rp, (long long)ldp, Rm, (long long)ldm, t2);
+  HIP_TRY(hipGetLastError());
+  return QEMB_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // reductions (deterministic: fixed grid, fixed tree)
 // ------------------------------------------------------------------------------------------------

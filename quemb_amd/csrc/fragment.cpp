@@ -157,7 +157,7 @@ int Fragment::prepare_ccsd(int o, const double* h, const double* dm0, const Frag
   if (!sres.converged) { set_error("fragment SCF did not converge (also not with level shift 0.2)"); return QEMB_ERR_NOCONV; }
   QTRY(X1.alloc(n2 * n2));
   MoIntegrals ints;
-  QTRY(mo_transform(n_, o, nf_, X0, X1, C_, ints));
+  QTRY(mo_transform(n_, o, nf_, X0, X1, C_, ints, /*build_Vl=*/true));   // measurement hook: dense block available for export
   X0.release(); X1.release();
   cc_.reset(new CcsdSolver());
   QTRY(cc_->setup(std::move(ints), eps_));

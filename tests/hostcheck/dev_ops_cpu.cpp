@@ -95,6 +95,42 @@ int dev_sym_ladder_scatter(int64_t o, int64_t v, const double* R, double* t2) {
   }
   return 0;
 }
+int dev_ladder_pack_vvvv(int64_t n, int64_t o, const double* M, double* Vp, int64_t ldp, double* Vm, int64_t ldm) {
+  const int64_t v = n - o;
+  for (int64_t a = 0; a < v; ++a) for (int64_t b = 0; b <= a; ++b) {
+    double* vp = Vp + (a * (a + 1) / 2 + b) * ldp; std::fill(vp, vp + ldp, 0.0);
+    double* vm = a > b ? Vm + (a * (a - 1) / 2 + b) * ldm : nullptr; if (vm) std::fill(vm, vm + ldm, 0.0);
+    for (int64_t c = 0; c < v; ++c) for (int64_t d = 0; d <= c; ++d) {
+      const double x = M[(((o + a) * n + (o + c)) * n + (o + b)) * n + (o + d)], y = M[(((o + a) * n + (o + d)) * n + (o + b)) * n + (o + c)];
+      vp[c * (c + 1) / 2 + d] = x + y;
+      if (vm && c > d) vm[c * (c - 1) / 2 + d] = x - y;
+    }
+  }
+  return 0;
+}
+int dev_ladder_pack_tau(int64_t o, int64_t v, const double* tau, double* Tp, int64_t ldp, double* Tm, int64_t ldm) {
+  for (int64_t i = 0; i < o; ++i) for (int64_t j = 0; j <= i; ++j) {
+    const double* t = tau + (i * o + j) * v * v;
+    double* tp = Tp + (i * (i + 1) / 2 + j) * ldp; std::fill(tp, tp + ldp, 0.0);
+    double* tm = i > j ? Tm + (i * (i - 1) / 2 + j) * ldm : nullptr; if (tm) std::fill(tm, tm + ldm, 0.0);
+    for (int64_t c = 0; c < v; ++c) for (int64_t d = 0; d <= c; ++d) {
+      const double x = t[c * v + d], y = t[d * v + c];
+      tp[c * (c + 1) / 2 + d] = (c == d ? 0.25 : 0.5) * (x + y);
+      if (tm && c > d) tm[c * (c - 1) / 2 + d] = 0.5 * (x - y);
+    }
+  }
+  return 0;
+}
+int dev_ladder_scatter_pm(int64_t o, int64_t v, const double* Rp, int64_t ldp, const double* Rm, int64_t ldm, double* t2) {
+  for (int64_t i = 0; i < o; ++i) for (int64_t j = 0; j <= i; ++j) for (int64_t a = 0; a < v; ++a) for (int64_t b = 0; b <= a; ++b) {
+    const double p = Rp[(i * (i + 1) / 2 + j) * ldp + a * (a + 1) / 2 + b];
+    const double m = (i > j && a > b) ? Rm[(i * (i - 1) / 2 + j) * ldm + a * (a - 1) / 2 + b] : 0.0;
+    t2[((i * o + j) * v + a) * v + b] += p + m;
+    if (a != b) t2[((i * o + j) * v + b) * v + a] += p - m;
+    if (i != j) { t2[((j * o + i) * v + a) * v + b] += p - m; if (a != b) t2[((j * o + i) * v + b) * v + a] += p + m; }
+  }
+  return 0;
+}
 int dev_dot(int64_t n, const double* x, const double* y, double* o) { long double s = 0; for (int64_t i = 0; i < n; ++i) s += (long double)x[i] * y[i]; *o = (double)s; return 0; }
 int dev_absmax(int64_t n, const double* x, double* o) { double m = 0; for (int64_t i = 0; i < n; ++i) m = std::max(m, std::fabs(x[i])); *o = m; return 0; }
 int dev_gemv_rows(int64_t rows, int64_t cols, const double* T, int64_t ldt, const double* x, double* y, double alpha, double beta) {

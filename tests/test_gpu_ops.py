@@ -306,3 +306,33 @@ def test_gemm_single_m_tile_configs(qlib, cfg, M, ks):
     finally:
         qlib.qemb_set_gemm_ksplit(0)
     assert np.abs(got - A @ B).max() < 1e-10
+
+
+@pytest.mark.parametrize("o,v", [(3, 5), (6, 17), (4, 40)])
+def test_pm_packed_ladder_equals_dense(qlib, o, v):
+    """pack (+/-) operands, two GEMMs over pairs, scatter == dense sum_cd (ac|bd) tau_ijcd for every (i,j,a,b)."""
+    rng = np.random.default_rng(o * 100 + v)
+    n = o + v
+    Bm = rng.standard_normal((2 * n, n, n)); Bm = Bm + Bm.transpose(0, 2, 1)
+    M = np.einsum("Ppq,Prs->pqrs", Bm, Bm)
+    tau = rng.standard_normal((o, o, v, v)); tau = tau + tau.transpose(1, 0, 3, 2)
+    npv, nmv, npo, nmo = v * (v + 1) // 2, v * (v - 1) // 2, o * (o + 1) // 2, o * (o - 1) // 2
+    ldp, ldm = npv + (npv & 1), nmv + (nmv & 1)
+    dM, dT = DeviceBuffer.from_numpy(M), DeviceBuffer.from_numpy(tau)
+    dVp, dVm = DeviceBuffer(npv * ldp), DeviceBuffer(max(nmv, 1) * ldm)
+    dTp, dTm = DeviceBuffer(npo * ldp), DeviceBuffer(max(nmo, 1) * ldm)
+    dRp, dRm = DeviceBuffer(npo * ldp), DeviceBuffer(max(nmo, 1) * ldm)
+    check(qlib.qemb_op_ladder_pack_vvvv(n, o, dM.ptr, dVp.ptr, ldp, dVm.ptr, ldm))
+    check(qlib.qemb_op_ladder_pack_tau(o, v, dT.ptr, dTp.ptr, ldp, dTm.ptr, ldm))
+    vv = M[o:, o:, o:, o:]
+    il, sl = np.tril_indices(v), np.tril_indices(v, -1)
+    Vp = dVp.numpy((npv, ldp))[:, :npv]
+    ref_p = (vv.transpose(0, 2, 1, 3) + vv.transpose(0, 2, 3, 1))[il[0], il[1]][:, il[0], il[1]]     # (ac|bd)+(ad|bc) at [ab,cd]
+    assert np.allclose(Vp, ref_p, atol=1e-12)
+    check(qlib.qemb_op_gemm(npo, npv, ldp, 1.0, dTp.ptr, ldp, 1, 0, dVp.ptr, ldp, 1, 0, 0.0, dRp.ptr, ldp, 0, 1))
+    check(qlib.qemb_op_gemm(nmo, nmv, ldm, 1.0, dTm.ptr, ldm, 1, 0, dVm.ptr, ldm, 1, 0, 0.0, dRm.ptr, ldm, 0, 1))
+    t2 = rng.standard_normal((o, o, v, v))
+    d2 = DeviceBuffer.from_numpy(t2)
+    check(qlib.qemb_op_ladder_scatter_pm(o, v, dRp.ptr, ldp, dRm.ptr, ldm, d2.ptr))
+    ref = t2 + np.einsum("acbd,ijcd->ijab", vv, tau)
+    assert np.abs(d2.numpy(t2.shape) - ref).max() < 1e-10 * np.abs(ref).max()

@@ -57,6 +57,11 @@ if __name__ == "__main__":
         lib.qemb_set_gemm_ksplit(ks)
         r = bench(npair, v * v, v * v, 1, 1, 10, tag=f"pp-ladder packed i>=j rows (M={npair}), 224x128 tile, ksplit={ks}")
         print(json.dumps(dict(dense_equivalent_tflops=2.0 * o * o * v ** 4 / (r["ms"] * 1e-3) / 1e12)), flush=True)
+    npv, nmv = v * (v + 1) // 2, v * (v - 1) // 2
+    lib.qemb_set_gemm_ksplit(8)
+    r1 = bench(npair, npv, npv, 1, 1, 10, tag="pp-ladder (+) block M=npair(o) N=K=npair(v), ksplit=8")
+    r2 = bench(o * (o - 1) // 2, nmv, nmv, 1, 1, 10, tag="pp-ladder (-) block, ksplit=8")
+    print(json.dumps(dict(tag="(+/-) ladder total", ms=r1["ms"] + r2["ms"], dense_equivalent_tflops=2.0 * o * o * v ** 4 / ((r1["ms"] + r2["ms"]) * 1e-3) / 1e12)), flush=True)
     lib.qemb_set_gemm_ksplit(0)
     bench(o, v, o * v * v, 1, 0, -1, tag="t1 term: M=o N=v K=o v^2 (split-K)")
     bench(v, v, o * o * v, 0, 0, -1, tag="Fvv: M=v N=v K=o^2 v (split-K)")
