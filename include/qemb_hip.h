@@ -76,9 +76,6 @@ int qemb_op_outer4(const int64_t dim[4], const double* u, int64_t su0, int64_t s
                    int64_t sv1, int64_t sv3, double* out, const int64_t so[4], double alpha, double beta);
 int qemb_op_div_denom(double* x, int64_t d0, int64_t d1, int64_t d2, int64_t d3, const double* ea,
                       const double* eb, const double* ec, const double* ed);
-/* out[p,:] = in[i*o+j,:] for pairs p = i(i+1)/2+j, i>=j;  t2[i,j,a,b] += R[p,a,b], t2[j,i,a,b] += R[p,b,a] (i != j) */
-int qemb_op_sym_pack_rows(int64_t o, int64_t ncols, const double* in, double* out);
-int qemb_op_sym_ladder_scatter(int64_t o, int64_t v, const double* R, double* t2);
 /* (+/-) pair-packed pp-ladder helpers, P(x,y) = x(x+1)/2+y (x>=y), Q(x,y) = x(x-1)/2+y (x>y):
  * Vp[P(ab),P(cd)] = (ac|bd)+(ad|bc), Vm[Q(ab),Q(cd)] = (ac|bd)-(ad|bc) from the n^4 MO tensor (virtuals offset o);
  * Tp[P(ij),P(cd)] = w(tau_ijcd+tau_ijdc), w = 1/2 | 1/4 (c==d), Tm[Q(ij),Q(cd)] = (tau_ijcd-tau_ijdc)/2;
@@ -90,6 +87,8 @@ int qemb_op_dot(int64_t n, const double* x, const double* y, double* out_dev);
 int qemb_op_absmax(int64_t n, const double* x, double* out_dev);
 int qemb_op_gemv_rows(int64_t rows, int64_t cols, const double* T, int64_t ldt, const double* x, double* y,
                       double alpha, double beta);
+int qemb_op_gemv_rows_batched(int64_t rows, int64_t cols, int64_t nbatch, const double* T, int64_t ldt, int64_t strideT,
+                              const double* x, int64_t stridex, double* y, double alpha, double beta);
 int qemb_op_contract_mid(int64_t outer, int64_t mid, int64_t inner, const double* T, const double* x,
                          double* Y, int64_t ldy, double alpha, double beta);
 int qemb_op_unpack_s4(int64_t n, const double* s4, double* s1);

@@ -62,8 +62,6 @@ def _declare(lib):
     f("qemb_set_gemm_config", I, I)
     f("qemb_set_gemm_splitk", I, I)
     f("qemb_set_gemm_ksplit", I, I)
-    f("qemb_op_sym_pack_rows", I, L, L, P, P)
-    f("qemb_op_sym_ladder_scatter", I, L, L, P, P)
     f("qemb_op_ladder_pack_vvvv", I, L, L, P, P, L, P, L)
     f("qemb_op_ladder_pack_tau", I, L, L, P, P, L, P, L)
     f("qemb_op_ladder_scatter_pm", I, L, L, P, L, P, L, P)
@@ -74,6 +72,7 @@ def _declare(lib):
     f("qemb_op_dot", I, L, P, P, P)
     f("qemb_op_absmax", I, L, P, P)
     f("qemb_op_gemv_rows", I, L, L, P, L, P, P, D, D)
+    f("qemb_op_gemv_rows_batched", I, L, L, L, P, L, L, P, L, P, D, D)
     f("qemb_op_contract_mid", I, L, L, L, P, P, P, L, D, D)
     f("qemb_op_unpack_s4", I, L, P, P)
     f("qemb_op_pack_s4", I, L, P, P)

@@ -70,8 +70,6 @@ int qemb_op_outer4(const int64_t dim[4], const double* u, int64_t su0, int64_t s
 }
 int qemb_op_div_denom(double* x, int64_t d0, int64_t d1, int64_t d2, int64_t d3, const double* ea, const double* eb,
                       const double* ec, const double* ed) { return dev_div_denom(x, d0, d1, d2, d3, ea, eb, ec, ed); }
-int qemb_op_sym_pack_rows(int64_t o, int64_t ncols, const double* in, double* out) { return dev_sym_pack_rows(o, ncols, in, out); }
-int qemb_op_sym_ladder_scatter(int64_t o, int64_t v, const double* R, double* t2) { return dev_sym_ladder_scatter(o, v, R, t2); }
 int qemb_op_ladder_pack_vvvv(int64_t n, int64_t o, const double* M, double* Vp, int64_t ldp, double* Vm, int64_t ldm) { return dev_ladder_pack_vvvv(n, o, M, Vp, ldp, Vm, ldm); }
 int qemb_op_ladder_pack_tau(int64_t o, int64_t v, const double* tau, double* Tp, int64_t ldp, double* Tm, int64_t ldm) { return dev_ladder_pack_tau(o, v, tau, Tp, ldp, Tm, ldm); }
 int qemb_op_ladder_scatter_pm(int64_t o, int64_t v, const double* Rp, int64_t ldp, const double* Rm, int64_t ldm, double* t2) { return dev_ladder_scatter_pm(o, v, Rp, ldp, Rm, ldm, t2); }
@@ -79,6 +77,8 @@ int qemb_op_dot(int64_t n, const double* x, const double* y, double* o) { return
 int qemb_op_absmax(int64_t n, const double* x, double* o) { return dev_absmax(n, x, o); }
 int qemb_op_gemv_rows(int64_t rows, int64_t cols, const double* T, int64_t ldt, const double* x, double* y, double alpha,
                       double beta) { return dev_gemv_rows(rows, cols, T, ldt, x, y, alpha, beta); }
+int qemb_op_gemv_rows_batched(int64_t rows, int64_t cols, int64_t nbatch, const double* T, int64_t ldt, int64_t strideT, const double* x,
+                              int64_t stridex, double* y, double alpha, double beta) { return dev_gemv_rows_batched(rows, cols, nbatch, T, ldt, strideT, x, stridex, y, alpha, beta); }
 int qemb_op_contract_mid(int64_t outer, int64_t mid, int64_t inner, const double* T, const double* x, double* Y,
                          int64_t ldy, double alpha, double beta) { return dev_contract_mid(outer, mid, inner, T, x, Y, ldy, alpha, beta); }
 int qemb_op_unpack_s4(int64_t n, const double* s4, double* s1) { return dev_unpack_s4(n, s4, s1); }

@@ -179,8 +179,7 @@ int CcsdSolver::update_amps(double* t1n, double* t2n) {
   QTRY(dev_gemv_rows(nov, nov, Lovov_, nov, t1, Fov_, 1.0, 0.0));                  // Fov[k,c]
   QTRY(dev_contract_mid(1, nov, oo, Lovoo_, t1, Z_, oo, 1.0, 0.0));                // Z[k,i]
   QTRY(dev_contract_mid(1, nov, vv, I_.ovvv, t1, Y_, vv, 2.0, 0.0));               // Y[a,c] = 2 ovvv[kdac] t1[kd]
-  for (int64_t k = 0; k < o; ++k)                                                  // Ytmp[c,a] = ovvv[kcad] t1[kd]
-    QTRY(dev_gemv_rows(vv, v, I_.ovvv.p + k * v * vv, v, t1 + k * v, Ytmp_, 1.0, k == 0 ? 0.0 : 1.0));
+  QTRY(dev_gemv_rows_batched(vv, v, o, I_.ovvv, v, v * vv, t1, v, Ytmp_, 1.0, 0.0));   // Ytmp[c,a] = ovvv[kcad] t1[kd]
   QTRY(perm4(Y_, Ytmp_, 1, 1, v, v, 0, 1, 3, 2, -1.0, 1.0));                       // Y[a,c] -= Ytmp[c,a]
   QTRY(dcopy(oo, Foo_, Loo_)); QTRY(axpby(oo, 1.0, Z_, 1.0, Loo_));                // Loo' = Foo' + Z
   QTRY(dcopy(vv, Fvv_, Lvv_)); QTRY(axpby(vv, 1.0, Y_, 1.0, Lvv_));                // Lvv' = Fvv' + Y

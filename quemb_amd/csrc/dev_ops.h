@@ -92,12 +92,6 @@ int dev_outer4(const Outer4Desc& c);
 int dev_div_denom(double* x, int64_t d0, int64_t d1, int64_t d2, int64_t d3,
                   const double* ea, const double* eb, const double* ec, const double* ed);
 
-// ---- (i,j) <-> (j,i) symmetry of the doubles amplitudes: tau[j,i,d,c] = tau[i,j,c,d] --------------------------
-// out[p, c] = in[(i*o + j), c] for the o(o+1)/2 pairs p = i(i+1)/2 + j, i >= j   (rows of length ncols)
-int dev_sym_pack_rows(int64_t o, int64_t ncols, const double* in, double* out);
-// t2[i,j,a,b] += R[p,a,b] and, for i != j, t2[j,i,a,b] += R[p,b,a]   (R: npair(o) x v x v)
-int dev_sym_ladder_scatter(int64_t o, int64_t v, const double* R, double* t2);
-
 // ---- (+/-) packed pp-ladder: R_ijab = sum_cd (ac|bd) tau_ijcd through symmetric / antisymmetric pair combinations ------
 // pairs: P(x,y) = x(x+1)/2 + y for x >= y ("plus" blocks), Q(x,y) = x(x-1)/2 + y for x > y ("minus" blocks).
 // Vp[P(a,b), P(c,d)] = (ac|bd) + (ad|bc),  Vm[Q(a,b), Q(c,d)] = (ac|bd) - (ad|bc)   from the MO tensor M[p,q,r,s] (n^4),
@@ -119,6 +113,9 @@ int dev_absmax(int64_t n, const double* x, double* out_dev);
 // y[r] = alpha * sum_c T[r*ldt + c] * x[c] + beta*y[r]        r < rows, c < cols
 int dev_gemv_rows(int64_t rows, int64_t cols, const double* T, int64_t ldt, const double* x,
                   double* y, double alpha, double beta);
+// y[r] = alpha * sum_b sum_c T[b*strideT + r*ldt + c] * x[b*stridex + c] + beta*y[r]   (sum over a batch of matrices)
+int dev_gemv_rows_batched(int64_t rows, int64_t cols, int64_t nbatch, const double* T, int64_t ldt, int64_t strideT,
+                          const double* x, int64_t stridex, double* y, double alpha, double beta);
 // Y[p*ldy + r] = alpha * sum_m x[m] * T[(p*mid + m)*inner + r] + beta*Y   p<outer, m<mid, r<inner
 int dev_contract_mid(int64_t outer, int64_t mid, int64_t inner, const double* T, const double* x,
                      double* Y, int64_t ldy, double alpha, double beta);

@@ -352,70 +352,6 @@ int dev_div_denom(double* x, int64_t d0, int64_t d1, int64_t d2, int64_t d3, con
   return QEMB_OK;
 }
 
-// ------------------------------------------------------------------------------------------------
-// (ij) <-> (ji) symmetry helpers of the pp-ladder
-// ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) sym_pack_rows_kernel(long long o, long long ncols, const double* __restrict__ in, double* __restrict__ out) {
-  const long long p = blockIdx.y;
-  long long i = (long long)((sqrt(8.0 * (double)p + 1.0) - 1.0) * 0.5);
-  while (i * (i + 1) / 2 > p) --i;
-  while ((i + 1) * (i + 2) / 2 <= p) ++i;
-  const long long j = p - i * (i + 1) / 2;
-  const double* src = in + (i * o + j) * ncols;
-  double* dst = out + p * ncols;
-  for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < ncols; c += (long long)gridDim.x * blockDim.x) dst[c] = src[c];
-}
-int dev_sym_pack_rows(int64_t o, int64_t ncols, const double* in, double* out) {
-  REQUIRE_INIT();
-  const long long np = o * (o + 1) / 2;
-  if (np <= 0 || ncols <= 0) return QEMB_OK;
-  if (np > 65535) { set_error("dev_sym_pack_rows: too many pairs"); return QEMB_ERR_ARG; }
-  const unsigned gx = (unsigned)std::min<long long>((ncols + 255) / 256, 1024);
-  hipLaunchKernelGGL(sym_pack_rows_kernel, dim3(gx, (unsigned)np), dim3(256), 0, g_stream, (long long)o, (long long)ncols, in, out);
-  HIP_TRY(hipGetLastError());
-  return QEMB_OK;
-}
-// one block: pair p, 32 x 32 tile (a-block, b-block); direct add to t2[i,j] and LDS-transposed add to t2[j,i]
-__global__ void __launch_bounds__(256) sym_ladder_scatter_kernel(long long o, long long v, const double* __restrict__ R, double* __restrict__ t2) {
-  __shared__ double tile[32][33];
-  const long long p = blockIdx.y;
-  long long i = (long long)((sqrt(8.0 * (double)p + 1.0) - 1.0) * 0.5);
-  while (i * (i + 1) / 2 > p) --i;
-  while ((i + 1) * (i + 2) / 2 <= p) ++i;
-  const long long j = p - i * (i + 1) / 2;
-  const long long tb = (v + 31) / 32;
-  const long long ta = blockIdx.x / tb, tbk = blockIdx.x % tb;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  const double* Rp = R + p * v * v;
-  double* dij = t2 + (i * o + j) * v * v;
-  double* dji = t2 + (j * o + i) * v * v;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const long long a = ta * 32 + ty + 8 * r, b = tbk * 32 + tx;
-    if (a < v && b < v) {
-      const double x = Rp[a * v + b];
-      dij[a * v + b] += x;
-      tile[ty + 8 * r][tx] = x;
-    }
-  }
-  if (i == j) return;
-  __syncthreads();
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {   // t2[j,i,b,a] += R[p,a,b]: rows b (from this tile's b-block), cols a
-    const long long b = tbk * 32 + ty + 8 * r, a = ta * 32 + tx;
-    if (a < v && b < v) dji[b * v + a] += tile[tx][ty + 8 * r];
-  }
-}
-int dev_sym_ladder_scatter(int64_t o, int64_t v, const double* R, double* t2) {
-  REQUIRE_INIT();
-  const long long np = o * (o + 1) / 2, tb = (v + 31) / 32;
-  if (np <= 0 || v <= 0) return QEMB_OK;
-  if (np > 65535) { set_error("dev_sym_ladder_scatter: too many pairs"); return QEMB_ERR_ARG; }
-  hipLaunchKernelGGL(sym_ladder_scatter_kernel, dim3((unsigned)(tb * tb), (unsigned)np), dim3(256), 0, g_stream, (long long)o, (long long)v, R, t2);
-  HIP_TRY(hipGetLastError());
-  return QEMB_OK;
-}
-
 // ---- (+/-) packed ladder ------------------------------------------------------------------------------------
 __device__ __forceinline__ void unpair_ge(long long p, long long& x, long long& y) {   // p = x(x+1)/2 + y, x >= y
   x = (long long)((sqrt(8.0 * (double)p + 1.0) - 1.0) * 0.5);
@@ -582,6 +518,31 @@ int dev_gemv_rows(int64_t rows, int64_t cols, const double* T, int64_t ldt, cons
   if (rows <= 0) return QEMB_OK;
   const unsigned grid = (unsigned)std::min<int64_t>(rows, 1 << 20);
   hipLaunchKernelGGL(gemv_rows_kernel, dim3(grid), dim3(256), 0, g_stream, (long long)rows, (long long)cols, T, (long long)ldt, x, y, alpha, beta);
+  HIP_TRY(hipGetLastError());
+  return QEMB_OK;
+}
+
+__global__ void __launch_bounds__(256) gemv_rows_batched_kernel(long long rows, long long cols, long long nbatch, const double* __restrict__ T,
+                                                               long long ldt, long long strideT, const double* __restrict__ x, long long stridex,
+                                                               double* __restrict__ y, double alpha, double beta) {
+  __shared__ double sh[4];
+  const long long tot = nbatch * cols;
+  for (long long r = blockIdx.x; r < rows; r += gridDim.x) {
+    double acc = 0.0;
+    for (long long t = threadIdx.x; t < tot; t += blockDim.x) {
+      const long long b = t / cols, c = t - b * cols;
+      acc += T[b * strideT + r * ldt + c] * x[b * stridex + c];
+    }
+    const double s = block_reduce<false>(acc, sh);
+    if (threadIdx.x == 0) y[r] = (beta != 0.0) ? alpha * s + beta * y[r] : alpha * s;
+  }
+}
+int dev_gemv_rows_batched(int64_t rows, int64_t cols, int64_t nbatch, const double* T, int64_t ldt, int64_t strideT, const double* x,
+                          int64_t stridex, double* y, double alpha, double beta) {
+  REQUIRE_INIT();
+  if (rows <= 0) return QEMB_OK;
+  hipLaunchKernelGGL(gemv_rows_batched_kernel, dim3((unsigned)std::min<int64_t>(rows, 1 << 20)), dim3(256), 0, g_stream, (long long)rows, (long long)cols,
+                     (long long)nbatch, T, (long long)ldt, (long long)strideT, x, (long long)stridex, y, alpha, beta);
   HIP_TRY(hipGetLastError());
   return QEMB_OK;
 }

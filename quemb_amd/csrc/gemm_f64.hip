@@ -386,13 +386,7 @@ int dev_gemm(const GemmDesc& d) {
     case 0: return launch_layout<4, 4, 2, 2, 16>(d, s, vec2);   // 128 x 128, 4 waves
     case 1: return launch_layout<2, 2, 2, 2, 16>(d, s, vec2);   //  64 x  64, 4 waves
     case 2: return launch_layout<1, 1, 2, 2, 32>(d, s, vec2);   //  32 x  32, 4 waves
-    case 3: return launch_layout<5, 4, 1, 4, 16>(d, s, vec2);   //  80 x 256, 4 waves (M = 400 = 5*80)
     case 4: return launch_layout<4, 4, 2, 4, 16>(d, s, vec2);   // 128 x 256, 8 waves
-    case 5: return launch_layout<5, 2, 1, 4, 16>(d, s, vec2);   //  80 x 128, 4 waves
-    case 6: return launch_layout<5, 4, 1, 2, 16>(d, s, vec2);   //  80 x 128, 2 waves
-    case 7: return launch_layout<5, 1, 1, 4, 16>(d, s, vec2);   //  80 x  64, 4 waves
-    case 8: return launch_layout<5, 1, 1, 8, 16>(d, s, vec2);   //  80 x 128, 8 waves
-    case 9: return launch_layout<5, 2, 1, 8, 16>(d, s, vec2);   //  80 x 256, 8 waves
     case 10: return launch_layout<14, 1, 1, 8, 16>(d, s, vec2); // 224 x 128, 8 waves: all packed (i>=j) rows of o = 20 in ONE tile
     case 11: return launch_layout<7, 1, 1, 8, 16>(d, s, vec2);  // 112 x 128, 8 waves
     case 12: return launch_layout<4, 1, 1, 8, 16>(d, s, vec2);  //  64 x 128, 8 waves

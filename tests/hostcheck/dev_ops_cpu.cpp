@@ -81,20 +81,6 @@ int dev_div_denom(double* x, int64_t d0, int64_t d1, int64_t d2, int64_t d3, con
     x[((i0 * d1 + i1) * d2 + i2) * d3 + i3] /= (ea[i0] + (eb ? eb[i1] : 0.0) - ec[i2] - (ed ? ed[i3] : 0.0));
   return 0;
 }
-int dev_sym_pack_rows(int64_t o, int64_t ncols, const double* in, double* out) {
-  for (int64_t i = 0; i < o; ++i) for (int64_t j = 0; j <= i; ++j) std::memcpy(out + (i * (i + 1) / 2 + j) * ncols, in + (i * o + j) * ncols, sizeof(double) * ncols);
-  return 0;
-}
-int dev_sym_ladder_scatter(int64_t o, int64_t v, const double* R, double* t2) {
-  for (int64_t i = 0; i < o; ++i) for (int64_t j = 0; j <= i; ++j) {
-    const double* Rp = R + (i * (i + 1) / 2 + j) * v * v;
-    for (int64_t a = 0; a < v; ++a) for (int64_t b = 0; b < v; ++b) {
-      t2[((i * o + j) * v + a) * v + b] += Rp[a * v + b];
-      if (i != j) t2[((j * o + i) * v + b) * v + a] += Rp[a * v + b];
-    }
-  }
-  return 0;
-}
 int dev_ladder_pack_vvvv(int64_t n, int64_t o, const double* M, double* Vp, int64_t ldp, double* Vm, int64_t ldm) {
   const int64_t v = n - o;
   for (int64_t a = 0; a < v; ++a) for (int64_t b = 0; b <= a; ++b) {
@@ -135,6 +121,15 @@ int dev_dot(int64_t n, const double* x, const double* y, double* o) { long doubl
 int dev_absmax(int64_t n, const double* x, double* o) { double m = 0; for (int64_t i = 0; i < n; ++i) m = std::max(m, std::fabs(x[i])); *o = m; return 0; }
 int dev_gemv_rows(int64_t rows, int64_t cols, const double* T, int64_t ldt, const double* x, double* y, double alpha, double beta) {
   for (int64_t r = 0; r < rows; ++r) { double s = 0; for (int64_t c = 0; c < cols; ++c) s += T[r * ldt + c] * x[c]; y[r] = (beta != 0.0) ? alpha * s + beta * y[r] : alpha * s; }
+  return 0;
+}
+int dev_gemv_rows_batched(int64_t rows, int64_t cols, int64_t nbatch, const double* T, int64_t ldt, int64_t strideT, const double* x,
+                          int64_t stridex, double* y, double alpha, double beta) {
+  for (int64_t r = 0; r < rows; ++r) {
+    double s = 0;
+    for (int64_t b = 0; b < nbatch; ++b) for (int64_t c = 0; c < cols; ++c) s += T[b * strideT + r * ldt + c] * x[b * stridex + c];
+    y[r] = (beta != 0.0) ? alpha * s + beta * y[r] : alpha * s;
+  }
   return 0;
 }
 int dev_contract_mid(int64_t outer, int64_t mid, int64_t inner, const double* T, const double* x, double* Y, int64_t ldy, double alpha, double beta) {

@@ -53,10 +53,6 @@ if __name__ == "__main__":
         print(json.dumps(dict(tag="mfma_f64 register-only peak", blocks_per_cu=bpc, tflops=t.value)), flush=True)
     bench(o * o, v * v, v * v, 1, 1, 1, tag="pp-ladder dense tau[ij,cd] W[ab,cd]")
     npair = o * (o + 1) // 2
-    for ks in (1, 2, 4, 5, 8):
-        lib.qemb_set_gemm_ksplit(ks)
-        r = bench(npair, v * v, v * v, 1, 1, 10, tag=f"pp-ladder packed i>=j rows (M={npair}), 224x128 tile, ksplit={ks}")
-        print(json.dumps(dict(dense_equivalent_tflops=2.0 * o * o * v ** 4 / (r["ms"] * 1e-3) / 1e12)), flush=True)
     npv, nmv = v * (v + 1) // 2, v * (v - 1) // 2
     lib.qemb_set_gemm_ksplit(8)
     r1 = bench(npair, npv, npv, 1, 1, 10, tag="pp-ladder (+) block M=npair(o) N=K=npair(v), ksplit=8")
