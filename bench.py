@@ -270,9 +270,11 @@ def main():
             "mean_e_corr_per_fragment": float(tot[5]) / max(n_frag_total, 1),
             "roofline": {"bound": "mfma", "kernel": "dgemm_mfma_kernel<14,1,1,8,16> x2 (pp-ladder over (+/-) packed pairs: M=npair(o) N=K=npair(v), split-K + slab reduce)",
                          "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_MFMA_TFLOPS,
-                         "traffic": traffic, "avg_launch_ms": lad_avg * 1e3, "launches": lad_cnt, "flop_per_launch": flop_ladder,
+                         # one pp-ladder = TWO dispatches of this kernel ((+) and (-) pair blocks); per-dispatch averages:
+                         "traffic": None if traffic is None else traffic / 2.0, "avg_launch_ms": lad_avg * 1e3 / 2.0,
+                         "launches": 2 * lad_cnt, "flop_per_launch": flop_ladder / 2.0, "ladder_ms": lad_avg * 1e3,
                          "dense_equivalent_tflops": flop_dense / lad_avg / 1e12 if lad_avg > 0 else 0.0,
-                         "algorithmic_bytes_per_launch": 8.0 * (float(npv) ** 2 + float(nmv) ** 2 + 2.0 * npair_o * npv + 2.0 * nmo * nmv)},
+                         "algorithmic_bytes_per_launch": 4.0 * (float(npv) ** 2 + float(nmv) ** 2 + 2.0 * npair_o * npv + 2.0 * nmo * nmv)},
             "device_time_ms_rank0": {"ccsd_iteration_avg": it_ms / max(it_cnt, 1), "ccsd_iterations": it_cnt, "rings_avg": ring_ms / max(ring_cnt, 1),
                                      "mo_transform_avg": ao_ms / max(ao_cnt, 1), "fragment_scf_avg": scf_ms / max(scf_cnt, 1)},
         }
