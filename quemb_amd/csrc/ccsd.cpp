@@ -267,48 +267,43 @@ int CcsdSolver::update_amps(double* t1n, double* t2n) {
   }
   // ---- ph rings
   QTRY(dev_timer_begin(TIMER_RINGS));
-  //   W1[(ia),(kc)] = Wvoov[a,k,i,c]
+  // The t2-dependent parts of both ring intermediates come from TWO (ov)^3 products instead of three: with
+  //   u~ = 2T - Tp - 2 t1(x)t1,  Tp~ = Tp + 2 t1(x)t1   (t1(x)t1[(ia),(ld)] = t1[id] t1[la]),  L = 2 ovov - ovov_t,
+  //   Wvoov += 1/4 u~ L - 1/4 Tp~ ovov_t,      Wvovo -= 1/2 Tp~ ovov_t
+  // (expand: 1/4 (2T - Tp)(2 ovov - ovov_t) = (T - Tp/2) ovov - T ovov_t / 2 + Tp ovov_t / 4, and the t1(x)t1 pieces
+  // reproduce -ovov[ldkc] t1[id] t1[la] and -ovov[lckd] t1[id] t1[la]).
+  auto add_t1t1 = [&](double* dst, double alpha) {
+    Outer4Desc d{};   // loop (i,l,d,a): u = t1[i,d], v = t1[l,a]; out dst[i,a,l,d]
+    d.dim[0] = o; d.dim[1] = o; d.dim[2] = v; d.dim[3] = v;
+    d.u = t1; d.su0 = v; d.su2 = 1; d.v = t1; d.sv1 = v; d.sv3 = 1;
+    d.out = dst; d.so[0] = v * o * v; d.so[1] = v; d.so[2] = 1; d.so[3] = o * v;
+    d.alpha = alpha; d.beta = 1.0;
+    return dev_outer4(d);
+  };
+  QTRY(dcopy(N2, Tp_, S_)); QTRY(axpby(N2, 2.0, T_, -1.0, S_));                     // S = u = 2T - Tp   (kept for the update)
+  QTRY(dcopy(N2, S_, W12_)); QTRY(add_t1t1(W12_, -2.0));                           // W12 (scratch) = u~
   QTRY(dcopy(N2, W1base_, W1_));
   QTRY(gemm_nt(o * vv, o, v, 1.0, I_.ovvv, t1, 0.0, G1_));                         // G1[k,c,a,i] = ovvv[kcad] t1[id]
   QTRY(perm4(W1_, G1_, o, v, v, o, 3, 2, 0, 1, 1.0, 1.0));
   QTRY(gemm(o, v, o, 1.0, I_.ovoo, o, false, t1, v, false, 0.0, G1_, v, nov, oo, 0, nov));   // G1[k,c,i,a] = ovoo[kcli] t1[la]
   QTRY(perm4(W1_, G1_, o, v, o, v, 2, 3, 0, 1, -1.0, 1.0));
-  //   S = T - Tp/2 - t1[id] t1[la]   at [(ia),(ld)]
-  QTRY(dcopy(N2, T_, S_)); QTRY(axpby(N2, -0.5, Tp_, 1.0, S_));
-  {
-    Outer4Desc d{};   // loop (i,l,d,a): u = t1[i,d], v = t1[l,a]; out S[i,a,l,d]
-    d.dim[0] = o; d.dim[1] = o; d.dim[2] = v; d.dim[3] = v;
-    d.u = t1; d.su0 = v; d.su2 = 1; d.v = t1; d.sv1 = v; d.sv3 = 1;
-    d.out = S_; d.so[0] = v * o * v; d.so[1] = v; d.so[2] = 1; d.so[3] = o * v;
-    d.alpha = -1.0; d.beta = 1.0;
-    QTRY(dev_outer4(d));
-  }
-  QTRY(gemm_nn(nov, nov, nov, 1.0, S_, I_.ovov, 1.0, W1_));
-  QTRY(gemm_nn(nov, nov, nov, -0.5, T_, ovov_t_, 1.0, W1_));
+  QTRY(gemm_nn(nov, nov, nov, 0.25, W12_, Lovov_, 1.0, W1_));                      // + 1/4 u~ L
+  QTRY(dcopy(N2, Tp_, W12_)); QTRY(add_t1t1(W12_, 2.0));                           // W12 (scratch) = Tp~
+  QTRY(gemm_nn(nov, nov, nov, 1.0, W12_, ovov_t_, 0.0, R_));                       // R (scratch) = Tp~ ovov_t
+  QTRY(axpby(N2, -0.25, R_, 1.0, W1_));
   //   W2[(ia),(kc)] = Wvovo[a,k,c,i]
   QTRY(dcopy(N2, W2base_, W2_));
   QTRY(gemm(o, vv, v, 1.0, t1, v, true, I_.ovvv, vv, false, 0.0, G1_, vv, o, 0, v * vv, o * vv));   // G1[k,i,a,c] = t1[id] ovvv[kdac]
   QTRY(perm4(W2_, G1_, o, o, v, v, 1, 2, 0, 3, 1.0, 1.0));
   QTRY(gemm_tn(v, v * oo, o, 1.0, t1, I_.ovoo, 0.0, G1_));                         // G1[a,c,k,i] = t1[la] ovoo[lcki]
   QTRY(perm4(W2_, G1_, v, v, o, o, 3, 0, 2, 1, -1.0, 1.0));
-  //   S = Tp/2 + t1[id] t1[la]
-  QTRY(dev_fill(S_, N2, 0.0)); QTRY(axpby(N2, 0.5, Tp_, 0.0, S_));
-  {
-    Outer4Desc d{};
-    d.dim[0] = o; d.dim[1] = o; d.dim[2] = v; d.dim[3] = v;
-    d.u = t1; d.su0 = v; d.su2 = 1; d.v = t1; d.sv1 = v; d.sv3 = 1;
-    d.out = S_; d.so[0] = v * o * v; d.so[1] = v; d.so[2] = 1; d.so[3] = o * v;
-    d.alpha = 1.0; d.beta = 1.0;
-    QTRY(dev_outer4(d));
-  }
-  QTRY(gemm_nn(nov, nov, nov, -1.0, S_, ovov_t_, 1.0, W2_));
-  //   contributions to U
-  QTRY(dcopy(N2, W1_, W12_)); QTRY(axpby(N2, -1.0, W2_, 2.0, W12_));               // 2 W1 - W2
-  QTRY(gemm_nn(nov, nov, nov, 1.0, W12_, T_, 0.0, R_));                            // (2 Wvoov - Wvovo) t2[kjcb]
-  QTRY(gemm_nn(nov, nov, nov, -1.0, W1_, Tp_, 1.0, R_));                           // - Wvoov t2[kjbc]
+  QTRY(axpby(N2, -0.5, R_, 1.0, W2_));
+  // Update, also two products:  (2 Wvoov - Wvovo) T - Wvoov Tp = (Wvoov - Wvovo/2) u - (Wvovo Tp)/2  with T = (u + Tp)/2
+  QTRY(gemm_nn(nov, nov, nov, 1.0, W2_, Tp_, 0.0, R_));                            // A3 = Wvovo[bkci] t2[kjac] at R[i,b,j,a]
+  QTRY(perm4(U_, R_, o, v, o, v, 0, 2, 3, 1, -1.0, 1.0));                          // U[i,j,a,b] -= A3[i,b,j,a]
+  QTRY(dcopy(N2, W1_, W12_)); QTRY(axpby(N2, -0.5, W2_, 1.0, W12_));               // Wvoov - Wvovo/2
+  QTRY(gemm_nn(nov, nov, nov, 1.0, W12_, S_, -0.5, R_));                           // R = (Wvoov - Wvovo/2) u - A3/2
   QTRY(perm4(U_, R_, o, v, o, v, 0, 2, 1, 3, 1.0, 1.0));                           // R[i,a,j,b] -> U[i,j,a,b]
-  QTRY(gemm_nn(nov, nov, nov, 1.0, W2_, Tp_, 0.0, R_));                            // Wvovo[bkci] t2[kjac] at R[i,b,j,a]
-  QTRY(perm4(U_, R_, o, v, o, v, 0, 2, 3, 1, -1.0, 1.0));
   QTRY(dev_timer_end(TIMER_RINGS));
 
   // ---- symmetrise and divide

@@ -23,6 +23,11 @@
 
 namespace qemb {
 
+// pooled device allocations (dev_alloc parks freed blocks, so the per-call scratch of the Jacobi / Cholesky drivers
+// costs no hipMalloc / hipFree after the first call)
+#define QTRY_ALLOC(ptr, bytes)                                                                  \
+  do { void* _q = nullptr; int _rc = dev_alloc(&_q, (bytes)); if (_rc) return _rc; ptr = (decltype(ptr))_q; } while (0)
+
 // ------------------------------------------------------------------------------------------------
 // Jacobi core: orthogonalise the rows of W (nvec x len, ld = ldw), accumulate rotations in Vt (nvec x nvec)
 // ------------------------------------------------------------------------------------------------
@@ -139,7 +144,7 @@ static int jacobi_rows(int nvec, int64_t len, double* W, int64_t ldw, double* Vt
   if (nvec < 2) { if (sweeps_out) *sweeps_out = 0; return QEMB_OK; }
   const int np = (nvec % 2 == 0) ? nvec : nvec + 1;
   unsigned long long* d_off = nullptr;
-  HIP_TRY(hipMalloc((void**)&d_off, sizeof(unsigned long long)));
+  QTRY_ALLOC(d_off, sizeof(unsigned long long));
   const double tol = std::max(1.0e-15, std::sqrt((double)len) * 2.22e-16);   // LAPACK dgesvj-style
   const int max_sweeps = 40;
   int sweep = 0;
@@ -154,7 +159,7 @@ static int jacobi_rows(int nvec, int64_t len, double* W, int64_t ldw, double* Vt
     HIP_TRY(hipStreamSynchronize(s));
     if (bits == 0ULL) { conv = true; ++sweep; break; }   // a full sweep without a single rotation
   }
-  (void)hipFree(d_off);
+  (void)dev_free(d_off);
   if (sweeps_out) *sweeps_out = sweep;
   if (!conv) { set_error("Jacobi sweeps did not converge in 40 sweeps"); return QEMB_ERR_NOCONV; }
   return QEMB_OK;
@@ -166,9 +171,9 @@ int dev_jacobi_eigh(int64_t n64, double* A, double* w, double* V, int* sweeps_ou
   const int n = (int)n64;
   if (n <= 0) return QEMB_OK;
   double *Vt = nullptr, *tmp = nullptr; int* d_perm = nullptr;
-  HIP_TRY(hipMalloc((void**)&Vt, sizeof(double) * (size_t)n * n));
-  HIP_TRY(hipMalloc((void**)&tmp, sizeof(double) * (size_t)n));
-  HIP_TRY(hipMalloc((void**)&d_perm, sizeof(int) * (size_t)n));
+  QTRY_ALLOC(Vt, sizeof(double) * (size_t)n * n);
+  QTRY_ALLOC(tmp, sizeof(double) * (size_t)n);
+  QTRY_ALLOC(d_perm, sizeof(int) * (size_t)n);
   // Gershgorin shift
   hipLaunchKernelGGL(rowabssum_kernel, dim3(n), dim3(256), 0, s, n, (long long)n, A, (long long)n, tmp);
   std::vector<double> h(n);
@@ -196,7 +201,7 @@ int dev_jacobi_eigh(int64_t n64, double* A, double* w, double* V, int* sweeps_ou
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s));
   }
-  (void)hipFree(Vt); (void)hipFree(tmp); (void)hipFree(d_perm);
+  (void)dev_free(Vt); (void)dev_free(tmp); (void)dev_free(d_perm);
   return rc;
 }
 
@@ -207,10 +212,10 @@ int dev_jacobi_svd(int64_t m64, int64_t n64, double* G, double* sv, double* U, d
   if (n <= 0 || m <= 0) return QEMB_OK;
   if (m < n) { set_error("dev_jacobi_svd: need m >= n"); return QEMB_ERR_ARG; }
   double *Wt = nullptr, *Vt = nullptr, *tmp = nullptr; int* d_perm = nullptr;
-  HIP_TRY(hipMalloc((void**)&Wt, sizeof(double) * (size_t)n * m));
-  HIP_TRY(hipMalloc((void**)&Vt, sizeof(double) * (size_t)n * n));
-  HIP_TRY(hipMalloc((void**)&tmp, sizeof(double) * (size_t)n));
-  HIP_TRY(hipMalloc((void**)&d_perm, sizeof(int) * (size_t)n));
+  QTRY_ALLOC(Wt, sizeof(double) * (size_t)n * m);
+  QTRY_ALLOC(Vt, sizeof(double) * (size_t)n * n);
+  QTRY_ALLOC(tmp, sizeof(double) * (size_t)n);
+  QTRY_ALLOC(d_perm, sizeof(int) * (size_t)n);
   // Wt = G^T (n x m): columns of G become contiguous rows
   Copy4Desc c{};
   c.dim[0] = 1; c.dim[1] = 1; c.dim[2] = n; c.dim[3] = m;
@@ -250,7 +255,7 @@ int dev_jacobi_svd(int64_t m64, int64_t n64, double* G, double* sv, double* U, d
       HIP_TRY(hipStreamSynchronize(s));
     }
   }
-  (void)hipFree(Wt); (void)hipFree(Vt); (void)hipFree(tmp); (void)hipFree(d_perm);
+  (void)dev_free(Wt); (void)dev_free(Vt); (void)dev_free(tmp); (void)dev_free(d_perm);
   return rc;
 }
 
@@ -319,9 +324,9 @@ int dev_cholesky_lower(int64_t n64, double* A) {
   const int n = (int)n64;
   if (n <= 0) return QEMB_OK;
   double *Dinv = nullptr, *panel = nullptr; int* d_fail = nullptr;
-  HIP_TRY(hipMalloc((void**)&Dinv, sizeof(double) * NB * NB));
-  HIP_TRY(hipMalloc((void**)&panel, sizeof(double) * (size_t)n * NB));
-  HIP_TRY(hipMalloc((void**)&d_fail, sizeof(int)));
+  QTRY_ALLOC(Dinv, sizeof(double) * NB * NB);
+  QTRY_ALLOC(panel, sizeof(double) * (size_t)n * NB);
+  QTRY_ALLOC(d_fail, sizeof(int));
   HIP_TRY(hipMemsetAsync(d_fail, 0, sizeof(int), s));
   int rc = QEMB_OK;
   for (int k0 = 0; k0 < n && rc == QEMB_OK; k0 += NB) {
@@ -362,7 +367,7 @@ int dev_cholesky_lower(int64_t n64, double* A) {
     HIP_TRY(hipStreamSynchronize(s));
     if (fail) { set_error("Cholesky: matrix is not positive definite"); rc = QEMB_ERR_NUMERIC; }
   }
-  (void)hipFree(Dinv); (void)hipFree(panel); (void)hipFree(d_fail);
+  (void)dev_free(Dinv); (void)dev_free(panel); (void)dev_free(d_fail);
   return rc;
 }
 
@@ -372,9 +377,9 @@ int dev_tri_inverse_lower(int64_t n64, const double* L, double* X) {
   const int n = (int)n64;
   if (n <= 0) return QEMB_OK;
   double *Dinv = nullptr, *T = nullptr, *Lc = nullptr;
-  HIP_TRY(hipMalloc((void**)&Dinv, sizeof(double) * NB * NB));
-  HIP_TRY(hipMalloc((void**)&T, sizeof(double) * (size_t)NB * n));
-  HIP_TRY(hipMalloc((void**)&Lc, sizeof(double) * (size_t)n * n));   // diag_block_kernel takes non-const
+  QTRY_ALLOC(Dinv, sizeof(double) * NB * NB);
+  QTRY_ALLOC(T, sizeof(double) * (size_t)NB * n);
+  QTRY_ALLOC(Lc, sizeof(double) * (size_t)n * n);   // diag_block_kernel takes non-const
   HIP_TRY(hipMemcpyAsync(Lc, L, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToDevice, s));
   int rc = dev_fill(X, (int64_t)n * n, 0.0);
   for (int i0 = 0; i0 < n && rc == QEMB_OK; i0 += NB) {
@@ -404,7 +409,7 @@ int dev_tri_inverse_lower(int64_t n64, const double* L, double* X) {
     rc = dev_gemm(h);
   }
   HIP_TRY(hipStreamSynchronize(s));
-  (void)hipFree(Dinv); (void)hipFree(T); (void)hipFree(Lc);
+  (void)dev_free(Dinv); (void)dev_free(T); (void)dev_free(Lc);
   return rc;
 }
 
