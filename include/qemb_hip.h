@@ -187,6 +187,11 @@ int qemb_df_free(qemb_df_t df);
  * 1 = (naux,N,N), 2 = (naux, npair(N)) unique pairs mu >= nu (SemiSparseSym3DTensor without screening) */
 int qemb_df_set_ints(qemb_df_t df, int N, const double* ints, int layout);
 int qemb_df_transform(qemb_df_t df, const double* TA, int n, double* out_s4_host, qemb_frag_t frag);
+/* the same with the MO-coefficient screening of transform_integral(int_P_mu_nu, TA, S_abs, L_PQ, MO_coeff_epsilon)
+ * (_cpp/eri_sparse_DF.cpp:739-751): (P|mu i) is kept only for mu with |S_abs TA|(mu,i) >= epsilon (get_AO_per_MO :443);
+ * unstored (screened) AO pairs of the SemiSparseSym3DTensor are passed as zeros of the packed layout 2.              */
+int qemb_df_transform_screened(qemb_df_t df, const double* TA, int n, const double* S_abs, double MO_coeff_epsilon,
+                               double* out_s4_host, qemb_frag_t frag);
 
 /* ---------------------------------------------------------------- Schmidt decomposition ---------- */
 /* schmidt_decomposition(mo_coeff, nocc, AO_in_frag, thr_bath) -> (TA_lo_eo, n_f, n_b), molbe/pfrag.py:403-411.

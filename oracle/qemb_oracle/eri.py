@@ -99,3 +99,37 @@ def df_transform_packed(P_munu_packed, L_PQ, TA):
     sym = Pij[:, jl[0], jl[1]]
     X = scipy.linalg.solve_triangular(L_PQ, sym, lower=True)
     return X.T @ X
+
+
+def transform_integral_semisparse(P_munu_packed, stored_pairs, TA, S_abs, L_PQ, MO_coeff_epsilon):
+    """Literal restatement of transform_integral (_cpp/eri_sparse_DF.cpp:739-751):
+    get_AO_per_MO (:443-465) -> contract_with_TA_1st (:484-532) -> contract_with_TA_2nd_to_sym_dense (:560-605) ->
+    eval_via_cholesky (:611-621).  P_munu_packed: (naux, npair(N)) for mu >= nu; stored_pairs: boolean (N, N) mask of the
+    AO pairs present in the SemiSparseSym3DTensor (exch_reachable)."""
+    import scipy.linalg
+    naux = P_munu_packed.shape[0]
+    N, nmo = TA.shape
+    X = np.abs(S_abs @ TA)
+    AO_by_MO = [[mu for mu in range(N) if X[mu, i] >= MO_coeff_epsilon] for i in range(nmo)]
+    col = lambda mu, nu: ravel_symmetric(mu, nu)
+    g = {}
+    for i in range(nmo):
+        for mu in AO_by_MO[i]:
+            acc = np.zeros(naux)
+            for nu in range(N):
+                if stored_pairs[mu, nu]:
+                    acc += TA[nu, i] * P_munu_packed[:, col(mu, nu)]
+            g[(mu, i)] = acc
+    npr = npair(nmo)
+    sym = np.zeros((naux, npr))
+    for ij in range(npr):
+        i = int((np.sqrt(8 * ij + 1) - 1) // 2)
+        j = ij - i * (i + 1) // 2
+        if j > i:
+            i, j = j, i
+        tmp = np.zeros(naux)
+        for mu in AO_by_MO[i]:
+            tmp += TA[mu, j] * g[(mu, i)]
+        sym[:, ij] = tmp
+    Xs = scipy.linalg.solve_triangular(L_PQ, sym, lower=True)
+    return Xs.T @ Xs

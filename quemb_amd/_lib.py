@@ -113,6 +113,7 @@ def _declare(lib):
     f("qemb_df_free", I, V)
     f("qemb_df_set_ints", I, V, I, P, I)
     f("qemb_df_transform", I, V, P, I, P, V)
+    f("qemb_df_transform_screened", I, V, P, I, P, D, P, V)
     f("qemb_schmidt", I, P, I, I, I, LP, I, D, P, I, IP, IP)
     f("qemb_schmidt_svd", I, P, I, LP, I, D, P, I, IP, IP)
     f("qemb_nsocc_guess", I, P, I, I, P, IP, P)

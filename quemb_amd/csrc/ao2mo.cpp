@@ -97,7 +97,7 @@ int DfContext::set_ints_packed(int N_, const double* h) {
   return dev_unpack_tril_rows(naux, N, tmp, Lpq);
 }
 
-int DfContext::transform(const double* TA, int n, double* out_s4) const {
+int DfContext::transform(const double* TA, int n, double* out_s4, const double* S_abs, double eps) const {
   if (!Linv.p || !Lpq.p) { set_error("DfContext: metric and 3-index integrals must be set"); return QEMB_ERR_ARG; }
   if (n <= 0 || n > N) { set_error("df transform: need 0 < n <= N"); return QEMB_ERR_ARG; }
   const int64_t np = npair(n);
@@ -107,6 +107,16 @@ int DfContext::transform(const double* TA, int n, double* out_s4) const {
   QTRY(dev_timer_begin(TIMER_DF));
   // T1[L,i,nu] = sum_mu TA[mu,i] (L|mu nu)              (eri_onthefly.py:134, batched over L)
   QTRY(gemm(n, N, N, 1.0, TA, n, false, Lpq, N, false, 0.0, T1, N, naux, 0, (int64_t)N * N, (int64_t)n * N));
+  if (S_abs) {
+    // semi-sparse semantics (eri_sparse_DF.cpp:443-532): AO_by_MO[i] = {mu : |S_abs TA|(mu,i) >= eps}; (P|mu i) exists
+    // only for mu in AO_by_MO[i].  Pair screening of (P|mu nu) itself arrives as zeros in the packed input.
+    DBuf X, mask;
+    QTRY(X.alloc((int64_t)n * N)); QTRY(mask.alloc((int64_t)n * N));
+    // X[i,mu] = sum_nu TA[nu,i] S_abs[nu,mu]   (S_abs symmetric)
+    QTRY(gemm(n, N, N, 1.0, TA, n, false, S_abs, N, false, 0.0, X, N));
+    QTRY(dev_threshold_mask((int64_t)n * N, X, eps, mask));
+    QTRY(dev_mul_bcast_rows(naux, (int64_t)n * N, T1, mask));
+  }
   // T2[(L,i),j] = sum_nu T1[(L,i),nu] TA[nu,j]           (eri_onthefly.py:136)
   QTRY(gemm((int64_t)naux * n, n, N, 1.0, T1, N, true, TA, n, false, 0.0, T2, n));
   // unique pairs i >= j                                   (eri_sparse_DF.cpp:560-605 sym_P_pq)

@@ -28,7 +28,9 @@ class DfContext {
   int set_ints_pqL(int N_, const double* pqL_host);               // (N, N, naux) as produced by getints3c
   int set_ints_Lpq(int N_, const double* Lpq_host);               // (naux, N, N)
   int set_ints_packed(int N_, const double* P_munu_packed_host);  // (naux, npair(N)), mu >= nu
-  int transform(const double* TA_dev, int n, double* out_s4_dev) const;
+  // S_abs_dev (N x N, may be null) + eps: the MO-coefficient screening of the semi-sparse transform
+  // (_cpp/eri_sparse_DF.cpp:443-465 get_AO_per_MO): (P|mu i) is kept only where |S_abs TA|(mu,i) >= eps.
+  int transform(const double* TA_dev, int n, double* out_s4_dev, const double* S_abs_dev = nullptr, double eps = 0.0) const;
 };
 
 }  // namespace qemb

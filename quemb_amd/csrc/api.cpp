@@ -249,6 +249,18 @@ int qemb_df_set_ints(qemb_df_t df, int N, const double* ints, int layout) {
   set_error("qemb_df_set_ints: layout must be 0, 1 or 2");
   return QEMB_ERR_ARG;
 }
+int qemb_df_transform_screened(qemb_df_t df, const double* TA, int n, const double* S_abs, double MO_coeff_epsilon,
+                               double* out_s4_host, qemb_frag_t frag) {
+  if (!df || !TA || !S_abs) { set_error("qemb_df_transform_screened: null argument"); return QEMB_ERR_ARG; }
+  DfContext* d = reinterpret_cast<DfContext*>(df);
+  DBuf dTA, dS, s4;
+  int rc;
+  if ((rc = dTA.alloc((int64_t)d->N * n)) || (rc = dS.alloc((int64_t)d->N * d->N))) return rc;
+  if ((rc = dev_h2d(dTA, TA, sizeof(double) * d->N * n)) || (rc = dev_h2d(dS, S_abs, sizeof(double) * d->N * d->N))) return rc;
+  if ((rc = s4.alloc(((int64_t)n * (n + 1) / 2) * ((int64_t)n * (n + 1) / 2)))) return rc;
+  if ((rc = d->transform(dTA, n, s4, dS, MO_coeff_epsilon))) return rc;
+  return deliver_s4(s4, n, out_s4_host, frag);
+}
 int qemb_df_transform(qemb_df_t df, const double* TA, int n, double* out_s4_host, qemb_frag_t frag) {
   if (!df || !TA) { set_error("qemb_df_transform: null argument"); return QEMB_ERR_ARG; }
   DfContext* d = reinterpret_cast<DfContext*>(df);

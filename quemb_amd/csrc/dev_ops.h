@@ -103,6 +103,12 @@ int dev_ladder_pack_tau(int64_t o, int64_t v, const double* tau, double* Tp, int
 // t2[j,i,b,a] += Rp + Rm  (each distinct element once; Rm = 0 where i == j or a == b)
 int dev_ladder_scatter_pm(int64_t o, int64_t v, const double* Rp, int64_t ldp, const double* Rm, int64_t ldm, double* t2);
 
+// ---- screening helpers of the semi-sparse DF transform ---------------------------------------------------------------
+// out[i] = (|x[i]| >= eps) ? 1 : 0
+int dev_threshold_mask(int64_t n, const double* x, double eps, double* out);
+// x[r*cols + c] *= m[c]   for r < rows   (broadcast a mask / scale row over a batch of rows)
+int dev_mul_bcast_rows(int64_t rows, int64_t cols, double* x, const double* m);
+
 // ---- reductions ---------------------------------------------------------------------------------
 // out_dev[0] = sum_i x[i]*y[i]   (deterministic two-stage reduction; out_dev is a device double)
 int dev_dot(int64_t n, const double* x, const double* y, double* out_dev);

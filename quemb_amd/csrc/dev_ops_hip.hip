@@ -352,6 +352,32 @@ int dev_div_denom(double* x, int64_t d0, int64_t d1, int64_t d2, int64_t d3, con
   return QEMB_OK;
 }
 
+// ---- screening helpers (semi-sparse DF) --------------------------------------------------------------------------
+__global__ void threshold_mask_kernel(long long n, const double* __restrict__ x, double eps, double* __restrict__ out) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    out[i] = (fabs(x[i]) >= eps) ? 1.0 : 0.0;
+}
+int dev_threshold_mask(int64_t n, const double* x, double eps, double* out) {
+  REQUIRE_INIT();
+  if (n <= 0) return QEMB_OK;
+  hipLaunchKernelGGL(threshold_mask_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 4096)), dim3(256), 0, g_stream, (long long)n, x, eps, out);
+  HIP_TRY(hipGetLastError());
+  return QEMB_OK;
+}
+__global__ void __launch_bounds__(256) mul_bcast_rows_kernel(long long rows, long long cols, double* __restrict__ x, const double* __restrict__ m) {
+  for (long long r = blockIdx.y; r < rows; r += gridDim.y)
+    for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < cols; c += (long long)gridDim.x * blockDim.x)
+      x[r * cols + c] *= m[c];
+}
+int dev_mul_bcast_rows(int64_t rows, int64_t cols, double* x, const double* m) {
+  REQUIRE_INIT();
+  if (rows <= 0 || cols <= 0) return QEMB_OK;
+  hipLaunchKernelGGL(mul_bcast_rows_kernel, dim3((unsigned)std::min<int64_t>((cols + 255) / 256, 1024), (unsigned)std::min<int64_t>(rows, 65535)), dim3(256), 0, g_stream,
+                     (long long)rows, (long long)cols, x, m);
+  HIP_TRY(hipGetLastError());
+  return QEMB_OK;
+}
+
 // ---- (+/-) packed ladder ------------------------------------------------------------------------------------
 __device__ __forceinline__ void unpair_ge(long long p, long long& x, long long& y) {   // p = x(x+1)/2 + y, x >= y
   x = (long long)((sqrt(8.0 * (double)p + 1.0) - 1.0) * 0.5);

@@ -112,15 +112,24 @@ class DFContext:
         check(self.lib.qemb_df_set_ints(self.h, int(nao), ints.ctypes.data, code), "qemb_df_set_ints", self.lib)
         self.nao = int(nao)
 
-    def transform(self, TA, frag=None, want_host=True):
+    def transform(self, TA, frag=None, want_host=True, S_abs=None, MO_coeff_epsilon=None):
+        """(ij|kl) 4-fold packed.  With `S_abs` and `MO_coeff_epsilon` the reference's semi-sparse screening is applied
+        (transform_integral(int_P_mu_nu, TA, S_abs, L_PQ, MO_coeff_epsilon), molbe/eri_sparse_DF.py:677-678)."""
         TA = _arr(TA)
         if self.nao is None or TA.shape[0] != self.nao:
             raise ValueError("DFContext.transform: set_ints first / TA has the wrong number of rows")
         n = TA.shape[1]
         npair = n * (n + 1) // 2
         out = np.empty((npair, npair)) if want_host else None
-        check(self.lib.qemb_df_transform(self.h, TA.ctypes.data, n, None if out is None else out.ctypes.data,
-                                         None if frag is None else frag.h), "qemb_df_transform", self.lib)
+        op = None if out is None else out.ctypes.data
+        fh = None if frag is None else frag.h
+        if S_abs is not None:
+            S_abs = _arr(S_abs)
+            eps = 1e-5 if MO_coeff_epsilon is None else float(MO_coeff_epsilon)     # reference default, mbe.py:189
+            check(self.lib.qemb_df_transform_screened(self.h, TA.ctypes.data, n, S_abs.ctypes.data, eps, op, fh),
+                  "qemb_df_transform_screened", self.lib)
+        else:
+            check(self.lib.qemb_df_transform(self.h, TA.ctypes.data, n, op, fh), "qemb_df_transform", self.lib)
         return out
 
     def free(self):

@@ -109,13 +109,20 @@ class BE:
                 ao.transform(self.Fobjs[I].TA, frag=self.Fobjs[I].dev, want_host=False)
             ao.free()
         elif it in ("int-direct-DF-hip", "sparse-DF-hip"):
+            # df_ints: (ints, j2c, layout) or a dict(ints=, layout=, j2c= | L_PQ=, S_abs=, MO_coeff_epsilon=).
+            # "sparse-DF-hip" applies the MO-coefficient screening of the reference's semi-sparse transform
+            # (eri_sparse_DF.py:535-656, MO_coeff_epsilon default 1e-5, mbe.py:189) when S_abs is given.
             if self._df_ints is None:
-                raise ValueError("df_ints=(ints, j2c, layout) has to be given for a DF transform")
-            ints, j2c, layout = self._df_ints
-            df = et.DFContext(j2c=j2c, lib=self.lib)
-            df.set_ints(ints, self.S.shape[0], layout)
+                raise ValueError("df_ints has to be given for a DF transform")
+            d = self._df_ints
+            if not isinstance(d, dict):
+                d = dict(ints=d[0], j2c=d[1], layout=d[2])
+            df = et.DFContext(j2c=d.get("j2c"), L_PQ=d.get("L_PQ"), lib=self.lib)
+            df.set_ints(d["ints"], self.S.shape[0], d.get("layout", "pqL"))
+            S_abs = d.get("S_abs") if it == "sparse-DF-hip" else None
             for I in idx:
-                df.transform(self.Fobjs[I].TA, frag=self.Fobjs[I].dev, want_host=False)
+                df.transform(self.Fobjs[I].TA, frag=self.Fobjs[I].dev, want_host=False, S_abs=S_abs,
+                             MO_coeff_epsilon=d.get("MO_coeff_epsilon"))
             df.free()
         else:
             raise ValueError(f"int_transform {it!r} is not one of {et.HIP_INT_TRANSFORMS}")

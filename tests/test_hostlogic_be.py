@@ -166,3 +166,31 @@ def test_hf_jacobian_matches_finite_differences(hlib):
         Pm = rm["mo_coeff"][:, : f.nsocc] @ rm["mo_coeff"][:, : f.nsocc].T
         fd = (Pp - Pm) / (2 * eps)
         assert np.abs(dP[k] - fd).max() < 2e-6
+
+
+def _semisparse_case(seed=9):
+    rng = np.random.default_rng(seed)
+    N, n, naux = 12, 5, 40
+    # a banded "overlap" so that both screenings bite: AO pairs |mu-nu| > 5 are not stored
+    stored = np.abs(np.subtract.outer(np.arange(N), np.arange(N))) <= 5
+    L = rng.standard_normal((naux, N, N)); L = (L + L.transpose(0, 2, 1)) * stored
+    S_abs = np.exp(-0.9 * np.abs(np.subtract.outer(np.arange(N), np.arange(N))))
+    TA = np.linalg.qr(rng.standard_normal((N, N)))[0][:, :n] * np.exp(-0.8 * np.abs(np.subtract.outer(np.arange(N), 2.0 * np.arange(n))))
+    A = rng.standard_normal((naux, naux)); j2c = A @ A.T + naux * np.eye(naux)
+    il = np.tril_indices(N)
+    return N, n, naux, stored, np.ascontiguousarray(L[:, il[0], il[1]]), S_abs, TA, np.linalg.cholesky(j2c)
+
+
+def test_semisparse_df_screening_matches_reference_algorithm(hlib):
+    from quemb_amd import eri_transform as et
+    N, n, naux, stored, packed, S_abs, TA, Lpq = _semisparse_case()
+    for eps in (0.0, 1e-3, 5e-2, 0.3):
+        ref = oeri.transform_integral_semisparse(packed, stored, TA, S_abs, Lpq, eps)
+        df = et.DFContext(L_PQ=Lpq, lib=hlib)
+        df.set_ints(packed, N, "packed")
+        got = df.transform(TA, S_abs=S_abs, MO_coeff_epsilon=eps)
+        assert np.abs(got - ref).max() < 1e-11 * max(1.0, np.abs(ref).max()), eps
+    # the screening really changes the result at a coarse threshold and vanishes at eps = 0
+    dense = df.transform(TA)
+    assert np.abs(oeri.transform_integral_semisparse(packed, stored, TA, S_abs, Lpq, 0.0) - dense).max() < 1e-11
+    assert np.abs(oeri.transform_integral_semisparse(packed, stored, TA, S_abs, Lpq, 0.3) - dense).max() > 1e-6
