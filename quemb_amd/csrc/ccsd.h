@@ -65,6 +65,16 @@ class CcsdSolver {
   DBuf Foo_, Fvv_, Fov_, Z_, Y_, Ytmp_, Loo_, Lvv_, Q_, Wo_, O1_, X_, scal_;
   std::vector<DeviceDIIS> diis_;
   bool first_ = true;
+  // hipGraph of one update_amps (small fragments are launch bound: ~170 launches of a few microseconds each)
+  dev_graph_t graph_ = nullptr;
+  int eager_iters_ = 0;
+  bool graph_ok_ = true;
+ public:
+  ~CcsdSolver() { if (graph_) dev_graph_destroy(graph_); }
+  CcsdSolver() = default;
+  CcsdSolver(const CcsdSolver&) = delete;
+  CcsdSolver& operator=(const CcsdSolver&) = delete;
+ private:
   double ecc_ = 0.0;
 };
 

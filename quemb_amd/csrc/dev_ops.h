@@ -36,6 +36,17 @@ int dev_fill(double* x, int64_t n, double value);
 int dev_mem_info(size_t* free_b, size_t* total_b);
 const char* dev_backend_name();      // "hip-gfx950" for the product, "hostcheck" for the mock
 
+// ---- stream capture (hipGraph) of launch-bound loops ------------------------------------------------------------------
+// Between begin and end every dev_* launch is recorded instead of executed; the recorded graph can then be replayed
+// with one host call.  Only pure launch sequences may be captured (no allocation, no host transfer, no timers).
+// dev_graph_begin returns 1 (not an error) when the backend cannot capture; the caller then simply runs eagerly.
+typedef void* dev_graph_t;
+int dev_graph_begin();
+int dev_graph_end(dev_graph_t* out);
+int dev_graph_launch(dev_graph_t g);
+int dev_graph_destroy(dev_graph_t g);
+bool dev_capturing();
+
 // ---- timing (HIP events on the library stream) ------------------------------------------------
 // A "lap" accumulates elapsed device time of every region bracketed with the same slot id.
 int dev_timer_begin(int slot);

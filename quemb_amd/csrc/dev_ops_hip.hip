@@ -28,6 +28,7 @@ void set_error(const std::string& msg) { g_err = msg; }
 const char* last_error() { return g_err.c_str(); }
 
 static hipStream_t g_stream = nullptr;
+static bool g_capturing = false;          // inside hipStreamBeginCapture .. EndCapture (dev_graph_*)
 static int g_device = -1;
 static double* g_partials = nullptr;       // reduction scratch (NPART doubles)
 static constexpr int NPART = 2048;
@@ -79,6 +80,11 @@ int dev_trim() {
 }
 int dev_alloc(void** p, size_t bytes) {
   REQUIRE_INIT();
+  if (g_capturing) {   // pooled blocks are fine, a real hipMalloc is not
+    const size_t want = ((bytes ? bytes : 16) + 255) / 256 * 256;
+    auto hit = g_pool.find(want);
+    if (hit == g_pool.end() || hit->second.empty()) { set_error("device allocation inside a captured region"); return QEMB_ERR_ALLOC; }
+  }
   if (bytes == 0) bytes = 16;
   bytes = (bytes + 255) / 256 * 256;
   auto it = g_pool.find(bytes);
@@ -128,6 +134,7 @@ int dev_mem_info(size_t* free_b, size_t* total_b) { REQUIRE_INIT(); HIP_TRY(hipM
 
 double* gemm_workspace(size_t bytes) {
   if (bytes <= g_gws_bytes) return g_gws;
+  if (g_capturing) { set_error("split-K workspace growth inside a captured region"); return nullptr; }
   if (g_gws) { (void)hipStreamSynchronize(g_stream); (void)hipFree(g_gws); g_gws = nullptr; g_gws_bytes = 0; }
   const size_t want = bytes < ((size_t)64 << 20) ? ((size_t)64 << 20) : bytes;
   if (hipMalloc((void**)&g_gws, want) != hipSuccess) { set_error("split-K workspace hipMalloc failed"); return nullptr; }
@@ -137,6 +144,7 @@ double* gemm_workspace(size_t bytes) {
 
 static int ensure_ws(size_t bytes) {
   if (bytes <= g_ws_bytes) return QEMB_OK;
+  if (g_capturing) { set_error("workspace growth inside a captured region"); return QEMB_ERR_ALLOC; }
   if (g_ws) { HIP_TRY(hipStreamSynchronize(g_stream)); HIP_TRY(hipFree(g_ws)); g_ws = nullptr; g_ws_bytes = 0; }
   hipError_t e = hipMalloc((void**)&g_ws, bytes);
   if (e != hipSuccess) { set_error("workspace hipMalloc failed"); return QEMB_ERR_ALLOC; }
@@ -144,9 +152,35 @@ static int ensure_ws(size_t bytes) {
   return QEMB_OK;
 }
 
+// ---- stream capture ---------------------------------------------------------------------------------
+bool dev_capturing() { return g_capturing; }
+int dev_graph_begin() {
+  REQUIRE_INIT();
+  if (g_capturing) { set_error("dev_graph_begin: already capturing"); return QEMB_ERR_ARG; }
+  HIP_TRY(hipStreamBeginCapture(g_stream, hipStreamCaptureModeThreadLocal));
+  g_capturing = true;
+  return QEMB_OK;
+}
+int dev_graph_end(dev_graph_t* out) {
+  REQUIRE_INIT();
+  if (!g_capturing) { set_error("dev_graph_end: not capturing"); return QEMB_ERR_ARG; }
+  g_capturing = false;
+  hipGraph_t graph = nullptr;
+  HIP_TRY(hipStreamEndCapture(g_stream, &graph));
+  hipGraphExec_t exec = nullptr;
+  hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  if (e != hipSuccess) { set_error(std::string("hipGraphInstantiate failed: ") + hipGetErrorString(e)); return QEMB_ERR_DEVICE; }
+  *out = exec;
+  return QEMB_OK;
+}
+int dev_graph_launch(dev_graph_t g) { REQUIRE_INIT(); HIP_TRY(hipGraphLaunch((hipGraphExec_t)g, g_stream)); return QEMB_OK; }
+int dev_graph_destroy(dev_graph_t g) { if (g) (void)hipGraphExecDestroy((hipGraphExec_t)g); return QEMB_OK; }
+
 // ---- timers -----------------------------------------------------------------------------------
 int dev_timer_begin(int slot) {
   REQUIRE_INIT();
+  if (g_capturing) return QEMB_OK;
   if (slot < 0 || slot >= TIMER_NSLOTS) return QEMB_ERR_ARG;
   TimerSlot& t = g_timers[slot];
   hipEvent_t a, b;
@@ -157,6 +191,7 @@ int dev_timer_begin(int slot) {
 }
 int dev_timer_end(int slot) {
   REQUIRE_INIT();
+  if (g_capturing) return QEMB_OK;
   if (slot < 0 || slot >= TIMER_NSLOTS) return QEMB_ERR_ARG;
   TimerSlot& t = g_timers[slot];
   if (t.pending.empty()) return QEMB_ERR_ARG;

@@ -34,6 +34,11 @@ int dev_h2d(void* d, const void* s, size_t b) { std::memcpy(d, s, b); return 0; 
 int dev_d2h(void* d, const void* s, size_t b) { std::memcpy(d, s, b); return 0; }
 int dev_d2d(void* d, const void* s, size_t b) { std::memmove(d, s, b); return 0; }
 int dev_fill(double* x, int64_t n, double v) { std::fill(x, x + n, v); return 0; }
+int dev_graph_begin() { return 1; }   // the mock cannot capture: drivers run eagerly
+int dev_graph_end(dev_graph_t*) { return QEMB_ERR_DEVICE; }
+int dev_graph_launch(dev_graph_t) { return QEMB_ERR_DEVICE; }
+int dev_graph_destroy(dev_graph_t) { return 0; }
+bool dev_capturing() { return false; }
 int dev_mem_info(size_t* f, size_t* t) { *f = *t = (size_t)1 << 34; return 0; }
 
 static double g_tot[TIMER_NSLOTS]; static int64_t g_cnt[TIMER_NSLOTS];
