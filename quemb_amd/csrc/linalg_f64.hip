@@ -99,6 +99,63 @@ __global__ void __launch_bounds__(256) jacobi_round_kernel(double* W, long long 
   }
 }
 
+// Single-workgroup variant for small problems (nvec, len <= JS_MAX): W and Vt live in LDS, every round is one pass of
+// the workgroup's 16 waves over the n/2 pairs (one pair per wave at a time), rounds and sweeps are separated by
+// __syncthreads instead of kernel launches.  A 41-orbital fragment Fock matrix (octane BE2) needs ~330 rounds per
+// eigh: one launch here instead of 330.
+constexpr int JS_MAX = 96;
+__global__ void __launch_bounds__(1024) jacobi_small_kernel(double* Wg, long long ldw, int len, double* Vtg, int nvec, int np,
+                                                            double tol, double floor2, int max_sweeps, int* sweeps_out) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int ldW = len + 1, ldV = nvec + 1;
+  double* W = lds;
+  double* V = lds + (size_t)nvec * ldW;
+  __shared__ int rotated;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+  for (int t = tid; t < nvec * len; t += blockDim.x) W[(t / len) * ldW + (t % len)] = Wg[(long long)(t / len) * ldw + (t % len)];
+  for (int t = tid; t < nvec * nvec; t += blockDim.x) V[(t / nvec) * ldV + (t % nvec)] = Vtg[(long long)(t / nvec) * nvec + (t % nvec)];
+  __syncthreads();
+  int sweep = 0;
+  for (; sweep < max_sweeps; ++sweep) {
+    if (tid == 0) rotated = 0;
+    __syncthreads();
+    for (int r = 0; r < np - 1; ++r) {
+      for (int k = wave; k < np / 2; k += nwaves) {
+        int p, q;
+        rr_pair(np, r, k, p, q);
+        if (q >= nvec) continue;
+        double* wp = W + p * ldW; double* wq = W + q * ldW;
+        double a = 0.0, b = 0.0, g = 0.0;
+        for (int i = lane; i < len; i += 64) { const double x = wp[i], y = wq[i]; a += x * x; b += y * y; g += x * y; }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { a += __shfl_xor(a, off, 64); b += __shfl_xor(b, off, 64); g += __shfl_xor(g, off, 64); }
+        double c = 1.0, sn = 0.0;
+        if (a > floor2 && b > floor2) {
+          const double rel = fabs(g) / sqrt(a * b);
+          if (rel > tol) {
+            const double zeta = (b - a) / (2.0 * g);
+            const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+            c = 1.0 / sqrt(1.0 + t * t); sn = c * t;
+          }
+        }
+        if (sn != 0.0) {
+          if (lane == 0) rotated = 1;
+          for (int i = lane; i < len; i += 64) { const double x = wp[i], y = wq[i]; wp[i] = c * x - sn * y; wq[i] = sn * x + c * y; }
+          double* vp = V + p * ldV; double* vq = V + q * ldV;
+          for (int i = lane; i < nvec; i += 64) { const double x = vp[i], y = vq[i]; vp[i] = c * x - sn * y; vq[i] = sn * x + c * y; }
+        }
+      }
+      __syncthreads();
+    }
+    const int any = rotated;
+    __syncthreads();
+    if (!any) { ++sweep; break; }
+  }
+  for (int t = tid; t < nvec * len; t += blockDim.x) Wg[(long long)(t / len) * ldw + (t % len)] = W[(t / len) * ldW + (t % len)];
+  for (int t = tid; t < nvec * nvec; t += blockDim.x) Vtg[(long long)(t / nvec) * nvec + (t % nvec)] = V[(t / nvec) * ldV + (t % nvec)];
+  if (tid == 0) sweeps_out[0] = (sweep <= max_sweeps && !rotated) ? sweep : -1;
+}
+
 // out[i] = sum_k X[i*ldx+k] * Y[i*ldy+k]
 __global__ void __launch_bounds__(256) rowdot_kernel(int nrow, long long len, const double* X, long long ldx, const double* Y, long long ldy, double* out) {
   __shared__ double sh[4];
@@ -143,6 +200,23 @@ static int jacobi_rows(int nvec, int64_t len, double* W, int64_t ldw, double* Vt
   hipStream_t s = hip_stream();
   if (nvec < 2) { if (sweeps_out) *sweeps_out = 0; return QEMB_OK; }
   const int np = (nvec % 2 == 0) ? nvec : nvec + 1;
+  if (Vt && nvec <= JS_MAX && len <= JS_MAX) {   // LDS-resident single-workgroup path
+    int* d_sw = nullptr;
+    QTRY_ALLOC(d_sw, sizeof(int));
+    const double tol_s = std::max(1.0e-15, std::sqrt((double)len) * 2.22e-16);
+    const size_t lds = sizeof(double) * ((size_t)nvec * (len + 1) + (size_t)nvec * (nvec + 1));
+    static bool attr_set = false;
+    if (!attr_set) { HIP_TRY(hipFuncSetAttribute((const void*)jacobi_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64)); attr_set = true; }
+    hipLaunchKernelGGL(jacobi_small_kernel, dim3(1), dim3(1024), lds, s, W, (long long)ldw, (int)len, Vt, nvec, np, tol_s, floor2, 40, d_sw);
+    HIP_TRY(hipGetLastError());
+    int sw = 0;
+    HIP_TRY(hipMemcpyAsync(&sw, d_sw, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    (void)dev_free(d_sw);
+    if (sweeps_out) *sweeps_out = sw;
+    if (sw < 0) { set_error("Jacobi sweeps did not converge in 40 sweeps"); return QEMB_ERR_NOCONV; }
+    return QEMB_OK;
+  }
   unsigned long long* d_off = nullptr;
   QTRY_ALLOC(d_off, sizeof(unsigned long long));
   const double tol = std::max(1.0e-15, std::sqrt((double)len) * 2.22e-16);   // LAPACK dgesvj-style
