@@ -198,6 +198,10 @@ int qemb_df_transform_screened(qemb_df_t df, const double* TA, int n, const doub
  * lmo: N x nmo row-major; TA_lo_eo: caller buffer N x ld (ld >= n_f + n_b; 2*n_f always suffices).      */
 int qemb_schmidt(const double* lmo, int N, int nmo, int nocc, const int64_t* frag_idx, int n_f, double thr,
                  double* TA_lo_eo, int ld, int* n_b, int* sweeps);
+/* Same contract and (for the idempotent HF 1-RDM of pfrag.py:448-450) the same bath as qemb_schmidt, through the
+ * rank-n_f invariant subspace spanned by D[env,frag]: O(N_env n_f nocc) instead of the O(N_env^3) eigenproblem.   */
+int qemb_schmidt_subspace(const double* lmo, int N, int nmo, int nocc, const int64_t* frag_idx, int n_f, double thr,
+                          double* TA_lo_eo, int ld, int* n_b, int* sweeps);
 /* schmidt_decomp_svd(rdm, Frag_sites, thr_bath) -> TA, kbe/solver.py:9 (real part)                     */
 int qemb_schmidt_svd(const double* rdm, int N, const int64_t* frag_idx, int n_f, double thr, double* TA, int ld,
                      int* n_b, int* sweeps);

@@ -115,6 +115,7 @@ def _declare(lib):
     f("qemb_df_transform", I, V, P, I, P, V)
     f("qemb_df_transform_screened", I, V, P, I, P, D, P, V)
     f("qemb_schmidt", I, P, I, I, I, LP, I, D, P, I, IP, IP)
+    f("qemb_schmidt_subspace", I, P, I, I, I, LP, I, D, P, I, IP, IP)
     f("qemb_schmidt_svd", I, P, I, LP, I, D, P, I, IP, IP)
     f("qemb_nsocc_guess", I, P, I, I, P, IP, P)
     f("qemb_matmul", I, L, L, L, P, I, P, I, P)

@@ -14,6 +14,8 @@ extern int g_gemm_force_cfg;
 extern int g_gemm_splitk_enabled;
 int schmidt_eigh(const double* lmo, int N, int nmo, int nocc, const int64_t* frag, int n_f, double thr, double* TA_out,
                  int ld_out, int* n_b_out, int* sweeps_out);
+int schmidt_subspace(const double* lmo, int N, int nmo, int nocc, const int64_t* frag, int n_f, double thr, double* TA_out,
+                     int ld_out, int* n_b_out, int* sweeps_out);
 int schmidt_svd(const double* rdm, int N, const int64_t* frag_in, int n_f, double thr, double* TA_out, int ld_out, int* n_b_out,
                 int* sweeps_out);
 int nsocc_guess(const double* Cproj, int n, int nocc, double* P_out, int* nsocc, double* mo_out);
@@ -278,6 +280,11 @@ int qemb_schmidt(const double* lmo, int N, int nmo, int nocc, const int64_t* fra
                  int* n_b, int* sweeps) {
   if (!lmo || !frag_idx || !TA || !n_b) { set_error("qemb_schmidt: null argument"); return QEMB_ERR_ARG; }
   return schmidt_eigh(lmo, N, nmo, nocc, frag_idx, n_f, thr, TA, ld, n_b, sweeps);
+}
+int qemb_schmidt_subspace(const double* lmo, int N, int nmo, int nocc, const int64_t* frag_idx, int n_f, double thr, double* TA,
+                          int ld, int* n_b, int* sweeps) {
+  if (!lmo || !frag_idx || !TA || !n_b) { set_error("qemb_schmidt_subspace: null argument"); return QEMB_ERR_ARG; }
+  return schmidt_subspace(lmo, N, nmo, nocc, frag_idx, n_f, thr, TA, ld, n_b, sweeps);
 }
 int qemb_schmidt_svd(const double* rdm, int N, const int64_t* frag_idx, int n_f, double thr, double* TA, int ld, int* n_b,
                      int* sweeps) {

@@ -51,6 +51,66 @@ int schmidt_eigh(const double* lmo, int N, int nmo, int nocc, const int64_t* fra
   return 0;
 }
 
+// Same result as schmidt_eigh for an idempotent D = C_occ C_occ^T at O(N_env n_f^2 + N_env nocc n_f) cost instead of the
+// O(N_env^3) eigenproblem: D_env^2 = D_env - D_ef D_fe, hence D_env D_ef = D_ef (1 - D_ff): the column space R of D_ef
+// (dimension <= n_f) is invariant under the symmetric D_env, the eigenvectors with 0 < lambda < 1 (the bath) all lie in
+// R, and everything in R-perp has lambda in {0, 1}.  So: orthonormalise D_ef (Jacobi SVD of an N_env x n_f matrix),
+// project D_env on that basis (n_f x n_f), diagonalise the projection, rotate back.
+int schmidt_subspace(const double* lmo, int N, int nmo, int nocc, const int64_t* frag, int n_f, double thr, double* TA_out,
+                     int ld_out, int* n_b_out, int* sweeps_out) {
+  if (N <= 0 || nocc <= 0 || nocc > nmo || n_f <= 0 || n_f >= N) { set_error("schmidt: bad dimensions"); return QEMB_ERR_ARG; }
+  std::vector<char> isfrag((size_t)N, 0);
+  for (int k = 0; k < n_f; ++k) {
+    if (frag[k] < 0 || frag[k] >= N || isfrag[(size_t)frag[k]]) { set_error("schmidt: bad fragment index list"); return QEMB_ERR_ARG; }
+    isfrag[(size_t)frag[k]] = 1;
+  }
+  std::vector<int> env;
+  for (int i = 0; i < N; ++i) if (!isfrag[(size_t)i]) env.push_back(i);
+  const int ne = (int)env.size();
+  if (ne < n_f) return schmidt_eigh(lmo, N, nmo, nocc, frag, n_f, thr, TA_out, ld_out, n_b_out, sweeps_out);
+  std::vector<double> cenv((size_t)ne * nocc), cf((size_t)n_f * nocc);
+  for (int r = 0; r < ne; ++r) for (int k = 0; k < nocc; ++k) cenv[(size_t)r * nocc + k] = lmo[(size_t)env[(size_t)r] * nmo + k];
+  for (int r = 0; r < n_f; ++r) for (int k = 0; k < nocc; ++k) cf[(size_t)r * nocc + k] = lmo[(size_t)frag[r] * nmo + k];
+  DBuf dCe, dCf, dDef, ds, dU;
+  QTRY(dCe.alloc((int64_t)ne * nocc)); QTRY(dCf.alloc((int64_t)n_f * nocc)); QTRY(dDef.alloc((int64_t)ne * n_f));
+  QTRY(ds.alloc(n_f)); QTRY(dU.alloc((int64_t)ne * n_f));
+  QTRY(dev_h2d(dCe, cenv.data(), sizeof(double) * ne * nocc));
+  QTRY(dev_h2d(dCf, cf.data(), sizeof(double) * n_f * nocc));
+  QTRY(dev_timer_begin(TIMER_SCHMIDT));
+  QTRY(gemm_nt(ne, n_f, nocc, 1.0, dCe, dCf, 0.0, dDef));                       // D_ef = C_env C_f^T
+  QTRY(dev_jacobi_svd(ne, n_f, dDef, ds, dU, nullptr, sweeps_out));
+  std::vector<double> sv((size_t)n_f);
+  QTRY(dev_d2h(sv.data(), ds, sizeof(double) * n_f));
+  int r = 0;
+  while (r < n_f && sv[(size_t)r] > 1.0e-9) ++r;      // sigma^2 = lambda (1 - lambda): a safe superset of thr < lambda < 1 - thr
+  *n_b_out = 0;
+  for (int i = 0; i < N; ++i) for (int c = 0; c < ld_out; ++c) TA_out[(size_t)i * ld_out + c] = 0.0;
+  for (int k = 0; k < n_f; ++k) TA_out[(size_t)frag[k] * ld_out + k] = 1.0;
+  if (r == 0) { QTRY(dev_timer_end(TIMER_SCHMIDT)); return 0; }
+  // A = U_r^T D_env U_r = Z^T Z,  Z = C_env^T U_r   (nocc x r); U is ne x n_f row-major, its first r columns are used
+  DBuf dZ, dA, dw, dY, dB;
+  QTRY(dZ.alloc((int64_t)nocc * r)); QTRY(dA.alloc((int64_t)r * r)); QTRY(dw.alloc(r)); QTRY(dY.alloc((int64_t)r * r));
+  QTRY(gemm(nocc, r, ne, 1.0, dCe, nocc, false, dU, n_f, false, 0.0, dZ, r));      // Z[k,b] = sum_e C_env[e,k] U[e,b]
+  QTRY(gemm(r, r, nocc, 1.0, dZ, r, false, dZ, r, false, 0.0, dA, r));             // A = Z^T Z
+  QTRY(dev_jacobi_eigh(r, dA, dw, dY, nullptr));
+  QTRY(dev_timer_end(TIMER_SCHMIDT));
+  std::vector<double> w((size_t)r), Y((size_t)r * r), U((size_t)ne * n_f);
+  QTRY(dev_d2h(w.data(), dw, sizeof(double) * r));
+  QTRY(dev_d2h(Y.data(), dY, sizeof(double) * r * r));
+  QTRY(dev_d2h(U.data(), dU, sizeof(double) * ne * n_f));
+  std::vector<int> bidx;
+  for (int i = 0; i < r; ++i) if (thr < std::fabs(w[(size_t)i]) && std::fabs(w[(size_t)i]) < 1.0 - thr) bidx.push_back(i);
+  const int nb = (int)bidx.size();
+  *n_b_out = nb;
+  if (n_f + nb > ld_out) { set_error("schmidt: output buffer too narrow for n_f + n_b columns"); return QEMB_ERR_ARG; }
+  for (int e = 0; e < ne; ++e) for (int b = 0; b < nb; ++b) {
+    double acc = 0.0;
+    for (int c = 0; c < r; ++c) acc += U[(size_t)e * n_f + c] * Y[(size_t)c * r + bidx[(size_t)b]];
+    TA_out[(size_t)env[(size_t)e] * ld_out + n_f + b] = acc;
+  }
+  return 0;
+}
+
 // rdm: N x N (host, real).  kbe/solver.py:9-46.
 int schmidt_svd(const double* rdm, int N, const int64_t* frag_in, int n_f, double thr, double* TA_out, int ld_out, int* n_b_out,
                 int* sweeps_out) {

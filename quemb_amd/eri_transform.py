@@ -144,9 +144,13 @@ class DFContext:
             pass
 
 
-def schmidt_decomposition(mo_coeff, nocc, AO_in_frag, thr_bath=1.0e-10, cinv=None, rdm=None, norb=None, lib=None):
+def schmidt_decomposition(mo_coeff, nocc, AO_in_frag, thr_bath=1.0e-10, cinv=None, rdm=None, norb=None, lib=None, method="eigh"):
     """Same signature / return as molbe/pfrag.py:403-411: (TA_lo_eo, n_f, n_b).  The `cinv`, `rdm` and `norb`
-    variants of the reference are only reached from UBE (out of scope) and raise here."""
+    variants of the reference are only reached from UBE (out of scope) and raise here.
+    method="eigh" is the reference's formulation (Jacobi eigh of the full environment block); method="subspace" gives the
+    same bath through the rank-n_f invariant subspace of D[env,frag] (see csrc/schmidt.cpp) at a fraction of the cost."""
+    if method not in ("eigh", "subspace"):
+        raise ValueError("method must be 'eigh' or 'subspace'")
     if cinv is not None or rdm is not None or norb is not None:
         raise NotImplementedError("schmidt_decomposition: cinv / rdm / norb variants (UBE) are outside the hot path")
     lib = lib or _lib.init()
@@ -158,7 +162,8 @@ def schmidt_decomposition(mo_coeff, nocc, AO_in_frag, thr_bath=1.0e-10, cinv=Non
     while True:
         TA = np.empty((N, ld))
         nb, sw = C.c_int(), C.c_int()
-        rc = lib.qemb_schmidt(C_.ctypes.data, N, nmo, int(nocc), frag.ctypes.data_as(C.POINTER(C.c_int64)), nf, float(thr_bath),
+        fn = lib.qemb_schmidt if method == "eigh" else lib.qemb_schmidt_subspace
+        rc = fn(C_.ctypes.data, N, nmo, int(nocc), frag.ctypes.data_as(C.POINTER(C.c_int64)), nf, float(thr_bath),
                               TA.ctypes.data, ld, C.byref(nb), C.byref(sw))
         if rc == -1 and b"too narrow" in lib.qemb_last_error() and ld < N:
             ld = N          # more bath orbitals than fragment orbitals (non-idempotent input): retry with full width

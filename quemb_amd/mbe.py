@@ -32,7 +32,7 @@ def initialize_pot(n_frag, relAO_per_edge):
 class BE:
     def __init__(self, mf, fobj, *, lo_method="lowdin", thr_bath=1.0e-10, int_transform="in-core-hip", auxbasis=None,
                  df_ints=None, nproc=1, ompnum=1, initialize_fragment_idx=None, solver_opts=None, lib=None, distribute=True,
-                 eri_file=None, scratch_dir=None, restart=False):
+                 eri_file=None, scratch_dir=None, restart=False, schmidt_method="subspace"):
         if lo_method != "lowdin":
             raise NotImplementedError("only lo_method='lowdin' is mirrored (localisation is upstream of the hot path)")
         if getattr(fobj, "frozen_core", False):
@@ -41,6 +41,7 @@ class BE:
             raise NotImplementedError("restart files are outside the hot path")
         self.mf, self.fobj, self.lib = mf, fobj, lib
         self.thr_bath = thr_bath
+        self.schmidt_method = schmidt_method      # 'eigh' = reference formulation, 'subspace' = same bath, O(N_env n_f nocc)
         self.int_transform = int_transform
         self.opts = solver_opts
         self.unrestricted = False
@@ -88,7 +89,7 @@ class BE:
         self.emap = ErrorMap(self.Fobjs) if fo.n_BE != 1 and any(fo.relAO_per_edge_per_frag) else None
         # Schmidt decomposition of every fragment this rank may own (cheap; sizes decide the partition)
         for f in self.Fobjs:
-            f.sd(self.W, self.lmo_coeff, self.Nocc, thr_bath=self.thr_bath)
+            f.sd(self.W, self.lmo_coeff, self.Nocc, thr_bath=self.thr_bath, method=self.schmidt_method)
             f.get_nsocc(self.S, self.C, self.Nocc)
         costs = [fragment_cost(f.nao, f.nsocc) for f in self.Fobjs]
         self.owner = partition_fragments(costs, self.world)

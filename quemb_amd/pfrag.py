@@ -64,10 +64,11 @@ class Frags:
         self._hf_jk = None
 
     # ------------------------------------------------------------------ Schmidt (pfrag.py:146-180)
-    def sd(self, lao, lmo, nocc, thr_bath, norb=None):
+    def sd(self, lao, lmo, nocc, thr_bath, norb=None, method="eigh"):
         if norb is not None:
             raise NotImplementedError("norb (UBE) is outside the hot path")
-        self.TA_lo_eo, self.n_f, self.n_b = et.schmidt_decomposition(lmo, nocc, self.AO_in_frag, thr_bath=thr_bath, lib=self.lib)
+        self.TA_lo_eo, self.n_f, self.n_b = et.schmidt_decomposition(lmo, nocc, self.AO_in_frag, thr_bath=thr_bath, lib=self.lib,
+                                                                      method=method)
         self.TA = et.matmul(lao, self.TA_lo_eo, lib=self.lib)
         self.nao = self.TA.shape[1]
         self.dev = DeviceFragment(self.nao, self.n_frag, lib=self.lib)
@@ -165,8 +166,6 @@ class Frags:
     # ------------------------------------------------------------------ the sweep body
     def solve(self, opts=None, eeval=True, use_cumulant=True, want_t2=False):
         """update_heff -> scf -> solve_ccsd -> rdm1 -> get_frag_energy for this fragment (solver.py:301-547)."""
-        if not use_cumulant:
-            raise NotImplementedError("non-cumulant energy expression is not implemented on the device")
         if eeval:
             w, cen = self.weight_and_relAO_per_center
             self.dev.set_energy_data(self.h1, self.veff0, self.veff, w, cen)
@@ -177,4 +176,25 @@ class Frags:
         self.t2 = out["t2"]
         self.rdm1__ = out["rdm1_mo"]
         self._rdm1 = out["rdm1_emb"]
+        if eeval and not use_cumulant:
+            out["e_frag"] = self._noncumulant_energy(out)
         return out
+
+    def _noncumulant_energy(self, out):
+        """get_frag_energy(use_cumulant=False) (helper.py:292-339): the 2-RDM then carries the mean-field pieces
+        (make_rdm2_urlx(with_dm1=True), ccsd_rdm.py:40-53).  They are bilinear in D0 = C_o C_o^T and the first-order
+        change D' = C [[0,t1],[t1^T,0]] C^T, so their contraction with the fragment ERIs reduces to J/K builds on the
+        device:  e2_P += sum_Q D0_PQ (J[D'] - K[D']/2 + 2 J[D0] - K[D0])_PQ + D'_PQ (J[D0] - K[D0]/2)_PQ."""
+        nf, o = self.n_frag, self.nsocc
+        C = out["mo_coeff"]
+        D0 = C[:, :o] @ C[:, :o].T
+        rdm = out["rdm1_emb"]
+        Dp = 2.0 * (rdm - D0)
+        J0, K0 = self.dev.jk(D0)
+        Jp, Kp = self.dev.jk(Dp)
+        e2x = np.einsum("ij,ij->i", D0[:nf], (Jp - 0.5 * Kp + 2.0 * J0 - K0)[:nf]) + np.einsum("ij,ij->i", Dp[:nf], (J0 - 0.5 * K0)[:nf])
+        e1 = 2.0 * np.einsum("ij,ij->i", self.h1[:nf], rdm[:nf])
+        ec = np.einsum("ij,ij->i", self.veff[:nf], rdm[:nf])
+        w, cen = self.weight_and_relAO_per_center
+        e2c = out["e_frag"][1]                       # cumulant part, already centre-summed on the device
+        return np.array([w * sum(e1[c] for c in cen), e2c + w * sum(e2x[c] for c in cen), w * sum(ec[c] for c in cen)])

@@ -46,6 +46,10 @@ def test_schmidt_matches_reference_goldens(qlib):
     for case in range(4):
         Cm, nocc, frag = g[f"C{case}"], int(g[f"nocc{case}"]), list(g[f"frag{case}"])
         TA, nf, nb = et.schmidt_decomposition(Cm, nocc, frag)
+        TAs_, nfs_, nbs_ = et.schmidt_decomposition(Cm, nocc, frag, lib=None, method="subspace")
+        assert (nfs_, nbs_) == (nf, nb) and np.abs(TAs_ @ TAs_.T - TA @ TA.T).max() < 1e-9
+        for k in range(nf, nf + nb):      # same eigenvectors (up to sign), same order
+            assert min(np.abs(TAs_[:, k] - TA[:, k]).max(), np.abs(TAs_[:, k] + TA[:, k]).max()) < 1e-7
         ref = g[f"TA{case}"]
         assert (nf, nb) == tuple(g[f"nfnb{case}"]) and TA.shape == ref.shape
         assert np.array_equal(TA[:, :nf], ref[:, :nf])

@@ -77,6 +77,10 @@ def test_schmidt_matches_reference_goldens(hlib):
     for case in range(4):
         Cm, nocc, frag = g[f"C{case}"], int(g[f"nocc{case}"]), list(g[f"frag{case}"])
         TA, nf, nb = et.schmidt_decomposition(Cm, nocc, frag, lib=hlib)
+        TAs_, nfs_, nbs_ = et.schmidt_decomposition(Cm, nocc, frag, lib=hlib, method="subspace")
+        assert (nfs_, nbs_) == (nf, nb) and np.abs(TAs_ @ TAs_.T - TA @ TA.T).max() < 1e-9
+        for k in range(nf, nf + nb):      # same eigenvectors (up to sign), same order
+            assert min(np.abs(TAs_[:, k] - TA[:, k]).max(), np.abs(TAs_[:, k] + TA[:, k]).max()) < 1e-7
         ref = g[f"TA{case}"]
         assert (nf, nb) == tuple(g[f"nfnb{case}"]) and TA.shape == ref.shape
         assert np.array_equal(TA[:, :nf], ref[:, :nf])
@@ -194,3 +198,44 @@ def test_semisparse_df_screening_matches_reference_algorithm(hlib):
     dense = df.transform(TA)
     assert np.abs(oeri.transform_integral_semisparse(packed, stored, TA, S_abs, Lpq, 0.0) - dense).max() < 1e-11
     assert np.abs(oeri.transform_integral_semisparse(packed, stored, TA, S_abs, Lpq, 0.3) - dense).max() > 1e-6
+
+
+def test_h8_be1_chemical_potential_only(hlib):
+    """BE1 (no edges, one AO per fragment): only the global chemical potential is optimised (mbe.py:897-905)."""
+    from quemb_amd.fragpart import FragPart
+    from quemb_amd.integrals import RHF, Mole
+    from quemb_amd.mbe import BE
+    mol = Mole([["H", (0.0, 0.0, float(i))] for i in range(8)])
+    mf = RHF(mol); mf.kernel()
+    fobj = FragPart.from_json(GOLDEN / "fragmentation.json", "test_autogen_h_linear_be1", n_BE=1)
+    be = BE(mf, fobj, lib=hlib, distribute=False)
+    assert abs(be.hf_err) < 1e-8
+    with pytest.raises(ValueError):
+        be.optimize(solver="CCSD", only_chem=False)
+    opt = be.optimize(solver="CCSD", only_chem=True, conv_tol=1e-8)
+    assert opt.err < 1e-8 and len(be.pot) == 1
+    # electron count restored: sum of centre populations == Nocc
+    tr = sum(f._rdm1[i, i] for f in be.Fobjs for i in f.weight_and_relAO_per_center[1])
+    assert abs(tr - be.Nocc) < 1e-7
+    with pytest.raises(ValueError):
+        be.oneshot(solver="FCI")
+
+
+def test_noncumulant_energy_expression(hlib):
+    """use_cumulant=False (helper.py:292-296 + make_rdm2_urlx(with_dm1=True)) through J/K builds == the oracle's
+    explicit n^4 2-RDM contraction (itself pinned to the reference's golden for both flags)."""
+    from quemb_amd.pfrag import Frags
+    from qemb_oracle import ccsd as occsd, rdm as ordm, scf as oscf
+    n, o, nf, cen = 8, 3, 3, [0, 2]
+    h, e1 = synthetic_fragment(n, o, 123)
+    rng = np.random.default_rng(4)
+    mk = lambda: (lambda a: a + a.T)(rng.standard_normal((n, n)))
+    f = Frags(list(range(nf)), 0, [], [], [], [], (0.5, cen), [0], lib=hlib)
+    f.set_eri(oeri.pack_s4(e1))
+    f.nsocc, f.h1, f.veff0, f.veff, f.fock, f.heff, f.dm0 = o, mk(), mk(), mk(), h, np.zeros((n, n)), None
+    out = f.solve(eeval=True, use_cumulant=False)
+    mf = oscf.rhf(h, e1, o)
+    t1, t2, _, _ = occsd.solve_ccsd(h, e1, o, mf["mo_coeff"], mf["mo_energy"])
+    ref = obe.get_frag_energy(mf["mo_coeff"], o, nf, (0.5, cen), np.zeros((n, n)), f.h1, ordm.make_rdm1_ccsd_t1(t1),
+                              ordm.make_rdm2_urlx(t1, t2, with_dm1=True), oeri.pack_s4(e1), f.veff0, f.veff, False)
+    assert np.allclose(out["e_frag"], ref, atol=1e-8), (out["e_frag"], ref)
