@@ -56,7 +56,11 @@ def all_reduce_sum(buf: np.ndarray, device=None):
     import torch
     backend = d.get_backend()
     if backend == "nccl":
-        t = torch.from_numpy(buf).to(device if device is not None else torch.device("cuda", torch.cuda.current_device()))
+        if device is None:
+            from . import _lib
+            idx = _lib._initialised_device if _lib._initialised_device is not None else torch.cuda.current_device()
+            device = torch.device("cuda", idx)
+        t = torch.from_numpy(buf).to(device)
         d.all_reduce(t, op=d.ReduceOp.SUM)
         buf[:] = t.cpu().numpy()
     else:

@@ -67,4 +67,5 @@ if __name__ == "__main__":
         bench(4096, 4096, 4096, 1, 1, cfg, tag="square NT")
         bench(4096, 4096, 4096, 1, 0, cfg, tag="square NN")
         bench(4096, 4096, 4096, 0, 0, cfg, tag="square TN")
-    bench(220, 220 ** 3, 220, 0, 1, 0, tag="quarter transform C^T X^T")
+    for cfg in (0, 4, 10):
+        bench(220, 220 ** 3, 220, 0, 1, cfg, tag="quarter transform C^T X^T")
