@@ -94,6 +94,15 @@ int qemb_op_contract_mid(int64_t outer, int64_t mid, int64_t inner, const double
 int qemb_op_unpack_s4(int64_t n, const double* s4, double* s1);
 int qemb_op_pack_s4(int64_t n, const double* s1, double* s4);
 int qemb_op_unpack_s8_to_s4(int64_t n, const double* s8, double* s4);
+/* pair-packed MO transformation helpers (half the flops of the four-index ao2mo.kernel call of PySCF's cc.ao2mo(),
+ * which solve_ccsd reaches at molbe/solver.py:900): row gather r >= s; block gather from the half-packed tensor
+ * Mh[p][q][P(r,s)]; block gather from the 3/4-transformed tensor T[q'][P(r',s')][p]; (+/-) ladder operands from Mh. */
+int qemb_op_pack_pair_rows(int64_t n, int64_t ncols, const double* in, double* out);
+int qemb_op_extract_hp(int64_t n, const double* Mh, int64_t p0, int64_t q0, int64_t r0, int64_t s0, int64_t sp, int64_t sq,
+                       int64_t sr, int64_t ss, double* out);
+int qemb_op_extract_mid_pair(int64_t rows, int64_t n, int64_t ncols, const double* T, int64_t r0, int64_t s0, int64_t sr,
+                             int64_t ss, int64_t c0, int64_t sc, double* out);
+int qemb_op_ladder_pack_vvvv_hp(int64_t n, int64_t o, const double* Mh, double* Vp, int64_t ldp, double* Vm, int64_t ldm);
 int qemb_op_unpack_tril_rows(int64_t rows, int64_t n, const double* packed, double* full);
 int qemb_op_pack_tril_rows(int64_t rows, int64_t n, const double* full, double* packed);
 int qemb_op_jacobi_eigh(int64_t n, double* A, double* w, double* V, int* sweeps);

@@ -23,62 +23,66 @@
 namespace qemb {
 
 // ------------------------------------------------------------------------------------------------------------
-// embedding -> MO transformation: four quarter transforms, each  Out[s',(pqr)] = sum_s C[s,s'] In[(pqr),s]
-// (TN GEMM, M = n, N = n^3, K = n).  The index order cycles, so after four steps the layout is [p',q',r',s'].
-// After step three the tensor is [q',r',s',P] with P still in the embedding basis: exactly the 3/4-transformed
-// integrals (P q'|r' s') that the fragment-projected energy of get_frag_energy (helper.py:307-321) needs.
+// embedding -> MO transformation on pair-packed operands.  Every step is the TN GEMM
+//   Out[x', (rest)] = sum_x C[x,x'] In[(rest), x]      (M = n, N = rest, K = n)
+// and both pair symmetries of (pq|rs) are used, so each GEMM runs over npair*n columns instead of n^3
+// (half the flops of the full four-index transformation):
+//   X1 [pq][r][s]        <- unpack rs of the resident s4 block (p >= q rows only)
+//   X0 [s'][pq][r]       <- GEMM over s          X1 [r'][s'][pq]   <- GEMM over r   (symmetric in r',s')
+//   X0 [(r's')][pq]      <- keep r' >= s' rows   X1 [(r's')][p][q] <- unpack pq
+//   X0 [q'][(r's')][P]   <- GEMM over q: the 3/4-transformed integrals (P q'|r' s') that the
+//                           fragment-projected energy of get_frag_energy (helper.py:307-321) needs
+//   X1 [p'][q'][(r's')]  <- GEMM over p: the half-packed MO tensor every block below is gathered from
 // ------------------------------------------------------------------------------------------------------------
-int mo_transform(int n, int o, int nf, double* X0, double* X1, const double* C, MoIntegrals& out, bool build_Vl) {
+int64_t mo_transform_work(int n) { return (int64_t)n * n * ((int64_t)n * (n + 1) / 2); }
+
+int mo_transform(int n, int o, int nf, const double* eri_s4, double* X0, double* X1, const double* C, MoIntegrals& out, bool build_Vl) {
   const int v = n - o;
-  const int64_t n3 = (int64_t)n * n * n;
+  const int64_t np = (int64_t)n * (n + 1) / 2, ncol = np * n;
   out.n = n; out.o = o; out.v = v; out.nf = nf;
-  double* src = X0; double* dst = X1;
   QTRY(dev_timer_begin(TIMER_AO2MO));
-  for (int step = 0; step < 4; ++step) {
-    QTRY(gemm(n, n3, n, 1.0, C, n, false, src, n, true, 0.0, dst, n3));
-    std::swap(src, dst);
-    if (step == 2 && nf > 0) {   // src = [q',r',s',P]
-      QTRY(out.A1.alloc((int64_t)v * o * v * nf));
-      QTRY(out.A2.alloc((int64_t)o * o * v * nf));
-      QTRY(extract4(out.A1, src, n, n, n, o, 0, o, 0, v, o, v, nf));
-      QTRY(extract4(out.A2, src, n, n, n, 0, 0, o, 0, o, o, v, nf));
-    }
+  QTRY(dev_unpack_tril_rows(np, n, eri_s4, X1));
+  QTRY(gemm(n, ncol, n, 1.0, C, n, false, X1, n, true, 0.0, X0, ncol));
+  QTRY(gemm(n, ncol, n, 1.0, C, n, false, X0, n, true, 0.0, X1, ncol));
+  QTRY(dev_pack_pair_rows(n, np, X1, X0));
+  QTRY(dev_unpack_tril_rows(np, n, X0, X1));
+  QTRY(gemm(n, ncol, n, 1.0, C, n, false, X1, n, true, 0.0, X0, ncol));
+  if (nf > 0) {   // X0 = [q'][(r's')][P]
+    QTRY(out.A1.alloc((int64_t)v * o * v * nf));
+    QTRY(out.A2.alloc((int64_t)o * o * v * nf));
+    QTRY(dev_extract_mid_pair(v, n, n, X0 + (int64_t)o * ncol, 0, o, o, v, 0, nf, out.A1));   // A1[a,j,b,P] = (P a|j b)
+    QTRY(dev_extract_mid_pair(o, n, n, X0, 0, o, o, v, 0, nf, out.A2));                        // A2[i,j,b,P] = (P i|j b)
   }
-  const double* M = src;   // [p',q',r',s']
+  QTRY(gemm(n, ncol, n, 1.0, C, n, false, X0, n, true, 0.0, X1, ncol));
+  const double* Mh = X1;   // [p'][q'][(r's')]
   QTRY(out.oooo.alloc((int64_t)o * o * o * o));
   QTRY(out.ovoo.alloc((int64_t)o * v * o * o));
   QTRY(out.ovov.alloc((int64_t)o * v * o * v));
   QTRY(out.oovv.alloc((int64_t)o * o * v * v));
   QTRY(out.ovvo.alloc((int64_t)o * v * v * o));
   QTRY(out.ovvv.alloc((int64_t)o * v * v * v));
-  QTRY(extract4(out.oooo, M, n, n, n, 0, 0, 0, 0, o, o, o, o));
-  QTRY(extract4(out.ovoo, M, n, n, n, 0, o, 0, 0, o, v, o, o));
-  QTRY(extract4(out.ovov, M, n, n, n, 0, o, 0, o, o, v, o, v));
-  QTRY(extract4(out.oovv, M, n, n, n, 0, 0, o, o, o, o, v, v));
-  QTRY(extract4(out.ovvo, M, n, n, n, 0, o, o, 0, o, v, v, o));
-  QTRY(extract4(out.ovvv, M, n, n, n, 0, o, o, o, o, v, v, v));
+  QTRY(dev_extract_hp(n, Mh, 0, 0, 0, 0, o, o, o, o, out.oooo));
+  QTRY(dev_extract_hp(n, Mh, 0, o, 0, 0, o, v, o, o, out.ovoo));
+  QTRY(dev_extract_hp(n, Mh, 0, o, 0, o, o, v, o, v, out.ovov));
+  QTRY(dev_extract_hp(n, Mh, 0, 0, o, o, o, o, v, v, out.oovv));
+  QTRY(dev_extract_hp(n, Mh, 0, o, o, 0, o, v, v, o, out.ovvo));
+  QTRY(dev_extract_hp(n, Mh, 0, o, o, o, o, v, v, v, out.ovvv));
   {  // (+/-) pair-packed ladder operands (6.4 GB instead of the 12.8 GB dense v^4 block at v = 200)
-    const int64_t np = (int64_t)v * (v + 1) / 2, nm = (int64_t)v * (v - 1) / 2;
-    out.ldp = np + (np & 1); out.ldm = nm + (nm & 1);
+    const int64_t npv = (int64_t)v * (v + 1) / 2, nm = (int64_t)v * (v - 1) / 2;
+    out.ldp = npv + (npv & 1); out.ldm = nm + (nm & 1);
     if (out.ldm == 0) out.ldm = 2;
-    QTRY(out.Vp.alloc(np * out.ldp));
+    QTRY(out.Vp.alloc(npv * out.ldp));
     QTRY(out.Vm.alloc(std::max<int64_t>(nm, 1) * out.ldm));
-    QTRY(dev_ladder_pack_vvvv(n, o, M, out.Vp, out.ldp, out.Vm, out.ldm));
+    QTRY(dev_ladder_pack_vvvv_hp(n, o, Mh, out.Vp, out.ldp, out.Vm, out.ldm));
   }
-  if (build_Vl) {  // Vl[a,b,c,d] = M[o+a, o+c, o+b, o+d]: loop over the source order (a,c,b,d)
-    QTRY(out.Vl.alloc((int64_t)v * v * v * v));
-    Copy4Desc c{};
-    const int64_t n1 = n, n2 = (int64_t)n * n, n3s = (int64_t)n * n * n;
-    c.dim[0] = v; c.dim[1] = v; c.dim[2] = v; c.dim[3] = v;
-    c.in = M + o * n3s + o * n2 + o * n1 + o;
-    c.si[0] = n3s; c.si[1] = n2; c.si[2] = n1; c.si[3] = 1;
-    c.out = out.Vl;
-    c.so[0] = (int64_t)v * v * v;  // a
-    c.so[1] = v;                   // c
-    c.so[2] = (int64_t)v * v;      // b
-    c.so[3] = 1;                   // d
-    c.alpha = 1.0; c.beta = 0.0;
-    QTRY(dev_copy4(c));
+  if (build_Vl) {  // Vl[a,b,c,d] = (ac|bd): gather [a][c][b][d] (X0 is free now), then swap the middle indices
+    const int64_t v4 = (int64_t)v * v * v * v;
+    QTRY(out.Vl.alloc(v4));
+    DBuf tmp;
+    double* g = X0;
+    if (v4 > mo_transform_work(n)) { QTRY(tmp.alloc(v4)); g = tmp; }
+    QTRY(dev_extract_hp(n, Mh, o, o, o, o, v, v, v, v, g));
+    QTRY(perm4(out.Vl, g, v, v, v, v, 0, 2, 1, 3));
   }
   QTRY(dev_timer_end(TIMER_AO2MO));
   return 0;

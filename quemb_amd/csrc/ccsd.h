@@ -27,9 +27,11 @@ struct MoIntegrals {
   DBuf A1, A2;      // A1[a,j,b,P] = (P a|j b), A2[i,j,b,P] = (P i|j b), P < nf in the EMBEDDING basis
 };
 
-// eri_s1: (n^4) embedding-basis ERIs [p,q,r,s] on the device -- OVERWRITTEN (used as ping-pong buffer);
-// work: second n^4 device buffer; C: n x n MO coefficients (columns) on the device.
-int mo_transform(int n, int o, int nf, double* eri_s1, double* work, const double* C, MoIntegrals& out, bool build_Vl = false);
+// eri_s4: (npair x npair) 4-fold packed embedding-basis ERIs on the device (read only); X0, X1: two device work
+// buffers of mo_transform_work(n) = n^2 * npair doubles each; C: n x n MO coefficients (columns) on the device.
+int64_t mo_transform_work(int n);
+int mo_transform(int n, int o, int nf, const double* eri_s4, double* X0, double* X1, const double* C, MoIntegrals& out,
+                 bool build_Vl = false);
 
 class CcsdSolver {
  public:

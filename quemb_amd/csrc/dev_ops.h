@@ -103,6 +103,19 @@ int dev_outer4(const Outer4Desc& c);
 int dev_div_denom(double* x, int64_t d0, int64_t d1, int64_t d2, int64_t d3,
                   const double* ea, const double* eb, const double* ec, const double* ed);
 
+// ---- pair-packed MO transformation helpers ---------------------------------------------------------------------------
+// out[P(x,y), c] = in[(x*n + y), c] for x >= y  (row gather of an (n*n) x ncols matrix; ncols-long rows)
+int dev_pack_pair_rows(int64_t n, int64_t ncols, const double* in, double* out);
+// Mh: [n][n][npair(n)] with the LAST pair packed ((pq|rs), r >= s).  out (contiguous s0 x s1 x s2 x s3) =
+// Mh[p0+p, q0+q, P(r0+r, s0+s)]
+int dev_extract_hp(int64_t n, const double* Mh, int64_t p0, int64_t q0, int64_t r0, int64_t s0, int64_t sp, int64_t sq,
+                   int64_t sr, int64_t ss, double* out);
+// T: [rows][npair(n)][ncols] -> out[rows][s_r][s_s][ncols] = T[row, P(r0+r, s0+s), :]   (the 3/4-transformed integrals)
+int dev_extract_mid_pair(int64_t rows, int64_t n, int64_t ncols, const double* T, int64_t r0, int64_t s0, int64_t sr,
+                         int64_t ss, int64_t c0, int64_t sc, double* out);
+// (+/-) ladder operands from the half-packed MO tensor (same outputs as dev_ladder_pack_vvvv)
+int dev_ladder_pack_vvvv_hp(int64_t n, int64_t o, const double* Mh, double* Vp, int64_t ldp, double* Vm, int64_t ldm);
+
 // ---- (+/-) packed pp-ladder: R_ijab = sum_cd (ac|bd) tau_ijcd through symmetric / antisymmetric pair combinations ------
 // pairs: P(x,y) = x(x+1)/2 + y for x >= y ("plus" blocks), Q(x,y) = x(x-1)/2 + y for x > y ("minus" blocks).
 // Vp[P(a,b), P(c,d)] = (ac|bd) + (ad|bc),  Vm[Q(a,b), Q(c,d)] = (ac|bd) - (ad|bc)   from the MO tensor M[p,q,r,s] (n^4),

@@ -413,13 +413,74 @@ int dev_mul_bcast_rows(int64_t rows, int64_t cols, double* x, const double* m) {
   return QEMB_OK;
 }
 
-// ---- (+/-) packed ladder ------------------------------------------------------------------------------------
+// ---- pair-packed MO transformation helpers --------------------------------------------------------------------------
+__device__ __forceinline__ long long pair_idx(long long i, long long j);
 __device__ __forceinline__ void unpair_ge(long long p, long long& x, long long& y) {   // p = x(x+1)/2 + y, x >= y
   x = (long long)((sqrt(8.0 * (double)p + 1.0) - 1.0) * 0.5);
   while (x * (x + 1) / 2 > p) --x;
   while ((x + 1) * (x + 2) / 2 <= p) ++x;
   y = p - x * (x + 1) / 2;
 }
+__global__ void __launch_bounds__(256) pack_pair_rows_kernel(long long n, long long ncols, const double* __restrict__ in, double* __restrict__ out) {
+  const long long np = n * (n + 1) / 2;
+  for (long long p = blockIdx.y; p < np; p += gridDim.y) {
+    long long x, y; unpair_ge(p, x, y);
+    const double* src = in + (x * n + y) * ncols;
+    double* dst = out + p * ncols;
+    for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < ncols; c += (long long)gridDim.x * blockDim.x) dst[c] = src[c];
+  }
+}
+int dev_pack_pair_rows(int64_t n, int64_t ncols, const double* in, double* out) {
+  REQUIRE_INIT();
+  const long long np = n * (n + 1) / 2;
+  if (np <= 0 || ncols <= 0) return QEMB_OK;
+  hipLaunchKernelGGL(pack_pair_rows_kernel, dim3((unsigned)std::min<long long>((ncols + 255) / 256, 256), (unsigned)std::min<long long>(np, 65535)), dim3(256), 0, g_stream,
+                     (long long)n, (long long)ncols, in, out);
+  HIP_TRY(hipGetLastError());
+  return QEMB_OK;
+}
+__global__ void __launch_bounds__(256) extract_hp_kernel(long long n, const double* __restrict__ Mh, long long p0, long long q0, long long r0, long long s0,
+                                                        long long sp, long long sq, long long sr, long long ss, double* __restrict__ out) {
+  const long long np = n * (n + 1) / 2, nrs = sr * ss;
+  for (long long pq = blockIdx.x; pq < sp * sq; pq += gridDim.x) {
+    const long long p = pq / sq, q = pq - p * sq;
+    const double* src = Mh + ((p0 + p) * n + (q0 + q)) * np;
+    double* dst = out + pq * nrs;
+    for (long long t = threadIdx.x; t < nrs; t += blockDim.x) {
+      const long long r = t / ss, s = t - r * ss;
+      dst[t] = src[pair_idx(r0 + r, s0 + s)];
+    }
+  }
+}
+int dev_extract_hp(int64_t n, const double* Mh, int64_t p0, int64_t q0, int64_t r0, int64_t s0, int64_t sp, int64_t sq, int64_t sr, int64_t ss, double* out) {
+  REQUIRE_INIT();
+  if (sp <= 0 || sq <= 0 || sr <= 0 || ss <= 0) return QEMB_OK;
+  hipLaunchKernelGGL(extract_hp_kernel, dim3((unsigned)std::min<int64_t>(sp * sq, 1 << 20)), dim3(256), 0, g_stream, (long long)n, Mh, (long long)p0, (long long)q0,
+                     (long long)r0, (long long)s0, (long long)sp, (long long)sq, (long long)sr, (long long)ss, out);
+  HIP_TRY(hipGetLastError());
+  return QEMB_OK;
+}
+__global__ void __launch_bounds__(256) extract_mid_pair_kernel(long long rows, long long n, long long ncols, const double* __restrict__ T, long long r0, long long s0,
+                                                              long long sr, long long ss, long long c0, long long sc, double* __restrict__ out) {
+  const long long np = n * (n + 1) / 2;
+  for (long long row = blockIdx.y; row < rows; row += gridDim.y)
+    for (long long rs = blockIdx.x; rs < sr * ss; rs += gridDim.x) {
+      const long long r = rs / ss, s = rs - r * ss;
+      const double* src = T + (row * np + pair_idx(r0 + r, s0 + s)) * ncols + c0;
+      double* dst = out + (row * sr * ss + rs) * sc;
+      for (long long c = threadIdx.x; c < sc; c += blockDim.x) dst[c] = src[c];
+    }
+}
+int dev_extract_mid_pair(int64_t rows, int64_t n, int64_t ncols, const double* T, int64_t r0, int64_t s0, int64_t sr, int64_t ss, int64_t c0, int64_t sc, double* out) {
+  REQUIRE_INIT();
+  if (rows <= 0 || sr <= 0 || ss <= 0 || sc <= 0) return QEMB_OK;
+  hipLaunchKernelGGL(extract_mid_pair_kernel, dim3((unsigned)std::min<int64_t>(sr * ss, 65535), (unsigned)std::min<int64_t>(rows, 65535)), dim3(64), 0, g_stream,
+                     (long long)rows, (long long)n, (long long)ncols, T, (long long)r0, (long long)s0, (long long)sr, (long long)ss, (long long)c0, (long long)sc, out);
+  HIP_TRY(hipGetLastError());
+  return QEMB_OK;
+}
+
+// ---- (+/-) packed ladder ------------------------------------------------------------------------------------
 // one block row per (a >= b); threads run over P(c,d).  Reads M[a,c,b,d] (d contiguous) and M[a,d,b,c].
 __global__ void __launch_bounds__(256) ladder_pack_vvvv_kernel(long long n, long long o, const double* __restrict__ M,
                                                               double* __restrict__ Vp, long long ldp, double* __restrict__ Vm, long long ldm) {
@@ -444,6 +505,33 @@ int dev_ladder_pack_vvvv(int64_t n, int64_t o, const double* M, double* Vp, int6
   const long long v = n - o, np = v * (v + 1) / 2;
   if (np <= 0) return QEMB_OK;
   hipLaunchKernelGGL(ladder_pack_vvvv_kernel, dim3((unsigned)std::min<long long>(np, 1 << 20)), dim3(256), 0, g_stream, (long long)n, (long long)o, M, Vp, (long long)ldp, Vm, (long long)ldm);
+  HIP_TRY(hipGetLastError());
+  return QEMB_OK;
+}
+// same outputs from the half-packed MO tensor Mh[p][q][P(r,s)]: (ac|bd) = Mh[o+a, o+c, P(o+b, o+d)]
+__global__ void __launch_bounds__(256) ladder_pack_vvvv_hp_kernel(long long n, long long o, const double* __restrict__ Mh,
+                                                                 double* __restrict__ Vp, long long ldp, double* __restrict__ Vm, long long ldm) {
+  const long long v = n - o, np = v * (v + 1) / 2, npn = n * (n + 1) / 2;
+  for (long long ab = blockIdx.x; ab < np; ab += gridDim.x) {
+    long long a, b; unpair_ge(ab, a, b);
+    double* vp = Vp + ab * ldp;
+    double* vm = (a > b) ? Vm + (a * (a - 1) / 2 + b) * ldm : nullptr;
+    for (long long cd = threadIdx.x; cd < ldp; cd += blockDim.x) {
+      if (cd >= np) { vp[cd] = 0.0; continue; }
+      long long c, d; unpair_ge(cd, c, d);
+      const double x = Mh[((o + a) * n + (o + c)) * npn + pair_idx(o + b, o + d)];
+      const double y = Mh[((o + a) * n + (o + d)) * npn + pair_idx(o + b, o + c)];
+      vp[cd] = x + y;
+      if (vm && c > d) vm[c * (c - 1) / 2 + d] = x - y;
+    }
+    if (vm) { const long long nm = v * (v - 1) / 2; for (long long q = nm + threadIdx.x; q < ldm; q += blockDim.x) vm[q] = 0.0; }
+  }
+}
+int dev_ladder_pack_vvvv_hp(int64_t n, int64_t o, const double* Mh, double* Vp, int64_t ldp, double* Vm, int64_t ldm) {
+  REQUIRE_INIT();
+  const long long v = n - o, np = v * (v + 1) / 2;
+  if (np <= 0) return QEMB_OK;
+  hipLaunchKernelGGL(ladder_pack_vvvv_hp_kernel, dim3((unsigned)std::min<long long>(np, 1 << 20)), dim3(256), 0, g_stream, (long long)n, (long long)o, Mh, Vp, (long long)ldp, Vm, (long long)ldm);
   HIP_TRY(hipGetLastError());
   return QEMB_OK;
 }
@@ -652,6 +740,46 @@ int dev_contract_mid(int64_t outer, int64_t mid, int64_t inner, const double* T,
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ long long pair_idx(long long i, long long j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
 
+// Tiled triangular unpack: one workgroup per packed row, 32 x 32 tiles of the lower triangle staged through LDS so that
+// both the [k][l] image and its mirror [l][k] are written in 256-byte runs and every packed element is read once.
+// dup != 0: the row index is itself a pair (p >= q) of an s4 block; the n x n image goes to rows (p,q) and (q,p).
+__global__ void __launch_bounds__(256) unpack_tril_tiled_kernel(long long rows, long long n, const double* __restrict__ packed,
+                                                               double* __restrict__ full, int dup) {
+  __shared__ double tile[32][33];
+  const long long np = n * (n + 1) / 2, n2 = n * n;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int nt = (int)((n + 31) / 32);
+  for (long long r = blockIdx.x; r < rows; r += gridDim.x) {
+    const double* src = packed + r * np;
+    double* dst0 = full + r * n2;
+    double* dst1 = nullptr;
+    if (dup) {
+      long long p, q; unpair_ge(r, p, q);
+      dst0 = full + (p * n + q) * n2;
+      if (p != q) dst1 = full + (q * n + p) * n2;
+    }
+    for (int tk = 0; tk < nt; ++tk)
+      for (int tl = 0; tl <= tk; ++tl) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int kk = ty + 8 * i;
+          const long long k = tk * 32 + kk, l = tl * 32 + tx;
+          tile[kk][tx] = (k < n && l <= k) ? src[k * (k + 1) / 2 + l] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int kk = ty + 8 * i;
+          const long long k = tk * 32 + kk, l = tl * 32 + tx;
+          if (k < n && l <= k) { const double x = tile[kk][tx]; dst0[k * n + l] = x; if (dst1) dst1[k * n + l] = x; }
+          const long long lr = tl * 32 + kk, kc = tk * 32 + tx;
+          if (kc < n && lr < kc) { const double y = tile[tx][kk]; dst0[lr * n + kc] = y; if (dst1) dst1[lr * n + kc] = y; }
+        }
+        __syncthreads();
+      }
+  }
+}
+
 // s1[i,j,k,l] = s4[pair(i,j), pair(k,l)];  one block row per (i,j), threads along (k,l)
 __global__ void __launch_bounds__(256) unpack_s4_kernel(long long n, const double* s4, double* s1) {
   const long long np = n * (n + 1) / 2, n2 = n * n;
@@ -667,7 +795,12 @@ __global__ void __launch_bounds__(256) unpack_s4_kernel(long long n, const doubl
 }
 int dev_unpack_s4(int64_t n, const double* s4, double* s1) {
   REQUIRE_INIT();
-  hipLaunchKernelGGL(unpack_s4_kernel, dim3((unsigned)std::min<int64_t>(n * n, 1 << 20)), dim3(256), 0, g_stream, (long long)n, s4, s1);
+  if (n >= 32) {
+    const int64_t np = n * (n + 1) / 2;
+    hipLaunchKernelGGL(unpack_tril_tiled_kernel, dim3((unsigned)std::min<int64_t>(np, 1 << 20)), dim3(256), 0, g_stream, (long long)np, (long long)n, s4, s1, 1);
+  } else {
+    hipLaunchKernelGGL(unpack_s4_kernel, dim3((unsigned)std::min<int64_t>(n * n, 1 << 20)), dim3(256), 0, g_stream, (long long)n, s4, s1);
+  }
   HIP_TRY(hipGetLastError());
   return QEMB_OK;
 }
@@ -719,7 +852,10 @@ __global__ void __launch_bounds__(256) unpack_tril_rows_kernel(long long rows, l
 int dev_unpack_tril_rows(int64_t rows, int64_t n, const double* packed, double* full) {
   REQUIRE_INIT();
   if (rows <= 0) return QEMB_OK;
-  hipLaunchKernelGGL(unpack_tril_rows_kernel, dim3((unsigned)std::min<int64_t>(rows, 1 << 20)), dim3(256), 0, g_stream, (long long)rows, (long long)n, packed, full);
+  if (n >= 32)
+    hipLaunchKernelGGL(unpack_tril_tiled_kernel, dim3((unsigned)std::min<int64_t>(rows, 1 << 20)), dim3(256), 0, g_stream, (long long)rows, (long long)n, packed, full, 0);
+  else
+    hipLaunchKernelGGL(unpack_tril_rows_kernel, dim3((unsigned)std::min<int64_t>(rows, 1 << 20)), dim3(256), 0, g_stream, (long long)rows, (long long)n, packed, full);
   HIP_TRY(hipGetLastError());
   return QEMB_OK;
 }

@@ -44,7 +44,7 @@ int Fragment::run_scf(int o, const double* h, const double* dm0, const ScfOption
     QTRY(dev_jacobi_eigh(n_, tmp, eps_, C_, nullptr));
     QTRY(gemm(n_, n_, o, 2.0, C_, n_, true, C_, n_, true, 0.0, dm_, n_));
   }
-  return rhf_device(n_, o, hd, X0, dm_, opt, C_, eps_, J_, K_, sres);
+  return rhf_device(n_, o, hd, X0, dm_, opt, C_, eps_, J_, K_, sres, eri_s4_);
 }
 
 int Fragment::hf_veff_from_dm(const double* P_host, double* J_host, double* K_host) {
@@ -54,7 +54,7 @@ int Fragment::hf_veff_from_dm(const double* P_host, double* J_host, double* K_ho
   QTRY(X0.alloc(n2 * n2)); QTRY(P.alloc(n2)); QTRY(J.alloc(n2)); QTRY(K.alloc(n2));
   QTRY(dev_unpack_s4(n_, eri_s4_, X0));
   QTRY(dev_h2d(P, P_host, sizeof(double) * n2));
-  QTRY(build_jk(n_, X0, P, J, K));
+  QTRY(build_jk(n_, X0, P, J, K, eri_s4_));
   QTRY(dev_d2h(J_host, J, sizeof(double) * n2));
   QTRY(dev_d2h(K_host, K, sizeof(double) * n2));
   return 0;
@@ -95,9 +95,9 @@ int Fragment::cphf_response(int o, const double* h, const double* dm0, const Scf
   std::vector<double> C((size_t)n2), eps((size_t)n);
   QTRY(dev_d2h(C.data(), C_, sizeof(double) * n2));
   QTRY(dev_d2h(eps.data(), eps_, sizeof(double) * n));
-  QTRY(X1.alloc(n2 * n2));
+  QTRY(X1.alloc(mo_transform_work(n)));
   MoIntegrals ints;
-  QTRY(mo_transform(n, o, 0, X0, X1, C_, ints));
+  QTRY(mo_transform(n, o, 0, eri_s4_, X0, X1, C_, ints));
   X0.release(); X1.release();
   DBuf A, L, Linv, d;
   QTRY(A.alloc(nov * nov)); QTRY(d.alloc(nov));
@@ -155,9 +155,9 @@ int Fragment::prepare_ccsd(int o, const double* h, const double* dm0, const Frag
   ScfResult sres;
   QTRY(run_scf(o, h, dm0, opt.scf, X0, &sres));
   if (!sres.converged) { set_error("fragment SCF did not converge (also not with level shift 0.2)"); return QEMB_ERR_NOCONV; }
-  QTRY(X1.alloc(n2 * n2));
+  QTRY(X1.alloc(mo_transform_work(n_)));
   MoIntegrals ints;
-  QTRY(mo_transform(n_, o, nf_, X0, X1, C_, ints, /*build_Vl=*/true));   // measurement hook: dense block available for export
+  QTRY(mo_transform(n_, o, nf_, eri_s4_, X0, X1, C_, ints, /*build_Vl=*/true));   // measurement hook: dense block available for export
   X0.release(); X1.release();
   cc_.reset(new CcsdSolver());
   QTRY(cc_->setup(std::move(ints), eps_));
@@ -189,9 +189,9 @@ int Fragment::solve(int o, const double* h, const double* dm0, const FragmentOpt
   QTRY(dev_d2h(C.data(), C_, sizeof(double) * n2));
   QTRY(dev_d2h(eps.data(), eps_, sizeof(double) * n));
   // ---- integrals + CCSD
-  QTRY(X1.alloc(n2 * n2));
+  QTRY(X1.alloc(mo_transform_work(n)));
   MoIntegrals ints;
-  QTRY(mo_transform(n, o, eeval ? nf_ : 0, X0, X1, C_, ints));
+  QTRY(mo_transform(n, o, eeval ? nf_ : 0, eri_s4_, X0, X1, C_, ints));
   X0.release(); X1.release();
   cc_.reset(new CcsdSolver());
   QTRY(cc_->setup(std::move(ints), eps_));

@@ -11,9 +11,25 @@
 
 namespace qemb {
 
-int build_jk(int n, const double* eri, const double* dm, double* J, double* K) {
+int build_jk(int n, const double* eri, const double* dm, double* J, double* K, const double* eri_s4) {
   const int64_t n2 = (int64_t)n * n;
-  if (J) QTRY(dev_gemv_rows(n2, n2, eri, n2, dm, J, 1.0, 0.0));
+  if (J && eri_s4) {
+    // J from the 4-fold packed block (a quarter of the bytes): Jp = eri_s4 . Dp, Dp[rs] = D[r,s] + D[s,r] (r > s), D[r,r]
+    const int64_t np = (int64_t)n * (n + 1) / 2;
+    DBuf D2, Dp, Jp;
+    QTRY(D2.alloc(n2)); QTRY(Dp.alloc(np)); QTRY(Jp.alloc(np));
+    QTRY(perm4(D2, dm, 1, 1, n, n, 0, 1, 3, 2));            // D^T
+    QTRY(axpby(n2, 1.0, dm, 1.0, D2));                      // D + D^T
+    Copy4Desc c{};
+    c.dim[0] = 1; c.dim[1] = 1; c.dim[2] = 1; c.dim[3] = n;
+    c.in = dm; c.si[3] = n + 1; c.out = D2; c.so[3] = n + 1; c.alpha = 1.0; c.beta = 0.0;
+    QTRY(dev_copy4(c));                                     // diagonal back to D[r,r]
+    QTRY(dev_pack_tril_rows(1, n, D2, Dp));
+    QTRY(dev_gemv_rows(np, np, eri_s4, np, Dp, Jp, 1.0, 0.0));
+    QTRY(dev_unpack_tril_rows(1, n, Jp, J));
+  } else if (J) {
+    QTRY(dev_gemv_rows(n2, n2, eri, n2, dm, J, 1.0, 0.0));
+  }
   // K[p,r] = sum_{q,s} D[q,s] (pq|sr): treat eri as [p][(q,s)][r]
   if (K) QTRY(dev_contract_mid(n, n2, n, eri, dm, K, n, 1.0, 0.0));
   return 0;
@@ -24,18 +40,20 @@ static int density_from_mos(int n, int o, const double* C, double* dm) {
   return gemm(n, n, o, 2.0, C, n, true, C, n, true, 0.0, dm, n);
 }
 
-static int rhf_loop(int n, int o, const double* h, const double* eri, double* dm, const ScfOptions& opt, double* C,
-                    double* eps, double* J, double* K, ScfResult* res) {
+static int rhf_loop(int n, int o, const double* h, const double* eri, const double* eri_s4, double* dm, const ScfOptions& opt,
+                    double* C, double* eps, double* J, double* K, ScfResult* res) {
   const int64_t n2 = (int64_t)n * n;
-  DBuf F, Fd, err, tmp, scal, hpf;
+  DBuf F, Fd, err, tmp, scal, hpf, Cprev, V;
   QTRY(F.alloc(n2)); QTRY(Fd.alloc(n2)); QTRY(err.alloc(n2)); QTRY(tmp.alloc(n2)); QTRY(scal.alloc(4)); QTRY(hpf.alloc(n2));
+  QTRY(Cprev.alloc(n2)); QTRY(V.alloc(n2));
+  bool have_prev = false;
   DeviceDIIS diis(opt.diis_space, n2);
   QTRY(diis.init());
   double e_old = 0.0;
   res->converged = false;
   int cyc = 0;
   for (cyc = 0; cyc < opt.max_cycle; ++cyc) {
-    QTRY(build_jk(n, eri, dm, J, K));
+    QTRY(build_jk(n, eri, dm, J, K, eri_s4));
     QTRY(dcopy(n2, h, F)); QTRY(axpby(n2, 1.0, J, 1.0, F)); QTRY(axpby(n2, -0.5, K, 1.0, F));
     QTRY(dcopy(n2, h, hpf)); QTRY(axpby(n2, 1.0, F, 1.0, hpf));
     QTRY(dev_dot(n2, hpf, dm, scal));                                   // 2 E = <h + F, D>
@@ -59,12 +77,22 @@ static int rhf_loop(int n, int o, const double* h, const double* eri, double* dm
       QTRY(dev_h2d(tmp, ident.data(), sizeof(double) * n2));
       QTRY(axpby(n2, 1.0, tmp, 1.0, Fd));
     }
-    QTRY(dev_jacobi_eigh(n, Fd, eps, C, nullptr));
+    if (have_prev) {
+      // rotate into the previous cycle's orbitals first: the Jacobi sweeps start from a nearly diagonal matrix
+      QTRY(gemm_nn(n, n, n, 1.0, Fd, Cprev, 0.0, tmp));
+      QTRY(gemm_tn(n, n, n, 1.0, Cprev, tmp, 0.0, Fd));
+      QTRY(dev_jacobi_eigh(n, Fd, eps, V, nullptr));
+      QTRY(gemm_nn(n, n, n, 1.0, Cprev, V, 0.0, C));
+    } else {
+      QTRY(dev_jacobi_eigh(n, Fd, eps, C, nullptr));
+    }
+    QTRY(dcopy(n2, C, Cprev));
+    have_prev = true;
     QTRY(density_from_mos(n, o, C, dm));
   }
   res->cycles = cyc + (res->converged ? 1 : 0);
   // canonical orbitals of the Fock matrix of the final density (PySCF does the same extra diagonalisation)
-  QTRY(build_jk(n, eri, dm, J, K));
+  QTRY(build_jk(n, eri, dm, J, K, eri_s4));
   QTRY(dcopy(n2, h, F)); QTRY(axpby(n2, 1.0, J, 1.0, F)); QTRY(axpby(n2, -0.5, K, 1.0, F));
   QTRY(dcopy(n2, F, Fd));
   QTRY(dev_jacobi_eigh(n, Fd, eps, C, nullptr));
@@ -73,7 +101,7 @@ static int rhf_loop(int n, int o, const double* h, const double* eri, double* dm
 }
 
 int rhf_device(int n, int o, const double* h, const double* eri, double* dm, const ScfOptions& opt, double* C, double* eps,
-               double* J_out, double* K_out, ScfResult* res) {
+               double* J_out, double* K_out, ScfResult* res, const double* eri_s4) {
   if (n <= 0 || o <= 0 || o > n) { set_error("rhf_device: bad dimensions"); return QEMB_ERR_ARG; }
   const int64_t n2 = (int64_t)n * n;
   DBuf Jb, Kb;
@@ -83,13 +111,13 @@ int rhf_device(int n, int o, const double* h, const double* eri, double* dm, con
   QTRY(dev_timer_begin(TIMER_SCF));
   DBuf dm_start;
   QTRY(dm_start.alloc(n2)); QTRY(dcopy(n2, dm, dm_start));
-  QTRY(rhf_loop(n, o, h, eri, dm, opt, C, eps, J, K, res));
+  QTRY(rhf_loop(n, o, h, eri, eri_s4, dm, opt, C, eps, J, K, res));
   if (!res->converged) {
     // molbe/helper.py:128-149: retry with level_shift = 0.2 and a 25-vector DIIS space
     ScfOptions o2 = opt;
     o2.level_shift = 0.2; o2.diis_space = 25;
     QTRY(dcopy(n2, dm_start, dm));
-    QTRY(rhf_loop(n, o, h, eri, dm, o2, C, eps, J, K, res));
+    QTRY(rhf_loop(n, o, h, eri, eri_s4, dm, o2, C, eps, J, K, res));
   }
   QTRY(dev_timer_end(TIMER_SCF));
   return 0;

@@ -21,12 +21,13 @@ struct ScfResult {
   int cycles = 0;
 };
 
-// J[p,q] = (pq|rs) D[r,s],  K[p,r] = (pq|rs) D[q,s]   from the full n^4 tensor (HBM bound)
-int build_jk(int n, const double* eri_s1, const double* dm, double* J, double* K);
+// J[p,q] = (pq|rs) D[r,s],  K[p,r] = (pq|rs) D[q,s]   from the full n^4 tensor (HBM bound).  With eri_s4 (the resident
+// npair x npair block) J is contracted from the packed form instead: a quarter of the bytes.
+int build_jk(int n, const double* eri_s1, const double* dm, double* J, double* K, const double* eri_s4 = nullptr);
 
 // h, dm (in: guess, out: converged density), C, eps: device buffers (n*n, n*n, n*n, n).
 // J_out/K_out (nullable): J and K of the converged density (n*n each).
 int rhf_device(int n, int o, const double* h, const double* eri_s1, double* dm, const ScfOptions& opt, double* C,
-               double* eps, double* J_out, double* K_out, ScfResult* res);
+               double* eps, double* J_out, double* K_out, ScfResult* res, const double* eri_s4 = nullptr);
 
 }  // namespace qemb

@@ -99,6 +99,36 @@ int dev_ladder_pack_vvvv(int64_t n, int64_t o, const double* M, double* Vp, int6
   }
   return 0;
 }
+static inline int64_t pidx(int64_t i, int64_t j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
+int dev_pack_pair_rows(int64_t n, int64_t ncols, const double* in, double* out) {
+  for (int64_t x = 0; x < n; ++x) for (int64_t y = 0; y <= x; ++y) std::copy(in + (x * n + y) * ncols, in + (x * n + y + 1) * ncols, out + pidx(x, y) * ncols);
+  return 0;
+}
+int dev_extract_hp(int64_t n, const double* Mh, int64_t p0, int64_t q0, int64_t r0, int64_t s0, int64_t sp, int64_t sq, int64_t sr, int64_t ss, double* out) {
+  const int64_t np = n * (n + 1) / 2;
+  for (int64_t p = 0; p < sp; ++p) for (int64_t q = 0; q < sq; ++q) for (int64_t r = 0; r < sr; ++r) for (int64_t s = 0; s < ss; ++s)
+    out[((p * sq + q) * sr + r) * ss + s] = Mh[((p0 + p) * n + (q0 + q)) * np + pidx(r0 + r, s0 + s)];
+  return 0;
+}
+int dev_extract_mid_pair(int64_t rows, int64_t n, int64_t ncols, const double* T, int64_t r0, int64_t s0, int64_t sr, int64_t ss, int64_t c0, int64_t sc, double* out) {
+  const int64_t np = n * (n + 1) / 2;
+  for (int64_t row = 0; row < rows; ++row) for (int64_t r = 0; r < sr; ++r) for (int64_t s = 0; s < ss; ++s) for (int64_t c = 0; c < sc; ++c)
+    out[((row * sr + r) * ss + s) * sc + c] = T[(row * np + pidx(r0 + r, s0 + s)) * ncols + c0 + c];
+  return 0;
+}
+int dev_ladder_pack_vvvv_hp(int64_t n, int64_t o, const double* Mh, double* Vp, int64_t ldp, double* Vm, int64_t ldm) {
+  const int64_t v = n - o, npn = n * (n + 1) / 2;
+  for (int64_t a = 0; a < v; ++a) for (int64_t b = 0; b <= a; ++b) {
+    double* vp = Vp + (a * (a + 1) / 2 + b) * ldp; std::fill(vp, vp + ldp, 0.0);
+    double* vm = a > b ? Vm + (a * (a - 1) / 2 + b) * ldm : nullptr; if (vm) std::fill(vm, vm + ldm, 0.0);
+    for (int64_t c = 0; c < v; ++c) for (int64_t d = 0; d <= c; ++d) {
+      const double x = Mh[((o + a) * n + (o + c)) * npn + pidx(o + b, o + d)], y = Mh[((o + a) * n + (o + d)) * npn + pidx(o + b, o + c)];
+      vp[c * (c + 1) / 2 + d] = x + y;
+      if (vm && c > d) vm[c * (c - 1) / 2 + d] = x - y;
+    }
+  }
+  return 0;
+}
 int dev_ladder_pack_tau(int64_t o, int64_t v, const double* tau, double* Tp, int64_t ldp, double* Tm, int64_t ldm) {
   for (int64_t i = 0; i < o; ++i) for (int64_t j = 0; j <= i; ++j) {
     const double* t = tau + (i * o + j) * v * v;
@@ -148,7 +178,6 @@ int dev_contract_mid(int64_t outer, int64_t mid, int64_t inner, const double* T,
   }
   return 0;
 }
-static inline int64_t pidx(int64_t i, int64_t j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
 int dev_unpack_s4(int64_t n, const double* s4, double* s1) {
   const int64_t np = n * (n + 1) / 2;
   for (int64_t i = 0; i < n; ++i) for (int64_t j = 0; j < n; ++j) for (int64_t k = 0; k < n; ++k) for (int64_t l = 0; l < n; ++l)
