@@ -97,6 +97,7 @@ int qemb_op_unpack_s8_to_s4(int64_t n, const double* s8, double* s4);
 /* pair-packed MO transformation helpers (half the flops of the four-index ao2mo.kernel call of PySCF's cc.ao2mo(),
  * which solve_ccsd reaches at molbe/solver.py:900): row gather r >= s; block gather from the half-packed tensor
  * Mh[p][q][P(r,s)]; block gather from the 3/4-transformed tensor T[q'][P(r',s')][p]; (+/-) ladder operands from Mh. */
+int qemb_op_mirror_lower(int64_t n, double* A, int64_t lda);   /* A[r][c] = A[c][r], r < c (completes a SYRK-style result) */
 int qemb_op_pack_pair_rows(int64_t n, int64_t ncols, const double* in, double* out);
 int qemb_op_extract_hp(int64_t n, const double* Mh, int64_t p0, int64_t q0, int64_t r0, int64_t s0, int64_t sp, int64_t sq,
                        int64_t sr, int64_t ss, double* out);

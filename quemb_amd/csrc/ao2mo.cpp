@@ -11,6 +11,7 @@
 //   packed result -- no n^2 x n^2 intermediate and no restore step.  288 GB of HBM hold the whole (P|mu nu)
 //   tensor, so the reference's memory-driven aux blocking (eri_onthefly.py:18-42) is not needed.
 #include "ao2mo.h"
+#include <algorithm>
 
 namespace qemb {
 
@@ -19,35 +20,47 @@ static inline int64_t npair(int64_t n) { return n * (n + 1) / 2; }
 int AoEri::upload(int N_, const double* host, int sym) {
   N = N_;
   const int64_t np = npair(N), n2 = (int64_t)N * N;
-  QTRY(s1.alloc(n2 * n2));
-  if (sym == 1) return dev_h2d(s1, host, sizeof(double) * n2 * n2);
-  DBuf s4;
   QTRY(s4.alloc(np * np));
-  if (sym == 4) {
-    QTRY(dev_h2d(s4, host, sizeof(double) * np * np));
-  } else if (sym == 8) {
+  if (sym == 4) return dev_h2d(s4, host, sizeof(double) * np * np);
+  if (sym == 8) {
     DBuf s8;
     const int64_t n8 = np * (np + 1) / 2;
     QTRY(s8.alloc(n8));
     QTRY(dev_h2d(s8, host, sizeof(double) * n8));
-    QTRY(dev_unpack_s8_to_s4(N, s8, s4));
-  } else { set_error("AoEri::upload: sym must be 1, 4 or 8"); return QEMB_ERR_ARG; }
-  return dev_unpack_s4(N, s4, s1);
+    return dev_unpack_s8_to_s4(N, s8, s4);
+  }
+  if (sym == 1) {
+    DBuf s1;
+    QTRY(s1.alloc(n2 * n2));
+    QTRY(dev_h2d(s1, host, sizeof(double) * n2 * n2));
+    return dev_pack_s4(N, s1, s4);
+  }
+  set_error("AoEri::upload: sym must be 1, 4 or 8");
+  return QEMB_ERR_ARG;
 }
 
+// Both pair symmetries are kept through the four quarter transforms (each the TN GEMM
+// Out[x',(rest)] = sum_x TA[x,x'] In[(rest),x]):
+//   [mn][k][l] (unpack kl of the resident s4 rows) -> GEMM l -> [l'][mn][k] -> GEMM k -> [k'][l'][mn]
+//   -> keep k' >= l' rows -> [(kl)][mn] -> unpack mn -> [(kl)][m][n] -> GEMM n -> [j'][(kl)][m] -> GEMM m -> [i'][j'][(kl)]
+//   -> keep i' >= j' rows = the 4-fold packed (npair(n) x npair(n)) result of dataset f{I}.
+// 2 N^2 n (npair(N) + npair(n)) + 2 N n^2 (npair(N) + npair(n)) flop: half of the four full quarter transforms.
 int ao2mo_dense(const AoEri& ao, const double* TA, int n, double* out_s4) {
   const int64_t N = ao.N;
   if (N <= 0 || n <= 0 || n > N) { set_error("ao2mo_dense: need 0 < n <= N"); return QEMB_ERR_ARG; }
+  const int64_t npN = npair(N), npn = npair(n);
   DBuf W1, W2;
-  QTRY(W1.alloc((int64_t)n * N * N * N));
-  QTRY(W2.alloc((int64_t)n * n * N * N));
+  QTRY(W1.alloc(std::max<int64_t>(npN * N * N, (int64_t)n * n * npN)));
+  QTRY(W2.alloc(std::max<int64_t>((int64_t)n * npN * N, npn * N * N)));
   QTRY(dev_timer_begin(TIMER_AO2MO));
-  // each step: Out[s', rest] = sum_s TA[s,s'] In[rest, s]     (A = TA stored K x M, B = In stored N x K)
-  QTRY(gemm(n, N * N * N, N, 1.0, TA, n, false, ao.s1, N, true, 0.0, W1, N * N * N));        // [s', p, q, r]
-  QTRY(gemm(n, (int64_t)n * N * N, N, 1.0, TA, n, false, W1, N, true, 0.0, W2, (int64_t)n * N * N));   // [r', s', p, q]
-  QTRY(gemm(n, (int64_t)n * n * N, N, 1.0, TA, n, false, W2, N, true, 0.0, W1, (int64_t)n * n * N));   // [q', r', s', p]
-  QTRY(gemm(n, (int64_t)n * n * n, N, 1.0, TA, n, false, W1, N, true, 0.0, W2, (int64_t)n * n * n));   // [p', q', r', s']
-  QTRY(dev_pack_s4(n, W2, out_s4));
+  QTRY(dev_unpack_tril_rows(npN, N, ao.s4, W1));                                                   // [mn][k][l]
+  QTRY(gemm(n, npN * N, N, 1.0, TA, n, false, W1, N, true, 0.0, W2, npN * N));                     // [l'][mn][k]
+  QTRY(gemm(n, (int64_t)n * npN, N, 1.0, TA, n, false, W2, N, true, 0.0, W1, (int64_t)n * npN));   // [k'][l'][mn]
+  QTRY(dev_pack_pair_rows(n, npN, W1, W2));                                                        // [(kl)][mn]
+  QTRY(dev_unpack_tril_rows(npn, N, W2, W1));                                                      // [(kl)][m][n]
+  QTRY(gemm(n, npn * N, N, 1.0, TA, n, false, W1, N, true, 0.0, W2, npn * N));                     // [j'][(kl)][m]
+  QTRY(gemm(n, (int64_t)n * npn, N, 1.0, TA, n, false, W2, N, true, 0.0, W1, (int64_t)n * npn));   // [i'][j'][(kl)]
+  QTRY(dev_pack_pair_rows(n, npn, W1, out_s4));
   QTRY(dev_timer_end(TIMER_AO2MO));
   return 0;
 }
@@ -124,7 +137,17 @@ int DfContext::transform(const double* TA, int n, double* out_s4, const double* 
   // bb = L^-1 bp                                          (eri_onthefly.py:141 / cublasDtrsm :667)
   QTRY(gemm(naux, np, naux, 1.0, Linv, naux, true, bp, np, false, 0.0, bb, np));
   // (ij|kl) = sum_L bb[L,ij] bb[L,kl] over packed pairs   (eri_onthefly.py:143 / cublasDsyrk :684, beta = 0)
-  QTRY(gemm(np, np, naux, 1.0, bb, np, false, bb, np, false, 0.0, out_s4, np));
+  // The result is symmetric: only block columns at and below the diagonal are computed (9/16 of the flops with 8
+  // blocks), then mirrored.
+  {
+    const int64_t nblk = np >= 2048 ? 8 : 1;
+    const int64_t w = ((np + nblk - 1) / nblk + 127) / 128 * 128;
+    for (int64_t c0 = 0; c0 < np; c0 += w) {
+      const int64_t cw = std::min(w, np - c0);
+      QTRY(gemm(np - c0, cw, naux, 1.0, bb.p + c0, np, false, bb.p + c0, np, false, 0.0, out_s4 + c0 * np + c0, np));
+    }
+    if (nblk > 1) QTRY(dev_mirror_lower(np, out_s4, np));
+  }
   QTRY(dev_timer_end(TIMER_DF));
   return 0;
 }

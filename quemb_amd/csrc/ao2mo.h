@@ -6,11 +6,12 @@
 
 namespace qemb {
 
-// AO ERIs resident on the device as the full N^4 tensor (built once from s8 / s4 / s1 host input).
+// AO ERIs resident on the device in the 4-fold packed (npair(N) x npair(N)) form (built once from s8 / s4 / s1 host
+// input): a quarter of the N^4 tensor, and exactly the operand the pair-packed transform starts from.
 class AoEri {
  public:
   int N = 0;
-  DBuf s1;
+  DBuf s4;
   int upload(int N_, const double* eri_host, int sym);   // sym = 8, 4 or 1
 };
 

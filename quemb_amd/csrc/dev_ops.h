@@ -103,6 +103,9 @@ int dev_outer4(const Outer4Desc& c);
 int dev_div_denom(double* x, int64_t d0, int64_t d1, int64_t d2, int64_t d3,
                   const double* ea, const double* eb, const double* ec, const double* ed);
 
+// A[r][c] = A[c][r] for r < c  (n x n, leading dimension lda): completes a matrix whose lower triangle was computed
+int dev_mirror_lower(int64_t n, double* A, int64_t lda);
+
 // ---- pair-packed MO transformation helpers ---------------------------------------------------------------------------
 // out[P(x,y), c] = in[(x*n + y), c] for x >= y  (row gather of an (n*n) x ncols matrix; ncols-long rows)
 int dev_pack_pair_rows(int64_t n, int64_t ncols, const double* in, double* out);

@@ -413,6 +413,36 @@ int dev_mul_bcast_rows(int64_t rows, int64_t cols, double* x, const double* m) {
   return QEMB_OK;
 }
 
+__global__ void __launch_bounds__(256) mirror_lower_kernel(long long n, double* __restrict__ A, long long lda) {
+  __shared__ double tile[32][33];
+  // blockIdx.x enumerates lower-triangle 32 x 32 tiles (tr >= tc)
+  long long t = blockIdx.x;
+  long long tr = (long long)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+  while (tr * (tr + 1) / 2 > t) --tr;
+  while ((tr + 1) * (tr + 2) / 2 <= t) ++tr;
+  const long long tc = t - tr * (tr + 1) / 2;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const long long r = tr * 32 + ty + 8 * i, c = tc * 32 + tx;
+    tile[ty + 8 * i][tx] = (r < n && c < n) ? A[r * lda + c] : 0.0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const long long r = tc * 32 + ty + 8 * i, c = tr * 32 + tx;   // destination (upper) element (r, c) = source (c, r)
+    if (r < n && c < n && r < c) A[r * lda + c] = tile[tx][ty + 8 * i];
+  }
+}
+int dev_mirror_lower(int64_t n, double* A, int64_t lda) {
+  REQUIRE_INIT();
+  if (n <= 1) return QEMB_OK;
+  const long long nt = (n + 31) / 32;
+  hipLaunchKernelGGL(mirror_lower_kernel, dim3((unsigned)(nt * (nt + 1) / 2)), dim3(256), 0, g_stream, (long long)n, A, (long long)lda);
+  HIP_TRY(hipGetLastError());
+  return QEMB_OK;
+}
+
 // ---- pair-packed MO transformation helpers --------------------------------------------------------------------------
 __device__ __forceinline__ long long pair_idx(long long i, long long j);
 __device__ __forceinline__ void unpair_ge(long long p, long long& x, long long& y) {   // p = x(x+1)/2 + y, x >= y

@@ -100,6 +100,10 @@ int dev_ladder_pack_vvvv(int64_t n, int64_t o, const double* M, double* Vp, int6
   return 0;
 }
 static inline int64_t pidx(int64_t i, int64_t j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
+int dev_mirror_lower(int64_t n, double* A, int64_t lda) {
+  for (int64_t r = 0; r < n; ++r) for (int64_t c = r + 1; c < n; ++c) A[r * lda + c] = A[c * lda + r];
+  return 0;
+}
 int dev_pack_pair_rows(int64_t n, int64_t ncols, const double* in, double* out) {
   for (int64_t x = 0; x < n; ++x) for (int64_t y = 0; y <= x; ++y) std::copy(in + (x * n + y) * ncols, in + (x * n + y + 1) * ncols, out + pidx(x, y) * ncols);
   return 0;

@@ -181,6 +181,17 @@ def test_pack_unpack(qlib, n):
     assert np.array_equal(dP2.numpy((rows, npair)), P)
 
 
+@pytest.mark.parametrize("n", [1, 31, 100])
+def test_mirror_lower(qlib, n):
+    rng = np.random.default_rng(5 + n)
+    A = rng.standard_normal((n, n + 3))
+    dA = DeviceBuffer.from_numpy(A)
+    check(qlib.qemb_op_mirror_lower(n, dA.ptr, n + 3))
+    B = dA.numpy((n, n + 3))
+    ref = A.copy(); sq = np.tril(A[:, :n]); ref[:, :n] = sq + np.tril(sq, -1).T
+    assert np.array_equal(B, ref)
+
+
 def test_pair_packed_transform_helpers(qlib):
     """dev_pack_pair_rows / dev_extract_hp / dev_extract_mid_pair / dev_ladder_pack_vvvv_hp against numpy indexing."""
     rng = np.random.default_rng(77)
