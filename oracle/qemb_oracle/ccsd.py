@@ -31,9 +31,12 @@ class Eris:
         self.fock = np.diag(self.mo_energy) if fock is None else fock
 
 
-def energy(t1, t2, eris):
+def energy(t1, t2, eris, es=None):
     nocc = eris.nocc
     fov = eris.fock[:nocc, nocc:]
+    if es is not None:      # recording path (ccsd_lambda.py): same expression, differentiable
+        tau = es("ia,jb->ijab", t1, t1) + t2
+        return 2 * es("ia,ia->", fov, t1) + 2 * es("ijab,iajb->", tau, eris.ovov) - es("ijab,ibja->", tau, eris.ovov)
     e = 2 * np.einsum("ia,ia", fov, t1)
     tau = np.einsum("ia,jb->ijab", t1, t1) + t2
     e += 2 * np.einsum("ijab,iajb", tau, eris.ovov)
@@ -51,14 +54,18 @@ def init_amps(eris):
     return t1, t2
 
 
-def update_amps(t1, t2, eris):
-    """SURVEY.md Appendix A, line by line (== pyscf cc/rccsd.py update_amps + rintermediates)."""
+def _einsum(*a):
+    return np.einsum(*a, optimize=True)
+
+
+def amplitude_numerators(t1, t2, eris, es=_einsum):
+    """SURVEY.md Appendix A, line by line (== pyscf cc/rccsd.py update_amps + rintermediates) up to the division by
+    the orbital-energy denominators.  `es` is the contraction routine (ccsd_lambda.py passes a recording one)."""
     nocc, nvir = t1.shape
     fock = eris.fock
     eo, ev = eris.mo_energy[:nocc], eris.mo_energy[nocc:]
     fov = fock[:nocc, nocc:]; foo = fock[:nocc, :nocc]; fvv = fock[nocc:, nocc:]
     ovov, ovoo, ovvv, oovv, ovvo, oooo, vvvv = eris.ovov, eris.ovoo, eris.ovvv, eris.oovv, eris.ovvo, eris.oooo, eris.vvvv
-    es = lambda *a: np.einsum(*a, optimize=True)
 
     Foo = 2 * es("kcld,ilcd->ki", ovov, t2) - es("kdlc,ilcd->ki", ovov, t2) \
         + 2 * es("kcld,ic,ld->ki", ovov, t1, t1) - es("kdlc,ic,ld->ki", ovov, t1, t1) + foo
@@ -103,7 +110,13 @@ def update_amps(t1, t2, eris):
     t2new += tmp + tmp.transpose(1, 0, 3, 2)
     tmp = es("akic,kjbc->ijab", Wvoov, t2); t2new -= tmp + tmp.transpose(1, 0, 3, 2)
     tmp = es("bkci,kjac->ijab", Wvovo, t2); t2new -= tmp + tmp.transpose(1, 0, 3, 2)
+    return t1new, t2new
 
+
+def update_amps(t1, t2, eris):
+    nocc = t1.shape[0]
+    eo, ev = eris.mo_energy[:nocc], eris.mo_energy[nocc:]
+    t1new, t2new = amplitude_numerators(t1, t2, eris)
     eia = eo[:, None] - ev[None, :]
     eijab = eia[:, None, :, None] + eia[None, :, None, :]
     return t1new / eia, t2new / eijab
