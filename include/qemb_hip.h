@@ -129,6 +129,10 @@ typedef struct {
   int scf_diis_space;        /*                    default 8                                       */
   int warm_start;            /* reuse t1/t2 of the previous sweep as the CCSD guess (default 0)      */
   int verbose;
+  int relax_density;         /* solve_ccsd(relax=True), solver.py:925-939: CCSD Lambda equations, response 1-RDM in
+                              * rdm1_mo / rdm1_emb and the relaxed with_dm1=False 2-RDM in e_frag (default 0)          */
+  double lambda_conv_tol;    /* |dz|               default 1e-8  (PySCF solve_lambda 1e-5)          */
+  int lambda_max_cycle;      /*                    default 100                                      */
 } qemb_solver_opts;
 void qemb_default_opts(qemb_solver_opts* opts);
 
@@ -152,6 +156,8 @@ int qemb_frag_solve(qemb_frag_t f, int nsocc, const double* h, const double* dm0
                     int eeval, double* mo_coeff, double* mo_energy, double* rdm1_emb, double* rdm1_mo, double* t1,
                     double* t2, double* e_frag, double* e_corr_mo, double* e_scf, double* ebe_hf, int* n_iter,
                     int* scf_cycles);
+/* number of Lambda iterations of the last qemb_frag_solve with relax_density (0 otherwise) */
+int qemb_frag_lambda_iters(qemb_frag_t f, int* n_iter);
 /* fragment RHF only: get_scfObj(fock + heff, eri, nocc, dm0) of molbe/helper.py:73-151 as used by
  * Frags.scf(fs=True) at initialisation (mbe.py:1160).  J, K: of the converged density (nullable).        */
 int qemb_frag_scf(qemb_frag_t f, int nsocc, const double* h, const double* dm0, const qemb_solver_opts* opts,

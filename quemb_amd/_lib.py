@@ -29,7 +29,8 @@ class SolverOpts(C.Structure):
     """qemb_solver_opts (include/qemb_hip.h)."""
     _fields_ = [("cc_conv_tol", C.c_double), ("cc_conv_tol_normt", C.c_double), ("cc_max_cycle", C.c_int),
                 ("cc_diis_space", C.c_int), ("scf_conv_tol", C.c_double), ("scf_conv_tol_grad", C.c_double),
-                ("scf_max_cycle", C.c_int), ("scf_diis_space", C.c_int), ("warm_start", C.c_int), ("verbose", C.c_int)]
+                ("scf_max_cycle", C.c_int), ("scf_diis_space", C.c_int), ("warm_start", C.c_int), ("verbose", C.c_int),
+                ("relax_density", C.c_int), ("lambda_conv_tol", C.c_double), ("lambda_max_cycle", C.c_int)]
 
 
 _lib = None
@@ -101,6 +102,7 @@ def _declare(lib):
     f("qemb_frag_set_energy_data", I, V, P, P, P, D, IP, I)
     f("qemb_frag_jk", I, V, P, P, P)
     f("qemb_frag_solve", I, V, I, P, P, OP, I, P, P, P, P, P, P, P, DP, DP, DP, IP, IP)
+    f("qemb_frag_lambda_iters", I, P, C.POINTER(C.c_int))
     f("qemb_frag_scf", I, V, I, P, P, OP, P, P, P, P, DP, IP, IP)
     f("qemb_frag_cphf", I, V, I, P, P, OP, P, I, P)
     f("qemb_ccsd_solve", I, I, I, I, P, P, P, OP, P, P, D, IP, I, P, P, P, P, P, P, DP, IP)

@@ -76,8 +76,6 @@ def be_func_parallel(pot, Fobjs, Nocc, solver, enuc, solver_args=None, scratch_d
     rank; only the fragments with owner[i] == rank need device state (fock / ERIs) on this rank."""
     if solver != "CCSD":
         raise ValueError("Solver not implemented")
-    if relax_density:
-        raise NotImplementedError("relax_density=True needs the CCSD Lambda equations (SURVEY 8f.3)")
     rank, ws = world()
     if owner is None:
         owner = [i % ws for i in range(len(Fobjs))]
@@ -89,7 +87,7 @@ def be_func_parallel(pot, Fobjs, Nocc, solver, enuc, solver_args=None, scratch_d
         f = Fobjs[i]
         if pot is not None:
             f.update_heff(pot, only_chem=only_chem)
-        out = f.solve(opts=opts, eeval=eeval, use_cumulant=use_cumulant)
+        out = f.solve(opts=opts, eeval=eeval, use_cumulant=use_cumulant, relax_density=relax_density)
         buf[2 * nm + 4] += out["n_iter"]
         if eeval:
             buf[2 * nm + 1: 2 * nm + 4] += out["e_frag"]

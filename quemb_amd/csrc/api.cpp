@@ -108,6 +108,8 @@ void qemb_default_opts(qemb_solver_opts* o) {
   o->cc_conv_tol = c.conv_tol; o->cc_conv_tol_normt = c.conv_tol_normt; o->cc_max_cycle = c.max_cycle; o->cc_diis_space = c.diis_space;
   o->scf_conv_tol = s.conv_tol; o->scf_conv_tol_grad = s.conv_tol_grad; o->scf_max_cycle = s.max_cycle; o->scf_diis_space = s.diis_space;
   o->warm_start = 0; o->verbose = 0;
+  LambdaOptions l;
+  o->relax_density = 0; o->lambda_conv_tol = l.conv_tol; o->lambda_max_cycle = l.max_cycle;
 }
 static FragmentOptions to_opts(const qemb_solver_opts* o) {
   FragmentOptions f;
@@ -117,6 +119,8 @@ static FragmentOptions to_opts(const qemb_solver_opts* o) {
     f.scf.conv_tol = o->scf_conv_tol; f.scf.conv_tol_grad = o->scf_conv_tol_grad; f.scf.max_cycle = o->scf_max_cycle;
     f.scf.diis_space = o->scf_diis_space; f.scf.verbose = o->verbose;
     f.warm_start = o->warm_start;
+    f.relax_density = o->relax_density; f.lam.conv_tol = o->lambda_conv_tol; f.lam.max_cycle = o->lambda_max_cycle;
+    f.lam.diis_space = o->cc_diis_space; f.lam.verbose = o->verbose;
   }
   return f;
 }
@@ -154,6 +158,7 @@ int qemb_frag_solve(qemb_frag_t f, int nsocc, const double* h, const double* dm0
   int rc = FRAG(f)->solve(nsocc, h, dm0, to_opts(opts), eeval, &r, mo_coeff, mo_energy, rdm1_emb, rdm1_mo, t1, t2);
   if (n_iter) *n_iter = r.n_iter;
   if (scf_cycles) *scf_cycles = r.scf_cycles;
+  FRAG(f)->last_lambda_iters = r.lambda_iters;
   if (rc) return rc;
   if (e_frag) { e_frag[0] = r.e_frag[0]; e_frag[1] = r.e_frag[1]; e_frag[2] = r.e_frag[2]; }
   if (e_corr_mo) *e_corr_mo = r.e_corr_mo;
@@ -161,6 +166,7 @@ int qemb_frag_solve(qemb_frag_t f, int nsocc, const double* h, const double* dm0
   if (ebe_hf) *ebe_hf = r.ebe_hf;
   return QEMB_OK;
 }
+int qemb_frag_lambda_iters(qemb_frag_t f, int* n_iter) { CHECK_FRAG(f); if (n_iter) *n_iter = FRAG(f)->last_lambda_iters; return QEMB_OK; }
 int qemb_frag_scf(qemb_frag_t f, int nsocc, const double* h, const double* dm0, const qemb_solver_opts* opts, double* mo_coeff,
                   double* mo_energy, double* J, double* K, double* e_scf, int* converged, int* cycles) {
   CHECK_FRAG(f);

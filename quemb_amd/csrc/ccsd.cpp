@@ -36,7 +36,7 @@ namespace qemb {
 // ------------------------------------------------------------------------------------------------------------
 int64_t mo_transform_work(int n) { return (int64_t)n * n * ((int64_t)n * (n + 1) / 2); }
 
-int mo_transform(int n, int o, int nf, const double* eri_s4, double* X0, double* X1, const double* C, MoIntegrals& out, bool build_Vl) {
+int mo_transform(int n, int o, int nf, const double* eri_s4, double* X0, double* X1, const double* C, MoIntegrals& out, bool build_Vl, bool build_T34) {
   const int v = n - o;
   const int64_t np = (int64_t)n * (n + 1) / 2, ncol = np * n;
   out.n = n; out.o = o; out.v = v; out.nf = nf;
@@ -47,7 +47,10 @@ int mo_transform(int n, int o, int nf, const double* eri_s4, double* X0, double*
   QTRY(dev_pack_pair_rows(n, np, X1, X0));
   QTRY(dev_unpack_tril_rows(np, n, X0, X1));
   QTRY(gemm(n, ncol, n, 1.0, C, n, false, X1, n, true, 0.0, X0, ncol));
-  if (nf > 0) {   // X0 = [q'][(r's')][P]
+  if (nf > 0 && build_T34) {   // every (P q'|r' s'), pair unpacked: the operand of CcLambda::densities
+    QTRY(out.T34.alloc((int64_t)n * n * n * nf));
+    QTRY(dev_extract_mid_pair(n, n, n, X0, 0, 0, n, n, 0, nf, out.T34));
+  } else if (nf > 0) {   // X0 = [q'][(r's')][P]
     QTRY(out.A1.alloc((int64_t)v * o * v * nf));
     QTRY(out.A2.alloc((int64_t)o * o * v * nf));
     QTRY(dev_extract_mid_pair(v, n, n, X0 + (int64_t)o * ncol, 0, o, o, v, 0, nf, out.A1));   // A1[a,j,b,P] = (P a|j b)
@@ -169,6 +172,40 @@ int CcsdSolver::set_amps(const double* t1d, const double* t2d) {
   return energy(t1(), t2(), &ecc_);
 }
 
+// pp-ladder through the (+/-) pair-packed operands (see the comment in update_amps)
+int CcsdSolver::apply_ladder(const double* x, double* out) {
+  const int64_t o = o_, v = v_;
+  {
+    const int64_t npo = o * (o + 1) / 2, nmo = o * (o - 1) / 2, npv = v * (v + 1) / 2, nmv = v * (v - 1) / 2;
+    const int64_t ldp = I_.ldp, ldm = I_.ldm;
+    QTRY(dev_ladder_pack_tau(o, v, x, LTp_, ldp, LTm_, ldm));
+    auto pick = [](int64_t rows, int64_t cols, int& cfg, int& ks) {
+      cfg = -1; ks = 0;
+      if (rows > 224 || cols < 2048) return;
+      cfg = rows <= 64 ? 12 : (rows <= 112 ? 11 : 10);
+      const int64_t tiles = (cols + 127) / 128;
+      double best = 0.0;
+      for (int c = 1; c <= 8; ++c) {
+        const int64_t units = tiles * c, rounds = (units + 255) / 256;
+        const double eff = (double)units / (double)(rounds * 256) - (c == 1 ? 0.0 : 0.002 * c);
+        if (units >= 512 && eff > best + 1e-9) { best = eff; ks = c; }
+      }
+      if (ks == 0) ks = (int)std::max<int64_t>(1, std::min<int64_t>(8, (1024 + tiles - 1) / tiles));
+    };
+    int cfg, ks;
+    QTRY(dev_timer_begin(TIMER_LADDER));
+    pick(npo, npv, cfg, ks);
+    QTRY(gemm(npo, npv, ldp, 1.0, LTp_, ldp, true, I_.Vp, ldp, true, 0.0, LRp_, ldp, 1, 0, 0, 0, cfg, ks));
+    if (nmo > 0 && nmv > 0) {
+      pick(nmo, nmv, cfg, ks);
+      QTRY(gemm(nmo, nmv, ldm, 1.0, LTm_, ldm, true, I_.Vm, ldm, true, 0.0, LRm_, ldm, 1, 0, 0, 0, cfg, ks));
+    }
+    QTRY(dev_timer_end(TIMER_LADDER));
+    QTRY(dev_ladder_scatter_pm(o, v, LRp_, ldp, LRm_, ldm, out));
+  }
+  return 0;
+}
+
 int CcsdSolver::update_amps(double* t1n, double* t2n) {
   const int64_t o = o_, v = v_, nov = o * v, oo = o * o, vv = v * v, N2 = oo * vv;
   const double* t1 = this->t1();
@@ -217,34 +254,7 @@ int CcsdSolver::update_amps(double* t1n, double* t2n) {
   // are computed -- 2 npair(o) npair(v)^2 + 2 npair'(o) npair'(v)^2 flops = 1/4 of the dense 2 o^2 v^4 -- and the
   // operands Vp, Vm (6.4 GB together at v = 200) are each streamed ONCE through a tile that holds every packed (ij) row
   // (224 x 128, 8 waves), K split over workgroups to fill whole rounds of the 256 CUs.
-  {
-    const int64_t npo = o * (o + 1) / 2, nmo = o * (o - 1) / 2, npv = v * (v + 1) / 2, nmv = v * (v - 1) / 2;
-    const int64_t ldp = I_.ldp, ldm = I_.ldm;
-    QTRY(dev_ladder_pack_tau(o, v, tau_, LTp_, ldp, LTm_, ldm));
-    auto pick = [](int64_t rows, int64_t cols, int& cfg, int& ks) {
-      cfg = -1; ks = 0;
-      if (rows > 224 || cols < 2048) return;
-      cfg = rows <= 64 ? 12 : (rows <= 112 ? 11 : 10);
-      const int64_t tiles = (cols + 127) / 128;
-      double best = 0.0;
-      for (int c = 1; c <= 8; ++c) {
-        const int64_t units = tiles * c, rounds = (units + 255) / 256;
-        const double eff = (double)units / (double)(rounds * 256) - (c == 1 ? 0.0 : 0.002 * c);
-        if (units >= 512 && eff > best + 1e-9) { best = eff; ks = c; }
-      }
-      if (ks == 0) ks = (int)std::max<int64_t>(1, std::min<int64_t>(8, (1024 + tiles - 1) / tiles));
-    };
-    int cfg, ks;
-    QTRY(dev_timer_begin(TIMER_LADDER));
-    pick(npo, npv, cfg, ks);
-    QTRY(gemm(npo, npv, ldp, 1.0, LTp_, ldp, true, I_.Vp, ldp, true, 0.0, LRp_, ldp, 1, 0, 0, 0, cfg, ks));
-    if (nmo > 0 && nmv > 0) {
-      pick(nmo, nmv, cfg, ks);
-      QTRY(gemm(nmo, nmv, ldm, 1.0, LTm_, ldm, true, I_.Vm, ldm, true, 0.0, LRm_, ldm, 1, 0, 0, 0, cfg, ks));
-    }
-    QTRY(dev_timer_end(TIMER_LADDER));
-    QTRY(dev_ladder_scatter_pm(o, v, LRp_, ldp, LRm_, ldm, t2n));
-  }
+  QTRY(apply_ladder(tau_, t2n));
 
   // ---- T2 equation: terms that enter as P(X) accumulate in U
   QTRY(gemm(v, v, v, 1.0, Lvv_, v, true, t2, v, false, 0.0, U_, v, oo, 0, vv, vv));   // Lvv'[a,c] t2[ijcb]

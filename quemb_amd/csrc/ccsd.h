@@ -25,15 +25,19 @@ struct MoIntegrals {
   DBuf Vp, Vm;
   int64_t ldp = 0, ldm = 0;
   DBuf A1, A2;      // A1[a,j,b,P] = (P a|j b), A2[i,j,b,P] = (P i|j b), P < nf in the EMBEDDING basis
+  DBuf T34;         // T34[q',r',s',P] = (P q'|r' s'), P < nf: all 3/4-transformed integrals (relaxed-density energy only)
 };
 
 // eri_s4: (npair x npair) 4-fold packed embedding-basis ERIs on the device (read only); X0, X1: two device work
 // buffers of mo_transform_work(n) = n^2 * npair doubles each; C: n x n MO coefficients (columns) on the device.
 int64_t mo_transform_work(int n);
 int mo_transform(int n, int o, int nf, const double* eri_s4, double* X0, double* X1, const double* C, MoIntegrals& out,
-                 bool build_Vl = false);
+                 bool build_Vl = false, bool build_T34 = false);
+
+class CcLambda;
 
 class CcsdSolver {
+  friend class CcLambda;
  public:
   int setup(MoIntegrals&& ints, const double* mo_energy_dev);
   int init_amps();                                  // MP2 guess (t1 = 0 for the diagonal Fock)
@@ -44,6 +48,9 @@ class CcsdSolver {
   int energy_intermediates(std::vector<double>& Z1, std::vector<double>& Z2);
   // copy a named integral block to the host (measurement / debugging): oooo ovoo ovov ovvv Vl W1base W2base eo ev
   int export_block(const char* name, double* host, int64_t nelem);
+  // out[i,j,a,b] += sum_cd (ac|bd) x[i,j,c,d] through the (+/-) pair-packed operands; x must satisfy x[j,i,d,c] = x[i,j,c,d]
+  int apply_ladder(const double* x, double* out);
+  const MoIntegrals& integrals() const { return I_; }
   double* t1() { return amp_.p; }
   double* t2() { return amp_.p + (int64_t)o_ * v_; }
   int o() const { return o_; }

@@ -191,7 +191,7 @@ int Fragment::solve(int o, const double* h, const double* dm0, const FragmentOpt
   // ---- integrals + CCSD
   QTRY(X1.alloc(mo_transform_work(n)));
   MoIntegrals ints;
-  QTRY(mo_transform(n, o, eeval ? nf_ : 0, eri_s4_, X0, X1, C_, ints));
+  QTRY(mo_transform(n, o, eeval ? nf_ : 0, eri_s4_, X0, X1, C_, ints, /*build_Vl=*/false, /*build_T34=*/opt.relax_density != 0));
   X0.release(); X1.release();
   cc_.reset(new CcsdSolver());
   QTRY(cc_->setup(std::move(ints), eps_));
@@ -209,8 +209,22 @@ int Fragment::solve(int o, const double* h, const double* dm0, const FragmentOpt
   QTRY(dev_d2h(t1.data(), cc_->t1(), sizeof(double) * o * v));
   if (t1_out) std::memcpy(t1_out, t1.data(), sizeof(double) * o * v);
   if (t2_out) QTRY(dev_d2h(t2_out, cc_->t2(), sizeof(double) * (int64_t)o * o * v * v));
+  // ---- relax_density: Lambda equations, response 1-RDM and the contraction of the response 2-RDM with the fragment ERIs
+  std::vector<double> dm1r, Imat;
+  if (opt.relax_density) {
+    CcLambda lam(*cc_);
+    QTRY(lam.setup());
+    bool lconv = false;
+    QTRY(lam.kernel(opt.lam, &res->lambda_iters, &lconv));
+    if (!lconv) { set_error("CCSD Lambda equations did not converge in max_cycle iterations"); return QEMB_ERR_NOCONV; }
+    dm1r.assign((size_t)n2, 0.0);
+    if (eeval) Imat.assign((size_t)n * nf_, 0.0);
+    QTRY(lam.densities(dm1r.data(), eeval ? cc_->integrals().T34.p : nullptr, nf_, eeval ? Imat.data() : nullptr));
+  }
   // rdm1_mo = [[2 I, t1], [t1^T, 0]]  (shared/external/ccsd_rdm.py:10-20)
-  if (rdm1_mo) {
+  if (rdm1_mo && opt.relax_density) {
+    std::memcpy(rdm1_mo, dm1r.data(), sizeof(double) * n2);
+  } else if (rdm1_mo) {
     std::memset(rdm1_mo, 0, sizeof(double) * n2);
     for (int i = 0; i < o; ++i) rdm1_mo[(size_t)i * n + i] = 2.0;
     for (int i = 0; i < o; ++i) for (int a = 0; a < v; ++a) { rdm1_mo[(size_t)i * n + o + a] = t1[(size_t)i * v + a]; rdm1_mo[(size_t)(o + a) * n + i] = t1[(size_t)i * v + a]; }
@@ -224,6 +238,11 @@ int Fragment::solve(int o, const double* h, const double* dm0, const FragmentOpt
     const double sym = 0.5 * (rdm[(size_t)p * n + q] + rdm[(size_t)q * n + p]);
     rdm[(size_t)p * n + q] = rdm[(size_t)q * n + p] = hfdm[(size_t)p * n + q] + sym;
   }
+  if (opt.relax_density) {   // rdm_emb = C dm1 C^T / 2 with the full response density
+    std::vector<double> Y((size_t)n2, 0.0);
+    for (int p = 0; p < n; ++p) for (int r = 0; r < n; ++r) { const double c = C[(size_t)p * n + r]; for (int q = 0; q < n; ++q) Y[(size_t)p * n + q] += c * dm1r[(size_t)r * n + q]; }
+    for (int p = 0; p < n; ++p) for (int q = 0; q < n; ++q) { double t = 0; for (int r = 0; r < n; ++r) t += Y[(size_t)p * n + r] * C[(size_t)q * n + r]; rdm[(size_t)p * n + q] = 0.5 * t; }
+  }
   if (rdm1_emb) std::memcpy(rdm1_emb, rdm.data(), sizeof(double) * n2);
   if (mo_coeff) std::memcpy(mo_coeff, C.data(), sizeof(double) * n2);
   if (mo_energy) std::memcpy(mo_energy, eps.data(), sizeof(double) * n);
@@ -231,7 +250,7 @@ int Fragment::solve(int o, const double* h, const double* dm0, const FragmentOpt
   if (eeval) {
     if (h1_.empty() || veff0_.empty()) { set_error("Fragment: set_energy_data(h1, veff0, ...) before an energy evaluation"); return QEMB_ERR_ARG; }
     std::vector<double> Z1, Z2;
-    QTRY(cc_->energy_intermediates(Z1, Z2));
+    if (!opt.relax_density) QTRY(cc_->energy_intermediates(Z1, Z2));
     std::vector<double> e1((size_t)nf_, 0.0), e2((size_t)nf_, 0.0), ec((size_t)nf_, 0.0);
     for (int P = 0; P < nf_; ++P) {
       double s1 = 0, sc = 0;
@@ -241,6 +260,11 @@ int Fragment::solve(int o, const double* h, const double* dm0, const FragmentOpt
       }
       e1[P] = s1; ec[P] = sc;
       double s2 = 0;
+      if (opt.relax_density) {   // e2_P = 1/4 sum_p' C[P,p'] I[p',P]  (cc_lambda.h)
+        for (int q = 0; q < n; ++q) s2 += C[(size_t)P * n + q] * Imat[(size_t)q * nf_ + P];
+        e2[P] = 0.25 * s2;
+        continue;
+      }
       for (int i = 0; i < o; ++i) s2 += C[(size_t)P * n + i] * Z1[(size_t)i * nf_ + P];
       for (int a = 0; a < v; ++a) s2 += C[(size_t)P * n + o + a] * Z2[(size_t)a * nf_ + P];
       e2[P] = 0.5 * s2;

@@ -5,6 +5,7 @@
 #include <memory>
 #include <vector>
 #include "ccsd.h"
+#include "cc_lambda.h"
 #include "scf.h"
 
 namespace qemb {
@@ -14,10 +15,13 @@ struct FragmentOptions {
   ScfOptions scf;
   int warm_start = 0;      // reuse converged t1/t2 of the previous solve as the CCSD guess (reference restarts from MP2)
   int keep_amplitudes = 1; // keep t1/t2 resident after the solve
+  int relax_density = 0;   // solve_ccsd(relax=True), solver.py:925-939: Lambda equations + response densities
+  LambdaOptions lam;
 };
 
 struct FragmentResult {
   int n_iter = 0;
+  int lambda_iters = 0;
   int scf_cycles = 0;
   int ccsd_converged = 0, scf_converged = 0;
   double e_corr_mo = 0.0;      // CCSD correlation energy of the embedding problem
@@ -29,6 +33,7 @@ struct FragmentResult {
 class Fragment {
  public:
   Fragment(int n, int nf) : n_(n), nf_(nf) {}
+  int last_lambda_iters = 0;
   int n() const { return n_; }
   int nf() const { return nf_; }
   int o() const { return o_; }

@@ -86,8 +86,10 @@ class DeviceFragment:
                                        out["rdm1_mo"].ctypes.data, out["t1"].ctypes.data, _p(out["t2"]), e_frag.ctypes.data,
                                        C.byref(ecorr), C.byref(escf), C.byref(ebehf), C.byref(nit), C.byref(ncyc)),
               "qemb_frag_solve", self.lib)
+        nlam = C.c_int()
+        check(self.lib.qemb_frag_lambda_iters(self.h, C.byref(nlam)), "qemb_frag_lambda_iters", self.lib)
         out.update(e_frag=e_frag, e_corr_mo=ecorr.value, e_scf=escf.value, ebe_hf=ebehf.value, n_iter=nit.value,
-                   scf_cycles=ncyc.value)
+                   scf_cycles=ncyc.value, lambda_iters=nlam.value)
         return out
 
     def scf(self, nsocc, h, dm0=None, opts=None):

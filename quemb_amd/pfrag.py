@@ -164,8 +164,14 @@ class Frags:
         return None
 
     # ------------------------------------------------------------------ the sweep body
-    def solve(self, opts=None, eeval=True, use_cumulant=True, want_t2=False):
-        """update_heff -> scf -> solve_ccsd -> rdm1 -> get_frag_energy for this fragment (solver.py:301-547)."""
+    def solve(self, opts=None, eeval=True, use_cumulant=True, want_t2=False, relax_density=False):
+        """update_heff -> scf -> solve_ccsd -> rdm1 -> get_frag_energy for this fragment (solver.py:301-547).
+        relax_density: solve_ccsd(relax=True) (solver.py:925-939) -- Lambda equations on the device, response densities."""
+        if bool(relax_density) != bool(getattr(opts, "relax_density", 0) if opts is not None else 0):
+            from ._lib import SolverOpts
+            from .fragsolver import default_opts
+            opts = SolverOpts.from_buffer_copy(opts) if opts is not None else default_opts(self.dev.lib)
+            opts.relax_density = int(bool(relax_density))
         if eeval:
             w, cen = self.weight_and_relAO_per_center
             self.dev.set_energy_data(self.h1, self.veff0, self.veff, w, cen)

@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import numpy as np
 
+from ._lib import SolverOpts
 from .fragsolver import DeviceFragment, default_opts
 
 
@@ -87,7 +88,8 @@ def solve_ccsd(h, eri_s4, nsocc, dm0=None, *, n_frag=0, rdm_return=False, rdm2_r
     Returns (t1, t2) or (t1, t2, rdm1_mo, mo_coeff) with rdm_return.  The dense 2-RDM is never formed on the device
     (rdm2_return raises): its only consumer, get_frag_energy, is evaluated in contracted form by `Frags.solve`."""
     if relax:
-        raise NotImplementedError("relaxed CCSD densities (Lambda equations) are a 'next' row (SURVEY 8f.3)")
+        opts = SolverOpts.from_buffer_copy(opts) if opts is not None else default_opts(lib)
+        opts.relax_density = 1
     if rdm2_return:
         raise NotImplementedError("the n^4 2-RDM is not materialised; use Frags.solve(eeval=True) for energies")
     n = h.shape[0]
@@ -106,15 +108,13 @@ def be_func(pot, Fobjs, Nocc, solver, enuc, solver_args=None, scratch_dir=None, 
     per-sweep counters) are additions; everything else has the reference's meaning."""
     if solver != "CCSD":
         raise ValueError("Solver not implemented")
-    if relax_density:
-        raise NotImplementedError("relax_density=True needs the CCSD Lambda equations (SURVEY 8f.3)")
     total_e = [0.0, 0.0, 0.0]
     n_iter = 0
     for fobj in Fobjs:
         if pot is not None:
             fobj.update_heff(pot, only_chem=only_chem)
         assert fobj.fock is not None and fobj.heff is not None
-        out = fobj.solve(opts=opts, eeval=eeval, use_cumulant=use_cumulant)
+        out = fobj.solve(opts=opts, eeval=eeval, use_cumulant=use_cumulant, relax_density=relax_density)
         n_iter += out["n_iter"]
         if eeval:
             total_e = [a + b for a, b in zip(total_e, out["e_frag"])]

@@ -76,3 +76,31 @@ def test_one_call_abi_and_jk(qlib):
     J, K = fr.jk(P)
     Jr, Kr = scf.get_jk(e1, P)
     assert np.abs(J - Jr).max() < 1e-11 and np.abs(K - Kr).max() < 1e-11
+
+
+@pytest.mark.parametrize("n,o,nf,cen", [(6, 2, 3, [0, 1]), (13, 5, 4, [0, 2]), (24, 6, 7, [1, 2, 3])])
+def test_relaxed_density_pipeline_matches_oracle(qlib, n, o, nf, cen):
+    """relax_density=True (solve_ccsd(relax=True), molbe/solver.py:925-939): Lambda equations + response densities on the
+    device against the oracle's reverse-mode restatement (pinned by energy derivatives, tests/test_oracle_lambda.py)."""
+    from qemb_oracle import ccsd_lambda
+    h, e1 = synthetic_fragment(n, o, 900 + n)
+    h1, veff0, veff = _energy_data(n, n + 1)
+    s4 = eri.pack_s4(e1)
+    fr = DeviceFragment(n, nf)
+    fr.set_eri_s4(s4)
+    fr.set_energy_data(h1, veff0, veff, 1.0, cen)
+    opts = default_opts(cc_conv_tol=1e-12, cc_conv_tol_normt=1e-10, scf_conv_tol=1e-12, scf_conv_tol_grad=1e-8, relax_density=1,
+                        lambda_conv_tol=1e-10)
+    out = fr.solve(o, h, opts=opts, eeval=True)
+    mf = scf.rhf(h, e1, o, conv_tol=1e-12, conv_tol_grad=1e-8)
+    eris = ccsd.Eris(e1, mf["mo_coeff"], o, mo_energy=mf["mo_energy"])
+    conv, ecc, t1, t2, _ = ccsd.kernel(eris, conv_tol=1e-12, conv_tol_normt=1e-10)
+    z1, z2, nit, lag = ccsd_lambda.solve_lambda(t1, t2, eris, conv_tol=1e-11)
+    dm1, _ = ccsd_lambda.response_densities(lag, z1, z2)
+    g2 = ccsd_lambda.make_rdm2_relaxed(lag, z1, z2)
+    C = mf["mo_coeff"]
+    assert abs(out["e_corr_mo"] - ecc) < TOL_E
+    assert abs(out["lambda_iters"] - nit) <= 2
+    assert np.abs(out["rdm1_emb"] - 0.5 * C @ dm1 @ C.T).max() < TOL_RDM
+    e_ref = be.get_frag_energy(C, o, nf, (1.0, cen), np.zeros((n, n)), h1, dm1, g2, s4, veff0, None, True)
+    assert np.abs(np.array(out["e_frag"]) - np.array(e_ref)).max() < TOL_E, (out["e_frag"], e_ref)

@@ -111,3 +111,35 @@ def test_warm_start_and_errors(hlib):
     assert abs(a["e_corr_mo"] - b["e_corr_mo"]) < 1e-9 and b["n_iter"] <= 3
     with pytest.raises(QembError):
         fr.solve(o, h, opts=default_opts(hlib, cc_max_cycle=1), eeval=False)   # non-convergence is an error
+
+
+@pytest.mark.parametrize("n,o,nf,cen", [(6, 2, 3, [0, 1]), (8, 3, 3, [1]), (7, 4, 2, [0])])
+def test_relaxed_density_fragment_solve_matches_oracle(hlib, n, o, nf, cen):
+    """relax_density=True (solve_ccsd(relax=True), molbe/solver.py:925-939): Lambda equations, response 1-RDM and the
+    relaxed with_dm1=False 2-RDM contracted into the fragment energy -- against oracle/qemb_oracle/ccsd_lambda.py."""
+    from qemb_oracle import ccsd_lambda
+    from quemb_amd.fragsolver import DeviceFragment, default_opts
+    h, e1, h1, veff0, veff = _problem(n, o, nf, 70 + n)
+    s4 = eri.pack_s4(e1)
+    fr = DeviceFragment(n, nf, lib=hlib)
+    fr.set_eri_s4(s4)
+    fr.set_energy_data(h1, veff0, veff, 0.75, cen)
+    opts = default_opts(hlib, cc_conv_tol=1e-13, cc_conv_tol_normt=1e-11, scf_conv_tol=1e-13, scf_conv_tol_grad=1e-9,
+                        relax_density=1, lambda_conv_tol=1e-11)
+    out = fr.solve(o, h, opts=opts, eeval=True)
+    assert out["lambda_iters"] > 1
+    mf = scf.rhf(h, e1, o, conv_tol=1e-13, conv_tol_grad=1e-9)
+    eris = ccsd.Eris(e1, mf["mo_coeff"], o, mo_energy=mf["mo_energy"])
+    conv, ecc, t1, t2, _ = ccsd.kernel(eris, conv_tol=1e-13, conv_tol_normt=1e-11)
+    z1, z2, nit, lag = ccsd_lambda.solve_lambda(t1, t2, eris, conv_tol=1e-12)
+    dm1, _ = ccsd_lambda.response_densities(lag, z1, z2)
+    g2 = ccsd_lambda.make_rdm2_relaxed(lag, z1, z2)
+    C = mf["mo_coeff"]
+    assert np.abs(out["rdm1_emb"] - 0.5 * C @ dm1 @ C.T).max() < 1e-8
+    assert abs(np.trace(out["rdm1_mo"]) - 2 * o) < 1e-9                  # the response density keeps the electron count
+    TA = np.zeros((n + 2, n))
+    e_ref = be.get_frag_energy(C, o, nf, (0.75, cen), TA, h1, dm1, g2, s4, veff0, None, True)
+    assert np.allclose(out["e_frag"], e_ref, atol=1e-8), (out["e_frag"], e_ref)
+    # and it differs from the unrelaxed answer (the test would otherwise not see the Lambda part)
+    out0 = fr.solve(o, h, opts=default_opts(hlib, cc_conv_tol=1e-13, cc_conv_tol_normt=1e-11), eeval=True)
+    assert out0["lambda_iters"] == 0 and abs(out0["e_frag"][1] - out["e_frag"][1]) > 1e-6
