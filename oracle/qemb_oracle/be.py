@@ -182,7 +182,7 @@ def solve_error(Fobjs, Nocc, only_chem=False):
     return float(np.mean(err_vec * err_vec) ** 0.5), err_vec
 
 
-def solve_fragment(fr, use_cumulant=True, eeval=True, ccsd_kw=None):
+def solve_fragment(fr, use_cumulant=True, eeval=True, ccsd_kw=None, relax_density=False):
     """One pass of the body of be_func's loop (molbe/solver.py:301-547) == run_solver (be_parallel.py:40-307):
     fragment RHF -> CCSD -> rdm1 back-rotation -> fragment energy."""
     ccsd_kw = ccsd_kw or {}
@@ -193,23 +193,33 @@ def solve_fragment(fr, use_cumulant=True, eeval=True, ccsd_kw=None):
     t1, t2, ecorr_mo, nit = occsd.solve_ccsd(None, fr.eri_s4, fr.nsocc, mf["mo_coeff"], mf["mo_energy"], **ccsd_kw)
     fr.t1, fr.t2 = t1, t2
     rdm1 = ordm.make_rdm1_ccsd_t1(t1)
+    if relax_density:        # solve_ccsd(relax=True), molbe/solver.py:925-939
+        from . import ccsd_lambda as olam
+        eris = occsd.Eris(fr.eri_s4, mf["mo_coeff"], fr.nsocc, mo_energy=mf["mo_energy"])
+        z1, z2, _, lag = olam.solve_lambda(t1, t2, eris, conv_tol=1e-11)
+        rdm1, _ = olam.response_densities(lag, z1, z2)
     fr.rdm1__ = rdm1.copy()
     fr._rdm1 = fr.mo_coeffs @ rdm1 @ fr.mo_coeffs.T * 0.5
     e_f = None
     if eeval:
-        rdm2 = ordm.make_rdm2_urlx(t1, t2, with_dm1=not use_cumulant)
+        if relax_density:
+            rdm2 = olam.make_rdm2_relaxed(lag, z1, z2)
+            if not use_cumulant:
+                rdm2 = ordm.add_dm1_terms(rdm2, rdm1, fr.nsocc)
+        else:
+            rdm2 = ordm.make_rdm2_urlx(t1, t2, with_dm1=not use_cumulant)
         e_f = get_frag_energy(fr.mo_coeffs, fr.nsocc, fr.n_frag, fr.weight_and_relAO_per_center, fr.TA, fr.h1, rdm1,
                               rdm2, fr.eri_s4, fr.veff0, fr.veff, use_cumulant)
     return e_f, nit, ecorr_mo
 
 
-def be_func(pot, Fobjs, Nocc, only_chem=False, eeval=False, return_vec=False, use_cumulant=True, ccsd_kw=None):
-    """molbe/solver.py:244-562 restricted to solver == 'CCSD', relax_density False."""
+def be_func(pot, Fobjs, Nocc, only_chem=False, eeval=False, return_vec=False, use_cumulant=True, ccsd_kw=None, relax_density=False):
+    """molbe/solver.py:244-562 restricted to solver == 'CCSD'."""
     total_e = [0.0, 0.0, 0.0]
     for f in Fobjs:
         if pot is not None:
             update_heff(f, pot, only_chem=only_chem)
-        e_f, _, _ = solve_fragment(f, use_cumulant=use_cumulant, eeval=eeval, ccsd_kw=ccsd_kw)
+        e_f, _, _ = solve_fragment(f, use_cumulant=use_cumulant, eeval=eeval, ccsd_kw=ccsd_kw, relax_density=relax_density)
         if eeval:
             total_e = [a + b for a, b in zip(total_e, e_f)]
             update_ebe_hf(f)

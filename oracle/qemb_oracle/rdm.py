@@ -36,3 +36,21 @@ def make_rdm2_urlx(t1, t2, with_dm1=True):
                 dm2[i, i, j, j] += 4
                 dm2[i, j, j, i] -= 2
     return dm2
+
+
+def add_dm1_terms(dm2, dm1, nocc):
+    """The with_dm1=True completion of a normal-ordered 2-RDM (PySCF cc/ccsd_rdm.py _make_rdm2, same statements as
+    shared/external/ccsd_rdm.py:40-53): products of the correlation 1-RDM with the HF determinant + the HF 2-RDM."""
+    dm2 = dm2.copy()
+    dm1 = dm1.copy()
+    dm1[np.diag_indices(nocc)] -= 2
+    for i in range(nocc):
+        dm2[i, i, :, :] += dm1 * 2
+        dm2[:, :, i, i] += dm1 * 2
+        dm2[:, i, i, :] -= dm1
+        dm2[i, :, :, i] -= dm1.T
+    for i in range(nocc):
+        for j in range(nocc):
+            dm2[i, i, j, j] += 4
+            dm2[i, j, j, i] -= 2
+    return dm2

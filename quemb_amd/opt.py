@@ -37,7 +37,7 @@ class BEOPT:
     def objfunc(self, xk):
         """molbe/opt.py:89-144: error vector of one sweep; records the RMS error and the BE energies."""
         err_, errvec_, ebe_ = self._sweep(list(xk), only_chem=self.only_chem, use_cumulant=self.use_cumulant, eeval=True,
-                                          return_vec=True)
+                                          return_vec=True, relax_density=self.relax_density)
         self.err = err_
         self.Ebe = ebe_
         self.pot = list(xk)

@@ -151,3 +151,29 @@ def test_semisparse_df_screening_matches_reference_algorithm(qlib):
     dense = df.transform(TA)
     assert np.abs(oeri.transform_integral_semisparse(packed, stored, TA, S_abs, Lpq, 0.0) - dense).max() < 1e-11
     assert np.abs(oeri.transform_integral_semisparse(packed, stored, TA, S_abs, Lpq, 0.3) - dense).max() > 1e-6
+
+
+def test_h8_relaxed_density_sweep_and_octane_relaxed_matching(qlib):
+    """relax_density=True through be_func on the device: H8 BE2 sweep against the oracle (Lambda + response densities), then the
+    octane BE2 density matching on relaxed densities converges and conserves the electron count of every fragment."""
+    from qemb_oracle import be as obe
+    from quemb_amd.solver import be_func
+    mf, be = _be("h8")
+    F = []
+    for I, f in enumerate(be.Fobjs):
+        o = obe.Frag(f.AO_in_frag, I, f.AO_per_edge, f.ref_frag_idx_per_edge, f.relAO_per_edge, f.relAO_in_ref_per_edge,
+                     f.weight_and_relAO_per_center, f.relAO_per_origin)
+        obe.init_fragment(o, be.W, be.lmo_coeff, be.Nocc, be.hcore, be.S, be.C, be.hf_dm, be.hf_veff, mf._eri)
+        F.append(o)
+    err, vec, (ecorr, comps) = be_func(None, be.Fobjs, be.Nocc, "CCSD", be.enuc, eeval=True, return_vec=True, relax_density=True, opts=be.opts)
+    err_o, vec_o, (ecorr_o, comps_o) = obe.be_func(None, F, be.Nocc, eeval=True, return_vec=True, relax_density=True)
+    assert abs(ecorr - ecorr_o) < 1e-8 and np.allclose(comps, comps_o, atol=1e-8)
+    assert np.abs(np.asarray(vec) - np.asarray(vec_o)).max() < 1e-7
+    mf8, be8 = _be("octane")
+    # (with the reference's HF Jacobian the relaxed problem needs ~100 quasi-Newton iterations for 1e-6; stop at 2e-5 here)
+    opt = be8.optimize(solver="CCSD", only_chem=False, relax_density=True, conv_tol=2e-5)
+    assert opt.err < 2e-5
+    for f in be8.Fobjs:
+        assert abs(np.trace(f.rdm1__) - 2 * f.nsocc) < 1e-8
+    # relaxed and unrelaxed matched energies differ in the 4th decimal for octane; both are near the golden of the latter
+    assert abs(be8.e_corr - (-0.5499514850769742)) < 5e-3

@@ -239,3 +239,49 @@ def test_noncumulant_energy_expression(hlib):
     ref = obe.get_frag_energy(mf["mo_coeff"], o, nf, (0.5, cen), np.zeros((n, n)), f.h1, ordm.make_rdm1_ccsd_t1(t1),
                               ordm.make_rdm2_urlx(t1, t2, with_dm1=True), oeri.pack_s4(e1), f.veff0, f.veff, False)
     assert np.allclose(out["e_frag"], ref, atol=1e-8), (out["e_frag"], ref)
+
+
+def test_h8_be2_relaxed_density_sweep_matches_oracle(hlib):
+    """be_func(..., relax_density=True) (molbe/solver.py:318-337 -> solve_ccsd(relax=True), :925-939) on H8 BE2: energies and the
+    density-matching residual of one sweep against the oracle's Lambda/response-density restatement; then the optimiser
+    runs on the relaxed densities (BEOPT passes relax_density on, molbe/opt.py:116,133)."""
+    from quemb_amd.solver import be_func
+    mf, fobj, be = _h8(hlib)
+    F = []
+    for I, f in enumerate(be.Fobjs):
+        o = obe.Frag(f.AO_in_frag, I, f.AO_per_edge, f.ref_frag_idx_per_edge, f.relAO_per_edge, f.relAO_in_ref_per_edge,
+                     f.weight_and_relAO_per_center, f.relAO_per_origin)
+        obe.init_fragment(o, be.W, be.lmo_coeff, be.Nocc, be.hcore, be.S, be.C, be.hf_dm, be.hf_veff, mf._eri)
+        F.append(o)
+    err, vec, (ecorr, comps) = be_func(None, be.Fobjs, be.Nocc, "CCSD", be.enuc, eeval=True, return_vec=True, relax_density=True,
+                                       opts=be.opts)
+    err_o, vec_o, (ecorr_o, comps_o) = obe.be_func(None, F, be.Nocc, eeval=True, return_vec=True, relax_density=True)
+    assert abs(ecorr - ecorr_o) < 1e-8 and np.allclose(comps, comps_o, atol=1e-8)
+    assert np.abs(np.asarray(vec) - np.asarray(vec_o)).max() < 1e-7
+    e_unrelaxed = be_func(None, be.Fobjs, be.Nocc, "CCSD", be.enuc, eeval=True, opts=be.opts)[0]
+    assert abs(e_unrelaxed - ecorr) > 1e-5
+    opt = be.optimize(solver="CCSD", conv_tol=1e-7, relax_density=True)
+    assert be.beopt.err < 1e-7
+
+
+def test_relaxed_noncumulant_energy_expression(hlib):
+    """use_cumulant=False with relax_density: make_rdm2(..., with_dm1=True) (solver.py:927-936) == relaxed normal-ordered
+    2-RDM + the dm1 x HF pieces, evaluated on the device through J/K builds."""
+    from quemb_amd.pfrag import Frags
+    from qemb_oracle import ccsd as occsd, ccsd_lambda, rdm as ordm, scf as oscf
+    n, o, nf, cen = 8, 3, 3, [0, 2]
+    h, e1 = synthetic_fragment(n, o, 321)
+    rng = np.random.default_rng(5)
+    mk = lambda: (lambda a: a + a.T)(rng.standard_normal((n, n)))
+    f = Frags(list(range(nf)), 0, [], [], [], [], (0.5, cen), [0], lib=hlib)
+    f.set_eri(oeri.pack_s4(e1))
+    f.nsocc, f.h1, f.veff0, f.veff, f.fock, f.heff, f.dm0 = o, mk(), mk(), mk(), h, np.zeros((n, n)), None
+    out = f.solve(eeval=True, use_cumulant=False, relax_density=True)
+    mf = oscf.rhf(h, e1, o)
+    eris = occsd.Eris(e1, mf["mo_coeff"], o, mo_energy=mf["mo_energy"])
+    conv, ecc, t1, t2, _ = occsd.kernel(eris, conv_tol=1e-13, conv_tol_normt=1e-11)
+    z1, z2, _, lag = ccsd_lambda.solve_lambda(t1, t2, eris, conv_tol=1e-12)
+    dm1, _ = ccsd_lambda.response_densities(lag, z1, z2)
+    g2 = ordm.add_dm1_terms(ccsd_lambda.make_rdm2_relaxed(lag, z1, z2), dm1, o)
+    ref = obe.get_frag_energy(mf["mo_coeff"], o, nf, (0.5, cen), np.zeros((n, n)), f.h1, dm1, g2, oeri.pack_s4(e1), f.veff0, f.veff, False)
+    assert np.allclose(out["e_frag"], ref, atol=1e-7), (out["e_frag"], ref)
