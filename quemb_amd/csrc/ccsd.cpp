@@ -182,7 +182,7 @@ int CcsdSolver::apply_ladder(const double* x, double* out) {
     auto pick = [](int64_t rows, int64_t cols, int& cfg, int& ks) {
       cfg = -1; ks = 0;
       if (rows > 224 || cols < 2048) return;
-      cfg = rows <= 64 ? 12 : (rows <= 112 ? 11 : 10);
+      cfg = rows <= 64 ? 12 : (rows <= 112 ? 11 : (rows <= 192 ? 15 : 13));
       const int64_t tiles = (cols + 127) / 128;
       double best = 0.0;
       for (int c = 1; c <= 8; ++c) {

@@ -390,6 +390,8 @@ int dev_gemm(const GemmDesc& d) {
     case 10: return launch_layout<14, 1, 1, 8, 16>(d, s, vec2); // 224 x 128, 8 waves: all packed (i>=j) rows of o = 20 in ONE tile
     case 11: return launch_layout<7, 1, 1, 8, 16>(d, s, vec2);  // 112 x 128, 8 waves
     case 12: return launch_layout<4, 1, 1, 8, 16>(d, s, vec2);  //  64 x 128, 8 waves
+    case 13: return launch_layout<7, 2, 2, 4, 16>(d, s, vec2);  // 224 x 128, 8 waves as 2 x 4: 9 LDS fragment reads per 14 MFMAs (15 for cfg 10)
+    case 15: return launch_layout<6, 2, 2, 4, 16>(d, s, vec2);  // 192 x 128, 8 waves as 2 x 4 (the 190 antisymmetric pair rows of o = 20)
     default: set_error("dev_gemm: unknown tile config"); return QEMB_ERR_ARG;
   }
 }

@@ -51,8 +51,18 @@ if __name__ == "__main__":
     for bpc in (1, 2, 4):
         t = C.c_double(); check(lib.qemb_mfma_f64_peak(40000, bpc, C.byref(t)))
         print(json.dumps(dict(tag="mfma_f64 register-only peak", blocks_per_cu=bpc, tflops=t.value)), flush=True)
-    bench(o * o, v * v, v * v, 1, 1, 1, tag="pp-ladder dense tau[ij,cd] W[ab,cd]")
     npair = o * (o + 1) // 2
+    if len(sys.argv) > 1 and sys.argv[1] == "ladder":
+        npv, nmv = v * (v + 1) // 2, v * (v - 1) // 2
+        for ks in (8,):
+            lib.qemb_set_gemm_ksplit(ks)
+            for cfg in (10, 13):
+                r1 = bench(npair, npv, npv, 1, 1, cfg, tag="pp-ladder (+) block ksplit=%d" % ks)
+            for cfg in (10, 13, 15):
+                r2 = bench(o * (o - 1) // 2, nmv, nmv, 1, 1, cfg, tag="pp-ladder (-) block ksplit=%d" % ks)
+        lib.qemb_set_gemm_ksplit(0)
+        sys.exit(0)
+    bench(o * o, v * v, v * v, 1, 1, 1, tag="pp-ladder dense tau[ij,cd] W[ab,cd]")
     npv, nmv = v * (v + 1) // 2, v * (v - 1) // 2
     lib.qemb_set_gemm_ksplit(8)
     r1 = bench(npair, npv, npv, 1, 1, 10, tag="pp-ladder (+) block M=npair(o) N=K=npair(v), ksplit=8")
