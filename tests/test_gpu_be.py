@@ -177,3 +177,18 @@ def test_h8_relaxed_density_sweep_and_octane_relaxed_matching(qlib):
         assert abs(np.trace(f.rdm1__) - 2 * f.nsocc) < 1e-8
     # relaxed and unrelaxed matched energies differ in the 4th decimal for octane; both are near the golden of the latter
     assert abs(be8.e_corr - (-0.5499514850769742)) < 5e-3
+
+
+def test_octane_chemical_potential_goldens_be2_be3(qlib):
+    """tests/chempot_molBE_test.py:51-65: octane/STO-3G, autogen BE2 and BE3, chemical-potential-only matching
+    (`only_chem=True`): E_tot = -310.33471581 / -310.33447096, delta 1e-4."""
+    from quemb_amd.fragpart import FragPart
+    from quemb_amd.integrals import RHF, Mole
+    from quemb_amd.mbe import BE
+    mol = Mole(GOLDEN / "octane.xyz")
+    mf = RHF(mol); mf.kernel()
+    for key, target in (("test_autogen_octane_be2", -310.33471581), ("test_autogen_octane_be3", -310.33447096)):
+        be = BE(mf, FragPart.from_json(GOLDEN / "fragmentation.json", key), distribute=False)
+        assert abs(be.ebe_hf - mf.e_tot) < 1e-6                 # HF-in-HF (tests/hf-in-hf_BE_test.py:56-63, 1e-5)
+        be.optimize(solver="CCSD", only_chem=True)
+        assert abs(be.ebe_tot - target) < 1e-4, (key, be.ebe_tot, target)
