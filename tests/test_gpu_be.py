@@ -192,3 +192,17 @@ def test_octane_chemical_potential_goldens_be2_be3(qlib):
         assert abs(be.ebe_hf - mf.e_tot) < 1e-6                 # HF-in-HF (tests/hf-in-hf_BE_test.py:56-63, 1e-5)
         be.optimize(solver="CCSD", only_chem=True)
         assert abs(be.ebe_tot - target) < 1e-4, (key, be.ebe_tot, target)
+
+
+def test_octane_be3_density_matching_golden(qlib):
+    """tests/molbe_octane_test.py:43-68 (the reference's QUEMB_DO_EXPENSIVE_TESTS case): BE3 CCSD density matching of octane,
+    E_tot = -310.3344717358742, E_corr = -0.5497021857717073 (np.isclose, rtol 1e-5; PySCF conv_tol 1e-7)."""
+    from quemb_amd.fragpart import FragPart
+    from quemb_amd.integrals import RHF, Mole
+    from quemb_amd.mbe import BE
+    mf = RHF(Mole(GOLDEN / "octane.xyz")); mf.kernel()
+    be = BE(mf, FragPart.from_json(GOLDEN / "fragmentation.json", "test_autogen_octane_be3"), distribute=False)
+    opt = be.optimize(solver="CCSD", only_chem=False)
+    assert opt.err < 1e-6
+    assert abs(be.e_corr - (-0.5497021857717073)) < 2e-6
+    assert abs(be.ebe_tot - (-310.3344717358742)) < 2e-6
