@@ -102,7 +102,7 @@ int CcsdSolver::setup(MoIntegrals&& ints, const double* mo_energy_dev) {
   // ---- constant tensors derived from the integral blocks
   QTRY(ovov_t_.alloc(nov * nov)); QTRY(Lovov_.alloc(nov * nov)); QTRY(Loovv_.alloc(N2)); QTRY(OVoovv_.alloc(N2));
   QTRY(Lovoo_.alloc(o * v * oo)); QTRY(W1base_.alloc(N2)); QTRY(W2base_.alloc(N2)); QTRY(Lph1_.alloc(N2));
-  QTRY(OVl_.alloc(o * v * vv)); QTRY(oooo_p_.alloc(oo * oo));
+  QTRY(oooo_p_.alloc(oo * oo));
   QTRY(perm4(ovov_t_, I_.ovov, o, v, o, v, 0, 3, 2, 1));                 // ovov_t[k,c,l,d] = ovov[k,d,l,c]
   QTRY(dcopy(nov * nov, I_.ovov, Lovov_));
   QTRY(axpby(nov * nov, -1.0, ovov_t_, 2.0, Lovov_));                    // Lovov = 2 ovov - ovov_t
@@ -114,7 +114,14 @@ int CcsdSolver::setup(MoIntegrals&& ints, const double* mo_energy_dev) {
   QTRY(perm4(W2base_, I_.oovv, o, o, v, v, 1, 2, 0, 3));                 // W2base[i,a,k,c] = oovv[k,i,a,c]
   QTRY(dcopy(N2, W2base_, Lph1_));
   QTRY(axpby(N2, 2.0, W1base_, -1.0, Lph1_));                            // Lph1 = 2 W1base - W2base
-  QTRY(perm4(OVl_, I_.ovvv, o, v, v, v, 0, 2, 3, 1));                    // OVl[k,a,c,d] = ovvv[k,d,a,c]
+  {  // OVl[k,a,c,d] = ovvv[k,d,a,c], kept only as its (+/-) pair-packed images over (c,d): the tau-side dressing of
+     // Wvvvv then contracts the SAME packed tau rows as the ladder, at half the flops of the dense o^2 x ov x v^2 product
+    DBuf OVl;
+    QTRY(OVl.alloc(o * v * vv));
+    QTRY(perm4(OVl, I_.ovvv, o, v, v, v, 0, 2, 3, 1));
+    QTRY(OVp_.alloc(nov * I_.ldp)); QTRY(OVm_.alloc(nov * I_.ldm));
+    QTRY(dev_pack_pm_cols(nov, v, OVl, OVp_, I_.ldp, OVm_, I_.ldm));
+  }
   QTRY(perm4(oooo_p_, I_.oooo, o, o, o, o, 0, 2, 1, 3));                 // oooo_p[k,l,i,j] = oooo[k,i,l,j]
   // ovvo / oovv are no longer needed once W1base / W2base exist
   I_.ovvo.release(); I_.oovv.release();
@@ -130,6 +137,7 @@ int CcsdSolver::setup(MoIntegrals&& ints, const double* mo_energy_dev) {
   {
     const int64_t npo = o * (o + 1) / 2, nmo = std::max<int64_t>(o * (o - 1) / 2, 1);
     QTRY(LTp_.alloc(npo * I_.ldp)); QTRY(LRp_.alloc(npo * I_.ldp)); QTRY(LTm_.alloc(nmo * I_.ldm)); QTRY(LRm_.alloc(nmo * I_.ldm));
+    QTRY(Xp_.alloc(npo * nov)); QTRY(Xm_.alloc(nmo * nov));
   }
   first_ = true;
   return 0;
@@ -172,6 +180,21 @@ int CcsdSolver::set_amps(const double* t1d, const double* t2d) {
   return energy(t1(), t2(), &ecc_);
 }
 
+// tile configuration and K split for the "few packed pair rows x many columns" GEMMs (ladder, tau-side dressing)
+static void pick_pair_gemm(int64_t rows, int64_t cols, int& cfg, int& ks) {
+  cfg = -1; ks = 0;
+  if (rows > 224 || cols < 2048) return;
+  cfg = rows <= 64 ? 12 : (rows <= 112 ? 11 : (rows <= 192 ? 15 : 13));
+  const int64_t tiles = (cols + 127) / 128;
+  double best = 0.0;
+  for (int c = 1; c <= 8; ++c) {
+    const int64_t units = tiles * c, rounds = (units + 255) / 256;
+    const double eff = (double)units / (double)(rounds * 256) - (c == 1 ? 0.0 : 0.002 * c);
+    if (units >= 512 && eff > best + 1e-9) { best = eff; ks = c; }
+  }
+  if (ks == 0) ks = (int)std::max<int64_t>(1, std::min<int64_t>(8, (1024 + tiles - 1) / tiles));
+}
+
 // pp-ladder through the (+/-) pair-packed operands (see the comment in update_amps)
 int CcsdSolver::apply_ladder(const double* x, double* out) {
   const int64_t o = o_, v = v_;
@@ -179,25 +202,12 @@ int CcsdSolver::apply_ladder(const double* x, double* out) {
     const int64_t npo = o * (o + 1) / 2, nmo = o * (o - 1) / 2, npv = v * (v + 1) / 2, nmv = v * (v - 1) / 2;
     const int64_t ldp = I_.ldp, ldm = I_.ldm;
     QTRY(dev_ladder_pack_tau(o, v, x, LTp_, ldp, LTm_, ldm));
-    auto pick = [](int64_t rows, int64_t cols, int& cfg, int& ks) {
-      cfg = -1; ks = 0;
-      if (rows > 224 || cols < 2048) return;
-      cfg = rows <= 64 ? 12 : (rows <= 112 ? 11 : (rows <= 192 ? 15 : 13));
-      const int64_t tiles = (cols + 127) / 128;
-      double best = 0.0;
-      for (int c = 1; c <= 8; ++c) {
-        const int64_t units = tiles * c, rounds = (units + 255) / 256;
-        const double eff = (double)units / (double)(rounds * 256) - (c == 1 ? 0.0 : 0.002 * c);
-        if (units >= 512 && eff > best + 1e-9) { best = eff; ks = c; }
-      }
-      if (ks == 0) ks = (int)std::max<int64_t>(1, std::min<int64_t>(8, (1024 + tiles - 1) / tiles));
-    };
     int cfg, ks;
     QTRY(dev_timer_begin(TIMER_LADDER));
-    pick(npo, npv, cfg, ks);
+    pick_pair_gemm(npo, npv, cfg, ks);
     QTRY(gemm(npo, npv, ldp, 1.0, LTp_, ldp, true, I_.Vp, ldp, true, 0.0, LRp_, ldp, 1, 0, 0, 0, cfg, ks));
     if (nmo > 0 && nmv > 0) {
-      pick(nmo, nmv, cfg, ks);
+      pick_pair_gemm(nmo, nmv, cfg, ks);
       QTRY(gemm(nmo, nmv, ldm, 1.0, LTm_, ldm, true, I_.Vm, ldm, true, 0.0, LRm_, ldm, 1, 0, 0, 0, cfg, ks));
     }
     QTRY(dev_timer_end(TIMER_LADDER));
@@ -260,7 +270,18 @@ int CcsdSolver::update_amps(double* t1n, double* t2n) {
   QTRY(gemm(v, v, v, 1.0, Lvv_, v, true, t2, v, false, 0.0, U_, v, oo, 0, vv, vv));   // Lvv'[a,c] t2[ijcb]
   QTRY(gemm_tn(o, o * vv, o, -1.0, Loo_, t2, 1.0, U_));                            // -Loo'[k,i] t2[kjab]
   //   t1-dressing of Wvvvv folded on the tau side: -t1[kb] (tau[ijcd] ovvv[kdac])
-  QTRY(gemm_nt(oo, nov, vv, 1.0, tau_, OVl_, 0.0, X_));                            // X[i,j,k,a]
+  {  // X[i,j,k,a] = tau[ijcd] OVl[k,a,c,d] from the packed tau rows LTp/LTm that apply_ladder just built:
+     //   X[ij] = Xp + Xm, X[ji] = Xp - Xm (i > j),  Xp = LTp OVp^T (c >= d),  Xm = LTm OVm^T (c > d)
+    const int64_t npo = o * (o + 1) / 2, nmo = o * (o - 1) / 2;
+    int cfg, ks;
+    pick_pair_gemm(npo, nov, cfg, ks);
+    QTRY(gemm(npo, nov, I_.ldp, 1.0, LTp_, I_.ldp, true, OVp_, I_.ldp, true, 0.0, Xp_, nov, 1, 0, 0, 0, cfg, ks));
+    if (nmo > 0) {
+      pick_pair_gemm(nmo, nov, cfg, ks);
+      QTRY(gemm(nmo, nov, I_.ldm, 1.0, LTm_, I_.ldm, true, OVm_, I_.ldm, true, 0.0, Xm_, nov, 1, 0, 0, 0, cfg, ks));
+    }
+    QTRY(dev_scatter_pm_rows(o, nov, Xp_, Xm_, X_));
+  }
   QTRY(gemm(v, v, o, -1.0, X_, v, false, t1, v, false, 1.0, U_, v, oo, nov, 0, vv));
   //   X1 = (ovvv[iacb] - oovv[kibc] t1[ka]) t1[jc]
   QTRY(gemm_nt(o, o * vv, v, 1.0, t1, I_.ovvv, 0.0, G1_));                         // G1[j,i,a,b] = t1[jc] ovvv[i,a,b,c]

@@ -66,11 +66,12 @@ class CcsdSolver {
   MoIntegrals I_;
   DBuf eo_, ev_;
   // derived constant tensors
-  DBuf ovov_t_, Lovov_, Loovv_, OVoovv_, Lovoo_, W1base_, W2base_, Lph1_, OVl_, oooo_p_;
+  DBuf ovov_t_, Lovov_, Loovv_, OVoovv_, Lovoo_, W1base_, W2base_, Lph1_, OVp_, OVm_, oooo_p_;   // OVp/OVm: (+/-) pair-packed OVl[k,a,c,d] = ovvv[k,d,a,c] over (c,d)
   // amplitudes (t1 then t2, one contiguous vector) and per-iteration work space
   DBuf amp_, ampn_, diff_;
   DBuf tau_, T_, Tp_, S_, W1_, W2_, W12_, R_, U_, G1_, G2_;
   DBuf LTp_, LTm_, LRp_, LRm_;   // (+/-) packed ladder: tau combinations and results
+  DBuf Xp_, Xm_;                 // (+/-) packed rows of X[i,j,k,a] = tau[ijcd] ovvv[kdac]
   DBuf Foo_, Fvv_, Fov_, Z_, Y_, Ytmp_, Loo_, Lvv_, Q_, Wo_, O1_, X_, scal_;
   std::vector<DeviceDIIS> diis_;
   bool first_ = true;

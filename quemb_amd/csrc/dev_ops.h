@@ -128,6 +128,11 @@ int dev_ladder_pack_vvvv(int64_t n, int64_t o, const double* M, double* Vp, int6
 int dev_ladder_pack_tau(int64_t o, int64_t v, const double* tau, double* Tp, int64_t ldp, double* Tm, int64_t ldm);
 // with Rp[P(i,j), P(a,b)], Rm[Q(i,j), Q(a,b)]:  t2[i,j,a,b] += Rp + Rm, t2[i,j,b,a] += Rp - Rm, t2[j,i,a,b] += Rp - Rm,
 // t2[j,i,b,a] += Rp + Rm  (each distinct element once; Rm = 0 where i == j or a == b)
+// Generic (+/-) pair packing of the last two (equal, size v) indices of in[rows][v][v]:
+//   Op[r, P(c,d)] = in[r,c,d] + in[r,d,c] (c >= d),  Om[r, Q(c,d)] = in[r,c,d] - in[r,d,c] (c > d); rows padded with zeros to ldp / ldm
+int dev_pack_pm_cols(int64_t rows, int64_t v, const double* in, double* Op, int64_t ldp, double* Om, int64_t ldm);
+// out[i,j,:] = Xp[P(i,j),:] + Xm[Q(i,j),:],  out[j,i,:] = Xp[P(i,j),:] - Xm[Q(i,j),:]  (i > j),  out[i,i,:] = Xp[P(i,i),:]
+int dev_scatter_pm_rows(int64_t o, int64_t ncols, const double* Xp, const double* Xm, double* out);
 int dev_ladder_scatter_pm(int64_t o, int64_t v, const double* Rp, int64_t ldp, const double* Rm, int64_t ldm, double* t2);
 
 // ---- screening helpers of the semi-sparse DF transform ---------------------------------------------------------------

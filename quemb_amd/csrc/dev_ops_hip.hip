@@ -589,6 +589,52 @@ int dev_ladder_pack_tau(int64_t o, int64_t v, const double* tau, double* Tp, int
   HIP_TRY(hipGetLastError());
   return QEMB_OK;
 }
+__global__ void __launch_bounds__(256) pack_pm_cols_kernel(long long rows, long long v, const double* __restrict__ in, double* __restrict__ Op, long long ldp,
+                                                          double* __restrict__ Om, long long ldm) {
+  const long long np = v * (v + 1) / 2, nm = v * (v - 1) / 2;
+  for (long long r = blockIdx.x; r < rows; r += gridDim.x) {
+    const double* t = in + r * v * v;
+    double* tp = Op + r * ldp;
+    double* tm = Om + r * ldm;
+    for (long long cd = threadIdx.x; cd < ldp; cd += blockDim.x) {
+      if (cd >= np) { tp[cd] = 0.0; continue; }
+      long long c, d; unpair_ge(cd, c, d);
+      const double x = t[c * v + d], y = t[d * v + c];
+      tp[cd] = x + y;
+      if (c > d) tm[c * (c - 1) / 2 + d] = x - y;
+    }
+    for (long long q = nm + threadIdx.x; q < ldm; q += blockDim.x) tm[q] = 0.0;
+  }
+}
+int dev_pack_pm_cols(int64_t rows, int64_t v, const double* in, double* Op, int64_t ldp, double* Om, int64_t ldm) {
+  REQUIRE_INIT();
+  if (rows <= 0 || v <= 0) return QEMB_OK;
+  hipLaunchKernelGGL(pack_pm_cols_kernel, dim3((unsigned)std::min<int64_t>(rows, 1 << 20)), dim3(256), 0, g_stream, (long long)rows, (long long)v, in, Op, (long long)ldp, Om, (long long)ldm);
+  HIP_TRY(hipGetLastError());
+  return QEMB_OK;
+}
+__global__ void __launch_bounds__(256) scatter_pm_rows_kernel(long long o, long long ncols, const double* __restrict__ Xp, const double* __restrict__ Xm, double* __restrict__ out) {
+  const long long ij = blockIdx.y;
+  long long i, j; unpair_ge(ij, i, j);
+  const double* xp = Xp + ij * ncols;
+  const double* xm = (i > j) ? Xm + (i * (i - 1) / 2 + j) * ncols : nullptr;
+  double* oij = out + (i * o + j) * ncols;
+  double* oji = out + (j * o + i) * ncols;
+  for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < ncols; c += (long long)gridDim.x * blockDim.x) {
+    const double p = xp[c];
+    if (xm) { const double m = xm[c]; oij[c] = p + m; oji[c] = p - m; }
+    else oij[c] = p;
+  }
+}
+int dev_scatter_pm_rows(int64_t o, int64_t ncols, const double* Xp, const double* Xm, double* out) {
+  REQUIRE_INIT();
+  const long long npo = o * (o + 1) / 2;
+  if (npo <= 0 || ncols <= 0) return QEMB_OK;
+  if (npo > 65535) { set_error("dev_scatter_pm_rows: too many pairs"); return QEMB_ERR_ARG; }
+  hipLaunchKernelGGL(scatter_pm_rows_kernel, dim3((unsigned)std::min<long long>((ncols + 255) / 256, 64), (unsigned)npo), dim3(256), 0, g_stream, (long long)o, (long long)ncols, Xp, Xm, out);
+  HIP_TRY(hipGetLastError());
+  return QEMB_OK;
+}
 // grid (v, npair(o)): block = (pair ij, row a); threads over b <= a.  Writes rows [i,j,a,:], [j,i,a,:] coalesced and
 // the transposed elements [i,j,b,a], [j,i,b,a] strided (L2-resident t2, 128 MB).
 __global__ void __launch_bounds__(256) ladder_scatter_pm_kernel(long long o, long long v, const double* __restrict__ Rp, long long ldp,

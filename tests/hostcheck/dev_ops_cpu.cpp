@@ -133,6 +133,26 @@ int dev_ladder_pack_vvvv_hp(int64_t n, int64_t o, const double* Mh, double* Vp, 
   }
   return 0;
 }
+int dev_pack_pm_cols(int64_t rows, int64_t v, const double* in, double* Op, int64_t ldp, double* Om, int64_t ldm) {
+  for (int64_t r = 0; r < rows; ++r) {
+    const double* t = in + r * v * v;
+    double* tp = Op + r * ldp; std::fill(tp, tp + ldp, 0.0);
+    double* tm = Om + r * ldm; std::fill(tm, tm + ldm, 0.0);
+    for (int64_t c = 0; c < v; ++c) for (int64_t d = 0; d <= c; ++d) {
+      tp[c * (c + 1) / 2 + d] = t[c * v + d] + t[d * v + c];
+      if (c > d) tm[c * (c - 1) / 2 + d] = t[c * v + d] - t[d * v + c];
+    }
+  }
+  return 0;
+}
+int dev_scatter_pm_rows(int64_t o, int64_t ncols, const double* Xp, const double* Xm, double* out) {
+  for (int64_t i = 0; i < o; ++i) for (int64_t j = 0; j <= i; ++j) for (int64_t c = 0; c < ncols; ++c) {
+    const double p = Xp[(i * (i + 1) / 2 + j) * ncols + c];
+    if (i > j) { const double m = Xm[(i * (i - 1) / 2 + j) * ncols + c]; out[(i * o + j) * ncols + c] = p + m; out[(j * o + i) * ncols + c] = p - m; }
+    else out[(i * o + j) * ncols + c] = p;
+  }
+  return 0;
+}
 int dev_ladder_pack_tau(int64_t o, int64_t v, const double* tau, double* Tp, int64_t ldp, double* Tm, int64_t ldm) {
   for (int64_t i = 0; i < o; ++i) for (int64_t j = 0; j <= i; ++j) {
     const double* t = tau + (i * o + j) * v * v;
