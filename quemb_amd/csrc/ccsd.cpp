@@ -205,9 +205,11 @@ int CcsdSolver::apply_ladder(const double* x, double* out) {
     int cfg, ks;
     QTRY(dev_timer_begin(TIMER_LADDER));
     pick_pair_gemm(npo, npv, cfg, ks);
+    if (cfg == 13 || cfg == 15) cfg += 10;      // same tiles under the ladder's own kernel symbol (profiles)
     QTRY(gemm(npo, npv, ldp, 1.0, LTp_, ldp, true, I_.Vp, ldp, true, 0.0, LRp_, ldp, 1, 0, 0, 0, cfg, ks));
     if (nmo > 0 && nmv > 0) {
       pick_pair_gemm(nmo, nmv, cfg, ks);
+      if (cfg == 13 || cfg == 15) cfg += 10;
       QTRY(gemm(nmo, nmv, ldm, 1.0, LTm_, ldm, true, I_.Vm, ldm, true, 0.0, LRm_, ldm, 1, 0, 0, 0, cfg, ks));
     }
     QTRY(dev_timer_end(TIMER_LADDER));

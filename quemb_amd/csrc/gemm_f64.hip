@@ -120,7 +120,9 @@ __device__ __forceinline__ void stage_store(const double (&reg)[NCH][VEC], doubl
   }
 }
 
-template <int WM, int WN, int WAVES_M, int WAVES_N, int BK, bool A_KC, bool B_KC, int VEC>
+// TAG does not change the code: it gives a call site its own kernel symbol so that profiles (rocprofv3 --stats, PMC) of the
+// pp-ladder are not mixed with other users of the same tile shape.
+template <int WM, int WN, int WAVES_M, int WAVES_N, int BK, bool A_KC, bool B_KC, int VEC, int TAG = 0>
 __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64, (WM * WN <= 16) ? 2 : 1)
     dgemm_mfma_kernel(GemmKArgs g) {
   constexpr int BM = WM * 16 * WAVES_M;
@@ -244,7 +246,7 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const double* __rest
 
 double* gemm_workspace(size_t bytes);   // dev_ops_hip.hip
 
-template <int WM, int WN, int WAVES_M, int WAVES_N, int BK, bool A_KC, bool B_KC, int VEC>
+template <int WM, int WN, int WAVES_M, int WAVES_N, int BK, bool A_KC, bool B_KC, int VEC, int TAG = 0>
 static int launch_cfg(const GemmDesc& d, hipStream_t s) {
   constexpr int BM = WM * 16 * WAVES_M, BN = WN * 16 * WAVES_N;
   using ImgA = LdsImage<BM, BK, A_KC>;
@@ -282,7 +284,7 @@ static int launch_cfg(const GemmDesc& d, hipStream_t s) {
     g.C = ws; g.ldc = d.N; g.strideC = d.M * d.N; g.alpha = 1.0; g.beta = 0.0;
   }
   const size_t lds = 2 * (size_t)(ImgA::SIZE + ImgB::SIZE) * sizeof(double);
-  auto kern = dgemm_mfma_kernel<WM, WN, WAVES_M, WAVES_N, BK, A_KC, B_KC, VEC>;
+  auto kern = dgemm_mfma_kernel<WM, WN, WAVES_M, WAVES_N, BK, A_KC, B_KC, VEC, TAG>;
   static bool attr_set = false;
   if (!attr_set) {
     HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -301,13 +303,13 @@ static int launch_cfg(const GemmDesc& d, hipStream_t s) {
   return QEMB_OK;
 }
 
-template <int WM, int WN, int WAVES_M, int WAVES_N, int BK>
+template <int WM, int WN, int WAVES_M, int WAVES_N, int BK, int TAG = 0>
 static int launch_layout(const GemmDesc& d, hipStream_t s, bool vec2) {
   const bool a = d.a_kcontig != 0, b = d.b_kcontig != 0;
 #define QEMB_GEMM_CASE(AK, BKC)                                                                \
   if (a == AK && b == BKC)                                                                      \
-    return vec2 ? launch_cfg<WM, WN, WAVES_M, WAVES_N, BK, AK, BKC, 2>(d, s)                     \
-                : launch_cfg<WM, WN, WAVES_M, WAVES_N, BK, AK, BKC, 1>(d, s);
+    return vec2 ? launch_cfg<WM, WN, WAVES_M, WAVES_N, BK, AK, BKC, 2, TAG>(d, s)                \
+                : launch_cfg<WM, WN, WAVES_M, WAVES_N, BK, AK, BKC, 1, TAG>(d, s);
   QEMB_GEMM_CASE(true, true)
   QEMB_GEMM_CASE(true, false)
   QEMB_GEMM_CASE(false, true)
@@ -392,6 +394,8 @@ int dev_gemm(const GemmDesc& d) {
     case 12: return launch_layout<4, 1, 1, 8, 16>(d, s, vec2);  //  64 x 128, 8 waves
     case 13: return launch_layout<7, 2, 2, 4, 16>(d, s, vec2);  // 224 x 128, 8 waves as 2 x 4: 9 LDS fragment reads per 14 MFMAs (15 for cfg 10)
     case 15: return launch_layout<6, 2, 2, 4, 16>(d, s, vec2);  // 192 x 128, 8 waves as 2 x 4 (the 190 antisymmetric pair rows of o = 20)
+    case 23: return launch_layout<7, 2, 2, 4, 16, 1>(d, s, vec2);   // = 13 under its own kernel symbol (pp-ladder, + pairs)
+    case 25: return launch_layout<6, 2, 2, 4, 16, 1>(d, s, vec2);   // = 15 under its own kernel symbol (pp-ladder, - pairs)
     default: set_error("dev_gemm: unknown tile config"); return QEMB_ERR_ARG;
   }
 }
