@@ -243,7 +243,7 @@ int CcsdSolver::update_amps(double* t1n, double* t2n) {
   QTRY(gemm_tn(o, v, o, -1.0, Loo_, t1, 1.0, t1n));                                // -(Foo'+Z)_ki t1[ka]
   QTRY(gemm_nt(o, o, v, 1.0, t1, Fov_, 0.0, Q_));                                  // Q[i,k] = t1[ic] Fov[kc]
   QTRY(gemm_nn(o, v, o, 1.0, Q_, t1, 1.0, t1n));                                   // Fov_kc t1[ic] t1[ka]
-  QTRY(dcopy(N2, T_, S_)); QTRY(axpby(N2, -1.0, Tp_, 2.0, S_));                    // Theta_ph = 2T - Tp
+  QTRY(lincomb2(N2, 2.0, T_, -1.0, Tp_, S_));                                      // Theta_ph = 2T - Tp
   QTRY(dev_gemv_rows(nov, nov, S_, nov, Fov_, t1n, 1.0, 1.0));                     // Fov_kc (2 t2[kica] - t2[ikca])
   QTRY(dev_gemv_rows(nov, nov, Lph1_, nov, t1, t1n, 1.0, 1.0));                    // (2 ovvo[kcai] - oovv[kiac]) t1[kc]
   QTRY(perm4(S_, t2, o, o, v, v, 0, 1, 3, 2, 2.0, 0.0)); QTRY(axpby(N2, -1.0, t2, 1.0, S_));  // Th[i,k,d,c] = 2 t2[ikcd] - t2[ikdc]
@@ -318,7 +318,7 @@ int CcsdSolver::update_amps(double* t1n, double* t2n) {
     d.alpha = alpha; d.beta = 1.0;
     return dev_outer4(d);
   };
-  QTRY(dcopy(N2, Tp_, S_)); QTRY(axpby(N2, 2.0, T_, -1.0, S_));                     // S = u = 2T - Tp   (kept for the update)
+  QTRY(lincomb2(N2, 2.0, T_, -1.0, Tp_, S_));                                      // S = u = 2T - Tp   (kept for the update)
   QTRY(dcopy(N2, S_, W12_)); QTRY(add_t1t1(W12_, -2.0));                           // W12 (scratch) = u~
   QTRY(dcopy(N2, W1base_, W1_));
   QTRY(gemm_nt(o * vv, o, v, 1.0, I_.ovvv, t1, 0.0, G1_));                         // G1[k,c,a,i] = ovvv[kcad] t1[id]
@@ -326,22 +326,22 @@ int CcsdSolver::update_amps(double* t1n, double* t2n) {
   QTRY(gemm(o, v, o, 1.0, I_.ovoo, o, false, t1, v, false, 0.0, G1_, v, nov, oo, 0, nov));   // G1[k,c,i,a] = ovoo[kcli] t1[la]
   QTRY(perm4(W1_, G1_, o, v, o, v, 2, 3, 0, 1, -1.0, 1.0));
   QTRY(gemm_nn(nov, nov, nov, 0.25, W12_, Lovov_, 1.0, W1_));                      // + 1/4 u~ L
-  QTRY(dcopy(N2, Tp_, W12_)); QTRY(add_t1t1(W12_, 2.0));                           // W12 (scratch) = Tp~
-  QTRY(gemm_nn(nov, nov, nov, 1.0, W12_, ovov_t_, 0.0, R_));                       // R (scratch) = Tp~ ovov_t
-  QTRY(axpby(N2, -0.25, R_, 1.0, W1_));
   //   W2[(ia),(kc)] = Wvovo[a,k,c,i]
   QTRY(dcopy(N2, W2base_, W2_));
   QTRY(gemm(o, vv, v, 1.0, t1, v, true, I_.ovvv, vv, false, 0.0, G1_, vv, o, 0, v * vv, o * vv));   // G1[k,i,a,c] = t1[id] ovvv[kdac]
   QTRY(perm4(W2_, G1_, o, o, v, v, 1, 2, 0, 3, 1.0, 1.0));
   QTRY(gemm_tn(v, v * oo, o, 1.0, t1, I_.ovoo, 0.0, G1_));                         // G1[a,c,k,i] = t1[la] ovoo[lcki]
   QTRY(perm4(W2_, G1_, v, v, o, o, 3, 0, 2, 1, -1.0, 1.0));
-  QTRY(axpby(N2, -0.5, R_, 1.0, W2_));
+  // The Tp~ ovov_t product enters Wvoov with -1/4 and Wvovo with -1/2, so it cancels in Wvoov - Wvovo/2: form that
+  // combination first (R), then let the GEMM accumulate the product straight into Wvovo.
+  QTRY(lincomb2(N2, 1.0, W1_, -0.5, W2_, R_));                                     // R = Wvoov - Wvovo/2
+  QTRY(dcopy(N2, Tp_, W12_)); QTRY(add_t1t1(W12_, 2.0));                           // W12 (scratch) = Tp~
+  QTRY(gemm_nn(nov, nov, nov, -0.5, W12_, ovov_t_, 1.0, W2_));                     // Wvovo -= 1/2 Tp~ ovov_t
   // Update, also two products:  (2 Wvoov - Wvovo) T - Wvoov Tp = (Wvoov - Wvovo/2) u - (Wvovo Tp)/2  with T = (u + Tp)/2
-  QTRY(gemm_nn(nov, nov, nov, 1.0, W2_, Tp_, 0.0, R_));                            // A3 = Wvovo[bkci] t2[kjac] at R[i,b,j,a]
-  QTRY(perm4(U_, R_, o, v, o, v, 0, 2, 3, 1, -1.0, 1.0));                          // U[i,j,a,b] -= A3[i,b,j,a]
-  QTRY(dcopy(N2, W1_, W12_)); QTRY(axpby(N2, -0.5, W2_, 1.0, W12_));               // Wvoov - Wvovo/2
-  QTRY(gemm_nn(nov, nov, nov, 1.0, W12_, S_, -0.5, R_));                           // R = (Wvoov - Wvovo/2) u - A3/2
-  QTRY(perm4(U_, R_, o, v, o, v, 0, 2, 1, 3, 1.0, 1.0));                           // R[i,a,j,b] -> U[i,j,a,b]
+  QTRY(gemm_nn(nov, nov, nov, 1.0, W2_, Tp_, 0.0, W1_));                           // A3 = Wvovo[bkci] t2[kjac] at W1[i,b,j,a]
+  QTRY(perm4(U_, W1_, o, v, o, v, 0, 2, 3, 1, -1.0, 1.0));                         // U[i,j,a,b] -= A3[i,b,j,a]
+  QTRY(gemm_nn(nov, nov, nov, 1.0, R_, S_, -0.5, W1_));                            // W1 = (Wvoov - Wvovo/2) u - A3/2
+  QTRY(perm4(U_, W1_, o, v, o, v, 0, 2, 1, 3, 1.0, 1.0));                          // [i,a,j,b] -> U[i,j,a,b]
   QTRY(dev_timer_end(TIMER_RINGS));
 
   // ---- symmetrise and divide
@@ -378,7 +378,7 @@ int CcsdSolver::iterate(double* e_corr, double* normt) {
     ++eager_iters_;
   }
   // diff = t_new - t (also the DIIS error vector: trial minus previously returned vector)
-  QTRY(dcopy(na, ampn_, diff_)); QTRY(axpby(na, -1.0, amp_, 1.0, diff_));
+  QTRY(lincomb2(na, 1.0, ampn_, -1.0, amp_, diff_));
   QTRY(dev_dot(na, diff_, diff_, scal_.p + 1));
   QTRY(dcopy(na, ampn_, amp_));
   if (!first_ && !diis_.empty()) QTRY(diis_[0].extrapolate(amp_, diff_));

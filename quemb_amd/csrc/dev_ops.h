@@ -97,6 +97,8 @@ struct Outer4Desc {
   double alpha, beta;
 };
 int dev_outer4(const Outer4Desc& c);
+// out = sum_{k < nterms} coef[k] * xs[k] + beta * out over n contiguous elements, one pass (nterms <= 8; out may alias any xs[k])
+int dev_lincomb(int64_t n, int nterms, const double* coef, const double* const* xs, double beta, double* out);
 
 // x[i0,i1,i2,i3] (contiguous, dims d0..d3) *= 1 / (ea[i0] + eb[i1] - ec[i2] - ed[i3])
 // (orbital-energy denominators; pass d1 = d3 = 1 with eb = ed = nullptr for t1)

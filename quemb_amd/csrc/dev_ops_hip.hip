@@ -443,6 +443,28 @@ int dev_mirror_lower(int64_t n, double* A, int64_t lda) {
   return QEMB_OK;
 }
 
+struct LincombK { const double* x[8]; double c[8]; int n; };
+__global__ void __launch_bounds__(256) lincomb_kernel(long long n, LincombK k, double beta, double* __restrict__ out) {
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
+    double acc = (beta != 0.0) ? beta * out[t] : 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) if (q < k.n) acc += k.c[q] * k.x[q][t];
+    out[t] = acc;
+  }
+}
+int dev_lincomb(int64_t n, int nterms, const double* coef, const double* const* xs, double beta, double* out) {
+  REQUIRE_INIT();
+  if (n <= 0) return QEMB_OK;
+  if (nterms < 0 || nterms > 8) { set_error("dev_lincomb: at most 8 terms"); return QEMB_ERR_ARG; }
+  LincombK k{};
+  k.n = nterms;
+  for (int q = 0; q < nterms; ++q) { k.x[q] = xs[q]; k.c[q] = coef[q]; }
+  const long long blocks = std::min<long long>((n + 255) / 256, 256 * 16);
+  hipLaunchKernelGGL(lincomb_kernel, dim3((unsigned)blocks), dim3(256), 0, g_stream, (long long)n, k, beta, out);
+  HIP_TRY(hipGetLastError());
+  return QEMB_OK;
+}
+
 // ---- pair-packed MO transformation helpers --------------------------------------------------------------------------
 __device__ __forceinline__ long long pair_idx(long long i, long long j);
 __device__ __forceinline__ void unpair_ge(long long p, long long& x, long long& y) {   // p = x(x+1)/2 + y, x >= y

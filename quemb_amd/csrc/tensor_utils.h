@@ -2,6 +2,7 @@
 // permutation / block extraction on top of dev_copy4, GEMM shorthands, and a device-resident DIIS.
 // Plain C++ over dev_ops.h (no HIP here).
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -62,6 +63,12 @@ inline int axpby(int64_t n, double alpha, const double* x, double beta, double* 
   return 0;
 }
 inline int dcopy(int64_t n, const double* x, double* y) { return axpby(n, 1.0, x, 0.0, y); }
+// out = a*x + b*y in one pass (out may alias x or y)
+inline int lincomb2(int64_t n, double a, const double* x, double b, const double* y, double* out) {
+  const double c[2] = {a, b};
+  const double* xs[2] = {x, y};
+  return dev_lincomb(n, 2, c, xs, 0.0, out);
+}
 
 // dst (contiguous, dims d[perm[0..3]]) = alpha * transpose(src, perm) + beta * dst;  src contiguous dims d
 inline int perm4(double* dst, const double* src, int64_t d0, int64_t d1, int64_t d2, int64_t d3, int p0, int p1, int p2,
@@ -172,7 +179,12 @@ class DeviceDIIS {
     rhs[0] = 1.0;
     if (!solve_dense(m + 1, A, rhs)) return 0;   // singular: keep the un-extrapolated vector
     for (int i = 0; i < m; ++i) if (!std::isfinite(rhs[i + 1])) return 0;
-    for (int i = 0; i < m; ++i) QTRY(axpby(n_, rhs[i + 1], xs_[i], i == 0 ? 0.0 : 1.0, x));
+    for (int i0 = 0; i0 < m; i0 += 8) {   // x = sum_i c_i x_i in one pass per eight vectors
+      const int cnt = std::min(8, m - i0);
+      double c[8]; const double* ps[8];
+      for (int q = 0; q < cnt; ++q) { c[q] = rhs[i0 + q + 1]; ps[q] = xs_[i0 + q].p; }
+      QTRY(dev_lincomb(n_, cnt, c, ps, i0 == 0 ? 0.0 : 1.0, x));
+    }
     return 0;
   }
   void reset() { count_ = 0; }

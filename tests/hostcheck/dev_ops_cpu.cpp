@@ -100,6 +100,10 @@ int dev_ladder_pack_vvvv(int64_t n, int64_t o, const double* M, double* Vp, int6
   return 0;
 }
 static inline int64_t pidx(int64_t i, int64_t j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
+int dev_lincomb(int64_t n, int nterms, const double* coef, const double* const* xs, double beta, double* out) {
+  for (int64_t t = 0; t < n; ++t) { double acc = beta != 0.0 ? beta * out[t] : 0.0; for (int q = 0; q < nterms; ++q) acc += coef[q] * xs[q][t]; out[t] = acc; }
+  return 0;
+}
 int dev_mirror_lower(int64_t n, double* A, int64_t lda) {
   for (int64_t r = 0; r < n; ++r) for (int64_t c = r + 1; c < n; ++c) A[r * lda + c] = A[c * lda + r];
   return 0;
