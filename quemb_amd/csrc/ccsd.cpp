@@ -311,10 +311,10 @@ int CcsdSolver::update_amps(double* t1n, double* t2n) {
   // (expand: 1/4 (2T - Tp)(2 ovov - ovov_t) = (T - Tp/2) ovov - T ovov_t / 2 + Tp ovov_t / 4, and the t1(x)t1 pieces
   // reproduce -ovov[ldkc] t1[id] t1[la] and -ovov[lckd] t1[id] t1[la]).
   auto add_t1t1 = [&](double* dst, double alpha) {
-    Outer4Desc d{};   // loop (i,l,d,a): u = t1[i,d], v = t1[l,a]; out dst[i,a,l,d]
+    Outer4Desc d{};   // loop (l,i,a,d), d fastest = contiguous in dst[i,a,l,d]: u = t1[l,a], v = t1[i,d]
     d.dim[0] = o; d.dim[1] = o; d.dim[2] = v; d.dim[3] = v;
     d.u = t1; d.su0 = v; d.su2 = 1; d.v = t1; d.sv1 = v; d.sv3 = 1;
-    d.out = dst; d.so[0] = v * o * v; d.so[1] = v; d.so[2] = 1; d.so[3] = o * v;
+    d.out = dst; d.so[0] = v; d.so[1] = v * o * v; d.so[2] = o * v; d.so[3] = 1;
     d.alpha = alpha; d.beta = 1.0;
     return dev_outer4(d);
   };

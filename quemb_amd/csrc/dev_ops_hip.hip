@@ -794,18 +794,20 @@ int dev_gemv_rows_batched(int64_t rows, int64_t cols, int64_t nbatch, const doub
   return QEMB_OK;
 }
 
-// partial[p][chunk][r] = sum_{m in chunk} x[m] * T[p][m][r];  threads run along r (contiguous)
-__global__ void __launch_bounds__(256) contract_mid_stage1(long long mid, long long inner, int nchunk, const double* T,
-                                                           const double* x, double* partial) {
+// partial[p][chunk][r] = sum_{m in chunk} x[m] * T[p][m][r];  threads run along r (contiguous), blockIdx.z tiles r
+__global__ void __launch_bounds__(256) contract_mid_stage1(long long mid, long long inner, int nchunk, const double* __restrict__ T,
+                                                           const double* __restrict__ x, double* __restrict__ partial) {
   const long long p = blockIdx.y;
   const int ch = blockIdx.x;
   const long long m_per = (mid + nchunk - 1) / nchunk;
   const long long m0 = ch * m_per, m1 = (m0 + m_per < mid) ? m0 + m_per : mid;
-  for (long long r = threadIdx.x; r < inner; r += blockDim.x) {
-    double acc = 0.0;
+  for (long long r = (long long)blockIdx.z * blockDim.x + threadIdx.x; r < inner; r += (long long)gridDim.z * blockDim.x) {
+    double a0 = 0.0, a1 = 0.0;
     const double* base = T + (p * mid) * inner + r;
-    for (long long m = m0; m < m1; ++m) acc += x[m] * base[m * inner];
-    partial[(p * nchunk + ch) * inner + r] = acc;
+    long long m = m0;
+    for (; m + 1 < m1; m += 2) { a0 += x[m] * base[m * inner]; a1 += x[m + 1] * base[(m + 1) * inner]; }
+    if (m < m1) a0 += x[m] * base[m * inner];
+    partial[(p * nchunk + ch) * inner + r] = a0 + a1;
   }
 }
 __global__ void __launch_bounds__(256) contract_mid_stage2(long long outer, long long inner, int nchunk, const double* partial,
@@ -823,10 +825,11 @@ int dev_contract_mid(int64_t outer, int64_t mid, int64_t inner, const double* T,
   if (outer <= 0 || inner <= 0) return QEMB_OK;
   if (outer > 65535) { set_error("dev_contract_mid: outer too large"); return QEMB_ERR_ARG; }
   // enough (p, chunk) workgroups to cover the chip: ~2048 in total, at least 8 rows of T per chunk
-  int nchunk = (int)std::max<int64_t>(1, std::min<int64_t>(mid / 8, std::max<int64_t>(1, 2048 / outer)));
+  const int64_t rblocks = std::min<int64_t>((inner + 255) / 256, 1024);
+  int nchunk = (int)std::max<int64_t>(1, std::min<int64_t>(mid / 8, std::max<int64_t>(1, (4096 + outer * rblocks - 1) / (outer * rblocks))));
   int rc = ensure_ws((size_t)outer * nchunk * inner * sizeof(double));
   if (rc) return rc;
-  hipLaunchKernelGGL(contract_mid_stage1, dim3(nchunk, (unsigned)outer), dim3(256), 0, g_stream, (long long)mid, (long long)inner, nchunk, T, x, g_ws);
+  hipLaunchKernelGGL(contract_mid_stage1, dim3(nchunk, (unsigned)outer, (unsigned)rblocks), dim3(256), 0, g_stream, (long long)mid, (long long)inner, nchunk, T, x, g_ws);
   const long long tot = outer * inner;
   hipLaunchKernelGGL(contract_mid_stage2, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, g_stream, (long long)outer, (long long)inner, nchunk, g_ws, Y, (long long)ldy, alpha, beta);
   HIP_TRY(hipGetLastError());
