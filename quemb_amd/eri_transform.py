@@ -187,6 +187,21 @@ def schmidt_decomp_svd(rdm, Frag_sites, thr_bath=1.0e-10, lib=None):
     return np.ascontiguousarray(TA[:, : nf + nb.value])
 
 
+def eigh(A, lib=None):
+    """Symmetric eigen-decomposition on the device (wavefront Jacobi): (w ascending, V columns)."""
+    from ._lib import DeviceBuffer
+    lib = lib or _lib.init()
+    A = _arr(A)
+    n = A.shape[0]
+    dA = DeviceBuffer(n * n, lib=lib); dA.upload(A)
+    dw, dV = DeviceBuffer(n, lib=lib), DeviceBuffer(n * n, lib=lib)
+    check(lib.qemb_op_jacobi_eigh(n, dA.ptr, dw.ptr, dV.ptr, None), "qemb_op_jacobi_eigh", lib)
+    w, V = dw.numpy((n,)), dV.numpy((n, n))
+    for b in (dA, dw, dV):
+        b.free()
+    return w, V
+
+
 def nsocc_guess(Cproj, lib=None):
     """Frags.get_nsocc core (molbe/pfrag.py:228-239): returns (P_, nsocc, mo_coeffs)."""
     lib = lib or _lib.init()

@@ -206,3 +206,9 @@ def test_octane_be3_density_matching_golden(qlib):
     assert opt.err < 1e-6
     assert abs(be.e_corr - (-0.5497021857717073)) < 2e-6
     assert abs(be.ebe_tot - (-310.3344717358742)) < 2e-6
+
+
+def test_periodic_front_end_matches_reference_goldens(qlib):
+    """kbe/pfrag.py:143-306 (k -> R Fourier, SVD Schmidt, cons_h1, get_nsocc) on the device against the reference's own outputs."""
+    from helpers import check_periodic_front_end
+    check_periodic_front_end(None)

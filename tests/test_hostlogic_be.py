@@ -300,3 +300,10 @@ def test_h8_chemical_potential_goldens_be2_be3(hlib):
         be = BE(mf, FragPart.from_json(GOLDEN / "fragmentation.json", key), lib=hlib, distribute=False)
         be.optimize(solver="CCSD", only_chem=True)
         assert abs(be.ebe_tot - target) < tol, (key, be.ebe_tot, target)
+
+
+def test_periodic_front_end_matches_reference_goldens(hlib):
+    """kbe front-end (kbe/pfrag.py:143-306, kbe/misc.py:24-34) against outputs of the reference's own functions on a synthetic
+    1-D periodic model (tests/golden/make_golden_kbe.py -> kbe.npz); see helpers.check_periodic_front_end."""
+    from helpers import check_periodic_front_end
+    check_periodic_front_end(hlib)
