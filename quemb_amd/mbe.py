@@ -169,8 +169,11 @@ class BE:
         return rets
 
     def optimize(self, solver="CCSD", method="QN", only_chem=False, use_cumulant=True, conv_tol=1.0e-6, relax_density=False,
-                 jac_solver="HF", nproc=1, ompnum=1, max_iter=500, trust_region=False, step_size=1e-6, solver_args=None):
-        """mbe.py:841-977."""
+                 jac_solver="HF", nproc=1, ompnum=1, max_iter=500, trust_region=False, step_size=1e-6, solver_args=None,
+                 warm_start=True):
+        """mbe.py:841-977.  `warm_start` (addition): every sweep after the first starts each fragment's CCSD from the
+        amplitudes of the previous sweep, which stay resident on the device (the reference restarts from MP2 at every
+        objective evaluation, solver.py:894-907); the converged amplitudes, hence all results, are the same."""
         from .opt import BEOPT
         from .jacobian import get_be_error_jacobian
         if solver != "CCSD":
@@ -190,7 +193,16 @@ class BE:
                                    world=self.world, opts=self.opts)
         if only_chem:
             J0 = J0[-1:, -1:]
-        be_.optimize(method, J0=J0, trust_region=trust_region)
+        saved_opts = self.opts
+        if warm_start:
+            from ._lib import SolverOpts
+            from .fragsolver import default_opts
+            self.opts = SolverOpts.from_buffer_copy(saved_opts) if saved_opts is not None else default_opts(self.lib)
+            self.opts.warm_start = 1
+        try:
+            be_.optimize(method, J0=J0, trust_region=trust_region)
+        finally:
+            self.opts = saved_opts
         self.pot = list(be_.pot)
         self.ebe_tot = be_.Ebe[0] + self.ebe_hf
         self.e_corr = be_.Ebe[0]
