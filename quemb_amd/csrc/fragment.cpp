@@ -214,12 +214,18 @@ int Fragment::solve(int o, const double* h, const double* dm0, const FragmentOpt
   if (opt.relax_density) {
     CcLambda lam(*cc_);
     QTRY(lam.setup());
+    if (opt.warm_start && z_prev_.p && z_prev_o_ == o) QTRY(lam.set_guess(z_prev_));
     bool lconv = false;
     QTRY(lam.kernel(opt.lam, &res->lambda_iters, &lconv));
     if (!lconv) { set_error("CCSD Lambda equations did not converge in max_cycle iterations"); return QEMB_ERR_NOCONV; }
     dm1r.assign((size_t)n2, 0.0);
     if (eeval) Imat.assign((size_t)n * nf_, 0.0);
     QTRY(lam.densities(dm1r.data(), eeval ? cc_->integrals().T34.p : nullptr, nf_, eeval ? Imat.data() : nullptr));
+    if (opt.keep_amplitudes || opt.warm_start) {
+      QTRY(z_prev_.alloc(lam.n_amp()));
+      QTRY(dcopy(lam.n_amp(), lam.z(), z_prev_));
+      z_prev_o_ = o;
+    }
   }
   // rdm1_mo = [[2 I, t1], [t1^T, 0]]  (shared/external/ccsd_rdm.py:10-20)
   if (rdm1_mo && opt.relax_density) {

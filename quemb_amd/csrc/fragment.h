@@ -72,6 +72,8 @@ class Fragment {
   DBuf C_, eps_, dm_, J_, K_;
   std::unique_ptr<CcsdSolver> cc_;
   DBuf t_prev_;   // warm-start amplitudes (t1 then t2)
+  DBuf z_prev_;   // warm-start Lambda multipliers (relax_density)
+  int z_prev_o_ = -1;
   int t_prev_o_ = -1;
 };
 
