@@ -138,6 +138,7 @@ int CcsdSolver::setup(MoIntegrals&& ints, const double* mo_energy_dev) {
     const int64_t npo = o * (o + 1) / 2, nmo = std::max<int64_t>(o * (o - 1) / 2, 1);
     QTRY(LTp_.alloc(npo * I_.ldp)); QTRY(LRp_.alloc(npo * I_.ldp)); QTRY(LTm_.alloc(nmo * I_.ldm)); QTRY(LRm_.alloc(nmo * I_.ldm));
     QTRY(Xp_.alloc(npo * nov)); QTRY(Xm_.alloc(nmo * nov));
+    QTRY(ZB_.alloc(N2)); QTRY(ZC_.alloc(N2));
   }
   first_ = true;
   return 0;
@@ -232,9 +233,26 @@ int CcsdSolver::update_amps(double* t1n, double* t2n) {
   QTRY(gemm_tn(v, v, oo * v, -1.0, tau_, Loovv_, 0.0, Fvv_));                      // Fvv'[a,c]
   QTRY(dev_gemv_rows(nov, nov, Lovov_, nov, t1, Fov_, 1.0, 0.0));                  // Fov[k,c]
   QTRY(dev_contract_mid(1, nov, oo, Lovoo_, t1, Z_, oo, 1.0, 0.0));                // Z[k,i]
-  QTRY(dev_contract_mid(1, nov, vv, I_.ovvv, t1, Y_, vv, 2.0, 0.0));               // Y[a,c] = 2 ovvv[kdac] t1[kd]
-  QTRY(dev_gemv_rows_batched(vv, v, o, I_.ovvv, v, v * vv, t1, v, Ytmp_, 1.0, 0.0));   // Ytmp[c,a] = ovvv[kcad] t1[kd]
-  QTRY(perm4(Y_, Ytmp_, 1, 1, v, v, 0, 1, 3, 2, -1.0, 1.0));                       // Y[a,c] -= Ytmp[c,a]
+  // The two t1-contractions of ovvv are formed ONCE per iteration (each is one pass over the 1.28 GB block) and serve the
+  // ring intermediates, the X1 term and -- through their k = i traces -- the Y intermediate:
+  QTRY(gemm_nt(o * vv, o, v, 1.0, I_.ovvv, t1, 0.0, ZB_));                         // ZB[k,c,a,i] = ovvv[kcad] t1[id]
+  QTRY(gemm(o, vv, v, 1.0, t1, v, true, I_.ovvv, vv, false, 0.0, ZC_, vv, o, 0, v * vv, o * vv));   // ZC[k,i,a,c] = t1[id] ovvv[kdac]
+  {  // Y[a,c] = 2 sum_k ZC[k,k,a,c] - sum_k ZB[k,c,a,k]
+    for (int64_t k0 = 0; k0 < o; k0 += 8) {
+      const int cnt = (int)std::min<int64_t>(8, o - k0);
+      double c[8]; const double* ps[8];
+      for (int q = 0; q < cnt; ++q) { c[q] = 2.0; ps[q] = ZC_.p + (k0 + q) * (o + 1) * vv; }
+      QTRY(dev_lincomb(vv, cnt, c, ps, k0 == 0 ? 0.0 : 1.0, Y_));
+    }
+    for (int64_t k = 0; k < o; ++k) {
+      Copy4Desc c{};   // loop (c,a): in ZB[k,c,a,k], out Y[a,c]
+      c.dim[0] = 1; c.dim[1] = 1; c.dim[2] = v; c.dim[3] = v;
+      c.in = ZB_.p + k * vv * o + k; c.si[2] = v * o; c.si[3] = o;
+      c.out = Y_; c.so[2] = 1; c.so[3] = v;
+      c.alpha = -1.0; c.beta = 1.0;
+      QTRY(dev_copy4(c));
+    }
+  }
   QTRY(dcopy(oo, Foo_, Loo_)); QTRY(axpby(oo, 1.0, Z_, 1.0, Loo_));                // Loo' = Foo' + Z
   QTRY(dcopy(vv, Fvv_, Lvv_)); QTRY(axpby(vv, 1.0, Y_, 1.0, Lvv_));                // Lvv' = Fvv' + Y
 
@@ -286,8 +304,7 @@ int CcsdSolver::update_amps(double* t1n, double* t2n) {
   }
   QTRY(gemm(v, v, o, -1.0, X_, v, false, t1, v, false, 1.0, U_, v, oo, nov, 0, vv));
   //   X1 = (ovvv[iacb] - oovv[kibc] t1[ka]) t1[jc]
-  QTRY(gemm_nt(o, o * vv, v, 1.0, t1, I_.ovvv, 0.0, G1_));                         // G1[j,i,a,b] = t1[jc] ovvv[i,a,b,c]
-  QTRY(perm4(U_, G1_, o, o, v, v, 1, 0, 2, 3, 1.0, 1.0));
+  QTRY(perm4(U_, ZB_, o, v, v, o, 0, 3, 1, 2, 1.0, 1.0));                          // U[i,j,a,b] += t1[jc] ovvv[i,a,b,c] = ZB[i,a,b,j]
   {  // oovv[k,i,b,c] = W2base[i,b,k,c]: G2[k,i,b,j] = oovv[(kib),c] t1[jc] needs the oovv layout -> rebuild it
     QTRY(perm4(G1_, W2base_, o, v, o, v, 2, 0, 1, 3));                             // G1 = oovv[k,i,b,c]
     QTRY(gemm_nt(oo * v, o, v, 1.0, G1_, t1, 0.0, G2_));                           // G2[k,i,b,j]
@@ -321,15 +338,13 @@ int CcsdSolver::update_amps(double* t1n, double* t2n) {
   QTRY(lincomb2(N2, 2.0, T_, -1.0, Tp_, S_));                                      // S = u = 2T - Tp   (kept for the update)
   QTRY(dcopy(N2, S_, W12_)); QTRY(add_t1t1(W12_, -2.0));                           // W12 (scratch) = u~
   QTRY(dcopy(N2, W1base_, W1_));
-  QTRY(gemm_nt(o * vv, o, v, 1.0, I_.ovvv, t1, 0.0, G1_));                         // G1[k,c,a,i] = ovvv[kcad] t1[id]
-  QTRY(perm4(W1_, G1_, o, v, v, o, 3, 2, 0, 1, 1.0, 1.0));
+  QTRY(perm4(W1_, ZB_, o, v, v, o, 3, 2, 0, 1, 1.0, 1.0));                         // + ovvv[kcad] t1[id]
   QTRY(gemm(o, v, o, 1.0, I_.ovoo, o, false, t1, v, false, 0.0, G1_, v, nov, oo, 0, nov));   // G1[k,c,i,a] = ovoo[kcli] t1[la]
   QTRY(perm4(W1_, G1_, o, v, o, v, 2, 3, 0, 1, -1.0, 1.0));
   QTRY(gemm_nn(nov, nov, nov, 0.25, W12_, Lovov_, 1.0, W1_));                      // + 1/4 u~ L
   //   W2[(ia),(kc)] = Wvovo[a,k,c,i]
   QTRY(dcopy(N2, W2base_, W2_));
-  QTRY(gemm(o, vv, v, 1.0, t1, v, true, I_.ovvv, vv, false, 0.0, G1_, vv, o, 0, v * vv, o * vv));   // G1[k,i,a,c] = t1[id] ovvv[kdac]
-  QTRY(perm4(W2_, G1_, o, o, v, v, 1, 2, 0, 3, 1.0, 1.0));
+  QTRY(perm4(W2_, ZC_, o, o, v, v, 1, 2, 0, 3, 1.0, 1.0));                         // + t1[id] ovvv[kdac]
   QTRY(gemm_tn(v, v * oo, o, 1.0, t1, I_.ovoo, 0.0, G1_));                         // G1[a,c,k,i] = t1[la] ovoo[lcki]
   QTRY(perm4(W2_, G1_, v, v, o, o, 3, 0, 2, 1, -1.0, 1.0));
   // The Tp~ ovov_t product enters Wvoov with -1/4 and Wvovo with -1/2, so it cancels in Wvoov - Wvovo/2: form that

@@ -72,6 +72,7 @@ class CcsdSolver {
   DBuf tau_, T_, Tp_, S_, W1_, W2_, W12_, R_, U_, G1_, G2_;
   DBuf LTp_, LTm_, LRp_, LRm_;   // (+/-) packed ladder: tau combinations and results
   DBuf Xp_, Xm_;                 // (+/-) packed rows of X[i,j,k,a] = tau[ijcd] ovvv[kdac]
+  DBuf ZB_, ZC_;                 // ZB[k,c,a,i] = ovvv[kcad] t1[id],  ZC[k,i,a,c] = t1[id] ovvv[kdac]  (one ovvv pass each per iteration)
   DBuf Foo_, Fvv_, Fov_, Z_, Y_, Ytmp_, Loo_, Lvv_, Q_, Wo_, O1_, X_, scal_;
   std::vector<DeviceDIIS> diis_;
   bool first_ = true;
