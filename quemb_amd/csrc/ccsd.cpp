@@ -36,12 +36,13 @@ namespace qemb {
 // ------------------------------------------------------------------------------------------------------------
 int64_t mo_transform_work(int n) { return (int64_t)n * n * ((int64_t)n * (n + 1) / 2); }
 
-int mo_transform(int n, int o, int nf, const double* eri_s4, double* X0, double* X1, const double* C, MoIntegrals& out, bool build_Vl, bool build_T34) {
+int mo_transform(int n, int o, int nf, const double* eri_s4, double* X0, double* X1, const double* C, MoIntegrals& out, bool build_Vl, bool build_T34,
+                 bool x1_is_unpacked) {
   const int v = n - o;
   const int64_t np = (int64_t)n * (n + 1) / 2, ncol = np * n;
   out.n = n; out.o = o; out.v = v; out.nf = nf;
   QTRY(dev_timer_begin(TIMER_AO2MO));
-  QTRY(dev_unpack_tril_rows(np, n, eri_s4, X1));
+  if (!x1_is_unpacked) QTRY(dev_unpack_tril_rows(np, n, eri_s4, X1));   // (the fragment RHF already built it for its exchange matrix)
   QTRY(gemm(n, ncol, n, 1.0, C, n, false, X1, n, true, 0.0, X0, ncol));
   QTRY(gemm(n, ncol, n, 1.0, C, n, false, X0, n, true, 0.0, X1, ncol));
   QTRY(dev_pack_pair_rows(n, np, X1, X0));

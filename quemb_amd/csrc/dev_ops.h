@@ -108,6 +108,10 @@ int dev_div_denom(double* x, int64_t d0, int64_t d1, int64_t d2, int64_t d3,
 // A[r][c] = A[c][r] for r < c  (n x n, leading dimension lda): completes a matrix whose lower triangle was computed
 int dev_mirror_lower(int64_t n, double* A, int64_t lda);
 
+// K[p,r] = sum_{q,s} (pq|rs) D[q,s] from the half-unpacked tensor H[P(p,q)][r][s] (p >= q rows only, npair(n) x n x n):
+// row (p,q) feeds K[p,:] with D[q,:] and, for p != q, K[q,:] with D[p,:].  Deterministic (per-row partials, fixed-order sum).
+int dev_k_from_pairs(int64_t n, const double* H, const double* D, double* K);
+
 // ---- pair-packed MO transformation helpers ---------------------------------------------------------------------------
 // out[P(x,y), c] = in[(x*n + y), c] for x >= y  (row gather of an (n*n) x ncols matrix; ncols-long rows)
 int dev_pack_pair_rows(int64_t n, int64_t ncols, const double* in, double* out);

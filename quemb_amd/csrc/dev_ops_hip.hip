@@ -836,6 +836,46 @@ int dev_contract_mid(int64_t outer, int64_t mid, int64_t inner, const double* T,
   return QEMB_OK;
 }
 
+// exchange matrix from pair rows: stage 1 = per-row partial vectors, stage 2 = fixed-order sum over the rows that feed K[p,:]
+__global__ void __launch_bounds__(256) k_pairs_stage1(long long n, const double* __restrict__ H, const double* __restrict__ D,
+                                                      double* __restrict__ P1, double* __restrict__ P2) {
+  extern __shared__ double sd[];            // D[q,:], D[p,:]
+  const long long pq = blockIdx.x;
+  long long p, q; unpair_ge(pq, p, q);
+  for (long long s = threadIdx.x; s < n; s += blockDim.x) { sd[s] = D[q * n + s]; sd[n + s] = D[p * n + s]; }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const double* X = H + pq * n * n;
+  for (long long r = wave; r < n; r += nw) {
+    const double* row = X + r * n;
+    double a1 = 0.0, a2 = 0.0;
+    for (long long s = lane; s < n; s += 64) { const double x = row[s]; a1 += x * sd[s]; a2 += x * sd[n + s]; }
+    a1 = wave_sum(a1); a2 = wave_sum(a2);
+    if (lane == 0) { P1[pq * n + r] = a1; P2[pq * n + r] = a2; }
+  }
+}
+__global__ void __launch_bounds__(256) k_pairs_stage2(long long n, const double* __restrict__ P1, const double* __restrict__ P2, double* __restrict__ K) {
+  const long long p = blockIdx.x;
+  for (long long r = threadIdx.x; r < n; r += blockDim.x) {
+    double acc = 0.0;
+    for (long long q = 0; q <= p; ++q) acc += P1[(p * (p + 1) / 2 + q) * n + r];
+    for (long long q = p + 1; q < n; ++q) acc += P2[(q * (q + 1) / 2 + p) * n + r];
+    K[p * n + r] = acc;
+  }
+}
+int dev_k_from_pairs(int64_t n, const double* H, const double* D, double* K) {
+  REQUIRE_INIT();
+  if (n <= 0) return QEMB_OK;
+  const long long np = n * (n + 1) / 2;
+  int rc = ensure_ws((size_t)2 * np * n * sizeof(double));
+  if (rc) return rc;
+  double* P1 = g_ws; double* P2 = g_ws + np * n;
+  hipLaunchKernelGGL(k_pairs_stage1, dim3((unsigned)np), dim3(256), (size_t)2 * n * sizeof(double), g_stream, (long long)n, H, D, P1, P2);
+  hipLaunchKernelGGL(k_pairs_stage2, dim3((unsigned)n), dim3(256), 0, g_stream, (long long)n, (const double*)P1, (const double*)P2, K);
+  HIP_TRY(hipGetLastError());
+  return QEMB_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // packed-pair transforms.  pair(i,j) = i(i+1)/2 + j, i >= j  (reference shared/helper.py:260-276)
 // ------------------------------------------------------------------------------------------------

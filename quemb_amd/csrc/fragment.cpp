@@ -51,8 +51,8 @@ int Fragment::hf_veff_from_dm(const double* P_host, double* J_host, double* K_ho
   if (!eri_s4_.p) { set_error("Fragment: ERIs not set"); return QEMB_ERR_ARG; }
   const int64_t n2 = (int64_t)n_ * n_;
   DBuf X0, P, J, K;
-  QTRY(X0.alloc(n2 * n2)); QTRY(P.alloc(n2)); QTRY(J.alloc(n2)); QTRY(K.alloc(n2));
-  QTRY(dev_unpack_s4(n_, eri_s4_, X0));
+  QTRY(X0.alloc(mo_transform_work(n_))); QTRY(P.alloc(n2)); QTRY(J.alloc(n2)); QTRY(K.alloc(n2));
+  QTRY(dev_unpack_tril_rows(npair(n_), n_, eri_s4_, X0));
   QTRY(dev_h2d(P, P_host, sizeof(double) * n2));
   QTRY(build_jk(n_, X0, P, J, K, eri_s4_));
   QTRY(dev_d2h(J_host, J, sizeof(double) * n2));
@@ -66,8 +66,8 @@ int Fragment::scf_only(int o, const double* h, const double* dm0, const ScfOptio
   if (o <= 0 || o > n_) { set_error("Fragment: need 0 < nsocc <= n"); return QEMB_ERR_ARG; }
   const int64_t n2 = (int64_t)n_ * n_;
   DBuf X0;
-  QTRY(X0.alloc(n2 * n2));
-  QTRY(dev_unpack_s4(n_, eri_s4_, X0));
+  QTRY(X0.alloc(mo_transform_work(n_)));
+  QTRY(dev_unpack_tril_rows(npair(n_), n_, eri_s4_, X0));     // half-unpacked [P(p,q)][r][s]
   QTRY(run_scf(o, h, dm0, opt, X0, sres));
   if (mo_coeff) QTRY(dev_d2h(mo_coeff, C_, sizeof(double) * n2));
   if (mo_energy) QTRY(dev_d2h(mo_energy, eps_, sizeof(double) * n_));
@@ -87,17 +87,17 @@ int Fragment::cphf_response(int o, const double* h, const double* dm0, const Scf
   const int n = n_, v = n - o;
   const int64_t n2 = (int64_t)n * n, nov = (int64_t)o * v;
   DBuf X0, X1;
-  QTRY(X0.alloc(n2 * n2));
-  QTRY(dev_unpack_s4(n, eri_s4_, X0));
+  QTRY(X1.alloc(mo_transform_work(n)));
+  QTRY(dev_unpack_tril_rows(npair(n), n, eri_s4_, X1));
   ScfResult sres;
-  QTRY(run_scf(o, h, dm0, opt, X0, &sres));
+  QTRY(run_scf(o, h, dm0, opt, X1, &sres));
   if (!sres.converged) { set_error("cphf_response: fragment SCF did not converge"); return QEMB_ERR_NOCONV; }
   std::vector<double> C((size_t)n2), eps((size_t)n);
   QTRY(dev_d2h(C.data(), C_, sizeof(double) * n2));
   QTRY(dev_d2h(eps.data(), eps_, sizeof(double) * n));
-  QTRY(X1.alloc(mo_transform_work(n)));
+  QTRY(X0.alloc(mo_transform_work(n)));
   MoIntegrals ints;
-  QTRY(mo_transform(n, o, 0, eri_s4_, X0, X1, C_, ints));
+  QTRY(mo_transform(n, o, 0, eri_s4_, X0, X1, C_, ints, false, false, /*x1_is_unpacked=*/true));
   X0.release(); X1.release();
   DBuf A, L, Linv, d;
   QTRY(A.alloc(nov * nov)); QTRY(d.alloc(nov));
@@ -147,17 +147,16 @@ int Fragment::cphf_response(int o, const double* h, const double* dm0, const Scf
 int Fragment::prepare_ccsd(int o, const double* h, const double* dm0, const FragmentOptions& opt) {
   if (!eri_s4_.p) { set_error("Fragment: ERIs not set"); return QEMB_ERR_ARG; }
   if (o <= 0 || o >= n_) { set_error("Fragment: need 0 < nsocc < n"); return QEMB_ERR_ARG; }
-  const int64_t n2 = (int64_t)n_ * n_;
   cc_.reset();
   DBuf X0, X1;
-  QTRY(X0.alloc(n2 * n2));
-  QTRY(dev_unpack_s4(n_, eri_s4_, X0));
-  ScfResult sres;
-  QTRY(run_scf(o, h, dm0, opt.scf, X0, &sres));
-  if (!sres.converged) { set_error("fragment SCF did not converge (also not with level shift 0.2)"); return QEMB_ERR_NOCONV; }
   QTRY(X1.alloc(mo_transform_work(n_)));
+  QTRY(dev_unpack_tril_rows(npair(n_), n_, eri_s4_, X1));
+  ScfResult sres;
+  QTRY(run_scf(o, h, dm0, opt.scf, X1, &sres));
+  if (!sres.converged) { set_error("fragment SCF did not converge (also not with level shift 0.2)"); return QEMB_ERR_NOCONV; }
+  QTRY(X0.alloc(mo_transform_work(n_)));
   MoIntegrals ints;
-  QTRY(mo_transform(n_, o, nf_, eri_s4_, X0, X1, C_, ints, /*build_Vl=*/true));   // measurement hook: dense block available for export
+  QTRY(mo_transform(n_, o, nf_, eri_s4_, X0, X1, C_, ints, /*build_Vl=*/true, false, /*x1_is_unpacked=*/true));   // measurement hook: dense block available for export
   X0.release(); X1.release();
   cc_.reset(new CcsdSolver());
   QTRY(cc_->setup(std::move(ints), eps_));
@@ -177,21 +176,22 @@ int Fragment::solve(int o, const double* h, const double* dm0, const FragmentOpt
   const int n = n_, v = n - o;
   const int64_t n2 = (int64_t)n * n;
   cc_.reset();
-  // ---- fragment RHF on the full n^4 tensor (kept for the MO transformation)
+  // ---- fragment RHF on the half-unpacked tensor [P(p,q)][r][s] (kept: it is the first operand of the MO transformation)
   DBuf X0, X1;
-  QTRY(X0.alloc(n2 * n2));
-  QTRY(dev_unpack_s4(n, eri_s4_, X0));
+  QTRY(X1.alloc(mo_transform_work(n)));
+  QTRY(dev_unpack_tril_rows(npair(n), n, eri_s4_, X1));
   ScfResult sres;
-  QTRY(run_scf(o, h, dm0, opt.scf, X0, &sres));
+  QTRY(run_scf(o, h, dm0, opt.scf, X1, &sres));
   res->scf_converged = sres.converged; res->scf_cycles = sres.cycles; res->e_scf = sres.e_tot;
   if (!sres.converged) { set_error("fragment SCF did not converge (also not with level shift 0.2)"); return QEMB_ERR_NOCONV; }
   std::vector<double> C((size_t)n2), eps((size_t)n), J((size_t)n2), K((size_t)n2);
   QTRY(dev_d2h(C.data(), C_, sizeof(double) * n2));
   QTRY(dev_d2h(eps.data(), eps_, sizeof(double) * n));
   // ---- integrals + CCSD
-  QTRY(X1.alloc(mo_transform_work(n)));
+  QTRY(X0.alloc(mo_transform_work(n)));
   MoIntegrals ints;
-  QTRY(mo_transform(n, o, eeval ? nf_ : 0, eri_s4_, X0, X1, C_, ints, /*build_Vl=*/false, /*build_T34=*/opt.relax_density != 0));
+  QTRY(mo_transform(n, o, eeval ? nf_ : 0, eri_s4_, X0, X1, C_, ints, /*build_Vl=*/false, /*build_T34=*/opt.relax_density != 0,
+                    /*x1_is_unpacked=*/true));
   X0.release(); X1.release();
   cc_.reset(new CcsdSolver());
   QTRY(cc_->setup(std::move(ints), eps_));

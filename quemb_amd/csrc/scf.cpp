@@ -30,8 +30,10 @@ int build_jk(int n, const double* eri, const double* dm, double* J, double* K, c
   } else if (J) {
     QTRY(dev_gemv_rows(n2, n2, eri, n2, dm, J, 1.0, 0.0));
   }
-  // K[p,r] = sum_{q,s} D[q,s] (pq|sr): treat eri as [p][(q,s)][r]
-  if (K) QTRY(dev_contract_mid(n, n2, n, eri, dm, K, n, 1.0, 0.0));
+  // K[p,r] = sum_{q,s} D[q,s] (pq|sr).  With eri_s4 given, `eri` is the half-unpacked tensor [P(p,q)][r][s] (half the bytes
+  // of the n^4 tensor, and the very operand the MO transformation starts from); otherwise the full s1 tensor [p][(q,s)][r].
+  if (K && eri_s4) QTRY(dev_k_from_pairs(n, eri, dm, K));
+  else if (K) QTRY(dev_contract_mid(n, n2, n, eri, dm, K, n, 1.0, 0.0));
   return 0;
 }
 

@@ -21,8 +21,9 @@ struct ScfResult {
   int cycles = 0;
 };
 
-// J[p,q] = (pq|rs) D[r,s],  K[p,r] = (pq|rs) D[q,s]   from the full n^4 tensor (HBM bound).  With eri_s4 (the resident
-// npair x npair block) J is contracted from the packed form instead: a quarter of the bytes.
+// J[p,q] = (pq|rs) D[r,s],  K[p,r] = (pq|rs) D[q,s]   (HBM bound).  Without eri_s4: `eri_s1` is the full n^4 tensor.  With
+// eri_s4 (the resident npair x npair block): J is contracted from the packed form (a quarter of the bytes) and `eri_s1` must be
+// the HALF-unpacked tensor [P(p,q)][r][s] (npair x n x n, half the bytes), from which K is built row pair by row pair.
 int build_jk(int n, const double* eri_s1, const double* dm, double* J, double* K, const double* eri_s4 = nullptr);
 
 // h, dm (in: guess, out: converged density), C, eps: device buffers (n*n, n*n, n*n, n).

@@ -108,6 +108,19 @@ int dev_mirror_lower(int64_t n, double* A, int64_t lda) {
   for (int64_t r = 0; r < n; ++r) for (int64_t c = r + 1; c < n; ++c) A[r * lda + c] = A[c * lda + r];
   return 0;
 }
+int dev_k_from_pairs(int64_t n, const double* H, const double* D, double* K) {
+  std::fill(K, K + n * n, 0.0);
+  for (int64_t p = 0; p < n; ++p) for (int64_t q = 0; q <= p; ++q) {
+    const double* X = H + pidx(p, q) * n * n;
+    for (int64_t r = 0; r < n; ++r) {
+      double a1 = 0.0, a2 = 0.0;
+      for (int64_t s = 0; s < n; ++s) { a1 += X[r * n + s] * D[q * n + s]; a2 += X[r * n + s] * D[p * n + s]; }
+      K[p * n + r] += a1;
+      if (p != q) K[q * n + r] += a2;
+    }
+  }
+  return 0;
+}
 int dev_pack_pair_rows(int64_t n, int64_t ncols, const double* in, double* out) {
   for (int64_t x = 0; x < n; ++x) for (int64_t y = 0; y <= x; ++y) std::copy(in + (x * n + y) * ncols, in + (x * n + y + 1) * ncols, out + pidx(x, y) * ncols);
   return 0;
