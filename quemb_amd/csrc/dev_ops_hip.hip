@@ -657,24 +657,49 @@ int dev_scatter_pm_rows(int64_t o, int64_t ncols, const double* Xp, const double
   HIP_TRY(hipGetLastError());
   return QEMB_OK;
 }
-// grid (v, npair(o)): block = (pair ij, row a); threads over b <= a.  Writes rows [i,j,a,:], [j,i,a,:] coalesced and
-// the transposed elements [i,j,b,a], [j,i,b,a] strided (L2-resident t2, 128 MB).
+// grid (lower-triangle 32 x 32 tiles of (a,b), npair(o)): the tile of R+/R- is staged through LDS so that both the [a][b] image
+// and its mirror [b][a] are updated in 256-byte runs, for t2[i,j] and t2[j,i].
 __global__ void __launch_bounds__(256) ladder_scatter_pm_kernel(long long o, long long v, const double* __restrict__ Rp, long long ldp,
                                                                const double* __restrict__ Rm, long long ldm, double* __restrict__ t2) {
-  const long long ij = blockIdx.y, a = blockIdx.x;
+  __shared__ double sp[32][33], sm[32][33];
+  const long long ij = blockIdx.y;
   long long i, j; unpair_ge(ij, i, j);
-  const double* rp = Rp + ij * ldp + a * (a + 1) / 2;
-  const double* rm = (i > j && a > 0) ? Rm + (i * (i - 1) / 2 + j) * ldm + a * (a - 1) / 2 : nullptr;
+  long long t = blockIdx.x, ta, tb; unpair_ge(t, ta, tb);            // tile row >= tile column
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const double* rp = Rp + ij * ldp;
+  const double* rm = (i > j) ? Rm + (i * (i - 1) / 2 + j) * ldm : nullptr;
   double* tij = t2 + (i * o + j) * v * v;
   double* tji = t2 + (j * o + i) * v * v;
-  for (long long b = threadIdx.x; b <= a; b += blockDim.x) {
-    const double p = rp[b];
-    const double m = (rm && b < a) ? rm[b] : 0.0;
-    tij[a * v + b] += p + m;
-    if (b != a) tij[b * v + a] += p - m;
-    if (i != j) {
-      tji[a * v + b] += p - m;
-      if (b != a) tji[b * v + a] += p + m;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int aa = ty + 8 * k;
+    const long long a = ta * 32 + aa, b = tb * 32 + tx;
+    double p = 0.0, m = 0.0;
+    if (a < v && b <= a) {
+      p = rp[a * (a + 1) / 2 + b];
+      if (rm && b < a) m = rm[a * (a - 1) / 2 + b];
+    }
+    sp[aa][tx] = p; sm[aa][tx] = m;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int aa = ty + 8 * k;
+    {  // image [a][b], b <= a
+      const long long a = ta * 32 + aa, b = tb * 32 + tx;
+      if (a < v && b <= a) {
+        const double p = sp[aa][tx], m = sm[aa][tx];
+        tij[a * v + b] += p + m;
+        if (i != j) tji[a * v + b] += p - m;
+      }
+    }
+    {  // mirror [b][a], b < a: destination row r = tb*32 + aa, column c = ta*32 + tx holds the element (a = c, b = r)
+      const long long r = tb * 32 + aa, c = ta * 32 + tx;
+      if (c < v && r < c) {
+        const double p = sp[tx][aa], m = sm[tx][aa];
+        tij[r * v + c] += p - m;
+        if (i != j) tji[r * v + c] += p + m;
+      }
     }
   }
 }
@@ -683,7 +708,8 @@ int dev_ladder_scatter_pm(int64_t o, int64_t v, const double* Rp, int64_t ldp, c
   const long long npo = o * (o + 1) / 2;
   if (npo <= 0 || v <= 0) return QEMB_OK;
   if (npo > 65535) { set_error("dev_ladder_scatter_pm: too many pairs"); return QEMB_ERR_ARG; }
-  hipLaunchKernelGGL(ladder_scatter_pm_kernel, dim3((unsigned)v, (unsigned)npo), dim3(256), 0, g_stream, (long long)o, (long long)v, Rp, (long long)ldp, Rm, (long long)ldm, t2);
+  const long long nt = (v + 31) / 32;
+  hipLaunchKernelGGL(ladder_scatter_pm_kernel, dim3((unsigned)(nt * (nt + 1) / 2), (unsigned)npo), dim3(256), 0, g_stream, (long long)o, (long long)v, Rp, (long long)ldp, Rm, (long long)ldm, t2);
   HIP_TRY(hipGetLastError());
   return QEMB_OK;
 }
