@@ -81,3 +81,10 @@ def test_generated_program_matches_the_oracle_tape():
             val2[s[1]] += s[2] * np.einsum("abcd,ijcd->ijab", Vl, val2[s[3]])
     assert np.abs(val2["t1_bar"] - val["t1_bar"]).max() < 1e-13 and np.abs(val2["t2_bar"] - val["t2_bar"]).max() < 1e-13
 
+
+
+def test_committed_program_is_the_generator_output(tmp_path):
+    """quemb_amd/csrc/cc_lambda_program.inc is generated; it must be exactly what tools/gen_cc_lambda.py emits."""
+    out = tmp_path / "prog.inc"
+    gen.emit(str(out))
+    assert out.read_text() == (ROOT / "quemb_amd" / "csrc" / "cc_lambda_program.inc").read_text()
