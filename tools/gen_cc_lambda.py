@@ -111,15 +111,25 @@ es("X", 1, "ijcd,kdac->ijka", "tau", "ovvv")              # t1 dressing of Wvvvv
 es("U", -1, "ijka,kb->ijab", "X", "t1")
 es("U", 1, "ac,ijcb->ijab", "Lvv", "t2")
 es("U", -1, "ki,kjab->ijab", "Loo", "t2")
-# ring intermediates: T2a = t2 + 2 t1 t1 in the [i,l,d,a] order of the products below
-perm("T2a", 1, "ilda->ilda", "t2"); es("T2a", 2, "id,la->ilda", "t1", "t1")
-perm("Wvoov", 1, "kcai->akic", "ovvo"); es("Wvoov", 1, "kcad,id->akic", "ovvv", "t1"); es("Wvoov", -1, "kcli,la->akic", "ovoo", "t1")
-es("Wvoov", -0.5, "ldkc,ilda->akic", "ovov", "T2a"); es("Wvoov", 0.5, "ldkc,ilad->akic", "Lovov", "t2")
-perm("Wvovo", 1, "kiac->akci", "oovv"); es("Wvovo", 1, "kdac,id->akci", "ovvv", "t1"); es("Wvovo", -1, "lcki,la->akci", "ovoo", "t1")
-es("Wvovo", -0.5, "lckd,ilda->akci", "ovov", "T2a")
-es("U", 2, "akic,kjcb->ijab", "Wvoov", "t2"); es("U", -1, "akci,kjcb->ijab", "Wvovo", "t2")
-es("U", -1, "akic,kjbc->ijab", "Wvoov", "t2")
-es("U", -1, "bkci,kjac->ijab", "Wvovo", "t2")
+# ring terms with FOUR (ov)^3 products (the factorisation of CcsdSolver::update_amps): in the ph layouts
+#   Tph[i,a,l,d] = t2[i,l,a,d], Tpp[i,a,l,d] = t2[i,l,d,a], u = 2 Tph - Tpp, u~ = u - 2 t1(x)t1, Tp~ = Tpp + 2 t1(x)t1,
+#   W1[i,a,k,c] = Wvoov[a,k,i,c] = base + 1/4 u~ L - 1/4 P,  W2[i,a,k,c] = Wvovo[a,k,c,i] = base - 1/2 P,  P = Tp~ ovov_t,
+#   update = (W1 - W2/2) u - 1/2 A3 (as [i,a,j,b]) and -A3 (as [i,b,j,a]),  A3 = W2 Tpp.
+perm("Tph", 1, "ilad->iald", "t2"); perm("Tpp", 1, "ilda->iald", "t2")
+perm("uph", 2, "iald->iald", "Tph"); perm("uph", -1, "iald->iald", "Tpp")
+perm("ut", 1, "iald->iald", "uph"); es("ut", -2, "id,la->iald", "t1", "t1")
+perm("Tpt", 1, "iald->iald", "Tpp"); es("Tpt", 2, "id,la->iald", "t1", "t1")
+perm("ovov_t", 1, "lckd->ldkc", "ovov")
+es("P", 1, "iald,ldkc->iakc", "Tpt", "ovov_t")
+perm("W1", 1, "kcai->iakc", "ovvo"); es("W1", 1, "kcad,id->iakc", "ovvv", "t1"); es("W1", -1, "kcli,la->iakc", "ovoo", "t1")
+es("W1", 0.25, "iald,ldkc->iakc", "ut", "Lovov"); perm("W1", -0.25, "iakc->iakc", "P")
+perm("W2", 1, "kiac->iakc", "oovv"); es("W2", 1, "kdac,id->iakc", "ovvv", "t1"); es("W2", -1, "lcki,la->iakc", "ovoo", "t1")
+perm("W2", -0.5, "iakc->iakc", "P")
+perm("Wc", 1, "iakc->iakc", "W1"); perm("Wc", -0.5, "iakc->iakc", "W2")
+es("A3", 1, "ibkc,kcja->ibja", "W2", "Tpp")
+perm("U", -1, "ibja->ijab", "A3")
+es("Rf", 1, "iakc,kcjb->iajb", "Wc", "uph"); perm("Rf", -0.5, "iajb->iajb", "A3")
+perm("U", 1, "iajb->ijab", "Rf")
 perm("n2", 1, "ijab->ijab", "U"); perm("n2", 1, "jiba->ijab", "U")
 # ---- energy (only its cotangents are used: E_bar = 1)
 ENERGY = [("es", "E", 2.0, "ia,ia->", "fov", "t1"), ("es", "E", 1.0, "ijab,iajb->", "tau", "Lovov")]
