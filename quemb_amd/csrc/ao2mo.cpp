@@ -53,13 +53,14 @@ int ao2mo_dense(const AoEri& ao, const double* TA, int n, double* out_s4) {
   QTRY(W1.alloc(std::max<int64_t>(npN * N * N, (int64_t)n * n * npN)));
   QTRY(W2.alloc(std::max<int64_t>((int64_t)n * npN * N, npn * N * N)));
   QTRY(dev_timer_begin(TIMER_AO2MO));
+  const int tcfg = (n > 192 && n <= 224) ? 13 : -1;   // one 224 x 128 tile instead of two padded 128-row tiles
   QTRY(dev_unpack_tril_rows(npN, N, ao.s4, W1));                                                   // [mn][k][l]
-  QTRY(gemm(n, npN * N, N, 1.0, TA, n, false, W1, N, true, 0.0, W2, npN * N));                     // [l'][mn][k]
-  QTRY(gemm(n, (int64_t)n * npN, N, 1.0, TA, n, false, W2, N, true, 0.0, W1, (int64_t)n * npN));   // [k'][l'][mn]
+  QTRY(gemm(n, npN * N, N, 1.0, TA, n, false, W1, N, true, 0.0, W2, npN * N, 1, 0, 0, 0, tcfg));                     // [l'][mn][k]
+  QTRY(gemm(n, (int64_t)n * npN, N, 1.0, TA, n, false, W2, N, true, 0.0, W1, (int64_t)n * npN, 1, 0, 0, 0, tcfg));   // [k'][l'][mn]
   QTRY(dev_pack_pair_rows(n, npN, W1, W2));                                                        // [(kl)][mn]
   QTRY(dev_unpack_tril_rows(npn, N, W2, W1));                                                      // [(kl)][m][n]
-  QTRY(gemm(n, npn * N, N, 1.0, TA, n, false, W1, N, true, 0.0, W2, npn * N));                     // [j'][(kl)][m]
-  QTRY(gemm(n, (int64_t)n * npn, N, 1.0, TA, n, false, W2, N, true, 0.0, W1, (int64_t)n * npn));   // [i'][j'][(kl)]
+  QTRY(gemm(n, npn * N, N, 1.0, TA, n, false, W1, N, true, 0.0, W2, npn * N, 1, 0, 0, 0, tcfg));                     // [j'][(kl)][m]
+  QTRY(gemm(n, (int64_t)n * npn, N, 1.0, TA, n, false, W2, N, true, 0.0, W1, (int64_t)n * npn, 1, 0, 0, 0, tcfg));   // [i'][j'][(kl)]
   QTRY(dev_pack_pair_rows(n, npn, W1, out_s4));
   QTRY(dev_timer_end(TIMER_AO2MO));
   return 0;

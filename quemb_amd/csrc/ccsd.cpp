@@ -43,11 +43,13 @@ int mo_transform(int n, int o, int nf, const double* eri_s4, double* X0, double*
   out.n = n; out.o = o; out.v = v; out.nf = nf;
   QTRY(dev_timer_begin(TIMER_AO2MO));
   if (!x1_is_unpacked) QTRY(dev_unpack_tril_rows(np, n, eri_s4, X1));   // (the fragment RHF already built it for its exchange matrix)
-  QTRY(gemm(n, ncol, n, 1.0, C, n, false, X1, n, true, 0.0, X0, ncol));
-  QTRY(gemm(n, ncol, n, 1.0, C, n, false, X0, n, true, 0.0, X1, ncol));
+  // 193..224 rows fit ONE 224 x 128 tile (1.8 % padding instead of the 14 % of two 128-row tiles at n = 220)
+  const int tcfg = (n > 192 && n <= 224) ? 13 : -1;
+  QTRY(gemm(n, ncol, n, 1.0, C, n, false, X1, n, true, 0.0, X0, ncol, 1, 0, 0, 0, tcfg));
+  QTRY(gemm(n, ncol, n, 1.0, C, n, false, X0, n, true, 0.0, X1, ncol, 1, 0, 0, 0, tcfg));
   QTRY(dev_pack_pair_rows(n, np, X1, X0));
   QTRY(dev_unpack_tril_rows(np, n, X0, X1));
-  QTRY(gemm(n, ncol, n, 1.0, C, n, false, X1, n, true, 0.0, X0, ncol));
+  QTRY(gemm(n, ncol, n, 1.0, C, n, false, X1, n, true, 0.0, X0, ncol, 1, 0, 0, 0, tcfg));
   if (nf > 0 && build_T34) {   // every (P q'|r' s'), pair unpacked: the operand of CcLambda::densities
     QTRY(out.T34.alloc((int64_t)n * n * n * nf));
     QTRY(dev_extract_mid_pair(n, n, n, X0, 0, 0, n, n, 0, nf, out.T34));
@@ -57,7 +59,7 @@ int mo_transform(int n, int o, int nf, const double* eri_s4, double* X0, double*
     QTRY(dev_extract_mid_pair(v, n, n, X0 + (int64_t)o * ncol, 0, o, o, v, 0, nf, out.A1));   // A1[a,j,b,P] = (P a|j b)
     QTRY(dev_extract_mid_pair(o, n, n, X0, 0, o, o, v, 0, nf, out.A2));                        // A2[i,j,b,P] = (P i|j b)
   }
-  QTRY(gemm(n, ncol, n, 1.0, C, n, false, X0, n, true, 0.0, X1, ncol));
+  QTRY(gemm(n, ncol, n, 1.0, C, n, false, X0, n, true, 0.0, X1, ncol, 1, 0, 0, 0, tcfg));
   const double* Mh = X1;   // [p'][q'][(r's')]
   QTRY(out.oooo.alloc((int64_t)o * o * o * o));
   QTRY(out.ovoo.alloc((int64_t)o * v * o * o));
