@@ -18,6 +18,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <string>
 
 namespace qemb {
@@ -375,7 +376,14 @@ int CcsdSolver::iterate(double* e_corr, double* normt) {
   QTRY(dev_timer_begin(TIMER_ITER));
   // Launch-bound regime (small fragments): record update_amps once (after one eager pass has settled every workspace)
   // and replay it as a hipGraph.  Large fragments are GEMM bound and keep the eager path with its per-kernel timers.
-  static const bool graphs_enabled = [] { const char* e = std::getenv("QEMB_GRAPH"); return !(e && e[0] == '0'); }();
+  // (hipGraph replay under rocprofv3's kernel tracing aborts inside the profiler on this ROCm: fall back to eager launches there)
+  static const bool graphs_enabled = [] {
+    const char* e = std::getenv("QEMB_GRAPH");
+    if (e) return e[0] != '0';
+    const char* pre = std::getenv("LD_PRELOAD");
+    if (std::getenv("ROCP_TOOL_LIBRARIES") || (pre && std::strstr(pre, "rocprofiler"))) return false;
+    return true;
+  }();
   const bool small = (int64_t)o_ * o_ * v_ * v_ <= (int64_t)1 << 22;
   if (graphs_enabled && small && graph_ok_ && graph_) {
     QTRY(dev_graph_launch(graph_));
