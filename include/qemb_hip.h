@@ -97,6 +97,12 @@ int qemb_op_unpack_s8_to_s4(int64_t n, const double* s8, double* s4);
 /* pair-packed MO transformation helpers (half the flops of the four-index ao2mo.kernel call of PySCF's cc.ao2mo(),
  * which solve_ccsd reaches at molbe/solver.py:900): row gather r >= s; block gather from the half-packed tensor
  * Mh[p][q][P(r,s)]; block gather from the 3/4-transformed tensor T[q'][P(r',s')][p]; (+/-) ladder operands from Mh. */
+/* Execution contexts (one HIP stream + workspaces + block cache each; no reference counterpart -- the reference overlaps
+ * fragments with a process pool, be_parallel.py:484).  qemb_ctx_count(n) makes contexts 0..n-1 available (0 = default) and
+ * returns how many exist (or < 0); qemb_ctx_bind(k) binds the CALLING host thread to context k, so that several host
+ * threads can each drive a fragment on their own stream. */
+int qemb_ctx_count(int n);
+int qemb_ctx_bind(int k);
 int qemb_op_mirror_lower(int64_t n, double* A, int64_t lda);   /* A[r][c] = A[c][r], r < c (completes a SYRK-style result) */
 int qemb_op_pack_pair_rows(int64_t n, int64_t ncols, const double* in, double* out);
 int qemb_op_extract_hp(int64_t n, const double* Mh, int64_t p0, int64_t q0, int64_t r0, int64_t s0, int64_t sp, int64_t sq,

@@ -25,7 +25,11 @@ const char* last_error();
 
 // ---- device / memory -----------------------------------------------------------------------
 int dev_init(int device);            // select device, create the library stream
-int dev_sync();                      // wait for the library stream
+int dev_sync();                      // wait for the calling thread's stream
+// Execution contexts: one HIP stream + workspaces + block cache each.  dev_ctx_count(n) makes contexts 0..n-1 available
+// (0 = default) and returns how many exist; dev_ctx_bind(k) binds the CALLING host thread to context k.
+int dev_ctx_count(int n);
+int dev_ctx_bind(int k);
 int dev_alloc(void** p, size_t bytes);
 int dev_free(void* p);                // parks the block in a free list (see dev_trim)
 int dev_trim();                       // release every parked block back to the driver

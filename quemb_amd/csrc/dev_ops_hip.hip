@@ -27,19 +27,44 @@ static thread_local std::string g_err;
 void set_error(const std::string& msg) { g_err = msg; }
 const char* last_error() { return g_err.c_str(); }
 
-static hipStream_t g_stream = nullptr;
-static bool g_capturing = false;          // inside hipStreamBeginCapture .. EndCapture (dev_graph_*)
-static int g_device = -1;
-static double* g_partials = nullptr;       // reduction scratch (NPART doubles)
-static constexpr int NPART = 2048;
-static double* g_ws = nullptr;             // growable workspace for contract_mid partials
-static size_t g_ws_bytes = 0;
-static double* g_gws = nullptr;            // split-K partial-sum workspace of the GEMM
-static size_t g_gws_bytes = 0;
-
+// One EXECUTION CONTEXT = one HIP stream with its own reduction scratch, workspaces, block cache, timers and capture state.
+// Every host thread is bound to a context (the process default unless dev_ctx_bind is called), so several fragments can be
+// driven concurrently from several host threads, each on its own stream: fragments whose kernels are latency bound
+// (n ~ 40-60) then overlap on the device.  Nothing is shared between contexts, so no locking is needed on the hot path.
 struct TimerSlot { hipEvent_t e0 = nullptr, e1 = nullptr; double total_ms = 0; int64_t count = 0;
                    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending; };
-static TimerSlot g_timers[TIMER_NSLOTS];
+static constexpr int NPART = 2048;
+struct DevCtx {
+  hipStream_t stream = nullptr;
+  bool capturing = false;            // inside hipStreamBeginCapture .. EndCapture (dev_graph_*)
+  double* partials = nullptr;        // reduction scratch (NPART doubles)
+  double* ws = nullptr;              // growable workspace for contract_mid / k_pairs partials
+  size_t ws_bytes = 0;
+  double* gws = nullptr;             // split-K partial-sum workspace of the GEMM
+  size_t gws_bytes = 0;
+  TimerSlot timers[TIMER_NSLOTS];
+  std::map<size_t, std::vector<void*>> pool;   // caching allocator (see below)
+  size_t pool_bytes = 0;
+};
+struct LiveBlock { size_t bytes; DevCtx* owner; };
+static std::map<void*, LiveBlock> g_live_blocks;   // every block handed out by dev_alloc, any context
+static std::mutex g_alloc_mutex;                   // allocator bookkeeping only (host side, off the kernel path)
+static int g_device = -1;
+static DevCtx g_default_ctx;
+static std::vector<DevCtx*> g_extra_ctx;          // created by dev_ctx_count(n); index k >= 1
+static std::mutex g_ctx_mutex;
+static thread_local DevCtx* t_ctx = nullptr;
+static inline DevCtx& ctx() { return t_ctx ? *t_ctx : g_default_ctx; }
+#define g_stream (ctx().stream)
+#define g_capturing (ctx().capturing)
+#define g_partials (ctx().partials)
+#define g_ws (ctx().ws)
+#define g_ws_bytes (ctx().ws_bytes)
+#define g_gws (ctx().gws)
+#define g_gws_bytes (ctx().gws_bytes)
+#define g_timers (ctx().timers)
+#define g_pool (ctx().pool)
+#define g_pool_bytes (ctx().pool_bytes)
 
 hipStream_t hip_stream() { return g_stream; }
 const char* dev_backend_name() { return "hip-gfx950"; }
@@ -49,12 +74,36 @@ int dev_init(int device) {
   HIP_TRY(hipGetDeviceCount(&ndev));
   if (ndev <= 0) { set_error("no HIP device visible: libqemb_hip has no CPU fallback"); return QEMB_ERR_DEVICE; }
   if (device < 0 || device >= ndev) { set_error("dev_init: device index out of range"); return QEMB_ERR_ARG; }
-  if (g_stream && g_device == device) return QEMB_OK;
+  DevCtx& c = g_default_ctx;
+  if (c.stream && g_device == device) return QEMB_OK;
   HIP_TRY(hipSetDevice(device));
-  if (g_stream) { (void)hipStreamDestroy(g_stream); g_stream = nullptr; g_partials = nullptr; g_ws = nullptr; g_ws_bytes = 0; g_gws = nullptr; g_gws_bytes = 0; }
-  HIP_TRY(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
-  HIP_TRY(hipMalloc((void**)&g_partials, NPART * sizeof(double)));
+  if (c.stream) { (void)hipStreamDestroy(c.stream); c = DevCtx(); }
+  HIP_TRY(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+  HIP_TRY(hipMalloc((void**)&c.partials, NPART * sizeof(double)));
   g_device = device;
+  return QEMB_OK;
+}
+// make sure contexts 0..n-1 exist (0 = the default one); returns the number available
+int dev_ctx_count(int n) {
+  if (!g_default_ctx.stream) { set_error("libqemb_hip: call qemb_init(device) first"); return QEMB_ERR_DEVICE; }
+  std::lock_guard<std::mutex> lock(g_ctx_mutex);
+  HIP_TRY(hipSetDevice(g_device));
+  while ((int)g_extra_ctx.size() + 1 < n) {
+    DevCtx* c = new DevCtx();
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc((void**)&c->partials, NPART * sizeof(double));
+    if (e != hipSuccess) { delete c; set_error(std::string("dev_ctx_count: ") + hipGetErrorString(e)); return QEMB_ERR_DEVICE; }
+    g_extra_ctx.push_back(c);
+  }
+  return (int)g_extra_ctx.size() + 1;
+}
+// bind the calling host thread to context k (HIP's current device is per thread as well)
+int dev_ctx_bind(int k) {
+  if (!g_default_ctx.stream) { set_error("libqemb_hip: call qemb_init(device) first"); return QEMB_ERR_DEVICE; }
+  std::lock_guard<std::mutex> lock(g_ctx_mutex);
+  if (k < 0 || k > (int)g_extra_ctx.size()) { set_error("dev_ctx_bind: no such context (call dev_ctx_count first)"); return QEMB_ERR_ARG; }
+  HIP_TRY(hipSetDevice(g_device));
+  t_ctx = (k == 0) ? &g_default_ctx : g_extra_ctx[k - 1];
   return QEMB_OK;
 }
 #define REQUIRE_INIT()                                                                          \
@@ -67,32 +116,29 @@ int dev_sync() { REQUIRE_INIT(); HIP_TRY(hipStreamSynchronize(g_stream)); return
 // freed blocks are parked in an exact-size free list and handed back to the next request of that size.  All work
 // is on ONE stream, so reuse is stream-ordered and needs no synchronisation.  dev_trim() / an allocation failure
 // releases the parked blocks.
-static std::map<size_t, std::vector<void*>> g_pool;
-static std::map<void*, size_t> g_live;
-static size_t g_pool_bytes = 0;
 
 int dev_trim() {
   if (!g_stream) return QEMB_OK;
   HIP_TRY(hipStreamSynchronize(g_stream));
+  std::lock_guard<std::mutex> lock(g_alloc_mutex);
   for (auto& kv : g_pool) for (void* q : kv.second) (void)hipFree(q);
   g_pool.clear(); g_pool_bytes = 0;
   return QEMB_OK;
 }
 int dev_alloc(void** p, size_t bytes) {
   REQUIRE_INIT();
-  if (g_capturing) {   // pooled blocks are fine, a real hipMalloc is not
-    const size_t want = ((bytes ? bytes : 16) + 255) / 256 * 256;
-    auto hit = g_pool.find(want);
-    if (hit == g_pool.end() || hit->second.empty()) { set_error("device allocation inside a captured region"); return QEMB_ERR_ALLOC; }
-  }
   if (bytes == 0) bytes = 16;
   bytes = (bytes + 255) / 256 * 256;
-  auto it = g_pool.find(bytes);
-  if (it != g_pool.end() && !it->second.empty()) {
-    *p = it->second.back(); it->second.pop_back(); g_pool_bytes -= bytes;
-    g_live[*p] = bytes;
-    return QEMB_OK;
+  {
+    std::lock_guard<std::mutex> lock(g_alloc_mutex);
+    auto it = g_pool.find(bytes);
+    if (it != g_pool.end() && !it->second.empty()) {
+      *p = it->second.back(); it->second.pop_back(); g_pool_bytes -= bytes;
+      g_live_blocks[*p] = LiveBlock{bytes, &ctx()};
+      return QEMB_OK;
+    }
   }
+  if (g_capturing) { set_error("device allocation inside a captured region"); return QEMB_ERR_ALLOC; }   // pooled blocks are fine, a real hipMalloc is not
   hipError_t e = hipMalloc(p, bytes);
   if (e != hipSuccess) {
     (void)hipGetLastError();
@@ -101,16 +147,24 @@ int dev_alloc(void** p, size_t bytes) {
     e = hipMalloc(p, bytes);
   }
   if (e != hipSuccess) { set_error("hipMalloc of " + std::to_string(bytes) + " bytes failed: " + hipGetErrorString(e)); return QEMB_ERR_ALLOC; }
-  g_live[*p] = bytes;
+  std::lock_guard<std::mutex> lock(g_alloc_mutex);
+  g_live_blocks[*p] = LiveBlock{bytes, &ctx()};
   return QEMB_OK;
 }
 int dev_free(void* p) {
   if (!p) return QEMB_OK;
-  auto it = g_live.find(p);
-  if (it == g_live.end()) { HIP_TRY(hipStreamSynchronize(g_stream)); HIP_TRY(hipFree(p)); return QEMB_OK; }
-  const size_t bytes = it->second;
-  g_live.erase(it);
-  g_pool[bytes].push_back(p); g_pool_bytes += bytes;
+  LiveBlock blk{0, nullptr};
+  {
+    std::lock_guard<std::mutex> lock(g_alloc_mutex);
+    auto it = g_live_blocks.find(p);
+    if (it != g_live_blocks.end()) { blk = it->second; g_live_blocks.erase(it); }
+  }
+  if (!blk.owner) { HIP_TRY(hipStreamSynchronize(g_stream)); HIP_TRY(hipFree(p)); return QEMB_OK; }
+  // a block goes back to the cache of the context that allocated it; when another context releases it, that context's
+  // stream is drained first so that the owner cannot reuse the block under kernels still in flight
+  if (blk.owner != &ctx() && g_stream) HIP_TRY(hipStreamSynchronize(g_stream));
+  std::lock_guard<std::mutex> lock(g_alloc_mutex);
+  blk.owner->pool[blk.bytes].push_back(p); blk.owner->pool_bytes += blk.bytes;
   return QEMB_OK;
 }
 int dev_h2d(void* dst, const void* src, size_t bytes) {

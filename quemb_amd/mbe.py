@@ -31,7 +31,7 @@ def initialize_pot(n_frag, relAO_per_edge):
 
 class BE:
     def __init__(self, mf, fobj, *, lo_method="lowdin", thr_bath=1.0e-10, int_transform="in-core-hip", auxbasis=None,
-                 df_ints=None, nproc=1, ompnum=1, initialize_fragment_idx=None, solver_opts=None, lib=None, distribute=True,
+                 df_ints=None, nproc=1, ompnum=1, initialize_fragment_idx=None, solver_opts=None, lib=None, distribute=True, nstreams=1,
                  eri_file=None, scratch_dir=None, restart=False, schmidt_method="subspace"):
         if lo_method != "lowdin":
             raise NotImplementedError("only lo_method='lowdin' is mirrored (localisation is upstream of the hot path)")
@@ -44,6 +44,7 @@ class BE:
         self.schmidt_method = schmidt_method      # 'eigh' = reference formulation, 'subspace' = same bath, O(N_env n_f nocc)
         self.int_transform = int_transform
         self.opts = solver_opts
+        self.nstreams = int(nstreams)             # fragments in flight at once on this GPU (solver.map_fragments)
         self.unrestricted = False
         self.ebe_hf = 0.0
         self.ebe_tot = 0.0
@@ -152,8 +153,8 @@ class BE:
     def _sweep(self, pot, **kw):
         if self.world > 1:
             return be_func_parallel(pot, self.Fobjs, self.Nocc, "CCSD", self.enuc, owner=self.owner, opts=self.opts,
-                                    stats=self.stats, emap=self.emap, **kw)
-        return be_func(pot, self.Fobjs, self.Nocc, "CCSD", self.enuc, opts=self.opts, stats=self.stats, **kw)
+                                    stats=self.stats, emap=self.emap, nstreams=self.nstreams, **kw)
+        return be_func(pot, self.Fobjs, self.Nocc, "CCSD", self.enuc, opts=self.opts, stats=self.stats, nstreams=self.nstreams, **kw)
 
     def oneshot(self, solver="CCSD", use_cumulant=True, nproc=1, ompnum=1, solver_args=None):
         """mbe.py:1240-1310."""

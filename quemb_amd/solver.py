@@ -102,19 +102,50 @@ def solve_ccsd(h, eri_s4, nsocc, dm0=None, *, n_frag=0, rdm_return=False, rdm2_r
     return out["t1"], out["t2"]
 
 
+def map_fragments(fn, frags, nstreams=1):
+    """[fn(f) for f in frags], with up to `nstreams` fragments in flight at once: each worker thread is bound to its own
+    execution context of the library (HIP stream + workspaces, qemb_ctx_bind), so fragments whose kernels are latency bound
+    overlap on the device.  The reference overlaps fragments with a process pool (be_parallel.py:484-513)."""
+    frags = list(frags)
+    if nstreams <= 1 or len(frags) <= 1:
+        return [fn(f) for f in frags]
+    import queue
+    from concurrent.futures import ThreadPoolExecutor
+    lib = frags[0].dev.lib
+    have = lib.qemb_ctx_count(int(nstreams) + 1)          # context 0 stays with the calling thread
+    if have < 0:
+        from ._lib import check
+        check(have, "qemb_ctx_count", lib)
+    nwork = min(int(nstreams), have - 1, len(frags))
+    if nwork <= 1:
+        return [fn(f) for f in frags]
+    ids = queue.Queue()
+    for k in range(1, nwork + 1):
+        ids.put(k)
+
+    def bind():
+        from ._lib import check
+        check(lib.qemb_ctx_bind(ids.get()), "qemb_ctx_bind", lib)
+    with ThreadPoolExecutor(max_workers=nwork, initializer=bind) as pool:
+        return list(pool.map(fn, frags))
+
+
 def be_func(pot, Fobjs, Nocc, solver, enuc, solver_args=None, scratch_dir=None, only_chem=False, eeval=False,
-            relax_density=False, return_vec=False, use_cumulant=True, *, opts=None, stats=None):
-    """molbe/solver.py:244-562 for solver == 'CCSD'.  `opts` (qemb_solver_opts) and `stats` (dict collecting
-    per-sweep counters) are additions; everything else has the reference's meaning."""
+            relax_density=False, return_vec=False, use_cumulant=True, *, opts=None, stats=None, nstreams=1):
+    """molbe/solver.py:244-562 for solver == 'CCSD'.  `opts` (qemb_solver_opts), `stats` (dict collecting per-sweep
+    counters) and `nstreams` (fragments in flight at once, see map_fragments) are additions; everything else has the
+    reference's meaning."""
     if solver != "CCSD":
         raise ValueError("Solver not implemented")
     total_e = [0.0, 0.0, 0.0]
     n_iter = 0
-    for fobj in Fobjs:
+
+    def one(fobj):
         if pot is not None:
             fobj.update_heff(pot, only_chem=only_chem)
         assert fobj.fock is not None and fobj.heff is not None
-        out = fobj.solve(opts=opts, eeval=eeval, use_cumulant=use_cumulant, relax_density=relax_density)
+        return fobj.solve(opts=opts, eeval=eeval, use_cumulant=use_cumulant, relax_density=relax_density)
+    for out in map_fragments(one, Fobjs, nstreams):
         n_iter += out["n_iter"]
         if eeval:
             total_e = [a + b for a, b in zip(total_e, out["e_frag"])]

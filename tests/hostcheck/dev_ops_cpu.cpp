@@ -104,6 +104,8 @@ int dev_lincomb(int64_t n, int nterms, const double* coef, const double* const* 
   for (int64_t t = 0; t < n; ++t) { double acc = beta != 0.0 ? beta * out[t] : 0.0; for (int q = 0; q < nterms; ++q) acc += coef[q] * xs[q][t]; out[t] = acc; }
   return 0;
 }
+int dev_ctx_count(int n) { (void)n; return 1; }
+int dev_ctx_bind(int k) { return k == 0 ? 0 : QEMB_ERR_ARG; }
 int dev_mirror_lower(int64_t n, double* A, int64_t lda) {
   for (int64_t r = 0; r < n; ++r) for (int64_t c = r + 1; c < n; ++c) A[r * lda + c] = A[c * lda + r];
   return 0;

@@ -212,3 +212,23 @@ def test_periodic_front_end_matches_reference_goldens(qlib):
     """kbe/pfrag.py:143-306 (k -> R Fourier, SVD Schmidt, cons_h1, get_nsocc) on the device against the reference's own outputs."""
     from helpers import check_periodic_front_end
     check_periodic_front_end(None)
+
+
+def test_concurrent_streams_give_identical_results(qlib):
+    """nstreams > 1: fragments driven from several host threads, each bound to its own execution context (HIP stream,
+    workspaces, block cache).  Results must be bit-for-bit those of the serial sweep (every kernel is deterministic and
+    nothing is shared between contexts)."""
+    from quemb_amd.solver import be_func
+    mf, be1 = _be("octane")
+    mf3, be3 = _be("octane", nstreams=3)
+    r1 = be_func(None, be1.Fobjs, be1.Nocc, "CCSD", be1.enuc, eeval=True, return_vec=True, opts=be1.opts)
+    r3 = be_func(None, be3.Fobjs, be3.Nocc, "CCSD", be3.enuc, eeval=True, return_vec=True, opts=be3.opts, nstreams=3)
+    assert r1[0] == r3[0] and np.array_equal(np.asarray(r1[1]), np.asarray(r3[1]))
+    assert r1[2][0] == r3[2][0]
+    for a, b in zip(be1.Fobjs, be3.Fobjs):
+        assert np.array_equal(a._rdm1, b._rdm1) and np.array_equal(a.t1, b.t1)
+    # a second pass (warm block caches, contexts reused) and the optimiser on top of it
+    r3b = be_func(None, be3.Fobjs, be3.Nocc, "CCSD", be3.enuc, eeval=True, return_vec=True, opts=be3.opts, nstreams=3)
+    assert r3b[2][0] == r3[2][0]
+    opt = be3.optimize(solver="CCSD", only_chem=False)
+    assert opt.err < 1e-6 and abs(be3.e_corr - (-0.5499514850769742)) < 5e-6
