@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--frags-per-gpu", type=int, default=8)
+    ap.add_argument("--nstreams", type=int, default=1, help="fragments in flight per GPU (separate HIP streams); the default 1 keeps the "
+                    "ladder kernel's HIP-event / rocprofv3 durations uncontended")
     ap.add_argument("--n", type=int, default=220)
     ap.add_argument("--nocc", type=int, default=20)
     ap.add_argument("--scale", type=float, default=0.03)
@@ -82,10 +84,14 @@ def make_fragment(lib, n, nf, seed, scale):
     return fr, h, B
 
 
-def read_timer(lib, slot):
-    ms = C.c_double(); cnt = C.c_int64()
-    lib.qemb_timer_read(slot, C.byref(ms), C.byref(cnt))
-    return ms.value, cnt.value
+def read_timer(lib, slot, nctx=1):
+    """device timer `slot` summed over the execution contexts 0..nctx-1"""
+    tot, n = 0.0, 0
+    for k in range(nctx):
+        ms = C.c_double(); cnt = C.c_int64()
+        lib.qemb_ctx_timer_read(k, slot, C.byref(ms), C.byref(cnt), 0)
+        tot += ms.value; n += cnt.value
+    return tot, n
 
 
 def cpu_baseline(fr, h, dm0, o, opts, iters, threads, timeout_s=300):
@@ -199,10 +205,25 @@ def main():
     comm_dev = torch.device("cuda", lrank) if backend == "nccl" else torch.device("cpu")
     buf_t = torch.zeros(8, dtype=torch.float64, device=comm_dev) if world > 1 else None
 
+    nctx = 1
+    pool = None
+    if args.nstreams > 1:      # be_func(..., nstreams=k): worker threads, each bound to its own execution context (HIP stream)
+        import queue
+        from concurrent.futures import ThreadPoolExecutor
+        from quemb_amd._lib import check
+        nctx = lib.qemb_ctx_count(args.nstreams + 1)
+        ids = queue.Queue()
+        for k in range(1, args.nstreams + 1):
+            ids.put(k)
+        pool = ThreadPoolExecutor(max_workers=args.nstreams, initializer=lambda: check(lib.qemb_ctx_bind(ids.get()), "qemb_ctx_bind", lib))
+
+    def one(t):
+        fr, h, dm0 = t
+        return fr.solve(o, h, dm0, opts=opts, eeval=True)
+
     def sweep():
         acc = np.zeros(8)
-        for fr, h, dm0 in frs:
-            out = fr.solve(o, h, dm0, opts=opts, eeval=True)
+        for out in (pool.map(one, frs) if pool else map(one, frs)):
             acc[0] += out["n_iter"]; acc[1:4] += out["e_frag"]; acc[4] += np.trace(out["rdm1_emb"][:nf, :nf]); acc[5] += out["e_corr_mo"]; acc[6] += 1
         if world > 1:      # the one exchange of a sweep: residual/energy buffer, RCCL sum-all-reduce
             buf_t.copy_(torch.from_numpy(acc))
@@ -215,7 +236,8 @@ def main():
         sweep()
     log("timed sweeps")
     for s in range(8):
-        lib.qemb_timer_reset(s)
+        for k in range(nctx):
+            lib.qemb_ctx_timer_read(k, s, None, None, 1)
     if world > 1:
         dist.barrier()
     lib.qemb_sync(); sync()
@@ -238,11 +260,11 @@ def main():
 
     log(f"timed region done: {dt:.2f} s for {args.steps} step(s)")
     if rank == 0:
-        lad_ms, lad_cnt = read_timer(lib, 0)
-        it_ms, it_cnt = read_timer(lib, 2)
-        ao_ms, ao_cnt = read_timer(lib, 3)
-        scf_ms, scf_cnt = read_timer(lib, 4)
-        ring_ms, ring_cnt = read_timer(lib, 1)
+        lad_ms, lad_cnt = read_timer(lib, 0, nctx)
+        it_ms, it_cnt = read_timer(lib, 2, nctx)
+        ao_ms, ao_cnt = read_timer(lib, 3, nctx)
+        scf_ms, scf_cnt = read_timer(lib, 4, nctx)
+        ring_ms, ring_cnt = read_timer(lib, 1, nctx)
         lad_avg = lad_ms / max(lad_cnt, 1) * 1e-3
         npair_o = o * (o + 1) // 2
         npv, nmv, nmo = v * (v + 1) // 2, v * (v - 1) // 2, o * (o - 1) // 2
@@ -264,7 +286,7 @@ def main():
             "config": {"workload": f"BASELINE configs[2]: synthetic fragment sweep, {F} fragments per GPU ({F * world} total), "
                                    f"n_occ={o} n_virt={v} (n={n}), DF-factorised ERIs naux={3 * n} scale={args.scale}, "
                                    "one be_func sweep per step (fragment RHF + MO transform + RCCSD to |dE|<1e-10 + energies + 1 all-reduce)",
-                       "fragments_per_gpu": F, "n_occ": o, "n_virt": v, "parallelism": f"fragments sharded over {world} GPU(s), 1 RCCL all-reduce per sweep"},
+                       "fragments_per_gpu": F, "n_occ": o, "n_virt": v, "fragments_in_flight_per_gpu": args.nstreams, "parallelism": f"fragments sharded over {world} GPU(s), 1 RCCL all-reduce per sweep"},
             "fragments_per_s": n_frag_total / dt,
             "ccsd_iterations_per_fragment": n_iter_total / max(n_frag_total, 1),
             "mean_e_corr_per_fragment": float(tot[5]) / max(n_frag_total, 1),

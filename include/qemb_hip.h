@@ -103,6 +103,7 @@ int qemb_op_unpack_s8_to_s4(int64_t n, const double* s8, double* s4);
  * threads can each drive a fragment on their own stream. */
 int qemb_ctx_count(int n);
 int qemb_ctx_bind(int k);
+int qemb_ctx_timer_read(int ctx, int slot, double* total_ms, int64_t* count, int reset);   /* device timers of an idle context */
 int qemb_op_mirror_lower(int64_t n, double* A, int64_t lda);   /* A[r][c] = A[c][r], r < c (completes a SYRK-style result) */
 int qemb_op_pack_pair_rows(int64_t n, int64_t ncols, const double* in, double* out);
 int qemb_op_extract_hp(int64_t n, const double* Mh, int64_t p0, int64_t q0, int64_t r0, int64_t s0, int64_t sp, int64_t sq,

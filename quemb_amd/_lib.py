@@ -83,6 +83,7 @@ def _declare(lib):
     f("qemb_op_mirror_lower", I, L, P, L)
     f("qemb_ctx_count", I, I)
     f("qemb_ctx_bind", I, I)
+    f("qemb_ctx_timer_read", I, I, I, C.POINTER(C.c_double), C.POINTER(c_i64), I)
     f("qemb_op_extract_hp", I, L, P, L, L, L, L, L, L, L, L, P)
     f("qemb_op_extract_mid_pair", I, L, L, L, P, L, L, L, L, L, L, P)
     f("qemb_op_ladder_pack_vvvv_hp", I, L, L, P, P, L, P, L)

@@ -88,6 +88,7 @@ int qemb_op_pack_s4(int64_t n, const double* s1, double* s4) { return dev_pack_s
 int qemb_op_unpack_s8_to_s4(int64_t n, const double* s8, double* s4) { return dev_unpack_s8_to_s4(n, s8, s4); }
 int qemb_ctx_count(int n) { return dev_ctx_count(n); }
 int qemb_ctx_bind(int k) { return dev_ctx_bind(k); }
+int qemb_ctx_timer_read(int ctx, int slot, double* total_ms, int64_t* count, int reset) { return dev_ctx_timer_read(ctx, slot, total_ms, count, reset); }
 int qemb_op_mirror_lower(int64_t n, double* A, int64_t lda) { return dev_mirror_lower(n, A, lda); }
 int qemb_op_pack_pair_rows(int64_t n, int64_t ncols, const double* in, double* out) { return dev_pack_pair_rows(n, ncols, in, out); }
 int qemb_op_extract_hp(int64_t n, const double* Mh, int64_t p0, int64_t q0, int64_t r0, int64_t s0, int64_t sp, int64_t sq, int64_t sr, int64_t ss, double* out) {

@@ -57,6 +57,7 @@ int dev_timer_begin(int slot);
 int dev_timer_end(int slot);
 int dev_timer_read(int slot, double* total_ms, int64_t* count);   // syncs
 int dev_timer_reset(int slot);
+int dev_ctx_timer_read(int ctx, int slot, double* total_ms, int64_t* count, int reset);   // another context's timers (idle context)
 enum { TIMER_LADDER = 0, TIMER_RINGS = 1, TIMER_ITER = 2, TIMER_AO2MO = 3, TIMER_SCF = 4,
        TIMER_GEMM_ANY = 5, TIMER_SCHMIDT = 6, TIMER_DF = 7, TIMER_NSLOTS = 16 };
 

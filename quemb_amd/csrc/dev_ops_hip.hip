@@ -252,11 +252,9 @@ int dev_timer_end(int slot) {
   HIP_TRY(hipEventRecord(t.pending.back().second, g_stream));
   return QEMB_OK;
 }
-int dev_timer_read(int slot, double* total_ms, int64_t* count) {
-  REQUIRE_INIT();
-  if (slot < 0 || slot >= TIMER_NSLOTS) return QEMB_ERR_ARG;
-  TimerSlot& t = g_timers[slot];
-  HIP_TRY(hipStreamSynchronize(g_stream));
+static int timer_collect(DevCtx& c, int slot, double* total_ms, int64_t* count) {
+  TimerSlot& t = c.timers[slot];
+  HIP_TRY(hipStreamSynchronize(c.stream));
   for (auto& pr : t.pending) {
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, pr.first, pr.second));
@@ -267,6 +265,25 @@ int dev_timer_read(int slot, double* total_ms, int64_t* count) {
   if (total_ms) *total_ms = t.total_ms;
   if (count) *count = t.count;
   return QEMB_OK;
+}
+int dev_timer_read(int slot, double* total_ms, int64_t* count) {
+  REQUIRE_INIT();
+  if (slot < 0 || slot >= TIMER_NSLOTS) return QEMB_ERR_ARG;
+  return timer_collect(ctx(), slot, total_ms, count);
+}
+// timers of context k (call while no thread is driving that context); reset != 0 also clears them
+int dev_ctx_timer_read(int k, int slot, double* total_ms, int64_t* count, int reset) {
+  REQUIRE_INIT();
+  if (slot < 0 || slot >= TIMER_NSLOTS) return QEMB_ERR_ARG;
+  DevCtx* c = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(g_ctx_mutex);
+    if (k < 0 || k > (int)g_extra_ctx.size()) { set_error("dev_ctx_timer_read: no such context"); return QEMB_ERR_ARG; }
+    c = (k == 0) ? &g_default_ctx : g_extra_ctx[k - 1];
+  }
+  int rc = timer_collect(*c, slot, total_ms, count);
+  if (rc == QEMB_OK && reset) { c->timers[slot].total_ms = 0; c->timers[slot].count = 0; }
+  return rc;
 }
 int dev_timer_reset(int slot) {
   double a; int64_t c;

@@ -104,6 +104,7 @@ int dev_lincomb(int64_t n, int nterms, const double* coef, const double* const* 
   for (int64_t t = 0; t < n; ++t) { double acc = beta != 0.0 ? beta * out[t] : 0.0; for (int q = 0; q < nterms; ++q) acc += coef[q] * xs[q][t]; out[t] = acc; }
   return 0;
 }
+int dev_ctx_timer_read(int k, int slot, double* total_ms, int64_t* count, int reset) { (void)k; (void)reset; return dev_timer_read(slot, total_ms, count); }
 int dev_ctx_count(int n) { (void)n; return 1; }
 int dev_ctx_bind(int k) { return k == 0 ? 0 : QEMB_ERR_ARG; }
 int dev_mirror_lower(int64_t n, double* A, int64_t lda) {
