@@ -25,6 +25,7 @@
 //    logical tile order, m-tiles fastest, so the m-tiles that share one streamed B panel (W_vvvv for
 //    the ladder: 12.8 GB) run on one XCD at the same time and the panel is fetched from HBM once.
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cstdint>
 #include "dev_ops.h"
 #include "hip_common.h"
@@ -285,7 +286,7 @@ static int launch_cfg(const GemmDesc& d, hipStream_t s) {
   }
   const size_t lds = 2 * (size_t)(ImgA::SIZE + ImgB::SIZE) * sizeof(double);
   auto kern = dgemm_mfma_kernel<WM, WN, WAVES_M, WAVES_N, BK, A_KC, B_KC, VEC, TAG>;
-  static bool attr_set = false;
+  static std::atomic<bool> attr_set{false};   // benign if two threads both set the attribute once
   if (!attr_set) {
     HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;

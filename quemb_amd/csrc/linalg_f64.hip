@@ -13,6 +13,7 @@
 // Also here: blocked Cholesky and triangular inverse for the DF metric (reference: eri_onthefly.py:108,141;
 // _cpp/eri_sparse_DF.cpp:611-621), built from a 32x32 LDS diagonal-block kernel plus the MFMA GEMM.
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
@@ -205,7 +206,7 @@ static int jacobi_rows(int nvec, int64_t len, double* W, int64_t ldw, double* Vt
     QTRY_ALLOC(d_sw, sizeof(int));
     const double tol_s = std::max(1.0e-15, std::sqrt((double)len) * 2.22e-16);
     const size_t lds = sizeof(double) * ((size_t)nvec * (len + 1) + (size_t)nvec * (nvec + 1));
-    static bool attr_set = false;
+    static std::atomic<bool> attr_set{false};   // benign if two threads both set the attribute once
     if (!attr_set) { HIP_TRY(hipFuncSetAttribute((const void*)jacobi_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64)); attr_set = true; }
     hipLaunchKernelGGL(jacobi_small_kernel, dim3(1), dim3(1024), lds, s, W, (long long)ldw, (int)len, Vt, nvec, np, tol_s, floor2, 40, d_sw);
     HIP_TRY(hipGetLastError());
