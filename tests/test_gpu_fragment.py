@@ -104,3 +104,30 @@ def test_relaxed_density_pipeline_matches_oracle(qlib, n, o, nf, cen):
     assert np.abs(out["rdm1_emb"] - 0.5 * C @ dm1 @ C.T).max() < TOL_RDM
     e_ref = be.get_frag_energy(C, o, nf, (1.0, cen), np.zeros((n, n)), h1, dm1, g2, s4, veff0, None, True)
     assert np.abs(np.array(out["e_frag"]) - np.array(e_ref)).max() < TOL_E, (out["e_frag"], e_ref)
+
+
+@pytest.mark.parametrize("n,o", [(2, 1), (3, 1), (3, 2), (4, 3), (5, 1), (5, 4)])
+@pytest.mark.parametrize("relax", [0, 1])
+def test_degenerate_fragment_sizes(qlib, n, o, relax):
+    """One occupied or one virtual orbital: the pair-packed operands (ladder, tau-side dressing, MO transform) have empty
+    antisymmetric blocks; amplitudes, energies and (relaxed) densities still match the oracle."""
+    from qemb_oracle import ccsd_lambda
+    h, e1 = synthetic_fragment(n, o, 300 + 10 * n + o, scale=0.12)
+    fr = DeviceFragment(n, 1)
+    fr.set_eri_s4(eri.pack_s4(e1))
+    fr.set_energy_data(h, h, None, 1.0, [0])
+    out = fr.solve(o, h, opts=default_opts(relax_density=relax, cc_conv_tol=1e-13, cc_conv_tol_normt=1e-11, lambda_conv_tol=1e-11), eeval=True)
+    mf = scf.rhf(h, e1, o)
+    eris = ccsd.Eris(e1, mf["mo_coeff"], o, mo_energy=mf["mo_energy"])
+    conv, ecc, t1, t2, _ = ccsd.kernel(eris, conv_tol=1e-13, conv_tol_normt=1e-11)
+    assert abs(out["e_corr_mo"] - ecc) < 1e-11
+    C = mf["mo_coeff"]
+    if relax:
+        z1, z2, _, lag = ccsd_lambda.solve_lambda(t1, t2, eris, conv_tol=1e-12)
+        dm1, _ = ccsd_lambda.response_densities(lag, z1, z2)
+        g2 = ccsd_lambda.make_rdm2_relaxed(lag, z1, z2)
+    else:
+        dm1, g2 = rdm.make_rdm1_ccsd_t1(t1), rdm.make_rdm2_urlx(t1, t2, with_dm1=False)
+    assert np.abs(out["rdm1_emb"] - 0.5 * C @ dm1 @ C.T).max() < 1e-9
+    e_ref = be.get_frag_energy(C, o, 1, (1.0, [0]), np.zeros((n, n)), h, dm1, g2, eri.pack_s4(e1), h, None, True)
+    assert np.abs(np.array(out["e_frag"]) - np.array(e_ref)).max() < 1e-9
