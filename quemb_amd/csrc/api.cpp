@@ -89,6 +89,14 @@ int qemb_op_unpack_s8_to_s4(int64_t n, const double* s8, double* s4) { return de
 int qemb_ctx_count(int n) { return dev_ctx_count(n); }
 int qemb_ctx_bind(int k) { return dev_ctx_bind(k); }
 int qemb_ctx_timer_read(int ctx, int slot, double* total_ms, int64_t* count, int reset) { return dev_ctx_timer_read(ctx, slot, total_ms, count, reset); }
+int qemb_op_k_from_pairs(int64_t n, const double* H, const double* D, double* K) { return dev_k_from_pairs(n, H, D, K); }
+int qemb_op_pack_pm_cols(int64_t rows, int64_t v, const double* in, double* Op, int64_t ldp, double* Om, int64_t ldm) { return dev_pack_pm_cols(rows, v, in, Op, ldp, Om, ldm); }
+int qemb_op_scatter_pm_rows(int64_t o, int64_t ncols, const double* Xp, const double* Xm, double* out) { return dev_scatter_pm_rows(o, ncols, Xp, Xm, out); }
+int qemb_op_lincomb2(int64_t n, double a, const double* x, double b, const double* y, double beta, double* out) {
+  const double c[2] = {a, b};
+  const double* xs[2] = {x, y};
+  return dev_lincomb(n, 2, c, xs, beta, out);
+}
 int qemb_op_mirror_lower(int64_t n, double* A, int64_t lda) { return dev_mirror_lower(n, A, lda); }
 int qemb_op_pack_pair_rows(int64_t n, int64_t ncols, const double* in, double* out) { return dev_pack_pair_rows(n, ncols, in, out); }
 int qemb_op_extract_hp(int64_t n, const double* Mh, int64_t p0, int64_t q0, int64_t r0, int64_t s0, int64_t sp, int64_t sq, int64_t sr, int64_t ss, double* out) {

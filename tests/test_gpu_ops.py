@@ -372,3 +372,52 @@ def test_pm_packed_ladder_equals_dense(qlib, o, v):
     check(qlib.qemb_op_ladder_scatter_pm(o, v, dRp.ptr, ldp, dRm.ptr, ldm, d2.ptr))
     ref = t2 + np.einsum("acbd,ijcd->ijab", vv, tau)
     assert np.abs(d2.numpy(t2.shape) - ref).max() < 1e-10 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("n", [3, 17, 70])
+def test_k_from_pairs_and_unpack(qlib, n):
+    """K[p,r] = sum_qs (pq|rs) D[q,s] from the half-unpacked pair-row tensor == the dense contraction."""
+    rng = np.random.default_rng(n)
+    eri = _sym_eri(n, rng)
+    il = np.tril_indices(n)
+    npair = len(il[0])
+    s4 = eri[il][:, il[0], il[1]]
+    D = rng.standard_normal((n, n))                     # not symmetric on purpose
+    d4, dH = DeviceBuffer.from_numpy(s4), DeviceBuffer(npair * n * n)
+    check(qlib.qemb_op_unpack_tril_rows(npair, n, d4.ptr, dH.ptr))
+    assert np.array_equal(dH.numpy((npair, n, n)), eri[il])
+    dD, dK = DeviceBuffer.from_numpy(D), DeviceBuffer(n * n)
+    check(qlib.qemb_op_k_from_pairs(n, dH.ptr, dD.ptr, dK.ptr))
+    ref = np.einsum("pqrs,qs->pr", eri, D)
+    assert np.abs(dK.numpy((n, n)) - ref).max() < 1e-11 * max(1.0, np.abs(ref).max())
+
+
+def test_pm_pair_packing_roundtrip_and_lincomb(qlib):
+    rng = np.random.default_rng(9)
+    rows, v, o, ncols = 5, 7, 4, 6
+    A = rng.standard_normal((rows, v, v))
+    npv, nmv = v * (v + 1) // 2, v * (v - 1) // 2
+    ldp, ldm = npv + (npv & 1), nmv + (nmv & 1)
+    dA, dP, dM = DeviceBuffer.from_numpy(A), DeviceBuffer(rows * ldp), DeviceBuffer(rows * ldm)
+    check(qlib.qemb_op_pack_pm_cols(rows, v, dA.ptr, dP.ptr, ldp, dM.ptr, ldm))
+    P, M = dP.numpy((rows, ldp)), dM.numpy((rows, ldm))
+    il = np.tril_indices(v); ils = np.tril_indices(v, -1)
+    assert np.array_equal(P[:, :npv], (A + A.transpose(0, 2, 1))[:, il[0], il[1]]) and not P[:, npv:].any()
+    assert np.array_equal(M[:, :nmv], (A - A.transpose(0, 2, 1))[:, ils[0], ils[1]]) and not M[:, nmv:].any()
+    npo, nmo = o * (o + 1) // 2, o * (o - 1) // 2
+    Xp, Xm = rng.standard_normal((npo, ncols)), rng.standard_normal((nmo, ncols))
+    dXp, dXm, dO = DeviceBuffer.from_numpy(Xp), DeviceBuffer.from_numpy(Xm), DeviceBuffer(o * o * ncols)
+    check(qlib.qemb_op_scatter_pm_rows(o, ncols, dXp.ptr, dXm.ptr, dO.ptr))
+    out = dO.numpy((o, o, ncols))
+    for i in range(o):
+        for j in range(i + 1):
+            p = Xp[i * (i + 1) // 2 + j]
+            if i == j:
+                assert np.array_equal(out[i, i], p)
+            else:
+                m = Xm[i * (i - 1) // 2 + j]
+                assert np.array_equal(out[i, j], p + m) and np.array_equal(out[j, i], p - m)
+    x, y, z = rng.standard_normal(1000), rng.standard_normal(1000), rng.standard_normal(1000)
+    dx, dy, dz = DeviceBuffer.from_numpy(x), DeviceBuffer.from_numpy(y), DeviceBuffer.from_numpy(z)
+    check(qlib.qemb_op_lincomb2(1000, 2.0, dx.ptr, -0.5, dy.ptr, 3.0, dz.ptr))
+    assert np.abs(dz.numpy() - (2.0 * x - 0.5 * y + 3.0 * z)).max() < 1e-14
