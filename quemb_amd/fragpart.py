@@ -45,6 +45,17 @@ class FragPart:
     def all_centers_are_origins(self):
         return all(sorted(c) == sorted(o) for (_, c), o in zip(self.weight_and_relAO_per_center_per_frag, self.relAO_per_origin_per_frag))
 
+    def replicate_sites(self, k: int) -> "FragPart":
+        """The same fragmentation with k AOs per site (site a -> AOs k*a .. k*a+k-1): what the atom-based lists of a linear
+        H chain become in a basis with k functions per atom."""
+        ex = lambda lst: [k * a + j for a in lst for j in range(k)]
+        return FragPart(AO_per_frag=[ex(f) for f in self.AO_per_frag],
+                        AO_per_edge_per_frag=[[ex(e) for e in edges] for edges in self.AO_per_edge_per_frag],
+                        ref_frag_idx_per_edge_per_frag=[list(r) for r in self.ref_frag_idx_per_edge_per_frag],
+                        relAO_per_origin_per_frag=[ex(o) for o in self.relAO_per_origin_per_frag],
+                        weight_and_relAO_per_center_per_frag=[(w, ex(c)) for w, c in self.weight_and_relAO_per_center_per_frag],
+                        n_BE=self.n_BE)
+
     @classmethod
     def from_json(cls, path, key, n_BE=2):
         d = json.loads(Path(path).read_text())[key]

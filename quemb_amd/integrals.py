@@ -27,6 +27,13 @@ _STO3G = {
           ("s", [2.9412494, 0.6834831, 0.2222899], [-0.09996723, 0.39951283, 0.70011547]),
           ("p", [2.9412494, 0.6834831, 0.2222899], [0.15591627, 0.60768372, 0.39195739])],
 }
+# cc-pVDZ, hydrogen only (2s1p; EMSL / PySCF 'cc-pvdz'): a multi-AO-per-atom test basis for the s/p generator
+_CCPVDZ = {
+    "H": [("s", [13.0100000, 1.9620000, 0.4446000], [0.0196850, 0.1379770, 0.4781480]),
+          ("s", [0.1220000], [1.0]),
+          ("p", [0.7270000], [1.0])],
+}
+_BASES = {"sto-3g": _STO3G, "cc-pvdz": _CCPVDZ}
 _Z = {"H": 1, "C": 6}
 
 
@@ -60,8 +67,9 @@ def read_xyz(path):
 
 class Mole:
     def __init__(self, atom, basis="sto-3g", unit="Angstrom"):
-        if basis.lower() != "sto-3g":
-            raise NotImplementedError("only STO-3G (H, C) is built in")
+        if basis.lower() not in _BASES:
+            raise NotImplementedError("built-in bases: STO-3G (H, C), cc-pVDZ (H)")
+        table = _BASES[basis.lower()]
         if isinstance(atom, (str, Path)):
             atom = read_xyz(atom)
         scale = 1.0 / BOHR if unit.lower().startswith("a") else 1.0
@@ -70,7 +78,9 @@ class Mole:
         self.bfs = []
         self.ao_atom = []
         for ia, (sym, xyz) in enumerate(self.atom):
-            for l, exps, coefs in _STO3G[sym]:
+            if sym not in table:
+                raise NotImplementedError(f"no {basis} basis for {sym} is built in")
+            for l, exps, coefs in table[sym]:
                 comps = [(0, 0, 0)] if l == "s" else [(1, 0, 0), (0, 1, 0), (0, 0, 1)]
                 for lmn in comps:
                     self.bfs.append(self._make_bf(xyz, lmn, exps, coefs))

@@ -232,3 +232,24 @@ def test_concurrent_streams_give_identical_results(qlib):
     assert r3b[2][0] == r3[2][0]
     opt = be3.optimize(solver="CCSD", only_chem=False)
     assert opt.err < 1e-6 and abs(be3.e_corr - (-0.5499514850769742)) < 5e-6
+
+
+def test_h8_ccpvdz_hf_in_hf_and_oneshot_be2_vs_molecular_ccsd(qlib):
+    """H8 / cc-pVDZ (N = 40, p functions, 5 AOs per site): HF-in-HF (tests/hf-in-hf_BE_test.py:56-63) and the one-shot BE2 CCSD
+    correlation energy against the CCSD of the whole molecule run through the same device solver (BE2 is within 1e-3 Eh)."""
+    from quemb_amd.fragpart import FragPart
+    from quemb_amd.fragsolver import DeviceFragment, default_opts
+    from quemb_amd.integrals import RHF, Mole
+    from quemb_amd.mbe import BE
+    mol = Mole([["H", (0.0, 0.0, float(i))] for i in range(8)], basis="cc-pvdz")
+    mf = RHF(mol); mf.kernel()
+    N = mol.nao
+    w, U = np.linalg.eigh(mf.get_ovlp()); W = U @ np.diag(w ** -0.5) @ U.T
+    fr = DeviceFragment(N, N)
+    et.AOEri(mf._eri, N).transform(W, frag=fr, want_host=False)
+    out = fr.solve(mol.nelectron // 2, W.T @ mf.get_hcore() @ W, opts=default_opts(), eeval=False)
+    assert abs(out["e_scf"] + mf.energy_nuc() - mf.e_tot) < 1e-9            # the device RHF reproduces the molecular RHF
+    be = BE(mf, FragPart.from_json(GOLDEN / "fragmentation.json", "test_autogen_h_linear_be2").replicate_sites(5), distribute=False)
+    assert abs(be.hf_err) < 1e-9
+    e, _ = be.oneshot()
+    assert abs(e - out["e_corr_mo"]) < 2e-3, (e, out["e_corr_mo"])

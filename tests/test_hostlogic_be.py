@@ -307,3 +307,18 @@ def test_periodic_front_end_matches_reference_goldens(hlib):
     1-D periodic model (tests/golden/make_golden_kbe.py -> kbe.npz); see helpers.check_periodic_front_end."""
     from helpers import check_periodic_front_end
     check_periodic_front_end(hlib)
+
+
+def test_hf_in_hf_h8_ccpvdz_be1_be2_be3(hlib):
+    """tests/hf-in-hf_BE_test.py:56-63 for H8 / cc-pVDZ (the reference's second H8 basis): Schmidt + ERI transform + fragment Fock
+    reproduce the molecular HF energy, `ebe_hf == mf.e_tot` within 1e-5 (here 1e-9), for BE1, BE2, BE3.  The atom-based fixture
+    lists are replicated to the 5 AOs (2s1p) of each hydrogen."""
+    from quemb_amd.fragpart import FragPart
+    from quemb_amd.integrals import RHF, Mole
+    from quemb_amd.mbe import BE
+    mol = Mole([["H", (0.0, 0.0, float(i))] for i in range(8)], basis="cc-pvdz")
+    assert mol.nao == 40
+    mf = RHF(mol); mf.kernel()
+    for key in ("test_autogen_h_linear_be1", "test_autogen_h_linear_be2", "test_autogen_h_linear_be3"):
+        be = BE(mf, FragPart.from_json(GOLDEN / "fragmentation.json", key).replicate_sites(5), lib=hlib, distribute=False)
+        assert abs(be.hf_err) < 1e-9, (key, be.hf_err)
