@@ -54,7 +54,7 @@ def parse():
     ap.add_argument("--nocc", type=int, default=20)
     ap.add_argument("--scale", type=float, default=0.03)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-iters", type=int, default=1)
+    ap.add_argument("--cpu-iters", type=int, default=3, help="amplitude updates timed by the CPU baseline (about 4 s each on 16 threads)")
     ap.add_argument("--cpu-worker", type=str, default=None, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-threads", type=int, default=16, help="BLAS threads of the CPU baseline (the box's CPU share of one GPU)")
     return ap.parse_args()
