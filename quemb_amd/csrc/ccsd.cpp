@@ -227,8 +227,8 @@ int CcsdSolver::update_amps(double* t1n, double* t2n) {
   const int64_t o = o_, v = v_, nov = o * v, oo = o * o, vv = v * v, N2 = oo * vv;
   const double* t1 = this->t1();
   const double* t2 = this->t2();
-  // ---- amplitude layouts
-  QTRY(make_tau(t1, t2, tau_));
+  // ---- amplitude layouts.  tau_ already holds tau(t1, t2): every change of the amplitudes (init_amps, set_amps, iterate) ends
+  // with energy(), which builds it.
   QTRY(perm4(T_, t2, o, o, v, v, 0, 2, 1, 3));          // T [k,c,j,b] = t2[k,j,c,b]
   QTRY(perm4(Tp_, t2, o, o, v, v, 0, 3, 1, 2));         // Tp[k,c,j,b] = t2[k,j,b,c]
 
@@ -273,14 +273,14 @@ int CcsdSolver::update_amps(double* t1n, double* t2n) {
   QTRY(gemm_tn(o, v, o * v * o, -1.0, Lovoo_, T_, 1.0, t1n));                      // -(2 ovoo[lcki] - ovoo[kcli]) t2[klac]
 
   // ---- T2 equation: direct (unsymmetrised) part
-  QTRY(dcopy(N2, OVoovv_, t2n));                                                   // ovov[i,a,j,b]
+  // (the bare ovov[i,a,j,b] term is added by the finishing kernel)
   // Woooo[k,l,i,j]
   QTRY(dcopy(oo * oo, oooo_p_, Wo_));
   QTRY(gemm_nt(oo, oo, vv, 1.0, OVoovv_, tau_, 1.0, Wo_));                         // ovov[kcld] tau[ijcd]
   QTRY(gemm(o, oo, v, 1.0, t1, v, true, I_.ovoo, oo, false, 0.0, O1_, oo, o, 0, v * oo, o * oo));   // O1[l,j,k,i]
   QTRY(perm4(Wo_, O1_, o, o, o, o, 2, 0, 3, 1, 1.0, 1.0));                         // + ovoo[lcki] t1[jc]
   QTRY(perm4(Wo_, O1_, o, o, o, o, 0, 2, 1, 3, 1.0, 1.0));                         // + ovoo[kclj] t1[ic]
-  QTRY(gemm_tn(oo, vv, oo, 1.0, Wo_, tau_, 1.0, t2n));                             // Woooo[klij] tau[klab]
+  QTRY(gemm_tn(oo, vv, oo, 1.0, Wo_, tau_, 0.0, t2n));                             // Woooo[klij] tau[klab]  (first writer of t2n)
   // pp-ladder (the dominant kernel)
   // R_ijab = sum_cd (ac|bd) tau_ijcd through pair-packed symmetric / antisymmetric combinations:
   //   R = R+ + R-,  R+[P(ij),P(ab)] = sum_{c>=d} Vp[P(ab),P(cd)] Tp[P(ij),P(cd)],  R-[Q(ij),Q(ab)] = sum_{c>d} Vm Tm,
@@ -364,10 +364,8 @@ int CcsdSolver::update_amps(double* t1n, double* t2n) {
   QTRY(dev_timer_end(TIMER_RINGS));
 
   // ---- symmetrise and divide
-  QTRY(axpby(N2, 1.0, U_, 1.0, t2n));
-  QTRY(perm4(t2n, U_, o, o, v, v, 1, 0, 3, 2, 1.0, 1.0));
   QTRY(dev_div_denom(t1n, o, 1, v, 1, eo_, nullptr, ev_, nullptr));
-  QTRY(dev_div_denom(t2n, o, o, v, v, eo_, eo_, ev_, ev_));
+  QTRY(dev_ccsd_finish_t2(o, v, t2n, U_, OVoovv_, eo_, ev_));                      // (t2n + ovov + U + U^T(ji,ba)) / D in one pass
   return 0;
 }
 

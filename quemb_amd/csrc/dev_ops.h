@@ -144,6 +144,8 @@ int dev_ladder_pack_tau(int64_t o, int64_t v, const double* tau, double* Tp, int
 int dev_pack_pm_cols(int64_t rows, int64_t v, const double* in, double* Op, int64_t ldp, double* Om, int64_t ldm);
 // out[i,j,:] = Xp[P(i,j),:] + Xm[Q(i,j),:],  out[j,i,:] = Xp[P(i,j),:] - Xm[Q(i,j),:]  (i > j),  out[i,i,:] = Xp[P(i,i),:]
 int dev_scatter_pm_rows(int64_t o, int64_t ncols, const double* Xp, const double* Xm, double* out);
+// CCSD doubles update, last step in one pass:  t2n[i,j,a,b] = (t2n[i,j,a,b] + OV[i,j,a,b] + U[i,j,a,b] + U[j,i,b,a]) / (eo[i]+eo[j]-ev[a]-ev[b])
+int dev_ccsd_finish_t2(int64_t o, int64_t v, double* t2n, const double* U, const double* OV, const double* eo, const double* ev);
 int dev_ladder_scatter_pm(int64_t o, int64_t v, const double* Rp, int64_t ldp, const double* Rm, int64_t ldm, double* t2);
 
 // ---- screening helpers of the semi-sparse DF transform ---------------------------------------------------------------
@@ -157,6 +159,8 @@ int dev_mul_bcast_rows(int64_t rows, int64_t cols, double* x, const double* m);
 int dev_dot(int64_t n, const double* x, const double* y, double* out_dev);
 // out_dev[0] = max_i |x[i]|
 int dev_absmax(int64_t n, const double* x, double* out_dev);
+// out_dev[j] = <x, ys[j]> for j < m <= 8 in one pass over x (each result bit-identical to dev_dot)
+int dev_dot_many(int64_t n, const double* x, int m, const double* const* ys, double* out_dev);
 
 // ---- matrix-vector style contractions for J/K builds (HBM bound) -------------------------------
 // y[r] = alpha * sum_c T[r*ldt + c] * x[c] + beta*y[r]        r < rows, c < cols

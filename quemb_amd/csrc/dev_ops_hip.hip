@@ -37,7 +37,7 @@ static constexpr int NPART = 2048;
 struct DevCtx {
   hipStream_t stream = nullptr;
   bool capturing = false;            // inside hipStreamBeginCapture .. EndCapture (dev_graph_*)
-  double* partials = nullptr;        // reduction scratch (NPART doubles)
+  double* partials = nullptr;        // reduction scratch (8 x NPART doubles: up to eight dot products per pass)
   double* ws = nullptr;              // growable workspace for contract_mid / k_pairs partials
   size_t ws_bytes = 0;
   double* gws = nullptr;             // split-K partial-sum workspace of the GEMM
@@ -79,7 +79,7 @@ int dev_init(int device) {
   HIP_TRY(hipSetDevice(device));
   if (c.stream) { (void)hipStreamDestroy(c.stream); c = DevCtx(); }
   HIP_TRY(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
-  HIP_TRY(hipMalloc((void**)&c.partials, NPART * sizeof(double)));
+  HIP_TRY(hipMalloc((void**)&c.partials, 8 * NPART * sizeof(double)));
   g_device = device;
   return QEMB_OK;
 }
@@ -91,7 +91,7 @@ int dev_ctx_count(int n) {
   while ((int)g_extra_ctx.size() + 1 < n) {
     DevCtx* c = new DevCtx();
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipMalloc((void**)&c->partials, NPART * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&c->partials, 8 * NPART * sizeof(double));
     if (e != hipSuccess) { delete c; set_error(std::string("dev_ctx_count: ") + hipGetErrorString(e)); return QEMB_ERR_DEVICE; }
     g_extra_ctx.push_back(c);
   }
@@ -728,6 +728,43 @@ int dev_scatter_pm_rows(int64_t o, int64_t ncols, const double* Xp, const double
   HIP_TRY(hipGetLastError());
   return QEMB_OK;
 }
+// grid (32 x 32 tiles of (a,b), o*o): U[j,i,b,a] is read with a fastest (coalesced) and transposed through LDS
+__global__ void __launch_bounds__(256) ccsd_finish_t2_kernel(long long o, long long v, double* __restrict__ t2n, const double* __restrict__ U,
+                                                            const double* __restrict__ OV, const double* __restrict__ eo, const double* __restrict__ ev) {
+  __shared__ double tile[32][33];
+  const long long ij = blockIdx.y, i = ij / o, j = ij - i * o;
+  const long long nt = (v + 31) / 32;
+  const long long ta = blockIdx.x / nt, tb = blockIdx.x - ta * nt;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const double* Uji = U + (j * o + i) * v * v;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {      // tile[bb][aa] = U[j,i,b,a]
+    const int bb = ty + 8 * k;
+    const long long b = tb * 32 + bb, a = ta * 32 + tx;
+    tile[bb][tx] = (a < v && b < v) ? Uji[b * v + a] : 0.0;
+  }
+  __syncthreads();
+  const double eij = eo[i] + eo[j];
+  const long long base = ij * v * v;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int aa = ty + 8 * k;
+    const long long a = ta * 32 + aa, b = tb * 32 + tx;
+    if (a < v && b < v) {
+      const long long idx = base + a * v + b;
+      t2n[idx] = (t2n[idx] + OV[idx] + U[idx] + tile[tx][aa]) / (eij - ev[a] - ev[b]);
+    }
+  }
+}
+int dev_ccsd_finish_t2(int64_t o, int64_t v, double* t2n, const double* U, const double* OV, const double* eo, const double* ev) {
+  REQUIRE_INIT();
+  if (o <= 0 || v <= 0) return QEMB_OK;
+  if (o * o > 65535) { set_error("dev_ccsd_finish_t2: too many occupied pairs"); return QEMB_ERR_ARG; }
+  const long long nt = (v + 31) / 32;
+  hipLaunchKernelGGL(ccsd_finish_t2_kernel, dim3((unsigned)(nt * nt), (unsigned)(o * o)), dim3(256), 0, g_stream, (long long)o, (long long)v, t2n, U, OV, eo, ev);
+  HIP_TRY(hipGetLastError());
+  return QEMB_OK;
+}
 // grid (lower-triangle 32 x 32 tiles of (a,b), npair(o)): the tile of R+/R- is staged through LDS so that both the [a][b] image
 // and its mirror [b][a] are updated in 256-byte runs, for t2[i,j] and t2[j,i].
 __global__ void __launch_bounds__(256) ladder_scatter_pm_kernel(long long o, long long v, const double* __restrict__ Rp, long long ldp,
@@ -831,6 +868,46 @@ int dev_dot(int64_t n, const double* x, const double* y, double* out_dev) {
   const int np = (int)std::max<int64_t>(1, std::min<int64_t>((n + 1023) / 1024, NPART));
   hipLaunchKernelGGL(reduce_stage1<false>, dim3(np), dim3(256), 0, g_stream, (long long)n, x, y, g_partials);
   hipLaunchKernelGGL(reduce_stage2<false>, dim3(1), dim3(256), 0, g_stream, np, g_partials, out_dev);
+  HIP_TRY(hipGetLastError());
+  return QEMB_OK;
+}
+// out[j] = <x, ys[j]>, j < m <= 8, reading x once.  Same partition and summation order as dev_dot, so each result is
+// bit-identical to the single dot product.
+struct DotManyK { const double* y[8]; int m; };
+__global__ void __launch_bounds__(256) dot_many_stage1(long long n, const double* __restrict__ x, DotManyK k, double* __restrict__ partial, int np) {
+  __shared__ double sh[4];
+  double acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const double xi = x[i];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) if (j < k.m) acc[j] += xi * k.y[j][i];
+  }
+  for (int j = 0; j < k.m; ++j) {
+    const double r = block_reduce<false>(acc[j], sh);
+    if (threadIdx.x == 0) partial[(long long)j * np + blockIdx.x] = r;
+    __syncthreads();
+  }
+}
+__global__ void __launch_bounds__(256) dot_many_stage2(int np, const double* __restrict__ partial, double* __restrict__ out) {
+  __shared__ double sh[4];
+  const int j = blockIdx.x;
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < np; i += blockDim.x) acc += partial[(long long)j * np + i];
+  const double r = block_reduce<false>(acc, sh);
+  if (threadIdx.x == 0) out[j] = r;
+}
+int dev_dot_many(int64_t n, const double* x, int m, const double* const* ys, double* out_dev) {
+  REQUIRE_INIT();
+  if (m <= 0) return QEMB_OK;
+  if (m > 8) { set_error("dev_dot_many: at most 8 vectors"); return QEMB_ERR_ARG; }
+  const int np = (int)std::max<int64_t>(1, std::min<int64_t>((n + 1023) / 1024, NPART));
+  DotManyK k{};
+  k.m = m;
+  for (int j = 0; j < m; ++j) k.y[j] = ys[j];
+  hipLaunchKernelGGL(dot_many_stage1, dim3(np), dim3(256), 0, g_stream, (long long)n, x, k, g_partials, np);
+  hipLaunchKernelGGL(dot_many_stage2, dim3(m), dim3(256), 0, g_stream, np, (const double*)g_partials, out_dev);
   HIP_TRY(hipGetLastError());
   return QEMB_OK;
 }

@@ -163,7 +163,12 @@ class DeviceDIIS {
     ++count_;
     const int m = size();
     // refresh row/column `slot` of the Gram matrix
-    for (int j = 0; j < m; ++j) QTRY(dev_dot(n_, es_[slot], es_[j], scal_.p + j));
+    for (int j0 = 0; j0 < m; j0 += 8) {   // one pass over the new error vector per eight stored ones
+      const int cnt = std::min(8, m - j0);
+      const double* ps[8];
+      for (int q = 0; q < cnt; ++q) ps[q] = es_[j0 + q].p;
+      QTRY(dev_dot_many(n_, es_[slot], cnt, ps, scal_.p + j0));
+    }
     std::vector<double> row(m);
     QTRY(dev_d2h(row.data(), scal_.p, sizeof(double) * m));
     for (int j = 0; j < m; ++j) { B_[(size_t)slot * space_ + j] = row[j]; B_[(size_t)j * space_ + slot] = row[j]; }

@@ -199,6 +199,17 @@ int dev_ladder_scatter_pm(int64_t o, int64_t v, const double* Rp, int64_t ldp, c
 int dev_threshold_mask(int64_t n, const double* x, double eps, double* out) { for (int64_t i = 0; i < n; ++i) out[i] = std::fabs(x[i]) >= eps ? 1.0 : 0.0; return 0; }
 int dev_mul_bcast_rows(int64_t rows, int64_t cols, double* x, const double* m) { for (int64_t r = 0; r < rows; ++r) for (int64_t c = 0; c < cols; ++c) x[r * cols + c] *= m[c]; return 0; }
 int dev_dot(int64_t n, const double* x, const double* y, double* o) { long double s = 0; for (int64_t i = 0; i < n; ++i) s += (long double)x[i] * y[i]; *o = (double)s; return 0; }
+int dev_ccsd_finish_t2(int64_t o, int64_t v, double* t2n, const double* U, const double* OV, const double* eo, const double* ev) {
+  for (int64_t i = 0; i < o; ++i) for (int64_t j = 0; j < o; ++j) for (int64_t a = 0; a < v; ++a) for (int64_t b = 0; b < v; ++b) {
+    const int64_t idx = ((i * o + j) * v + a) * v + b;
+    t2n[idx] = (t2n[idx] + OV[idx] + U[idx] + U[((j * o + i) * v + b) * v + a]) / (eo[i] + eo[j] - ev[a] - ev[b]);
+  }
+  return 0;
+}
+int dev_dot_many(int64_t n, const double* x, int m, const double* const* ys, double* o) {
+  for (int j = 0; j < m; ++j) { double s = 0; for (int64_t i = 0; i < n; ++i) s += x[i] * ys[j][i]; o[j] = s; }
+  return 0;
+}
 int dev_absmax(int64_t n, const double* x, double* o) { double m = 0; for (int64_t i = 0; i < n; ++i) m = std::max(m, std::fabs(x[i])); *o = m; return 0; }
 int dev_gemv_rows(int64_t rows, int64_t cols, const double* T, int64_t ldt, const double* x, double* y, double alpha, double beta) {
   for (int64_t r = 0; r < rows; ++r) { double s = 0; for (int64_t c = 0; c < cols; ++c) s += T[r * ldt + c] * x[c]; y[r] = (beta != 0.0) ? alpha * s + beta * y[r] : alpha * s; }
