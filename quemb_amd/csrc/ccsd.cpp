@@ -150,12 +150,11 @@ int CcsdSolver::setup(MoIntegrals&& ints, const double* mo_energy_dev) {
 
 int CcsdSolver::make_tau(const double* t1, const double* t2, double* tau) {
   const int64_t o = o_, v = v_;
-  QTRY(dcopy(o * o * v * v, t2, tau));
   Outer4Desc d{};
   d.dim[0] = o; d.dim[1] = o; d.dim[2] = v; d.dim[3] = v;
   d.u = t1; d.su0 = v; d.su2 = 1; d.v = t1; d.sv1 = v; d.sv3 = 1;
   d.out = tau; d.so[0] = o * v * v; d.so[1] = v * v; d.so[2] = v; d.so[3] = 1;
-  d.alpha = 1.0; d.beta = 1.0;
+  d.alpha = 1.0; d.beta = 1.0; d.base = t2;          // tau = t2 + t1 (x) t1 in one pass
   return dev_outer4(d);
 }
 
@@ -331,30 +330,28 @@ int CcsdSolver::update_amps(double* t1n, double* t2n) {
   //   Wvoov += 1/4 u~ L - 1/4 Tp~ ovov_t,      Wvovo -= 1/2 Tp~ ovov_t
   // (expand: 1/4 (2T - Tp)(2 ovov - ovov_t) = (T - Tp/2) ovov - T ovov_t / 2 + Tp ovov_t / 4, and the t1(x)t1 pieces
   // reproduce -ovov[ldkc] t1[id] t1[la] and -ovov[lckd] t1[id] t1[la]).
-  auto add_t1t1 = [&](double* dst, double alpha) {
+  auto add_t1t1 = [&](double* dst, double alpha, const double* src) {   // dst = src + alpha t1 (x) t1
     Outer4Desc d{};   // loop (l,i,a,d), d fastest = contiguous in dst[i,a,l,d]: u = t1[l,a], v = t1[i,d]
     d.dim[0] = o; d.dim[1] = o; d.dim[2] = v; d.dim[3] = v;
     d.u = t1; d.su0 = v; d.su2 = 1; d.v = t1; d.sv1 = v; d.sv3 = 1;
     d.out = dst; d.so[0] = v; d.so[1] = v * o * v; d.so[2] = o * v; d.so[3] = 1;
-    d.alpha = alpha; d.beta = 1.0;
+    d.alpha = alpha; d.beta = 1.0; d.base = src;
     return dev_outer4(d);
   };
   QTRY(lincomb2(N2, 2.0, T_, -1.0, Tp_, S_));                                      // S = u = 2T - Tp   (kept for the update)
-  QTRY(dcopy(N2, S_, W12_)); QTRY(add_t1t1(W12_, -2.0));                           // W12 (scratch) = u~
-  QTRY(dcopy(N2, W1base_, W1_));
-  QTRY(perm4(W1_, ZB_, o, v, v, o, 3, 2, 0, 1, 1.0, 1.0));                         // + ovvv[kcad] t1[id]
+  QTRY(add_t1t1(W12_, -2.0, S_));                                                  // W12 (scratch) = u~ = u - 2 t1(x)t1
+  QTRY(perm4(W1_, ZB_, o, v, v, o, 3, 2, 0, 1, 1.0, 1.0, W1base_));                // W1 = W1base + ovvv[kcad] t1[id]
   QTRY(gemm(o, v, o, 1.0, I_.ovoo, o, false, t1, v, false, 0.0, G1_, v, nov, oo, 0, nov));   // G1[k,c,i,a] = ovoo[kcli] t1[la]
   QTRY(perm4(W1_, G1_, o, v, o, v, 2, 3, 0, 1, -1.0, 1.0));
   QTRY(gemm_nn(nov, nov, nov, 0.25, W12_, Lovov_, 1.0, W1_));                      // + 1/4 u~ L
   //   W2[(ia),(kc)] = Wvovo[a,k,c,i]
-  QTRY(dcopy(N2, W2base_, W2_));
-  QTRY(perm4(W2_, ZC_, o, o, v, v, 1, 2, 0, 3, 1.0, 1.0));                         // + t1[id] ovvv[kdac]
+  QTRY(perm4(W2_, ZC_, o, o, v, v, 1, 2, 0, 3, 1.0, 1.0, W2base_));                // W2 = W2base + t1[id] ovvv[kdac]
   QTRY(gemm_tn(v, v * oo, o, 1.0, t1, I_.ovoo, 0.0, G1_));                         // G1[a,c,k,i] = t1[la] ovoo[lcki]
   QTRY(perm4(W2_, G1_, v, v, o, o, 3, 0, 2, 1, -1.0, 1.0));
   // The Tp~ ovov_t product enters Wvoov with -1/4 and Wvovo with -1/2, so it cancels in Wvoov - Wvovo/2: form that
   // combination first (R), then let the GEMM accumulate the product straight into Wvovo.
   QTRY(lincomb2(N2, 1.0, W1_, -0.5, W2_, R_));                                     // R = Wvoov - Wvovo/2
-  QTRY(dcopy(N2, Tp_, W12_)); QTRY(add_t1t1(W12_, 2.0));                           // W12 (scratch) = Tp~
+  QTRY(add_t1t1(W12_, 2.0, Tp_));                                                  // W12 (scratch) = Tp~ = Tp + 2 t1(x)t1
   QTRY(gemm_nn(nov, nov, nov, -0.5, W12_, ovov_t_, 1.0, W2_));                     // Wvovo -= 1/2 Tp~ ovov_t
   // Update, also two products:  (2 Wvoov - Wvovo) T - Wvoov Tp = (Wvoov - Wvovo/2) u - (Wvovo Tp)/2  with T = (u + Tp)/2
   QTRY(gemm_nn(nov, nov, nov, 1.0, W2_, Tp_, 0.0, W1_));                           // A3 = Wvovo[bkci] t2[kjac] at W1[i,b,j,a]

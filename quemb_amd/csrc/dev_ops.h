@@ -89,6 +89,7 @@ struct Copy4Desc {
   const double* in; int64_t si[4];
   double* out; int64_t so[4];
   double alpha, beta;
+  const double* base = nullptr;   // out = alpha*in + beta*base, base addressed like out (nullptr: base = out, i.e. accumulate in place)
 };
 int dev_copy4(const Copy4Desc& c);
 
@@ -100,6 +101,7 @@ struct Outer4Desc {
   const double* v; int64_t sv1, sv3;
   double* out; int64_t so[4];
   double alpha, beta;
+  const double* base = nullptr;   // out = alpha*u(x)v + beta*base, base addressed like out (nullptr: base = out)
 };
 int dev_outer4(const Outer4Desc& c);
 // out = sum_{k < nterms} coef[k] * xs[k] + beta * out over n contiguous elements, one pass (nterms <= 8; out may alias any xs[k])

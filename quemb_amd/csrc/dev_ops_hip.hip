@@ -318,7 +318,7 @@ int dev_fill(double* x, int64_t n, double value) {
 struct Copy4K {
   long long d0, d1, d2, d3;
   long long si0, si1, si2, si3, so0, so1, so2, so3;
-  const double* in; double* out; double alpha, beta;
+  const double* in; double* out; double alpha, beta; const double* base;
 };
 
 __global__ void __launch_bounds__(256) copy4_linear_kernel(Copy4K c) {
@@ -331,8 +331,8 @@ __global__ void __launch_bounds__(256) copy4_linear_kernel(Copy4K c) {
            t += (long long)gridDim.x * blockDim.x) {
         const long long i2 = t / c.d3, i3 = t - i2 * c.d3;
         const double v = c.alpha * c.in[bi + i2 * c.si2 + i3 * c.si3];
-        double* p = c.out + bo + i2 * c.so2 + i3 * c.so3;
-        *p = (c.beta != 0.0) ? v + c.beta * (*p) : v;
+        const long long off = bo + i2 * c.so2 + i3 * c.so3;
+        c.out[off] = (c.beta != 0.0) ? v + c.beta * c.base[off] : v;
       }
     }
   }
@@ -358,8 +358,8 @@ __global__ void __launch_bounds__(256) copy4_transpose_kernel(Copy4K c, int tile
         const long long i3 = base3 + ty + 8 * r, i2 = base2 + tx;
         if (i2 < c.d2 && i3 < c.d3) {
           const double v = c.alpha * tile[tx][ty + 8 * r];
-          double* p = c.out + bo + i2 * c.so2 + i3 * c.so3;
-          *p = (c.beta != 0.0) ? v + c.beta * (*p) : v;
+          const long long off = bo + i2 * c.so2 + i3 * c.so3;
+          c.out[off] = (c.beta != 0.0) ? v + c.beta * c.base[off] : v;
         }
       }
       __syncthreads();
@@ -389,7 +389,7 @@ int dev_copy4(const Copy4Desc& cd) {
   c.d0 = d[0]; c.d1 = d[1]; c.d2 = d[2]; c.d3 = d[3];
   c.si0 = si[0]; c.si1 = si[1]; c.si2 = si[2]; c.si3 = si[3];
   c.so0 = so[0]; c.so1 = so[1]; c.so2 = so[2]; c.so3 = so[3];
-  c.in = cd.in; c.out = cd.out; c.alpha = cd.alpha; c.beta = cd.beta;
+  c.in = cd.in; c.out = cd.out; c.alpha = cd.alpha; c.beta = cd.beta; c.base = cd.base ? cd.base : cd.out;
   if (c.d2 * c.d3 >= (1LL << 40)) { set_error("dev_copy4: inner extent too large"); return QEMB_ERR_ARG; }
   const unsigned gy = (unsigned)std::min<long long>(c.d1, 65535), gz = (unsigned)std::min<long long>(c.d0, 65535);
   if (transpose) {
@@ -410,7 +410,7 @@ int dev_copy4(const Copy4Desc& cd) {
 // ------------------------------------------------------------------------------------------------
 struct Outer4K {
   long long d0, d1, d2, d3, su0, su2, sv1, sv3, so0, so1, so2, so3;
-  const double* u; const double* v; double* out; double alpha, beta;
+  const double* u; const double* v; double* out; double alpha, beta; const double* base;
 };
 __global__ void __launch_bounds__(256) outer4_kernel(Outer4K c) {
   const long long n23 = c.d2 * c.d3;
@@ -419,14 +419,14 @@ __global__ void __launch_bounds__(256) outer4_kernel(Outer4K c) {
       for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n23; t += (long long)gridDim.x * blockDim.x) {
         const long long i2 = t / c.d3, i3 = t - i2 * c.d3;
         const double val = c.alpha * c.u[i0 * c.su0 + i2 * c.su2] * c.v[i1 * c.sv1 + i3 * c.sv3];
-        double* p = c.out + i0 * c.so0 + i1 * c.so1 + i2 * c.so2 + i3 * c.so3;
-        *p = (c.beta != 0.0) ? val + c.beta * (*p) : val;
+        const long long off = i0 * c.so0 + i1 * c.so1 + i2 * c.so2 + i3 * c.so3;
+        c.out[off] = (c.beta != 0.0) ? val + c.beta * c.base[off] : val;
       }
 }
 int dev_outer4(const Outer4Desc& o) {
   REQUIRE_INIT();
   for (int k = 0; k < 4; ++k) if (o.dim[k] <= 0) return QEMB_OK;
-  Outer4K c{o.dim[0], o.dim[1], o.dim[2], o.dim[3], o.su0, o.su2, o.sv1, o.sv3, o.so[0], o.so[1], o.so[2], o.so[3], o.u, o.v, o.out, o.alpha, o.beta};
+  Outer4K c{o.dim[0], o.dim[1], o.dim[2], o.dim[3], o.su0, o.su2, o.sv1, o.sv3, o.so[0], o.so[1], o.so[2], o.so[3], o.u, o.v, o.out, o.alpha, o.beta, o.base ? o.base : o.out};
   const long long n23 = c.d2 * c.d3;
   const unsigned gx = (unsigned)std::min<long long>((n23 + 255) / 256, 1 << 20);
   hipLaunchKernelGGL(outer4_kernel, dim3(gx, (unsigned)std::min<long long>(c.d1, 65535), (unsigned)std::min<long long>(c.d0, 65535)), dim3(256), 0, g_stream, c);

@@ -72,7 +72,7 @@ inline int lincomb2(int64_t n, double a, const double* x, double b, const double
 
 // dst (contiguous, dims d[perm[0..3]]) = alpha * transpose(src, perm) + beta * dst;  src contiguous dims d
 inline int perm4(double* dst, const double* src, int64_t d0, int64_t d1, int64_t d2, int64_t d3, int p0, int p1, int p2,
-                 int p3, double alpha = 1.0, double beta = 0.0) {
+                 int p3, double alpha = 1.0, double beta = 0.0, const double* base = nullptr) {
   const int64_t d[4] = {d0, d1, d2, d3};
   const int perm[4] = {p0, p1, p2, p3};
   int64_t od[4], ostr[4];
@@ -83,6 +83,7 @@ inline int perm4(double* dst, const double* src, int64_t d0, int64_t d1, int64_t
   c.si[3] = 1; c.si[2] = d[3]; c.si[1] = d[3] * d[2]; c.si[0] = d[3] * d[2] * d[1];
   for (int k = 0; k < 4; ++k) { c.dim[k] = d[k]; }
   for (int k = 0; k < 4; ++k) c.so[perm[k]] = ostr[k];
+  c.base = base;      // dst = alpha * transpose(src) + beta * base  (base laid out like dst; nullptr: accumulate into dst)
   return dev_copy4(c);
 }
 

@@ -68,16 +68,18 @@ int dev_gemm(const GemmDesc& g) {
 int dev_copy4(const Copy4Desc& c) {
   for (int64_t i0 = 0; i0 < c.dim[0]; ++i0) for (int64_t i1 = 0; i1 < c.dim[1]; ++i1) for (int64_t i2 = 0; i2 < c.dim[2]; ++i2) for (int64_t i3 = 0; i3 < c.dim[3]; ++i3) {
     const double v = c.alpha * c.in[i0 * c.si[0] + i1 * c.si[1] + i2 * c.si[2] + i3 * c.si[3]];
-    double* p = c.out + i0 * c.so[0] + i1 * c.so[1] + i2 * c.so[2] + i3 * c.so[3];
-    *p = (c.beta != 0.0) ? v + c.beta * (*p) : v;
+    const int64_t off = i0 * c.so[0] + i1 * c.so[1] + i2 * c.so[2] + i3 * c.so[3];
+    const double* base = c.base ? c.base : c.out;
+    c.out[off] = (c.beta != 0.0) ? v + c.beta * base[off] : v;
   }
   return 0;
 }
 int dev_outer4(const Outer4Desc& c) {
   for (int64_t i0 = 0; i0 < c.dim[0]; ++i0) for (int64_t i1 = 0; i1 < c.dim[1]; ++i1) for (int64_t i2 = 0; i2 < c.dim[2]; ++i2) for (int64_t i3 = 0; i3 < c.dim[3]; ++i3) {
     const double v = c.alpha * c.u[i0 * c.su0 + i2 * c.su2] * c.v[i1 * c.sv1 + i3 * c.sv3];
-    double* p = c.out + i0 * c.so[0] + i1 * c.so[1] + i2 * c.so[2] + i3 * c.so[3];
-    *p = (c.beta != 0.0) ? v + c.beta * (*p) : v;
+    const int64_t off = i0 * c.so[0] + i1 * c.so[1] + i2 * c.so[2] + i3 * c.so[3];
+    const double* base = c.base ? c.base : c.out;
+    c.out[off] = (c.beta != 0.0) ? v + c.beta * base[off] : v;
   }
   return 0;
 }
