@@ -1000,7 +1000,7 @@ int dev_contract_mid(int64_t outer, int64_t mid, int64_t inner, const double* T,
   if (outer > 65535) { set_error("dev_contract_mid: outer too large"); return QEMB_ERR_ARG; }
   // enough (p, chunk) workgroups to cover the chip: ~2048 in total, at least 8 rows of T per chunk
   const int64_t rblocks = std::min<int64_t>((inner + 255) / 256, 1024);
-  int nchunk = (int)std::max<int64_t>(1, std::min<int64_t>(mid / 8, std::max<int64_t>(1, (4096 + outer * rblocks - 1) / (outer * rblocks))));
+  int nchunk = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(mid / 8, 128), std::max<int64_t>(1, (4096 + outer * rblocks - 1) / (outer * rblocks))));   // <= 128 partial slabs: stage 2 sums them serially
   int rc = ensure_ws((size_t)outer * nchunk * inner * sizeof(double));
   if (rc) return rc;
   hipLaunchKernelGGL(contract_mid_stage1, dim3(nchunk, (unsigned)outer, (unsigned)rblocks), dim3(256), 0, g_stream, (long long)mid, (long long)inner, nchunk, T, x, g_ws);

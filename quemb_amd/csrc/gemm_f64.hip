@@ -244,6 +244,28 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const double* __rest
     *c = (beta != 0.0) ? alpha * acc + beta * (*c) : alpha * acc;
   }
 }
+// Few outputs, many slabs (the o x o / v x v shaped intermediates with K = o v^2 split several hundred ways): one WAVE per
+// output element, lane l sums slabs l, l+64, ... and the 64 partial sums are combined in a fixed butterfly order.
+__global__ void __launch_bounds__(256) splitk_reduce_wave_kernel(const double* __restrict__ ws, int S, long long M, long long N,
+                                                                 double* __restrict__ C, long long ldc, long long strideC,
+                                                                 double alpha, double beta) {
+  const long long mn = M * N;
+  const long long b = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+  for (long long t = wave; t < mn; t += nwaves) {
+    double acc = 0.0;
+    const double* p = ws + b * S * mn + t;
+    for (int s = lane; s < S; s += 64) acc += p[(long long)s * mn];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if (lane == 0) {
+      const long long m = t / N, n = t - m * N;
+      double* c = C + b * strideC + m * ldc + n;
+      *c = (beta != 0.0) ? alpha * acc + beta * (*c) : alpha * acc;
+    }
+  }
+}
 
 double* gemm_workspace(size_t bytes);   // dev_ops_hip.hip
 
@@ -296,9 +318,15 @@ static int launch_cfg(const GemmDesc& d, hipStream_t s) {
   hipLaunchKernelGGL(kern, grid, block, lds, s, g);
   if (g.ksplit > 1) {
     const long long mn = d.M * d.N;
-    const unsigned gx = (unsigned)((mn + 255) / 256 < 2048 ? (mn + 255) / 256 : 2048);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(gx, (unsigned)d.batch), dim3(256), 0, s, (const double*)g.C, g.ksplit,
-                       (long long)d.M, (long long)d.N, d.C, (long long)d.ldc, (long long)d.strideC, d.alpha, d.beta);
+    if (g.ksplit >= 128 && mn <= 65536) {
+      const unsigned gx = (unsigned)((mn + 3) / 4 < 4096 ? (mn + 3) / 4 : 4096);      // 4 waves per block, one wave per element
+      hipLaunchKernelGGL(splitk_reduce_wave_kernel, dim3(gx, (unsigned)d.batch), dim3(256), 0, s, (const double*)g.C, g.ksplit,
+                         (long long)d.M, (long long)d.N, d.C, (long long)d.ldc, (long long)d.strideC, d.alpha, d.beta);
+    } else {
+      const unsigned gx = (unsigned)((mn + 255) / 256 < 2048 ? (mn + 255) / 256 : 2048);
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3(gx, (unsigned)d.batch), dim3(256), 0, s, (const double*)g.C, g.ksplit,
+                         (long long)d.M, (long long)d.N, d.C, (long long)d.ldc, (long long)d.strideC, d.alpha, d.beta);
+    }
   }
   HIP_TRY(hipGetLastError());
   return QEMB_OK;
