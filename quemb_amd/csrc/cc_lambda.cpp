@@ -139,13 +139,9 @@ int CcLambda::setup() {
   buf_.clear(); buf_.resize(kNumTensors);
   ptr_.assign(kNumTensors, nullptr);
   cache_.clear();
-  // ovvo / oovv were folded into W1base / W2base by CcsdSolver::setup: W1base[i,a,k,c] = ovvo[k,c,a,i], W2base[i,a,k,c] = oovv[k,i,a,c]
-  QTRY(ovvo_.alloc(N2)); QTRY(oovv_.alloc(N2));
-  QTRY(perm4(ovvo_, cc_.W1base_, o, v, o, v, 2, 3, 1, 0));
-  QTRY(perm4(oovv_, cc_.W2base_, o, v, o, v, 2, 0, 1, 3));
   struct { const char* name; double* p; } ext[] = {
       {"t1", cc_.t1()}, {"t2", cc_.t2()}, {"oooo", cc_.I_.oooo.p}, {"ovoo", cc_.I_.ovoo.p}, {"ovov", cc_.I_.ovov.p},
-      {"oovv", oovv_.p}, {"ovvo", ovvo_.p}, {"ovvv", cc_.I_.ovvv.p}};
+      {"oovv", cc_.I_.oovv.p}, {"ovvo", cc_.I_.ovvo.p}, {"ovvv", cc_.I_.ovvv.p}};
   for (auto& e : ext) {
     const int id = id_of(e.name);
     if (id < 0 || !e.p) { set_error("cc_lambda: missing input tensor"); return QEMB_ERR_ARG; }

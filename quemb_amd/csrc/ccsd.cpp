@@ -127,8 +127,7 @@ int CcsdSolver::setup(MoIntegrals&& ints, const double* mo_energy_dev) {
     QTRY(dev_pack_pm_cols(nov, v, OVl, OVp_, I_.ldp, OVm_, I_.ldm));
   }
   QTRY(perm4(oooo_p_, I_.oooo, o, o, o, o, 0, 2, 1, 3));                 // oooo_p[k,l,i,j] = oooo[k,i,l,j]
-  // ovvo / oovv are no longer needed once W1base / W2base exist
-  I_.ovvo.release(); I_.oovv.release();
+  // (ovvo / oovv stay resident: 2 x 128 MB at n = 220 buy two permutation passes per iteration)
   // ---- amplitudes and work space
   const int64_t na = nov + N2;
   QTRY(amp_.alloc(na)); QTRY(ampn_.alloc(na)); QTRY(diff_.alloc(na));
@@ -308,18 +307,16 @@ int CcsdSolver::update_amps(double* t1n, double* t2n) {
   QTRY(gemm(v, v, o, -1.0, X_, v, false, t1, v, false, 1.0, U_, v, oo, nov, 0, vv));
   //   X1 = (ovvv[iacb] - oovv[kibc] t1[ka]) t1[jc]
   QTRY(perm4(U_, ZB_, o, v, v, o, 0, 3, 1, 2, 1.0, 1.0));                          // U[i,j,a,b] += t1[jc] ovvv[i,a,b,c] = ZB[i,a,b,j]
-  {  // oovv[k,i,b,c] = W2base[i,b,k,c]: G2[k,i,b,j] = oovv[(kib),c] t1[jc] needs the oovv layout -> rebuild it
-    QTRY(perm4(G1_, W2base_, o, v, o, v, 2, 0, 1, 3));                             // G1 = oovv[k,i,b,c]
-    QTRY(gemm_nt(oo * v, o, v, 1.0, G1_, t1, 0.0, G2_));                           // G2[k,i,b,j]
+  {
+    QTRY(gemm_nt(oo * v, o, v, 1.0, I_.oovv, t1, 0.0, G2_));                       // G2[k,i,b,j] = oovv[(kib),c] t1[jc]
     QTRY(gemm_tn(v, o * v * o, o, 1.0, t1, G2_, 0.0, G1_));                        // G1[a,i,b,j] = t1[ka] G2[k,i,b,j]
     QTRY(perm4(U_, G1_, v, o, v, o, 1, 3, 0, 2, -1.0, 1.0));
   }
   //   X2 = (ovvo[kcai] t1[jc] + ovoo[iajk]) t1[kb]   (enters with a minus sign)
   QTRY(gemm_nn(o * v * o, v, o, 1.0, I_.ovoo, t1, 0.0, G1_));                      // G1[i,a,j,b] = ovoo[i,a,j,k] t1[kb]
   QTRY(perm4(U_, G1_, o, v, o, v, 0, 2, 1, 3, -1.0, 1.0));
-  {  // ovvo[k,c,a,i] = W1base[i,a,k,c]
-    QTRY(perm4(G1_, W1base_, o, v, o, v, 2, 3, 1, 0));                             // G1 = ovvo[k,c,a,i]
-    QTRY(gemm(o, v * o, v, 1.0, t1, v, true, G1_, v * o, false, 0.0, G2_, v * o, o, 0, v * v * o, o * v * o));  // G2[k,j,a,i]
+  {
+    QTRY(gemm(o, v * o, v, 1.0, t1, v, true, I_.ovvo, v * o, false, 0.0, G2_, v * o, o, 0, v * v * o, o * v * o));  // G2[k,j,a,i] = t1[jc] ovvo[k,c,a,i]
     QTRY(gemm_tn(o * v * o, v, o, 1.0, G2_, t1, 0.0, G1_));                        // G1[j,a,i,b] = G2[k,(jai)] t1[kb]
     QTRY(perm4(U_, G1_, o, v, o, v, 2, 0, 1, 3, -1.0, 1.0));
   }
