@@ -1063,8 +1063,9 @@ __global__ void __launch_bounds__(256) unpack_tril_tiled_kernel(long long rows, 
   __shared__ double tile[32][33];
   const long long np = n * (n + 1) / 2, n2 = n * n;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  const int nt = (int)((n + 31) / 32);
-  for (long long r = blockIdx.x; r < rows; r += gridDim.x) {
+  // blockIdx.x = lower-triangle tile (tk >= tl), blockIdx.y (looped) = packed row: every block moves one 32 x 32 tile
+  long long tt = blockIdx.x, tk, tl; unpair_ge(tt, tk, tl);
+  for (long long r = blockIdx.y; r < rows; r += gridDim.y) {
     const double* src = packed + r * np;
     double* dst0 = full + r * n2;
     double* dst1 = nullptr;
@@ -1073,25 +1074,22 @@ __global__ void __launch_bounds__(256) unpack_tril_tiled_kernel(long long rows, 
       dst0 = full + (p * n + q) * n2;
       if (p != q) dst1 = full + (q * n + p) * n2;
     }
-    for (int tk = 0; tk < nt; ++tk)
-      for (int tl = 0; tl <= tk; ++tl) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int kk = ty + 8 * i;
-          const long long k = tk * 32 + kk, l = tl * 32 + tx;
-          tile[kk][tx] = (k < n && l <= k) ? src[k * (k + 1) / 2 + l] : 0.0;
-        }
-        __syncthreads();
+    for (int i = 0; i < 4; ++i) {
+      const int kk = ty + 8 * i;
+      const long long k = tk * 32 + kk, l = tl * 32 + tx;
+      tile[kk][tx] = (k < n && l <= k) ? src[k * (k + 1) / 2 + l] : 0.0;
+    }
+    __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int kk = ty + 8 * i;
-          const long long k = tk * 32 + kk, l = tl * 32 + tx;
-          if (k < n && l <= k) { const double x = tile[kk][tx]; dst0[k * n + l] = x; if (dst1) dst1[k * n + l] = x; }
-          const long long lr = tl * 32 + kk, kc = tk * 32 + tx;
-          if (kc < n && lr < kc) { const double y = tile[tx][kk]; dst0[lr * n + kc] = y; if (dst1) dst1[lr * n + kc] = y; }
-        }
-        __syncthreads();
-      }
+    for (int i = 0; i < 4; ++i) {
+      const int kk = ty + 8 * i;
+      const long long k = tk * 32 + kk, l = tl * 32 + tx;
+      if (k < n && l <= k) { const double x = tile[kk][tx]; dst0[k * n + l] = x; if (dst1) dst1[k * n + l] = x; }
+      const long long lr = tl * 32 + kk, kc = tk * 32 + tx;
+      if (kc < n && lr < kc) { const double y = tile[tx][kk]; dst0[lr * n + kc] = y; if (dst1) dst1[lr * n + kc] = y; }
+    }
+    __syncthreads();
   }
 }
 
@@ -1112,7 +1110,8 @@ int dev_unpack_s4(int64_t n, const double* s4, double* s1) {
   REQUIRE_INIT();
   if (n >= 32) {
     const int64_t np = n * (n + 1) / 2;
-    hipLaunchKernelGGL(unpack_tril_tiled_kernel, dim3((unsigned)std::min<int64_t>(np, 1 << 20)), dim3(256), 0, g_stream, (long long)np, (long long)n, s4, s1, 1);
+    const int64_t nt = (n + 31) / 32;
+    hipLaunchKernelGGL(unpack_tril_tiled_kernel, dim3((unsigned)(nt * (nt + 1) / 2), (unsigned)std::min<int64_t>(np, 65535)), dim3(256), 0, g_stream, (long long)np, (long long)n, s4, s1, 1);
   } else {
     hipLaunchKernelGGL(unpack_s4_kernel, dim3((unsigned)std::min<int64_t>(n * n, 1 << 20)), dim3(256), 0, g_stream, (long long)n, s4, s1);
   }
@@ -1168,7 +1167,10 @@ int dev_unpack_tril_rows(int64_t rows, int64_t n, const double* packed, double* 
   REQUIRE_INIT();
   if (rows <= 0) return QEMB_OK;
   if (n >= 32)
-    hipLaunchKernelGGL(unpack_tril_tiled_kernel, dim3((unsigned)std::min<int64_t>(rows, 1 << 20)), dim3(256), 0, g_stream, (long long)rows, (long long)n, packed, full, 0);
+  {
+    const int64_t nt = (n + 31) / 32;
+    hipLaunchKernelGGL(unpack_tril_tiled_kernel, dim3((unsigned)(nt * (nt + 1) / 2), (unsigned)std::min<int64_t>(rows, 65535)), dim3(256), 0, g_stream, (long long)rows, (long long)n, packed, full, 0);
+  }
   else
     hipLaunchKernelGGL(unpack_tril_rows_kernel, dim3((unsigned)std::min<int64_t>(rows, 1 << 20)), dim3(256), 0, g_stream, (long long)rows, (long long)n, packed, full);
   HIP_TRY(hipGetLastError());
