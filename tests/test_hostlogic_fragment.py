@@ -143,3 +143,16 @@ def test_relaxed_density_fragment_solve_matches_oracle(hlib, n, o, nf, cen):
     # and it differs from the unrelaxed answer (the test would otherwise not see the Lambda part)
     out0 = fr.solve(o, h, opts=default_opts(hlib, cc_conv_tol=1e-13, cc_conv_tol_normt=1e-11), eeval=True)
     assert out0["lambda_iters"] == 0 and abs(out0["e_frag"][1] - out["e_frag"][1]) > 1e-6
+
+
+def test_lambda_nonconvergence_is_an_error(hlib):
+    """Non-convergence is reported, not returned silently (status -4 like the amplitude equations)."""
+    from quemb_amd._lib import QembError
+    from quemb_amd.fragsolver import DeviceFragment, default_opts
+    h, e1, h1, veff0, veff = _problem(6, 2, 3, 5)
+    fr = DeviceFragment(6, 3, lib=hlib)
+    fr.set_eri_s4(eri.pack_s4(e1))
+    with pytest.raises(QembError, match="Lambda"):
+        fr.solve(2, h, opts=default_opts(hlib, relax_density=1, lambda_max_cycle=1), eeval=False)
+    out = fr.solve(2, h, opts=default_opts(hlib, relax_density=1), eeval=False)     # and the handle is still usable
+    assert out["lambda_iters"] > 1
