@@ -237,8 +237,11 @@ int CcsdSolver::update_amps(double* t1n, double* t2n) {
   QTRY(dev_contract_mid(1, nov, oo, Lovoo_, t1, Z_, oo, 1.0, 0.0));                // Z[k,i]
   // The two t1-contractions of ovvv are formed ONCE per iteration (each is one pass over the 1.28 GB block) and serve the
   // ring intermediates, the X1 term and -- through their k = i traces -- the Y intermediate:
-  QTRY(gemm_nt(o * vv, o, v, 1.0, I_.ovvv, t1, 0.0, ZB_));                         // ZB[k,c,a,i] = ovvv[kcad] t1[id]
-  QTRY(gemm(o, vv, v, 1.0, t1, v, true, I_.ovvv, vv, false, 0.0, ZC_, vv, o, 0, v * vv, o * vv));   // ZC[k,i,a,c] = t1[id] ovvv[kdac]
+  // (n_occ <= 32 columns / rows: 128 x 32 and 32 x 128 tiles instead of padding n_occ to a 64-wide tile, which made these
+  //  HBM-bound passes MFMA-bound)
+  const int cfg_tall = (o <= 32) ? 20 : -1, cfg_wide = (o <= 32) ? 21 : -1;
+  QTRY(gemm(o * vv, o, v, 1.0, I_.ovvv, v, true, t1, v, true, 0.0, ZB_, o, 1, 0, 0, 0, cfg_tall));     // ZB[k,c,a,i] = ovvv[kcad] t1[id]
+  QTRY(gemm(o, vv, v, 1.0, t1, v, true, I_.ovvv, vv, false, 0.0, ZC_, vv, o, 0, v * vv, o * vv, cfg_wide));   // ZC[k,i,a,c] = t1[id] ovvv[kdac]
   {  // Y[a,c] = 2 sum_k ZC[k,k,a,c] - sum_k ZB[k,c,a,k]
     for (int64_t k0 = 0; k0 < o; k0 += 8) {
       const int cnt = (int)std::min<int64_t>(8, o - k0);
@@ -290,7 +293,7 @@ int CcsdSolver::update_amps(double* t1n, double* t2n) {
 
   // ---- T2 equation: terms that enter as P(X) accumulate in U
   QTRY(gemm(v, v, v, 1.0, Lvv_, v, true, t2, v, false, 0.0, U_, v, oo, 0, vv, vv));   // Lvv'[a,c] t2[ijcb]
-  QTRY(gemm_tn(o, o * vv, o, -1.0, Loo_, t2, 1.0, U_));                            // -Loo'[k,i] t2[kjab]
+  QTRY(gemm(o, o * vv, o, -1.0, Loo_, o, false, t2, o * vv, false, 1.0, U_, o * vv, 1, 0, 0, 0, cfg_wide));   // -Loo'[k,i] t2[kjab]
   //   t1-dressing of Wvvvv folded on the tau side: -t1[kb] (tau[ijcd] ovvv[kdac])
   {  // X[i,j,k,a] = tau[ijcd] OVl[k,a,c,d] from the packed tau rows LTp/LTm that apply_ladder just built:
      //   X[ij] = Xp + Xm, X[ji] = Xp - Xm (i > j),  Xp = LTp OVp^T (c >= d),  Xm = LTm OVm^T (c > d)
@@ -308,7 +311,7 @@ int CcsdSolver::update_amps(double* t1n, double* t2n) {
   //   X1 = (ovvv[iacb] - oovv[kibc] t1[ka]) t1[jc]
   QTRY(perm4(U_, ZB_, o, v, v, o, 0, 3, 1, 2, 1.0, 1.0));                          // U[i,j,a,b] += t1[jc] ovvv[i,a,b,c] = ZB[i,a,b,j]
   {
-    QTRY(gemm_nt(oo * v, o, v, 1.0, I_.oovv, t1, 0.0, G2_));                       // G2[k,i,b,j] = oovv[(kib),c] t1[jc]
+    QTRY(gemm(oo * v, o, v, 1.0, I_.oovv, v, true, t1, v, true, 0.0, G2_, o, 1, 0, 0, 0, cfg_tall));   // G2[k,i,b,j] = oovv[(kib),c] t1[jc]
     QTRY(gemm_tn(v, o * v * o, o, 1.0, t1, G2_, 0.0, G1_));                        // G1[a,i,b,j] = t1[ka] G2[k,i,b,j]
     QTRY(perm4(U_, G1_, v, o, v, o, 1, 3, 0, 2, -1.0, 1.0));
   }
@@ -316,7 +319,7 @@ int CcsdSolver::update_amps(double* t1n, double* t2n) {
   QTRY(gemm_nn(o * v * o, v, o, 1.0, I_.ovoo, t1, 0.0, G1_));                      // G1[i,a,j,b] = ovoo[i,a,j,k] t1[kb]
   QTRY(perm4(U_, G1_, o, v, o, v, 0, 2, 1, 3, -1.0, 1.0));
   {
-    QTRY(gemm(o, v * o, v, 1.0, t1, v, true, I_.ovvo, v * o, false, 0.0, G2_, v * o, o, 0, v * v * o, o * v * o));  // G2[k,j,a,i] = t1[jc] ovvo[k,c,a,i]
+    QTRY(gemm(o, v * o, v, 1.0, t1, v, true, I_.ovvo, v * o, false, 0.0, G2_, v * o, o, 0, v * v * o, o * v * o, cfg_wide));  // G2[k,j,a,i] = t1[jc] ovvo[k,c,a,i]
     QTRY(gemm_tn(o * v * o, v, o, 1.0, G2_, t1, 0.0, G1_));                        // G1[j,a,i,b] = G2[k,(jai)] t1[kb]
     QTRY(perm4(U_, G1_, o, v, o, v, 2, 0, 1, 3, -1.0, 1.0));
   }
@@ -338,7 +341,7 @@ int CcsdSolver::update_amps(double* t1n, double* t2n) {
   QTRY(lincomb2(N2, 2.0, T_, -1.0, Tp_, S_));                                      // S = u = 2T - Tp   (kept for the update)
   QTRY(add_t1t1(W12_, -2.0, S_));                                                  // W12 (scratch) = u~ = u - 2 t1(x)t1
   QTRY(perm4(W1_, ZB_, o, v, v, o, 3, 2, 0, 1, 1.0, 1.0, W1base_));                // W1 = W1base + ovvv[kcad] t1[id]
-  QTRY(gemm(o, v, o, 1.0, I_.ovoo, o, false, t1, v, false, 0.0, G1_, v, nov, oo, 0, nov));   // G1[k,c,i,a] = ovoo[kcli] t1[la]
+  QTRY(gemm(o, v, o, 1.0, I_.ovoo, o, false, t1, v, false, 0.0, G1_, v, nov, oo, 0, nov, cfg_wide));   // G1[k,c,i,a] = ovoo[kcli] t1[la]
   QTRY(perm4(W1_, G1_, o, v, o, v, 2, 3, 0, 1, -1.0, 1.0));
   QTRY(gemm_nn(nov, nov, nov, 0.25, W12_, Lovov_, 1.0, W1_));                      // + 1/4 u~ L
   //   W2[(ia),(kc)] = Wvovo[a,k,c,i]

@@ -423,6 +423,8 @@ int dev_gemm(const GemmDesc& d) {
     case 12: return launch_layout<4, 1, 1, 8, 16>(d, s, vec2);  //  64 x 128, 8 waves
     case 13: return launch_layout<7, 2, 2, 4, 16>(d, s, vec2);  // 224 x 128, 8 waves as 2 x 4: 9 LDS fragment reads per 14 MFMAs (15 for cfg 10)
     case 15: return launch_layout<6, 2, 2, 4, 16>(d, s, vec2);  // 192 x 128, 8 waves as 2 x 4 (the 190 antisymmetric pair rows of o = 20)
+    case 20: return launch_layout<4, 1, 2, 2, 16>(d, s, vec2);   // 128 x  32, 4 waves: tall products with N = n_occ (the t1 contractions of ovvv)
+    case 21: return launch_layout<1, 4, 2, 2, 16>(d, s, vec2);   //  32 x 128, 4 waves: the same with M = n_occ
     case 23: return launch_layout<7, 2, 2, 4, 16, 1>(d, s, vec2);   // = 13 under its own kernel symbol (pp-ladder, + pairs)
     case 25: return launch_layout<6, 2, 2, 4, 16, 1>(d, s, vec2);   // = 15 under its own kernel symbol (pp-ladder, - pairs)
     default: set_error("dev_gemm: unknown tile config"); return QEMB_ERR_ARG;
