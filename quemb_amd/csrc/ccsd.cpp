@@ -30,10 +30,10 @@ namespace qemb {
 // (half the flops of the full four-index transformation):
 //   X1 [pq][r][s]        <- unpack rs of the resident s4 block (p >= q rows only)
 //   X0 [s'][pq][r]       <- GEMM over s          X1 [r'][s'][pq]   <- GEMM over r   (symmetric in r',s')
-//   X0 [(r's')][pq]      <- keep r' >= s' rows   X1 [(r's')][p][q] <- unpack pq
-//   X0 [q'][(r's')][P]   <- GEMM over q: the 3/4-transformed integrals (P q'|r' s') that the
+//   X0 [(r's')][p][q]    <- keep r' >= s' rows and unpack pq (one fused pass)
+//   X1 [q'][(r's')][P]   <- GEMM over q: the 3/4-transformed integrals (P q'|r' s') that the
 //                           fragment-projected energy of get_frag_energy (helper.py:307-321) needs
-//   X1 [p'][q'][(r's')]  <- GEMM over p: the half-packed MO tensor every block below is gathered from
+//   X0 [p'][q'][(r's')]  <- GEMM over p: the half-packed MO tensor every block below is gathered from
 // ------------------------------------------------------------------------------------------------------------
 int64_t mo_transform_work(int n) { return (int64_t)n * n * ((int64_t)n * (n + 1) / 2); }
 
@@ -48,20 +48,19 @@ int mo_transform(int n, int o, int nf, const double* eri_s4, double* X0, double*
   const int tcfg = (n > 192 && n <= 224) ? 13 : -1;
   QTRY(gemm(n, ncol, n, 1.0, C, n, false, X1, n, true, 0.0, X0, ncol, 1, 0, 0, 0, tcfg));
   QTRY(gemm(n, ncol, n, 1.0, C, n, false, X0, n, true, 0.0, X1, ncol, 1, 0, 0, 0, tcfg));
-  QTRY(dev_pack_pair_rows(n, np, X1, X0));
-  QTRY(dev_unpack_tril_rows(np, n, X0, X1));
-  QTRY(gemm(n, ncol, n, 1.0, C, n, false, X1, n, true, 0.0, X0, ncol, 1, 0, 0, 0, tcfg));
+  QTRY(dev_unpack_tril_pair_rows(n, X1, X0));      // keep r' >= s' rows AND unpack pq, one pass: X0 = [(r's')][p][q]
+  QTRY(gemm(n, ncol, n, 1.0, C, n, false, X0, n, true, 0.0, X1, ncol, 1, 0, 0, 0, tcfg));   // X1 = [q'][(r's')][P]
   if (nf > 0 && build_T34) {   // every (P q'|r' s'), pair unpacked: the operand of CcLambda::densities
     QTRY(out.T34.alloc((int64_t)n * n * n * nf));
-    QTRY(dev_extract_mid_pair(n, n, n, X0, 0, 0, n, n, 0, nf, out.T34));
-  } else if (nf > 0) {   // X0 = [q'][(r's')][P]
+    QTRY(dev_extract_mid_pair(n, n, n, X1, 0, 0, n, n, 0, nf, out.T34));
+  } else if (nf > 0) {
     QTRY(out.A1.alloc((int64_t)v * o * v * nf));
     QTRY(out.A2.alloc((int64_t)o * o * v * nf));
-    QTRY(dev_extract_mid_pair(v, n, n, X0 + (int64_t)o * ncol, 0, o, o, v, 0, nf, out.A1));   // A1[a,j,b,P] = (P a|j b)
-    QTRY(dev_extract_mid_pair(o, n, n, X0, 0, o, o, v, 0, nf, out.A2));                        // A2[i,j,b,P] = (P i|j b)
+    QTRY(dev_extract_mid_pair(v, n, n, X1 + (int64_t)o * ncol, 0, o, o, v, 0, nf, out.A1));   // A1[a,j,b,P] = (P a|j b)
+    QTRY(dev_extract_mid_pair(o, n, n, X1, 0, o, o, v, 0, nf, out.A2));                        // A2[i,j,b,P] = (P i|j b)
   }
-  QTRY(gemm(n, ncol, n, 1.0, C, n, false, X0, n, true, 0.0, X1, ncol, 1, 0, 0, 0, tcfg));
-  const double* Mh = X1;   // [p'][q'][(r's')]
+  QTRY(gemm(n, ncol, n, 1.0, C, n, false, X1, n, true, 0.0, X0, ncol, 1, 0, 0, 0, tcfg));
+  const double* Mh = X0;   // [p'][q'][(r's')]
   QTRY(out.oooo.alloc((int64_t)o * o * o * o));
   QTRY(out.ovoo.alloc((int64_t)o * v * o * o));
   QTRY(out.ovov.alloc((int64_t)o * v * o * v));
@@ -82,11 +81,11 @@ int mo_transform(int n, int o, int nf, const double* eri_s4, double* X0, double*
     QTRY(out.Vm.alloc(std::max<int64_t>(nm, 1) * out.ldm));
     QTRY(dev_ladder_pack_vvvv_hp(n, o, Mh, out.Vp, out.ldp, out.Vm, out.ldm));
   }
-  if (build_Vl) {  // Vl[a,b,c,d] = (ac|bd): gather [a][c][b][d] (X0 is free now), then swap the middle indices
+  if (build_Vl) {  // Vl[a,b,c,d] = (ac|bd): gather [a][c][b][d] (X1 is free now), then swap the middle indices
     const int64_t v4 = (int64_t)v * v * v * v;
     QTRY(out.Vl.alloc(v4));
     DBuf tmp;
-    double* g = X0;
+    double* g = X1;
     if (v4 > mo_transform_work(n)) { QTRY(tmp.alloc(v4)); g = tmp; }
     QTRY(dev_extract_hp(n, Mh, o, o, o, o, v, v, v, v, g));
     QTRY(perm4(out.Vl, g, v, v, v, v, 0, 2, 1, 3));

@@ -186,6 +186,8 @@ int dev_unpack_s8_to_s4(int64_t n, const double* s8, double* s4);
 // rows of a (rows x npair(n)) packed matrix -> (rows x n x n) full symmetric, and back
 int dev_unpack_tril_rows(int64_t rows, int64_t n, const double* packed, double* full);
 int dev_pack_tril_rows(int64_t rows, int64_t n, const double* full, double* packed);
+// full[P(x,y)][k][l] = in[(x*n + y)][P(k,l)], x >= y: pair-row selection of an (n*n) x npair(n) matrix fused with the unpack
+int dev_unpack_tril_pair_rows(int64_t n, const double* in, double* full);
 
 // ---- symmetric eigen / SVD by wavefront Jacobi (no MFMA) -----------------------------------------
 // A (n x n, symmetric, row-major, overwritten) -> eigenvalues w[n] ascending and eigenvectors in the

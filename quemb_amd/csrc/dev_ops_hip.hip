@@ -1057,7 +1057,8 @@ __device__ __forceinline__ long long pair_idx(long long i, long long j) { return
 
 // Tiled triangular unpack: one workgroup per packed row, 32 x 32 tiles of the lower triangle staged through LDS so that
 // both the [k][l] image and its mirror [l][k] are written in 256-byte runs and every packed element is read once.
-// dup != 0: the row index is itself a pair (p >= q) of an s4 block; the n x n image goes to rows (p,q) and (q,p).
+// dup == 1: the row index is itself a pair (p >= q) of an s4 block; the n x n image goes to rows (p,q) and (q,p).
+// dup == 2: the SOURCE rows are gathered: packed row r = pair (x,y), x >= y, is read from row x*n + y (pair-row selection fused in).
 __global__ void __launch_bounds__(256) unpack_tril_tiled_kernel(long long rows, long long n, const double* __restrict__ packed,
                                                                double* __restrict__ full, int dup) {
   __shared__ double tile[32][33];
@@ -1069,10 +1070,13 @@ __global__ void __launch_bounds__(256) unpack_tril_tiled_kernel(long long rows, 
     const double* src = packed + r * np;
     double* dst0 = full + r * n2;
     double* dst1 = nullptr;
-    if (dup) {
+    if (dup == 1) {
       long long p, q; unpair_ge(r, p, q);
       dst0 = full + (p * n + q) * n2;
       if (p != q) dst1 = full + (q * n + p) * n2;
+    } else if (dup == 2) {           // source rows are the x >= y rows of an (n*n)-row matrix: row r = pair (x,y) lives at x*n + y
+      long long x, y; unpair_ge(r, x, y);
+      src = packed + (x * n + y) * np;
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -1173,6 +1177,24 @@ int dev_unpack_tril_rows(int64_t rows, int64_t n, const double* packed, double* 
   }
   else
     hipLaunchKernelGGL(unpack_tril_rows_kernel, dim3((unsigned)std::min<int64_t>(rows, 1 << 20)), dim3(256), 0, g_stream, (long long)rows, (long long)n, packed, full);
+  HIP_TRY(hipGetLastError());
+  return QEMB_OK;
+}
+// full[P(x,y)][k][l] = packed[(x*n + y)][P(k,l)] for x >= y: "keep the x >= y rows" and "unpack the pair column" in one pass
+int dev_unpack_tril_pair_rows(int64_t n, const double* packed_n2_rows, double* full) {
+  REQUIRE_INIT();
+  const int64_t np = n * (n + 1) / 2;
+  if (n < 32) {   // small problems: two simple passes through the head of `full`'s tail are not worth a kernel; use a staging buffer
+    void* tmp = nullptr;
+    int rc = dev_alloc(&tmp, sizeof(double) * (size_t)np * np);
+    if (rc) return rc;
+    rc = dev_pack_pair_rows(n, np, packed_n2_rows, (double*)tmp);
+    if (!rc) rc = dev_unpack_tril_rows(np, n, (const double*)tmp, full);
+    (void)dev_free(tmp);
+    return rc;
+  }
+  const int64_t nt = (n + 31) / 32;
+  hipLaunchKernelGGL(unpack_tril_tiled_kernel, dim3((unsigned)(nt * (nt + 1) / 2), (unsigned)std::min<int64_t>(np, 65535)), dim3(256), 0, g_stream, (long long)np, (long long)n, packed_n2_rows, full, 2);
   HIP_TRY(hipGetLastError());
   return QEMB_OK;
 }
