@@ -57,11 +57,10 @@ int ao2mo_dense(const AoEri& ao, const double* TA, int n, double* out_s4) {
   QTRY(dev_unpack_tril_rows(npN, N, ao.s4, W1));                                                   // [mn][k][l]
   QTRY(gemm(n, npN * N, N, 1.0, TA, n, false, W1, N, true, 0.0, W2, npN * N, 1, 0, 0, 0, tcfg));                     // [l'][mn][k]
   QTRY(gemm(n, (int64_t)n * npN, N, 1.0, TA, n, false, W2, N, true, 0.0, W1, (int64_t)n * npN, 1, 0, 0, 0, tcfg));   // [k'][l'][mn]
-  QTRY(dev_pack_pair_rows(n, npN, W1, W2));                                                        // [(kl)][mn]
-  QTRY(dev_unpack_tril_rows(npn, N, W2, W1));                                                      // [(kl)][m][n]
-  QTRY(gemm(n, npn * N, N, 1.0, TA, n, false, W1, N, true, 0.0, W2, npn * N, 1, 0, 0, 0, tcfg));                     // [j'][(kl)][m]
-  QTRY(gemm(n, (int64_t)n * npn, N, 1.0, TA, n, false, W2, N, true, 0.0, W1, (int64_t)n * npn, 1, 0, 0, 0, tcfg));   // [i'][j'][(kl)]
-  QTRY(dev_pack_pair_rows(n, npn, W1, out_s4));
+  QTRY(dev_unpack_tril_pair_rows(n, N, W1, W2));                                                   // keep k' >= l' rows, unpack mn: W2 = [(kl)][m][n]
+  QTRY(gemm(n, npn * N, N, 1.0, TA, n, false, W2, N, true, 0.0, W1, npn * N, 1, 0, 0, 0, tcfg));                     // [j'][(kl)][m]
+  QTRY(gemm(n, (int64_t)n * npn, N, 1.0, TA, n, false, W1, N, true, 0.0, W2, (int64_t)n * npn, 1, 0, 0, 0, tcfg));   // [i'][j'][(kl)]
+  QTRY(dev_pack_pair_rows(n, npn, W2, out_s4));
   QTRY(dev_timer_end(TIMER_AO2MO));
   return 0;
 }

@@ -48,7 +48,7 @@ int mo_transform(int n, int o, int nf, const double* eri_s4, double* X0, double*
   const int tcfg = (n > 192 && n <= 224) ? 13 : -1;
   QTRY(gemm(n, ncol, n, 1.0, C, n, false, X1, n, true, 0.0, X0, ncol, 1, 0, 0, 0, tcfg));
   QTRY(gemm(n, ncol, n, 1.0, C, n, false, X0, n, true, 0.0, X1, ncol, 1, 0, 0, 0, tcfg));
-  QTRY(dev_unpack_tril_pair_rows(n, X1, X0));      // keep r' >= s' rows AND unpack pq, one pass: X0 = [(r's')][p][q]
+  QTRY(dev_unpack_tril_pair_rows(n, n, X1, X0));      // keep r' >= s' rows AND unpack pq, one pass: X0 = [(r's')][p][q]
   QTRY(gemm(n, ncol, n, 1.0, C, n, false, X0, n, true, 0.0, X1, ncol, 1, 0, 0, 0, tcfg));   // X1 = [q'][(r's')][P]
   if (nf > 0 && build_T34) {   // every (P q'|r' s'), pair unpacked: the operand of CcLambda::densities
     QTRY(out.T34.alloc((int64_t)n * n * n * nf));

@@ -186,8 +186,9 @@ int dev_unpack_s8_to_s4(int64_t n, const double* s8, double* s4);
 // rows of a (rows x npair(n)) packed matrix -> (rows x n x n) full symmetric, and back
 int dev_unpack_tril_rows(int64_t rows, int64_t n, const double* packed, double* full);
 int dev_pack_tril_rows(int64_t rows, int64_t n, const double* full, double* packed);
-// full[P(x,y)][k][l] = in[(x*n + y)][P(k,l)], x >= y: pair-row selection of an (n*n) x npair(n) matrix fused with the unpack
-int dev_unpack_tril_pair_rows(int64_t n, const double* in, double* full);
+// full[P(x,y)][k][l] = in[(x*nr + y)][P(k,l)], x >= y (x, y < nr; k, l < n): pair-row selection of an (nr*nr) x npair(n) matrix
+// fused with the unpack of its pair column
+int dev_unpack_tril_pair_rows(int64_t nr, int64_t n, const double* in, double* full);
 
 // ---- symmetric eigen / SVD by wavefront Jacobi (no MFMA) -----------------------------------------
 // A (n x n, symmetric, row-major, overwritten) -> eigenvalues w[n] ascending and eigenvectors in the

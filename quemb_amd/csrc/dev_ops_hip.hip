@@ -1060,7 +1060,7 @@ __device__ __forceinline__ long long pair_idx(long long i, long long j) { return
 // dup == 1: the row index is itself a pair (p >= q) of an s4 block; the n x n image goes to rows (p,q) and (q,p).
 // dup == 2: the SOURCE rows are gathered: packed row r = pair (x,y), x >= y, is read from row x*n + y (pair-row selection fused in).
 __global__ void __launch_bounds__(256) unpack_tril_tiled_kernel(long long rows, long long n, const double* __restrict__ packed,
-                                                               double* __restrict__ full, int dup) {
+                                                               double* __restrict__ full, int dup, long long nr) {
   __shared__ double tile[32][33];
   const long long np = n * (n + 1) / 2, n2 = n * n;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -1076,7 +1076,7 @@ __global__ void __launch_bounds__(256) unpack_tril_tiled_kernel(long long rows, 
       if (p != q) dst1 = full + (q * n + p) * n2;
     } else if (dup == 2) {           // source rows are the x >= y rows of an (n*n)-row matrix: row r = pair (x,y) lives at x*n + y
       long long x, y; unpair_ge(r, x, y);
-      src = packed + (x * n + y) * np;
+      src = packed + (x * nr + y) * np;
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -1115,7 +1115,7 @@ int dev_unpack_s4(int64_t n, const double* s4, double* s1) {
   if (n >= 32) {
     const int64_t np = n * (n + 1) / 2;
     const int64_t nt = (n + 31) / 32;
-    hipLaunchKernelGGL(unpack_tril_tiled_kernel, dim3((unsigned)(nt * (nt + 1) / 2), (unsigned)std::min<int64_t>(np, 65535)), dim3(256), 0, g_stream, (long long)np, (long long)n, s4, s1, 1);
+    hipLaunchKernelGGL(unpack_tril_tiled_kernel, dim3((unsigned)(nt * (nt + 1) / 2), (unsigned)std::min<int64_t>(np, 65535)), dim3(256), 0, g_stream, (long long)np, (long long)n, s4, s1, 1, (long long)n);
   } else {
     hipLaunchKernelGGL(unpack_s4_kernel, dim3((unsigned)std::min<int64_t>(n * n, 1 << 20)), dim3(256), 0, g_stream, (long long)n, s4, s1);
   }
@@ -1173,28 +1173,29 @@ int dev_unpack_tril_rows(int64_t rows, int64_t n, const double* packed, double* 
   if (n >= 32)
   {
     const int64_t nt = (n + 31) / 32;
-    hipLaunchKernelGGL(unpack_tril_tiled_kernel, dim3((unsigned)(nt * (nt + 1) / 2), (unsigned)std::min<int64_t>(rows, 65535)), dim3(256), 0, g_stream, (long long)rows, (long long)n, packed, full, 0);
+    hipLaunchKernelGGL(unpack_tril_tiled_kernel, dim3((unsigned)(nt * (nt + 1) / 2), (unsigned)std::min<int64_t>(rows, 65535)), dim3(256), 0, g_stream, (long long)rows, (long long)n, packed, full, 0, (long long)n);
   }
   else
     hipLaunchKernelGGL(unpack_tril_rows_kernel, dim3((unsigned)std::min<int64_t>(rows, 1 << 20)), dim3(256), 0, g_stream, (long long)rows, (long long)n, packed, full);
   HIP_TRY(hipGetLastError());
   return QEMB_OK;
 }
-// full[P(x,y)][k][l] = packed[(x*n + y)][P(k,l)] for x >= y: "keep the x >= y rows" and "unpack the pair column" in one pass
-int dev_unpack_tril_pair_rows(int64_t n, const double* packed_n2_rows, double* full) {
+// full[P(x,y)][k][l] = in[(x*nr + y)][P(k,l)] for x >= y (x, y < nr; k, l < n): "keep the x >= y rows" and "unpack the pair column"
+// in one pass
+int dev_unpack_tril_pair_rows(int64_t nr, int64_t n, const double* in, double* full) {
   REQUIRE_INIT();
-  const int64_t np = n * (n + 1) / 2;
-  if (n < 32) {   // small problems: two simple passes through the head of `full`'s tail are not worth a kernel; use a staging buffer
+  const int64_t np = n * (n + 1) / 2, npr = nr * (nr + 1) / 2;
+  if (n < 32) {   // small problems: two simple passes through a staging buffer
     void* tmp = nullptr;
-    int rc = dev_alloc(&tmp, sizeof(double) * (size_t)np * np);
+    int rc = dev_alloc(&tmp, sizeof(double) * (size_t)npr * np);
     if (rc) return rc;
-    rc = dev_pack_pair_rows(n, np, packed_n2_rows, (double*)tmp);
-    if (!rc) rc = dev_unpack_tril_rows(np, n, (const double*)tmp, full);
+    rc = dev_pack_pair_rows(nr, np, in, (double*)tmp);
+    if (!rc) rc = dev_unpack_tril_rows(npr, n, (const double*)tmp, full);
     (void)dev_free(tmp);
     return rc;
   }
   const int64_t nt = (n + 31) / 32;
-  hipLaunchKernelGGL(unpack_tril_tiled_kernel, dim3((unsigned)(nt * (nt + 1) / 2), (unsigned)std::min<int64_t>(np, 65535)), dim3(256), 0, g_stream, (long long)np, (long long)n, packed_n2_rows, full, 2);
+  hipLaunchKernelGGL(unpack_tril_tiled_kernel, dim3((unsigned)(nt * (nt + 1) / 2), (unsigned)std::min<int64_t>(npr, 65535)), dim3(256), 0, g_stream, (long long)npr, (long long)n, in, full, 2, (long long)nr);
   HIP_TRY(hipGetLastError());
   return QEMB_OK;
 }

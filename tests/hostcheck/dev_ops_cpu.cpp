@@ -257,10 +257,10 @@ int dev_unpack_tril_rows(int64_t rows, int64_t n, const double* p, double* f) {
   for (int64_t r = 0; r < rows; ++r) for (int64_t k = 0; k < n; ++k) for (int64_t l = 0; l < n; ++l) f[(r * n + k) * n + l] = p[r * np + pidx(k, l)];
   return 0;
 }
-int dev_unpack_tril_pair_rows(int64_t n, const double* in, double* f) {
+int dev_unpack_tril_pair_rows(int64_t nr, int64_t n, const double* in, double* f) {
   const int64_t np = n * (n + 1) / 2;
-  for (int64_t x = 0; x < n; ++x) for (int64_t y = 0; y <= x; ++y) for (int64_t k = 0; k < n; ++k) for (int64_t l = 0; l < n; ++l)
-    f[(pidx(x, y) * n + k) * n + l] = in[(x * n + y) * np + pidx(k, l)];
+  for (int64_t x = 0; x < nr; ++x) for (int64_t y = 0; y <= x; ++y) for (int64_t k = 0; k < n; ++k) for (int64_t l = 0; l < n; ++l)
+    f[(pidx(x, y) * n + k) * n + l] = in[(x * nr + y) * np + pidx(k, l)];
   return 0;
 }
 int dev_pack_tril_rows(int64_t rows, int64_t n, const double* f, double* p) {
