@@ -88,9 +88,10 @@ def _declare(lib):
     f("qemb_ctx_count", I, I)
     f("qemb_ctx_bind", I, I)
     f("qemb_ctx_timer_read", I, I, I, C.POINTER(C.c_double), C.POINTER(c_i64), I)
-    f("qemb_op_extract_hp", I, L, P, L, L, L, L, L, L, L, L, P)
-    f("qemb_op_extract_mid_pair", I, L, L, L, P, L, L, L, L, L, L, P)
-    f("qemb_op_ladder_pack_vvvv_hp", I, L, L, P, P, L, P, L)
+    f("qemb_op_unpack_tril_pair_rows", I, L, L, P, P)
+    f("qemb_op_extract_pf", I, L, P, L, L, L, L, L, L, L, L, P)
+    f("qemb_op_extract_pf_t", I, L, P, L, L, L, L, L, L, L, L, P)
+    f("qemb_op_ladder_pack_vvvv_pf", I, L, L, P, P, L, P, L)
     f("qemb_op_pack_tril_rows", I, L, L, P, P)
     f("qemb_op_jacobi_eigh", I, L, P, P, P, C.POINTER(I))
     f("qemb_op_jacobi_svd", I, L, L, P, P, P, P, C.POINTER(I))

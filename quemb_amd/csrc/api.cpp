@@ -99,13 +99,14 @@ int qemb_op_lincomb2(int64_t n, double a, const double* x, double b, const doubl
 }
 int qemb_op_mirror_lower(int64_t n, double* A, int64_t lda) { return dev_mirror_lower(n, A, lda); }
 int qemb_op_pack_pair_rows(int64_t n, int64_t ncols, const double* in, double* out) { return dev_pack_pair_rows(n, ncols, in, out); }
-int qemb_op_extract_hp(int64_t n, const double* Mh, int64_t p0, int64_t q0, int64_t r0, int64_t s0, int64_t sp, int64_t sq, int64_t sr, int64_t ss, double* out) {
-  return dev_extract_hp(n, Mh, p0, q0, r0, s0, sp, sq, sr, ss, out);
+int qemb_op_extract_pf(int64_t n, const double* Mp, int64_t p0, int64_t q0, int64_t r0, int64_t s0, int64_t sp, int64_t sq, int64_t sr, int64_t ss, double* out) {
+  return dev_extract_pf(n, Mp, p0, q0, r0, s0, sp, sq, sr, ss, out);
 }
-int qemb_op_extract_mid_pair(int64_t rows, int64_t n, int64_t ncols, const double* T, int64_t r0, int64_t s0, int64_t sr, int64_t ss, int64_t c0, int64_t sc, double* out) {
-  return dev_extract_mid_pair(rows, n, ncols, T, r0, s0, sr, ss, c0, sc, out);
+int qemb_op_extract_pf_t(int64_t n, const double* T, int64_t x0, int64_t r0, int64_t s0, int64_t c0, int64_t sx, int64_t sr, int64_t ss, int64_t sc, double* out) {
+  return dev_extract_pf_t(n, T, x0, r0, s0, c0, sx, sr, ss, sc, out);
 }
-int qemb_op_ladder_pack_vvvv_hp(int64_t n, int64_t o, const double* Mh, double* Vp, int64_t ldp, double* Vm, int64_t ldm) { return dev_ladder_pack_vvvv_hp(n, o, Mh, Vp, ldp, Vm, ldm); }
+int qemb_op_ladder_pack_vvvv_pf(int64_t n, int64_t o, const double* Mp, double* Vp, int64_t ldp, double* Vm, int64_t ldm) { return dev_ladder_pack_vvvv_pf(n, o, Mp, Vp, ldp, Vm, ldm); }
+int qemb_op_unpack_tril_pair_rows(int64_t nr, int64_t n, const double* in, double* full) { return dev_unpack_tril_pair_rows(nr, n, in, full); }
 int qemb_op_unpack_tril_rows(int64_t rows, int64_t n, const double* p, double* f) { return dev_unpack_tril_rows(rows, n, p, f); }
 int qemb_op_pack_tril_rows(int64_t rows, int64_t n, const double* f, double* p) { return dev_pack_tril_rows(rows, n, f, p); }
 int qemb_op_jacobi_eigh(int64_t n, double* A, double* w, double* V, int* sweeps) { return dev_jacobi_eigh(n, A, w, V, sweeps); }

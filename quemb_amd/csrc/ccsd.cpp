@@ -31,9 +31,9 @@ namespace qemb {
 //   X1 [pq][r][s]        <- unpack rs of the resident s4 block (p >= q rows only)
 //   X0 [s'][pq][r]       <- GEMM over s          X1 [r'][s'][pq]   <- GEMM over r   (symmetric in r',s')
 //   X0 [(r's')][p][q]    <- keep r' >= s' rows and unpack pq (one fused pass)
-//   X1 [q'][(r's')][P]   <- GEMM over q: the 3/4-transformed integrals (P q'|r' s') that the
+//   X1 [(r's')][P][q']   <- batched GEMM slab.C: the 3/4-transformed integrals (P q'|r' s') that the
 //                           fragment-projected energy of get_frag_energy (helper.py:307-321) needs
-//   X0 [p'][q'][(r's')]  <- GEMM over p: the half-packed MO tensor every block below is gathered from
+//   X0 [(r's')][p'][q']  <- batched GEMM C^T.slab: the pair-first MO tensor every block below is gathered from in contiguous runs
 // ------------------------------------------------------------------------------------------------------------
 int64_t mo_transform_work(int n) { return (int64_t)n * n * ((int64_t)n * (n + 1) / 2); }
 
@@ -49,37 +49,40 @@ int mo_transform(int n, int o, int nf, const double* eri_s4, double* X0, double*
   QTRY(gemm(n, ncol, n, 1.0, C, n, false, X1, n, true, 0.0, X0, ncol, 1, 0, 0, 0, tcfg));
   QTRY(gemm(n, ncol, n, 1.0, C, n, false, X0, n, true, 0.0, X1, ncol, 1, 0, 0, 0, tcfg));
   QTRY(dev_unpack_tril_pair_rows(n, n, X1, X0));      // keep r' >= s' rows AND unpack pq, one pass: X0 = [(r's')][p][q]
-  QTRY(gemm(n, ncol, n, 1.0, C, n, false, X0, n, true, 0.0, X1, ncol, 1, 0, 0, 0, tcfg));   // X1 = [q'][(r's')][P]
-  if (nf > 0 && build_T34) {   // every (P q'|r' s'), pair unpacked: the operand of CcLambda::densities
+  // the last two quarter transforms act on the n x n slab of every pair (r's'): two batched GEMMs, slab <- C^T slab C, which
+  // leave the pair index IN FRONT -- every gather below then reads contiguous runs
+  const int64_t n2 = (int64_t)n * n;
+  QTRY(gemm(n, n, n, 1.0, X0, n, true, C, n, false, 0.0, X1, n, np, n2, 0, n2, tcfg));      // X1[(r's')][P][q'] = sum_q X0[..][P][q] C[q,q']
+  if (nf > 0 && build_T34) {   // every (P q'|r' s') as T34[q'][r'][s'][P]: the operand of CcLambda::densities
     QTRY(out.T34.alloc((int64_t)n * n * n * nf));
-    QTRY(dev_extract_mid_pair(n, n, n, X1, 0, 0, n, n, 0, nf, out.T34));
+    QTRY(dev_extract_pf_t(n, X1, 0, 0, 0, 0, n, n, n, nf, out.T34));
   } else if (nf > 0) {
     QTRY(out.A1.alloc((int64_t)v * o * v * nf));
     QTRY(out.A2.alloc((int64_t)o * o * v * nf));
-    QTRY(dev_extract_mid_pair(v, n, n, X1 + (int64_t)o * ncol, 0, o, o, v, 0, nf, out.A1));   // A1[a,j,b,P] = (P a|j b)
-    QTRY(dev_extract_mid_pair(o, n, n, X1, 0, o, o, v, 0, nf, out.A2));                        // A2[i,j,b,P] = (P i|j b)
+    QTRY(dev_extract_pf_t(n, X1, o, 0, o, 0, v, o, v, nf, out.A1));     // A1[a,j,b,P] = (P a|j b) = X1[P(j,b)][P][a]
+    QTRY(dev_extract_pf_t(n, X1, 0, 0, o, 0, o, o, v, nf, out.A2));     // A2[i,j,b,P] = (P i|j b)
   }
-  QTRY(gemm(n, ncol, n, 1.0, C, n, false, X1, n, true, 0.0, X0, ncol, 1, 0, 0, 0, tcfg));
-  const double* Mh = X0;   // [p'][q'][(r's')]
+  QTRY(gemm(n, n, n, 1.0, C, n, false, X1, n, false, 0.0, X0, n, np, 0, n2, n2, tcfg));     // X0[(r's')][p'][q'] = sum_p C[p,p'] X1[..][p][q']
+  const double* Mp = X0;   // pair-first MO tensor Mp[P(r',s')][p'][q'] = (r's'|p'q')
   QTRY(out.oooo.alloc((int64_t)o * o * o * o));
   QTRY(out.ovoo.alloc((int64_t)o * v * o * o));
   QTRY(out.ovov.alloc((int64_t)o * v * o * v));
   QTRY(out.oovv.alloc((int64_t)o * o * v * v));
   QTRY(out.ovvo.alloc((int64_t)o * v * v * o));
   QTRY(out.ovvv.alloc((int64_t)o * v * v * v));
-  QTRY(dev_extract_hp(n, Mh, 0, 0, 0, 0, o, o, o, o, out.oooo));
-  QTRY(dev_extract_hp(n, Mh, 0, o, 0, 0, o, v, o, o, out.ovoo));
-  QTRY(dev_extract_hp(n, Mh, 0, o, 0, o, o, v, o, v, out.ovov));
-  QTRY(dev_extract_hp(n, Mh, 0, 0, o, o, o, o, v, v, out.oovv));
-  QTRY(dev_extract_hp(n, Mh, 0, o, o, 0, o, v, v, o, out.ovvo));
-  QTRY(dev_extract_hp(n, Mh, 0, o, o, o, o, v, v, v, out.ovvv));
+  QTRY(dev_extract_pf(n, Mp, 0, 0, 0, 0, o, o, o, o, out.oooo));
+  QTRY(dev_extract_pf(n, Mp, 0, o, 0, 0, o, v, o, o, out.ovoo));
+  QTRY(dev_extract_pf(n, Mp, 0, o, 0, o, o, v, o, v, out.ovov));
+  QTRY(dev_extract_pf(n, Mp, 0, 0, o, o, o, o, v, v, out.oovv));
+  QTRY(dev_extract_pf(n, Mp, 0, o, o, 0, o, v, v, o, out.ovvo));
+  QTRY(dev_extract_pf(n, Mp, 0, o, o, o, o, v, v, v, out.ovvv));
   {  // (+/-) pair-packed ladder operands (6.4 GB instead of the 12.8 GB dense v^4 block at v = 200)
     const int64_t npv = (int64_t)v * (v + 1) / 2, nm = (int64_t)v * (v - 1) / 2;
     out.ldp = npv + (npv & 1); out.ldm = nm + (nm & 1);
     if (out.ldm == 0) out.ldm = 2;
     QTRY(out.Vp.alloc(npv * out.ldp));
     QTRY(out.Vm.alloc(std::max<int64_t>(nm, 1) * out.ldm));
-    QTRY(dev_ladder_pack_vvvv_hp(n, o, Mh, out.Vp, out.ldp, out.Vm, out.ldm));
+    QTRY(dev_ladder_pack_vvvv_pf(n, o, Mp, out.Vp, out.ldp, out.Vm, out.ldm));
   }
   if (build_Vl) {  // Vl[a,b,c,d] = (ac|bd): gather [a][c][b][d] (X1 is free now), then swap the middle indices
     const int64_t v4 = (int64_t)v * v * v * v;
@@ -87,7 +90,7 @@ int mo_transform(int n, int o, int nf, const double* eri_s4, double* X0, double*
     DBuf tmp;
     double* g = X1;
     if (v4 > mo_transform_work(n)) { QTRY(tmp.alloc(v4)); g = tmp; }
-    QTRY(dev_extract_hp(n, Mh, o, o, o, o, v, v, v, v, g));
+    QTRY(dev_extract_pf(n, Mp, o, o, o, o, v, v, v, v, g));
     QTRY(perm4(out.Vl, g, v, v, v, v, 0, 2, 1, 3));
   }
   QTRY(dev_timer_end(TIMER_AO2MO));

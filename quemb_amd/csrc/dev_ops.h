@@ -122,15 +122,15 @@ int dev_k_from_pairs(int64_t n, const double* H, const double* D, double* K);
 // ---- pair-packed MO transformation helpers ---------------------------------------------------------------------------
 // out[P(x,y), c] = in[(x*n + y), c] for x >= y  (row gather of an (n*n) x ncols matrix; ncols-long rows)
 int dev_pack_pair_rows(int64_t n, int64_t ncols, const double* in, double* out);
-// Mh: [n][n][npair(n)] with the LAST pair packed ((pq|rs), r >= s).  out (contiguous s0 x s1 x s2 x s3) =
-// Mh[p0+p, q0+q, P(r0+r, s0+s)]
-int dev_extract_hp(int64_t n, const double* Mh, int64_t p0, int64_t q0, int64_t r0, int64_t s0, int64_t sp, int64_t sq,
+// ---- gathers from the PAIR-FIRST MO tensor Mp[P(p,q)][r][s] = (pq|rs) (npair(n) x n x n), all reads in contiguous runs
+// out (contiguous sp x sq x sr x ss) = Mp[P(p0+p, q0+q)][r0+r][s0+s]
+int dev_extract_pf(int64_t n, const double* Mp, int64_t p0, int64_t q0, int64_t r0, int64_t s0, int64_t sp, int64_t sq,
                    int64_t sr, int64_t ss, double* out);
-// T: [rows][npair(n)][ncols] -> out[rows][s_r][s_s][ncols] = T[row, P(r0+r, s0+s), :]   (the 3/4-transformed integrals)
-int dev_extract_mid_pair(int64_t rows, int64_t n, int64_t ncols, const double* T, int64_t r0, int64_t s0, int64_t sr,
-                         int64_t ss, int64_t c0, int64_t sc, double* out);
-// (+/-) ladder operands from the half-packed MO tensor (same outputs as dev_ladder_pack_vvvv)
-int dev_ladder_pack_vvvv_hp(int64_t n, int64_t o, const double* Mh, double* Vp, int64_t ldp, double* Vm, int64_t ldm);
+// T: [npair(n)][n][n] with T[P(r,s)][c][x] -> out[sx][sr][ss][sc] = T[P(r0+r, s0+s)][c0+c][x0+x]   (3/4-transformed integrals)
+int dev_extract_pf_t(int64_t n, const double* T, int64_t x0, int64_t r0, int64_t s0, int64_t c0, int64_t sx, int64_t sr,
+                     int64_t ss, int64_t sc, double* out);
+// (+/-) ladder operands: Vp[P(ab),P(cd)] = Mp[P(va,vc)][vb][vd] + Mp[P(vb,vc)][va][vd]  (v* = o + *), Vm with the minus sign
+int dev_ladder_pack_vvvv_pf(int64_t n, int64_t o, const double* Mp, double* Vp, int64_t ldp, double* Vm, int64_t ldm);
 
 // ---- (+/-) packed pp-ladder: R_ijab = sum_cd (ac|bd) tau_ijcd through symmetric / antisymmetric pair combinations ------
 // pairs: P(x,y) = x(x+1)/2 + y for x >= y ("plus" blocks), Q(x,y) = x(x-1)/2 + y for x > y ("minus" blocks).

@@ -562,43 +562,73 @@ int dev_pack_pair_rows(int64_t n, int64_t ncols, const double* in, double* out) 
   HIP_TRY(hipGetLastError());
   return QEMB_OK;
 }
-__global__ void __launch_bounds__(256) extract_hp_kernel(long long n, const double* __restrict__ Mh, long long p0, long long q0, long long r0, long long s0,
+// ---- gathers from the pair-first MO tensor ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) extract_pf_kernel(long long n, const double* __restrict__ Mp, long long p0, long long q0, long long r0, long long s0,
                                                         long long sp, long long sq, long long sr, long long ss, double* __restrict__ out) {
-  const long long np = n * (n + 1) / 2, nrs = sr * ss;
+  const long long nrs = sr * ss;
   for (long long pq = blockIdx.x; pq < sp * sq; pq += gridDim.x) {
     const long long p = pq / sq, q = pq - p * sq;
-    const double* src = Mh + ((p0 + p) * n + (q0 + q)) * np;
+    const double* src = Mp + pair_idx(p0 + p, q0 + q) * n * n + r0 * n + s0;
     double* dst = out + pq * nrs;
     for (long long t = threadIdx.x; t < nrs; t += blockDim.x) {
       const long long r = t / ss, s = t - r * ss;
-      dst[t] = src[pair_idx(r0 + r, s0 + s)];
+      dst[t] = src[r * n + s];
     }
   }
 }
-int dev_extract_hp(int64_t n, const double* Mh, int64_t p0, int64_t q0, int64_t r0, int64_t s0, int64_t sp, int64_t sq, int64_t sr, int64_t ss, double* out) {
+int dev_extract_pf(int64_t n, const double* Mp, int64_t p0, int64_t q0, int64_t r0, int64_t s0, int64_t sp, int64_t sq, int64_t sr, int64_t ss, double* out) {
   REQUIRE_INIT();
   if (sp <= 0 || sq <= 0 || sr <= 0 || ss <= 0) return QEMB_OK;
-  hipLaunchKernelGGL(extract_hp_kernel, dim3((unsigned)std::min<int64_t>(sp * sq, 1 << 20)), dim3(256), 0, g_stream, (long long)n, Mh, (long long)p0, (long long)q0,
+  hipLaunchKernelGGL(extract_pf_kernel, dim3((unsigned)std::min<int64_t>(sp * sq, 1 << 20)), dim3(256), 0, g_stream, (long long)n, Mp, (long long)p0, (long long)q0,
                      (long long)r0, (long long)s0, (long long)sp, (long long)sq, (long long)sr, (long long)ss, out);
   HIP_TRY(hipGetLastError());
   return QEMB_OK;
 }
-__global__ void __launch_bounds__(256) extract_mid_pair_kernel(long long rows, long long n, long long ncols, const double* __restrict__ T, long long r0, long long s0,
-                                                              long long sr, long long ss, long long c0, long long sc, double* __restrict__ out) {
-  const long long np = n * (n + 1) / 2;
-  for (long long row = blockIdx.y; row < rows; row += gridDim.y)
-    for (long long rs = blockIdx.x; rs < sr * ss; rs += gridDim.x) {
-      const long long r = rs / ss, s = rs - r * ss;
-      const double* src = T + (row * np + pair_idx(r0 + r, s0 + s)) * ncols + c0;
-      double* dst = out + (row * sr * ss + rs) * sc;
-      for (long long c = threadIdx.x; c < sc; c += blockDim.x) dst[c] = src[c];
+// out[x][r][s][c] = T[P(r0+r,s0+s)][c0+c][x0+x]: one workgroup per (r,s) slab reads the sc x sx corner (rows of sx contiguous doubles)
+__global__ void __launch_bounds__(256) extract_pf_t_kernel(long long n, const double* __restrict__ T, long long x0, long long r0, long long s0, long long c0,
+                                                          long long sx, long long sr, long long ss, long long sc, double* __restrict__ out) {
+  for (long long rs = blockIdx.x; rs < sr * ss; rs += gridDim.x) {
+    const long long r = rs / ss, s = rs - r * ss;
+    const double* src = T + pair_idx(r0 + r, s0 + s) * n * n + c0 * n + x0;
+    for (long long t = threadIdx.x; t < sc * sx; t += blockDim.x) {
+      const long long c = t / sx, x = t - c * sx;
+      out[(x * sr * ss + rs) * sc + c] = src[c * n + x];
     }
+  }
 }
-int dev_extract_mid_pair(int64_t rows, int64_t n, int64_t ncols, const double* T, int64_t r0, int64_t s0, int64_t sr, int64_t ss, int64_t c0, int64_t sc, double* out) {
+int dev_extract_pf_t(int64_t n, const double* T, int64_t x0, int64_t r0, int64_t s0, int64_t c0, int64_t sx, int64_t sr, int64_t ss, int64_t sc, double* out) {
   REQUIRE_INIT();
-  if (rows <= 0 || sr <= 0 || ss <= 0 || sc <= 0) return QEMB_OK;
-  hipLaunchKernelGGL(extract_mid_pair_kernel, dim3((unsigned)std::min<int64_t>(sr * ss, 65535), (unsigned)std::min<int64_t>(rows, 65535)), dim3(64), 0, g_stream,
-                     (long long)rows, (long long)n, (long long)ncols, T, (long long)r0, (long long)s0, (long long)sr, (long long)ss, (long long)c0, (long long)sc, out);
+  if (sx <= 0 || sr <= 0 || ss <= 0 || sc <= 0) return QEMB_OK;
+  hipLaunchKernelGGL(extract_pf_t_kernel, dim3((unsigned)std::min<int64_t>(sr * ss, 1 << 20)), dim3(256), 0, g_stream, (long long)n, T, (long long)x0, (long long)r0,
+                     (long long)s0, (long long)c0, (long long)sx, (long long)sr, (long long)ss, (long long)sc, out);
+  HIP_TRY(hipGetLastError());
+  return QEMB_OK;
+}
+// one workgroup per output row P(a,b); for every c the two source runs (d = 0..c) are contiguous:
+//   (ac|bd) = Mp[P(va,vc)][vb][vd],   (ad|bc) = (bc|ad) = Mp[P(vb,vc)][va][vd]
+__global__ void __launch_bounds__(256) ladder_pack_vvvv_pf_kernel(long long n, long long o, const double* __restrict__ Mp,
+                                                                 double* __restrict__ Vp, long long ldp, double* __restrict__ Vm, long long ldm) {
+  const long long v = n - o, np = v * (v + 1) / 2, nm = v * (v - 1) / 2, n2 = n * n;
+  for (long long ab = blockIdx.x; ab < np; ab += gridDim.x) {
+    long long a, b; unpair_ge(ab, a, b);
+    double* vp = Vp + ab * ldp;
+    double* vm = (a > b) ? Vm + (a * (a - 1) / 2 + b) * ldm : nullptr;
+    for (long long cd = threadIdx.x; cd < ldp; cd += blockDim.x) {
+      if (cd >= np) { vp[cd] = 0.0; continue; }
+      long long c, d; unpair_ge(cd, c, d);
+      const double x = Mp[pair_idx(o + a, o + c) * n2 + (o + b) * n + (o + d)];
+      const double y = Mp[pair_idx(o + b, o + c) * n2 + (o + a) * n + (o + d)];
+      vp[cd] = x + y;
+      if (vm && c > d) vm[c * (c - 1) / 2 + d] = x - y;
+    }
+    if (vm) for (long long q = nm + threadIdx.x; q < ldm; q += blockDim.x) vm[q] = 0.0;
+  }
+}
+int dev_ladder_pack_vvvv_pf(int64_t n, int64_t o, const double* Mp, double* Vp, int64_t ldp, double* Vm, int64_t ldm) {
+  REQUIRE_INIT();
+  const long long v = n - o, np = v * (v + 1) / 2;
+  if (np <= 0) return QEMB_OK;
+  hipLaunchKernelGGL(ladder_pack_vvvv_pf_kernel, dim3((unsigned)std::min<long long>(np, 1 << 20)), dim3(256), 0, g_stream, (long long)n, (long long)o, Mp, Vp, (long long)ldp, Vm, (long long)ldm);
   HIP_TRY(hipGetLastError());
   return QEMB_OK;
 }
@@ -628,33 +658,6 @@ int dev_ladder_pack_vvvv(int64_t n, int64_t o, const double* M, double* Vp, int6
   const long long v = n - o, np = v * (v + 1) / 2;
   if (np <= 0) return QEMB_OK;
   hipLaunchKernelGGL(ladder_pack_vvvv_kernel, dim3((unsigned)std::min<long long>(np, 1 << 20)), dim3(256), 0, g_stream, (long long)n, (long long)o, M, Vp, (long long)ldp, Vm, (long long)ldm);
-  HIP_TRY(hipGetLastError());
-  return QEMB_OK;
-}
-// same outputs from the half-packed MO tensor Mh[p][q][P(r,s)]: (ac|bd) = Mh[o+a, o+c, P(o+b, o+d)]
-__global__ void __launch_bounds__(256) ladder_pack_vvvv_hp_kernel(long long n, long long o, const double* __restrict__ Mh,
-                                                                 double* __restrict__ Vp, long long ldp, double* __restrict__ Vm, long long ldm) {
-  const long long v = n - o, np = v * (v + 1) / 2, npn = n * (n + 1) / 2;
-  for (long long ab = blockIdx.x; ab < np; ab += gridDim.x) {
-    long long a, b; unpair_ge(ab, a, b);
-    double* vp = Vp + ab * ldp;
-    double* vm = (a > b) ? Vm + (a * (a - 1) / 2 + b) * ldm : nullptr;
-    for (long long cd = threadIdx.x; cd < ldp; cd += blockDim.x) {
-      if (cd >= np) { vp[cd] = 0.0; continue; }
-      long long c, d; unpair_ge(cd, c, d);
-      const double x = Mh[((o + a) * n + (o + c)) * npn + pair_idx(o + b, o + d)];
-      const double y = Mh[((o + a) * n + (o + d)) * npn + pair_idx(o + b, o + c)];
-      vp[cd] = x + y;
-      if (vm && c > d) vm[c * (c - 1) / 2 + d] = x - y;
-    }
-    if (vm) { const long long nm = v * (v - 1) / 2; for (long long q = nm + threadIdx.x; q < ldm; q += blockDim.x) vm[q] = 0.0; }
-  }
-}
-int dev_ladder_pack_vvvv_hp(int64_t n, int64_t o, const double* Mh, double* Vp, int64_t ldp, double* Vm, int64_t ldm) {
-  REQUIRE_INIT();
-  const long long v = n - o, np = v * (v + 1) / 2;
-  if (np <= 0) return QEMB_OK;
-  hipLaunchKernelGGL(ladder_pack_vvvv_hp_kernel, dim3((unsigned)std::min<long long>(np, 1 << 20)), dim3(256), 0, g_stream, (long long)n, (long long)o, Mh, Vp, (long long)ldp, Vm, (long long)ldm);
   HIP_TRY(hipGetLastError());
   return QEMB_OK;
 }

@@ -14,7 +14,7 @@ def build(force=False):
     deps = srcs + sorted(CSRC.glob("*.h")) + [CSRC.parent.parent / "include" / "qemb_hip.h"]
     if OUT.exists() and not force and all(OUT.stat().st_mtime > d.stat().st_mtime for d in deps):
         return OUT
-    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fopenmp", "-DQEMB_HOSTCHECK", f"-I{CSRC}", "-o", str(OUT)] + [str(s) for s in srcs]
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fopenmp", "-Wl,--no-undefined", "-DQEMB_HOSTCHECK", f"-I{CSRC}", "-o", str(OUT)] + [str(s) for s in srcs]
     subprocess.run(cmd, check=True)
     return OUT
 

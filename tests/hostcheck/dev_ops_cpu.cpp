@@ -130,25 +130,23 @@ int dev_pack_pair_rows(int64_t n, int64_t ncols, const double* in, double* out) 
   for (int64_t x = 0; x < n; ++x) for (int64_t y = 0; y <= x; ++y) std::copy(in + (x * n + y) * ncols, in + (x * n + y + 1) * ncols, out + pidx(x, y) * ncols);
   return 0;
 }
-int dev_extract_hp(int64_t n, const double* Mh, int64_t p0, int64_t q0, int64_t r0, int64_t s0, int64_t sp, int64_t sq, int64_t sr, int64_t ss, double* out) {
-  const int64_t np = n * (n + 1) / 2;
+int dev_extract_pf(int64_t n, const double* Mp, int64_t p0, int64_t q0, int64_t r0, int64_t s0, int64_t sp, int64_t sq, int64_t sr, int64_t ss, double* out) {
   for (int64_t p = 0; p < sp; ++p) for (int64_t q = 0; q < sq; ++q) for (int64_t r = 0; r < sr; ++r) for (int64_t s = 0; s < ss; ++s)
-    out[((p * sq + q) * sr + r) * ss + s] = Mh[((p0 + p) * n + (q0 + q)) * np + pidx(r0 + r, s0 + s)];
+    out[((p * sq + q) * sr + r) * ss + s] = Mp[(pidx(p0 + p, q0 + q) * n + (r0 + r)) * n + (s0 + s)];
   return 0;
 }
-int dev_extract_mid_pair(int64_t rows, int64_t n, int64_t ncols, const double* T, int64_t r0, int64_t s0, int64_t sr, int64_t ss, int64_t c0, int64_t sc, double* out) {
-  const int64_t np = n * (n + 1) / 2;
-  for (int64_t row = 0; row < rows; ++row) for (int64_t r = 0; r < sr; ++r) for (int64_t s = 0; s < ss; ++s) for (int64_t c = 0; c < sc; ++c)
-    out[((row * sr + r) * ss + s) * sc + c] = T[(row * np + pidx(r0 + r, s0 + s)) * ncols + c0 + c];
+int dev_extract_pf_t(int64_t n, const double* T, int64_t x0, int64_t r0, int64_t s0, int64_t c0, int64_t sx, int64_t sr, int64_t ss, int64_t sc, double* out) {
+  for (int64_t x = 0; x < sx; ++x) for (int64_t r = 0; r < sr; ++r) for (int64_t s = 0; s < ss; ++s) for (int64_t c = 0; c < sc; ++c)
+    out[((x * sr + r) * ss + s) * sc + c] = T[(pidx(r0 + r, s0 + s) * n + (c0 + c)) * n + (x0 + x)];
   return 0;
 }
-int dev_ladder_pack_vvvv_hp(int64_t n, int64_t o, const double* Mh, double* Vp, int64_t ldp, double* Vm, int64_t ldm) {
-  const int64_t v = n - o, npn = n * (n + 1) / 2;
+int dev_ladder_pack_vvvv_pf(int64_t n, int64_t o, const double* Mp, double* Vp, int64_t ldp, double* Vm, int64_t ldm) {
+  const int64_t v = n - o;
   for (int64_t a = 0; a < v; ++a) for (int64_t b = 0; b <= a; ++b) {
     double* vp = Vp + (a * (a + 1) / 2 + b) * ldp; std::fill(vp, vp + ldp, 0.0);
     double* vm = a > b ? Vm + (a * (a - 1) / 2 + b) * ldm : nullptr; if (vm) std::fill(vm, vm + ldm, 0.0);
     for (int64_t c = 0; c < v; ++c) for (int64_t d = 0; d <= c; ++d) {
-      const double x = Mh[((o + a) * n + (o + c)) * npn + pidx(o + b, o + d)], y = Mh[((o + a) * n + (o + d)) * npn + pidx(o + b, o + c)];
+      const double x = Mp[(pidx(o + a, o + c) * n + (o + b)) * n + (o + d)], y = Mp[(pidx(o + b, o + c) * n + (o + a)) * n + (o + d)];
       vp[c * (c + 1) / 2 + d] = x + y;
       if (vm && c > d) vm[c * (c - 1) / 2 + d] = x - y;
     }

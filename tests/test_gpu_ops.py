@@ -193,39 +193,42 @@ def test_mirror_lower(qlib, n):
 
 
 def test_pair_packed_transform_helpers(qlib):
-    """dev_pack_pair_rows / dev_extract_hp / dev_extract_mid_pair / dev_ladder_pack_vvvv_hp against numpy indexing."""
+    """dev_pack_pair_rows / dev_unpack_tril_pair_rows / dev_extract_pf / dev_extract_pf_t / dev_ladder_pack_vvvv_pf against numpy indexing."""
     rng = np.random.default_rng(77)
-    n, o = 11, 3
-    v = n - o
-    npair = n * (n + 1) // 2
-    il = np.tril_indices(n)
-    pidx = np.zeros((n, n), dtype=np.int64)
-    pidx[il] = np.arange(npair); pidx = np.maximum(pidx, pidx.T)
-    ncols = 13
-    A = rng.standard_normal((n * n, ncols))
-    dA, dO = DeviceBuffer.from_numpy(A), DeviceBuffer(npair * ncols)
-    check(qlib.qemb_op_pack_pair_rows(n, ncols, dA.ptr, dO.ptr))
-    assert np.array_equal(dO.numpy((npair, ncols)), A.reshape(n, n, ncols)[il])
-    eri = _sym_eri(n, rng)
-    Mh = np.ascontiguousarray(eri[:, :, il[0], il[1]])          # [p][q][(rs)]
-    dM = DeviceBuffer.from_numpy(Mh)
-    for (p0, q0, r0, s0, sp, sq, sr, ss) in [(0, 0, 0, 0, o, o, o, o), (0, o, o, 0, o, v, v, o), (0, o, o, o, o, v, v, v), (o, o, o, o, v, v, v, v)]:
-        dB = DeviceBuffer(sp * sq * sr * ss)
-        check(qlib.qemb_op_extract_hp(n, dM.ptr, p0, q0, r0, s0, sp, sq, sr, ss, dB.ptr))
-        assert np.array_equal(dB.numpy((sp, sq, sr, ss)), eri[p0:p0 + sp, q0:q0 + sq, r0:r0 + sr, s0:s0 + ss])
-    T = np.ascontiguousarray(eri.transpose(1, 2, 3, 0)[:, il[0], il[1], :])   # T[q][(rs)][P] = (P q|r s)
-    dT, dB = DeviceBuffer.from_numpy(T), DeviceBuffer(v * o * v * 4)
-    check(qlib.qemb_op_extract_mid_pair(v, n, n, dT.ptr + o * npair * n * 8, 0, o, o, v, 0, 4, dB.ptr))
-    assert np.array_equal(dB.numpy((v, o, v, 4)), eri[:4, o:, :o, o:].transpose(1, 2, 3, 0))
-    npv, nmv = v * (v + 1) // 2, v * (v - 1) // 2
-    ldp, ldm = npv + (npv & 1), nmv + (nmv & 1)
-    dVp, dVm = DeviceBuffer(npv * ldp), DeviceBuffer(nmv * ldm)
-    dVp2, dVm2 = DeviceBuffer(npv * ldp), DeviceBuffer(nmv * ldm)
-    check(qlib.qemb_op_ladder_pack_vvvv_hp(n, o, dM.ptr, dVp.ptr, ldp, dVm.ptr, ldm))
-    dE = DeviceBuffer.from_numpy(eri)
-    check(qlib.qemb_op_ladder_pack_vvvv(n, o, dE.ptr, dVp2.ptr, ldp, dVm2.ptr, ldm))
-    assert np.array_equal(dVp.numpy((npv, ldp)), dVp2.numpy((npv, ldp)))
-    assert np.array_equal(dVm.numpy((nmv, ldm)), dVm2.numpy((nmv, ldm)))
+    for n, o in ((11, 3), (37, 5)):                   # n >= 32 takes the LDS-tiled fused unpack
+        v = n - o
+        npair = n * (n + 1) // 2
+        il = np.tril_indices(n)
+        ncols = 13
+        A = rng.standard_normal((n * n, ncols))
+        dA, dO = DeviceBuffer.from_numpy(A), DeviceBuffer(npair * ncols)
+        check(qlib.qemb_op_pack_pair_rows(n, ncols, dA.ptr, dO.ptr))
+        assert np.array_equal(dO.numpy((npair, ncols)), A.reshape(n, n, ncols)[il])
+        eri = _sym_eri(n, rng)
+        # rows (x,y) all n*n, columns packed pairs -> keep x >= y rows and unpack the columns in one pass
+        Xin = np.ascontiguousarray(eri[:, :, il[0], il[1]]).reshape(n * n, npair)
+        dX, dF = DeviceBuffer.from_numpy(Xin), DeviceBuffer(npair * n * n)
+        check(qlib.qemb_op_unpack_tril_pair_rows(n, n, dX.ptr, dF.ptr))
+        Mp = eri[il]                                                # Mp[P(p,q)][r][s]
+        assert np.array_equal(dF.numpy((npair, n, n)), Mp)
+        dM = dF
+        for (p0, q0, r0, s0, sp, sq, sr, ss) in [(0, 0, 0, 0, o, o, o, o), (0, o, o, 0, o, v, v, o), (0, o, o, o, o, v, v, v), (o, o, o, o, v, v, v, v)]:
+            dB = DeviceBuffer(sp * sq * sr * ss)
+            check(qlib.qemb_op_extract_pf(n, dM.ptr, p0, q0, r0, s0, sp, sq, sr, ss, dB.ptr))
+            assert np.array_equal(dB.numpy((sp, sq, sr, ss)), eri[p0:p0 + sp, q0:q0 + sq, r0:r0 + sr, s0:s0 + ss])
+        # T[P(r,s)][c][x] = (c x|r s) -> out[x][r][s][c]
+        dB = DeviceBuffer(v * o * v * 4)
+        check(qlib.qemb_op_extract_pf_t(n, dM.ptr, o, 0, o, 0, v, o, v, 4, dB.ptr))
+        assert np.array_equal(dB.numpy((v, o, v, 4)), eri[:4, o:, :o, o:].transpose(1, 2, 3, 0))
+        npv, nmv = v * (v + 1) // 2, v * (v - 1) // 2
+        ldp, ldm = npv + (npv & 1), nmv + (nmv & 1)
+        dVp, dVm = DeviceBuffer(npv * ldp), DeviceBuffer(max(nmv, 1) * ldm)
+        dVp2, dVm2 = DeviceBuffer(npv * ldp), DeviceBuffer(max(nmv, 1) * ldm)
+        check(qlib.qemb_op_ladder_pack_vvvv_pf(n, o, dM.ptr, dVp.ptr, ldp, dVm.ptr, ldm))
+        dE = DeviceBuffer.from_numpy(eri)
+        check(qlib.qemb_op_ladder_pack_vvvv(n, o, dE.ptr, dVp2.ptr, ldp, dVm2.ptr, ldm))
+        assert np.array_equal(dVp.numpy((npv, ldp)), dVp2.numpy((npv, ldp)))
+        assert np.array_equal(dVm.numpy((nmv, ldm)), dVm2.numpy((nmv, ldm)))
 
 
 @pytest.mark.parametrize("n", [2, 7, 42, 131, 220])
