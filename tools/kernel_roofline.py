@@ -10,7 +10,7 @@ bytes_of = {   # kernel-name fragment -> (algorithmic bytes, what)
     "unpack_tril_tiled_kernel": ((npn * npn + npn * n * n) * 8, "s4 rows -> [P(pq)][r][s] (read packed + write unpacked)"),
     "k_pairs_stage1": (npn * n * n * 8, "exchange matrix from the half-unpacked tensor (read once)"),
     "pack_pair_rows_kernel": (2 * npn * npn * 8, "keep r' >= s' rows"),
-    "ladder_pack_vvvv_hp_kernel": (2 * (npv * npv + (npv - v) ** 2) * 8, "(+/-) ladder operands from the half-packed MO tensor"),
+    "ladder_pack_vvvv_pf_kernel": (2 * (npv * npv + (npv - v) ** 2) * 8, "(+/-) ladder operands from the pair-first MO tensor"),
     "ladder_scatter_pm_kernel": (2 * N2 + 2 * (o * (o + 1) // 2) * npv * 8, "ladder result -> four index images of t2 (r/w t2 + read R+/R-)"),
     "lincomb_kernel": (3 * N2, "a x + b y (two reads + one write of an o^2 v^2 tensor)"),
     "div_denom_kernel": (2 * N2, "t2 / D"),
