@@ -48,6 +48,8 @@ def test_two_rank_sweep_equals_single_process():
     import torch.multiprocessing as mp
     for p in (ROOT, ROOT / "tests", ROOT / "tests" / "hostcheck"):
         sys.path.insert(0, str(p))
+    import build as hc_build
+    hc_build.build()                      # build the mock device library once, before the ranks start
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
