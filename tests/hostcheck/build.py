@@ -13,7 +13,7 @@ OUT = HERE / "libqemb_hostcheck.so"
 
 def build(force=False):
     srcs = sorted(CSRC.glob("*.cpp")) + [HERE / "dev_ops_cpu.cpp"]
-    deps = srcs + sorted(CSRC.glob("*.h")) + [CSRC.parent.parent / "include" / "qemb_hip.h"]
+    deps = srcs + sorted(CSRC.glob("*.h")) + sorted(CSRC.glob("*.inc")) + [CSRC.parent.parent / "include" / "qemb_hip.h"]
     def fresh():
         return OUT.exists() and all(OUT.stat().st_mtime > d.stat().st_mtime for d in deps)
     if fresh() and not force:
