@@ -94,6 +94,22 @@ int qemb_op_contract_mid(int64_t outer, int64_t mid, int64_t inner, const double
 int qemb_op_unpack_s4(int64_t n, const double* s4, double* s1);
 int qemb_op_pack_s4(int64_t n, const double* s1, double* s4);
 int qemb_op_unpack_s8_to_s4(int64_t n, const double* s8, double* s4);
+/* A[r][c] = A[c][r], r < c (completes a SYRK-style result computed on and below the diagonal) */
+int qemb_op_mirror_lower(int64_t n, double* A, int64_t lda);
+/* exchange matrix K[p,r] = sum (pq|rs) D[q,s] from the half-unpacked tensor H[P(p,q)][r][s] (scf.hf.dot_eri_dm's K at helper.py:64) */
+int qemb_op_k_from_pairs(int64_t n, const double* H, const double* D, double* K);
+/* (+/-) pair packing of the last two indices of in[rows][v][v] (Op: c >= d sums, Om: c > d differences; rows padded to ldp / ldm)
+ * and the inverse scatter of packed pair ROWS: out[i,j,:] = Xp + Xm, out[j,i,:] = Xp - Xm */
+int qemb_op_pack_pm_cols(int64_t rows, int64_t v, const double* in, double* Op, int64_t ldp, double* Om, int64_t ldm);
+int qemb_op_scatter_pm_rows(int64_t o, int64_t ncols, const double* Xp, const double* Xm, double* out);
+int qemb_op_lincomb2(int64_t n, double a, const double* x, double b, const double* y, double beta, double* out);   /* out = a x + b y + beta out */
+/* Execution contexts (one HIP stream + workspaces + block cache each; no reference counterpart -- the reference overlaps
+ * fragments with a process pool, be_parallel.py:484).  qemb_ctx_count(n) makes contexts 0..n-1 available (0 = default) and
+ * returns how many exist (or < 0); qemb_ctx_bind(k) binds the CALLING host thread to context k, so that several host
+ * threads can each drive a fragment on their own stream; qemb_ctx_timer_read reads the device timers of an idle context. */
+int qemb_ctx_count(int n);
+int qemb_ctx_bind(int k);
+int qemb_ctx_timer_read(int ctx, int slot, double* total_ms, int64_t* count, int reset);
 /* pair-packed MO transformation helpers (half the flops of the four-index ao2mo.kernel call of PySCF's cc.ao2mo(), which
  * solve_ccsd reaches at molbe/solver.py:900): row gather x >= y; the same fused with the unpack of the pair column; block gathers
  * from the pair-first MO tensor Mp[P(p,q)][r][s] and from the 3/4-transformed tensor T[P(r,s)][c][x]; (+/-) ladder operands. */

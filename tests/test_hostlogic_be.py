@@ -322,3 +322,15 @@ def test_hf_in_hf_h8_ccpvdz_be1_be2_be3(hlib):
     for key in ("test_autogen_h_linear_be1", "test_autogen_h_linear_be2", "test_autogen_h_linear_be3"):
         be = BE(mf, FragPart.from_json(GOLDEN / "fragmentation.json", key).replicate_sites(5), lib=hlib, distribute=False)
         assert abs(be.hf_err) < 1e-9, (key, be.hf_err)
+
+
+def test_every_exported_entry_point_is_declared_in_the_public_header():
+    """The converse of the export test: nothing is exported by api.cpp (or bound by _lib.py) without a declaration in include/qemb_hip.h."""
+    import re
+    from helpers import ROOT
+    header = (ROOT / "include" / "qemb_hip.h").read_text()
+    api = (ROOT / "quemb_amd" / "csrc" / "api.cpp").read_text()
+    exported = set(re.findall(r"^(?:int|void|const char\*)\s+(qemb_[a-z0-9_]+)\s*\(", api, flags=re.M))
+    bound = set(re.findall(r'f\("(qemb_[a-z0-9_]+)"', (ROOT / "quemb_amd" / "_lib.py").read_text()))
+    missing = sorted(f for f in exported | bound if not re.search(r"\b%s\s*\(" % f, header))
+    assert not missing, missing
