@@ -30,10 +30,12 @@ void Fragment::set_energy_data(const double* h1, const double* veff0, const doub
   centers_.assign(centers, centers + ncen);
 }
 
-int Fragment::run_scf(int o, const double* h, const double* dm0, const ScfOptions& opt, double* X0, ScfResult* sres) {
+int Fragment::run_scf(int o, const double* h, const double* dm0, const ScfOptions& opt, double* X0, ScfResult* sres, bool warm) {
   const int64_t n2 = (int64_t)n_ * n_;
   o_ = o;
-  QTRY(C_.alloc(n2)); QTRY(eps_.alloc(n_)); QTRY(dm_.alloc(n2)); QTRY(J_.alloc(n2)); QTRY(K_.alloc(n2));
+  const bool c_guess = warm && have_C_ && C_.p && dm0;
+  if (!c_guess) { have_C_ = false; QTRY(C_.alloc(n2)); }
+  QTRY(eps_.alloc(n_)); QTRY(dm_.alloc(n2)); QTRY(J_.alloc(n2)); QTRY(K_.alloc(n2));
   DBuf hd;
   QTRY(hd.alloc(n2));
   QTRY(dev_h2d(hd, h, sizeof(double) * n2));
@@ -44,7 +46,9 @@ int Fragment::run_scf(int o, const double* h, const double* dm0, const ScfOption
     QTRY(dev_jacobi_eigh(n_, tmp, eps_, C_, nullptr));
     QTRY(gemm(n_, n_, o, 2.0, C_, n_, true, C_, n_, true, 0.0, dm_, n_));
   }
-  return rhf_device(n_, o, hd, X0, dm_, opt, C_, eps_, J_, K_, sres, eri_s4_);
+  const int rc = rhf_device(n_, o, hd, X0, dm_, opt, C_, eps_, J_, K_, sres, eri_s4_, c_guess);
+  have_C_ = (rc == 0 && sres->converged);
+  return rc;
 }
 
 int Fragment::hf_veff_from_dm(const double* P_host, double* J_host, double* K_host) {
@@ -181,7 +185,7 @@ int Fragment::solve(int o, const double* h, const double* dm0, const FragmentOpt
   QTRY(X1.alloc(mo_transform_work(n)));
   QTRY(dev_unpack_tril_rows(npair(n), n, eri_s4_, X1));
   ScfResult sres;
-  QTRY(run_scf(o, h, dm0, opt.scf, X1, &sres));
+  QTRY(run_scf(o, h, dm0, opt.scf, X1, &sres, opt.warm_start != 0));
   res->scf_converged = sres.converged; res->scf_cycles = sres.cycles; res->e_scf = sres.e_tot;
   if (!sres.converged) { set_error("fragment SCF did not converge (also not with level shift 0.2)"); return QEMB_ERR_NOCONV; }
   std::vector<double> C((size_t)n2), eps((size_t)n), J((size_t)n2), K((size_t)n2);

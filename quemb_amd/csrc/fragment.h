@@ -62,7 +62,8 @@ class Fragment {
   int hf_veff_from_dm(const double* P_host, double* J_host, double* K_host);   // J,K of an n x n density
 
  private:
-  int run_scf(int o, const double* h, const double* dm0, const ScfOptions& opt, double* X0, ScfResult* sres);
+  int run_scf(int o, const double* h, const double* dm0, const ScfOptions& opt, double* X0, ScfResult* sres, bool warm = false);
+  bool have_C_ = false;    // C_ holds the orbitals of a converged earlier solve (eigensolver warm start when opt.warm_start)
   int n_, nf_, o_ = -1;
   DBuf eri_s4_;
   std::vector<double> h1_, veff0_, veff_;

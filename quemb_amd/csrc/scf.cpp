@@ -43,12 +43,13 @@ static int density_from_mos(int n, int o, const double* C, double* dm) {
 }
 
 static int rhf_loop(int n, int o, const double* h, const double* eri, const double* eri_s4, double* dm, const ScfOptions& opt,
-                    double* C, double* eps, double* J, double* K, ScfResult* res) {
+                    double* C, double* eps, double* J, double* K, ScfResult* res, bool c_is_guess) {
   const int64_t n2 = (int64_t)n * n;
   DBuf F, Fd, err, tmp, scal, hpf, Cprev, V;
   QTRY(F.alloc(n2)); QTRY(Fd.alloc(n2)); QTRY(err.alloc(n2)); QTRY(tmp.alloc(n2)); QTRY(scal.alloc(4)); QTRY(hpf.alloc(n2));
   QTRY(Cprev.alloc(n2)); QTRY(V.alloc(n2));
   bool have_prev = false;
+  if (c_is_guess) { QTRY(dcopy(n2, C, Cprev)); have_prev = true; }
   DeviceDIIS diis(opt.diis_space, n2);
   QTRY(diis.init());
   double e_old = 0.0;
@@ -103,7 +104,7 @@ static int rhf_loop(int n, int o, const double* h, const double* eri, const doub
 }
 
 int rhf_device(int n, int o, const double* h, const double* eri, double* dm, const ScfOptions& opt, double* C, double* eps,
-               double* J_out, double* K_out, ScfResult* res, const double* eri_s4) {
+               double* J_out, double* K_out, ScfResult* res, const double* eri_s4, bool c_is_guess) {
   if (n <= 0 || o <= 0 || o > n) { set_error("rhf_device: bad dimensions"); return QEMB_ERR_ARG; }
   const int64_t n2 = (int64_t)n * n;
   DBuf Jb, Kb;
@@ -113,13 +114,16 @@ int rhf_device(int n, int o, const double* h, const double* eri, double* dm, con
   QTRY(dev_timer_begin(TIMER_SCF));
   DBuf dm_start;
   QTRY(dm_start.alloc(n2)); QTRY(dcopy(n2, dm, dm_start));
-  QTRY(rhf_loop(n, o, h, eri, eri_s4, dm, opt, C, eps, J, K, res));
+  DBuf c_start;
+  if (c_is_guess) { QTRY(c_start.alloc(n2)); QTRY(dcopy(n2, C, c_start)); }
+  QTRY(rhf_loop(n, o, h, eri, eri_s4, dm, opt, C, eps, J, K, res, c_is_guess));
   if (!res->converged) {
     // molbe/helper.py:128-149: retry with level_shift = 0.2 and a 25-vector DIIS space
     ScfOptions o2 = opt;
     o2.level_shift = 0.2; o2.diis_space = 25;
     QTRY(dcopy(n2, dm_start, dm));
-    QTRY(rhf_loop(n, o, h, eri, eri_s4, dm, o2, C, eps, J, K, res));
+    if (c_is_guess) QTRY(dcopy(n2, c_start, C));
+    QTRY(rhf_loop(n, o, h, eri, eri_s4, dm, o2, C, eps, J, K, res, c_is_guess));
   }
   QTRY(dev_timer_end(TIMER_SCF));
   return 0;

@@ -29,6 +29,8 @@ int build_jk(int n, const double* eri_s1, const double* dm, double* J, double* K
 // h, dm (in: guess, out: converged density), C, eps: device buffers (n*n, n*n, n*n, n).
 // J_out/K_out (nullable): J and K of the converged density (n*n each).
 int rhf_device(int n, int o, const double* h, const double* eri_s1, double* dm, const ScfOptions& opt, double* C,
-               double* eps, double* J_out, double* K_out, ScfResult* res, const double* eri_s4 = nullptr);
+               double* eps, double* J_out, double* K_out, ScfResult* res, const double* eri_s4 = nullptr,
+               bool c_is_guess = false);   // c_is_guess: C holds orbitals of a nearby problem (previous sweep): the first
+                                           // Fock eigenproblem is rotated into them, like every later cycle into its predecessor
 
 }  // namespace qemb
