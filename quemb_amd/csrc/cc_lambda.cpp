@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 namespace qemb {
@@ -113,6 +114,9 @@ int CcLambda::contract(int dst, double coef, std::string sa, std::string sb, con
   else if (sb == Nord + Kord) { B = ptr_[b]; b_kc = true; }
   else { QTRY(operand(b, sb, Kord + Nord, &B, sB)); b_kc = false; }
   const int64_t lda = a_kc ? K : M, ldb = b_kc ? K : N;
+  static const bool trace = std::getenv("QEMB_LAMBDA_TRACE") != nullptr;
+  if (trace) std::fprintf(stderr, "[qemb lambda] %s,%s->%s  M=%lld N=%lld K=%lld a_kc=%d b_kc=%d permA=%d permB=%d permC=%d\n", sa.c_str(), sb.c_str(), so.c_str(),
+                          (long long)M, (long long)N, (long long)K, (int)a_kc, (int)b_kc, (int)(sA.p != nullptr), (int)(sB.p != nullptr), (int)(so != Mord + Nord));
   if (so == Mord + Nord) return gemm(M, N, K, coef, A, lda, a_kc, B, ldb, b_kc, 1.0, ptr_[dst], N);
   QTRY(sC.alloc(M * N));
   QTRY(gemm(M, N, K, 1.0, A, lda, a_kc, B, ldb, b_kc, 0.0, sC, N));

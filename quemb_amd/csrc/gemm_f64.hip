@@ -27,6 +27,8 @@
 #include <hip/hip_runtime.h>
 #include <atomic>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include "dev_ops.h"
 #include "hip_common.h"
 
@@ -390,7 +392,28 @@ int dev_mfma_f64_peak(int iters, int blocks_per_cu, double* tflops) {
   return QEMB_OK;
 }
 
+static int dev_gemm_dispatch(const GemmDesc& d);
+
+// QEMB_GEMM_TRACE=1: every product is timed on its own (events + a stream sync) and logged -- a debugging aid, not a mode to run in
 int dev_gemm(const GemmDesc& d) {
+  static const bool trace = std::getenv("QEMB_GEMM_TRACE") != nullptr;
+  hipEvent_t t0, t1;
+  if (!trace || dev_capturing() || hipEventCreate(&t0) != hipSuccess || hipEventCreate(&t1) != hipSuccess) return dev_gemm_dispatch(d);
+  hipStream_t s = hip_stream();
+  float ms = 0.f;
+  (void)hipEventRecord(t0, s);
+  const int rc = dev_gemm_dispatch(d);
+  (void)hipEventRecord(t1, s);
+  (void)hipEventSynchronize(t1);
+  (void)hipEventElapsedTime(&ms, t0, t1);
+  (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
+  std::fprintf(stderr, "[qemb gemm] M=%lld N=%lld K=%lld batch=%lld a_kc=%d b_kc=%d cfg=%d beta=%g  %.4f ms  %.1f TF\n", (long long)d.M, (long long)d.N,
+               (long long)d.K, (long long)d.batch, (int)d.a_kcontig, (int)d.b_kcontig, d.cfg, d.beta, ms,
+               ms > 0 ? 2.0 * d.M * d.N * d.K * d.batch / (ms * 1e9) : 0.0);
+  return rc;
+}
+
+static int dev_gemm_dispatch(const GemmDesc& d) {
   if (d.M <= 0 || d.N <= 0 || d.batch <= 0) return QEMB_OK;
   if (d.K < 0 || !d.A || !d.B || !d.C) { set_error("dev_gemm: bad arguments"); return QEMB_ERR_ARG; }
   if (d.M > 0x3fffffff || d.N > 0x3fffffff || d.K > 0x3fffffff) {

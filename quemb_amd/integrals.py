@@ -106,6 +106,22 @@ class Mole:
     def _arr(self):
         return (_BF * self.nao)(*self.bfs)
 
+    @property
+    def natm(self):
+        return len(self.atom)
+
+    def atom_charge(self, ia):
+        return _Z[self.atom[ia][0]]
+
+    def aoslice_by_atom(self):
+        """PySCF's (shell0, shell1, ao0, ao1) per atom; only the AO range is meaningful here (shells are not tracked)."""
+        ao = np.asarray(self.ao_atom)
+        out = []
+        for ia in range(self.natm):
+            w = np.nonzero(ao == ia)[0]
+            out.append((0, 0, int(w[0]), int(w[-1]) + 1))
+        return np.array(out)
+
     def energy_nuc(self):
         e = 0.0
         for i, (si, xi) in enumerate(self.atom):

@@ -5,7 +5,7 @@
 make_rdm1(), get_veff() -- a real `pyscf.scf.RHF` or `quemb_amd.integrals.RHF`.  What runs where:
   host (NumPy, once per system, out of scope per SURVEY 2): Loewdin localisation W = S^-1/2 (mbe.py:1395-1398);
   device (libqemb_hip): Schmidt decomposition, AO->fragment ERI transform, fragment Fock / SCF, CCSD, energies.
-Only lo_method="lowdin", restricted, no frozen core are mirrored (the configurations of SURVEY section 8).
+Only lo_method="lowdin", restricted is mirrored (the configurations of SURVEY section 8); frozen core as in mbe.py:397-419.
 """
 
 from __future__ import annotations
@@ -35,8 +35,6 @@ class BE:
                  eri_file=None, scratch_dir=None, restart=False, schmidt_method="subspace"):
         if lo_method != "lowdin":
             raise NotImplementedError("only lo_method='lowdin' is mirrored (localisation is upstream of the hot path)")
-        if getattr(fobj, "frozen_core", False):
-            raise NotImplementedError("frozen core is not mirrored")
         if restart:
             raise NotImplementedError("restart files are outside the hot path")
         self.mf, self.fobj, self.lib = mf, fobj, lib
@@ -59,6 +57,24 @@ class BE:
         self.hf_etot = float(mf.e_tot)
         self.E_core = 0.0
         self.ncore = 0
+        self.C_core = self.P_core = self.core_veff = None
+        self.frozen_core = bool(getattr(fobj, "frozen_core", False))
+        if self.frozen_core:
+            # mbe.py:397-419: the lowest `ncore` canonical MOs are frozen; their mean field moves from hf_veff into hcore
+            if getattr(fobj, "ncore", None) is None and hasattr(fobj, "set_core"):
+                fobj.set_core(mf.mol)
+            if fobj.ncore is None or fobj.no_core_idx is None or fobj.core_list is None:
+                raise ValueError("frozen-core fragmentation without ncore / no_core_idx / core_list")
+            self.ncore, self.no_core_idx, self.core_list = fobj.ncore, fobj.no_core_idx, fobj.core_list
+            self.Nocc -= self.ncore
+            Cv = self.C[:, self.ncore: self.ncore + self.Nocc]
+            self.hf_dm = 2.0 * Cv @ Cv.T
+            self.C_core = self.C[:, : self.ncore]
+            self.P_core = self.C_core @ self.C_core.T
+            self.core_veff = np.asarray(mf.get_veff(dm=self.P_core * 2.0))
+            self.E_core = float(np.einsum("ji,ji->", 2.0 * self.hcore + self.core_veff, self.P_core))
+            self.hf_veff = self.hf_veff - self.core_veff
+            self.hcore = self.hcore + self.core_veff
         self.pot = initialize_pot(fobj.n_frag, fobj.relAO_per_edge_per_frag)
         self.Fobjs: list[Frags] = []
         self.stats = {}
@@ -73,7 +89,15 @@ class BE:
         es_, vs_ = np.linalg.eigh(self.S)
         edx = es_ > 1.0e-15
         self.W = (vs_[:, edx] / np.sqrt(es_[edx])) @ vs_[:, edx].T
-        self.lmo_coeff = self.W.T @ self.S @ self.C
+        if self.frozen_core:
+            # mbe.py:1418-1431: project the core out of the Loewdin orbitals, keep the columns that stay populated (> 0.7),
+            # re-orthonormalise symmetrically -- N - ncore valence LOs in the order of the valence AOs
+            C_ = (np.eye(self.W.shape[0]) - self.P_core @ self.S) @ self.W
+            Cpop = np.diag(C_.T @ self.S @ C_)
+            C_ = C_[:, np.where(Cpop > 0.7)[0]]
+            es_, vs_ = np.linalg.eigh(C_.T @ self.S @ C_)
+            self.W = C_ @ ((vs_ / np.sqrt(es_)) @ vs_.T)
+        self.lmo_coeff = self.W.T @ self.S @ self.C[:, self.ncore:]
 
     # ------------------------------------------------------------------ initialisation (mbe.py:1183-1237)
     def initialize(self, eri_, initialize_fragment_idx=None):
@@ -91,7 +115,7 @@ class BE:
         # Schmidt decomposition of every fragment this rank may own (cheap; sizes decide the partition)
         for f in self.Fobjs:
             f.sd(self.W, self.lmo_coeff, self.Nocc, thr_bath=self.thr_bath, method=self.schmidt_method)
-            f.get_nsocc(self.S, self.C, self.Nocc)
+            f.get_nsocc(self.S, self.C, self.Nocc, ncore=self.ncore)
         costs = [fragment_cost(f.nao, f.nsocc) for f in self.Fobjs]
         self.owner = partition_fragments(costs, self.world)
         if initialize_fragment_idx is None:
@@ -148,6 +172,32 @@ class BE:
         self.hf_err = self.hf_etot - self.ebe_hf
         if self.rank == 0:
             print(f"HF-in-HF error                 :  {self.hf_err:>.4e} Ha", flush=True)
+
+    # ------------------------------------------------------------------ full-basis 1-RDM (mbe.py:488-700)
+    def rdm1_fullbasis(self, return_ao=True, only_rdm1=True, only_rdm2=False, return_lo=False, return_RDM2=False, print_energy=False):
+        """The democratically partitioned one-particle density matrix of the whole system from the fragment solutions of the
+        last sweep (mbe.py:560-577, :649-659): every fragment contributes P_c . rdm1_eo through the projector P_c on its
+        centre AOs.  Only the 1-RDM is mirrored (`only_rdm1=True`): the reference's two-particle part transforms the dense
+        n^4 fragment 2-RDMs, which the device path never forms (csrc/fragment.cpp contracts them in place)."""
+        if not only_rdm1 or only_rdm2 or return_RDM2:
+            raise NotImplementedError("rdm1_fullbasis: only the one-particle density matrix is mirrored (only_rdm1=True)")
+        nao = self.C.shape[0]
+        rdm1AO = np.zeros((nao, nao))
+        for I in self.my_frags:
+            f = self.Fobjs[I]
+            if f.rdm1__ is None:
+                raise RuntimeError("rdm1_fullbasis: run oneshot() or optimize() first")
+            cind = [f.AO_in_frag[i] for i in f.weight_and_relAO_per_center[1]]
+            SW = self.S @ self.W[:, cind]
+            Pc_ = f.TA.T @ SW @ SW.T @ f.TA
+            rdm1_eo = f.mo_coeffs @ f.rdm1__ @ f.mo_coeffs.T
+            rdm1AO += f.TA @ (Pc_ @ rdm1_eo) @ f.TA.T
+        if self.world > 1:
+            all_reduce_sum(rdm1AO)
+        rdm1AO = (rdm1AO + rdm1AO.T) / 2.0
+        rdm1LO = self.W.T @ self.S @ rdm1AO @ self.S @ self.W if return_lo else None
+        out = rdm1AO if return_ao else self.C.T @ self.S @ rdm1AO @ self.S @ self.C
+        return (out, rdm1LO) if return_lo else out
 
     # ------------------------------------------------------------------ sweeps
     def _sweep(self, pot, **kw):

@@ -208,6 +208,29 @@ def test_octane_be3_density_matching_golden(qlib):
     assert abs(be.ebe_tot - (-310.3344717358742)) < 2e-6
 
 
+def test_octane_frozen_core_density_matching_golden(qlib):
+    """tests/molbe_octane_get_rdms_test.py:52-67: octane/STO-3G BE2 CCSD density matching with the frozen-core approximation,
+    chemgen and autogen fragmentations alike: E_tot = -310.3311676424482 (np.isclose, rtol 1e-5).  The chemgen lists are the
+    reference's own expected data (tests/golden/fragmentation_chemgen.json); the autogen ones are the all-electron fixture
+    with the core AOs dropped (`FragPart.freeze_core`, the rule of molbe/autofrag.py:519-548)."""
+    from quemb_amd.fragpart import FragPart
+    from quemb_amd.integrals import RHF, Mole
+    from quemb_amd.mbe import BE
+    mol = Mole(GOLDEN / "octane.xyz")
+    mf = RHF(mol); mf.kernel()
+    for fobj in (FragPart.from_json(GOLDEN / "fragmentation_chemgen.json", "chemgen_octane_be2_frozen_core"),
+                 FragPart.from_json(GOLDEN / "fragmentation.json", "test_autogen_octane_be2").freeze_core(mol)):
+        assert fobj.frozen_core
+        be = BE(mf, fobj, distribute=False)
+        assert be.ncore == 8 and be.W.shape == (58, 50) and be.Nocc == 25
+        assert abs(be.ebe_hf - mf.e_tot) < 1e-7                 # HF-in-HF with E_core (mbe.py:1170)
+        opt = be.optimize(solver="CCSD", only_chem=False)
+        assert opt.err < 1e-6
+        assert abs(be.ebe_tot - (-310.3311676424482)) < 5e-6, be.ebe_tot
+        D_ao = be.rdm1_fullbasis(return_ao=True, only_rdm1=True)     # :59 of the reference test; the 50 valence electrons
+        assert abs(np.trace(D_ao @ be.S) - 50.0) < 1e-4
+
+
 def test_periodic_front_end_matches_reference_goldens(qlib):
     """kbe/pfrag.py:143-306 (k -> R Fourier, SVD Schmidt, cons_h1, get_nsocc) on the device against the reference's own outputs."""
     from helpers import check_periodic_front_end
