@@ -208,6 +208,22 @@ def test_octane_be3_density_matching_golden(qlib):
     assert abs(be.ebe_tot - (-310.3344717358742)) < 2e-6
 
 
+def test_hf_in_hf_reference_cases(qlib):
+    """tests/hf-in-hf_BE_test.py:16-63, every molecular case: H8/STO-3G, H8/cc-pVDZ and octane/STO-3G, autogen BE1, BE2, BE3:
+    `ebe_hf == mf.e_tot` (reference delta 1e-5; here 1e-7)."""
+    from quemb_amd.fragpart import FragPart
+    from quemb_amd.integrals import RHF, Mole
+    from quemb_amd.mbe import BE
+    h8 = [["H", (0.0, 0.0, float(i))] for i in range(8)]
+    for mol, stem, rep in ((Mole(h8), "test_autogen_h_linear_be", 1), (Mole(h8, basis="cc-pvdz"), "test_autogen_h_linear_be", 5),
+                           (Mole(GOLDEN / "octane.xyz"), "test_autogen_octane_be", 1)):
+        mf = RHF(mol); mf.kernel()
+        for n_BE in (1, 2, 3):
+            fobj = FragPart.from_json(GOLDEN / "fragmentation.json", f"{stem}{n_BE}", n_BE=n_BE)
+            be = BE(mf, fobj.replicate_sites(rep) if rep > 1 else fobj, distribute=False)
+            assert abs(be.ebe_hf - mf.e_tot) < 1e-7, (stem, rep, n_BE, be.ebe_hf - mf.e_tot)
+
+
 def test_octane_frozen_core_density_matching_golden(qlib):
     """tests/molbe_octane_get_rdms_test.py:52-67: octane/STO-3G BE2 CCSD density matching with the frozen-core approximation,
     chemgen and autogen fragmentations alike: E_tot = -310.3311676424482 (np.isclose, rtol 1e-5).  The chemgen lists are the
