@@ -199,6 +199,10 @@ class BE:
         out = rdm1AO if return_ao else self.C.T @ self.S @ rdm1AO @ self.S @ self.C
         return (out, rdm1LO) if return_lo else out
 
+    def compute_numerical_jacobian(self, solver="CCSD", only_chem=False, nproc=1, step_size=1e-6):
+        from .numerical_jac import compute_numerical_jacobian
+        return compute_numerical_jacobian(self, solver, only_chem, nproc, step_size=step_size)
+
     # ------------------------------------------------------------------ sweeps
     def _sweep(self, pot, **kw):
         if self.world > 1:
@@ -240,10 +244,13 @@ class BE:
         be_ = BEOPT(pot, self.Fobjs, self.Nocc, self.enuc, solver=solver, only_chem=only_chem, use_cumulant=use_cumulant,
                     max_space=max_iter, conv_tol=conv_tol, relax_density=relax_density, ebe_hf=self.ebe_hf,
                     sweep=self._sweep, verbose=self.rank == 0)
-        J0 = get_be_error_jacobian(self.fobj.n_frag, self.Fobjs, jac_solver=jac_solver, owner=self.owner, rank=self.rank,
-                                   world=self.world, opts=self.opts)
-        if only_chem:
-            J0 = J0[-1:, -1:]
+        if jac_solver == "Numerical":
+            J0 = self.compute_numerical_jacobian(solver, only_chem, nproc, step_size=step_size)      # mbe.py:942-945
+        else:
+            J0 = get_be_error_jacobian(self.fobj.n_frag, self.Fobjs, jac_solver=jac_solver, owner=self.owner, rank=self.rank,
+                                       world=self.world, opts=self.opts)
+            if only_chem:
+                J0 = J0[-1:, -1:]
         saved_opts = self.opts
         if warm_start:
             from ._lib import SolverOpts

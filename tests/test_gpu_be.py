@@ -208,6 +208,23 @@ def test_octane_be3_density_matching_golden(qlib):
     assert abs(be.ebe_tot - (-310.3344717358742)) < 2e-6
 
 
+def test_octane_numerical_jacobian_matching(qlib):
+    """tests/numerical_jac_test.py:24-44 in spirit (octane, BE2, `jac_solver="Numerical"` against `"HF"`, atol 1e-5): the
+    281 x 281 central-difference CCSD Jacobian (2 x 280 single-fragment solves + 2 sweeps) and the HF (CPHF) Jacobian lead the
+    QN optimisation to the same energy."""
+    import time
+    mf, be = _be("octane")
+    t0 = time.time()
+    be.optimize(solver="CCSD", jac_solver="Numerical", step_size=1e-4)
+    t_num = time.time() - t0
+    mf2, be2 = _be("octane")
+    t0 = time.time()
+    be2.optimize(solver="CCSD", jac_solver="HF")
+    print(f"octane BE2 matching: numerical Jacobian {t_num:.2f} s / {be.beopt.iter} QN iterations, HF Jacobian {time.time() - t0:.2f} s / {be2.beopt.iter}")
+    assert be.beopt.err < 1e-6 and abs(be.ebe_tot - be2.ebe_tot) < 2e-6
+    assert abs(be.ebe_tot - (-310.3347211309688)) < 5e-6         # tests/molbe_octane_test.py:32-36
+
+
 def test_hf_in_hf_reference_cases(qlib):
     """tests/hf-in-hf_BE_test.py:16-63, every molecular case: H8/STO-3G, H8/cc-pVDZ and octane/STO-3G, autogen BE1, BE2, BE3:
     `ebe_hf == mf.e_tot` (reference delta 1e-5; here 1e-7)."""

@@ -377,6 +377,30 @@ def test_frozen_core_lists_and_hf_in_hf(hlib):
     assert abs(be.E_core - np.einsum("ji,ji->", 2.0 * mf.get_hcore() + mf.get_veff(dm=2.0 * be.P_core), be.P_core)) < 1e-12
 
 
+def test_numerical_jacobian(hlib):
+    """molbe/numerical_jac.py:11-168 / tests/numerical_jac_test.py:46-63 (H8, BE2, CCSD): the central-difference Jacobian of
+    the matching conditions.  Columns agree with independent finite differences through full sweeps, and the QN optimisation
+    started from it ends at the energy of the one started from the HF Jacobian (reference atol 1e-5; here 1e-7)."""
+    mf, fobj, be = _h8(hlib)
+    h = 1e-4
+    Jn = be.compute_numerical_jacobian("CCSD", False, 1, step_size=h)
+    assert Jn.shape == (len(be.pot), len(be.pot))
+    for k in (0, 3, len(be.pot) - 2, len(be.pot) - 1):
+        x = np.array(be.pot, float); x[k] += h
+        ep = be._sweep(list(x), eeval=False, return_vec=True)[1]
+        x[k] -= 2 * h
+        em = be._sweep(list(x), eeval=False, return_vec=True)[1]
+        assert np.abs((ep - em) / (2 * h) - Jn[:, k]).max() < 5e-6, k
+    be.optimize(solver="CCSD", jac_solver="Numerical", conv_tol=1e-7, step_size=h)
+    mf2, fobj2, be2 = _h8(hlib)
+    be2.optimize(solver="CCSD", jac_solver="HF", conv_tol=1e-7)
+    assert abs(be.ebe_tot - be2.ebe_tot) < 1e-7
+    assert be.beopt.iter <= be2.beopt.iter            # the CCSD response is the exact first-order model of the sweep
+    mf3, fobj3, be3 = _h8(hlib)
+    J1 = be3.compute_numerical_jacobian("CCSD", True, 1, step_size=h)
+    assert J1.shape == (1, 1) and abs(J1[0, 0] - Jn[-1, -1]) < 1e-6
+
+
 def test_every_exported_entry_point_is_declared_in_the_public_header():
     """The converse of the export test: nothing is exported by api.cpp (or bound by _lib.py) without a declaration in include/qemb_hip.h."""
     import re
