@@ -37,7 +37,9 @@ def _worker(rank, world, port, q):
     assert all((be.Fobjs[i].fock is not None) == (be.owner[i] == rank) for i in range(fobj.n_frag))
     ecorr, comps = be.oneshot()
     opt = be.optimize(solver="CCSD", only_chem=False, conv_tol=1e-7)
-    q.put((rank, ecorr, list(comps), be.ebe_hf, list(be.pot), be.e_corr, opt.err, opt.iter))
+    D_ao = be.rdm1_fullbasis(only_rdm1=True)                              # summed over ranks
+    Jn = be.compute_numerical_jacobian("CCSD", False, 1, step_size=1e-4)   # every rank fills the columns of its fragments
+    q.put((rank, ecorr, list(comps), be.ebe_hf, list(be.pot), be.e_corr, opt.err, opt.iter, D_ao, Jn))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -56,7 +58,7 @@ def test_two_rank_sweep_equals_single_process():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=500) for _ in range(2))
+    res = sorted((q.get(timeout=500) for _ in range(2)), key=lambda r: r[0])
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
@@ -73,7 +75,10 @@ def test_two_rank_sweep_equals_single_process():
     be = BE(mf, fobj, lib=lib, distribute=False)
     e1, c1 = be.oneshot()
     opt = be.optimize(solver="CCSD", only_chem=False, conv_tol=1e-7)
-    for (rank, ecorr, comps, ebe_hf, pot, e_opt, err, it) in res:
+    D1 = be.rdm1_fullbasis(only_rdm1=True)
+    J1 = be.compute_numerical_jacobian("CCSD", False, 1, step_size=1e-4)
+    for (rank, ecorr, comps, ebe_hf, pot, e_opt, err, it, D_ao, Jn) in res:
+        assert np.abs(D_ao - D1).max() < 1e-8 and np.abs(Jn - J1).max() < 1e-6
         assert abs(ecorr - e1) < 1e-11 and np.allclose(comps, c1, atol=1e-11)
         assert abs(ebe_hf - be.ebe_hf) < 1e-10
         assert np.allclose(pot, be.pot, atol=1e-8) and abs(e_opt - be.e_corr) < 1e-9
