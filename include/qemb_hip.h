@@ -218,6 +218,13 @@ int qemb_df_free(qemb_df_t df);
 /* 3-index integrals: layout 0 = (N,N,naux) "pqL" as getints3c returns them (eri_onthefly.py:85),
  * 1 = (naux,N,N), 2 = (naux, npair(N)) unique pairs mu >= nu (SemiSparseSym3DTensor without screening) */
 int qemb_df_set_ints(qemb_df_t df, int N, const double* ints, int layout);
+/* The reference's SemiSparseSym3DTensor itself (_cpp/eri_sparse_DF.cpp:110-298), never expanded to the dense (P|mu nu):
+ * unique_dense_data = the (naux x n_unique) column-major matrix of the reference (one aux vector per stored unique AO pair;
+ * n_unique x naux when read row-major); exch_reachable_with_offsets (:260-279) in CSR form: the partners of AO mu are
+ * reach_nu[reach_ptr[mu] .. reach_ptr[mu+1]) and reach_off[...] is the column of the pair's aux vector.  Device memory is
+ * O(n_unique naux); both transforms below then run the screened algorithm on this storage.                            */
+int qemb_df_set_ints_semisparse(qemb_df_t df, int N, int64_t n_unique, const double* unique_dense_data, const int64_t* reach_ptr,
+                                const int32_t* reach_nu, const int64_t* reach_off);
 int qemb_df_transform(qemb_df_t df, const double* TA, int n, double* out_s4_host, qemb_frag_t frag);
 /* the same with the MO-coefficient screening of transform_integral(int_P_mu_nu, TA, S_abs, L_PQ, MO_coeff_epsilon)
  * (_cpp/eri_sparse_DF.cpp:739-751): (P|mu i) is kept only for mu with |S_abs TA|(mu,i) >= epsilon (get_AO_per_MO :443);

@@ -123,10 +123,40 @@ def transform_integral_semisparse(P_munu_packed, stored_pairs, TA, S_abs, L_PQ, 
     npr = npair(nmo)
     sym = np.zeros((naux, npr))
     for ij in range(npr):
-        i = int((np.sqrt(8 * ij + 1) - 1) // 2)
-        j = ij - i * (i + 1) // 2
-        if j > i:
-            i, j = j, i
+        # unravel_symmetric (indexers.hpp:89-96) returns (smaller, larger): the AO list of the SMALLER orbital index is walked
+        j = int((np.sqrt(8 * ij + 1) - 1) // 2)
+        i = ij - j * (j + 1) // 2
+        assert i <= j
+        tmp = np.zeros(naux)
+        for mu in AO_by_MO[i]:
+            tmp += TA[mu, j] * g[(mu, i)]
+        sym[:, ij] = tmp
+    Xs = scipy.linalg.solve_triangular(L_PQ, sym, lower=True)
+    return Xs.T @ Xs
+
+
+def transform_integral_semisparse_csr(unique_dense_data, exch_reachable_with_offsets, TA, S_abs, L_PQ, MO_coeff_epsilon):
+    """transform_integral (_cpp/eri_sparse_DF.cpp:739-751) on the reference's own storage: `unique_dense_data` (naux, n_unique),
+    one aux vector per stored unique AO pair, and `exch_reachable_with_offsets[mu] = [(column, nu), ...]` (:260-279).
+    The loops are those of get_AO_per_MO (:443-465), contract_with_TA_1st (:514-521), contract_with_TA_2nd_to_sym_dense (:586-595,
+    (i, j) = unravel_symmetric -> i <= j, the AO list of i is walked) and eval_via_cholesky (:611-621)."""
+    import scipy.linalg
+    naux = unique_dense_data.shape[0]
+    N, nmo = TA.shape
+    X = np.abs(S_abs @ TA) if S_abs is not None else None
+    AO_by_MO = [[mu for mu in range(N) if X is None or X[mu, i] >= MO_coeff_epsilon] for i in range(nmo)]
+    g = {}
+    for i in range(nmo):
+        for mu in AO_by_MO[i]:
+            acc = np.zeros(naux)
+            for off, nu in exch_reachable_with_offsets[mu]:
+                acc += TA[nu, i] * unique_dense_data[:, off]
+            g[(mu, i)] = acc
+    npr = npair(nmo)
+    sym = np.zeros((naux, npr))
+    for ij in range(npr):
+        j = int((np.sqrt(8 * ij + 1) - 1) // 2)
+        i = ij - j * (j + 1) // 2
         tmp = np.zeros(naux)
         for mu in AO_by_MO[i]:
             tmp += TA[mu, j] * g[(mu, i)]

@@ -127,6 +127,7 @@ def _declare(lib):
     f("qemb_lpq_upload", I, P, I, C.POINTER(c_vp))
     f("qemb_df_free", I, V)
     f("qemb_df_set_ints", I, V, I, P, I)
+    f("qemb_df_set_ints_semisparse", I, V, I, L, P, P, P, P)
     f("qemb_df_transform", I, V, P, I, P, V)
     f("qemb_df_transform_screened", I, V, P, I, P, D, P, V)
     f("qemb_schmidt", I, P, I, I, I, LP, I, D, P, I, IP, IP)

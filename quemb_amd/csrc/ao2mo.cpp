@@ -12,6 +12,7 @@
 //   tensor, so the reference's memory-driven aux blocking (eri_onthefly.py:18-42) is not needed.
 #include "ao2mo.h"
 #include <algorithm>
+#include <cstdlib>
 
 namespace qemb {
 
@@ -85,12 +86,14 @@ int DfContext::set_cholesky_factor(int naux_, const double* Lh) {
 }
 int DfContext::set_ints_Lpq(int N_, const double* h) {
   N = N_;
+  Usp.release(); n_unique = 0;
   if (naux <= 0) { set_error("DfContext: set the metric first"); return QEMB_ERR_ARG; }
   QTRY(Lpq.alloc((int64_t)naux * N * N));
   return dev_h2d(Lpq, h, sizeof(double) * naux * N * N);
 }
 int DfContext::set_ints_pqL(int N_, const double* h) {
   N = N_;
+  Usp.release(); n_unique = 0;
   if (naux <= 0) { set_error("DfContext: set the metric first"); return QEMB_ERR_ARG; }
   DBuf tmp;
   const int64_t n2 = (int64_t)N * N;
@@ -102,6 +105,7 @@ int DfContext::set_ints_pqL(int N_, const double* h) {
 }
 int DfContext::set_ints_packed(int N_, const double* h) {
   N = N_;
+  Usp.release(); n_unique = 0;
   if (naux <= 0) { set_error("DfContext: set the metric first"); return QEMB_ERR_ARG; }
   DBuf tmp;
   QTRY(tmp.alloc((int64_t)naux * npair(N)));
@@ -110,9 +114,131 @@ int DfContext::set_ints_packed(int N_, const double* h) {
   return dev_unpack_tril_rows(naux, N, tmp, Lpq);
 }
 
+int DfContext::set_ints_semisparse(int N_, int64_t n_unique_, const double* unique_host, const int64_t* ptr, const int32_t* nu,
+                                   const int64_t* off) {
+  if (naux <= 0) { set_error("DfContext: set the metric first"); return QEMB_ERR_ARG; }
+  if (N_ <= 0 || n_unique_ < 0 || !ptr || (n_unique_ > 0 && (!unique_host || !nu || !off))) { set_error("set_ints_semisparse: bad arguments"); return QEMB_ERR_ARG; }
+  if (ptr[0] != 0) { set_error("set_ints_semisparse: reach_ptr[0] must be 0"); return QEMB_ERR_ARG; }
+  for (int mu = 0; mu < N_; ++mu) {
+    if (ptr[mu + 1] < ptr[mu]) { set_error("set_ints_semisparse: reach_ptr must be non-decreasing"); return QEMB_ERR_ARG; }
+    for (int64_t e = ptr[mu]; e < ptr[mu + 1]; ++e)
+      if (nu[e] < 0 || nu[e] >= N_ || off[e] < 0 || off[e] >= n_unique_) { set_error("set_ints_semisparse: partner or offset out of range"); return QEMB_ERR_ARG; }
+  }
+  N = N_; n_unique = n_unique_;
+  reach_ptr.assign(ptr, ptr + N + 1);
+  reach_nu.assign(nu, nu + ptr[N]);
+  reach_off.assign(off, off + ptr[N]);
+  Lpq.release();
+  QTRY(Usp.alloc(std::max<int64_t>(1, n_unique * naux)));
+  return n_unique > 0 ? dev_h2d(Usp, unique_host, sizeof(double) * n_unique * naux) : QEMB_OK;
+}
+
+// bpT[P(i,j)][L'] (pair rows of naux) -> (ij|kl) = sum_L bb[ij][L] bb[kl][L], bb = bpT Linv^T   (eval_via_cholesky, eri_sparse_DF.cpp:611-621)
+int DfContext::finish_from_pair_rows(int n, const double* bpT, double* out_s4) const {
+  const int64_t np = npair(n);
+  DBuf bbT;
+  QTRY(bbT.alloc(np * naux));
+  QTRY(gemm(np, naux, naux, 1.0, bpT, naux, true, Linv, naux, true, 0.0, bbT, naux));
+  const int64_t nblk = np >= 2048 ? 8 : 1;
+  const int64_t w = ((np + nblk - 1) / nblk + 127) / 128 * 128;
+  for (int64_t c0 = 0; c0 < np; c0 += w) {
+    const int64_t cw = std::min(w, np - c0);
+    QTRY(gemm(np - c0, cw, naux, 1.0, bbT.p + c0 * naux, naux, true, bbT.p + c0 * naux, naux, true, 0.0, out_s4 + c0 * np + c0, np));
+  }
+  if (nblk > 1) QTRY(dev_mirror_lower(np, out_s4, np));
+  return 0;
+}
+
+// transform_integral on the semi-sparse tensor (_cpp/eri_sparse_DF.cpp:739-751).  The irregular first contraction
+// (contract_with_TA_1st :484-532, an AXPY per (mu, i, nu) in the reference) becomes, for a block of AOs mu, ONE batched GEMM:
+//   (P|mu i) = sum_{nu in reach(mu)} TA[nu,i] (P|mu nu)   ==   T1[mu][i][P] = TAg[mu]^T Dg[mu],
+// Dg[mu][k][:] = aux vector of the k-th partner of mu, TAg[mu][k][:] = TA row of that partner (zero rows pad short lists), both
+// gathered by index.  Every stored aux vector is read twice (once per member of its pair) instead of once per (mu, i).
+int DfContext::transform_semisparse(const double* TA, int n, double* out_s4, const double* S_abs, double eps) const {
+  const int64_t np = npair(n);
+  DBuf T1, T2, bpT, maskb, Xb, TAact, idx_dev;
+  QTRY(dev_timer_begin(TIMER_DF));
+  // get_AO_per_MO (:443-465): (P|mu i) exists only where |S_abs TA|(mu,i) >= eps.  AOs that no embedding orbital reaches drop out
+  // of BOTH contractions, so the work and the intermediate follow the fragment's footprint, not the size of the molecule.
+  std::vector<int64_t> act;
+  if (S_abs) {
+    QTRY(Xb.alloc((int64_t)N * n)); QTRY(maskb.alloc((int64_t)N * n));
+    QTRY(gemm(N, n, N, 1.0, S_abs, N, true, TA, n, false, 0.0, Xb, n));
+    QTRY(dev_threshold_mask((int64_t)N * n, Xb, eps, maskb));
+    std::vector<double> mh((size_t)N * n);
+    QTRY(dev_d2h(mh.data(), maskb, sizeof(double) * N * n));
+    for (int64_t mu = 0; mu < N; ++mu) {
+      bool any = false;
+      for (int i = 0; i < n && !any; ++i) any = mh[(size_t)mu * n + i] != 0.0;
+      if (any) act.push_back(mu);
+    }
+  } else {
+    act.resize(N);
+    for (int64_t mu = 0; mu < N; ++mu) act[mu] = mu;
+  }
+  const int64_t Na = (int64_t)act.size();
+  if (Na == 0) {                                          // everything screened away: the transformed integrals vanish
+    QTRY(dev_fill(out_s4, np * np, 0.0));
+    return dev_timer_end(TIMER_DF);
+  }
+  QTRY(T1.alloc(Na * n * naux));
+  {
+    // blocks of (active) AOs whose gathered operands stay under ~1 GiB
+    int64_t budget = (int64_t)1 << 27;
+    if (const char* e = std::getenv("QEMB_DF_GATHER_BUDGET")) budget = std::max<int64_t>(1, std::atoll(e));   // doubles; tests force several blocks
+    int64_t a0 = 0;
+    std::vector<int64_t> idxD, idxT;
+    DBuf Dg, TAg;
+    while (a0 < Na) {
+      int64_t Kc = 0, a1 = a0;
+      while (a1 < Na) {
+        const int64_t k = reach_ptr[act[a1] + 1] - reach_ptr[act[a1]];
+        const int64_t Kn = std::max(Kc, std::max<int64_t>(k, 1));
+        if (a1 > a0 && (a1 + 1 - a0) * Kn * (naux + n) > budget) break;
+        Kc = Kn; ++a1;
+      }
+      const int64_t B = a1 - a0;
+      idxD.assign(B * Kc, -1); idxT.assign(B * Kc, -1);
+      for (int64_t b = 0; b < B; ++b) {
+        const int64_t e0 = reach_ptr[act[a0 + b]], cnt = reach_ptr[act[a0 + b] + 1] - e0;
+        for (int64_t k = 0; k < cnt; ++k) { idxD[b * Kc + k] = reach_off[e0 + k]; idxT[b * Kc + k] = reach_nu[e0 + k]; }
+      }
+      QTRY(idx_dev.alloc(2 * B * Kc));
+      QTRY(dev_h2d(idx_dev, idxD.data(), sizeof(int64_t) * B * Kc));
+      QTRY(dev_h2d(idx_dev.p + B * Kc, idxT.data(), sizeof(int64_t) * B * Kc));
+      QTRY(Dg.alloc(B * Kc * naux)); QTRY(TAg.alloc(B * Kc * n));
+      QTRY(dev_gather_rows(B * Kc, naux, reinterpret_cast<const int64_t*>(idx_dev.p), Usp, naux, Dg));
+      QTRY(dev_gather_rows(B * Kc, n, reinterpret_cast<const int64_t*>(idx_dev.p + B * Kc), TA, n, TAg));
+      QTRY(gemm(n, naux, Kc, 1.0, TAg, n, false, Dg, naux, false, 0.0, T1.p + a0 * n * naux, naux, B, Kc * n, Kc * naux, (int64_t)n * naux));
+      QTRY(dev_sync());                                  // the host index vectors and the scratch are reused by the next block
+      a0 = a1;
+    }
+  }
+  // rows of TA (and of the mask) of the active AOs
+  QTRY(idx_dev.alloc(Na));
+  QTRY(dev_h2d(idx_dev, act.data(), sizeof(int64_t) * Na));
+  QTRY(TAact.alloc(Na * n));
+  QTRY(dev_gather_rows(Na, n, reinterpret_cast<const int64_t*>(idx_dev.p), TA, n, TAact));
+  if (S_abs) {
+    QTRY(dev_gather_rows(Na, n, reinterpret_cast<const int64_t*>(idx_dev.p), maskb, n, Xb));      // Xb: compacted mask [a][i]
+    QTRY(dev_scale_rows(Na * n, naux, T1, Xb));
+  }
+  // contract_with_TA_2nd_to_sym_dense (:560-605): for i <= j, sum_{mu in AO_by_MO[i]} TA[mu,j] (P|mu i) -> T2[j][i][P], batched over i
+  QTRY(T2.alloc((int64_t)n * n * naux));
+  QTRY(gemm(n, naux, Na, 1.0, TAact, n, false, T1, (int64_t)n * naux, false, 0.0, T2, (int64_t)n * naux, n, 0, naux, naux));
+  T1.release();
+  QTRY(bpT.alloc(np * naux));
+  QTRY(dev_pack_pair_rows(n, naux, T2, bpT));            // rows (j >= i) of T2[j][i][:]
+  T2.release();
+  QTRY(finish_from_pair_rows(n, bpT, out_s4));
+  QTRY(dev_timer_end(TIMER_DF));
+  return 0;
+}
+
 int DfContext::transform(const double* TA, int n, double* out_s4, const double* S_abs, double eps) const {
-  if (!Linv.p || !Lpq.p) { set_error("DfContext: metric and 3-index integrals must be set"); return QEMB_ERR_ARG; }
   if (n <= 0 || n > N) { set_error("df transform: need 0 < n <= N"); return QEMB_ERR_ARG; }
+  if (Linv.p && Usp.p) return transform_semisparse(TA, n, out_s4, S_abs, eps);
+  if (!Linv.p || !Lpq.p) { set_error("DfContext: metric and 3-index integrals must be set"); return QEMB_ERR_ARG; }
   const int64_t np = npair(n);
   DBuf T1, T2, bp, bb;
   QTRY(T1.alloc((int64_t)naux * n * N)); QTRY(T2.alloc((int64_t)naux * n * n));
@@ -130,8 +256,15 @@ int DfContext::transform(const double* TA, int n, double* out_s4, const double* 
     QTRY(dev_threshold_mask((int64_t)n * N, X, eps, mask));
     QTRY(dev_mul_bcast_rows(naux, (int64_t)n * N, T1, mask));
   }
-  // T2[(L,i),j] = sum_nu T1[(L,i),nu] TA[nu,j]           (eri_onthefly.py:136)
-  QTRY(gemm((int64_t)naux * n, n, N, 1.0, T1, N, true, TA, n, false, 0.0, T2, n));
+  if (S_abs) {
+    // contract_with_TA_2nd_to_sym_dense (eri_sparse_DF.cpp:586-595): for the pair (i <= j) the AO list of the SMALLER index i is
+    // walked, sum_{mu in AO_by_MO[i]} TA[mu,j] (P|mu i).  T2[L][j][i] = sum_nu TA[nu,j] T1[L,i,nu], whose lower triangle
+    // (row j >= column i) is exactly that element.
+    QTRY(gemm(n, n, N, 1.0, TA, n, false, T1, N, true, 0.0, T2, n, naux, 0, (int64_t)n * N, (int64_t)n * n));
+  } else {
+    // T2[(L,i),j] = sum_nu T1[(L,i),nu] TA[nu,j]           (eri_onthefly.py:136; symmetric in i, j)
+    QTRY(gemm((int64_t)naux * n, n, N, 1.0, T1, N, true, TA, n, false, 0.0, T2, n));
+  }
   // unique pairs i >= j                                   (eri_sparse_DF.cpp:560-605 sym_P_pq)
   QTRY(dev_pack_tril_rows(naux, n, T2, bp));
   // bb = L^-1 bp                                          (eri_onthefly.py:141 / cublasDtrsm :667)

@@ -1,6 +1,7 @@
 // ao2mo.h -- AO -> embedding-basis ERI transforms (rows a3, a4, a5 of SURVEY.md section 8).
 #pragma once
 #include <cstdint>
+#include <vector>
 #include "dev_ops.h"
 #include "tensor_utils.h"
 
@@ -29,9 +30,22 @@ class DfContext {
   int set_ints_pqL(int N_, const double* pqL_host);               // (N, N, naux) as produced by getints3c
   int set_ints_Lpq(int N_, const double* Lpq_host);               // (naux, N, N)
   int set_ints_packed(int N_, const double* P_munu_packed_host);  // (naux, npair(N)), mu >= nu
+  // The reference's SemiSparseSym3DTensor (_cpp/eri_sparse_DF.cpp:110-298) as it is, never expanded: `unique` = one aux vector
+  // (naux doubles) per stored unique AO pair, n_unique x naux row-major (= the column-major naux x n_unique Eigen matrix);
+  // exch_reachable_with_offsets in CSR form (partners nu of mu and the row of the pair's aux vector).  O(n_unique naux) memory.
+  int set_ints_semisparse(int N_, int64_t n_unique_, const double* unique_host, const int64_t* reach_ptr, const int32_t* reach_nu,
+                          const int64_t* reach_off);
   // S_abs_dev (N x N, may be null) + eps: the MO-coefficient screening of the semi-sparse transform
   // (_cpp/eri_sparse_DF.cpp:443-465 get_AO_per_MO): (P|mu i) is kept only where |S_abs TA|(mu,i) >= eps.
   int transform(const double* TA_dev, int n, double* out_s4_dev, const double* S_abs_dev = nullptr, double eps = 0.0) const;
+
+  DBuf Usp;                              // semi-sparse storage: [n_unique][naux]
+  int64_t n_unique = 0;
+  std::vector<int64_t> reach_ptr, reach_off;
+  std::vector<int32_t> reach_nu;
+ private:
+  int transform_semisparse(const double* TA_dev, int n, double* out_s4_dev, const double* S_abs_dev, double eps) const;
+  int finish_from_pair_rows(int n, const double* bpT, double* out_s4) const;
 };
 
 }  // namespace qemb

@@ -278,6 +278,11 @@ int qemb_df_set_ints(qemb_df_t df, int N, const double* ints, int layout) {
   set_error("qemb_df_set_ints: layout must be 0, 1 or 2");
   return QEMB_ERR_ARG;
 }
+int qemb_df_set_ints_semisparse(qemb_df_t df, int N, int64_t n_unique, const double* unique_dense_data, const int64_t* reach_ptr,
+                                const int32_t* reach_nu, const int64_t* reach_off) {
+  if (!df) { set_error("qemb_df_set_ints_semisparse: null handle"); return QEMB_ERR_ARG; }
+  return reinterpret_cast<DfContext*>(df)->set_ints_semisparse(N, n_unique, unique_dense_data, reach_ptr, reach_nu, reach_off);
+}
 int qemb_df_transform_screened(qemb_df_t df, const double* TA, int n, const double* S_abs, double MO_coeff_epsilon,
                                double* out_s4_host, qemb_frag_t frag) {
   if (!df || !TA || !S_abs) { set_error("qemb_df_transform_screened: null argument"); return QEMB_ERR_ARG; }

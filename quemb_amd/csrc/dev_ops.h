@@ -156,6 +156,11 @@ int dev_threshold_mask(int64_t n, const double* x, double eps, double* out);
 // x[r*cols + c] *= m[c]   for r < rows   (broadcast a mask / scale row over a batch of rows)
 int dev_mul_bcast_rows(int64_t rows, int64_t cols, double* x, const double* m);
 
+// dst[r, 0:len] = idx[r] >= 0 ? src[idx[r]*ld + 0:len] : 0   (row gather; idx is an int64 array ON THE DEVICE; dst rows are len long)
+int dev_gather_rows(int64_t nrows, int64_t len, const int64_t* idx_dev, const double* src, int64_t ld, double* dst);
+// x[r, 0:len] *= s[r]
+int dev_scale_rows(int64_t nrows, int64_t len, double* x, const double* s);
+
 // ---- reductions ---------------------------------------------------------------------------------
 // out_dev[0] = sum_i x[i]*y[i]   (deterministic two-stage reduction; out_dev is a device double)
 int dev_dot(int64_t n, const double* x, const double* y, double* out_dev);

@@ -484,6 +484,42 @@ int dev_mul_bcast_rows(int64_t rows, int64_t cols, double* x, const double* m) {
   return QEMB_OK;
 }
 
+// one row per blockIdx.y (grid-stride), 256 threads stride along the row: reads and writes are contiguous runs of `len` doubles
+__global__ void __launch_bounds__(256) gather_rows_kernel(long long nrows, long long len, const long long* __restrict__ idx,
+                                                          const double* __restrict__ src, long long ld, double* __restrict__ dst) {
+  for (long long r = blockIdx.y; r < nrows; r += gridDim.y) {
+    const long long sr = idx[r];
+    const double* in = src + (sr < 0 ? 0 : sr) * ld;
+    double* out = dst + r * len;
+    for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < len; c += (long long)gridDim.x * blockDim.x)
+      out[c] = sr < 0 ? 0.0 : in[c];
+  }
+}
+int dev_gather_rows(int64_t nrows, int64_t len, const int64_t* idx_dev, const double* src, int64_t ld, double* dst) {
+  REQUIRE_INIT();
+  if (nrows <= 0 || len <= 0) return QEMB_OK;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)std::min<int64_t>((len + 255) / 256, 64), (unsigned)std::min<int64_t>(nrows, 65535)), dim3(256), 0, g_stream,
+                     (long long)nrows, (long long)len, (const long long*)idx_dev, src, (long long)ld, dst);
+  HIP_TRY(hipGetLastError());
+  return QEMB_OK;
+}
+__global__ void __launch_bounds__(256) scale_rows_kernel(long long nrows, long long len, double* __restrict__ x, const double* __restrict__ s) {
+  for (long long r = blockIdx.y; r < nrows; r += gridDim.y) {
+    const double f = s[r];
+    if (f == 1.0) continue;
+    double* row = x + r * len;
+    for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < len; c += (long long)gridDim.x * blockDim.x) row[c] = (f == 0.0) ? 0.0 : row[c] * f;
+  }
+}
+int dev_scale_rows(int64_t nrows, int64_t len, double* x, const double* s) {
+  REQUIRE_INIT();
+  if (nrows <= 0 || len <= 0) return QEMB_OK;
+  hipLaunchKernelGGL(scale_rows_kernel, dim3((unsigned)std::min<int64_t>((len + 255) / 256, 64), (unsigned)std::min<int64_t>(nrows, 65535)), dim3(256), 0, g_stream,
+                     (long long)nrows, (long long)len, x, s);
+  HIP_TRY(hipGetLastError());
+  return QEMB_OK;
+}
+
 __global__ void __launch_bounds__(256) mirror_lower_kernel(long long n, double* __restrict__ A, long long lda) {
   __shared__ double tile[32][33];
   // blockIdx.x enumerates lower-triangle 32 x 32 tiles (tr >= tc)

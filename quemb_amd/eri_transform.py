@@ -82,6 +82,73 @@ class AOEri:
             pass
 
 
+def ravel_symmetric(a: int, b: int) -> int:
+    """_cpp/indexers.hpp:75-79."""
+    return a * (a + 1) // 2 + b if a > b else b * (b + 1) // 2 + a
+
+
+class SemiSparseSym3DTensor:
+    """Host-side mirror of the reference's `SemiSparseSym3DTensor` (_cpp/eri_sparse_DF.cpp:110-298; Python binding :785-815):
+    (P|mu nu) stored for the AO pairs of `exch_reachable` only, one aux vector per unique pair (nu <= mu), in the column order
+    of `compute_offsets_and_unique` (:248-258).  `DFContext.set_ints_semisparse` uploads it -- or the reference's own object,
+    which exposes the same `unique_dense_data` / `exch_reachable_with_offsets` -- without ever expanding it."""
+
+    def __init__(self, shape, exch_reachable, unique_dense_data=None):
+        naux, nao, nao2 = (int(x) for x in shape)
+        if nao != nao2 or len(exch_reachable) != nao:
+            raise ValueError("SemiSparseSym3DTensor: shape = (naux, nao, nao) and one reachable list per AO")       # :213-224
+        self.shape = (naux, nao, nao)
+        self.exch_reachable = [sorted(int(x) for x in r) for r in exch_reachable]
+        self.exch_reachable_unique = [[nu for nu in r if nu <= mu] for mu, r in enumerate(self.exch_reachable)]   # indexers.hpp:149-162
+        self.offsets = {}
+        for mu, r in enumerate(self.exch_reachable_unique):
+            for nu in r:
+                self.offsets[ravel_symmetric(mu, nu)] = len(self.offsets)
+        try:
+            self.exch_reachable_with_offsets = [[(self.offsets[ravel_symmetric(mu, nu)], nu) for nu in r]
+                                                for mu, r in enumerate(self.exch_reachable)]
+        except KeyError:
+            raise ValueError("SemiSparseSym3DTensor: exch_reachable must be symmetric (nu in reach(mu) <=> mu in reach(nu))") from None
+        self.exch_reachable_unique_with_offsets = [[(o, nu) for o, nu in r if mu <= nu] for mu, r in enumerate(self.exch_reachable_with_offsets)]
+        n_unique = len(self.offsets)
+        if unique_dense_data is None:
+            self.unique_dense_data = np.full((naux, n_unique), np.nan, order="F")                                  # :160
+        else:
+            self.unique_dense_data = np.asfortranarray(unique_dense_data, dtype=np.float64)
+            if self.unique_dense_data.shape != (naux, n_unique):
+                raise ValueError("SemiSparseSym3DTensor: unique_dense_data must be (naux, n_unique)")
+
+    @property
+    def mut_unique_dense_data(self):
+        return self.unique_dense_data
+
+    @property
+    def nonzero_size(self):
+        return self.unique_dense_data.size
+
+    def get_aux_vector(self, mu, nu):
+        return self.unique_dense_data[:, self.offsets[ravel_symmetric(mu, nu)]]
+
+    @classmethod
+    def from_dense(cls, P_mu_nu, exch_reachable):
+        """Keep the stored pairs of a dense (naux, N, N) array."""
+        P_mu_nu = np.asarray(P_mu_nu)
+        t = cls(P_mu_nu.shape, exch_reachable)
+        for mu, r in enumerate(t.exch_reachable_unique):
+            for nu in r:
+                t.unique_dense_data[:, t.offsets[ravel_symmetric(mu, nu)]] = P_mu_nu[:, mu, nu]
+        return t
+
+
+def _reach_csr(exch_reachable_with_offsets):
+    ptr = np.zeros(len(exch_reachable_with_offsets) + 1, dtype=np.int64)
+    for mu, r in enumerate(exch_reachable_with_offsets):
+        ptr[mu + 1] = ptr[mu] + len(r)
+    off = np.fromiter((o for r in exch_reachable_with_offsets for o, _ in r), dtype=np.int64, count=int(ptr[-1]))
+    nu = np.fromiter((n for r in exch_reachable_with_offsets for _, n in r), dtype=np.int32, count=int(ptr[-1]))
+    return ptr, nu, off
+
+
 class DFContext:
     """Density-fitting context: metric factor and (P|mu nu) resident on the device."""
 
@@ -111,6 +178,21 @@ class DFContext:
             raise ValueError("DFContext.set_ints: array size does not match layout")
         check(self.lib.qemb_df_set_ints(self.h, int(nao), ints.ctypes.data, code), "qemb_df_set_ints", self.lib)
         self.nao = int(nao)
+
+    def set_ints_semisparse(self, int_P_mu_nu):
+        """Upload a SemiSparseSym3DTensor (this module's or the reference's pybind object: `unique_dense_data` (naux, n_unique) and
+        `exch_reachable_with_offsets`) as it is; `transform` then runs transform_integral's algorithm on the sparse storage."""
+        data = np.asarray(int_P_mu_nu.unique_dense_data)
+        if data.ndim != 2 or data.shape[0] != self.naux:
+            raise ValueError("DFContext.set_ints_semisparse: unique_dense_data must be (naux, n_unique)")
+        rows = np.ascontiguousarray(data.T, dtype=np.float64)           # n_unique x naux; a view when the input is column-major
+        if np.isnan(rows).any():
+            raise ValueError("DFContext.set_ints_semisparse: unique_dense_data has unfilled (NaN) columns")       # eri_sparse_DF.py:494
+        ptr, nu, off = _reach_csr(int_P_mu_nu.exch_reachable_with_offsets)
+        nao = len(ptr) - 1
+        check(self.lib.qemb_df_set_ints_semisparse(self.h, nao, rows.shape[0], rows.ctypes.data, ptr.ctypes.data, nu.ctypes.data,
+                                                   off.ctypes.data), "qemb_df_set_ints_semisparse", self.lib)
+        self.nao = nao
 
     def transform(self, TA, frag=None, want_host=True, S_abs=None, MO_coeff_epsilon=None):
         """(ij|kl) 4-fold packed.  With `S_abs` and `MO_coeff_epsilon` the reference's semi-sparse screening is applied

@@ -135,7 +135,7 @@ class BE:
                 ao.transform(self.Fobjs[I].TA, frag=self.Fobjs[I].dev, want_host=False)
             ao.free()
         elif it in ("int-direct-DF-hip", "sparse-DF-hip"):
-            # df_ints: (ints, j2c, layout) or a dict(ints=, layout=, j2c= | L_PQ=, S_abs=, MO_coeff_epsilon=).
+            # df_ints: (ints, j2c, layout) or a dict(ints=, layout= | int_P_mu_nu=, j2c= | L_PQ=, S_abs=, MO_coeff_epsilon=).
             # "sparse-DF-hip" applies the MO-coefficient screening of the reference's semi-sparse transform
             # (eri_sparse_DF.py:535-656, MO_coeff_epsilon default 1e-5, mbe.py:189) when S_abs is given.
             if self._df_ints is None:
@@ -144,7 +144,11 @@ class BE:
             if not isinstance(d, dict):
                 d = dict(ints=d[0], j2c=d[1], layout=d[2])
             df = et.DFContext(j2c=d.get("j2c"), L_PQ=d.get("L_PQ"), lib=self.lib)
-            df.set_ints(d["ints"], self.S.shape[0], d.get("layout", "pqL"))
+            if d.get("int_P_mu_nu") is not None:
+                # the semi-sparse tensor itself (et.SemiSparseSym3DTensor or the reference's object, eri_sparse_DF.py:433-496)
+                df.set_ints_semisparse(d["int_P_mu_nu"])
+            else:
+                df.set_ints(d["ints"], self.S.shape[0], d.get("layout", "pqL"))
             S_abs = d.get("S_abs") if it == "sparse-DF-hip" else None
             for I in idx:
                 df.transform(self.Fobjs[I].TA, frag=self.Fobjs[I].dev, want_host=False, S_abs=S_abs,

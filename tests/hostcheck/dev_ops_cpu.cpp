@@ -196,6 +196,11 @@ int dev_ladder_scatter_pm(int64_t o, int64_t v, const double* Rp, int64_t ldp, c
   }
   return 0;
 }
+int dev_gather_rows(int64_t nrows, int64_t len, const int64_t* idx, const double* src, int64_t ld, double* dst) {
+  for (int64_t r = 0; r < nrows; ++r) for (int64_t c = 0; c < len; ++c) dst[r * len + c] = idx[r] < 0 ? 0.0 : src[idx[r] * ld + c];
+  return 0;
+}
+int dev_scale_rows(int64_t nrows, int64_t len, double* x, const double* s) { for (int64_t r = 0; r < nrows; ++r) for (int64_t c = 0; c < len; ++c) x[r * len + c] *= s[r]; return 0; }
 int dev_threshold_mask(int64_t n, const double* x, double eps, double* out) { for (int64_t i = 0; i < n; ++i) out[i] = std::fabs(x[i]) >= eps ? 1.0 : 0.0; return 0; }
 int dev_mul_bcast_rows(int64_t rows, int64_t cols, double* x, const double* m) { for (int64_t r = 0; r < rows; ++r) for (int64_t c = 0; c < cols; ++c) x[r * cols + c] *= m[c]; return 0; }
 int dev_dot(int64_t n, const double* x, const double* y, double* o) { long double s = 0; for (int64_t i = 0; i < n; ++i) s += (long double)x[i] * y[i]; *o = (double)s; return 0; }

@@ -122,7 +122,14 @@ def test_h8_df_transform_path(qlib):
     fobj = FragPart.from_json(GOLDEN / "fragmentation.json", "test_autogen_h_linear_be2")
     be_df = BE(mf, fobj, int_transform="int-direct-DF-hip", df_ints=(pqL, j2c, "pqL"), distribute=False)
     be_in = BE(mf, fobj, distribute=False)
-    assert abs(be_df.oneshot()[0] - be_in.oneshot()[0]) < 1e-6
+    e_in = be_in.oneshot()[0]
+    assert abs(be_df.oneshot()[0] - e_in) < 1e-6
+    # the same integrals handed over as the reference's semi-sparse tensor (every AO pair stored, no MO screening: eps = 0)
+    from quemb_amd import eri_transform as et
+    t = et.SemiSparseSym3DTensor.from_dense(np.ascontiguousarray(pqL.transpose(2, 0, 1)), [list(range(N))] * N)
+    be_sp = BE(mf, fobj, int_transform="sparse-DF-hip", distribute=False,
+               df_ints=dict(int_P_mu_nu=t, j2c=j2c, S_abs=np.abs(mf.get_ovlp()), MO_coeff_epsilon=0.0))
+    assert abs(be_sp.oneshot()[0] - e_in) < 1e-6
 
 
 def _semisparse_case(seed=9):
@@ -177,6 +184,70 @@ def test_h8_relaxed_density_sweep_and_octane_relaxed_matching(qlib):
         assert abs(np.trace(f.rdm1__) - 2 * f.nsocc) < 1e-8
     # relaxed and unrelaxed matched energies differ in the 4th decimal for octane; both are near the golden of the latter
     assert abs(be8.e_corr - (-0.5499514850769742)) < 5e-3
+
+
+def test_semisparse_tensor_storage_is_consumed_as_is(qlib):
+    """Row a5 on the reference's own storage: a SemiSparseSym3DTensor (unique aux vectors + exch_reachable_with_offsets,
+    _cpp/eri_sparse_DF.cpp:110-298) goes to the device unexpanded and `transform_integral` (:739-751) runs on it -- the irregular
+    first contraction as gathered, batched GEMMs.  Checked against the literal loops of the reference on the same storage, against
+    the dense-with-zeros path, and for the layout conventions of the mirror class (offset order, unique = nu <= mu)."""
+    from quemb_amd import eri_transform as et
+    N, n, naux, stored, packed, S_abs, TA, Lpq = _semisparse_case()
+    il = np.tril_indices(N)
+    full = np.zeros((naux, N, N)); full[:, il[0], il[1]] = packed; full[:, il[1], il[0]] = packed
+    reach = [[int(nu) for nu in np.nonzero(stored[mu])[0]] for mu in range(N)]
+    t = et.SemiSparseSym3DTensor.from_dense(full, reach)
+    assert t.unique_dense_data.shape == (naux, sum(len(r) for r in t.exch_reachable_unique)) and t.unique_dense_data.flags.f_contiguous
+    assert t.offsets[et.ravel_symmetric(0, 0)] == 0 and t.offsets[et.ravel_symmetric(1, 0)] == 1 and t.offsets[et.ravel_symmetric(1, 1)] == 2
+    assert all(nu <= mu for mu, r in enumerate(t.exch_reachable_unique) for nu in r)
+    assert np.array_equal(t.get_aux_vector(3, 7), full[:, 7, 3])
+    df = et.DFContext(L_PQ=Lpq, lib=None)
+    df.set_ints_semisparse(t)
+    dfd = et.DFContext(L_PQ=Lpq, lib=None)
+    dfd.set_ints(packed, N, "packed")
+    for eps in (0.0, 1e-3, 5e-2, 0.3):
+        ref = oeri.transform_integral_semisparse_csr(t.unique_dense_data, t.exch_reachable_with_offsets, TA, S_abs, Lpq, eps)
+        got = df.transform(TA, S_abs=S_abs, MO_coeff_epsilon=eps)
+        tol = 1e-11 * max(1.0, np.abs(ref).max())
+        assert np.abs(got - ref).max() < tol, eps
+        assert np.abs(got - dfd.transform(TA, S_abs=S_abs, MO_coeff_epsilon=eps)).max() < tol
+        assert np.abs(ref - oeri.transform_integral_semisparse(packed, stored, TA, S_abs, Lpq, eps)).max() < tol
+    # no MO screening: the plain DF transform of the stored pairs
+    assert np.abs(df.transform(TA) - dfd.transform(TA)).max() < 1e-11 * np.abs(ref).max()
+    # a larger, ragged case (lists of very different lengths, several gather blocks are not needed but empty lists are)
+    rng = np.random.default_rng(5)
+    N2, n2, naux2 = 40, 9, 23
+    stored2 = np.abs(np.subtract.outer(np.arange(N2), np.arange(N2))) <= rng.integers(0, 9, N2)[:, None]
+    stored2 = stored2 & stored2.T
+    stored2[17, :] = stored2[:, 17] = False                               # an AO without any partner
+    L2 = rng.standard_normal((naux2, N2, N2)); L2 = (L2 + L2.transpose(0, 2, 1)) * stored2
+    t2 = et.SemiSparseSym3DTensor.from_dense(L2, [[int(x) for x in np.nonzero(stored2[mu])[0]] for mu in range(N2)])
+    TA2 = np.linalg.qr(rng.standard_normal((N2, N2)))[0][:, :n2]
+    S2 = np.exp(-0.5 * np.abs(np.subtract.outer(np.arange(N2), np.arange(N2))))
+    A = rng.standard_normal((naux2, naux2)); Lc = np.linalg.cholesky(A @ A.T + naux2 * np.eye(naux2))
+    df2 = et.DFContext(L_PQ=Lc, lib=None)
+    df2.set_ints_semisparse(t2)
+    import os
+    for eps, budget in ((0.0, None), (0.2, None), (0.2, "700"), (0.0, "1")):     # small budgets: several gather blocks, down to one AO each
+        ref2 = oeri.transform_integral_semisparse_csr(t2.unique_dense_data, t2.exch_reachable_with_offsets, TA2, S2, Lc, eps)
+        if budget:
+            os.environ["QEMB_DF_GATHER_BUDGET"] = budget
+        try:
+            got2 = df2.transform(TA2, S_abs=S2, MO_coeff_epsilon=eps)
+        finally:
+            os.environ.pop("QEMB_DF_GATHER_BUDGET", None)
+        assert np.abs(got2 - ref2).max() < 1e-11 * max(1.0, np.abs(ref2).max()), (eps, budget)
+    # embedding orbitals localised on a stretch of the AOs: distant AOs are reached by no orbital and leave both contractions
+    TA3 = np.zeros((N2, n2)); TA3[5:20] = np.linalg.qr(rng.standard_normal((15, n2)))[0]
+    n_act = int((np.abs(S2 @ TA3) >= 0.05).any(axis=1).sum())
+    assert 0 < n_act < N2
+    ref3 = oeri.transform_integral_semisparse_csr(t2.unique_dense_data, t2.exch_reachable_with_offsets, TA3, S2, Lc, 0.05)
+    assert np.abs(df2.transform(TA3, S_abs=S2, MO_coeff_epsilon=0.05) - ref3).max() < 1e-11 * max(1.0, np.abs(ref3).max())
+    assert np.abs(df2.transform(TA3, S_abs=S2, MO_coeff_epsilon=1e9)).max() == 0.0          # everything screened away
+    with pytest.raises(ValueError):
+        et.SemiSparseSym3DTensor((naux, N, N), [[1], []] + [[] for _ in range(N - 2)])       # not symmetric
+    with pytest.raises(ValueError):
+        df.set_ints_semisparse(et.SemiSparseSym3DTensor((naux, N, N), reach))                  # unfilled (NaN) data
 
 
 def test_octane_chemical_potential_goldens_be2_be3(qlib):
