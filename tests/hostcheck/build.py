@@ -12,6 +12,9 @@ OUT = HERE / "libqemb_hostcheck.so"
 
 
 def build(force=False):
+    # QEMB_HOSTCHECK_LIB: use a prebuilt variant instead (e.g. an -fsanitize=address,undefined build, see tests/hostcheck/README)
+    if os.environ.get("QEMB_HOSTCHECK_LIB"):
+        return Path(os.environ["QEMB_HOSTCHECK_LIB"])
     srcs = sorted(CSRC.glob("*.cpp")) + [HERE / "dev_ops_cpu.cpp"]
     deps = srcs + sorted(CSRC.glob("*.h")) + sorted(CSRC.glob("*.inc")) + [CSRC.parent.parent / "include" / "qemb_hip.h"]
     def fresh():
