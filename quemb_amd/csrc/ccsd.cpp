@@ -244,22 +244,7 @@ int CcsdSolver::update_amps(double* t1n, double* t2n) {
   const int cfg_tall = (o <= 32) ? 20 : -1, cfg_wide = (o <= 32) ? 21 : -1;
   QTRY(gemm(o * vv, o, v, 1.0, I_.ovvv, v, true, t1, v, true, 0.0, ZB_, o, 1, 0, 0, 0, cfg_tall));     // ZB[k,c,a,i] = ovvv[kcad] t1[id]
   QTRY(gemm(o, vv, v, 1.0, t1, v, true, I_.ovvv, vv, false, 0.0, ZC_, vv, o, 0, v * vv, o * vv, cfg_wide));   // ZC[k,i,a,c] = t1[id] ovvv[kdac]
-  {  // Y[a,c] = 2 sum_k ZC[k,k,a,c] - sum_k ZB[k,c,a,k]
-    for (int64_t k0 = 0; k0 < o; k0 += 8) {
-      const int cnt = (int)std::min<int64_t>(8, o - k0);
-      double c[8]; const double* ps[8];
-      for (int q = 0; q < cnt; ++q) { c[q] = 2.0; ps[q] = ZC_.p + (k0 + q) * (o + 1) * vv; }
-      QTRY(dev_lincomb(vv, cnt, c, ps, k0 == 0 ? 0.0 : 1.0, Y_));
-    }
-    for (int64_t k = 0; k < o; ++k) {
-      Copy4Desc c{};   // loop (c,a): in ZB[k,c,a,k], out Y[a,c]
-      c.dim[0] = 1; c.dim[1] = 1; c.dim[2] = v; c.dim[3] = v;
-      c.in = ZB_.p + k * vv * o + k; c.si[2] = v * o; c.si[3] = o;
-      c.out = Y_; c.so[2] = 1; c.so[3] = v;
-      c.alpha = -1.0; c.beta = 1.0;
-      QTRY(dev_copy4(c));
-    }
-  }
+  QTRY(dev_ccsd_y_traces(o, v, ZC_, ZB_, Y_));                                       // Y[a,c] = 2 sum_k ZC[k,k,a,c] - sum_k ZB[k,c,a,k]
   QTRY(dcopy(oo, Foo_, Loo_)); QTRY(axpby(oo, 1.0, Z_, 1.0, Loo_));                // Loo' = Foo' + Z
   QTRY(dcopy(vv, Fvv_, Lvv_)); QTRY(axpby(vv, 1.0, Y_, 1.0, Lvv_));                // Lvv' = Fvv' + Y
 
@@ -271,8 +256,8 @@ int CcsdSolver::update_amps(double* t1n, double* t2n) {
   QTRY(lincomb2(N2, 2.0, T_, -1.0, Tp_, S_));                                      // Theta_ph = 2T - Tp
   QTRY(dev_gemv_rows(nov, nov, S_, nov, Fov_, t1n, 1.0, 1.0));                     // Fov_kc (2 t2[kica] - t2[ikca])
   QTRY(dev_gemv_rows(nov, nov, Lph1_, nov, t1, t1n, 1.0, 1.0));                    // (2 ovvo[kcai] - oovv[kiac]) t1[kc]
-  QTRY(perm4(S_, t2, o, o, v, v, 0, 1, 3, 2, 2.0, 0.0)); QTRY(axpby(N2, -1.0, t2, 1.0, S_));  // Th[i,k,d,c] = 2 t2[ikcd] - t2[ikdc]
-  QTRY(gemm_nn(o, v, o * vv, 1.0, S_, I_.ovvv, 1.0, t1n));                         // (2 ovvv[kdac] - ovvv[kcad]) t2[ikcd]
+  QTRY(perm4(W12_, t2, o, o, v, v, 0, 1, 3, 2, 2.0, -1.0, t2));                    // Th[i,k,d,c] = 2 t2[ikcd] - t2[ikdc]  (W12: scratch until the rings)
+  QTRY(gemm_nn(o, v, o * vv, 1.0, W12_, I_.ovvv, 1.0, t1n));                       // (2 ovvv[kdac] - ovvv[kcad]) t2[ikcd]
   QTRY(gemm_tn(o, v, o * v * o, -1.0, Lovoo_, T_, 1.0, t1n));                      // -(2 ovoo[lcki] - ovoo[kcli]) t2[klac]
 
   // ---- T2 equation: direct (unsymmetrised) part
@@ -340,7 +325,7 @@ int CcsdSolver::update_amps(double* t1n, double* t2n) {
     d.alpha = alpha; d.beta = 1.0; d.base = src;
     return dev_outer4(d);
   };
-  QTRY(lincomb2(N2, 2.0, T_, -1.0, Tp_, S_));                                      // S = u = 2T - Tp   (kept for the update)
+  // (S = u = 2T - Tp was formed for the T1 equation and is still intact: the update below uses it again)
   QTRY(add_t1t1(W12_, -2.0, S_));                                                  // W12 (scratch) = u~ = u - 2 t1(x)t1
   QTRY(perm4(W1_, ZB_, o, v, v, o, 3, 2, 0, 1, 1.0, 1.0, W1base_));                // W1 = W1base + ovvv[kcad] t1[id]
   QTRY(gemm(o, v, o, 1.0, I_.ovoo, o, false, t1, v, false, 0.0, G1_, v, nov, oo, 0, nov, cfg_wide));   // G1[k,c,i,a] = ovoo[kcli] t1[la]
@@ -382,6 +367,10 @@ int CcsdSolver::iterate(double* e_corr, double* normt) {
     return true;
   }();
   const bool small = (int64_t)o_ * o_ * v_ * v_ <= (int64_t)1 << 22;
+  // With DIIS the new amplitudes and their error vector go straight into the storage of the next DIIS slot (no staging copies);
+  // the graph replay of small fragments has its output address baked in and keeps the staging buffer.
+  const bool use_diis = !first_ && !diis_.empty();
+  double* out = (use_diis && !(graphs_enabled && small && graph_ok_)) ? diis_[0].next_x() : ampn_.p;
   if (graphs_enabled && small && graph_ok_ && graph_) {
     QTRY(dev_graph_launch(graph_));
   } else if (graphs_enabled && small && graph_ok_ && eager_iters_ >= 1) {
@@ -397,14 +386,19 @@ int CcsdSolver::iterate(double* e_corr, double* normt) {
       QTRY(update_amps(ampn_.p, ampn_.p + (int64_t)o_ * v_));
     }
   } else {
-    QTRY(update_amps(ampn_.p, ampn_.p + (int64_t)o_ * v_));
+    QTRY(update_amps(out, out + (int64_t)o_ * v_));
     ++eager_iters_;
   }
   // diff = t_new - t (also the DIIS error vector: trial minus previously returned vector)
-  QTRY(lincomb2(na, 1.0, ampn_, -1.0, amp_, diff_));
-  QTRY(dev_dot(na, diff_, diff_, scal_.p + 1));
-  QTRY(dcopy(na, ampn_, amp_));
-  if (!first_ && !diis_.empty()) QTRY(diis_[0].extrapolate(amp_, diff_));
+  double* err = use_diis ? diis_[0].next_e() : diff_.p;
+  QTRY(lincomb2(na, 1.0, out, -1.0, amp_, err));
+  QTRY(dev_dot(na, err, err, scal_.p + 1));
+  if (use_diis) {
+    if (out != diis_[0].next_x()) QTRY(dcopy(na, out, diis_[0].next_x()));
+    QTRY(diis_[0].extrapolate_pushed(amp_));
+  } else {
+    QTRY(dcopy(na, out, amp_));
+  }
   first_ = false;
   double nn = 0.0;
   QTRY(dev_d2h(&nn, scal_.p + 1, sizeof(double)));

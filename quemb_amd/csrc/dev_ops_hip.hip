@@ -484,6 +484,24 @@ int dev_mul_bcast_rows(int64_t rows, int64_t cols, double* x, const double* m) {
   return QEMB_OK;
 }
 
+__global__ void __launch_bounds__(256) ccsd_y_traces_kernel(long long o, long long v, const double* __restrict__ ZC, const double* __restrict__ ZB,
+                                                            double* __restrict__ Y) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= v * v) return;
+  const long long a = idx / v, c = idx % v;
+  double s = 0.0;
+  for (long long k = 0; k < o; ++k)
+    s += 2.0 * ZC[((k * o + k) * v + a) * v + c] - ZB[((k * v + c) * v + a) * o + k];
+  Y[idx] = s;
+}
+int dev_ccsd_y_traces(int64_t o, int64_t v, const double* ZC, const double* ZB, double* Y) {
+  REQUIRE_INIT();
+  if (v <= 0) return QEMB_OK;
+  hipLaunchKernelGGL(ccsd_y_traces_kernel, dim3((unsigned)((v * v + 255) / 256)), dim3(256), 0, g_stream, (long long)o, (long long)v, ZC, ZB, Y);
+  HIP_TRY(hipGetLastError());
+  return QEMB_OK;
+}
+
 // one row per blockIdx.y (grid-stride), 256 threads stride along the row: reads and writes are contiguous runs of `len` doubles
 __global__ void __launch_bounds__(256) gather_rows_kernel(long long nrows, long long len, const long long* __restrict__ idx,
                                                           const double* __restrict__ src, long long ld, double* __restrict__ dst) {

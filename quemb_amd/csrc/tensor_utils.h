@@ -158,9 +158,21 @@ class DeviceDIIS {
   int size() const { return count_ < space_ ? count_ : space_; }
   // push (x, e) and overwrite x with the extrapolated vector
   int extrapolate(double* x, const double* e) {
+    QTRY(dcopy(n_, x, next_x()));
+    QTRY(dcopy(n_, e, next_e()));
+    return extrapolate_pushed(x, true);
+  }
+  // Zero-copy variant for the large vectors of the CCSD iteration: the producer writes the trial vector and its error vector
+  // straight into the storage of the next slot, then extrapolate_pushed(x_out) forms x_out = sum_i c_i x_i.
+  double* next_x() { return xs_[count_ % space_]; }
+  double* next_e() { return es_[count_ % space_]; }
+  int extrapolate_pushed(double* x, bool x_holds_trial = false) {
     const int slot = count_ % space_;
-    QTRY(dcopy(n_, x, xs_[slot]));
-    QTRY(dcopy(n_, e, es_[slot]));
+    // every early return below leaves the un-extrapolated trial vector in x
+    struct Fallback {
+      DeviceDIIS* d; double* x; int slot; bool armed;
+      ~Fallback() { if (armed) dcopy(d->n_, d->xs_[slot], x); }
+    } fb{this, x, slot, !x_holds_trial};
     ++count_;
     const int m = size();
     // refresh row/column `slot` of the Gram matrix
@@ -191,6 +203,7 @@ class DeviceDIIS {
       for (int q = 0; q < cnt; ++q) { c[q] = rhs[i0 + q + 1]; ps[q] = xs_[i0 + q].p; }
       QTRY(dev_lincomb(n_, cnt, c, ps, i0 == 0 ? 0.0 : 1.0, x));
     }
+    fb.armed = false;
     return 0;
   }
   void reset() { count_ = 0; }

@@ -196,6 +196,14 @@ int dev_ladder_scatter_pm(int64_t o, int64_t v, const double* Rp, int64_t ldp, c
   }
   return 0;
 }
+int dev_ccsd_y_traces(int64_t o, int64_t v, const double* ZC, const double* ZB, double* Y) {
+  for (int64_t a = 0; a < v; ++a) for (int64_t c = 0; c < v; ++c) {
+    double s = 0.0;
+    for (int64_t k = 0; k < o; ++k) s += 2.0 * ZC[((k * o + k) * v + a) * v + c] - ZB[((k * v + c) * v + a) * o + k];
+    Y[a * v + c] = s;
+  }
+  return 0;
+}
 int dev_gather_rows(int64_t nrows, int64_t len, const int64_t* idx, const double* src, int64_t ld, double* dst) {
   for (int64_t r = 0; r < nrows; ++r) for (int64_t c = 0; c < len; ++c) dst[r * len + c] = idx[r] < 0 ? 0.0 : src[idx[r] * ld + c];
   return 0;
