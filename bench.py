@@ -27,6 +27,8 @@ import numpy as np
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
+# the host driver of this pool only supports dmabuf IPC: RCCL needs this before the runtime starts (already exported on the boxes)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 PEAK_FP64_MFMA_TFLOPS = 78.6     # MI355X FP64 matrix peak (AMD spec; == the FP64 vector peak). The MI355X guide
                                  # lists no f64 row; see DESIGN.md "Roofline".
