@@ -177,6 +177,23 @@ class BE:
         if self.rank == 0:
             print(f"HF-in-HF error                 :  {self.hf_err:>.4e} Ha", flush=True)
 
+    # ------------------------------------------------------------------ on-disk hand-off (mbe.py:1039, helper.py:182-189)
+    def dump_fragment_eris(self, directory):
+        """Spill the device-resident fragment ERIs: one `f{I}.npy` per owned fragment, the FP64 (npair(n), npair(n)) 4-fold packed
+        array the reference keeps as dataset "f{I}" of scratch/eri_file.h5 (h5py is not available here; `.npy` is the stand-in)."""
+        from pathlib import Path
+        d = Path(directory)
+        d.mkdir(parents=True, exist_ok=True)
+        for I in self.my_frags:
+            np.save(d / f"{self.Fobjs[I].dname}.npy", self.Fobjs[I].dev.get_eri_s4())
+        return d
+
+    def load_fragment_eris(self, directory):
+        """Inverse of dump_fragment_eris: put `f{I}.npy` back on the device (e.g. ERIs transformed elsewhere / by the reference)."""
+        from pathlib import Path
+        for I in self.my_frags:
+            self.Fobjs[I].set_eri(np.load(Path(directory) / f"{self.Fobjs[I].dname}.npy"))
+
     # ------------------------------------------------------------------ full-basis 1-RDM (mbe.py:488-700)
     def rdm1_fullbasis(self, return_ao=True, only_rdm1=True, only_rdm2=False, return_lo=False, return_RDM2=False, print_energy=False):
         """The democratically partitioned one-particle density matrix of the whole system from the fragment solutions of the
