@@ -4,7 +4,9 @@ Mirror of `get_be_error_jacobian(n_frag, Fobjs, jac_solver="HF")` (shared/extern
 `get_atbe_Jblock_frag` (:316-392): for every fragment the RHF density response dP/d(lambda) to each unit matching
 potential (`get_vpots_frag`, :464-490) and to the chemical potential comes from one device CPHF solve
 (`qemb_frag_cphf`); the bookkeeping that scatters edge / centre elements into the block Jacobian is host logic.
-Only jac_solver="HF" is available (MP2 / CCSD response Jacobians are SURVEY 8f.3).
+jac_solver="HF" is the analytic one; the exact CCSD response of the sweep comes from `numerical_jac.compute_numerical_jacobian`
+(`BE.optimize(jac_solver="Numerical")`).  The reference's "MP2" / "CCSD" options (jac_utils.py:162-178: an MP2-amplitude model of
+the t1 response, built from per-perturbation integral derivatives on the host) are not reproduced.
 """
 
 from __future__ import annotations
@@ -58,7 +60,7 @@ def jblock_frag(fobj, opts=None):
 
 def get_be_error_jacobian(n_frag, Fobjs, jac_solver="HF", *, owner=None, rank=0, world=1, opts=None):
     if jac_solver.upper() != "HF":
-        raise NotImplementedError("only the HF (CPHF) Jacobian is implemented on the device")
+        raise NotImplementedError("analytic Jacobian: jac_solver='HF' (CPHF on the device); use jac_solver='Numerical' for the CCSD response")
     # sizes are static; the CPHF blocks of the fragments this rank owns are computed here and summed over ranks
     ncouts = [sum(len(e) * (len(e) + 1) // 2 for e in f.relAO_per_edge) for f in Fobjs]
     norgs = [len([1 for j in f.relAO_per_origin for k in f.relAO_per_origin if j <= k]) for f in Fobjs]
