@@ -14,6 +14,8 @@ import itertools
 import numpy as np
 
 from . import eri_transform as et
+from .fragsolver import DeviceFragment
+from .pfrag import Frags
 
 
 def _Ts(kmesh):
@@ -31,17 +33,21 @@ def get_phase1(a_vec, kpts, kmesh):
     return np.exp(-1.0j * (_Ts(kmesh) @ np.asarray(a_vec) @ np.asarray(kpts).T))
 
 
-class KFrags:
+class KFrags(Frags):
     """The periodic `Frags` state that sd / cons_h1 / get_nsocc read and write (kbe/pfrag.py:41-141)."""
 
-    def __init__(self, AO_in_frag, weight_and_relAO_per_center=None, lib=None):
-        self.AO_in_frag = list(AO_in_frag)
-        self.n_frag = len(self.AO_in_frag)
-        self.weight_and_relAO_per_center = weight_and_relAO_per_center
-        self.lib = lib
-        self.TA = self.TA_lo_eo = self.h1 = self.rdm1_lo_k = None
-        self.nao = self.nsocc = 0
-        self._mo_coeffs = None
+    def __init__(self, AO_in_frag, weight_and_relAO_per_center=None, lib=None, ifrag=0, AO_per_edge=(), ref_frag_idx_per_edge=(),
+                 relAO_per_edge=(), relAO_in_ref_per_edge=(), relAO_per_origin=None, unitcell=1, unitcell_nkpt=1.0):
+        """kbe/pfrag.py:48-141.  Beyond the k-space pieces (sd, cons_h1, cons_fock, get_nsocc) a periodic fragment is the molecular
+        one: scf / update_heff / set_udim / update_ebe_hf / solve are inherited from `pfrag.Frags` (the reference repeats them
+        verbatim, kbe/pfrag.py:315-480)."""
+        w = weight_and_relAO_per_center if weight_and_relAO_per_center is not None else (1.0, list(range(len(AO_in_frag))))
+        super().__init__(AO_in_frag, ifrag, list(AO_per_edge), list(ref_frag_idx_per_edge), list(relAO_per_edge),
+                         list(relAO_in_ref_per_edge), w, list(relAO_per_origin) if relAO_per_origin is not None else list(range(len(AO_in_frag))),
+                         lib=lib)
+        self.unitcell = unitcell
+        self.unitcell_nkpt = unitcell_nkpt
+        self.rdm1_lo_k = None
 
     def sd(self, lao, lmo, nocc, thr_bath=1.0e-10, a_vec=None, kpts=None, kmesh=None, h1=None):
         """kbe/pfrag.py:143-216.  Sets rdm1_lo_k, TA_lo_eo (nk, nlo, teo), TA (nk, nao, teo), nao = teo."""
@@ -72,6 +78,7 @@ class KFrags:
         self.TA_lo_eo = TA_k
         self.TA = np.stack([lao[k] @ TA_k[k] for k in range(nk)])
         self.nao = self.TA.shape[-1]
+        self.dev = DeviceFragment(self.nao, self.n_frag, lib=self.lib)
         return self.TA
 
     def cons_h1(self, h1):
@@ -83,6 +90,28 @@ class KFrags:
         else:
             raise ValueError(f"Imaginary Hcore {np.abs(h1_eo.imag).max()}")
         return self.h1
+
+    def cons_fock(self, hf_veff, S, dm, eri_=None):
+        """kbe/pfrag.py:240-268 with kbe/helper.py:11-60 (get_veff): the k-averaged projections of the density and of the mean field
+        are host sums over k; J and K of the projected (real) density come from the device-resident fragment ERIs."""
+        if eri_ is not None:
+            self.set_eri(eri_)
+        nk, nao, neo = self.TA.shape
+        P_ = np.zeros((neo, neo), dtype=np.complex128)
+        veff0 = np.zeros((neo, neo), dtype=np.complex128)
+        for k in range(nk):
+            Cinv = self.TA[k].conj().T @ S[k]
+            P_ += Cinv @ dm[k] @ Cinv.conj().T
+            veff0 += self.TA[k].conj().T @ hf_veff[k] @ self.TA[k]
+        P_ = np.asarray((P_ / float(nk)).real, dtype=np.float64)
+        veff0 /= float(nk)
+        vj, vk = self.dev.jk(np.ascontiguousarray(P_))
+        veff_ = veff0 - (vj - 0.5 * vk)
+        if np.abs(veff_.imag).max() >= 1.0e-6:
+            raise ValueError(f"Imaginary Veff {abs(veff_.imag).max()}")
+        self.veff = veff_.real
+        self.veff0 = veff0.real
+        self.fock = self.h1 + veff_.real
 
     def get_nsocc(self, S, C, nocc, ncore=0):
         """kbe/pfrag.py:264-306: projected density, nsocc and the SVD guess orbitals (device SVD through nsocc_guess would need

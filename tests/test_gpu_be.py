@@ -341,6 +341,13 @@ def test_periodic_front_end_matches_reference_goldens(qlib):
     check_periodic_front_end(None)
 
 
+def test_periodic_fragment_sweep(qlib):
+    """kbe/pfrag.py:240-268 (cons_fock through kbe/helper.py get_veff) and the inherited scf / update_ebe_hf / sweep body on a
+    periodic fragment: k sums against a NumPy restatement, the solve against the oracle."""
+    from helpers import check_periodic_fragment_sweep
+    check_periodic_fragment_sweep(None)
+
+
 def test_concurrent_streams_give_identical_results(qlib):
     """nstreams > 1: fragments driven from several host threads, each bound to its own execution context (HIP stream,
     workspaces, block cache).  Results must be bit-for-bit those of the serial sweep (every kernel is deterministic and

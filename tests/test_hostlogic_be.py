@@ -384,6 +384,13 @@ def test_periodic_front_end_matches_reference_goldens(hlib):
     check_periodic_front_end(hlib)
 
 
+def test_periodic_fragment_sweep(hlib):
+    """kbe/pfrag.py:240-268 (cons_fock through kbe/helper.py get_veff) and the inherited scf / update_ebe_hf / sweep body on a
+    periodic fragment: k sums against a NumPy restatement, the solve against the oracle."""
+    from helpers import check_periodic_fragment_sweep
+    check_periodic_fragment_sweep(hlib)
+
+
 def test_hf_in_hf_h8_ccpvdz_be1_be2_be3(hlib):
     """tests/hf-in-hf_BE_test.py:56-63 for H8 / cc-pVDZ (the reference's second H8 basis): Schmidt + ERI transform + fragment Fock
     reproduce the molecular HF energy, `ebe_hf == mf.e_tot` within 1e-5 (here 1e-9), for BE1, BE2, BE3.  The atom-based fixture
