@@ -133,7 +133,7 @@ int CcsdSolver::setup(MoIntegrals&& ints, const double* mo_energy_dev) {
   // ---- amplitudes and work space
   const int64_t na = nov + N2;
   QTRY(amp_.alloc(na)); QTRY(ampn_.alloc(na)); QTRY(diff_.alloc(na));
-  for (DBuf* b : {&tau_, &T_, &Tp_, &S_, &W1_, &W2_, &W12_, &R_, &U_}) QTRY(b->alloc(N2));
+  for (DBuf* b : {&tau_, &T_, &Tp_, &S_, &W1_, &W2_, &W12_, &W12b_, &R_, &U_}) QTRY(b->alloc(N2));
   const int64_t NG = std::max<int64_t>(N2, oo * o * v);   // scratch also holds (o,o,v,o)-shaped temporaries
   QTRY(G1_.alloc(NG)); QTRY(G2_.alloc(NG));
   QTRY(Foo_.alloc(oo)); QTRY(Fvv_.alloc(vv)); QTRY(Fov_.alloc(nov)); QTRY(Z_.alloc(oo)); QTRY(Y_.alloc(vv));
@@ -229,8 +229,9 @@ int CcsdSolver::update_amps(double* t1n, double* t2n) {
   const double* t2 = this->t2();
   // ---- amplitude layouts.  tau_ already holds tau(t1, t2): every change of the amplitudes (init_amps, set_amps, iterate) ends
   // with energy(), which builds it.
-  QTRY(perm4(T_, t2, o, o, v, v, 0, 2, 1, 3));          // T [k,c,j,b] = t2[k,j,c,b]
-  QTRY(perm4(Tp_, t2, o, o, v, v, 0, 3, 1, 2));         // Tp[k,c,j,b] = t2[k,j,b,c]
+  // T [k,c,j,b] = t2[k,j,c,b], Tp[k,c,j,b] = t2[k,j,b,c], S = u = 2T - Tp (Theta_ph), and the t1-dressed ring operands
+  // u~ = u - 2 t1(x)t1 (W12_), Tp~ = Tp + 2 t1(x)t1 (W12b_), t1(x)t1[(ia),(ld)] = t1[id] t1[la] -- one pass over t2
+  QTRY(dev_ccsd_ph_layouts(o, v, t2, t1, T_, Tp_, S_, W12_, W12b_));
 
   // ---- one- and two-index intermediates (energy-shifted: Foo - eps, Fvv - eps, ...)
   QTRY(gemm_nt(o, o, o * vv, 1.0, Loovv_, tau_, 0.0, Foo_));                       // Foo'[k,i]
@@ -253,11 +254,10 @@ int CcsdSolver::update_amps(double* t1n, double* t2n) {
   QTRY(gemm_tn(o, v, o, -1.0, Loo_, t1, 1.0, t1n));                                // -(Foo'+Z)_ki t1[ka]
   QTRY(gemm_nt(o, o, v, 1.0, t1, Fov_, 0.0, Q_));                                  // Q[i,k] = t1[ic] Fov[kc]
   QTRY(gemm_nn(o, v, o, 1.0, Q_, t1, 1.0, t1n));                                   // Fov_kc t1[ic] t1[ka]
-  QTRY(lincomb2(N2, 2.0, T_, -1.0, Tp_, S_));                                      // Theta_ph = 2T - Tp
   QTRY(dev_gemv_rows(nov, nov, S_, nov, Fov_, t1n, 1.0, 1.0));                     // Fov_kc (2 t2[kica] - t2[ikca])
   QTRY(dev_gemv_rows(nov, nov, Lph1_, nov, t1, t1n, 1.0, 1.0));                    // (2 ovvo[kcai] - oovv[kiac]) t1[kc]
-  QTRY(perm4(W12_, t2, o, o, v, v, 0, 1, 3, 2, 2.0, -1.0, t2));                    // Th[i,k,d,c] = 2 t2[ikcd] - t2[ikdc]  (W12: scratch until the rings)
-  QTRY(gemm_nn(o, v, o * vv, 1.0, W12_, I_.ovvv, 1.0, t1n));                       // (2 ovvv[kdac] - ovvv[kcad]) t2[ikcd]
+  QTRY(perm4(R_, t2, o, o, v, v, 0, 1, 3, 2, 2.0, -1.0, t2));                      // Th[i,k,d,c] = 2 t2[ikcd] - t2[ikdc]  (R: scratch until the rings)
+  QTRY(gemm_nn(o, v, o * vv, 1.0, R_, I_.ovvv, 1.0, t1n));                       // (2 ovvv[kdac] - ovvv[kcad]) t2[ikcd]
   QTRY(gemm_tn(o, v, o * v * o, -1.0, Lovoo_, T_, 1.0, t1n));                      // -(2 ovoo[lcki] - ovoo[kcli]) t2[klac]
 
   // ---- T2 equation: direct (unsymmetrised) part
@@ -317,16 +317,7 @@ int CcsdSolver::update_amps(double* t1n, double* t2n) {
   //   Wvoov += 1/4 u~ L - 1/4 Tp~ ovov_t,      Wvovo -= 1/2 Tp~ ovov_t
   // (expand: 1/4 (2T - Tp)(2 ovov - ovov_t) = (T - Tp/2) ovov - T ovov_t / 2 + Tp ovov_t / 4, and the t1(x)t1 pieces
   // reproduce -ovov[ldkc] t1[id] t1[la] and -ovov[lckd] t1[id] t1[la]).
-  auto add_t1t1 = [&](double* dst, double alpha, const double* src) {   // dst = src + alpha t1 (x) t1
-    Outer4Desc d{};   // loop (l,i,a,d), d fastest = contiguous in dst[i,a,l,d]: u = t1[l,a], v = t1[i,d]
-    d.dim[0] = o; d.dim[1] = o; d.dim[2] = v; d.dim[3] = v;
-    d.u = t1; d.su0 = v; d.su2 = 1; d.v = t1; d.sv1 = v; d.sv3 = 1;
-    d.out = dst; d.so[0] = v; d.so[1] = v * o * v; d.so[2] = o * v; d.so[3] = 1;
-    d.alpha = alpha; d.beta = 1.0; d.base = src;
-    return dev_outer4(d);
-  };
-  // (S = u = 2T - Tp was formed for the T1 equation and is still intact: the update below uses it again)
-  QTRY(add_t1t1(W12_, -2.0, S_));                                                  // W12 (scratch) = u~ = u - 2 t1(x)t1
+  // (S = u, W12_ = u~ and W12b_ = Tp~ were formed by dev_ccsd_ph_layouts at the top of the update)
   QTRY(perm4(W1_, ZB_, o, v, v, o, 3, 2, 0, 1, 1.0, 1.0, W1base_));                // W1 = W1base + ovvv[kcad] t1[id]
   QTRY(gemm(o, v, o, 1.0, I_.ovoo, o, false, t1, v, false, 0.0, G1_, v, nov, oo, 0, nov, cfg_wide));   // G1[k,c,i,a] = ovoo[kcli] t1[la]
   QTRY(perm4(W1_, G1_, o, v, o, v, 2, 3, 0, 1, -1.0, 1.0));
@@ -338,8 +329,7 @@ int CcsdSolver::update_amps(double* t1n, double* t2n) {
   // The Tp~ ovov_t product enters Wvoov with -1/4 and Wvovo with -1/2, so it cancels in Wvoov - Wvovo/2: form that
   // combination first (R), then let the GEMM accumulate the product straight into Wvovo.
   QTRY(lincomb2(N2, 1.0, W1_, -0.5, W2_, R_));                                     // R = Wvoov - Wvovo/2
-  QTRY(add_t1t1(W12_, 2.0, Tp_));                                                  // W12 (scratch) = Tp~ = Tp + 2 t1(x)t1
-  QTRY(gemm_nn(nov, nov, nov, -0.5, W12_, ovov_t_, 1.0, W2_));                     // Wvovo -= 1/2 Tp~ ovov_t
+  QTRY(gemm_nn(nov, nov, nov, -0.5, W12b_, ovov_t_, 1.0, W2_));                     // Wvovo -= 1/2 Tp~ ovov_t
   // Update, also two products:  (2 Wvoov - Wvovo) T - Wvoov Tp = (Wvoov - Wvovo/2) u - (Wvovo Tp)/2  with T = (u + Tp)/2
   QTRY(gemm_nn(nov, nov, nov, 1.0, W2_, Tp_, 0.0, W1_));                           // A3 = Wvovo[bkci] t2[kjac] at W1[i,b,j,a]
   QTRY(perm4(U_, W1_, o, v, o, v, 0, 2, 3, 1, -1.0, 1.0));                         // U[i,j,a,b] -= A3[i,b,j,a]

@@ -149,6 +149,10 @@ int dev_scatter_pm_rows(int64_t o, int64_t ncols, const double* Xp, const double
 // CCSD doubles update, last step in one pass:  t2n[i,j,a,b] = (t2n[i,j,a,b] + OV[i,j,a,b] + U[i,j,a,b] + U[j,i,b,a]) / (eo[i]+eo[j]-ev[a]-ev[b])
 int dev_ccsd_finish_t2(int64_t o, int64_t v, double* t2n, const double* U, const double* OV, const double* eo, const double* ev);
 int dev_ladder_scatter_pm(int64_t o, int64_t v, const double* Rp, int64_t ldp, const double* Rm, int64_t ldm, double* t2);
+// The particle-hole layouts of t2 for the ring terms, all from ONE pass over t2 (t2: [o][o][v][v]; every output [o][v][o][v]):
+//   T [k,c,j,b] = t2[k,j,c,b]        Tp[k,c,j,b] = t2[k,j,b,c]        S = 2 T - Tp
+//   Ut[k,c,j,b] = S  - 2 t1[j,c] t1[k,b]        Tpt[k,c,j,b] = Tp + 2 t1[j,c] t1[k,b]
+int dev_ccsd_ph_layouts(int64_t o, int64_t v, const double* t2, const double* t1, double* T, double* Tp, double* S, double* Ut, double* Tpt);
 // Y[a,c] = 2 sum_k ZC[k,k,a,c] - sum_k ZB[k,c,a,k]   (ZC: [o][o][v][v], ZB: [o][v][v][o]; the k = i traces of the two ovvv.t1 products)
 int dev_ccsd_y_traces(int64_t o, int64_t v, const double* ZC, const double* ZB, double* Y);
 

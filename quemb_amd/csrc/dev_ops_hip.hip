@@ -484,6 +484,51 @@ int dev_mul_bcast_rows(int64_t rows, int64_t cols, double* x, const double* m) {
   return QEMB_OK;
 }
 
+// one 32 x 32 tile (c-range, b-range) of one (k, j) pair per workgroup: X = t2[k,j] is read as the tile and as the mirrored tile
+// (for the transposed outputs, through LDS), every output tile is written in rows of 32 contiguous doubles
+__global__ void __launch_bounds__(256) ccsd_ph_layouts_kernel(long long o, long long v, const double* __restrict__ t2, const double* __restrict__ t1,
+                                                              double* __restrict__ T, double* __restrict__ Tp, double* __restrict__ S,
+                                                              double* __restrict__ Ut, double* __restrict__ Tpt, int tiles) {
+  __shared__ double xt[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  const long long tc = blockIdx.x / tiles, tb = blockIdx.x % tiles;
+  const long long k = blockIdx.z, j = blockIdx.y;
+  const double* __restrict__ X = t2 + (k * o + j) * v * v;
+  // mirrored tile: rows b-range, columns c-range -> xt[b_local][c_local]
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const long long b = tb * 32 + ty + 8 * r, c = tc * 32 + tx;
+    xt[ty + 8 * r][tx] = (b < v && c < v) ? X[b * v + c] : 0.0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const long long c = tc * 32 + ty + 8 * r, b = tb * 32 + tx;
+    if (c < v && b < v) {
+      const double x = X[c * v + b];                 // t2[k,j,c,b]
+      const double xp = xt[tx][ty + 8 * r];          // t2[k,j,b,c]
+      const double tt = 2.0 * t1[j * v + c] * t1[k * v + b];
+      const long long off = ((k * v + c) * o + j) * v + b;
+      T[off] = x;
+      Tp[off] = xp;
+      const double s = 2.0 * x - xp;
+      S[off] = s;
+      Ut[off] = s - tt;
+      Tpt[off] = xp + tt;
+    }
+  }
+}
+int dev_ccsd_ph_layouts(int64_t o, int64_t v, const double* t2, const double* t1, double* T, double* Tp, double* S, double* Ut, double* Tpt) {
+  REQUIRE_INIT();
+  if (o <= 0 || v <= 0) return QEMB_OK;
+  if (o > 65535) { set_error("dev_ccsd_ph_layouts: too many occupied orbitals"); return QEMB_ERR_ARG; }
+  const long long tiles = (v + 31) / 32;
+  hipLaunchKernelGGL(ccsd_ph_layouts_kernel, dim3((unsigned)(tiles * tiles), (unsigned)o, (unsigned)o), dim3(256), 0, g_stream, (long long)o, (long long)v, t2, t1,
+                     T, Tp, S, Ut, Tpt, (int)tiles);
+  HIP_TRY(hipGetLastError());
+  return QEMB_OK;
+}
+
 __global__ void __launch_bounds__(256) ccsd_y_traces_kernel(long long o, long long v, const double* __restrict__ ZC, const double* __restrict__ ZB,
                                                             double* __restrict__ Y) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;

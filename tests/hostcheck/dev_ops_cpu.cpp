@@ -196,6 +196,14 @@ int dev_ladder_scatter_pm(int64_t o, int64_t v, const double* Rp, int64_t ldp, c
   }
   return 0;
 }
+int dev_ccsd_ph_layouts(int64_t o, int64_t v, const double* t2, const double* t1, double* T, double* Tp, double* S, double* Ut, double* Tpt) {
+  for (int64_t k = 0; k < o; ++k) for (int64_t c = 0; c < v; ++c) for (int64_t j = 0; j < o; ++j) for (int64_t b = 0; b < v; ++b) {
+    const int64_t off = ((k * v + c) * o + j) * v + b;
+    const double x = t2[((k * o + j) * v + c) * v + b], xp = t2[((k * o + j) * v + b) * v + c], tt = 2.0 * t1[j * v + c] * t1[k * v + b];
+    T[off] = x; Tp[off] = xp; S[off] = 2.0 * x - xp; Ut[off] = 2.0 * x - xp - tt; Tpt[off] = xp + tt;
+  }
+  return 0;
+}
 int dev_ccsd_y_traces(int64_t o, int64_t v, const double* ZC, const double* ZB, double* Y) {
   for (int64_t a = 0; a < v; ++a) for (int64_t c = 0; c < v; ++c) {
     double s = 0.0;
