@@ -235,7 +235,7 @@ int CcsdSolver::update_amps(double* t1n, double* t2n) {
 
   // ---- one- and two-index intermediates (energy-shifted: Foo - eps, Fvv - eps, ...)
   QTRY(gemm_nt(o, o, o * vv, 1.0, Loovv_, tau_, 0.0, Foo_));                       // Foo'[k,i]
-  QTRY(gemm_tn(v, v, oo * v, -1.0, tau_, Loovv_, 0.0, Fvv_));                      // Fvv'[a,c]
+  QTRY(gemm(v, v, oo * v, -1.0, tau_, v, false, Loovv_, v, false, 0.0, Fvv_, v, 1, 0, 0, 0, (v <= 256) ? 1 : -1));   // Fvv'[a,c]  (64 x 64 tiles: split-K supplies the blocks)
   QTRY(dev_gemv_rows(nov, nov, Lovov_, nov, t1, Fov_, 1.0, 0.0));                  // Fov[k,c]
   QTRY(dev_contract_mid(1, nov, oo, Lovoo_, t1, Z_, oo, 1.0, 0.0));                // Z[k,i]
   // The two t1-contractions of ovvv are formed ONCE per iteration (each is one pass over the 1.28 GB block) and serve the
@@ -257,8 +257,8 @@ int CcsdSolver::update_amps(double* t1n, double* t2n) {
   QTRY(dev_gemv_rows(nov, nov, S_, nov, Fov_, t1n, 1.0, 1.0));                     // Fov_kc (2 t2[kica] - t2[ikca])
   QTRY(dev_gemv_rows(nov, nov, Lph1_, nov, t1, t1n, 1.0, 1.0));                    // (2 ovvo[kcai] - oovv[kiac]) t1[kc]
   QTRY(perm4(R_, t2, o, o, v, v, 0, 1, 3, 2, 2.0, -1.0, t2));                      // Th[i,k,d,c] = 2 t2[ikcd] - t2[ikdc]  (R: scratch until the rings)
-  QTRY(gemm_nn(o, v, o * vv, 1.0, R_, I_.ovvv, 1.0, t1n));                       // (2 ovvv[kdac] - ovvv[kcad]) t2[ikcd]
-  QTRY(gemm_tn(o, v, o * v * o, -1.0, Lovoo_, T_, 1.0, t1n));                      // -(2 ovoo[lcki] - ovoo[kcli]) t2[klac]
+  QTRY(gemm(o, v, o * vv, 1.0, R_, o * vv, true, I_.ovvv, v, false, 1.0, t1n, v, 1, 0, 0, 0, cfg_wide));     // (2 ovvv[kdac] - ovvv[kcad]) t2[ikcd]
+  QTRY(gemm(o, v, o * v * o, -1.0, Lovoo_, o, false, T_, v, false, 1.0, t1n, v, 1, 0, 0, 0, cfg_wide));     // -(2 ovoo[lcki] - ovoo[kcli]) t2[klac]
 
   // ---- T2 equation: direct (unsymmetrised) part
   // (the bare ovov[i,a,j,b] term is added by the finishing kernel)
