@@ -279,7 +279,8 @@ int CcsdSolver::update_amps(double* t1n, double* t2n) {
   QTRY(apply_ladder(tau_, t2n));
 
   // ---- T2 equation: terms that enter as P(X) accumulate in U
-  QTRY(gemm(v, v, v, 1.0, Lvv_, v, true, t2, v, false, 0.0, U_, v, oo, 0, vv, vv));   // Lvv'[a,c] t2[ijcb]
+  // Lvv'[a,c] t2[ijcb] enters as its P-partner t2[ijac] Lvv'[b,c] (U is only used as U + U^T(ji,ba)): ONE (o^2 v) x v x v product
+  QTRY(gemm(oo * v, v, v, 1.0, t2, v, true, Lvv_, v, true, 0.0, U_, v));
   QTRY(gemm(o, o * vv, o, -1.0, Loo_, o, false, t2, o * vv, false, 1.0, U_, o * vv, 1, 0, 0, 0, cfg_wide));   // -Loo'[k,i] t2[kjab]
   //   t1-dressing of Wvvvv folded on the tau side: -t1[kb] (tau[ijcd] ovvv[kdac])
   {  // X[i,j,k,a] = tau[ijcd] OVl[k,a,c,d] from the packed tau rows LTp/LTm that apply_ladder just built:
@@ -294,7 +295,7 @@ int CcsdSolver::update_amps(double* t1n, double* t2n) {
     }
     QTRY(dev_scatter_pm_rows(o, nov, Xp_, Xm_, X_));
   }
-  QTRY(gemm(v, v, o, -1.0, X_, v, false, t1, v, false, 1.0, U_, v, oo, nov, 0, vv));
+  QTRY(dev_small_k_update(oo, v, v, o, -1.0, X_, nov, t1, U_, vv));                 // U[ij][a][b] -= sum_k X[ij][k][a] t1[k][b]
   //   X1 = (ovvv[iacb] - oovv[kibc] t1[ka]) t1[jc]
   QTRY(perm4(U_, ZB_, o, v, v, o, 0, 3, 1, 2, 1.0, 1.0));                          // U[i,j,a,b] += t1[jc] ovvv[i,a,b,c] = ZB[i,a,b,j]
   {

@@ -529,6 +529,51 @@ int dev_ccsd_ph_layouts(int64_t o, int64_t v, const double* t2, const double* t1
   return QEMB_OK;
 }
 
+__global__ void __launch_bounds__(256) small_k_update_kernel(long long M, long long N, long long K, double alpha, const double* __restrict__ A, long long sA,
+                                                             const double* __restrict__ B, double* __restrict__ C, long long sC, int tiles_n) {
+  __shared__ double As[32][33], Bs[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const long long tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+  const long long m0 = tm * 32, n0 = tn * 32;
+  {
+    const long long z = blockIdx.y;
+    const double* __restrict__ Az = A + z * sA;
+    double* __restrict__ Cz = C + z * sC;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (long long k0 = 0; k0 < K; k0 += 32) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long long k = k0 + ty + 8 * r;
+        As[ty + 8 * r][tx] = (k < K && m0 + tx < M) ? Az[k * M + m0 + tx] : 0.0;
+        Bs[ty + 8 * r][tx] = (k < K && n0 + tx < N) ? B[k * N + n0 + tx] : 0.0;
+      }
+      __syncthreads();
+      const int kc = (int)((K - k0 < 32) ? K - k0 : 32);
+      for (int k = 0; k < kc; ++k) {
+        const double b = Bs[k][tx];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] += As[k][ty + 8 * r] * b;
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const long long m = m0 + ty + 8 * r, n = n0 + tx;
+      if (m < M && n < N) Cz[m * N + n] += alpha * acc[r];
+    }
+  }
+}
+int dev_small_k_update(int64_t batch, int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t sA, const double* B, double* C, int64_t sC) {
+  REQUIRE_INIT();
+  if (batch <= 0 || M <= 0 || N <= 0 || K <= 0) return QEMB_OK;
+  if (batch > 65535) { set_error("dev_small_k_update: batch too large"); return QEMB_ERR_ARG; }
+  const long long tiles_m = (M + 31) / 32, tiles_n = (N + 31) / 32;
+  hipLaunchKernelGGL(small_k_update_kernel, dim3((unsigned)(tiles_m * tiles_n), (unsigned)batch), dim3(256), 0, g_stream, (long long)M, (long long)N, (long long)K, alpha,
+                     A, (long long)sA, B, C, (long long)sC, (int)tiles_n);
+  HIP_TRY(hipGetLastError());
+  return QEMB_OK;
+}
+
 __global__ void __launch_bounds__(256) ccsd_y_traces_kernel(long long o, long long v, const double* __restrict__ ZC, const double* __restrict__ ZB,
                                                             double* __restrict__ Y) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;

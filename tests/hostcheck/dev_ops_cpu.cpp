@@ -204,6 +204,14 @@ int dev_ccsd_ph_layouts(int64_t o, int64_t v, const double* t2, const double* t1
   }
   return 0;
 }
+int dev_small_k_update(int64_t batch, int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t sA, const double* B, double* C, int64_t sC) {
+  for (int64_t z = 0; z < batch; ++z) for (int64_t m = 0; m < M; ++m) for (int64_t n = 0; n < N; ++n) {
+    double s = 0.0;
+    for (int64_t k = 0; k < K; ++k) s += A[z * sA + k * M + m] * B[k * N + n];
+    C[z * sC + m * N + n] += alpha * s;
+  }
+  return 0;
+}
 int dev_ccsd_y_traces(int64_t o, int64_t v, const double* ZC, const double* ZB, double* Y) {
   for (int64_t a = 0; a < v; ++a) for (int64_t c = 0; c < v; ++c) {
     double s = 0.0;
