@@ -116,6 +116,8 @@ int CcsdSolver::setup(MoIntegrals&& ints, const double* mo_energy_dev) {
   QTRY(perm4(OVoovv_, I_.ovov, o, v, o, v, 0, 2, 1, 3));                 // OVoovv[k,l,c,d] = ovov[k,c,l,d]
   QTRY(perm4(Lovoo_, I_.ovoo, o, v, o, o, 2, 1, 0, 3, -1.0, 0.0));       // -ovoo[k,c,l,i] at [l,c,k,i]
   QTRY(axpby(o * v * oo, 2.0, I_.ovoo, 1.0, Lovoo_));                    // Lovoo[l,c,k,i] = 2 ovoo[lcki] - ovoo[kcli]
+  QTRY(ovoo_ijka_.alloc(o * v * oo));
+  QTRY(perm4(ovoo_ijka_, I_.ovoo, o, v, o, o, 0, 2, 3, 1));               // ovoo[i,a,j,k] at [i,j,k,a]
   QTRY(perm4(W1base_, I_.ovvo, o, v, v, o, 3, 2, 0, 1));                 // W1base[i,a,k,c] = ovvo[k,c,a,i]
   QTRY(perm4(W2base_, I_.oovv, o, o, v, v, 1, 2, 0, 3));                 // W2base[i,a,k,c] = oovv[k,i,a,c]
   QTRY(dcopy(N2, W2base_, Lph1_));
@@ -295,22 +297,16 @@ int CcsdSolver::update_amps(double* t1n, double* t2n) {
     }
     QTRY(dev_scatter_pm_rows(o, nov, Xp_, Xm_, X_));
   }
-  QTRY(dev_small_k_update(oo, v, v, o, -1.0, X_, nov, t1, U_, vv));                 // U[ij][a][b] -= sum_k X[ij][k][a] t1[k][b]
-  //   X1 = (ovvv[iacb] - oovv[kibc] t1[ka]) t1[jc]
+  //   X1 = (ovvv[iacb] - oovv[kibc] t1[ka]) t1[jc],   X2 = (ovvo[kcai] t1[jc] + ovoo[iajk]) t1[kb] (enters with a minus sign)
   QTRY(perm4(U_, ZB_, o, v, v, o, 0, 3, 1, 2, 1.0, 1.0));                          // U[i,j,a,b] += t1[jc] ovvv[i,a,b,c] = ZB[i,a,b,j]
-  {
-    QTRY(gemm(oo * v, o, v, 1.0, I_.oovv, v, true, t1, v, true, 0.0, G2_, o, 1, 0, 0, 0, cfg_tall));   // G2[k,i,b,j] = oovv[(kib),c] t1[jc]
-    QTRY(gemm_tn(v, o * v * o, o, 1.0, t1, G2_, 0.0, G1_));                        // G1[a,i,b,j] = t1[ka] G2[k,i,b,j]
-    QTRY(perm4(U_, G1_, v, o, v, o, 1, 3, 0, 2, -1.0, 1.0));
-  }
-  //   X2 = (ovvo[kcai] t1[jc] + ovoo[iajk]) t1[kb]   (enters with a minus sign)
-  QTRY(gemm_nn(o * v * o, v, o, 1.0, I_.ovoo, t1, 0.0, G1_));                      // G1[i,a,j,b] = ovoo[i,a,j,k] t1[kb]
-  QTRY(perm4(U_, G1_, o, v, o, v, 0, 2, 1, 3, -1.0, 1.0));
-  {
-    QTRY(gemm(o, v * o, v, 1.0, t1, v, true, I_.ovvo, v * o, false, 0.0, G2_, v * o, o, 0, v * v * o, o * v * o, cfg_wide));  // G2[k,j,a,i] = t1[jc] ovvo[k,c,a,i]
-    QTRY(gemm_tn(o * v * o, v, o, 1.0, G2_, t1, 0.0, G1_));                        // G1[j,a,i,b] = G2[k,(jai)] t1[kb]
-    QTRY(perm4(U_, G1_, o, v, o, v, 2, 0, 1, 3, -1.0, 1.0));
-  }
+  // Every other t1-dressing term has the form U[i,j,a,b] -= sum_k A[i,j,k,a] t1[k,b] (the oovv one through its P-partner), with
+  // A only o^3 v large: the A's are summed first and ONE rank-n_occ update passes over U.
+  //   A = X[i,j,k,a] + ovoo[i,a,j,k] + (oovv[(k,j,a),c] t1[i,c]) + (t1[j,c] ovvo[k,c,a,i])
+  QTRY(gemm(oo * v, o, v, 1.0, I_.oovv, v, true, t1, v, true, 0.0, G2_, o, 1, 0, 0, 0, cfg_tall));                                   // G2[k,j,a,i] = oovv[(kja),c] t1[ic]
+  QTRY(gemm(o, v * o, v, 1.0, t1, v, true, I_.ovvo, v * o, false, 1.0, G2_, v * o, o, 0, v * v * o, o * v * o, cfg_wide));          //          += t1[jc] ovvo[k,c,a,i]
+  QTRY(axpby(o * oo * v, 1.0, ovoo_ijka_, 1.0, X_));
+  QTRY(perm4(X_, G2_, o, o, v, o, 3, 1, 0, 2, 1.0, 1.0));                          // A[i,j,k,a] += G2[k,j,a,i]
+  QTRY(dev_small_k_update(oo, v, v, o, -1.0, X_, nov, t1, U_, vv));                 // U[ij][a][b] -= sum_k A[ij][k][a] t1[k][b]
   // ---- ph rings
   QTRY(dev_timer_begin(TIMER_RINGS));
   // The t2-dependent parts of both ring intermediates come from TWO (ov)^3 products instead of three: with
