@@ -118,6 +118,8 @@ int CcsdSolver::setup(MoIntegrals&& ints, const double* mo_energy_dev) {
   QTRY(axpby(o * v * oo, 2.0, I_.ovoo, 1.0, Lovoo_));                    // Lovoo[l,c,k,i] = 2 ovoo[lcki] - ovoo[kcli]
   QTRY(ovoo_ijka_.alloc(o * v * oo));
   QTRY(perm4(ovoo_ijka_, I_.ovoo, o, v, o, o, 0, 2, 3, 1));               // ovoo[i,a,j,k] at [i,j,k,a]
+  QTRY(ovoo_kilc_.alloc(o * v * oo));
+  QTRY(perm4(ovoo_kilc_, I_.ovoo, o, v, o, o, 2, 3, 0, 1));               // ovoo[l,c,k,i] at [k,i,l,c]
   QTRY(perm4(W1base_, I_.ovvo, o, v, v, o, 3, 2, 0, 1));                 // W1base[i,a,k,c] = ovvo[k,c,a,i]
   QTRY(perm4(W2base_, I_.oovv, o, o, v, v, 1, 2, 0, 3));                 // W2base[i,a,k,c] = oovv[k,i,a,c]
   QTRY(dcopy(N2, W2base_, Lph1_));
@@ -233,7 +235,7 @@ int CcsdSolver::update_amps(double* t1n, double* t2n) {
   // with energy(), which builds it.
   // T [k,c,j,b] = t2[k,j,c,b], Tp[k,c,j,b] = t2[k,j,b,c], S = u = 2T - Tp (Theta_ph), and the t1-dressed ring operands
   // u~ = u - 2 t1(x)t1 (W12_), Tp~ = Tp + 2 t1(x)t1 (W12b_), t1(x)t1[(ia),(ld)] = t1[id] t1[la] -- one pass over t2
-  QTRY(dev_ccsd_ph_layouts(o, v, t2, t1, T_, Tp_, S_, W12_, W12b_));
+  QTRY(dev_ccsd_ph_layouts(o, v, t2, t1, T_, Tp_, S_, W12_, W12b_, R_));   // R_: Th[i,k,d,c] = 2 t2[ikcd] - t2[ikdc], scratch until the rings
 
   // ---- one- and two-index intermediates (energy-shifted: Foo - eps, Fvv - eps, ...)
   QTRY(gemm_nt(o, o, o * vv, 1.0, Loovv_, tau_, 0.0, Foo_));                       // Foo'[k,i]
@@ -258,7 +260,6 @@ int CcsdSolver::update_amps(double* t1n, double* t2n) {
   QTRY(gemm_nn(o, v, o, 1.0, Q_, t1, 1.0, t1n));                                   // Fov_kc t1[ic] t1[ka]
   QTRY(dev_gemv_rows(nov, nov, S_, nov, Fov_, t1n, 1.0, 1.0));                     // Fov_kc (2 t2[kica] - t2[ikca])
   QTRY(dev_gemv_rows(nov, nov, Lph1_, nov, t1, t1n, 1.0, 1.0));                    // (2 ovvo[kcai] - oovv[kiac]) t1[kc]
-  QTRY(perm4(R_, t2, o, o, v, v, 0, 1, 3, 2, 2.0, -1.0, t2));                      // Th[i,k,d,c] = 2 t2[ikcd] - t2[ikdc]  (R: scratch until the rings)
   QTRY(gemm(o, v, o * vv, 1.0, R_, o * vv, true, I_.ovvv, v, false, 1.0, t1n, v, 1, 0, 0, 0, cfg_wide));     // (2 ovvv[kdac] - ovvv[kcad]) t2[ikcd]
   QTRY(gemm(o, v, o * v * o, -1.0, Lovoo_, o, false, T_, v, false, 1.0, t1n, v, 1, 0, 0, 0, cfg_wide));     // -(2 ovoo[lcki] - ovoo[kcli]) t2[klac]
 
@@ -306,7 +307,7 @@ int CcsdSolver::update_amps(double* t1n, double* t2n) {
   QTRY(gemm(o, v * o, v, 1.0, t1, v, true, I_.ovvo, v * o, false, 1.0, G2_, v * o, o, 0, v * v * o, o * v * o, cfg_wide));          //          += t1[jc] ovvo[k,c,a,i]
   QTRY(axpby(o * oo * v, 1.0, ovoo_ijka_, 1.0, X_));
   QTRY(perm4(X_, G2_, o, o, v, o, 3, 1, 0, 2, 1.0, 1.0));                          // A[i,j,k,a] += G2[k,j,a,i]
-  QTRY(dev_small_k_update(oo, v, v, o, -1.0, X_, nov, t1, U_, vv));                 // U[ij][a][b] -= sum_k A[ij][k][a] t1[k][b]
+  QTRY(dev_small_k_update(oo, v, v, o, -1.0, X_, nov, t1, 0, U_, vv));                 // U[ij][a][b] -= sum_k A[ij][k][a] t1[k][b]
   // ---- ph rings
   QTRY(dev_timer_begin(TIMER_RINGS));
   // The t2-dependent parts of both ring intermediates come from TWO (ov)^3 products instead of three: with
@@ -315,14 +316,14 @@ int CcsdSolver::update_amps(double* t1n, double* t2n) {
   // (expand: 1/4 (2T - Tp)(2 ovov - ovov_t) = (T - Tp/2) ovov - T ovov_t / 2 + Tp ovov_t / 4, and the t1(x)t1 pieces
   // reproduce -ovov[ldkc] t1[id] t1[la] and -ovov[lckd] t1[id] t1[la]).
   // (S = u, W12_ = u~ and W12b_ = Tp~ were formed by dev_ccsd_ph_layouts at the top of the update)
-  QTRY(perm4(W1_, ZB_, o, v, v, o, 3, 2, 0, 1, 1.0, 1.0, W1base_));                // W1 = W1base + ovvv[kcad] t1[id]
-  QTRY(gemm(o, v, o, 1.0, I_.ovoo, o, false, t1, v, false, 0.0, G1_, v, nov, oo, 0, nov, cfg_wide));   // G1[k,c,i,a] = ovoo[kcli] t1[la]
-  QTRY(perm4(W1_, G1_, o, v, o, v, 2, 3, 0, 1, -1.0, 1.0));
+  // the rank-n_occ pieces -ovoo[kcli] t1[la] (Wvoov) and -t1[la] ovoo[lcki] (Wvovo) are subtracted from ZB / ZC in place (their last
+  // readers -- the Y traces and the X1 term -- are done), so ONE transposing pass per intermediate carries both pieces
+  QTRY(dev_small_k_update(nov, v, o, o, -1.0, t1, 0, I_.ovoo, oo, ZB_, v * o));    // ZB[k,c,a,i] -= sum_l t1[l,a] ovoo[k,c,l,i]
+  QTRY(perm4(W1_, ZB_, o, v, v, o, 3, 2, 0, 1, 1.0, 1.0, W1base_));                // W1 = W1base + ovvv[kcad] t1[id] - ovoo[kcli] t1[la]
   QTRY(gemm_nn(nov, nov, nov, 0.25, W12_, Lovov_, 1.0, W1_));                      // + 1/4 u~ L
   //   W2[(ia),(kc)] = Wvovo[a,k,c,i]
-  QTRY(perm4(W2_, ZC_, o, o, v, v, 1, 2, 0, 3, 1.0, 1.0, W2base_));                // W2 = W2base + t1[id] ovvv[kdac]
-  QTRY(gemm_tn(v, v * oo, o, 1.0, t1, I_.ovoo, 0.0, G1_));                         // G1[a,c,k,i] = t1[la] ovoo[lcki]
-  QTRY(perm4(W2_, G1_, v, v, o, o, 3, 0, 2, 1, -1.0, 1.0));
+  QTRY(dev_small_k_update(oo, v, v, o, -1.0, t1, 0, ovoo_kilc_, nov, ZC_, vv));     // ZC[k,i,a,c] -= sum_l t1[l,a] ovoo[l,c,k,i]
+  QTRY(perm4(W2_, ZC_, o, o, v, v, 1, 2, 0, 3, 1.0, 1.0, W2base_));                // W2 = W2base + t1[id] ovvv[kdac] - t1[la] ovoo[lcki]
   // The Tp~ ovov_t product enters Wvoov with -1/4 and Wvovo with -1/2, so it cancels in Wvoov - Wvovo/2: form that
   // combination first (R), then let the GEMM accumulate the product straight into Wvovo.
   QTRY(lincomb2(N2, 1.0, W1_, -0.5, W2_, R_));                                     // R = Wvoov - Wvovo/2

@@ -152,10 +152,13 @@ int dev_ladder_scatter_pm(int64_t o, int64_t v, const double* Rp, int64_t ldp, c
 // The particle-hole layouts of t2 for the ring terms, all from ONE pass over t2 (t2: [o][o][v][v]; every output [o][v][o][v]):
 //   T [k,c,j,b] = t2[k,j,c,b]        Tp[k,c,j,b] = t2[k,j,b,c]        S = 2 T - Tp
 //   Ut[k,c,j,b] = S  - 2 t1[j,c] t1[k,b]        Tpt[k,c,j,b] = Tp + 2 t1[j,c] t1[k,b]
-int dev_ccsd_ph_layouts(int64_t o, int64_t v, const double* t2, const double* t1, double* T, double* Tp, double* S, double* Ut, double* Tpt);
-// Batched small-K update (K = n_occ): C[z][m][n] += alpha sum_k A[z][k][m] B[k][n]   (A: [K][M] per batch, stride sA; B: [K][N] shared;
-// C: [M][N] per batch, stride sC).  One pass over C -- the products are HBM bound, a tiled GEMM with two k-steps is not.
-int dev_small_k_update(int64_t batch, int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t sA, const double* B, double* C, int64_t sC);
+// and, in the layout of t2 itself ([o][o][v][v]),  Th[k,j,c,b] = 2 t2[k,j,b,c] - t2[k,j,c,b]
+int dev_ccsd_ph_layouts(int64_t o, int64_t v, const double* t2, const double* t1, double* T, double* Tp, double* S, double* Ut, double* Tpt, double* Th);
+// Batched small-K update (K = n_occ): C[z][m][n] += alpha sum_k A[z][k][m] B[z][k][n]   (A: [K][M] per batch, stride sA; B: [K][N] per batch,
+// stride sB; a stride of 0 shares the operand; C: [M][N] per batch, stride sC).  One pass over C -- these products are HBM bound, a
+// tiled GEMM with two k-steps is not.
+int dev_small_k_update(int64_t batch, int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t sA, const double* B, int64_t sB,
+                       double* C, int64_t sC);
 // Y[a,c] = 2 sum_k ZC[k,k,a,c] - sum_k ZB[k,c,a,k]   (ZC: [o][o][v][v], ZB: [o][v][v][o]; the k = i traces of the two ovvv.t1 products)
 int dev_ccsd_y_traces(int64_t o, int64_t v, const double* ZC, const double* ZB, double* Y);
 

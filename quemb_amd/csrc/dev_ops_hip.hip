@@ -488,7 +488,7 @@ int dev_mul_bcast_rows(int64_t rows, int64_t cols, double* x, const double* m) {
 // (for the transposed outputs, through LDS), every output tile is written in rows of 32 contiguous doubles
 __global__ void __launch_bounds__(256) ccsd_ph_layouts_kernel(long long o, long long v, const double* __restrict__ t2, const double* __restrict__ t1,
                                                               double* __restrict__ T, double* __restrict__ Tp, double* __restrict__ S,
-                                                              double* __restrict__ Ut, double* __restrict__ Tpt, int tiles) {
+                                                              double* __restrict__ Ut, double* __restrict__ Tpt, double* __restrict__ Th, int tiles) {
   __shared__ double xt[32][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
   const long long tc = blockIdx.x / tiles, tb = blockIdx.x % tiles;
@@ -515,22 +515,23 @@ __global__ void __launch_bounds__(256) ccsd_ph_layouts_kernel(long long o, long 
       S[off] = s;
       Ut[off] = s - tt;
       Tpt[off] = xp + tt;
+      Th[((k * o + j) * v + c) * v + b] = 2.0 * xp - x;
     }
   }
 }
-int dev_ccsd_ph_layouts(int64_t o, int64_t v, const double* t2, const double* t1, double* T, double* Tp, double* S, double* Ut, double* Tpt) {
+int dev_ccsd_ph_layouts(int64_t o, int64_t v, const double* t2, const double* t1, double* T, double* Tp, double* S, double* Ut, double* Tpt, double* Th) {
   REQUIRE_INIT();
   if (o <= 0 || v <= 0) return QEMB_OK;
   if (o > 65535) { set_error("dev_ccsd_ph_layouts: too many occupied orbitals"); return QEMB_ERR_ARG; }
   const long long tiles = (v + 31) / 32;
   hipLaunchKernelGGL(ccsd_ph_layouts_kernel, dim3((unsigned)(tiles * tiles), (unsigned)o, (unsigned)o), dim3(256), 0, g_stream, (long long)o, (long long)v, t2, t1,
-                     T, Tp, S, Ut, Tpt, (int)tiles);
+                     T, Tp, S, Ut, Tpt, Th, (int)tiles);
   HIP_TRY(hipGetLastError());
   return QEMB_OK;
 }
 
 __global__ void __launch_bounds__(256) small_k_update_kernel(long long M, long long N, long long K, double alpha, const double* __restrict__ A, long long sA,
-                                                             const double* __restrict__ B, double* __restrict__ C, long long sC, int tiles_n) {
+                                                             const double* __restrict__ B, long long sB, double* __restrict__ C, long long sC, int tiles_n) {
   __shared__ double As[32][33], Bs[32][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const long long tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
@@ -538,6 +539,7 @@ __global__ void __launch_bounds__(256) small_k_update_kernel(long long M, long l
   {
     const long long z = blockIdx.y;
     const double* __restrict__ Az = A + z * sA;
+    const double* __restrict__ Bz = B + z * sB;
     double* __restrict__ Cz = C + z * sC;
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
     for (long long k0 = 0; k0 < K; k0 += 32) {
@@ -545,7 +547,7 @@ __global__ void __launch_bounds__(256) small_k_update_kernel(long long M, long l
       for (int r = 0; r < 4; ++r) {
         const long long k = k0 + ty + 8 * r;
         As[ty + 8 * r][tx] = (k < K && m0 + tx < M) ? Az[k * M + m0 + tx] : 0.0;
-        Bs[ty + 8 * r][tx] = (k < K && n0 + tx < N) ? B[k * N + n0 + tx] : 0.0;
+        Bs[ty + 8 * r][tx] = (k < K && n0 + tx < N) ? Bz[k * N + n0 + tx] : 0.0;
       }
       __syncthreads();
       const int kc = (int)((K - k0 < 32) ? K - k0 : 32);
@@ -563,13 +565,14 @@ __global__ void __launch_bounds__(256) small_k_update_kernel(long long M, long l
     }
   }
 }
-int dev_small_k_update(int64_t batch, int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t sA, const double* B, double* C, int64_t sC) {
+int dev_small_k_update(int64_t batch, int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t sA, const double* B, int64_t sB,
+                       double* C, int64_t sC) {
   REQUIRE_INIT();
   if (batch <= 0 || M <= 0 || N <= 0 || K <= 0) return QEMB_OK;
   if (batch > 65535) { set_error("dev_small_k_update: batch too large"); return QEMB_ERR_ARG; }
   const long long tiles_m = (M + 31) / 32, tiles_n = (N + 31) / 32;
   hipLaunchKernelGGL(small_k_update_kernel, dim3((unsigned)(tiles_m * tiles_n), (unsigned)batch), dim3(256), 0, g_stream, (long long)M, (long long)N, (long long)K, alpha,
-                     A, (long long)sA, B, C, (long long)sC, (int)tiles_n);
+                     A, (long long)sA, B, (long long)sB, C, (long long)sC, (int)tiles_n);
   HIP_TRY(hipGetLastError());
   return QEMB_OK;
 }

@@ -196,18 +196,20 @@ int dev_ladder_scatter_pm(int64_t o, int64_t v, const double* Rp, int64_t ldp, c
   }
   return 0;
 }
-int dev_ccsd_ph_layouts(int64_t o, int64_t v, const double* t2, const double* t1, double* T, double* Tp, double* S, double* Ut, double* Tpt) {
+int dev_ccsd_ph_layouts(int64_t o, int64_t v, const double* t2, const double* t1, double* T, double* Tp, double* S, double* Ut, double* Tpt, double* Th) {
   for (int64_t k = 0; k < o; ++k) for (int64_t c = 0; c < v; ++c) for (int64_t j = 0; j < o; ++j) for (int64_t b = 0; b < v; ++b) {
     const int64_t off = ((k * v + c) * o + j) * v + b;
     const double x = t2[((k * o + j) * v + c) * v + b], xp = t2[((k * o + j) * v + b) * v + c], tt = 2.0 * t1[j * v + c] * t1[k * v + b];
     T[off] = x; Tp[off] = xp; S[off] = 2.0 * x - xp; Ut[off] = 2.0 * x - xp - tt; Tpt[off] = xp + tt;
+    Th[((k * o + j) * v + c) * v + b] = 2.0 * xp - x;
   }
   return 0;
 }
-int dev_small_k_update(int64_t batch, int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t sA, const double* B, double* C, int64_t sC) {
+int dev_small_k_update(int64_t batch, int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t sA, const double* B, int64_t sB,
+                       double* C, int64_t sC) {
   for (int64_t z = 0; z < batch; ++z) for (int64_t m = 0; m < M; ++m) for (int64_t n = 0; n < N; ++n) {
     double s = 0.0;
-    for (int64_t k = 0; k < K; ++k) s += A[z * sA + k * M + m] * B[k * N + n];
+    for (int64_t k = 0; k < K; ++k) s += A[z * sA + k * M + m] * B[z * sB + k * N + n];
     C[z * sC + m * N + n] += alpha * s;
   }
   return 0;
