@@ -380,16 +380,17 @@ int CcsdSolver::iterate(double* e_corr, double* normt) {
   // diff = t_new - t (also the DIIS error vector: trial minus previously returned vector)
   double* err = use_diis ? diis_[0].next_e() : diff_.p;
   QTRY(lincomb2(na, 1.0, out, -1.0, amp_, err));
-  QTRY(dev_dot(na, err, err, scal_.p + 1));
+  double nn = 0.0;
   if (use_diis) {
+    // |t_new - t|^2 is the diagonal of the DIIS Gram row (same reduction, same bits as dev_dot): no separate pass, no second sync
     if (out != diis_[0].next_x()) QTRY(dcopy(na, out, diis_[0].next_x()));
-    QTRY(diis_[0].extrapolate_pushed(amp_));
+    QTRY(diis_[0].extrapolate_pushed(amp_, false, &nn));
   } else {
+    QTRY(dev_dot(na, err, err, scal_.p + 1));
     QTRY(dcopy(na, out, amp_));
+    QTRY(dev_d2h(&nn, scal_.p + 1, sizeof(double)));
   }
   first_ = false;
-  double nn = 0.0;
-  QTRY(dev_d2h(&nn, scal_.p + 1, sizeof(double)));
   *normt = std::sqrt(nn);
   QTRY(energy(t1(), t2(), &ecc_));
   *e_corr = ecc_;

@@ -166,7 +166,8 @@ class DeviceDIIS {
   // straight into the storage of the next slot, then extrapolate_pushed(x_out) forms x_out = sum_i c_i x_i.
   double* next_x() { return xs_[count_ % space_]; }
   double* next_e() { return es_[count_ % space_]; }
-  int extrapolate_pushed(double* x, bool x_holds_trial = false) {
+  // err_dot (optional): <e, e> of the vector just pushed -- the diagonal of the Gram row this call computes anyway
+  int extrapolate_pushed(double* x, bool x_holds_trial = false, double* err_dot = nullptr) {
     const int slot = count_ % space_;
     // every early return below leaves the un-extrapolated trial vector in x
     struct Fallback {
@@ -185,6 +186,7 @@ class DeviceDIIS {
     std::vector<double> row(m);
     QTRY(dev_d2h(row.data(), scal_.p, sizeof(double) * m));
     for (int j = 0; j < m; ++j) { B_[(size_t)slot * space_ + j] = row[j]; B_[(size_t)j * space_ + slot] = row[j]; }
+    if (err_dot) *err_dot = row[slot];
     if (m < 2) return 0;
     std::vector<double> A((size_t)(m + 1) * (m + 1), 0.0), rhs(m + 1, 0.0);
     double scale = 0.0;
