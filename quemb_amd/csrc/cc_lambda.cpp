@@ -30,6 +30,11 @@ int64_t CcLambda::size_of(int id) const {
   for (const char* c = kCcTensors[id].sig; *c; ++c) n *= (*c == 'o') ? o_ : v_;
   return n;
 }
+int CcLambda::settle(int id) {
+  if (ptr_[id] && fresh_[id]) { fresh_[id] = 0; return dev_fill(ptr_[id], size_of(id), 0.0); }
+  return 0;
+}
+
 int CcLambda::ensure(int id) {
   if (ptr_[id]) return 0;
   const int kind = kCcTensors[id].kind;
@@ -117,22 +122,26 @@ int CcLambda::contract(int dst, double coef, std::string sa, std::string sb, con
   static const bool trace = std::getenv("QEMB_LAMBDA_TRACE") != nullptr;
   if (trace) std::fprintf(stderr, "[qemb lambda] %s,%s->%s  M=%lld N=%lld K=%lld a_kc=%d b_kc=%d permA=%d permB=%d permC=%d\n", sa.c_str(), sb.c_str(), so.c_str(),
                           (long long)M, (long long)N, (long long)K, (int)a_kc, (int)b_kc, (int)(sA.p != nullptr), (int)(sB.p != nullptr), (int)(so != Mord + Nord));
-  if (so == Mord + Nord) return gemm(M, N, K, coef, A, lda, a_kc, B, ldb, b_kc, 1.0, ptr_[dst], N);
+  // products with an n_occ-sized side: 32 x 128 / 128 x 32 tiles instead of padding that side to 64 (these are HBM-bound passes
+  // over ovvv-sized operands; ccsd.cpp uses the same tiles for the t1 contractions)
+  const int cfg = (M <= 32 && N >= 64) ? 21 : (N <= 32 && M >= 64) ? 20 : -1;
+  if (so == Mord + Nord) return gemm(M, N, K, coef, A, lda, a_kc, B, ldb, b_kc, take_beta(dst), ptr_[dst], N, 1, 0, 0, 0, cfg);
   QTRY(sC.alloc(M * N));
-  QTRY(gemm(M, N, K, 1.0, A, lda, a_kc, B, ldb, b_kc, 0.0, sC, N));
-  return perm_acc(ptr_[dst], so, sC, Mord + Nord, coef, 1.0);
+  QTRY(gemm(M, N, K, 1.0, A, lda, a_kc, B, ldb, b_kc, 0.0, sC, N, 1, 0, 0, 0, cfg));
+  return perm_acc(ptr_[dst], so, sC, Mord + Nord, coef, take_beta(dst));
 }
 
 int CcLambda::run(const CcStmt& s) {
   QTRY(ensure(s.dst));
   if (s.op == CC_LADDER) {
     if (s.coef != 1.0) { set_error("cc_lambda: ladder statements carry unit coefficients"); return QEMB_ERR_ARG; }
+    QTRY(settle(s.dst));
     return cc_.apply_ladder(ptr_[s.a], ptr_[s.dst]);
   }
   const std::string subs(s.subs);
   const size_t arrow = subs.find("->");
   const std::string lhs = subs.substr(0, arrow), so = subs.substr(arrow + 2);
-  if (s.op == CC_PERM) return perm_acc(ptr_[s.dst], so, ptr_[s.a], lhs, s.coef, 1.0);
+  if (s.op == CC_PERM) return perm_acc(ptr_[s.dst], so, ptr_[s.a], lhs, s.coef, take_beta(s.dst));
   const size_t comma = lhs.find(',');
   return contract(s.dst, s.coef, lhs.substr(0, comma), lhs.substr(comma + 1), so, s.a, s.b);
 }
@@ -142,6 +151,7 @@ int CcLambda::setup() {
   const int64_t o = o_, v = v_, N2 = o * o * v * v;
   buf_.clear(); buf_.resize(kNumTensors);
   ptr_.assign(kNumTensors, nullptr);
+  fresh_.assign(kNumTensors, 0);
   cache_.clear();
   struct { const char* name; double* p; } ext[] = {
       {"t1", cc_.t1()}, {"t2", cc_.t2()}, {"oooo", cc_.I_.oooo.p}, {"ovoo", cc_.I_.ovoo.p}, {"ovov", cc_.I_.ovov.p},
@@ -163,19 +173,23 @@ int CcLambda::setup() {
 
 int CcLambda::backward(bool lambda_only) {
   const int64_t nov = (int64_t)o_ * v_;
+  // adjoints start from zero: allocated buffers are only MARKED (their first writer stores with beta = 0; settle() clears the ones that
+  // are read or accumulated into before any write)
   for (int k = 0; k < kNumTensors; ++k)
-    if (kCcTensors[k].kind == K_BAR && ptr_[k]) QTRY(dev_fill(ptr_[k], size_of(k), 0.0));
+    if (kCcTensors[k].kind == K_BAR && ptr_[k]) fresh_[k] = 1;
   const int n1b = id_of("n1_bar"), n2b = id_of("n2_bar");
   QTRY(ensure(n1b)); QTRY(ensure(n2b));
-  QTRY(dcopy(nov, z_, ptr_[n1b]));
-  QTRY(dcopy(size_of(n2b), z_.p + nov, ptr_[n2b]));
+  QTRY(dcopy(nov, z_, ptr_[n1b])); fresh_[n1b] = 0;
+  QTRY(dcopy(size_of(n2b), z_.p + nov, ptr_[n2b])); fresh_[n2b] = 0;
   for (int k = 0; k < kNumBackward; ++k) {
     const CcStmt& s = kCcBackward[k];
     if (lambda_only && !s.flag) continue;
-    if (kCcTensors[s.a].kind == K_BAR) QTRY(ensure(s.a));
-    if (s.b >= 0 && kCcTensors[s.b].kind == K_BAR) QTRY(ensure(s.b));
+    if (kCcTensors[s.a].kind == K_BAR) { QTRY(ensure(s.a)); QTRY(settle(s.a)); }
+    if (s.b >= 0 && kCcTensors[s.b].kind == K_BAR) { QTRY(ensure(s.b)); QTRY(settle(s.b)); }
     QTRY(run(s));
   }
+  for (int k = 0; k < kNumTensors; ++k)
+    if (kCcTensors[k].kind == K_BAR) QTRY(settle(k));        // never written in this sweep: really zero for the readers that follow
   return 0;
 }
 
