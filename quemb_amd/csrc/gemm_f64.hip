@@ -29,6 +29,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <vector>
 #include "dev_ops.h"
 #include "hip_common.h"
 
@@ -47,6 +48,7 @@ struct GemmKArgs {
   int tiles_m, tiles_n;
   int ksplit, kchunk;      // split-K: blockIdx.y = batch * ksplit + slice; slice s covers k in [s*kchunk, (s+1)*kchunk)
   double alpha, beta;
+  long long* cyc;          // debugging (QEMB_GEMM_TRACE): per-workgroup shader-clock ticks, or nullptr
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -99,6 +101,43 @@ __device__ __forceinline__ void stage_load(double (&reg)[NCH][VEC], const double
   }
 }
 
+// Interior tiles: per-thread chunk pointers are set up once (stage_ptrs) and advanced by one k-tile per call (stage_load_fast) -- two
+// integer adds per chunk in the main loop instead of the index arithmetic, bounds tests and branches of stage_load.  Rows beyond the
+// matrix are clamped to its last row (their products land in rows / columns of the tile that are never stored); only a k-tail needs
+// zeros, so the LAST tile of a slice still goes through stage_load.
+template <int BMN, int BK, bool KCONTIG, int VEC, int T, int NCH>
+__device__ __forceinline__ void stage_ptrs(const double* (&ptr)[NCH], const double* __restrict__ P, long long ld, int mn0, int k0, int MN, int tid) {
+  constexpr int CPR = (KCONTIG ? BK : BMN) / VEC;
+  constexpr int TOTAL = BMN * BK / VEC;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int chunk = tid + c * T;
+    if ((TOTAL % T != 0) && chunk >= TOTAL) { ptr[c] = P; continue; }
+    const int r = chunk / CPR, cc = (chunk % CPR) * VEC;
+    const int mn = KCONTIG ? r : cc, k = KCONTIG ? cc : r;
+    int gmn = mn0 + mn;
+    const int last = KCONTIG ? MN - 1 : MN - VEC;    // last addressable row / (VEC == 2, mn contiguous: MN and gmn are even) last chunk start
+    gmn = gmn < last ? gmn : (last > 0 ? last : 0);
+    ptr[c] = KCONTIG ? P + (long long)gmn * ld + (k0 + k) : P + (long long)(k0 + k) * ld + gmn;
+  }
+}
+template <int BMN, int BK, bool KCONTIG, int VEC, int T, int NCH>
+__device__ __forceinline__ void stage_load_fast(double (&reg)[NCH][VEC], const double* (&ptr)[NCH], long long step, int tid) {
+  // (threads whose chunk index runs past a tile that does not divide over the workgroup load from the operand's base instead -- a valid
+  //  address; stage_store never writes that register.  No divergence here: a branch would make the compiler wait for the loads in flight.)
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    if constexpr (VEC == 2) {
+      const d2 v = *reinterpret_cast<const d2*>(ptr[c]);
+      reg[c][0] = v[0];
+      reg[c][VEC - 1] = v[1];
+    } else {
+      reg[c][0] = *ptr[c];
+    }
+    ptr[c] += ((BMN * BK / VEC) % T != 0 && (tid + c * T) >= BMN * BK / VEC) ? 0 : step;   // a select, not a branch
+  }
+}
+
 template <int BMN, int BK, bool KCONTIG, int VEC, int T, int NCH>
 __device__ __forceinline__ void stage_store(const double (&reg)[NCH][VEC], double* __restrict__ S,
                                             int tid) {
@@ -128,6 +167,7 @@ __device__ __forceinline__ void stage_store(const double (&reg)[NCH][VEC], doubl
 template <int WM, int WN, int WAVES_M, int WAVES_N, int BK, bool A_KC, bool B_KC, int VEC, int TAG = 0>
 __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64, (WM * WN <= 16) ? 2 : 1)
     dgemm_mfma_kernel(GemmKArgs g) {
+  const long long t_start = g.cyc ? clock64() : 0;
   constexpr int BM = WM * 16 * WAVES_M;
   constexpr int BN = WN * 16 * WAVES_N;
   constexpr int T = WAVES_M * WAVES_N * 64;
@@ -178,6 +218,13 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64, (WM * WN <= 16) ? 2 : 1
   stage_store<BN, BK, B_KC, VEC, T, NCH_B>(rb, sB0, tid);
   __syncthreads();
 
+  const double* pa[NCH_A];
+  const double* pb[NCH_B];
+  stage_ptrs<BM, BK, A_KC, VEC, T, NCH_A>(pa, A, g.lda, m0, kbeg + BK, g.M, tid);   // tile 1 is the first one fetched inside the loop
+  stage_ptrs<BN, BK, B_KC, VEC, T, NCH_B>(pb, B, g.ldb, n0, kbeg + BK, g.N, tid);
+  const long long step_a = A_KC ? (long long)BK : (long long)BK * g.lda;
+  const long long step_b = B_KC ? (long long)BK : (long long)BK * g.ldb;
+
   const int fr = lane & 15, fk = lane >> 4;
   for (int kt = 0; kt < nk; ++kt) {
     const double* sA = (kt & 1) ? sA1 : sA0;
@@ -186,8 +233,13 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64, (WM * WN <= 16) ? 2 : 1
     double* nB = (kt & 1) ? sB0 : sB1;
     const bool more = (kt + 1 < nk);
     if (more) {  // issue next tile's global loads before this tile's MFMAs (latency hides under them)
-      stage_load<BM, BK, A_KC, VEC, T, NCH_A>(ra, A, g.lda, m0, kbeg + (kt + 1) * BK, g.M, kend, tid);
-      stage_load<BN, BK, B_KC, VEC, T, NCH_B>(rb, B, g.ldb, n0, kbeg + (kt + 1) * BK, g.N, kend, tid);
+      if (kt + 2 < nk) {         // interior tile: pointer-bump loads, no bounds logic
+        stage_load_fast<BM, BK, A_KC, VEC, T, NCH_A>(ra, pa, step_a, tid);
+        stage_load_fast<BN, BK, B_KC, VEC, T, NCH_B>(rb, pb, step_b, tid);
+      } else {                   // last tile of the slice: may carry a k-tail that must read as zeros
+        stage_load<BM, BK, A_KC, VEC, T, NCH_A>(ra, A, g.lda, m0, kbeg + (kt + 1) * BK, g.M, kend, tid);
+        stage_load<BN, BK, B_KC, VEC, T, NCH_B>(rb, B, g.ldb, n0, kbeg + (kt + 1) * BK, g.N, kend, tid);
+      }
     }
 #pragma unroll
     for (int ks = 0; ks < BK / 4; ++ks) {
@@ -229,6 +281,7 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64, (WM * WN <= 16) ? 2 : 1
       }
     }
   }
+  if (g.cyc && threadIdx.x == 0) g.cyc[(long long)blockIdx.y * gridDim.x + blockIdx.x] = clock64() - t_start;
 }
 
 // C[b][m][n] = alpha * sum_s ws[b][s][m][n] + beta * C   (fixed summation order: deterministic)
@@ -270,6 +323,8 @@ __global__ void __launch_bounds__(256) splitk_reduce_wave_kernel(const double* _
 }
 
 double* gemm_workspace(size_t bytes);   // dev_ops_hip.hip
+static long long* g_gemm_cyc = nullptr;          // QEMB_GEMM_TRACE: per-workgroup tick buffer of the traced launch
+static long long g_gemm_cyc_cap = 0, g_gemm_cyc_blocks = 0;
 
 template <int WM, int WN, int WAVES_M, int WAVES_N, int BK, bool A_KC, bool B_KC, int VEC, int TAG = 0>
 static int launch_cfg(const GemmDesc& d, hipStream_t s) {
@@ -284,6 +339,7 @@ static int launch_cfg(const GemmDesc& d, hipStream_t s) {
   g.tiles_m = (int)((d.M + BM - 1) / BM);
   g.tiles_n = (int)((d.N + BN - 1) / BN);
   g.alpha = d.alpha; g.beta = d.beta;
+  g.cyc = nullptr;
   // split-K when the output has too few tiles to occupy 256 CUs but K is long (the o x v, o x o, v x v shaped
   // CCSD intermediates contract over o*v^2 ... v^2 indices)
   g.ksplit = 1; g.kchunk = g.K > 0 ? g.K : 1;
@@ -317,6 +373,7 @@ static int launch_cfg(const GemmDesc& d, hipStream_t s) {
   }
   dim3 grid((unsigned)(g.tiles_m * g.tiles_n), (unsigned)(d.batch * g.ksplit), 1);
   dim3 block(WAVES_M * WAVES_N * 64, 1, 1);
+  if (g_gemm_cyc && (long long)grid.x * grid.y <= g_gemm_cyc_cap) { g.cyc = g_gemm_cyc; g_gemm_cyc_blocks = (long long)grid.x * grid.y; }
   hipLaunchKernelGGL(kern, grid, block, lds, s, g);
   if (g.ksplit > 1) {
     const long long mn = d.M * d.N;
@@ -401,15 +458,27 @@ int dev_gemm(const GemmDesc& d) {
   if (!trace || dev_capturing() || hipEventCreate(&t0) != hipSuccess || hipEventCreate(&t1) != hipSuccess) return dev_gemm_dispatch(d);
   hipStream_t s = hip_stream();
   float ms = 0.f;
+  if (!g_gemm_cyc) { g_gemm_cyc_cap = 1 << 20; if (hipMalloc((void**)&g_gemm_cyc, sizeof(long long) * g_gemm_cyc_cap) != hipSuccess) g_gemm_cyc = nullptr; }
+  g_gemm_cyc_blocks = 0;
   (void)hipEventRecord(t0, s);
   const int rc = dev_gemm_dispatch(d);
   (void)hipEventRecord(t1, s);
   (void)hipEventSynchronize(t1);
   (void)hipEventElapsedTime(&ms, t0, t1);
   (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
-  std::fprintf(stderr, "[qemb gemm] M=%lld N=%lld K=%lld batch=%lld a_kc=%d b_kc=%d cfg=%d beta=%g  %.4f ms  %.1f TF\n", (long long)d.M, (long long)d.N,
-               (long long)d.K, (long long)d.batch, (int)d.a_kcontig, (int)d.b_kcontig, d.cfg, d.beta, ms,
-               ms > 0 ? 2.0 * d.M * d.N * d.K * d.batch / (ms * 1e9) : 0.0);
+  // sum of the workgroups' shader-clock ticks / (256 CUs x time): the sustained clock when exactly one workgroup is resident per CU
+  // (the 8-wave ladder tiles), a multiple of it when several are
+  double ghz = 0.0;
+  if (g_gemm_cyc && g_gemm_cyc_blocks > 0 && ms > 0) {
+    std::vector<long long> h((size_t)g_gemm_cyc_blocks);
+    if (hipMemcpy(h.data(), g_gemm_cyc, sizeof(long long) * h.size(), hipMemcpyDeviceToHost) == hipSuccess) {
+      double sum = 0; for (long long c : h) sum += (double)c;
+      ghz = sum / 256.0 / (ms * 1e6);
+    }
+  }
+  std::fprintf(stderr, "[qemb gemm] M=%lld N=%lld K=%lld batch=%lld a_kc=%d b_kc=%d cfg=%d beta=%g  %.4f ms  %.1f TF  wg-ticks/(256 CU x t) = %.2f GHz (%lld workgroups)\n",
+               (long long)d.M, (long long)d.N, (long long)d.K, (long long)d.batch, (int)d.a_kcontig, (int)d.b_kcontig, d.cfg, d.beta, ms,
+               ms > 0 ? 2.0 * d.M * d.N * d.K * d.batch / (ms * 1e9) : 0.0, ghz, g_gemm_cyc_blocks);
   return rc;
 }
 

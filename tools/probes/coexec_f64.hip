@@ -3,10 +3,12 @@
 //   hipcc --offload-arch=gfx950 -O3 tools/probes/coexec_f64.hip -o tools/probes/coexec_f64 && ./tools/probes/coexec_f64
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <vector>
 typedef double d4 __attribute__((ext_vector_type(4)));
 
 template <int NM, int NV>
-__global__ void __launch_bounds__(256) probe(double* out, int iters) {
+__global__ void __launch_bounds__(256) probe(double* out, int iters, long long* cyc) {
+  const long long c0 = clock64();                 // s_memtime: shader-clock ticks on gfx950
   d4 acc[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) acc[i] = d4{0.0, 0.0, 0.0, 0.0};
@@ -28,23 +30,28 @@ __global__ void __launch_bounds__(256) probe(double* out, int iters) {
 #pragma unroll
   for (int j = 0; j < 16; ++j) s += v[j];
   if (s == 12345.678) out[0] = s;
+  if (threadIdx.x == 0) cyc[blockIdx.x] = clock64() - c0;
 }
 
 template <int NM, int NV>
 static void run(const char* label, int bpc) {
   double* out; hipMalloc((void**)&out, 64);
+  long long* cyc; hipMalloc((void**)&cyc, sizeof(long long) * 256 * bpc);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   const int iters = 20000, grid = 256 * bpc;
-  hipLaunchKernelGGL((probe<NM, NV>), dim3(grid), dim3(256), 0, 0, out, 64);
+  hipLaunchKernelGGL((probe<NM, NV>), dim3(grid), dim3(256), 0, 0, out, 64, cyc);
   hipEventRecord(e0, 0);
-  hipLaunchKernelGGL((probe<NM, NV>), dim3(grid), dim3(256), 0, 0, out, iters);
+  hipLaunchKernelGGL((probe<NM, NV>), dim3(grid), dim3(256), 0, 0, out, iters, cyc);
   hipEventRecord(e1, 0); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
   const double waves = (double)grid * 4;
   const double fm = NM ? waves * 8.0 * iters * 2048.0 : 0.0, fv = waves * 8.0 * iters * NV * 128.0;
-  std::printf("%-28s blocks/CU %d  %8.3f ms   MFMA %6.1f TF   VALU %6.1f TF   total %6.1f TF\n", label, bpc, ms, fm / ms / 1e9, fv / ms / 1e9,
-              (fm + fv) / ms / 1e9);
-  hipFree(out);
+  std::vector<long long> h(grid);
+  hipMemcpy(h.data(), cyc, sizeof(long long) * grid, hipMemcpyDeviceToHost);
+  double mean = 0; for (long long c : h) mean += (double)c; mean /= grid;
+  std::printf("%-28s blocks/CU %d  %8.3f ms   MFMA %6.1f TF   VALU %6.1f TF   total %6.1f TF   block cycles / kernel time = %.2f GHz\n", label, bpc, ms, fm / ms / 1e9,
+              fv / ms / 1e9, (fm + fv) / ms / 1e9, mean / (ms * 1e6));
+  hipFree(out); hipFree(cyc);
 }
 
 int main() {
