@@ -245,10 +245,12 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64, (WM * WN <= 16) ? 2 : 1
     for (int ks = 0; ks < BK / 4; ++ks) {
       const int kk = ks * 4 + fk;
       double a[WM], b[WN];
-#pragma unroll
-      for (int i = 0; i < WM; ++i) a[i] = sA[ImgA::off((wm * WM + i) * 16 + fr, kk)];
+      // B fragments first, then A row by row: LDS returns in order, so the MFMAs of row i only wait for a[0..i] (partial lgkmcnt)
+      // and the later fragment reads land under the earlier rows' MFMAs
 #pragma unroll
       for (int j = 0; j < WN; ++j) b[j] = sB[ImgB::off((wn * WN + j) * 16 + fr, kk)];
+#pragma unroll
+      for (int i = 0; i < WM; ++i) a[i] = sA[ImgA::off((wm * WM + i) * 16 + fr, kk)];
 #pragma unroll
       for (int i = 0; i < WM; ++i)
 #pragma unroll
