@@ -168,6 +168,24 @@ def parity_probe():
     return abs(out["e_corr_mo"] - ecc)
 
 
+def clock_probe(lib):
+    """Sustained shader clock under the pp-ladder kernel: one launch of the ladder tile (224 x 128, one 8-wave workgroup per CU) on
+    random operands with every workgroup recording its s_memtime ticks; sum(ticks) / (256 CUs x kernel time).  Outside the timed region."""
+    from quemb_amd._lib import DeviceBuffer, check
+    M, N, K = 210, 4096, 16384
+    rng = np.random.default_rng(7)
+    dA, dB, dC = DeviceBuffer.from_numpy(rng.standard_normal((M, K))), DeviceBuffer.from_numpy(rng.standard_normal((N, K))), DeviceBuffer(M * N)
+    vals = []
+    for _ in range(4):
+        ms, ghz, wg = C.c_double(), C.c_double(), C.c_int64()
+        check(lib.qemb_op_gemm_probe(M, N, K, dA.ptr, K, 1, dB.ptr, K, 1, dC.ptr, N, 23, 8, C.byref(ms), C.byref(ghz), C.byref(wg)), "qemb_op_gemm_probe", lib)
+        vals.append((ghz.value, ms.value, wg.value))
+    for b in (dA, dB, dC):
+        b.free()
+    ghz, ms, wg = sorted(vals[1:])[1]
+    return dict(ghz=ghz, ms=ms, workgroups=wg, tflops=2.0 * M * N * K / (ms * 1e9))
+
+
 def main():
     args = parse()
     if args.cpu_worker:
@@ -303,6 +321,16 @@ def main():
                                      "mo_transform_avg": ao_ms / max(ao_cnt, 1), "fragment_scf_avg": scf_ms / max(scf_cnt, 1)},
         }
         if world == 1:
+            try:
+                cp = clock_probe(lib)
+                clk = cp["ghz"]
+                res["roofline"].update({"sustained_clock_ghz": clk, "peak_at_sustained_clock": PEAK_FP64_MFMA_TFLOPS * clk / 2.4,
+                                        "frac_of_sustained_peak": achieved / (PEAK_FP64_MFMA_TFLOPS * clk / 2.4) if clk > 0 else None,
+                                        "clock_probe_tflops": cp["tflops"],
+                                        "clock_probe": "launches of the ladder tile (cfg 23, M=210 N=4096 K=16384, split-K 8 = 256 workgroups, random operands) "
+                                                       "right after the timed region, GPU still hot: sum of per-workgroup s_memtime ticks / (256 CUs x kernel time)"})
+            except Exception as e:  # noqa: BLE001
+                res["roofline"]["sustained_clock_ghz"] = f"probe failed: {e}"
             log("parity probe vs oracle")
             try:
                 res["parity_max_abs_err_Eh"] = parity_probe()

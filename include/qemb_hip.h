@@ -68,6 +68,11 @@ int qemb_set_gemm_config(int cfg);         /* -1 = automatic tile choice; >=0 fo
 /* calibration: sustained v_mfma_f64_16x16x4_f64 rate of the chip, registers only (TFLOP/s)           */
 int qemb_mfma_f64_peak(int iters, int blocks_per_cu, double* tflops);
 int qemb_set_gemm_splitk(int enabled);
+/* One product (device pointers) timed on its own, with the sustained shader clock of the launch: every workgroup records its
+ * s_memtime ticks, clock_ghz = sum(ticks) / (256 CUs x time) -- the clock itself when one workgroup is resident per CU (tile configs
+ * 13/15/23/25), a multiple of it otherwise.  Synchronises; a measuring aid for bench.py / tools, not part of the solver path.        */
+int qemb_op_gemm_probe(int64_t M, int64_t N, int64_t K, const double* A, int64_t lda, int a_kcontig, const double* B, int64_t ldb, int b_kcontig,
+                       double* C, int64_t ldc, int cfg, int ksplit, double* ms, double* clock_ghz, int64_t* workgroups);
 int qemb_set_gemm_ksplit(int ksplit);      /* explicit split-K factor for qemb_op_gemm (0 = automatic) */     /* split-K for few-tile / long-K products (default on)   */
 /* out[sum ik*so[k]] = alpha*in[sum ik*si[k]] + beta*out[...], 0<=ik<dim[k], 4 dims                  */
 int qemb_op_copy4(const int64_t dim[4], const double* in, const int64_t si[4], double* out,

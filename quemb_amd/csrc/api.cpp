@@ -47,6 +47,14 @@ int qemb_op_gemm(int64_t M, int64_t N, int64_t K, double alpha, const double* A,
   GemmDesc g{M, N, K, alpha, beta, A, lda, a_kcontig, strideA, B, ldb, b_kcontig, strideB, C, ldc, strideC, batch, -1, g_test_ksplit};
   return dev_gemm(g);
 }
+int qemb_op_gemm_probe(int64_t M, int64_t N, int64_t K, const double* A, int64_t lda, int a_kcontig, const double* B, int64_t ldb, int b_kcontig,
+                       double* C, int64_t ldc, int cfg, int ksplit, double* ms, double* clock_ghz, int64_t* workgroups) {
+  GemmDesc g{M, N, K, 1.0, 0.0, A, lda, a_kcontig, 0, B, ldb, b_kcontig, 0, C, ldc, 0, 1, cfg, ksplit};
+  long long wg = 0;
+  const int rc = dev_gemm_probe(g, ms, clock_ghz, &wg);
+  if (workgroups) *workgroups = wg;
+  return rc;
+}
 static int g_test_ksplit_dummy = 0;
 int qemb_set_gemm_ksplit(int ks) { g_test_ksplit = ks; (void)g_test_ksplit_dummy; return QEMB_OK; }
 int qemb_set_gemm_config(int cfg) { g_gemm_force_cfg = cfg; return QEMB_OK; }

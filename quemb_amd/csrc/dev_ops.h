@@ -79,6 +79,8 @@ struct GemmDesc {
   int ksplit = 0;      // split-K override (0: automatic)
 };
 int dev_gemm(const GemmDesc& g);
+// one product timed on its own with the sustained shader clock read back (see gemm_f64.hip); syncs the stream -- a measuring aid
+int dev_gemm_probe(const GemmDesc& g, double* ms, double* ghz, long long* workgroups);
 
 // ---- strided tensor copy / add (up to 4 dims) -------------------------------------------------
 // out[i0*so[0]+i1*so[1]+i2*so[2]+i3*so[3]] = alpha * in[i0*si[0]+...+i3*si[3]] + beta * out[...]

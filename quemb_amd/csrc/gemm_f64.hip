@@ -327,6 +327,7 @@ __global__ void __launch_bounds__(256) splitk_reduce_wave_kernel(const double* _
 double* gemm_workspace(size_t bytes);   // dev_ops_hip.hip
 static long long* g_gemm_cyc = nullptr;          // QEMB_GEMM_TRACE: per-workgroup tick buffer of the traced launch
 static long long g_gemm_cyc_cap = 0, g_gemm_cyc_blocks = 0;
+static bool g_gemm_cyc_on = false;
 
 template <int WM, int WN, int WAVES_M, int WAVES_N, int BK, bool A_KC, bool B_KC, int VEC, int TAG = 0>
 static int launch_cfg(const GemmDesc& d, hipStream_t s) {
@@ -375,7 +376,7 @@ static int launch_cfg(const GemmDesc& d, hipStream_t s) {
   }
   dim3 grid((unsigned)(g.tiles_m * g.tiles_n), (unsigned)(d.batch * g.ksplit), 1);
   dim3 block(WAVES_M * WAVES_N * 64, 1, 1);
-  if (g_gemm_cyc && (long long)grid.x * grid.y <= g_gemm_cyc_cap) { g.cyc = g_gemm_cyc; g_gemm_cyc_blocks = (long long)grid.x * grid.y; }
+  if (g_gemm_cyc_on && g_gemm_cyc && (long long)grid.x * grid.y <= g_gemm_cyc_cap) { g.cyc = g_gemm_cyc; g_gemm_cyc_blocks = (long long)grid.x * grid.y; }
   hipLaunchKernelGGL(kern, grid, block, lds, s, g);
   if (g.ksplit > 1) {
     const long long mn = d.M * d.N;
@@ -454,22 +455,24 @@ int dev_mfma_f64_peak(int iters, int blocks_per_cu, double* tflops) {
 static int dev_gemm_dispatch(const GemmDesc& d);
 
 // QEMB_GEMM_TRACE=1: every product is timed on its own (events + a stream sync) and logged -- a debugging aid, not a mode to run in
-int dev_gemm(const GemmDesc& d) {
-  static const bool trace = std::getenv("QEMB_GEMM_TRACE") != nullptr;
+// One launch timed on its own, with the shader clock read back: every workgroup records its s_memtime ticks; the sum of the ticks over
+// (256 CUs x kernel time) is the sustained clock when exactly one workgroup is resident per CU (the 8-wave ladder tiles) and a multiple
+// of it when several are.  Syncs the stream -- a measuring aid, never on a timed path.
+int dev_gemm_probe(const GemmDesc& d, double* ms_out, double* ghz_out, long long* workgroups) {
   hipEvent_t t0, t1;
-  if (!trace || dev_capturing() || hipEventCreate(&t0) != hipSuccess || hipEventCreate(&t1) != hipSuccess) return dev_gemm_dispatch(d);
+  if (dev_capturing() || hipEventCreate(&t0) != hipSuccess || hipEventCreate(&t1) != hipSuccess) { set_error("dev_gemm_probe: cannot time this launch"); return QEMB_ERR_DEVICE; }
   hipStream_t s = hip_stream();
   float ms = 0.f;
   if (!g_gemm_cyc) { g_gemm_cyc_cap = 1 << 20; if (hipMalloc((void**)&g_gemm_cyc, sizeof(long long) * g_gemm_cyc_cap) != hipSuccess) g_gemm_cyc = nullptr; }
   g_gemm_cyc_blocks = 0;
+  g_gemm_cyc_on = true;
   (void)hipEventRecord(t0, s);
   const int rc = dev_gemm_dispatch(d);
   (void)hipEventRecord(t1, s);
   (void)hipEventSynchronize(t1);
+  g_gemm_cyc_on = false;
   (void)hipEventElapsedTime(&ms, t0, t1);
   (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
-  // sum of the workgroups' shader-clock ticks / (256 CUs x time): the sustained clock when exactly one workgroup is resident per CU
-  // (the 8-wave ladder tiles), a multiple of it when several are
   double ghz = 0.0;
   if (g_gemm_cyc && g_gemm_cyc_blocks > 0 && ms > 0) {
     std::vector<long long> h((size_t)g_gemm_cyc_blocks);
@@ -478,9 +481,21 @@ int dev_gemm(const GemmDesc& d) {
       ghz = sum / 256.0 / (ms * 1e6);
     }
   }
+  if (ms_out) *ms_out = ms;
+  if (ghz_out) *ghz_out = ghz;
+  if (workgroups) *workgroups = g_gemm_cyc_blocks;
+  return rc;
+}
+
+// QEMB_GEMM_TRACE=1: every product goes through dev_gemm_probe and is logged -- a debugging aid, not a mode to run in
+int dev_gemm(const GemmDesc& d) {
+  static const bool trace = std::getenv("QEMB_GEMM_TRACE") != nullptr;
+  if (!trace || dev_capturing()) return dev_gemm_dispatch(d);
+  double ms = 0.0, ghz = 0.0; long long wg = 0;
+  const int rc = dev_gemm_probe(d, &ms, &ghz, &wg);
   std::fprintf(stderr, "[qemb gemm] M=%lld N=%lld K=%lld batch=%lld a_kc=%d b_kc=%d cfg=%d beta=%g  %.4f ms  %.1f TF  wg-ticks/(256 CU x t) = %.2f GHz (%lld workgroups)\n",
                (long long)d.M, (long long)d.N, (long long)d.K, (long long)d.batch, (int)d.a_kcontig, (int)d.b_kcontig, d.cfg, d.beta, ms,
-               ms > 0 ? 2.0 * d.M * d.N * d.K * d.batch / (ms * 1e9) : 0.0, ghz, g_gemm_cyc_blocks);
+               ms > 0 ? 2.0 * d.M * d.N * d.K * d.batch / (ms * 1e9) : 0.0, ghz, wg);
   return rc;
 }
 

@@ -48,6 +48,7 @@ int dev_timer_end(int s) { g_tot[s] += std::chrono::duration<double, std::milli>
 int dev_timer_read(int s, double* ms, int64_t* c) { if (ms) *ms = g_tot[s]; if (c) *c = g_cnt[s]; return 0; }
 int dev_timer_reset(int s) { g_tot[s] = 0; g_cnt[s] = 0; return 0; }
 
+int dev_gemm_probe(const GemmDesc&, double*, double*, long long*) { set_error("dev_gemm_probe: not available in the hostcheck build"); return QEMB_ERR_DEVICE; }
 int dev_gemm(const GemmDesc& g) {
   for (int64_t b = 0; b < g.batch; ++b) {
     const double* A = g.A + b * g.strideA; const double* B = g.B + b * g.strideB; double* C = g.C + b * g.strideC;
