@@ -29,6 +29,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 #include "dev_ops.h"
 #include "hip_common.h"
@@ -208,39 +209,52 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64, (WM * WN <= 16) ? 2 : 1
 #pragma unroll
     for (int j = 0; j < WN; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
 
-  double ra[NCH_A][VEC], rb[NCH_B][VEC];
+  // Operand staging is one tile deep for A and TWO tiles deep for B by default (DB): the B tile of step kt + 2 is requested before the
+  // MFMAs of step kt and only stored to LDS at the end of step kt + 1 -- a full tile more for the HBM latency; A (re-read by every
+  // column tile, L2 resident) stays one deep: the accumulators leave no registers for a second slot.
+  constexpr int DA = 1;
+  constexpr int DB = (VEC == 2 && WM < 14) ? 2 : 1;    // (the scalar-load variants and the 14 x 1 wave tile would spill)
+  double ra[DA][NCH_A][VEC], rb[DB][NCH_B][VEC];
   const int nk = (kend - kbeg + BK - 1) / BK;
-
-  // prologue: tile 0 -> LDS buffer 0
-  stage_load<BM, BK, A_KC, VEC, T, NCH_A>(ra, A, g.lda, m0, kbeg, g.M, kend, tid);
-  stage_load<BN, BK, B_KC, VEC, T, NCH_B>(rb, B, g.ldb, n0, kbeg, g.N, kend, tid);
-  stage_store<BM, BK, A_KC, VEC, T, NCH_A>(ra, sA0, tid);
-  stage_store<BN, BK, B_KC, VEC, T, NCH_B>(rb, sB0, tid);
-  __syncthreads();
 
   const double* pa[NCH_A];
   const double* pb[NCH_B];
-  stage_ptrs<BM, BK, A_KC, VEC, T, NCH_A>(pa, A, g.lda, m0, kbeg + BK, g.M, tid);   // tile 1 is the first one fetched inside the loop
+  stage_ptrs<BM, BK, A_KC, VEC, T, NCH_A>(pa, A, g.lda, m0, kbeg + BK, g.M, tid);   // tile 1 is the first one the pointer-bump loader fetches
   stage_ptrs<BN, BK, B_KC, VEC, T, NCH_B>(pb, B, g.ldb, n0, kbeg + BK, g.N, tid);
   const long long step_a = A_KC ? (long long)BK : (long long)BK * g.lda;
   const long long step_b = B_KC ? (long long)BK : (long long)BK * g.ldb;
+  // tile tt of the slice into a register slot: interior tiles through the pointer-bump loader, the last one (k-tail -> zeros) guarded
+  // (the scalar-load variants, VEC == 1, keep the guarded loader throughout: twice the chunks, so the pointer arrays would spill)
+  constexpr bool FAST = (VEC == 2);
+  auto fetch_a = [&](double (&r)[NCH_A][VEC], int tt) {
+    if (FAST && tt + 1 < nk) stage_load_fast<BM, BK, A_KC, VEC, T, NCH_A>(r, pa, step_a, tid);
+    else if (tt < nk) stage_load<BM, BK, A_KC, VEC, T, NCH_A>(r, A, g.lda, m0, kbeg + tt * BK, g.M, kend, tid);
+  };
+  auto fetch_b = [&](double (&r)[NCH_B][VEC], int tt) {
+    if (FAST && tt + 1 < nk) stage_load_fast<BN, BK, B_KC, VEC, T, NCH_B>(r, pb, step_b, tid);
+    else if (tt < nk) stage_load<BN, BK, B_KC, VEC, T, NCH_B>(r, B, g.ldb, n0, kbeg + tt * BK, g.N, kend, tid);
+  };
+
+  // prologue: tile 0 -> LDS buffer 0; with a two-deep operand, tile 1 is already requested
+  stage_load<BM, BK, A_KC, VEC, T, NCH_A>(ra[0], A, g.lda, m0, kbeg, g.M, kend, tid);
+  stage_load<BN, BK, B_KC, VEC, T, NCH_B>(rb[0], B, g.ldb, n0, kbeg, g.N, kend, tid);
+  stage_store<BM, BK, A_KC, VEC, T, NCH_A>(ra[0], sA0, tid);
+  stage_store<BN, BK, B_KC, VEC, T, NCH_B>(rb[0], sB0, tid);
+  if (DA == 2) fetch_a(ra[DA - 1], 1);
+  if (DB == 2) fetch_b(rb[DB - 1], 1);
+  __syncthreads();
 
   const int fr = lane & 15, fk = lane >> 4;
-  for (int kt = 0; kt < nk; ++kt) {
-    const double* sA = (kt & 1) ? sA1 : sA0;
-    const double* sB = (kt & 1) ? sB1 : sB0;
-    double* nA = (kt & 1) ? sA0 : sA1;
-    double* nB = (kt & 1) ? sB0 : sB1;
-    const bool more = (kt + 1 < nk);
-    if (more) {  // issue next tile's global loads before this tile's MFMAs (latency hides under them)
-      if (kt + 2 < nk) {         // interior tile: pointer-bump loads, no bounds logic
-        stage_load_fast<BM, BK, A_KC, VEC, T, NCH_A>(ra, pa, step_a, tid);
-        stage_load_fast<BN, BK, B_KC, VEC, T, NCH_B>(rb, pb, step_b, tid);
-      } else {                   // last tile of the slice: may carry a k-tail that must read as zeros
-        stage_load<BM, BK, A_KC, VEC, T, NCH_A>(ra, A, g.lda, m0, kbeg + (kt + 1) * BK, g.M, kend, tid);
-        stage_load<BN, BK, B_KC, VEC, T, NCH_B>(rb, B, g.ldb, n0, kbeg + (kt + 1) * BK, g.N, kend, tid);
-      }
-    }
+  // one k-tile; P = kt & 1 is a compile-time parity so that every register slot index is static
+  auto step = [&](auto parity, int kt) {
+    constexpr int P = decltype(parity)::value;
+    const double* sA = P ? sA1 : sA0;
+    const double* sB = P ? sB1 : sB0;
+    double* nA = P ? sA0 : sA1;
+    double* nB = P ? sB0 : sB1;
+    // requests for the tile DA / DB steps ahead (tile kt + 2 lands in slot P, tile kt + 1 of a one-deep operand in slot 0)
+    fetch_a(ra[DA == 2 ? P : 0], kt + DA);
+    fetch_b(rb[DB == 2 ? P : 0], kt + DB);
 #pragma unroll
     for (int ks = 0; ks < BK / 4; ++ks) {
       const int kk = ks * 4 + fk;
@@ -257,11 +271,15 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64, (WM * WN <= 16) ? 2 : 1
         for (int j = 0; j < WN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
     }
-    if (more) {
-      stage_store<BM, BK, A_KC, VEC, T, NCH_A>(ra, nA, tid);
-      stage_store<BN, BK, B_KC, VEC, T, NCH_B>(rb, nB, tid);
+    if (kt + 1 < nk) {      // tile kt + 1 (requested one or two steps ago) -> the other LDS buffer
+      stage_store<BM, BK, A_KC, VEC, T, NCH_A>(ra[DA == 2 ? 1 - P : 0], nA, tid);
+      stage_store<BN, BK, B_KC, VEC, T, NCH_B>(rb[DB == 2 ? 1 - P : 0], nB, tid);
     }
     __syncthreads();
+  };
+  for (int kt = 0; kt < nk; kt += 2) {
+    step(std::integral_constant<int, 0>{}, kt);
+    if (kt + 1 < nk) step(std::integral_constant<int, 1>{}, kt + 1);
   }
 
   // epilogue: D reg r of lane l -> row (l>>4)+4r, col l&15 of the 16x16 tile
