@@ -178,7 +178,7 @@ def clock_probe(lib):
     vals = []
     for _ in range(4):
         ms, ghz, wg = C.c_double(), C.c_double(), C.c_int64()
-        check(lib.qemb_op_gemm_probe(M, N, K, dA.ptr, K, 1, dB.ptr, K, 1, dC.ptr, N, 23, 8, C.byref(ms), C.byref(ghz), C.byref(wg)), "qemb_op_gemm_probe", lib)
+        check(lib.qemb_op_gemm_probe(M, N, K, dA.ptr, K, 1, dB.ptr, K, 1, dC.ptr, N, 13, 8, C.byref(ms), C.byref(ghz), C.byref(wg)), "qemb_op_gemm_probe", lib)
         vals.append((ghz.value, ms.value, wg.value))
     for b in (dA, dB, dC):
         b.free()
@@ -327,7 +327,7 @@ def main():
                 res["roofline"].update({"sustained_clock_ghz": clk, "peak_at_sustained_clock": PEAK_FP64_MFMA_TFLOPS * clk / 2.4,
                                         "frac_of_sustained_peak": achieved / (PEAK_FP64_MFMA_TFLOPS * clk / 2.4) if clk > 0 else None,
                                         "clock_probe_tflops": cp["tflops"],
-                                        "clock_probe": "launches of the ladder tile (cfg 23, M=210 N=4096 K=16384, split-K 8 = 256 workgroups, random operands) "
+                                        "clock_probe": "launches of the ladder tile (cfg 13 = the same code under the untagged kernel symbol, M=210 N=4096 K=16384, split-K 8 = 256 workgroups, random operands) "
                                                        "right after the timed region, GPU still hot: sum of per-workgroup s_memtime ticks / (256 CUs x kernel time)"})
             except Exception as e:  # noqa: BLE001
                 res["roofline"]["sustained_clock_ghz"] = f"probe failed: {e}"
