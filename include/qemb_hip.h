@@ -108,6 +108,17 @@ int qemb_op_k_from_pairs(int64_t n, const double* H, const double* D, double* K)
 int qemb_op_pack_pm_cols(int64_t rows, int64_t v, const double* in, double* Op, int64_t ldp, double* Om, int64_t ldm);
 int qemb_op_scatter_pm_rows(int64_t o, int64_t ncols, const double* Xp, const double* Xm, double* out);
 int qemb_op_lincomb2(int64_t n, double a, const double* x, double b, const double* y, double beta, double* out);   /* out = a x + b y + beta out */
+/* Single-pass kernels of the CCSD amplitude update (csrc/ccsd.cpp), device pointers:
+ *   small_k_update: C[z][m][n] += alpha sum_k A[z][k][m] B[z][k][n]  (K = n_occ; batch strides sA / sB / sC, 0 shares an operand)
+ *   ccsd_ph_layouts: from t2[o][o][v][v] and t1 in one pass T[k,c,j,b] = t2[k,j,c,b], Tp = t2[k,j,b,c], S = 2T - Tp,
+ *                    Ut = S - 2 t1[j,c] t1[k,b], Tpt = Tp + 2 t1[j,c] t1[k,b] (all [o][v][o][v]) and Th[k,j,c,b] = 2 t2[k,j,b,c] - t2[k,j,c,b]
+ *   ccsd_y_traces:  Y[a,c] = 2 sum_k ZC[k,k,a,c] - sum_k ZB[k,c,a,k]   (ZC [o][o][v][v], ZB [o][v][v][o])
+ * and of the semi-sparse DF transform: gather_rows dst[r,:] = idx[r] >= 0 ? src[idx[r],:] : 0 (idx: int64 on the device), scale_rows x[r,:] *= s[r] */
+int qemb_op_small_k_update(int64_t batch, int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t sA, const double* B, int64_t sB, double* C, int64_t sC);
+int qemb_op_ccsd_ph_layouts(int64_t o, int64_t v, const double* t2, const double* t1, double* T, double* Tp, double* S, double* Ut, double* Tpt, double* Th);
+int qemb_op_ccsd_y_traces(int64_t o, int64_t v, const double* ZC, const double* ZB, double* Y);
+int qemb_op_gather_rows(int64_t nrows, int64_t len, const int64_t* idx_dev, const double* src, int64_t ld, double* dst);
+int qemb_op_scale_rows(int64_t nrows, int64_t len, double* x, const double* s);
 /* Execution contexts (one HIP stream + workspaces + block cache each; no reference counterpart -- the reference overlaps
  * fragments with a process pool, be_parallel.py:484).  qemb_ctx_count(n) makes contexts 0..n-1 available (0 = default) and
  * returns how many exist (or < 0); qemb_ctx_bind(k) binds the CALLING host thread to context k, so that several host

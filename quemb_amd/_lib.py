@@ -86,6 +86,11 @@ def _declare(lib):
     f("qemb_op_pack_pm_cols", I, L, L, P, P, L, P, L)
     f("qemb_op_scatter_pm_rows", I, L, L, P, P, P)
     f("qemb_op_lincomb2", I, L, D, P, D, P, D, P)
+    f("qemb_op_small_k_update", I, L, L, L, L, D, P, L, P, L, P, L)
+    f("qemb_op_ccsd_ph_layouts", I, L, L, P, P, P, P, P, P, P, P)
+    f("qemb_op_ccsd_y_traces", I, L, L, P, P, P)
+    f("qemb_op_gather_rows", I, L, L, P, P, L, P)
+    f("qemb_op_scale_rows", I, L, L, P, P)
     f("qemb_ctx_count", I, I)
     f("qemb_ctx_bind", I, I)
     f("qemb_ctx_timer_read", I, I, I, C.POINTER(C.c_double), C.POINTER(c_i64), I)

@@ -106,6 +106,15 @@ int qemb_op_lincomb2(int64_t n, double a, const double* x, double b, const doubl
   return dev_lincomb(n, 2, c, xs, beta, out);
 }
 int qemb_op_mirror_lower(int64_t n, double* A, int64_t lda) { return dev_mirror_lower(n, A, lda); }
+int qemb_op_small_k_update(int64_t batch, int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t sA, const double* B, int64_t sB, double* C, int64_t sC) {
+  return dev_small_k_update(batch, M, N, K, alpha, A, sA, B, sB, C, sC);
+}
+int qemb_op_ccsd_ph_layouts(int64_t o, int64_t v, const double* t2, const double* t1, double* T, double* Tp, double* S, double* Ut, double* Tpt, double* Th) {
+  return dev_ccsd_ph_layouts(o, v, t2, t1, T, Tp, S, Ut, Tpt, Th);
+}
+int qemb_op_ccsd_y_traces(int64_t o, int64_t v, const double* ZC, const double* ZB, double* Y) { return dev_ccsd_y_traces(o, v, ZC, ZB, Y); }
+int qemb_op_gather_rows(int64_t nrows, int64_t len, const int64_t* idx_dev, const double* src, int64_t ld, double* dst) { return dev_gather_rows(nrows, len, idx_dev, src, ld, dst); }
+int qemb_op_scale_rows(int64_t nrows, int64_t len, double* x, const double* s) { return dev_scale_rows(nrows, len, x, s); }
 int qemb_op_pack_pair_rows(int64_t n, int64_t ncols, const double* in, double* out) { return dev_pack_pair_rows(n, ncols, in, out); }
 int qemb_op_extract_pf(int64_t n, const double* Mp, int64_t p0, int64_t q0, int64_t r0, int64_t s0, int64_t sp, int64_t sq, int64_t sr, int64_t ss, double* out) {
   return dev_extract_pf(n, Mp, p0, q0, r0, s0, sp, sq, sr, ss, out);

@@ -424,3 +424,51 @@ def test_pm_pair_packing_roundtrip_and_lincomb(qlib):
     dx, dy, dz = DeviceBuffer.from_numpy(x), DeviceBuffer.from_numpy(y), DeviceBuffer.from_numpy(z)
     check(qlib.qemb_op_lincomb2(1000, 2.0, dx.ptr, -0.5, dy.ptr, 3.0, dz.ptr))
     assert np.abs(dz.numpy() - (2.0 * x - 0.5 * y + 3.0 * z)).max() < 1e-14
+
+
+@pytest.mark.parametrize("o,v", [(1, 1), (3, 5), (4, 33), (7, 70)])
+def test_ccsd_single_pass_kernels(qlib, o, v):
+    """The fused element-wise kernels of the amplitude update against NumPy, at sizes that are not multiples of the 32 x 32 tiles."""
+    rng = np.random.default_rng(100 * o + v)
+    t2 = rng.standard_normal((o, o, v, v)); t1 = rng.standard_normal((o, v))
+    d2, d1 = DeviceBuffer.from_numpy(t2), DeviceBuffer.from_numpy(t1)
+    outs = [DeviceBuffer(o * o * v * v) for _ in range(6)]
+    check(qlib.qemb_op_ccsd_ph_layouts(o, v, d2.ptr, d1.ptr, *[b.ptr for b in outs]))
+    T, Tp, S, Ut, Tpt = [b.numpy((o, v, o, v)) for b in outs[:5]]
+    Th = outs[5].numpy((o, o, v, v))
+    T_ref = t2.transpose(0, 2, 1, 3); Tp_ref = t2.transpose(0, 3, 1, 2)
+    tt = 2.0 * np.einsum("jc,kb->kcjb", t1, t1)
+    assert np.array_equal(T, T_ref) and np.array_equal(Tp, Tp_ref)
+    assert np.abs(S - (2 * T_ref - Tp_ref)).max() < 1e-14 and np.abs(Ut - (2 * T_ref - Tp_ref - tt)).max() < 1e-13
+    assert np.abs(Tpt - (Tp_ref + tt)).max() < 1e-13 and np.abs(Th - (2 * t2.transpose(0, 1, 3, 2) - t2)).max() < 1e-14
+    ZC = rng.standard_normal((o, o, v, v)); ZB = rng.standard_normal((o, v, v, o))
+    dZC, dZB, dY = DeviceBuffer.from_numpy(ZC), DeviceBuffer.from_numpy(ZB), DeviceBuffer(v * v)
+    check(qlib.qemb_op_ccsd_y_traces(o, v, dZC.ptr, dZB.ptr, dY.ptr))
+    Y_ref = 2.0 * np.einsum("kkac->ac", ZC) - np.einsum("kcak->ac", ZB)
+    assert np.abs(dY.numpy((v, v)) - Y_ref).max() < 1e-12
+    # small-K update: batched A / shared B, shared A / batched B, K longer than one 32-step
+    for (batch, M, N, K, sharedA, sharedB) in ((o * o, v, v, o, False, True), (o * v, v, o, o, True, False), (3, 2 * v + 1, v, 37, False, False)):
+        A = rng.standard_normal((1 if sharedA else batch, K, M)); B = rng.standard_normal((1 if sharedB else batch, K, N)); C0 = rng.standard_normal((batch, M, N))
+        dA, dB, dC = DeviceBuffer.from_numpy(A), DeviceBuffer.from_numpy(B), DeviceBuffer.from_numpy(C0)
+        check(qlib.qemb_op_small_k_update(batch, M, N, K, -0.7, dA.ptr, 0 if sharedA else K * M, dB.ptr, 0 if sharedB else K * N, dC.ptr, M * N))
+        ref = C0 - 0.7 * np.einsum("zkm,zkn->zmn", np.broadcast_to(A, (batch, K, M)), np.broadcast_to(B, (batch, K, N)))
+        assert np.abs(dC.numpy((batch, M, N)) - ref).max() < 1e-12 * max(1.0, np.abs(ref).max())
+
+
+def test_gather_and_scale_rows(qlib):
+    rng = np.random.default_rng(12)
+    src = rng.standard_normal((9, 13))                       # rows of 13 with ld 13; gather 11 columns of each
+    idx = np.array([3, -1, 0, 8, 8, -1, 5], dtype=np.int64)
+    dsrc, ddst = DeviceBuffer.from_numpy(src), DeviceBuffer(len(idx) * 11)
+    didx = DeviceBuffer(len(idx)); check(qlib.qemb_h2d(didx.ptr, idx.ctypes.data, idx.nbytes))
+    check(qlib.qemb_op_gather_rows(len(idx), 11, didx.ptr, dsrc.ptr, 13, ddst.ptr))
+    ref = np.where(idx[:, None] >= 0, src[np.maximum(idx, 0), :11], 0.0)
+    assert np.array_equal(ddst.numpy((len(idx), 11)), ref)
+    x = rng.standard_normal((6, 300)); sc = np.array([1.0, 0.0, 2.5, 1.0, -1.0, 0.0])
+    x[1, 7] = np.inf                                          # a row scaled by zero is cleared, not multiplied
+    dx, ds = DeviceBuffer.from_numpy(x), DeviceBuffer.from_numpy(sc)
+    check(qlib.qemb_op_scale_rows(6, 300, dx.ptr, ds.ptr))
+    with np.errstate(invalid="ignore"):
+        ref = x * sc[:, None]
+    ref[1] = 0.0; ref[5] = 0.0
+    assert np.array_equal(dx.numpy((6, 300)), ref)
