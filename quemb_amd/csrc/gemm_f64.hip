@@ -211,8 +211,8 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64, (WM * WN <= 16) ? 2 : 1
 
   // Operand staging is one tile deep for A and TWO tiles deep for B by default (DB): the B tile of step kt + 2 is requested before the
   // MFMAs of step kt and only stored to LDS at the end of step kt + 1 -- a full tile more for the HBM latency; A (re-read by every
-  // column tile, L2 resident) stays one deep: the accumulators leave no registers for a second slot.
-  constexpr int DA = 1;
+  // column tile, L2 resident) stays one deep where the accumulators leave no registers for a second slot (the 7 x 2 and 4 x 4 wave tiles).
+  constexpr int DA = (VEC == 2 && (WM * WN <= 8 || (WM == 6 && WN == 2))) ? 2 : 1;   // small wave tiles and the 6 x 2 ladder tile have the registers
   constexpr int DB = (VEC == 2 && WM < 14) ? 2 : 1;    // (the scalar-load variants and the 14 x 1 wave tile would spill)
   double ra[DA][NCH_A][VEC], rb[DB][NCH_B][VEC];
   const int nk = (kend - kbeg + BK - 1) / BK;
