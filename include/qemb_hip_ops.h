@@ -1,0 +1,124 @@
+/* qemb_hip_ops.h -- device-pointer primitives, device timers and measurement / tuning hooks of libqemb_hip.so.
+ *
+ * NOT part of the product ABI (include/qemb_hip.h): these entry points exist so that the parity tests can compare every kernel the
+ * drivers are composed of with NumPy (tests/test_gpu_ops.py), and so that bench.py / tools/ can time single kernels.  All pointers
+ * are DEVICE pointers (qemb_malloc) unless stated.  The tuning setters (qemb_set_gemm_*) act on the CALLING HOST THREAD only -- a host
+ * thread drives one execution context (HIP stream), so a setter can never change the GEMMs in flight on another stream.
+ */
+#ifndef QEMB_HIP_OPS_H
+#define QEMB_HIP_OPS_H
+#include "qemb_hip.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* device-time laps measured with HIP events on the library stream (slot ids: see QEMB_TIMER_*) */
+#define QEMB_TIMER_LADDER 0
+#define QEMB_TIMER_RINGS 1
+#define QEMB_TIMER_ITER 2
+#define QEMB_TIMER_AO2MO 3
+#define QEMB_TIMER_SCF 4
+#define QEMB_TIMER_GEMM_ANY 5
+#define QEMB_TIMER_SCHMIDT 6
+#define QEMB_TIMER_DF 7
+int qemb_timer_begin(int slot);
+int qemb_timer_end(int slot);
+int qemb_timer_read(int slot, double* total_ms, int64_t* count);
+int qemb_timer_reset(int slot);
+int qemb_ctx_timer_read(int ctx, int slot, double* total_ms, int64_t* count, int reset);   /* timers of an idle execution context */
+int qemb_timer_live_events(int slot);      /* event pairs held by the calling context's slot (bounded by recycling)   */
+
+/* ---------------------------------------------------------------- device-pointer primitives ---- */
+/* (the kernels the drivers below are composed of; exported so the parity tests can hit each one)    */
+
+/* C[b] = alpha*op(A[b])*op(B[b]) + beta*C[b] on v_mfma_f64_16x16x4_f64.
+ * a_kcontig: A(m,k)=A[m*lda+k] else A[k*lda+m];  b_kcontig: B(k,n)=B[n*ldb+k] else B[k*ldb+n].      */
+int qemb_op_gemm(int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t lda, int a_kcontig,
+                 int64_t strideA, const double* B, int64_t ldb, int b_kcontig, int64_t strideB, double beta,
+                 double* C, int64_t ldc, int64_t strideC, int64_t batch);
+int qemb_set_gemm_config(int cfg);         /* -1 = automatic tile choice; >=0 forces a tile config  */
+/* calibration: sustained v_mfma_f64_16x16x4_f64 rate of the chip, registers only (TFLOP/s)           */
+int qemb_mfma_f64_peak(int iters, int blocks_per_cu, double* tflops);
+int qemb_set_gemm_splitk(int enabled);    /* automatic split-K for few-tile / long-K products (default on) */
+/* One product (device pointers) timed on its own, with the sustained shader clock of the launch: every workgroup records its
+ * s_memtime ticks, clock_ghz = sum(ticks) / (256 CUs x time) -- the clock itself when one workgroup is resident per CU (tile configs
+ * 13/15/23/25), a multiple of it otherwise.  Synchronises; a measuring aid for bench.py / tools, not part of the solver path.        */
+int qemb_op_gemm_probe(int64_t M, int64_t N, int64_t K, const double* A, int64_t lda, int a_kcontig, const double* B, int64_t ldb, int b_kcontig,
+                       double* C, int64_t ldc, int cfg, int ksplit, double* ms, double* clock_ghz, int64_t* workgroups);
+int qemb_set_gemm_ksplit(int ksplit);      /* explicit split-K factor for qemb_op_gemm (0 = automatic) */
+/* out[sum ik*so[k]] = alpha*in[sum ik*si[k]] + beta*out[...], 0<=ik<dim[k], 4 dims                  */
+int qemb_op_copy4(const int64_t dim[4], const double* in, const int64_t si[4], double* out,
+                  const int64_t so[4], double alpha, double beta);
+int qemb_op_outer4(const int64_t dim[4], const double* u, int64_t su0, int64_t su2, const double* v,
+                   int64_t sv1, int64_t sv3, double* out, const int64_t so[4], double alpha, double beta);
+int qemb_op_div_denom(double* x, int64_t d0, int64_t d1, int64_t d2, int64_t d3, const double* ea,
+                      const double* eb, const double* ec, const double* ed);
+/* (+/-) pair-packed pp-ladder helpers, P(x,y) = x(x+1)/2+y (x>=y), Q(x,y) = x(x-1)/2+y (x>y):
+ * Vp[P(ab),P(cd)] = (ac|bd)+(ad|bc), Vm[Q(ab),Q(cd)] = (ac|bd)-(ad|bc) from the n^4 MO tensor (virtuals offset o);
+ * Tp[P(ij),P(cd)] = w(tau_ijcd+tau_ijdc), w = 1/2 | 1/4 (c==d), Tm[Q(ij),Q(cd)] = (tau_ijcd-tau_ijdc)/2;
+ * scatter: t2[ijab] += Rp+Rm, t2[ijba] += Rp-Rm, t2[jiab] += Rp-Rm, t2[jiba] += Rp+Rm                         */
+int qemb_op_ladder_pack_vvvv(int64_t n, int64_t o, const double* M, double* Vp, int64_t ldp, double* Vm, int64_t ldm);
+int qemb_op_ladder_pack_tau(int64_t o, int64_t v, const double* tau, double* Tp, int64_t ldp, double* Tm, int64_t ldm);
+int qemb_op_ladder_scatter_pm(int64_t o, int64_t v, const double* Rp, int64_t ldp, const double* Rm, int64_t ldm, double* t2);
+int qemb_op_dot(int64_t n, const double* x, const double* y, double* out_dev);
+int qemb_op_absmax(int64_t n, const double* x, double* out_dev);
+int qemb_op_gemv_rows(int64_t rows, int64_t cols, const double* T, int64_t ldt, const double* x, double* y,
+                      double alpha, double beta);
+int qemb_op_gemv_rows_batched(int64_t rows, int64_t cols, int64_t nbatch, const double* T, int64_t ldt, int64_t strideT,
+                              const double* x, int64_t stridex, double* y, double alpha, double beta);
+int qemb_op_contract_mid(int64_t outer, int64_t mid, int64_t inner, const double* T, const double* x,
+                         double* Y, int64_t ldy, double alpha, double beta);
+int qemb_op_unpack_s4(int64_t n, const double* s4, double* s1);
+int qemb_op_pack_s4(int64_t n, const double* s1, double* s4);
+int qemb_op_unpack_s8_to_s4(int64_t n, const double* s8, double* s4);
+/* A[r][c] = A[c][r], r < c (completes a SYRK-style result computed on and below the diagonal) */
+int qemb_op_mirror_lower(int64_t n, double* A, int64_t lda);
+/* exchange matrix K[p,r] = sum (pq|rs) D[q,s] from the half-unpacked tensor H[P(p,q)][r][s] (scf.hf.dot_eri_dm's K at helper.py:64) */
+int qemb_op_k_from_pairs(int64_t n, const double* H, const double* D, double* K);
+/* (+/-) pair packing of the last two indices of in[rows][v][v] (Op: c >= d sums, Om: c > d differences; rows padded to ldp / ldm)
+ * and the inverse scatter of packed pair ROWS: out[i,j,:] = Xp + Xm, out[j,i,:] = Xp - Xm */
+int qemb_op_pack_pm_cols(int64_t rows, int64_t v, const double* in, double* Op, int64_t ldp, double* Om, int64_t ldm);
+int qemb_op_scatter_pm_rows(int64_t o, int64_t ncols, const double* Xp, const double* Xm, double* out);
+int qemb_op_lincomb2(int64_t n, double a, const double* x, double b, const double* y, double beta, double* out);   /* out = a x + b y + beta out */
+/* Single-pass kernels of the CCSD amplitude update (csrc/ccsd.cpp), device pointers:
+ *   small_k_update: C[z][m][n] += alpha sum_k A[z][k][m] B[z][k][n]  (K = n_occ; batch strides sA / sB / sC, 0 shares an operand)
+ *   ccsd_ph_layouts: from t2[o][o][v][v] and t1 in one pass T[k,c,j,b] = t2[k,j,c,b], Tp = t2[k,j,b,c], S = 2T - Tp,
+ *                    Ut = S - 2 t1[j,c] t1[k,b], Tpt = Tp + 2 t1[j,c] t1[k,b] (all [o][v][o][v]) and Th[k,j,c,b] = 2 t2[k,j,b,c] - t2[k,j,c,b]
+ *   ccsd_y_traces:  Y[a,c] = 2 sum_k ZC[k,k,a,c] - sum_k ZB[k,c,a,k]   (ZC [o][o][v][v], ZB [o][v][v][o])
+ * and of the semi-sparse DF transform: gather_rows dst[r,:] = idx[r] >= 0 ? src[idx[r],:] : 0 (idx: int64 on the device), scale_rows x[r,:] *= s[r] */
+int qemb_op_small_k_update(int64_t batch, int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t sA, const double* B, int64_t sB, double* C, int64_t sC);
+int qemb_op_ccsd_ph_layouts(int64_t o, int64_t v, const double* t2, const double* t1, double* T, double* Tp, double* S, double* Ut, double* Tpt, double* Th);
+int qemb_op_ccsd_y_traces(int64_t o, int64_t v, const double* ZC, const double* ZB, double* Y);
+int qemb_op_gather_rows(int64_t nrows, int64_t len, const int64_t* idx_dev, const double* src, int64_t ld, double* dst);
+int qemb_op_scale_rows(int64_t nrows, int64_t len, double* x, const double* s);
+/* pair-packed MO transformation helpers (half the flops of the four-index ao2mo.kernel call of PySCF's cc.ao2mo(), which
+ * solve_ccsd reaches at molbe/solver.py:900): row gather x >= y; the same fused with the unpack of the pair column; block gathers
+ * from the pair-first MO tensor Mp[P(p,q)][r][s] and from the 3/4-transformed tensor T[P(r,s)][c][x]; (+/-) ladder operands. */
+int qemb_op_pack_pair_rows(int64_t n, int64_t ncols, const double* in, double* out);
+int qemb_op_unpack_tril_pair_rows(int64_t nr, int64_t n, const double* in, double* full);
+int qemb_op_extract_pf(int64_t n, const double* Mp, int64_t p0, int64_t q0, int64_t r0, int64_t s0, int64_t sp, int64_t sq,
+                       int64_t sr, int64_t ss, double* out);
+int qemb_op_extract_pf_t(int64_t n, const double* T, int64_t x0, int64_t r0, int64_t s0, int64_t c0, int64_t sx, int64_t sr,
+                         int64_t ss, int64_t sc, double* out);
+int qemb_op_ladder_pack_vvvv_pf(int64_t n, int64_t o, const double* Mp, double* Vp, int64_t ldp, double* Vm, int64_t ldm);
+int qemb_op_unpack_tril_rows(int64_t rows, int64_t n, const double* packed, double* full);
+int qemb_op_pack_tril_rows(int64_t rows, int64_t n, const double* full, double* packed);
+int qemb_op_jacobi_eigh(int64_t n, double* A, double* w, double* V, int* sweeps);
+int qemb_op_jacobi_svd(int64_t m, int64_t n, double* G, double* s, double* U, double* V, int* sweeps);
+int qemb_op_cholesky_lower(int64_t n, double* A);
+int qemb_op_tri_inverse_lower(int64_t n, const double* L, double* Linv);
+
+
+/* measurement hooks: set up SCF + integrals once, then run/timed single CCSD iterations                */
+int qemb_frag_prepare_ccsd(qemb_frag_t f, int nsocc, const double* h, const double* dm0, const qemb_solver_opts* opts);
+int qemb_frag_ccsd_iterate(qemb_frag_t f, int niter, double* e_corr, double* normt);
+int qemb_frag_ccsd_reset(qemb_frag_t f);
+/* copy one MO-integral block of the prepared CCSD problem to the host: "oooo" "ovoo" "ovov" "ovvv" "Vl" (= (ac|bd) at
+ * [a,b,c,d]) "W1base" (= ovvo[k,c,a,i] at [i,a,k,c]) "W2base" (= oovv[k,i,a,c] at [i,a,k,c]) "eo" "ev"                     */
+int qemb_frag_ccsd_export(qemb_frag_t f, const char* name, double* host, int64_t nelem);
+
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QEMB_HIP_OPS_H */

@@ -1,4 +1,4 @@
-"""ctypes binding of libqemb_hip.so (C ABI: include/qemb_hip.h).
+"""ctypes binding of libqemb_hip.so (C ABI: include/qemb_hip.h; device primitives and measurement hooks: include/qemb_hip_ops.h).
 
 The reference binds its one native helper the same way -- ``ctypes`` + caller-allocated numpy buffers
 (shared/external/unrestricted_utils.py:142-160).  The library is built in-tree by ``__graft_entry__.build()``
@@ -59,6 +59,7 @@ def _declare(lib):
     f("qemb_timer_end", I, I)
     f("qemb_timer_read", I, I, C.POINTER(D), C.POINTER(L))
     f("qemb_timer_reset", I, I)
+    f("qemb_timer_live_events", I, I)
     f("qemb_op_gemm", I, L, L, L, D, P, L, I, L, P, L, I, L, D, P, L, L, L)
     f("qemb_op_gemm_probe", I, L, L, L, P, L, I, P, L, I, P, L, I, I, C.POINTER(D), C.POINTER(D), C.POINTER(L))
     f("qemb_set_gemm_config", I, I)

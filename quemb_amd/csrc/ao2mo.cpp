@@ -53,7 +53,7 @@ int ao2mo_dense(const AoEri& ao, const double* TA, int n, double* out_s4) {
   DBuf W1, W2;
   QTRY(W1.alloc(std::max<int64_t>(npN * N * N, (int64_t)n * n * npN)));
   QTRY(W2.alloc(std::max<int64_t>((int64_t)n * npN * N, npn * N * N)));
-  QTRY(dev_timer_begin(TIMER_AO2MO));
+  TimerScope lap_AO2MO(TIMER_AO2MO);
   const int tcfg = (n > 192 && n <= 224) ? 13 : -1;   // one 224 x 128 tile instead of two padded 128-row tiles
   QTRY(dev_unpack_tril_rows(npN, N, ao.s4, W1));                                                   // [mn][k][l]
   QTRY(gemm(n, npN * N, N, 1.0, TA, n, false, W1, N, true, 0.0, W2, npN * N, 1, 0, 0, 0, tcfg));                     // [l'][mn][k]
@@ -62,7 +62,7 @@ int ao2mo_dense(const AoEri& ao, const double* TA, int n, double* out_s4) {
   QTRY(gemm(n, npn * N, N, 1.0, TA, n, false, W2, N, true, 0.0, W1, npn * N, 1, 0, 0, 0, tcfg));                     // [j'][(kl)][m]
   QTRY(gemm(n, (int64_t)n * npn, N, 1.0, TA, n, false, W1, N, true, 0.0, W2, (int64_t)n * npn, 1, 0, 0, 0, tcfg));   // [i'][j'][(kl)]
   QTRY(dev_pack_pair_rows(n, npn, W2, out_s4));
-  QTRY(dev_timer_end(TIMER_AO2MO));
+  QTRY(lap_AO2MO.close());
   return 0;
 }
 
@@ -157,7 +157,7 @@ int DfContext::finish_from_pair_rows(int n, const double* bpT, double* out_s4) c
 int DfContext::transform_semisparse(const double* TA, int n, double* out_s4, const double* S_abs, double eps) const {
   const int64_t np = npair(n);
   DBuf T1, T2, bpT, maskb, Xb, TAact, idx_dev;
-  QTRY(dev_timer_begin(TIMER_DF));
+  TimerScope lap_DF(TIMER_DF);
   // get_AO_per_MO (:443-465): (P|mu i) exists only where |S_abs TA|(mu,i) >= eps.  AOs that no embedding orbital reaches drop out
   // of BOTH contractions, so the work and the intermediate follow the fragment's footprint, not the size of the molecule.
   std::vector<int64_t> act;
@@ -179,7 +179,7 @@ int DfContext::transform_semisparse(const double* TA, int n, double* out_s4, con
   const int64_t Na = (int64_t)act.size();
   if (Na == 0) {                                          // everything screened away: the transformed integrals vanish
     QTRY(dev_fill(out_s4, np * np, 0.0));
-    return dev_timer_end(TIMER_DF);
+    return lap_DF.close();
   }
   QTRY(T1.alloc(Na * n * naux));
   {
@@ -231,7 +231,7 @@ int DfContext::transform_semisparse(const double* TA, int n, double* out_s4, con
   QTRY(dev_pack_pair_rows(n, naux, T2, bpT));            // rows (j >= i) of T2[j][i][:]
   T2.release();
   QTRY(finish_from_pair_rows(n, bpT, out_s4));
-  QTRY(dev_timer_end(TIMER_DF));
+  QTRY(lap_DF.close());
   return 0;
 }
 
@@ -243,7 +243,7 @@ int DfContext::transform(const double* TA, int n, double* out_s4, const double* 
   DBuf T1, T2, bp, bb;
   QTRY(T1.alloc((int64_t)naux * n * N)); QTRY(T2.alloc((int64_t)naux * n * n));
   QTRY(bp.alloc((int64_t)naux * np)); QTRY(bb.alloc((int64_t)naux * np));
-  QTRY(dev_timer_begin(TIMER_DF));
+  TimerScope lap_DF(TIMER_DF);
   // T1[L,i,nu] = sum_mu TA[mu,i] (L|mu nu)              (eri_onthefly.py:134, batched over L)
   QTRY(gemm(n, N, N, 1.0, TA, n, false, Lpq, N, false, 0.0, T1, N, naux, 0, (int64_t)N * N, (int64_t)n * N));
   if (S_abs) {
@@ -281,7 +281,7 @@ int DfContext::transform(const double* TA, int n, double* out_s4, const double* 
     }
     if (nblk > 1) QTRY(dev_mirror_lower(np, out_s4, np));
   }
-  QTRY(dev_timer_end(TIMER_DF));
+  QTRY(lap_DF.close());
   return 0;
 }
 

@@ -2,7 +2,7 @@
 // Thin argument marshalling only; the work is in the drivers (ccsd.cpp, scf.cpp, ao2mo.cpp, schmidt.cpp)
 // and the device layer (dev_ops.h).
 #include <cstring>
-#include "../../include/qemb_hip.h"
+#include "../../include/qemb_hip_ops.h"
 #include "dev_ops.h"
 #include "fragment.h"
 #include "ao2mo.h"
@@ -10,8 +10,6 @@
 using namespace qemb;
 namespace qemb {
 int dev_mfma_f64_peak(int iters, int blocks_per_cu, double* tflops);
-extern int g_gemm_force_cfg;
-extern int g_gemm_splitk_enabled;
 int schmidt_eigh(const double* lmo, int N, int nmo, int nocc, const int64_t* frag, int n_f, double thr, double* TA_out,
                  int ld_out, int* n_b_out, int* sweeps_out);
 int schmidt_subspace(const double* lmo, int N, int nmo, int nocc, const int64_t* frag, int n_f, double thr, double* TA_out,
@@ -21,7 +19,7 @@ int schmidt_svd(const double* rdm, int N, const int64_t* frag_in, int n_f, doubl
 int nsocc_guess(const double* Cproj, int n, int nocc, double* P_out, int* nsocc, double* mo_out);
 }
 
-static int g_test_ksplit = 0;   // qemb_set_gemm_ksplit: split-K override of qemb_op_gemm (tests / tuning)
+static thread_local int g_test_ksplit = 0;   // qemb_set_gemm_ksplit: split-K override of qemb_op_gemm (tests / tuning), per calling thread
 
 extern "C" {
 
@@ -40,6 +38,7 @@ int qemb_timer_begin(int s) { return dev_timer_begin(s); }
 int qemb_timer_end(int s) { return dev_timer_end(s); }
 int qemb_timer_read(int s, double* ms, int64_t* c) { return dev_timer_read(s, ms, c); }
 int qemb_timer_reset(int s) { return dev_timer_reset(s); }
+int qemb_timer_live_events(int s) { return dev_timer_live_events(s); }
 
 int qemb_op_gemm(int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t lda, int a_kcontig,
                  int64_t strideA, const double* B, int64_t ldb, int b_kcontig, int64_t strideB, double beta,
@@ -55,15 +54,14 @@ int qemb_op_gemm_probe(int64_t M, int64_t N, int64_t K, const double* A, int64_t
   if (workgroups) *workgroups = wg;
   return rc;
 }
-static int g_test_ksplit_dummy = 0;
-int qemb_set_gemm_ksplit(int ks) { g_test_ksplit = ks; (void)g_test_ksplit_dummy; return QEMB_OK; }
-int qemb_set_gemm_config(int cfg) { g_gemm_force_cfg = cfg; return QEMB_OK; }
+int qemb_set_gemm_ksplit(int ks) { g_test_ksplit = ks; return QEMB_OK; }
+int qemb_set_gemm_config(int cfg) { dev_gemm_set_force_cfg(cfg); return QEMB_OK; }
 #ifndef QEMB_HOSTCHECK
 int qemb_mfma_f64_peak(int iters, int blocks_per_cu, double* tflops) { return dev_mfma_f64_peak(iters, blocks_per_cu, tflops); }
 #else
 int qemb_mfma_f64_peak(int, int, double*) { set_error("not available in the hostcheck build"); return QEMB_ERR_DEVICE; }
 #endif
-int qemb_set_gemm_splitk(int enabled) { g_gemm_splitk_enabled = enabled; return QEMB_OK; }
+int qemb_set_gemm_splitk(int enabled) { dev_gemm_set_auto_splitk(enabled); return QEMB_OK; }
 int qemb_op_copy4(const int64_t dim[4], const double* in, const int64_t si[4], double* out, const int64_t so[4],
                   double alpha, double beta) {
   Copy4Desc c{};

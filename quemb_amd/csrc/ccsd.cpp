@@ -42,7 +42,7 @@ int mo_transform(int n, int o, int nf, const double* eri_s4, double* X0, double*
   const int v = n - o;
   const int64_t np = (int64_t)n * (n + 1) / 2, ncol = np * n;
   out.n = n; out.o = o; out.v = v; out.nf = nf;
-  QTRY(dev_timer_begin(TIMER_AO2MO));
+  TimerScope lap_AO2MO(TIMER_AO2MO);
   if (!x1_is_unpacked) QTRY(dev_unpack_tril_rows(np, n, eri_s4, X1));   // (the fragment RHF already built it for its exchange matrix)
   // 193..224 rows fit ONE 224 x 128 tile (1.8 % padding instead of the 14 % of two 128-row tiles at n = 220)
   const int tcfg = (n > 192 && n <= 224) ? 13 : -1;
@@ -93,7 +93,7 @@ int mo_transform(int n, int o, int nf, const double* eri_s4, double* X0, double*
     QTRY(dev_extract_pf(n, Mp, o, o, o, o, v, v, v, v, g));
     QTRY(perm4(out.Vl, g, v, v, v, v, 0, 2, 1, 3));
   }
-  QTRY(dev_timer_end(TIMER_AO2MO));
+  QTRY(lap_AO2MO.close());
   return 0;
 }
 
@@ -212,7 +212,7 @@ int CcsdSolver::apply_ladder(const double* x, double* out) {
     const int64_t ldp = I_.ldp, ldm = I_.ldm;
     QTRY(dev_ladder_pack_tau(o, v, x, LTp_, ldp, LTm_, ldm));
     int cfg, ks;
-    QTRY(dev_timer_begin(TIMER_LADDER));
+    TimerScope lap_LADDER(TIMER_LADDER);
     pick_pair_gemm(npo, npv, cfg, ks);
     if (cfg == 13 || cfg == 15) cfg += 10;      // same tiles under the ladder's own kernel symbol (profiles)
     QTRY(gemm(npo, npv, ldp, 1.0, LTp_, ldp, true, I_.Vp, ldp, true, 0.0, LRp_, ldp, 1, 0, 0, 0, cfg, ks));
@@ -221,7 +221,7 @@ int CcsdSolver::apply_ladder(const double* x, double* out) {
       if (cfg == 13 || cfg == 15) cfg += 10;
       QTRY(gemm(nmo, nmv, ldm, 1.0, LTm_, ldm, true, I_.Vm, ldm, true, 0.0, LRm_, ldm, 1, 0, 0, 0, cfg, ks));
     }
-    QTRY(dev_timer_end(TIMER_LADDER));
+    QTRY(lap_LADDER.close());
     QTRY(dev_ladder_scatter_pm(o, v, LRp_, ldp, LRm_, ldm, out));
   }
   return 0;
@@ -309,7 +309,7 @@ int CcsdSolver::update_amps(double* t1n, double* t2n) {
   QTRY(perm4(X_, G2_, o, o, v, o, 3, 1, 0, 2, 1.0, 1.0));                          // A[i,j,k,a] += G2[k,j,a,i]
   QTRY(dev_small_k_update(oo, v, v, o, -1.0, X_, nov, t1, 0, U_, vv));                 // U[ij][a][b] -= sum_k A[ij][k][a] t1[k][b]
   // ---- ph rings
-  QTRY(dev_timer_begin(TIMER_RINGS));
+  TimerScope lap_RINGS(TIMER_RINGS);
   // The t2-dependent parts of both ring intermediates come from TWO (ov)^3 products instead of three: with
   //   u~ = 2T - Tp - 2 t1(x)t1,  Tp~ = Tp + 2 t1(x)t1   (t1(x)t1[(ia),(ld)] = t1[id] t1[la]),  L = 2 ovov - ovov_t,
   //   Wvoov += 1/4 u~ L - 1/4 Tp~ ovov_t,      Wvovo -= 1/2 Tp~ ovov_t
@@ -333,7 +333,7 @@ int CcsdSolver::update_amps(double* t1n, double* t2n) {
   QTRY(perm4(U_, W1_, o, v, o, v, 0, 2, 3, 1, -1.0, 1.0));                         // U[i,j,a,b] -= A3[i,b,j,a]
   QTRY(gemm_nn(nov, nov, nov, 1.0, R_, S_, -0.5, W1_));                            // W1 = (Wvoov - Wvovo/2) u - A3/2
   QTRY(perm4(U_, W1_, o, v, o, v, 0, 2, 1, 3, 1.0, 1.0));                          // [i,a,j,b] -> U[i,j,a,b]
-  QTRY(dev_timer_end(TIMER_RINGS));
+  QTRY(lap_RINGS.close());
 
   // ---- symmetrise and divide
   QTRY(dev_div_denom(t1n, o, 1, v, 1, eo_, nullptr, ev_, nullptr));
@@ -343,7 +343,7 @@ int CcsdSolver::update_amps(double* t1n, double* t2n) {
 
 int CcsdSolver::iterate(double* e_corr, double* normt) {
   const int64_t na = n_amp();
-  QTRY(dev_timer_begin(TIMER_ITER));
+  TimerScope lap_ITER(TIMER_ITER);
   // Launch-bound regime (small fragments): record update_amps once (after one eager pass has settled every workspace)
   // and replay it as a hipGraph.  Large fragments are GEMM bound and keep the eager path with its per-kernel timers.
   // (hipGraph replay under rocprofv3's kernel tracing aborts inside the profiler on this ROCm: fall back to eager launches there)
@@ -394,7 +394,7 @@ int CcsdSolver::iterate(double* e_corr, double* normt) {
   *normt = std::sqrt(nn);
   QTRY(energy(t1(), t2(), &ecc_));
   *e_corr = ecc_;
-  QTRY(dev_timer_end(TIMER_ITER));
+  QTRY(lap_ITER.close());
   return 0;
 }
 

@@ -12,7 +12,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <string>
-#include "../../include/qemb_hip.h"
+#include "../../include/qemb_hip_ops.h"
 
 namespace qemb {
 
@@ -58,8 +58,18 @@ int dev_timer_end(int slot);
 int dev_timer_read(int slot, double* total_ms, int64_t* count);   // syncs
 int dev_timer_reset(int slot);
 int dev_ctx_timer_read(int ctx, int slot, double* total_ms, int64_t* count, int reset);   // another context's timers (idle context)
+int dev_timer_live_events(int slot);   // event pairs currently held by the calling context's slot (bounded; test hook)
 enum { TIMER_LADDER = 0, TIMER_RINGS = 1, TIMER_ITER = 2, TIMER_AO2MO = 3, TIMER_SCF = 4,
        TIMER_GEMM_ANY = 5, TIMER_SCHMIDT = 6, TIMER_DF = 7, TIMER_NSLOTS = 16 };
+// A lap that always ends: the stop event is recorded when the scope is left, also on an early (error) return of the bracketed region.
+struct TimerScope {
+  int slot; bool open;
+  explicit TimerScope(int s) : slot(s), open(dev_timer_begin(s) == 0) {}
+  int close() { if (!open) return 0; open = false; return dev_timer_end(slot); }
+  ~TimerScope() { if (open) (void)dev_timer_end(slot); }
+  TimerScope(const TimerScope&) = delete;
+  TimerScope& operator=(const TimerScope&) = delete;
+};
 
 // ---- GEMM (FP64 MFMA) --------------------------------------------------------------------------
 // C[b] = alpha * op(A[b]) * op(B[b]) + beta * C[b],   b = 0..batch-1
@@ -79,6 +89,9 @@ struct GemmDesc {
   int ksplit = 0;      // split-K override (0: automatic)
 };
 int dev_gemm(const GemmDesc& g);
+// test / tuning hooks of the calling host thread: force a tile configuration (-1: automatic), switch the automatic split-K off
+void dev_gemm_set_force_cfg(int cfg);
+void dev_gemm_set_auto_splitk(int enabled);
 // one product timed on its own with the sustained shader clock read back (see gemm_f64.hip); syncs the stream -- a measuring aid
 int dev_gemm_probe(const GemmDesc& g, double* ms, double* ghz, long long* workgroups);
 

@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -31,8 +32,13 @@ const char* last_error() { return g_err.c_str(); }
 // Every host thread is bound to a context (the process default unless dev_ctx_bind is called), so several fragments can be
 // driven concurrently from several host threads, each on its own stream: fragments whose kernels are latency bound
 // (n ~ 40-60) then overlap on the device.  Nothing is shared between contexts, so no locking is needed on the hot path.
-struct TimerSlot { hipEvent_t e0 = nullptr, e1 = nullptr; double total_ms = 0; int64_t count = 0;
-                   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending; };
+// Device-time laps: every begin/end pair of a slot is one (start, stop) event pair.  Pairs are recycled through a per-slot free list
+// and collected without a host sync as soon as their stop event has completed, so a long optimisation that never reads its timers
+// keeps a bounded number of live events (TIMER_MAX_PENDING per slot); a begin whose end was never recorded (early return of the
+// bracketed region) is dropped at the next begin / collect instead of poisoning the slot.  QEMB_TIMERS=0 turns the laps off.
+struct TimerLap { hipEvent_t e0, e1; bool ended; };
+struct TimerSlot { double total_ms = 0; int64_t count = 0; std::vector<TimerLap> pending; std::vector<std::pair<hipEvent_t, hipEvent_t>> spare; };
+static constexpr size_t TIMER_MAX_PENDING = 64;
 static constexpr int NPART = 2048;
 struct DevCtx {
   hipStream_t stream = nullptr;
@@ -76,8 +82,13 @@ int dev_init(int device) {
   if (device < 0 || device >= ndev) { set_error("dev_init: device index out of range"); return QEMB_ERR_ARG; }
   DevCtx& c = g_default_ctx;
   if (c.stream && g_device == device) return QEMB_OK;
+  if (c.stream) {
+    // One process drives one GPU (one rank per GPU): device memory, streams and cached blocks of the first device are live behind
+    // handles the caller still holds, so a second device is refused rather than half torn down.
+    set_error("libqemb_hip is already initialised on device " + std::to_string(g_device) + "; one process drives one GPU");
+    return QEMB_ERR_DEVICE;
+  }
   HIP_TRY(hipSetDevice(device));
-  if (c.stream) { (void)hipStreamDestroy(c.stream); c = DevCtx(); }
   HIP_TRY(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
   HIP_TRY(hipMalloc((void**)&c.partials, 8 * NPART * sizeof(double)));
   g_device = device;
@@ -117,13 +128,35 @@ int dev_sync() { REQUIRE_INIT(); HIP_TRY(hipStreamSynchronize(g_stream)); return
 // is on ONE stream, so reuse is stream-ordered and needs no synchronisation.  dev_trim() / an allocation failure
 // releases the parked blocks.
 
+static void trim_ctx_locked(DevCtx& c) {      // g_alloc_mutex held; the context's stream has been drained
+  for (auto& kv : c.pool) for (void* q : kv.second) (void)hipFree(q);
+  c.pool.clear(); c.pool_bytes = 0;
+}
 int dev_trim() {
   if (!g_stream) return QEMB_OK;
   HIP_TRY(hipStreamSynchronize(g_stream));
   std::lock_guard<std::mutex> lock(g_alloc_mutex);
-  for (auto& kv : g_pool) for (void* q : kv.second) (void)hipFree(q);
-  g_pool.clear(); g_pool_bytes = 0;
+  trim_ctx_locked(ctx());
   return QEMB_OK;
+}
+// An allocation failed: hand the parked blocks of EVERY context back to the driver (a multi-GB block cached by another stream's
+// context is as good as free).  Each context's stream is drained first, so none of its parked blocks is still in use.
+static int trim_all_contexts() {
+  std::vector<DevCtx*> all;
+  {
+    std::lock_guard<std::mutex> lock(g_ctx_mutex);
+    all.push_back(&g_default_ctx);
+    for (DevCtx* c : g_extra_ctx) all.push_back(c);
+  }
+  for (DevCtx* c : all) if (c->stream) HIP_TRY(hipStreamSynchronize(c->stream));
+  std::lock_guard<std::mutex> lock(g_alloc_mutex);
+  for (DevCtx* c : all) trim_ctx_locked(*c);
+  return QEMB_OK;
+}
+// Cached blocks of one context are capped (QEMB_POOL_CAP_GB, default 96): beyond it a released block goes back to the driver.
+static size_t pool_cap_bytes() {
+  static const size_t cap = [] { const char* e = std::getenv("QEMB_POOL_CAP_GB"); const double gb = e ? std::atof(e) : 96.0; return (size_t)(gb * (double)(1ull << 30)); }();
+  return cap;
 }
 int dev_alloc(void** p, size_t bytes) {
   REQUIRE_INIT();
@@ -142,7 +175,7 @@ int dev_alloc(void** p, size_t bytes) {
   hipError_t e = hipMalloc(p, bytes);
   if (e != hipSuccess) {
     (void)hipGetLastError();
-    int rc = dev_trim();
+    int rc = trim_all_contexts();
     if (rc) return rc;
     e = hipMalloc(p, bytes);
   }
@@ -163,8 +196,15 @@ int dev_free(void* p) {
   // a block goes back to the cache of the context that allocated it; when another context releases it, that context's
   // stream is drained first so that the owner cannot reuse the block under kernels still in flight
   if (blk.owner != &ctx() && g_stream) HIP_TRY(hipStreamSynchronize(g_stream));
-  std::lock_guard<std::mutex> lock(g_alloc_mutex);
-  blk.owner->pool[blk.bytes].push_back(p); blk.owner->pool_bytes += blk.bytes;
+  {
+    std::lock_guard<std::mutex> lock(g_alloc_mutex);
+    if (blk.owner->pool_bytes + blk.bytes <= pool_cap_bytes()) {
+      blk.owner->pool[blk.bytes].push_back(p); blk.owner->pool_bytes += blk.bytes;
+      return QEMB_OK;
+    }
+  }
+  HIP_TRY(hipStreamSynchronize(g_stream));     // over the cap: really free it (hipFree also waits for the device)
+  HIP_TRY(hipFree(p));
   return QEMB_OK;
 }
 int dev_h2d(void* dst, const void* src, size_t bytes) {
@@ -232,36 +272,62 @@ int dev_graph_launch(dev_graph_t g) { REQUIRE_INIT(); HIP_TRY(hipGraphLaunch((hi
 int dev_graph_destroy(dev_graph_t g) { if (g) (void)hipGraphExecDestroy((hipGraphExec_t)g); return QEMB_OK; }
 
 // ---- timers -----------------------------------------------------------------------------------
+static bool timers_enabled() {
+  static const bool on = [] { const char* e = std::getenv("QEMB_TIMERS"); return !(e && e[0] == '0'); }();
+  return on;
+}
+// fold every lap whose stop event has completed into the totals (oldest first; stops at the first one still in flight unless `wait`)
+static void timer_harvest(TimerSlot& t, bool wait) {
+  size_t done = 0;
+  for (; done < t.pending.size(); ++done) {
+    TimerLap& lap = t.pending[done];
+    if (lap.ended) {
+      if (!wait && hipEventQuery(lap.e1) != hipSuccess) { (void)hipGetLastError(); break; }
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, lap.e0, lap.e1) == hipSuccess) { t.total_ms += ms; t.count += 1; }
+      else (void)hipGetLastError();
+    }                                   // a lap that was begun but never ended is dropped
+    t.spare.emplace_back(lap.e0, lap.e1);
+  }
+  t.pending.erase(t.pending.begin(), t.pending.begin() + done);
+}
 int dev_timer_begin(int slot) {
   REQUIRE_INIT();
-  if (g_capturing) return QEMB_OK;
+  if (g_capturing || !timers_enabled()) return QEMB_OK;
   if (slot < 0 || slot >= TIMER_NSLOTS) return QEMB_ERR_ARG;
   TimerSlot& t = g_timers[slot];
-  hipEvent_t a, b;
-  HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b));
-  HIP_TRY(hipEventRecord(a, g_stream));
-  t.pending.emplace_back(a, b);
+  if (!t.pending.empty() && !t.pending.back().ended) {     // the previous region left early: reuse its pair
+    HIP_TRY(hipEventRecord(t.pending.back().e0, g_stream));
+    return QEMB_OK;
+  }
+  if (t.pending.size() >= TIMER_MAX_PENDING) {
+    timer_harvest(t, false);
+    if (t.pending.size() >= TIMER_MAX_PENDING) { HIP_TRY(hipStreamSynchronize(g_stream)); timer_harvest(t, true); }
+  }
+  TimerLap lap{nullptr, nullptr, false};
+  if (!t.spare.empty()) { lap.e0 = t.spare.back().first; lap.e1 = t.spare.back().second; t.spare.pop_back(); }
+  else {
+    HIP_TRY(hipEventCreate(&lap.e0));
+    if (hipEventCreate(&lap.e1) != hipSuccess) { (void)hipEventDestroy(lap.e0); set_error("hipEventCreate failed"); return QEMB_ERR_DEVICE; }
+  }
+  t.pending.push_back(lap);
+  HIP_TRY(hipEventRecord(lap.e0, g_stream));
   return QEMB_OK;
 }
 int dev_timer_end(int slot) {
   REQUIRE_INIT();
-  if (g_capturing) return QEMB_OK;
+  if (g_capturing || !timers_enabled()) return QEMB_OK;
   if (slot < 0 || slot >= TIMER_NSLOTS) return QEMB_ERR_ARG;
   TimerSlot& t = g_timers[slot];
-  if (t.pending.empty()) return QEMB_ERR_ARG;
-  HIP_TRY(hipEventRecord(t.pending.back().second, g_stream));
+  if (t.pending.empty() || t.pending.back().ended) return QEMB_ERR_ARG;
+  HIP_TRY(hipEventRecord(t.pending.back().e1, g_stream));
+  t.pending.back().ended = true;
   return QEMB_OK;
 }
 static int timer_collect(DevCtx& c, int slot, double* total_ms, int64_t* count) {
   TimerSlot& t = c.timers[slot];
   HIP_TRY(hipStreamSynchronize(c.stream));
-  for (auto& pr : t.pending) {
-    float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, pr.first, pr.second));
-    t.total_ms += ms; t.count += 1;
-    (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second);
-  }
-  t.pending.clear();
+  timer_harvest(t, true);
   if (total_ms) *total_ms = t.total_ms;
   if (count) *count = t.count;
   return QEMB_OK;
@@ -291,6 +357,11 @@ int dev_timer_reset(int slot) {
   if (rc) return rc;
   g_timers[slot].total_ms = 0; g_timers[slot].count = 0;
   return QEMB_OK;
+}
+// number of live (pending + spare) event pairs of the calling context's slot: a test hook for the bounded-events guarantee
+int dev_timer_live_events(int slot) {
+  if (slot < 0 || slot >= TIMER_NSLOTS) return -1;
+  return (int)(g_timers[slot].pending.size() + g_timers[slot].spare.size());
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -303,6 +303,9 @@ int Fragment::solve(int o, const double* h, const double* dm0, const FragmentOpt
     QTRY(t_prev_.alloc(na));
     QTRY(dcopy(na, cc_->t1(), t_prev_));
     t_prev_o_ = o;
+    // the next sweep may drive this fragment from a host thread bound to ANOTHER execution context (stream): the kept amplitudes,
+    // multipliers and orbitals must be complete before this call returns (no inter-stream ordering exists otherwise)
+    QTRY(dev_sync());
   }
   cc_.reset();
   return 0;

@@ -39,8 +39,12 @@ namespace qemb {
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
 
-int g_gemm_force_cfg = -1;      // test / tuning hook (qemb_set_gemm_config)
-int g_gemm_splitk_enabled = 1;  // test hook
+// Test / tuning hooks (qemb_set_gemm_config, qemb_set_gemm_splitk).  Per calling HOST THREAD: a thread drives one execution context
+// (stream), so a setter cannot change the tile choice of GEMMs dispatched -- or being captured into a hipGraph -- by another thread.
+static thread_local int t_gemm_force_cfg = -1;
+static thread_local int t_gemm_splitk_enabled = 1;
+void dev_gemm_set_force_cfg(int cfg) { t_gemm_force_cfg = cfg; }
+void dev_gemm_set_auto_splitk(int enabled) { t_gemm_splitk_enabled = enabled; }
 
 struct GemmKArgs {
   const double* A; const double* B; double* C;
@@ -370,7 +374,7 @@ static int launch_cfg(const GemmDesc& d, hipStream_t s) {
     chunk = (chunk + 31) / 32 * 32;
     const long long S = (d.K + chunk - 1) / chunk;
     if (S > 1 && S * d.batch <= 65535) { g.ksplit = (int)S; g.kchunk = (int)chunk; }
-  } else if (g_gemm_splitk_enabled && tiles < 256 && d.K >= 1024) {
+  } else if (t_gemm_splitk_enabled && tiles < 256 && d.K >= 1024) {
     long long S = (768 + tiles - 1) / tiles;
     if (S > d.K / 256) S = d.K / 256;
     if (S > 1) {
@@ -434,37 +438,47 @@ static bool operand_vec2_ok(const double* p, int64_t ld, int64_t stride, int64_t
 
 
 
-// ---- calibration: back-to-back v_mfma_f64_16x16x4_f64 issue rate of the whole chip (no memory traffic) --------
-__global__ void __launch_bounds__(256) mfma_f64_peak_kernel(double* out, int iters) {
-  d4 acc[8];
+// ---- calibration: v_mfma_f64_16x16x4_f64 issue rate of the whole chip, registers only (no LDS, no memory traffic) -----------
+// An UPPER bound for the tiled GEMMs: 16 independent accumulator chains per wave (the 7 x 2 ladder tile has 14, the 4 x 4 tile 16),
+// so no MFMA ever waits for the previous result of its own chain; operands differ per lane and per chain (not the constant operands
+// a power-saving data path could exploit); 2 waves per SIMD by default (8-wave workgroups of the ladder tile: 2 per SIMD).
+template <int NACC>
+__global__ void __launch_bounds__(256) mfma_f64_peak_kernel(double* out, int iters, double seed) {
+  d4 acc[NACC];
+  double a[NACC], b[4];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) acc[i] = d4{0.0, 0.0, 0.0, 0.0};
-  double a = 1.0 + 1e-9 * threadIdx.x, b = 1.0 - 1e-9 * threadIdx.x;
+  for (int i = 0; i < NACC; ++i) {
+    acc[i] = d4{0.0, 0.0, 0.0, 0.0};
+    a[i] = seed * (1.0 + 0.37 * i) + 1e-3 * (double)((threadIdx.x * 2654435761u + i * 40503u) & 1023u) - 0.5;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) b[j] = seed * (0.5 - 0.21 * j) + 1e-3 * (double)((threadIdx.x * 40503u + j * 2654435761u) & 1023u) - 0.5;
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+    for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[i & 3], acc[i], 0, 0, 0);
   }
   double s = 0.0;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
   if (s == 12345.678) out[0] = s;   // keep the accumulators live
 }
 int dev_mfma_f64_peak(int iters, int blocks_per_cu, double* tflops) {
   hipStream_t s = hip_stream();
   if (!s) { set_error("libqemb_hip: call qemb_init(device) first"); return QEMB_ERR_DEVICE; }
+  constexpr int NACC = 16;
   double* out = nullptr;
   HIP_TRY(hipMalloc((void**)&out, 64));
   hipEvent_t e0, e1;
   HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
   const int grid = 256 * blocks_per_cu;
-  hipLaunchKernelGGL(mfma_f64_peak_kernel, dim3(grid), dim3(256), 0, s, out, 64);   // warm-up
+  hipLaunchKernelGGL(mfma_f64_peak_kernel<NACC>, dim3(grid), dim3(256), 0, s, out, 64, 0.731);   // warm-up
   HIP_TRY(hipEventRecord(e0, s));
-  hipLaunchKernelGGL(mfma_f64_peak_kernel, dim3(grid), dim3(256), 0, s, out, iters);
+  hipLaunchKernelGGL(mfma_f64_peak_kernel<NACC>, dim3(grid), dim3(256), 0, s, out, iters, 0.731);
   HIP_TRY(hipEventRecord(e1, s));
   HIP_TRY(hipEventSynchronize(e1));
   float ms = 0.f;
   HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-  const double flop = 2.0 * 16 * 16 * 4 * 8.0 * iters * 4.0 * grid;   // 8 MFMAs x 4 waves per block
+  const double flop = 2.0 * 16 * 16 * 4 * (double)NACC * iters * 4.0 * grid;   // NACC MFMAs x 4 waves per block
   *tflops = flop / (ms * 1e-3) / 1e12;
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(out);
   return QEMB_OK;
@@ -540,7 +554,7 @@ static int dev_gemm_dispatch(const GemmDesc& d) {
   else if (d.M >= 128 && d.N >= 128 && d.K >= 4096) cfg = 1;   // few tiles but a long K: split-K supplies the workgroups (200 x 200 x 80000: 0.24 vs 0.29 ms)
   else cfg = 2;
   if (d.cfg >= 0) cfg = d.cfg;
-  if (g_gemm_force_cfg >= 0) cfg = g_gemm_force_cfg;
+  if (t_gemm_force_cfg >= 0) cfg = t_gemm_force_cfg;
   switch (cfg) {
     case 0: return launch_layout<4, 4, 2, 2, 16>(d, s, vec2);   // 128 x 128, 4 waves
     case 1: return launch_layout<2, 2, 2, 2, 16>(d, s, vec2);   //  64 x  64, 4 waves

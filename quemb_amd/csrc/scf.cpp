@@ -111,7 +111,7 @@ int rhf_device(int n, int o, const double* h, const double* eri, double* dm, con
   double* J = J_out; double* K = K_out;
   if (!J) { QTRY(Jb.alloc(n2)); J = Jb; }
   if (!K) { QTRY(Kb.alloc(n2)); K = Kb; }
-  QTRY(dev_timer_begin(TIMER_SCF));
+  TimerScope lap_SCF(TIMER_SCF);
   DBuf dm_start;
   QTRY(dm_start.alloc(n2)); QTRY(dcopy(n2, dm, dm_start));
   DBuf c_start;
@@ -125,7 +125,7 @@ int rhf_device(int n, int o, const double* h, const double* eri, double* dm, con
     if (c_is_guess) QTRY(dcopy(n2, c_start, C));
     QTRY(rhf_loop(n, o, h, eri, eri_s4, dm, o2, C, eps, J, K, res, c_is_guess));
   }
-  QTRY(dev_timer_end(TIMER_SCF));
+  QTRY(lap_SCF.close());
   return 0;
 }
 

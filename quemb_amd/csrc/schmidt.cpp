@@ -33,10 +33,10 @@ int schmidt_eigh(const double* lmo, int N, int nmo, int nocc, const int64_t* fra
   DBuf dC, dD, dw, dV;
   QTRY(dC.alloc((int64_t)ne * nocc)); QTRY(dD.alloc((int64_t)ne * ne)); QTRY(dw.alloc(ne)); QTRY(dV.alloc((int64_t)ne * ne));
   QTRY(dev_h2d(dC, cenv.data(), sizeof(double) * ne * nocc));
-  QTRY(dev_timer_begin(TIMER_SCHMIDT));
+  TimerScope lap_SCHMIDT(TIMER_SCHMIDT);
   QTRY(gemm_nt(ne, ne, nocc, 1.0, dC, dC, 0.0, dD));
   QTRY(dev_jacobi_eigh(ne, dD, dw, dV, sweeps_out));                       // pfrag.py:468
-  QTRY(dev_timer_end(TIMER_SCHMIDT));
+  QTRY(lap_SCHMIDT.close());
   std::vector<double> w((size_t)ne), V((size_t)ne * ne);
   QTRY(dev_d2h(w.data(), dw, sizeof(double) * ne));
   QTRY(dev_d2h(V.data(), dV, sizeof(double) * ne * ne));
@@ -76,7 +76,7 @@ int schmidt_subspace(const double* lmo, int N, int nmo, int nocc, const int64_t*
   QTRY(ds.alloc(n_f)); QTRY(dU.alloc((int64_t)ne * n_f));
   QTRY(dev_h2d(dCe, cenv.data(), sizeof(double) * ne * nocc));
   QTRY(dev_h2d(dCf, cf.data(), sizeof(double) * n_f * nocc));
-  QTRY(dev_timer_begin(TIMER_SCHMIDT));
+  TimerScope lap_SCHMIDT(TIMER_SCHMIDT);
   QTRY(gemm_nt(ne, n_f, nocc, 1.0, dCe, dCf, 0.0, dDef));                       // D_ef = C_env C_f^T
   QTRY(dev_jacobi_svd(ne, n_f, dDef, ds, dU, nullptr, sweeps_out));
   std::vector<double> sv((size_t)n_f);
@@ -86,14 +86,14 @@ int schmidt_subspace(const double* lmo, int N, int nmo, int nocc, const int64_t*
   *n_b_out = 0;
   for (int i = 0; i < N; ++i) for (int c = 0; c < ld_out; ++c) TA_out[(size_t)i * ld_out + c] = 0.0;
   for (int k = 0; k < n_f; ++k) TA_out[(size_t)frag[k] * ld_out + k] = 1.0;
-  if (r == 0) { QTRY(dev_timer_end(TIMER_SCHMIDT)); return 0; }
+  if (r == 0) { QTRY(lap_SCHMIDT.close()); return 0; }
   // A = U_r^T D_env U_r = Z^T Z,  Z = C_env^T U_r   (nocc x r); U is ne x n_f row-major, its first r columns are used
   DBuf dZ, dA, dw, dY, dB;
   QTRY(dZ.alloc((int64_t)nocc * r)); QTRY(dA.alloc((int64_t)r * r)); QTRY(dw.alloc(r)); QTRY(dY.alloc((int64_t)r * r));
   QTRY(gemm(nocc, r, ne, 1.0, dCe, nocc, false, dU, n_f, false, 0.0, dZ, r));      // Z[k,b] = sum_e C_env[e,k] U[e,b]
   QTRY(gemm(r, r, nocc, 1.0, dZ, r, false, dZ, r, false, 0.0, dA, r));             // A = Z^T Z
   QTRY(dev_jacobi_eigh(r, dA, dw, dY, nullptr));
-  QTRY(dev_timer_end(TIMER_SCHMIDT));
+  QTRY(lap_SCHMIDT.close());
   std::vector<double> w((size_t)r), Y((size_t)r * r), U((size_t)ne * n_f);
   QTRY(dev_d2h(w.data(), dw, sizeof(double) * r));
   QTRY(dev_d2h(Y.data(), dY, sizeof(double) * r * r));
@@ -131,9 +131,9 @@ int schmidt_svd(const double* rdm, int N, const int64_t* frag_in, int n_f, doubl
   DBuf dG, ds, dU;
   QTRY(dG.alloc((int64_t)ne * n_f)); QTRY(ds.alloc(n_f)); QTRY(dU.alloc((int64_t)ne * n_f));
   QTRY(dev_h2d(dG, G.data(), sizeof(double) * ne * n_f));
-  QTRY(dev_timer_begin(TIMER_SCHMIDT));
+  TimerScope lap_SCHMIDT(TIMER_SCHMIDT);
   QTRY(dev_jacobi_svd(ne, n_f, dG, ds, dU, nullptr, sweeps_out));                                                           // :38
-  QTRY(dev_timer_end(TIMER_SCHMIDT));
+  QTRY(lap_SCHMIDT.close());
   std::vector<double> s((size_t)n_f), U((size_t)ne * n_f);
   QTRY(dev_d2h(s.data(), ds, sizeof(double) * n_f));
   QTRY(dev_d2h(U.data(), dU, sizeof(double) * ne * n_f));

@@ -16,7 +16,7 @@ def build(force=False):
     if os.environ.get("QEMB_HOSTCHECK_LIB"):
         return Path(os.environ["QEMB_HOSTCHECK_LIB"])
     srcs = sorted(CSRC.glob("*.cpp")) + [HERE / "dev_ops_cpu.cpp"]
-    deps = srcs + sorted(CSRC.glob("*.h")) + sorted(CSRC.glob("*.inc")) + [CSRC.parent.parent / "include" / "qemb_hip.h"]
+    deps = srcs + sorted(CSRC.glob("*.h")) + sorted(CSRC.glob("*.inc")) + [CSRC.parent.parent / "include" / "qemb_hip.h", CSRC.parent.parent / "include" / "qemb_hip_ops.h"]
     def fresh():
         return OUT.exists() and all(OUT.stat().st_mtime > d.stat().st_mtime for d in deps)
     if fresh() and not force:

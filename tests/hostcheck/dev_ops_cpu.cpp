@@ -22,8 +22,8 @@ static thread_local std::string g_err;
 void set_error(const std::string& m) { g_err = m; }
 const char* last_error() { return g_err.c_str(); }
 const char* dev_backend_name() { return "hostcheck"; }
-int g_gemm_force_cfg = -1;
-int g_gemm_splitk_enabled = 1;
+void dev_gemm_set_force_cfg(int) {}
+void dev_gemm_set_auto_splitk(int) {}
 
 int dev_init(int) { return 0; }
 int dev_sync() { return 0; }
@@ -47,6 +47,7 @@ int dev_timer_begin(int s) { g_t0[s] = std::chrono::steady_clock::now(); return 
 int dev_timer_end(int s) { g_tot[s] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - g_t0[s]).count(); g_cnt[s]++; return 0; }
 int dev_timer_read(int s, double* ms, int64_t* c) { if (ms) *ms = g_tot[s]; if (c) *c = g_cnt[s]; return 0; }
 int dev_timer_reset(int s) { g_tot[s] = 0; g_cnt[s] = 0; return 0; }
+int dev_timer_live_events(int) { return 0; }
 
 int dev_gemm_probe(const GemmDesc&, double*, double*, long long*) { set_error("dev_gemm_probe: not available in the hostcheck build"); return QEMB_ERR_DEVICE; }
 int dev_gemm(const GemmDesc& g) {

@@ -131,3 +131,83 @@ def test_degenerate_fragment_sizes(qlib, n, o, relax):
     assert np.abs(out["rdm1_emb"] - 0.5 * C @ dm1 @ C.T).max() < 1e-9
     e_ref = be.get_frag_energy(C, o, 1, (1.0, [0]), np.zeros((n, n)), h, dm1, g2, eri.pack_s4(e1), h, None, True)
     assert np.abs(np.array(out["e_frag"]) - np.array(e_ref)).max() < 1e-9
+
+
+def test_fragment_at_bench_tiles(qlib):
+    """n_occ = 20 (the benchmark's) with v = 64: the pp-ladder runs on the 224 x 128 / 192 x 128 tiles (GEMM configs 23 / 25: 210 and
+    190 packed pair rows, npair(v) = 2080 >= 2048 columns) and the t1 contractions on the 128 x 32 / 32 x 128 tiles (20 / 21) -- the
+    kernel instantiations the headline number is quoted on.  Expected values: the oracle's, stored once by
+    tests/golden/make_golden_frag84.py (several minutes of NumPy)."""
+    import sys
+    from helpers import GOLDEN
+    if str(GOLDEN) not in sys.path:
+        sys.path.insert(0, str(GOLDEN))
+    import make_golden_frag84 as mg
+    g = np.load(GOLDEN / "frag84.npz")
+    n, o, nf, cen = int(g["n"]), int(g["o"]), int(g["nf"]), [int(c) for c in g["cen"]]
+    assert (n, o, nf, int(g["seed"])) == (mg.N, mg.O, mg.NF, mg.SEED)
+    h, e1 = synthetic_fragment(n, o, int(g["seed"]))
+    h1, veff0, veff = mg.energy_data(n, n)
+    fr = DeviceFragment(n, nf)
+    fr.set_eri_s4(eri.pack_s4(e1))
+    fr.set_energy_data(h1, veff0, veff, 1.0, cen)
+    opts = default_opts(cc_conv_tol=1e-11, cc_conv_tol_normt=1e-9, scf_conv_tol=1e-12, scf_conv_tol_grad=1e-8)
+    out = fr.solve(o, h, opts=opts, eeval=True, want_t2=True)
+    assert abs(out["e_scf"] - float(g["e_scf"])) < TOL_E
+    assert np.abs(out["mo_energy"] - g["mo_energy"]).max() < 1e-7
+    assert abs(out["e_corr_mo"] - float(g["e_corr"])) < TOL_E, (out["e_corr_mo"], float(g["e_corr"]))
+    assert abs(out["n_iter"] - int(g["n_iter"])) <= 2
+    assert np.abs(out["rdm1_emb"] - g["rdm1_emb"]).max() < TOL_RDM
+    assert np.abs(np.array(out["e_frag"]) - g["e_frag"]).max() < TOL_E, (out["e_frag"], g["e_frag"])
+    assert abs(out["ebe_hf"] - float(g["ebe_hf"])) < TOL_E
+    assert abs(np.linalg.norm(out["t2"]) - float(g["t2_norm"])) < 1e-7
+    fr.free()
+
+
+@pytest.mark.parametrize("n,o", [(200, 80), (222, 150)])
+def test_mo_transform_at_bench_tile(qlib, n, o):
+    """192 < n <= 224: mo_transform (ccsd.cpp:48) runs its quarter transforms on the 224 x 128 tile (tcfg = 13), as at the benchmark's
+    n = 220.  The MO blocks exported from the device are compared with blocks assembled on the host from the density-fitting factor
+    of the synthetic fragment, (pq|rs) = sum_P B[P,p,q] B[P,r,s], rotated with the DEVICE's own orbitals (so that orbital phases and
+    rotations inside degenerate shells cannot enter)."""
+    from quemb_amd._lib import DeviceBuffer, check
+    rng = np.random.default_rng(n + o)
+    naux, v = 64, n - o
+    B = 0.03 * rng.standard_normal((naux, n, n)); B = 0.5 * (B + B.transpose(0, 2, 1))
+    il = np.tril_indices(n)
+    Bp = np.ascontiguousarray(B[:, il[0], il[1]])
+    npair = Bp.shape[1]
+    dB, d4 = DeviceBuffer.from_numpy(Bp), DeviceBuffer(npair * npair)
+    check(qlib.qemb_op_gemm(npair, npair, naux, 1.0, dB.ptr, npair, 0, 0, dB.ptr, npair, 0, 0, 0.0, d4.ptr, npair, 0, 1))
+    A = rng.standard_normal((n, n))
+    h = np.diag(0.5 * np.arange(n)) + 0.3 * 0.5 * (A + A.T)        # small gap: the orbitals mix strongly
+    fr = DeviceFragment(n, 8)
+    fr.set_eri_s4_dev(d4.ptr)
+    dB.free(); d4.free()
+    r = fr.scf(o, h, None)
+    assert r["converged"]
+    C = r["mo_coeff"]
+    fr.prepare_ccsd(o, h, 2.0 * C[:, :o] @ C[:, :o].T)
+    Bm = np.einsum("Ppq,pi,qj->Pij", B, C, C, optimize=True)
+    f = lambda x: np.ascontiguousarray(x).reshape(naux, -1)
+    Boo, Bov, Bvv = Bm[:, :o, :o], Bm[:, :o, o:], Bm[:, o:, o:]
+    tol = 1e-11
+    assert np.abs(fr.ccsd_export("oooo", (o, o, o, o)).reshape(o * o, -1) - f(Boo).T @ f(Boo)).max() < tol
+    assert np.abs(fr.ccsd_export("ovoo", (o, v, o, o)).reshape(o * v, -1) - f(Bov).T @ f(Boo)).max() < tol
+    assert np.abs(fr.ccsd_export("ovov", (o, v, o, v)).reshape(o * v, -1) - f(Bov).T @ f(Bov)).max() < tol
+    assert np.abs(fr.ccsd_export("ovvv", (o, v, v, v)).reshape(o * v, -1) - f(Bov).T @ f(Bvv)).max() < tol
+    assert np.abs(fr.ccsd_export("W1base", (o, v, o, v)) - (f(Bov).T @ f(Bov.transpose(0, 2, 1))).reshape(o, v, v, o).transpose(3, 2, 0, 1)).max() < tol
+    assert np.abs(fr.ccsd_export("W2base", (o, v, o, v)) - (f(Boo).T @ f(Bvv)).reshape(o, o, v, v).transpose(1, 2, 0, 3)).max() < tol
+    # (+/-) pair-packed ladder operands: Vp[P(ab),P(cd)] = (ac|bd) + (ad|bc), Vm[Q(ab),Q(cd)] = (ac|bd) - (ad|bc)
+    npv, nmv = v * (v + 1) // 2, v * (v - 1) // 2
+    ldp, ldm = npv + (npv & 1), max(nmv + (nmv & 1), 2)
+    Vp = fr.ccsd_export("Vp", (npv, ldp)); Vm = fr.ccsd_export("Vm", (max(nmv, 1), ldm))
+    vv = (f(Bvv).T @ f(Bvv)).reshape(v, v, v, v)             # (ab|cd) at [a,b,c,d]
+    Vac = vv.transpose(0, 2, 1, 3)                           # [a,b,c,d] = (ac|bd)
+    ilv, slv = np.tril_indices(v), np.tril_indices(v, -1)
+    assert np.abs(Vp[:, :npv] - (Vac + Vac.transpose(0, 1, 3, 2))[ilv[0], ilv[1]][:, ilv[0], ilv[1]]).max() < tol
+    assert np.abs(Vm[:, :nmv] - (Vac - Vac.transpose(0, 1, 3, 2))[slv[0], slv[1]][:, slv[0], slv[1]]).max() < tol
+    assert np.abs(fr.ccsd_export("Vl", (v, v, v, v)) - Vac).max() < tol
+    eo, ev = fr.ccsd_export("eo", (o,)), fr.ccsd_export("ev", (v,))
+    assert np.abs(np.concatenate([eo, ev]) - r["mo_energy"]).max() < 1e-9
+    fr.free()

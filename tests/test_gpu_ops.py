@@ -472,3 +472,129 @@ def test_gather_and_scale_rows(qlib):
         ref = x * sc[:, None]
     ref[1] = 0.0; ref[5] = 0.0
     assert np.array_equal(dx.numpy((6, 300)), ref)
+
+
+# ---- the tile configurations the headline benchmark runs on (BASELINE configs[2]: o = 20, v = 200) -----------------------------
+# cfg 13 / 23: 224 x 128 tile as 2 x 4 waves (7 x 2 MFMA tiles per wave) -- the (+) pair block of the pp-ladder (M = npair(20) = 210)
+#              and the K = n products of the MO transformation when 192 < n <= 224;
+# cfg 15 / 25: 192 x 128 tile (6 x 2 per wave) -- the (-) pair block (M = 190);
+# cfg 20 / 21: 128 x 32 / 32 x 128 tiles -- the products with an n_occ-sized side (ccsd.cpp:249).
+# 23 / 25 are 13 / 15 under the ladder's own kernel symbol (ccsd.cpp:217), i.e. separately compiled instantiations.
+@pytest.mark.parametrize("cfg,M", [(13, 210), (23, 210), (13, 224), (13, 220), (15, 190), (25, 190), (15, 192), (23, 97)])
+@pytest.mark.parametrize("a_kc,b_kc", [(1, 1), (1, 0), (0, 1), (0, 0)])
+@pytest.mark.parametrize("ks", [0, 8])
+def test_gemm_ladder_tile_configs(qlib, cfg, M, a_kc, b_kc, ks):
+    """bench-shaped products: one m-tile holding every packed pair row, N >= 2048 columns, long K (with a k-tail), split-K 0 / 8."""
+    rng = np.random.default_rng(1000 * cfg + M + 2 * a_kc + b_kc)
+    N, K = 2304 + 2 * (M % 7), 4100
+    A = rng.standard_normal((1, M, K)); B = rng.standard_normal((1, K, N)); C0 = rng.standard_normal((1, M, N))
+    qlib.qemb_set_gemm_ksplit(ks)
+    try:
+        got = _gemm(qlib, A, B, C0, 0.75, -0.5, a_kc, b_kc, cfg=cfg)
+        again = _gemm(qlib, A, B, C0, 0.75, -0.5, a_kc, b_kc, cfg=cfg)
+    finally:
+        qlib.qemb_set_gemm_ksplit(0)
+    ref = 0.75 * (A @ B) + -0.5 * C0
+    assert np.abs(got - ref).max() < 1e-12 * K, (cfg, M, a_kc, b_kc, ks, np.abs(got - ref).max())
+    assert np.array_equal(got, again), "split-K slab reduction must be run-to-run deterministic"
+
+
+@pytest.mark.parametrize("cfg,shape", [(13, (210, 2050, 1023)), (15, (190, 2049, 515)), (23, (210, 2049, 4097)), (25, (189, 2051, 4099))])
+@pytest.mark.parametrize("a_kc,b_kc", [(1, 1), (0, 0)])
+def test_gemm_ladder_tiles_scalar_load_variant(qlib, cfg, shape, a_kc, b_kc):
+    """odd extents / leading dimensions: the VEC = 1 instantiations of the same tiles (guarded scalar loads throughout)."""
+    M, N, K = shape
+    rng = np.random.default_rng(cfg * 31 + M + N + K)
+    A = rng.standard_normal((2, M, K)); B = rng.standard_normal((2, K, N)); C0 = rng.standard_normal((2, M, N))
+    got = _gemm(qlib, A, B, C0, 1.25, 0.5, a_kc, b_kc, cfg=cfg)
+    ref = 1.25 * np.einsum("bmk,bkn->bmn", A, B) + 0.5 * C0
+    assert np.abs(got - ref).max() < 1e-12 * K
+
+
+@pytest.mark.parametrize("cfg,shape", [(20, (8000, 20, 200)), (20, (4001, 32, 200)), (20, (8000, 20, 84000)), (20, (300, 7, 51)),
+                                       (21, (20, 8000, 200)), (21, (32, 4001, 200)), (21, (20, 200, 84000)), (21, (7, 300, 51))])
+@pytest.mark.parametrize("a_kc,b_kc", [(1, 1), (1, 0), (0, 1), (0, 0)])
+def test_gemm_skinny_tile_configs(qlib, cfg, shape, a_kc, b_kc):
+    """128 x 32 / 32 x 128 tiles of the t1 contractions (N or M = n_occ <= 32); the K = o v^2-long ones also split K."""
+    M, N, K = shape
+    rng = np.random.default_rng(cfg + M + 3 * N + 5 * K)
+    A = rng.standard_normal((1, M, K)); B = rng.standard_normal((1, K, N)); C0 = rng.standard_normal((1, M, N))
+    got = _gemm(qlib, A, B, C0, -1.0, 1.0, a_kc, b_kc, cfg=cfg)
+    ref = -(A @ B) + C0
+    assert np.abs(got - ref).max() < 1e-12 * max(K, 100)
+
+
+def test_gemm_skinny_batched_as_in_update_amps(qlib):
+    """the batched 32 x 128 call of ccsd.cpp (ZC[k,i,a,c] = t1[i,d] ovvv[k,d,a,c]): batch = o, shared A (stride 0)."""
+    o, v = 20, 64
+    rng = np.random.default_rng(3)
+    t1 = rng.standard_normal((o, v)); ovvv = rng.standard_normal((o, v, v * v))
+    dA, dB, dC = DeviceBuffer.from_numpy(t1), DeviceBuffer.from_numpy(ovvv), DeviceBuffer(o * o * v * v)
+    qlib.qemb_set_gemm_config(21)
+    try:
+        check(qlib.qemb_op_gemm(o, v * v, v, 1.0, dA.ptr, v, 1, 0, dB.ptr, v * v, 0, v * v * v, 0.0, dC.ptr, v * v, o * v * v, o))
+    finally:
+        qlib.qemb_set_gemm_config(-1)
+    ref = np.einsum("id,kdx->kix", t1, ovvv)
+    assert np.abs(dC.numpy((o, o, v * v)) - ref).max() < 1e-11
+
+
+@pytest.mark.parametrize("n,cfg", [(220, 13), (200, 13), (193, 13)])
+def test_gemm_mo_transform_products_at_bench_size(qlib, n, cfg):
+    """the two product shapes of mo_transform (ccsd.cpp:49-65) at 192 < n <= 224 with the 224 x 128 tile: the TN quarter transform
+    Out[x',(rest)] = C[x,x'] In[(rest),x] (M = K = n, N long) and the batched slab products (M = N = K = n, batch = pairs)."""
+    rng = np.random.default_rng(n)
+    ncol = 3000 + (n & 1)
+    Cm = rng.standard_normal((n, n)); X = rng.standard_normal((ncol, n))
+    dC, dX, dO = DeviceBuffer.from_numpy(Cm), DeviceBuffer.from_numpy(X), DeviceBuffer(n * ncol)
+    qlib.qemb_set_gemm_config(cfg)
+    try:
+        # A(m,k) = C[k*n + m] (not k-contiguous), B(k,nn) = X[nn*n + k] (k-contiguous)
+        check(qlib.qemb_op_gemm(n, ncol, n, 1.0, dC.ptr, n, 0, 0, dX.ptr, n, 1, 0, 0.0, dO.ptr, ncol, 0, 1))
+        assert np.abs(dO.numpy((n, ncol)) - Cm.T @ X.T).max() < 1e-11 * n
+        nb = 37
+        S = rng.standard_normal((nb, n, n))
+        dS, dR = DeviceBuffer.from_numpy(S), DeviceBuffer(nb * n * n)
+        check(qlib.qemb_op_gemm(n, n, n, 1.0, dS.ptr, n, 1, n * n, dC.ptr, n, 0, 0, 0.0, dR.ptr, n, n * n, nb))     # slab . C
+        assert np.abs(dR.numpy((nb, n, n)) - S @ Cm).max() < 1e-11 * n
+        check(qlib.qemb_op_gemm(n, n, n, 1.0, dC.ptr, n, 0, 0, dS.ptr, n, 0, n * n, 0.0, dR.ptr, n, n * n, nb))     # C^T . slab
+        assert np.abs(dR.numpy((nb, n, n)) - Cm.T @ S).max() < 1e-11 * n
+    finally:
+        qlib.qemb_set_gemm_config(-1)
+
+
+def test_pm_packed_ladder_at_bench_tiles(qlib):
+    """o = 20 with v = 66: npair(o) = 210 rows select the 224 x 128 tile (cfg 23), the 190 antisymmetric rows the 192 x 128 tile
+    (cfg 25), npair(v) = 2211 >= 2048 columns -- the dispatch of CcsdSolver::apply_ladder at the benchmark's o -- against the
+    dense sum_cd (ac|bd) tau_ijcd."""
+    o, v = 20, 66
+    rng = np.random.default_rng(o * 100 + v)
+    npv, nmv, npo, nmo = v * (v + 1) // 2, v * (v - 1) // 2, o * (o + 1) // 2, o * (o - 1) // 2
+    ldp, ldm = npv + (npv & 1), nmv + (nmv & 1)
+    Bv = rng.standard_normal((40, v, v)); Bv = Bv + Bv.transpose(0, 2, 1)
+    vv = np.einsum("Pac,Pbd->acbd", Bv, Bv, optimize=True)                   # (ac|bd) at [a,c,b,d]
+    tau = rng.standard_normal((o, o, v, v)); tau = tau + tau.transpose(1, 0, 3, 2)
+    il, sl = np.tril_indices(v), np.tril_indices(v, -1)
+    Vac = vv.transpose(0, 2, 1, 3)                                           # [a,b,c,d] = (ac|bd)
+    Vp = np.zeros((npv, ldp)); Vm = np.zeros((max(nmv, 1), ldm))
+    Vp[:, :npv] = (Vac + Vac.transpose(0, 1, 3, 2))[il[0], il[1]][:, il[0], il[1]]
+    Vm[:, :nmv] = (Vac - Vac.transpose(0, 1, 3, 2))[sl[0], sl[1]][:, sl[0], sl[1]]
+    dT = DeviceBuffer.from_numpy(tau)
+    dVp, dVm = DeviceBuffer.from_numpy(Vp), DeviceBuffer.from_numpy(Vm)
+    dTp, dTm = DeviceBuffer(npo * ldp), DeviceBuffer(nmo * ldm)
+    dRp, dRm = DeviceBuffer(npo * ldp), DeviceBuffer(nmo * ldm)
+    check(qlib.qemb_op_ladder_pack_tau(o, v, dT.ptr, dTp.ptr, ldp, dTm.ptr, ldm))
+    for cfg_p, cfg_m, ks in ((23, 25, 0), (23, 25, 8), (13, 15, 3)):
+        qlib.qemb_set_gemm_ksplit(ks)
+        try:
+            qlib.qemb_set_gemm_config(cfg_p)
+            check(qlib.qemb_op_gemm(npo, npv, ldp, 1.0, dTp.ptr, ldp, 1, 0, dVp.ptr, ldp, 1, 0, 0.0, dRp.ptr, ldp, 0, 1))
+            qlib.qemb_set_gemm_config(cfg_m)
+            check(qlib.qemb_op_gemm(nmo, nmv, ldm, 1.0, dTm.ptr, ldm, 1, 0, dVm.ptr, ldm, 1, 0, 0.0, dRm.ptr, ldm, 0, 1))
+        finally:
+            qlib.qemb_set_gemm_config(-1); qlib.qemb_set_gemm_ksplit(0)
+        t2 = rng.standard_normal((o, o, v, v))
+        d2 = DeviceBuffer.from_numpy(t2)
+        check(qlib.qemb_op_ladder_scatter_pm(o, v, dRp.ptr, ldp, dRm.ptr, ldm, d2.ptr))
+        ref = t2 + np.einsum("abcd,ijcd->ijab", Vac, tau, optimize=True)
+        assert np.abs(d2.numpy(t2.shape) - ref).max() < 1e-10 * np.abs(ref).max(), (cfg_p, cfg_m, ks)
