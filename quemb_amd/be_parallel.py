@@ -48,25 +48,50 @@ def fragment_cost(n, o):
     return float(o * o) * float(v) ** 4 + 4.0 * float(o * v) ** 3
 
 
-def all_reduce_sum(buf: np.ndarray, device=None):
-    """In-place sum over ranks of a float64 numpy buffer (no-op for a single process)."""
+class RankFailure(RuntimeError):
+    """Raised on EVERY rank when at least one rank failed while producing its share of an all-reduced buffer."""
+
+
+def all_reduce_sum(buf: np.ndarray, device=None, error: BaseException | None = None):
+    """In-place sum over ranks of a float64 numpy buffer (no-op for a single process).
+
+    `error` is the exception this rank caught while filling `buf` (None if it succeeded).  A fragment failure (SCF / CCSD
+    non-convergence, allocation failure, ...) is local to one rank; if that rank simply raised, the others would wait in the
+    collective forever.  So the failure count travels in one extra slot of the SAME all-reduce and every rank raises after it."""
     d = _dist()
     if d is None or d.get_world_size() == 1:
+        if error is not None:
+            raise error
         return buf
     import torch
+    ext = np.append(np.asarray(buf, dtype=np.float64).ravel(), 0.0 if error is None else 1.0)
+    if error is not None:
+        ext[:-1] = 0.0
     backend = d.get_backend()
     if backend == "nccl":
         if device is None:
             from . import _lib
             idx = _lib._initialised_device if _lib._initialised_device is not None else torch.cuda.current_device()
             device = torch.device("cuda", idx)
-        t = torch.from_numpy(buf).to(device)
+        t = torch.from_numpy(ext).to(device)
         d.all_reduce(t, op=d.ReduceOp.SUM)
-        buf[:] = t.cpu().numpy()
+        ext = t.cpu().numpy()
     else:
-        t = torch.from_numpy(buf)
+        t = torch.from_numpy(ext)
         d.all_reduce(t, op=d.ReduceOp.SUM)
+    nfail = int(round(ext[-1]))
+    if nfail:
+        msg = f"{nfail} of {d.get_world_size()} rank(s) failed in this step"
+        if error is not None:
+            raise RankFailure(f"{msg}; rank {d.get_rank()}: {error}") from error
+        raise RankFailure(msg + " (this rank succeeded)")
+    buf.reshape(-1)[:] = ext[:-1]
     return buf
+
+
+def all_reduce_bytes(n_values: int) -> int:
+    """bytes one rank contributes to the all-reduce of an n-value residual buffer (the values + the failure slot)"""
+    return 8 * (int(n_values) + 1)
 
 
 def be_func_parallel(pot, Fobjs, Nocc, solver, enuc, solver_args=None, scratch_dir=None, only_chem=False, eeval=False,
@@ -89,15 +114,21 @@ def be_func_parallel(pot, Fobjs, Nocc, solver, enuc, solver_args=None, scratch_d
         if pot is not None:
             f.update_heff(pot, only_chem=only_chem)
         return f.solve(opts=opts, eeval=eeval, use_cumulant=use_cumulant, relax_density=relax_density)
-    for out in map_fragments(one, [Fobjs[i] for i in mine], nstreams):
-        buf[2 * nm + 4] += out["n_iter"]
-        if eeval:
-            buf[2 * nm + 1: 2 * nm + 4] += out["e_frag"]
-    buf[2 * nm] = emap.fill(Fobjs, mine, buf[:nm], buf[nm:2 * nm])
-    all_reduce_sum(buf)
+    err = None
+    try:
+        for out in map_fragments(one, [Fobjs[i] for i in mine], nstreams):
+            buf[2 * nm + 4] += out["n_iter"]
+            if eeval:
+                buf[2 * nm + 1: 2 * nm + 4] += out["e_frag"]
+        buf[2 * nm] = emap.fill(Fobjs, mine, buf[:nm], buf[nm:2 * nm])
+    except Exception as e:  # noqa: BLE001 -- carried through the collective, re-raised on every rank
+        err = e
+    all_reduce_sum(buf, error=err)
     if stats is not None:
         stats["ccsd_iterations"] = stats.get("ccsd_iterations", 0) + int(round(buf[2 * nm + 4]))
         stats["fragments"] = stats.get("fragments", 0) + len(Fobjs)
+        stats["fragments_this_rank"] = len(mine)
+        stats["allreduce_bytes_per_sweep"] = all_reduce_bytes(len(buf))
     total_e = [float(x) for x in buf[2 * nm + 1: 2 * nm + 4]]
     Ecorr = sum(total_e)
     if eeval and not return_vec:

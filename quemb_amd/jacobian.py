@@ -65,20 +65,26 @@ def get_be_error_jacobian(n_frag, Fobjs, jac_solver="HF", *, owner=None, rank=0,
     ncouts = [sum(len(e) * (len(e) + 1) // 2 for e in f.relAO_per_edge) for f in Fobjs]
     norgs = [len([1 for j in f.relAO_per_origin for k in f.relAO_per_origin if j <= k]) for f in Fobjs]
     blocks = [None] * n_frag
-    for A in range(n_frag):
-        if owner is None or owner[A] == rank:
-            blocks[A] = jblock_frag(Fobjs[A], opts=opts)
+    err = None
+    try:
+        for A in range(n_frag):
+            if owner is None or owner[A] == rank:
+                blocks[A] = jblock_frag(Fobjs[A], opts=opts)
+    except Exception as e:  # noqa: BLE001 -- carried through the collective (be_parallel.all_reduce_sum)
+        if world == 1:
+            raise
+        err = e
     if world > 1:
         # pack (Je, Jc, xe, xc, y, alpha) of every fragment into one buffer, zeros where not owned
         sizes = [nc * nc + no * nc + nc + no + nc + 1 for nc, no in zip(ncouts, norgs)]
         buf = np.zeros(sum(sizes))
         off = 0
         for A in range(n_frag):
-            if blocks[A] is not None:
+            if blocks[A] is not None and err is None:
                 Je, Jc, xe, xc, y, al, _ = blocks[A]
                 buf[off: off + sizes[A]] = np.concatenate([Je.ravel(), Jc.ravel(), xe, xc, y, [al]])
             off += sizes[A]
-        all_reduce_sum(buf)
+        all_reduce_sum(buf, error=err)
         off = 0
         for A in range(n_frag):
             nc, no = ncouts[A], norgs[A]

@@ -160,18 +160,24 @@ class BE:
     def _initialize_fragments(self, idx):
         """mbe.py:1116-1180: h1, Fock, fragment SCF, dm0, fragment HF energies, HF-in-HF check."""
         E_hf = 0.0
-        for I in idx:
-            f = self.Fobjs[I]
-            f.h1 = f.TA.T @ self.hcore @ f.TA
-            f.cons_fock(self.hf_veff, self.S, self.hf_dm)
-            f.heff = np.zeros_like(f.h1)
-            f.scf(fs=True, opts=self.opts)
-            f.dm0 = 2.0 * f._mo_coeffs[:, : f.nsocc] @ f._mo_coeffs[:, : f.nsocc].T
-            f.update_ebe_hf()
-            E_hf += f.ebe_hf
+        err = None
+        try:
+            for I in idx:
+                f = self.Fobjs[I]
+                f.h1 = f.TA.T @ self.hcore @ f.TA
+                f.cons_fock(self.hf_veff, self.S, self.hf_dm)
+                f.heff = np.zeros_like(f.h1)
+                f.scf(fs=True, opts=self.opts)
+                f.dm0 = 2.0 * f._mo_coeffs[:, : f.nsocc] @ f._mo_coeffs[:, : f.nsocc].T
+                f.update_ebe_hf()
+                E_hf += f.ebe_hf
+        except Exception as e:  # noqa: BLE001 -- a failure on one rank must not leave the others waiting in the all-reduce
+            if self.world == 1:
+                raise
+            err = e
         buf = np.array([E_hf])
         if self.world > 1:
-            all_reduce_sum(buf)
+            all_reduce_sum(buf, error=err)
         self.ebe_hf = float(buf[0]) + self.enuc + self.E_core
         self.hf_err = self.hf_etot - self.ebe_hf
         if self.rank == 0:

@@ -65,20 +65,26 @@ def compute_numerical_jacobian(beobj, solver="CCSD", only_chem=False, nproc=1, s
     emap = beobj.emap if beobj.emap is not None else ErrorMap(beobj.Fobjs)
     nkpt = beobj.Fobjs[0].unitcell_nkpt
     cols = np.zeros((npot, npot))
-    for I in beobj.my_frags:
-        f = beobj.Fobjs[I]
-        for idx in range(f.udim, f.set_udim(f.udim)):
-            rd = []
-            for sgn in (+1.0, -1.0):
-                x = pot.copy(); x[idx] += sgn * step_size
-                out = f.dev.solve(f.nsocc, f.fock + calc_heff(f, x, only_chem), f.dm0, opts=opts, eeval=False)
-                rd.append(out["rdm1_emb"])
-            view = [None] * len(beobj.Fobjs)
-            view[I] = _Delta(rd[0] - rd[1])
-            edge = np.zeros(emap.n_match); cen = np.zeros(emap.n_match)
-            tr = emap.fill(view, [I], edge, cen) / nkpt
-            cols[:, idx] = (np.append(edge, tr) - np.append(cen, 0.0)) / (2 * step_size)
+    err = None
+    try:
+        for I in beobj.my_frags:
+            f = beobj.Fobjs[I]
+            for idx in range(f.udim, f.set_udim(f.udim)):
+                rd = []
+                for sgn in (+1.0, -1.0):
+                    x = pot.copy(); x[idx] += sgn * step_size
+                    out = f.dev.solve(f.nsocc, f.fock + calc_heff(f, x, only_chem), f.dm0, opts=opts, eeval=False)
+                    rd.append(out["rdm1_emb"])
+                view = [None] * len(beobj.Fobjs)
+                view[I] = _Delta(rd[0] - rd[1])
+                edge = np.zeros(emap.n_match); cen = np.zeros(emap.n_match)
+                tr = emap.fill(view, [I], edge, cen) / nkpt
+                cols[:, idx] = (np.append(edge, tr) - np.append(cen, 0.0)) / (2 * step_size)
+    except Exception as e:  # noqa: BLE001 -- carried through the collective (be_parallel.all_reduce_sum)
+        if beobj.world == 1:
+            raise
+        err = e
     if beobj.world > 1:
-        all_reduce_sum(cols)
+        all_reduce_sum(cols, error=err)
     J0[:, :-1] = cols[:, :-1]
     return J0
