@@ -7,12 +7,15 @@
 Workload (BASELINE.json configs[2], the one the metric's n_occ/n_virt and the 1/2/4/8-GPU scaling are quoted on;
 configs[1] -- octane BE2 -- is a parity case in tests/): F synthetic fragments PER GPU (weak scaling), each
 n = 220 embedding orbitals, n_occ = 20, n_virt = 200, DF-factorised 8-fold-symmetric ERIs (SURVEY.md 8d family,
-seed 20260803 + global fragment index; ERI scale 0.03), ERIs resident in HBM before timing.
+seed 20260803 + global fragment index; ERI scale 0.03 instead of 0.06), ERIs resident in HBM before timing.
 
-One STEP = one be_func sweep (one objective evaluation of the density-matching loop, molbe/solver.py:244) over the
-rank's fragments: per fragment  fragment RHF -> embedding->MO integral transform -> RCCSD to convergence ->
-1-RDM -> fragment energy;  then ONE all-reduce (RCCL) of the residual/energy buffer.  Nothing is cached between
-steps (amplitudes restart from MP2 exactly like the reference).
+One STEP = one objective evaluation of the density-matching loop through the PRODUCT sweep -- quemb_amd.solver.be_func
+(1 GPU) / quemb_amd.be_parallel.be_func_parallel (N GPUs), the mirrors of molbe/solver.py:244 and
+molbe/be_parallel.py:413 -- over `Frags` objects that are matched in a ring (edge AOs of fragment I against centre AOs
+of fragment I+1), so the residual buffer that is all-reduced is the real ErrorMap one.  Per fragment: update_heff ->
+fragment RHF -> embedding->MO integral transform -> RCCSD to convergence -> 1-RDM -> fragment energy; then ONE
+all-reduce (RCCL) of [edge values, centre values, sum centre diag, e1, e2, ec, n_iter, failure flag].  Nothing is cached
+between steps (amplitudes restart from MP2 exactly like the reference).
 value = CCSD iterations completed by all ranks in the K timed steps / wall time (max over ranks).
 """
 import argparse
@@ -33,7 +36,8 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 PEAK_FP64_MFMA_TFLOPS = 78.6     # MI355X FP64 matrix peak (AMD spec; == the FP64 vector peak). The MI355X guide
                                  # lists no f64 row; see DESIGN.md "Roofline".
 SEED0 = 20260803
-
+N_EDGE = 6                       # matched AOs per fragment of the synthetic ring (edge [0..5] <-> centre [6..11] of the next one)
+PMC_FILE = "profiles/r02_pmc_ladder.json"
 
 T_START = time.perf_counter()
 
@@ -50,22 +54,24 @@ def parse():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--frags-per-gpu", type=int, default=8)
-    ap.add_argument("--nstreams", type=int, default=1, help="fragments in flight per GPU (separate HIP streams); the default 1 keeps the "
-                    "ladder kernel's HIP-event / rocprofv3 durations uncontended")
+    ap.add_argument("--nstreams", type=int, default=3, help="fragments in flight per GPU (separate HIP streams, be_func(..., nstreams=k)); "
+                    "the roofline of the ladder kernel is measured in a separate single-stream pass after the timed region")
     ap.add_argument("--n", type=int, default=220)
     ap.add_argument("--nocc", type=int, default=20)
     ap.add_argument("--scale", type=float, default=0.03)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-iters", type=int, default=3, help="amplitude updates timed by the CPU baseline (about 4 s each on 16 threads)")
+    ap.add_argument("--cpu-iters", type=int, default=3, help="amplitude updates per worker timed by the CPU baseline")
+    ap.add_argument("--cpu-ompnum", type=int, default=4, help="BLAS threads per CPU worker (the reference's `ompnum`)")
     ap.add_argument("--cpu-worker", type=str, default=None, help=argparse.SUPPRESS)
-    ap.add_argument("--cpu-threads", type=int, default=16, help="BLAS threads of the CPU baseline (the box's CPU share of one GPU)")
+    ap.add_argument("--cpu-nproc", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--roofline-iters", type=int, default=8, help="single-stream CCSD iterations of the roofline pass")
     return ap.parse_args()
 
 
-def make_fragment(lib, n, nf, seed, scale):
-    """Synthetic fragment: h on the host, ERIs built on the device from the DF factor and left resident."""
+# ------------------------------------------------------------------------------------------------------------ workload
+def make_device_eris(lib, n, seed, scale):
+    """h (host) and the 4-fold packed ERIs built ON THE DEVICE from the DF factor of the synthetic family."""
     from quemb_amd._lib import DeviceBuffer, check
-    from quemb_amd.fragsolver import DeviceFragment
     rng = np.random.default_rng(seed)
     naux = 3 * n
     B = scale * rng.standard_normal((naux, n, n))
@@ -76,84 +82,156 @@ def make_fragment(lib, n, nf, seed, scale):
     dB = DeviceBuffer.from_numpy(Bp)
     d4 = DeviceBuffer(npair * npair)
     check(lib.qemb_op_gemm(npair, npair, naux, 1.0, dB.ptr, npair, 0, 0, dB.ptr, npair, 0, 0, 0.0, d4.ptr, npair, 0, 1))
+    dB.free()
     A = rng.standard_normal((n, n))
     h = np.diag(2.0 * np.arange(n)) + 0.3 * 0.5 * (A + A.T)
-    fr = DeviceFragment(n, nf)
-    fr.set_eri_s4_dev(d4.ptr)
-    dB.free(); d4.free()
     V = rng.standard_normal((n, n)); veff0 = 0.05 * (V + V.T)
-    fr.set_energy_data(h, veff0, None, 1.0, list(range(nf)))
-    return fr, h, B
+    return h, veff0, d4
 
 
-def read_timer(lib, slot, nctx=1):
+def make_ring(lib, n, o, nf, F_total, owner, rank, scale, opts):
+    """The fragment objects of the sweep: `quemb_amd.pfrag.Frags`, the mirror of molbe/pfrag.py:38.  Every rank holds the (light)
+    host objects of all fragments -- be_func_parallel's contract -- and the device state (ERIs in HBM, Fock, dm0) of its own."""
+    from quemb_amd.fragsolver import DeviceFragment
+    from quemb_amd.pfrag import Frags
+    edge, cen = list(range(N_EDGE)), list(range(N_EDGE, 2 * N_EDGE))
+    frs = []
+    for I in range(F_total):
+        f = Frags(list(range(nf)), I, [edge], [(I + 1) % F_total], [edge], [cen], (1.0, cen), cen, lib=lib)
+        f.nao, f.nsocc = n, o
+        if owner[I] == rank:
+            h, veff0, d4 = make_device_eris(lib, n, SEED0 + I, scale)
+            f.dev = DeviceFragment(n, nf, lib=lib)
+            f.dev.set_eri_s4_dev(d4.ptr); d4.free()
+            f.h1, f.veff0, f.veff, f.fock, f.heff = h, veff0, None, h, np.zeros((n, n))
+            r = f.dev.scf(o, h, None, opts=opts)        # BE.initialize does the same (Frags.scf(fs=True), mbe.py:1160)
+            f._mo_coeffs = r["mo_coeff"]
+            f.dm0 = 2.0 * r["mo_coeff"][:, :o] @ r["mo_coeff"][:, :o].T
+        frs.append(f)
+    c = 0
+    for f in frs:
+        f.udim = c
+        c = f.set_udim(c)
+    return frs, c + 1
+
+
+def read_timer(lib, slot, nctx=1, reset=0):
     """device timer `slot` summed over the execution contexts 0..nctx-1"""
     tot, n = 0.0, 0
     for k in range(nctx):
         ms = C.c_double(); cnt = C.c_int64()
-        lib.qemb_ctx_timer_read(k, slot, C.byref(ms), C.byref(cnt), 0)
+        lib.qemb_ctx_timer_read(k, slot, C.byref(ms), C.byref(cnt), reset)
         tot += ms.value; n += cnt.value
     return tot, n
 
 
-def cpu_baseline(fr, h, dm0, o, opts, iters, threads, timeout_s=300):
-    """The oracle ('port') on the host cores, timed on a bounded sample of the SAME workload: fragment 0 of this rank,
-    its MO integrals exported from the device (so no CPU time goes into re-deriving inputs), `iters` full RCCSD
-    amplitude updates (oracle/qemb_oracle/ccsd_lean.py, NumPy/BLAS) starting from the MP2 guess.  Runs in a child
-    process with the BLAS thread count pinned through the environment and a hard timeout."""
+# ------------------------------------------------------------------------------------------------------------ CPU baseline
+def usable_cores():
+    """host cores this process may use: scheduler affinity, capped by the cgroup CPU quota when there is one"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(p) + 0.5)))
+    except Exception:  # noqa: BLE001
+        pass
+    return n
+
+
+def cpu_baseline(fr, h, dm0, o, opts, iters, ompnum, timeout_s=420):
+    """QuEmb's own CPU shape (molbe/be_parallel.py:484-513: a pool of nproc = cores // ompnum worker processes, OMP_NUM_THREADS =
+    ompnum each, one fragment per worker at a time) with the oracle ('port': oracle/qemb_oracle/ccsd_lean.py, NumPy/BLAS) as the
+    per-fragment solver, timed on a BOUNDED sample of the same workload: every worker runs `iters` full RCCSD amplitude updates of
+    fragment 0 of this rank from the MP2 guess (the fragments of the sweep are statistically identical; the MO integrals are
+    exported from the device once and shared through /dev/shm so no CPU time goes into re-deriving inputs).
+    Also returns the device's energy after the SAME `iters` plain (no DIIS) updates for the full-size parity field."""
     import shutil
     import subprocess
     import tempfile
     n = fr.n
     v = n - o
     fr.prepare_ccsd(o, h, dm0, opts=opts)
+    e_dev, _ = fr.ccsd_iterate(iters)          # plain Jacobi updates from the MP2 guess (no DIIS outside CcsdSolver::kernel)
     shapes = dict(oooo=(o, o, o, o), ovoo=(o, v, o, o), ovov=(o, v, o, v), ovvv=(o, v, v, v), Vl=(v, v, v, v),
                   W1base=(o, v, o, v), W2base=(o, v, o, v), eo=(o,), ev=(v,))
+    cores = usable_cores()
+    nproc = max(1, cores // ompnum)
     base = "/dev/shm" if os.path.isdir("/dev/shm") else None
     d = tempfile.mkdtemp(prefix="qemb_bench_", dir=base)
+    info = dict(unit="CCSD iterations/s", cores=cores, os_cpu_count=os.cpu_count(), nproc=nproc, ompnum=ompnum, kind="port")
     try:
         for name, shp in shapes.items():
             np.save(os.path.join(d, name + ".npy"), fr.ccsd_export(name, shp))
-        log(f"cpu_baseline: integrals exported to {d}; running {iters} amplitude update(s) on {threads} threads")
-        env = dict(os.environ, OMP_NUM_THREADS=str(threads), OPENBLAS_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads))
-        p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--cpu-worker", d, "--cpu-iters", str(iters), "--nocc", str(o)],
-                           env=env, capture_output=True, text=True, timeout=timeout_s)
+        log(f"cpu_baseline: integrals exported to {d}; pool of {nproc} worker(s) x {ompnum} thread(s), {iters} amplitude update(s) each")
+        env = dict(os.environ, OMP_NUM_THREADS=str(ompnum), OPENBLAS_NUM_THREADS=str(ompnum), MKL_NUM_THREADS=str(ompnum))
+        p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--cpu-worker", d, "--cpu-iters", str(iters), "--nocc", str(o),
+                            "--cpu-nproc", str(nproc)], env=env, capture_output=True, text=True, timeout=timeout_s)
         if p.returncode != 0:
-            return dict(value=None, unit="CCSD iterations/s", cores=threads, kind="port", sample=f"worker failed: {p.stderr[-400:]}")
+            info.update(value=None, sample=f"worker failed: {p.stderr[-400:]}")
+            return info, e_dev, None
         r = json.loads(p.stdout.strip().splitlines()[-1])
-        return dict(value=1.0 / r["s_per_iteration"], unit="CCSD iterations/s", cores=threads, kind="port",
-                    sample=f"fragment 0 of the timed workload (n_occ={o}, n_virt={v}); MO integrals exported from the device; "
-                           f"{iters} full RCCSD amplitude update(s) from the MP2 guess by oracle/qemb_oracle/ccsd_lean.py (NumPy/BLAS, {threads} threads)",
-                    s_per_iteration=r["s_per_iteration"], e_corr_after_sample=r["e_corr"])
+        info.update(value=r["iterations_per_s"],
+                    sample=f"fragment 0 of the timed workload (n_occ={o}, n_virt={v}), MO integrals exported from the device and shared; "
+                           f"{nproc} worker processes x {iters} full RCCSD amplitude updates each from the MP2 guess "
+                           f"(oracle/qemb_oracle/ccsd_lean.py, NumPy/BLAS, OMP_NUM_THREADS={ompnum}); value = all updates / slowest worker's time",
+                    s_per_iteration_per_worker=r["s_per_iteration_per_worker"], pool_wall_s=r["pool_wall_s"],
+                    e_corr_after_sample=r["e_corr"])
+        # second figure: ONE process with every core as BLAS threads (round 1's baseline)
+        env1 = dict(os.environ, OMP_NUM_THREADS=str(cores), OPENBLAS_NUM_THREADS=str(cores), MKL_NUM_THREADS=str(cores))
+        p1 = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--cpu-worker", d, "--cpu-iters", str(max(1, iters - 1)), "--nocc", str(o),
+                             "--cpu-nproc", "1"], env=env1, capture_output=True, text=True, timeout=timeout_s)
+        if p1.returncode == 0:
+            r1 = json.loads(p1.stdout.strip().splitlines()[-1])
+            info["single_process_all_threads"] = dict(value=r1["iterations_per_s"], threads=cores, s_per_iteration=r1["s_per_iteration_per_worker"])
+        return info, e_dev, r["e_corr"]
     except subprocess.TimeoutExpired:
-        return dict(value=None, unit="CCSD iterations/s", cores=threads, kind="port", sample=f"worker exceeded {timeout_s} s")
+        info.update(value=None, sample=f"worker exceeded {timeout_s} s")
+        return info, e_dev, None
     finally:
         shutil.rmtree(d, ignore_errors=True)
 
 
-def cpu_worker(d, o, iters):
-    """child process of cpu_baseline: load the exported blocks, time the oracle's amplitude update."""
+def _cpu_pool_task(args):
+    """one worker of the CPU pool: `iters` amplitude updates of the exported fragment (blocks memory-mapped from /dev/shm)"""
+    d, o, iters = args
     sys.path.insert(0, str(ROOT / "oracle"))
     from qemb_oracle import ccsd_lean
-    ld = lambda nm: np.load(os.path.join(d, nm + ".npy"))
-    eo, ev = ld("eo"), ld("ev")
+    ld = lambda nm: np.load(os.path.join(d, nm + ".npy"), mmap_mode="r")
+    eo, ev = np.array(ld("eo")), np.array(ld("ev"))
     W1, W2 = ld("W1base"), ld("W2base")
     ovvo = np.ascontiguousarray(W1.transpose(2, 3, 1, 0))     # ovvo[k,c,a,i] = W1base[i,a,k,c]
     oovv = np.ascontiguousarray(W2.transpose(2, 0, 1, 3))     # oovv[k,i,a,c] = W2base[i,a,k,c]
-    er = ccsd_lean.LeanEris.from_blocks(o, np.concatenate([eo, ev]), ld("oooo"), ld("ovoo"), ld("ovov"), oovv, ovvo, ld("ovvv"), ld("Vl"))
+    er = ccsd_lean.LeanEris.from_blocks(o, np.concatenate([eo, ev]), np.array(ld("oooo")), np.array(ld("ovoo")), np.array(ld("ovov")),
+                                        oovv, ovvo, ld("ovvv"), ld("Vl"))
     eia = eo[:, None] - ev[None, :]
     t1 = np.zeros((o, len(ev))); t2 = er.ovov.transpose(0, 2, 1, 3) / (eia[:, None, :, None] + eia[None, :, None, :])
     t0 = time.perf_counter()
     for _ in range(iters):
         t1, t2 = ccsd_lean.update_amps(t1, t2, er)
-    dt = (time.perf_counter() - t0) / iters
+    dt = time.perf_counter() - t0
     tau = t2 + np.einsum("ia,jb->ijab", t1, t1)
     e = float(np.sum((2 * er.ovov.transpose(0, 2, 1, 3) - er.ovov.transpose(0, 2, 3, 1)) * tau))
-    print(json.dumps(dict(s_per_iteration=dt, e_corr=e)), flush=True)
+    return dt, e
 
 
+def cpu_worker(d, o, iters, nproc):
+    """child process of cpu_baseline (never touches the GPU): runs the worker pool and prints one JSON line"""
+    import multiprocessing as mp
+    t0 = time.perf_counter()
+    if nproc <= 1:
+        res = [_cpu_pool_task((d, o, iters))]
+    else:
+        with mp.get_context("spawn").Pool(nproc) as pool:
+            res = pool.map(_cpu_pool_task, [(d, o, iters)] * nproc, chunksize=1)
+    wall = time.perf_counter() - t0
+    slowest = max(r[0] for r in res)
+    print(json.dumps(dict(iterations_per_s=len(res) * iters / slowest, s_per_iteration_per_worker=slowest / iters, pool_wall_s=wall,
+                          e_corr=res[0][1])), flush=True)
+
+
+# ------------------------------------------------------------------------------------------------------------ probes
 def parity_probe():
-    """corr-E error vs the oracle on a small fragment of the same family (the metric's second half)."""
+    """corr-E error vs the oracle on a small fragment of the same family (the full solve: SCF + CCSD to convergence)."""
     sys.path.insert(0, str(ROOT / "oracle")); sys.path.insert(0, str(ROOT / "tests"))
     from helpers import synthetic_fragment
     from qemb_oracle import ccsd, eri, scf
@@ -186,10 +264,35 @@ def clock_probe(lib):
     return dict(ghz=ghz, ms=ms, workgroups=wg, tflops=2.0 * M * N * K / (ms * 1e9))
 
 
+def mfma_peak_probe(lib):
+    """register-only v_mfma_f64_16x16x4_f64 loop, 16 independent accumulator chains per wave, 2 waves per SIMD (gemm_f64.hip)"""
+    t = C.c_double()
+    best = 0.0
+    for _ in range(3):
+        if lib.qemb_mfma_f64_peak(40000, 2, C.byref(t)) == 0:
+            best = max(best, t.value)
+    return best
+
+
+def roofline_pass(lib, fr, h, dm0, o, opts, iters):
+    """The dominant kernel on its own: one fragment, ONE stream, `iters` CCSD iterations with the ladder bracketed by HIP events on the
+    stream it is launched on (QEMB_TIMER_LADDER).  Separate from the timed region, where several fragments share the device."""
+    for s in (0, 1, 2):
+        lib.qemb_ctx_timer_read(0, s, None, None, 1)
+    fr.prepare_ccsd(o, h, dm0, opts=opts)
+    fr.ccsd_iterate(2)
+    for s in (0, 1, 2):
+        lib.qemb_ctx_timer_read(0, s, None, None, 1)
+    fr.ccsd_iterate(iters)
+    lad = read_timer(lib, 0, 1); ring = read_timer(lib, 1, 1); it = read_timer(lib, 2, 1)
+    return dict(ladder_ms=lad[0] / max(lad[1], 1), ladder_count=lad[1], rings_ms=ring[0] / max(ring[1], 1), iter_ms=it[0] / max(it[1], 1))
+
+
+# ------------------------------------------------------------------------------------------------------------ main
 def main():
     args = parse()
     if args.cpu_worker:
-        return cpu_worker(args.cpu_worker, args.nocc, args.cpu_iters)
+        return cpu_worker(args.cpu_worker, args.nocc, args.cpu_iters, args.cpu_nproc)
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); lrank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     dist = None
@@ -199,129 +302,135 @@ def main():
     lrank = lrank % ndev
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(lrank)
+        if backend == "nccl" or torch.cuda.is_available():
+            torch.cuda.set_device(lrank)
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", lrank))
         else:
             dist.init_process_group(backend=backend)
     from quemb_amd import _lib
+    from quemb_amd.be_parallel import be_func_parallel, fragment_cost, partition_fragments
     from quemb_amd.fragsolver import default_opts
+    from quemb_amd.solver import ErrorMap, be_func
     lib = _lib.init(lrank)
     n, o, F = args.n, args.nocc, args.frags_per_gpu
     v = n - o
     nf = min(22, n // 2)
+    if nf < 2 * N_EDGE:
+        raise SystemExit(f"--n {n}: the synthetic ring needs at least {2 * N_EDGE} fragment sites (n >= {4 * N_EDGE})")
     opts = default_opts()
+    F_total = F * world
+    owner = partition_fragments([fragment_cost(n, o)] * F_total, world)     # the product's LPT partition (equal costs: F per rank)
 
     # ---- set-up (untimed): fragments resident in HBM, initial fragment SCF for dm0 (BE.initialize does the same)
-    frs = []
-    log(f"setting up {F} fragments per GPU (n={n}, n_occ={o})")
-    for i in range(F):
-        fr, h, _ = make_fragment(lib, n, nf, SEED0 + rank * F + i, args.scale)
-        r = fr.scf(o, h, None, opts=opts)
-        dm0 = 2.0 * r["mo_coeff"][:, :o] @ r["mo_coeff"][:, :o].T
-        frs.append((fr, h, dm0))
+    log(f"setting up {F} fragments per GPU (n={n}, n_occ={o}), {F_total} in the ring")
+    frs, npot = make_ring(lib, n, o, nf, F_total, owner, rank, args.scale, opts)
+    mine = [i for i in range(F_total) if owner[i] == rank]
+    emap = ErrorMap(frs)
+    pot = [0.0] * npot
+    Nocc = float(F_total * N_EDGE) * 1.0
     sync = torch.cuda.synchronize if torch.cuda.is_available() else (lambda: None)
-
-    comm_dev = torch.device("cuda", lrank) if backend == "nccl" else torch.device("cpu")
-    buf_t = torch.zeros(8, dtype=torch.float64, device=comm_dev) if world > 1 else None
-
-    nctx = 1
-    pool = None
-    if args.nstreams > 1:      # be_func(..., nstreams=k): worker threads, each bound to its own execution context (HIP stream)
-        import queue
-        from concurrent.futures import ThreadPoolExecutor
-        from quemb_amd._lib import check
-        nctx = lib.qemb_ctx_count(args.nstreams + 1)
-        ids = queue.Queue()
-        for k in range(1, args.nstreams + 1):
-            ids.put(k)
-        pool = ThreadPoolExecutor(max_workers=args.nstreams, initializer=lambda: check(lib.qemb_ctx_bind(ids.get()), "qemb_ctx_bind", lib))
-
-    def one(t):
-        fr, h, dm0 = t
-        return fr.solve(o, h, dm0, opts=opts, eeval=True)
+    nctx = lib.qemb_ctx_count(args.nstreams + 1) if args.nstreams > 1 else 1
+    stats = {}
 
     def sweep():
-        acc = np.zeros(8)
-        for out in (pool.map(one, frs) if pool else map(one, frs)):
-            acc[0] += out["n_iter"]; acc[1:4] += out["e_frag"]; acc[4] += np.trace(out["rdm1_emb"][:nf, :nf]); acc[5] += out["e_corr_mo"]; acc[6] += 1
-        if world > 1:      # the one exchange of a sweep: residual/energy buffer, RCCL sum-all-reduce
-            buf_t.copy_(torch.from_numpy(acc))
-            dist.all_reduce(buf_t, op=dist.ReduceOp.SUM)
-            acc = buf_t.cpu().numpy()
-        return acc
+        """one objective evaluation through the product sweep; returns the residual norm and the energies"""
+        if world > 1:
+            return be_func_parallel(pot, frs, Nocc, "CCSD", 0.0, eeval=True, return_vec=True, owner=owner, opts=opts, stats=stats, emap=emap,
+                                    nstreams=args.nstreams)
+        return be_func(pot, frs, Nocc, "CCSD", 0.0, eeval=True, return_vec=True, opts=opts, stats=stats, nstreams=args.nstreams)
 
     log("fragments resident; warm-up sweeps")
     for _ in range(args.warmup):
         sweep()
     log("timed sweeps")
     for s in range(8):
-        for k in range(nctx):
-            lib.qemb_ctx_timer_read(k, s, None, None, 1)
+        read_timer(lib, s, nctx, reset=1)
+    stats.clear()
     if world > 1:
         dist.barrier()
     lib.qemb_sync(); sync()
     t0 = time.perf_counter()
-    tot = np.zeros(8)
+    ecorr_sum = 0.0
     for _ in range(args.steps):
-        tot += sweep()
+        ernorm, ervec, (ecorr, _) = sweep()
+        ecorr_sum += ecorr
     lib.qemb_sync(); sync()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
+        comm_dev = torch.device("cuda", lrank) if backend == "nccl" else torch.device("cpu")
         tt = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    else:
-        pass
-    # `tot` is already summed over ranks inside sweep() when world > 1
-    n_iter_total = float(tot[0]); n_frag_total = float(tot[6])
+    # stats["ccsd_iterations"] is summed over ranks inside the sweep's all-reduce when world > 1
+    n_iter_total = float(stats.get("ccsd_iterations", 0)); n_frag_total = float(stats.get("fragments", 0))
 
     log(f"timed region done: {dt:.2f} s for {args.steps} step(s)")
     if rank == 0:
-        lad_ms, lad_cnt = read_timer(lib, 0, nctx)
         it_ms, it_cnt = read_timer(lib, 2, nctx)
         ao_ms, ao_cnt = read_timer(lib, 3, nctx)
         scf_ms, scf_cnt = read_timer(lib, 4, nctx)
         ring_ms, ring_cnt = read_timer(lib, 1, nctx)
-        lad_avg = lad_ms / max(lad_cnt, 1) * 1e-3
+        lad_ms_c, lad_cnt_c = read_timer(lib, 0, nctx)
+        fr0 = frs[mine[0]]
+        h0, dm00 = fr0.fock, fr0.dm0
+        log("roofline pass: one fragment, one stream")
+        rp = roofline_pass(lib, fr0.dev, h0, dm00, o, opts, args.roofline_iters)
+        lad_avg = rp["ladder_ms"] * 1e-3
         npair_o = o * (o + 1) // 2
         npv, nmv, nmo = v * (v + 1) // 2, v * (v - 1) // 2, o * (o - 1) // 2
         flop_ladder = 2.0 * npair_o * float(npv) ** 2 + 2.0 * nmo * float(nmv) ** 2   # executed: (+/-) pair-packed products
         flop_dense = 2.0 * o * o * float(v) ** 4                 # SURVEY 8(d) dense-equivalent figure
         achieved = flop_ladder / lad_avg / 1e12 if lad_avg > 0 else 0.0
-        traffic = None                                           # HBM bytes per launch from the separate --pmc passes
-        pmc = ROOT / "profiles" / "r01_pmc_ladder.json"
-        if pmc.exists():
-            try:
-                traffic = json.loads(pmc.read_text()).get("hbm_bytes_per_launch")
-            except Exception:  # noqa: BLE001
-                traffic = None
+        traffic, traffic_source = None, None                     # HBM bytes per launch from the separate --pmc passes
+        for cand in (PMC_FILE, "profiles/r01_pmc_ladder.json"):
+            pmc = ROOT / cand
+            if pmc.exists():
+                try:
+                    traffic = json.loads(pmc.read_text()).get("hbm_bytes_per_launch")
+                    traffic_source = f"{cand}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over tools/frag_bench.py (tools/pmc_ladder.sh), NOT collected in this run"
+                    break
+                except Exception:  # noqa: BLE001
+                    traffic = None
         res = {
-            "metric": "fragment CCSD iters/sec (full BE sweep over synthetic n_occ=20 n_virt=200 fragments); corr-E error vs oracle in parity_max_abs_err_Eh",
+            "metric": "fragment CCSD iters/sec (full BE sweep over synthetic n_occ=20 n_virt=200 fragments); corr-E error vs oracle in parity_max_abs_err_Eh / parity_n220_abs_err_Eh",
             "value": n_iter_total / dt, "unit": "CCSD iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[2]: synthetic fragment sweep, {F} fragments per GPU ({F * world} total), "
-                                   f"n_occ={o} n_virt={v} (n={n}), DF-factorised ERIs naux={3 * n} scale={args.scale}, "
-                                   "one be_func sweep per step (fragment RHF + MO transform + RCCSD to |dE|<1e-10 + energies + 1 all-reduce)",
-                       "fragments_per_gpu": F, "n_occ": o, "n_virt": v, "fragments_in_flight_per_gpu": args.nstreams, "parallelism": f"fragments sharded over {world} GPU(s), 1 RCCL all-reduce per sweep"},
+            "config": {"workload": f"BASELINE configs[2]: synthetic fragment sweep, {F} fragments per GPU ({F_total} total), "
+                                   f"n_occ={o} n_virt={v} (n={n}), DF-factorised ERIs naux={3 * n}, ERI scale={args.scale} (SURVEY 8d says 0.06: the oracle's "
+                                   "own RHF/CCSD diverges there for n > ~100, DESIGN.md), one be_func / be_func_parallel sweep per step "
+                                   "(update_heff + fragment RHF + MO transform + RCCSD to |dE|<1e-10 + 1-RDM + energies per fragment, solve_error, 1 all-reduce)",
+                       "fragments_per_gpu": F, "n_occ": o, "n_virt": v, "fragments_in_flight_per_gpu": args.nstreams,
+                       "parallelism": f"fragments sharded over {world} GPU(s) by the LPT partition, 1 RCCL all-reduce per sweep",
+                       "fragments_per_rank": [owner.count(r) for r in range(world)],
+                       "allreduce_bytes_per_sweep": stats.get("allreduce_bytes_per_sweep", 0 if world == 1 else None),
+                       "residual_slots": int(2 * emap.n_match + 5)},
             "fragments_per_s": n_frag_total / dt,
             "ccsd_iterations_per_fragment": n_iter_total / max(n_frag_total, 1),
-            "mean_e_corr_per_fragment": float(tot[5]) / max(n_frag_total, 1),
+            "mean_e_corr_per_sweep": ecorr_sum / args.steps,
+            "residual_norm": float(ernorm),
             "roofline": {"bound": "mfma", "kernel": "dgemm_mfma_kernel<7,2,2,4,16,true,true,2,1> (+ pairs, 224x128 tile) and <6,2,2,4,16,true,true,2,1> (- pairs, 192x128): pp-ladder over (+/-) packed pairs, M=npair(o) N=K=npair(v), split-K + slab reduce",
                          "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_MFMA_TFLOPS,
                          # one pp-ladder = TWO dispatches of this kernel ((+) and (-) pair blocks); per-dispatch averages:
-                         "traffic": None if traffic is None else traffic / 2.0, "avg_launch_ms": lad_avg * 1e3 / 2.0,
-                         "launches": 2 * lad_cnt, "flop_per_launch": flop_ladder / 2.0, "ladder_ms": lad_avg * 1e3,
+                         "traffic": None if traffic is None else traffic / 2.0, "traffic_source": traffic_source,
+                         "avg_launch_ms": lad_avg * 1e3 / 2.0, "launches": 2 * rp["ladder_count"],
+                         "measured": f"HIP events on the launch stream around the two ladder dispatches (+ their slab reductions) in a separate single-stream pass of {args.roofline_iters} CCSD iterations on fragment 0 right after the timed region",
+                         "flop_per_launch": flop_ladder / 2.0, "ladder_ms": lad_avg * 1e3,
                          "dense_equivalent_tflops": flop_dense / lad_avg / 1e12 if lad_avg > 0 else 0.0,
-                         "algorithmic_bytes_per_launch": 4.0 * (float(npv) ** 2 + float(nmv) ** 2 + 2.0 * npair_o * npv + 2.0 * nmo * nmv)},
-            "device_time_ms_rank0": {"ccsd_iteration_avg": it_ms / max(it_cnt, 1), "ccsd_iterations": it_cnt, "rings_avg": ring_ms / max(ring_cnt, 1),
+                         "algorithmic_bytes_per_launch": 4.0 * (float(npv) ** 2 + float(nmv) ** 2 + 2.0 * npair_o * npv + 2.0 * nmo * nmv),
+                         "ladder_ms_in_timed_region": lad_ms_c / max(lad_cnt_c, 1),
+                         "single_stream_iteration_ms": rp["iter_ms"], "single_stream_rings_ms": rp["rings_ms"]},
+            "device_time_ms_rank0": {"note": f"HIP-event brackets inside the timed region; with {args.nstreams} fragment(s) in flight the brackets of different streams overlap",
+                                     "ccsd_iteration_avg": it_ms / max(it_cnt, 1), "ccsd_iterations": it_cnt, "rings_avg": ring_ms / max(ring_cnt, 1),
                                      "mo_transform_avg": ao_ms / max(ao_cnt, 1), "fragment_scf_avg": scf_ms / max(scf_cnt, 1)},
         }
         if world == 1:
             try:
+                res["roofline"]["peak_measured"] = mfma_peak_probe(lib)
+                res["roofline"]["peak_measured_how"] = "register-only v_mfma_f64_16x16x4_f64 loop, 16 independent accumulator chains per wave, 8 waves per CU (qemb_mfma_f64_peak)"
                 cp = clock_probe(lib)
                 clk = cp["ghz"]
                 res["roofline"].update({"sustained_clock_ghz": clk, "peak_at_sustained_clock": PEAK_FP64_MFMA_TFLOPS * clk / 2.4,
@@ -337,8 +446,12 @@ def main():
             except Exception as e:  # noqa: BLE001
                 res["parity_max_abs_err_Eh"] = f"probe failed: {e}"
             if not args.no_cpu_baseline:
-                fr0, h0, dm00 = frs[0]
-                res["cpu_baseline"] = cpu_baseline(fr0, h0, dm00, o, opts, args.cpu_iters, args.cpu_threads)
+                info, e_dev, e_cpu = cpu_baseline(fr0.dev, h0, dm00, o, opts, args.cpu_iters, args.cpu_ompnum)
+                res["cpu_baseline"] = info
+                # full-size parity: the device and the oracle run the SAME args.cpu_iters plain amplitude updates on the same n = 220 fragment
+                res["parity_n220_abs_err_Eh"] = None if e_cpu is None else abs(e_dev - e_cpu)
+                res["parity_n220"] = dict(e_corr_device=e_dev, e_corr_oracle=e_cpu, updates=args.cpu_iters,
+                                          what="E_corr after the same number of plain (no DIIS) RCCSD amplitude updates from the MP2 guess, fragment 0 (n=220): device vs oracle/qemb_oracle/ccsd_lean.py on the device-exported MO integrals")
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

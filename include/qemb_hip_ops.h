@@ -114,7 +114,7 @@ int qemb_frag_prepare_ccsd(qemb_frag_t f, int nsocc, const double* h, const doub
 int qemb_frag_ccsd_iterate(qemb_frag_t f, int niter, double* e_corr, double* normt);
 int qemb_frag_ccsd_reset(qemb_frag_t f);
 /* copy one MO-integral block of the prepared CCSD problem to the host: "oooo" "ovoo" "ovov" "ovvv" "Vl" (= (ac|bd) at
- * [a,b,c,d]) "W1base" (= ovvo[k,c,a,i] at [i,a,k,c]) "W2base" (= oovv[k,i,a,c] at [i,a,k,c]) "eo" "ev"                     */
+ * [a,b,c,d]) "W1base" (= ovvo[k,c,a,i] at [i,a,k,c]) "W2base" (= oovv[k,i,a,c] at [i,a,k,c]) "eo" "ev" "Vp" "Vm" ((+/-) pair-packed ladder operands) "mo_coeff" (n x n)                     */
 int qemb_frag_ccsd_export(qemb_frag_t f, const char* name, double* host, int64_t nelem);
 
 

@@ -1,6 +1,7 @@
 // fragment.h -- one embedded fragment resident on the device and the body of the fragment sweep
 // (be_func's loop body, molbe/solver.py:301-547 == run_solver, molbe/be_parallel.py:40-307).
 #pragma once
+#include <string>
 #include <cstdint>
 #include <memory>
 #include <vector>
@@ -50,7 +51,14 @@ class Fragment {
   // Bench hooks: set up the CCSD problem once (SCF + transform), then time single iterations.
   int prepare_ccsd(int o, const double* h, const double* dm0, const FragmentOptions& opt);
   int ccsd_iterate(int niter, double* e_corr, double* normt);
-  int ccsd_export(const char* name, double* host, int64_t nelem) { if (!cc_) { set_error("Fragment: prepare_ccsd first"); return QEMB_ERR_ARG; } return cc_->export_block(name, host, nelem); }
+  int ccsd_export(const char* name, double* host, int64_t nelem) {
+    if (!cc_) { set_error("Fragment: prepare_ccsd first"); return QEMB_ERR_ARG; }
+    if (name && std::string(name) == "mo_coeff") {      // the orbitals the MO integrals were transformed with
+      if (nelem != (int64_t)n_ * n_) { set_error("export_block: element count mismatch"); return QEMB_ERR_ARG; }
+      return dev_d2h(host, C_, sizeof(double) * nelem);
+    }
+    return cc_->export_block(name, host, nelem);
+  }
   int ccsd_reset();                              // back to the MP2 guess
   // fragment RHF only (Frags.scf(fs=True), mbe.py:1160): outputs host n*n / n / n*n / n*n, nullable
   int scf_only(int o, const double* h, const double* dm0, const ScfOptions& opt, double* mo_coeff, double* mo_energy,

@@ -453,9 +453,11 @@ __global__ void __launch_bounds__(256) mfma_f64_peak_kernel(double* out, int ite
   }
 #pragma unroll
   for (int j = 0; j < 4; ++j) b[j] = seed * (0.5 - 0.21 * j) + 1e-3 * (double)((threadIdx.x * 40503u + j * 2654435761u) & 1023u) - 0.5;
+  // (inline asm with the accumulator tied to itself: through the builtin the compiler copies all 128 accumulator registers
+  //  between VGPRs and AGPRs around every trip of this loop -- 256 moves per 16 MFMAs)
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
-    for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[i & 3], acc[i], 0, 0, 0);
+    for (int i = 0; i < NACC; ++i) asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a[i]), "v"(b[i & 3]));
   }
   double s = 0.0;
 #pragma unroll

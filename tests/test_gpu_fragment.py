@@ -188,6 +188,7 @@ def test_mo_transform_at_bench_tile(qlib, n, o):
     assert r["converged"]
     C = r["mo_coeff"]
     fr.prepare_ccsd(o, h, 2.0 * C[:, :o] @ C[:, :o].T)
+    C = fr.ccsd_export("mo_coeff", (n, n))                # prepare_ccsd re-runs the fragment RHF from dm0: take ITS orbitals
     Bm = np.einsum("Ppq,pi,qj->Pij", B, C, C, optimize=True)
     f = lambda x: np.ascontiguousarray(x).reshape(naux, -1)
     Boo, Bov, Bvv = Bm[:, :o, :o], Bm[:, :o, o:], Bm[:, o:, o:]

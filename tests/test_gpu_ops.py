@@ -511,7 +511,7 @@ def test_gemm_ladder_tiles_scalar_load_variant(qlib, cfg, shape, a_kc, b_kc):
     assert np.abs(got - ref).max() < 1e-12 * K
 
 
-@pytest.mark.parametrize("cfg,shape", [(20, (8000, 20, 200)), (20, (4001, 32, 200)), (20, (8000, 20, 84000)), (20, (300, 7, 51)),
+@pytest.mark.parametrize("cfg,shape", [(20, (8000, 20, 200)), (20, (4001, 32, 200)), (20, (2000, 20, 20000)), (20, (300, 7, 51)),
                                        (21, (20, 8000, 200)), (21, (32, 4001, 200)), (21, (20, 200, 84000)), (21, (7, 300, 51))])
 @pytest.mark.parametrize("a_kc,b_kc", [(1, 1), (1, 0), (0, 1), (0, 0)])
 def test_gemm_skinny_tile_configs(qlib, cfg, shape, a_kc, b_kc):
@@ -598,3 +598,26 @@ def test_pm_packed_ladder_at_bench_tiles(qlib):
         check(qlib.qemb_op_ladder_scatter_pm(o, v, dRp.ptr, ldp, dRm.ptr, ldm, d2.ptr))
         ref = t2 + np.einsum("abcd,ijcd->ijab", Vac, tau, optimize=True)
         assert np.abs(d2.numpy(t2.shape) - ref).max() < 1e-10 * np.abs(ref).max(), (cfg_p, cfg_m, ks)
+
+
+def test_device_timers_hold_a_bounded_number_of_events(qlib):
+    """A long run that never reads its timers must not accumulate HIP events (dev_ops_hip.hip: laps are harvested and their event
+    pairs recycled), and a lap that was begun but never ended (early return of the bracketed region) must not poison the slot."""
+    slot = 9
+    check(qlib.qemb_timer_reset(slot))
+    x = DeviceBuffer.from_numpy(np.ones(1 << 16)); out = DeviceBuffer(2)
+    for _ in range(1000):
+        check(qlib.qemb_timer_begin(slot))
+        check(qlib.qemb_op_dot(1 << 16, x.ptr, x.ptr, out.ptr))
+        check(qlib.qemb_timer_end(slot))
+    assert qlib.qemb_timer_live_events(slot) <= 64
+    check(qlib.qemb_timer_begin(slot))            # begun, never ended ...
+    check(qlib.qemb_timer_begin(slot))            # ... the next lap reuses the pair
+    check(qlib.qemb_op_dot(1 << 16, x.ptr, x.ptr, out.ptr))
+    check(qlib.qemb_timer_end(slot))
+    check(qlib.qemb_timer_begin(slot))            # and a dangling one at read time is dropped
+    ms, cnt = C.c_double(), C.c_int64()
+    check(qlib.qemb_timer_read(slot, C.byref(ms), C.byref(cnt)))
+    assert cnt.value == 1001 and ms.value > 0.0
+    assert qlib.qemb_timer_end(slot) != 0         # nothing open any more
+    check(qlib.qemb_timer_reset(slot))
