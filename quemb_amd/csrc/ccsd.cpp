@@ -320,18 +320,25 @@ int CcsdSolver::update_amps(double* t1n, double* t2n) {
   // readers -- the Y traces and the X1 term -- are done), so ONE transposing pass per intermediate carries both pieces
   QTRY(dev_small_k_update(nov, v, o, o, -1.0, t1, 0, I_.ovoo, oo, ZB_, v * o));    // ZB[k,c,a,i] -= sum_l t1[l,a] ovoo[k,c,l,i]
   QTRY(perm4(W1_, ZB_, o, v, v, o, 3, 2, 0, 1, 1.0, 1.0, W1base_));                // W1 = W1base + ovvv[kcad] t1[id] - ovoo[kcli] t1[la]
-  QTRY(gemm_nn(nov, nov, nov, 0.25, W12_, Lovov_, 1.0, W1_));                      // + 1/4 u~ L
+  // The right-hand operands of all four (ov)^3 products are symmetric matrices over (kc),(ld) -- L and ovov_t by the integral symmetry
+  // (kc|ld) = (ld|kc), T' and u by t2[k,j,c,b] = t2[j,k,b,c] -- so each is passed in its K-contiguous (transposed) reading: both operands
+  // of the GEMM are then staged through the conflict-free [row][BK+2] LDS image, on the 128 x 256 tile (512 tiles at ov = 4000: two per CU).
+  const int cfg_ring = (nov >= 2048) ? 4 : -1;
+  auto ring = [&](double al, const double* A, const double* Bsym, double be, double* C) {
+    return gemm(nov, nov, nov, al, A, nov, true, Bsym, nov, true, be, C, nov, 1, 0, 0, 0, cfg_ring);
+  };
+  QTRY(ring(0.25, W12_, Lovov_, 1.0, W1_));                                        // + 1/4 u~ L
   //   W2[(ia),(kc)] = Wvovo[a,k,c,i]
   QTRY(dev_small_k_update(oo, v, v, o, -1.0, t1, 0, ovoo_kilc_, nov, ZC_, vv));     // ZC[k,i,a,c] -= sum_l t1[l,a] ovoo[l,c,k,i]
   QTRY(perm4(W2_, ZC_, o, o, v, v, 1, 2, 0, 3, 1.0, 1.0, W2base_));                // W2 = W2base + t1[id] ovvv[kdac] - t1[la] ovoo[lcki]
   // The Tp~ ovov_t product enters Wvoov with -1/4 and Wvovo with -1/2, so it cancels in Wvoov - Wvovo/2: form that
   // combination first (R), then let the GEMM accumulate the product straight into Wvovo.
   QTRY(lincomb2(N2, 1.0, W1_, -0.5, W2_, R_));                                     // R = Wvoov - Wvovo/2
-  QTRY(gemm_nn(nov, nov, nov, -0.5, W12b_, ovov_t_, 1.0, W2_));                     // Wvovo -= 1/2 Tp~ ovov_t
+  QTRY(ring(-0.5, W12b_, ovov_t_, 1.0, W2_));                                       // Wvovo -= 1/2 Tp~ ovov_t
   // Update, also two products:  (2 Wvoov - Wvovo) T - Wvoov Tp = (Wvoov - Wvovo/2) u - (Wvovo Tp)/2  with T = (u + Tp)/2
-  QTRY(gemm_nn(nov, nov, nov, 1.0, W2_, Tp_, 0.0, W1_));                           // A3 = Wvovo[bkci] t2[kjac] at W1[i,b,j,a]
+  QTRY(ring(1.0, W2_, Tp_, 0.0, W1_));                                             // A3 = Wvovo[bkci] t2[kjac] at W1[i,b,j,a]
   QTRY(perm4(U_, W1_, o, v, o, v, 0, 2, 3, 1, -1.0, 1.0));                         // U[i,j,a,b] -= A3[i,b,j,a]
-  QTRY(gemm_nn(nov, nov, nov, 1.0, R_, S_, -0.5, W1_));                            // W1 = (Wvoov - Wvovo/2) u - A3/2
+  QTRY(ring(1.0, R_, S_, -0.5, W1_));                                              // W1 = (Wvoov - Wvovo/2) u - A3/2
   QTRY(perm4(U_, W1_, o, v, o, v, 0, 2, 1, 3, 1.0, 1.0));                          // [i,a,j,b] -> U[i,j,a,b]
   QTRY(lap_RINGS.close());
 

@@ -71,7 +71,7 @@ struct LdsImage {
   static constexpr int LDK = BK + PADK;      // row stride (doubles) of the K-contiguous image
   static constexpr int LDMN = BMN + PADMN;   // row stride (doubles) of the M/N-contiguous image
   static constexpr int SIZE = KCONTIG ? BMN * LDK : BK * LDMN;
-  __device__ static __forceinline__ int off(int mn, int k) {
+  __host__ __device__ static constexpr int off(int mn, int k) {
     return KCONTIG ? mn * LDK + k : k * LDMN + mn;
   }
 };
@@ -167,9 +167,57 @@ __device__ __forceinline__ void stage_store(const double (&reg)[NCH][VEC], doubl
   }
 }
 
+
+// ---- MODE 1 main loop: explicit LDS fragment reads --------------------------------------------------------------------------------
+// The compiler fuses neighbouring ds_read_b64 of the classic loop into ds_read2_b64: half the LDS rate (4 x 16-lane groups, banks mod
+// 32) and, on the [row][BK+2] image, 2-way conflicts -- 16 LDS cycles for two fragment reads instead of 4 -- and it issues all reads
+// of a k-step in one burst after the previous step's last MFMA, so both waves of a SIMD (in lockstep after the per-tile barrier) leave
+// the matrix pipe idle while eight waves queue on the LDS.  Here every fragment is read by an explicit ds_read_b64 (never fused) and
+// the reads run ONE k-step ahead: the B fragments are double buffered, each A fragment register is refilled right after the last MFMA
+// that consumed it, and the per-tile barrier sits before the LAST k-step of the tile, whose fragments are by then in registers -- so
+// the first reads of the next tile (issued during that last k-step) find their LDS buffer published and never wait.
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
+__device__ __forceinline__ unsigned lds_byte_address(const double* p) {
+  return (unsigned)(size_t)(__attribute__((address_space(3))) const double*)p;
+}
+template <int OFF>
+__device__ __forceinline__ void lds_read_f64(double& dst, unsigned base) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds_read_b64 immediate offset");
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(base), "n"(OFF));
+}
+// wait until at most N LDS operations of this wave are outstanding; x is "modified" so that its consumers are ordered behind the wait
+template <int N>
+__device__ __forceinline__ void lds_wait(double& x) {
+  asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(x) : "n"(N));
+}
+
+// one chunk (index C of NCH) of stage_store: lets the MODE 1 loop spread the LDS stores of the next tile between its MFMA rows
+template <int BMN, int BK, bool KCONTIG, int VEC, int T, int NCH, int C>
+__device__ __forceinline__ void stage_store_chunk(const double (&reg)[NCH][VEC], double* __restrict__ S, int tid) {
+  using Img = LdsImage<BMN, BK, KCONTIG>;
+  constexpr int CPR = (KCONTIG ? BK : BMN) / VEC;
+  constexpr int TOTAL = BMN * BK / VEC;
+  const int chunk = tid + C * T;
+  if ((TOTAL % T != 0) && chunk >= TOTAL) return;
+  const int r = chunk / CPR;
+  const int cc = (chunk % CPR) * VEC;
+  const int mn = KCONTIG ? r : cc;
+  const int k = KCONTIG ? cc : r;
+  double* dst = S + Img::off(mn, k);
+  if constexpr (VEC == 2) {
+    d2 v = {reg[C][0], reg[C][VEC - 1]};
+    *reinterpret_cast<d2*>(dst) = v;
+  } else {
+    dst[0] = reg[C][0];
+  }
+}
+
 // TAG does not change the code: it gives a call site its own kernel symbol so that profiles (rocprofv3 --stats, PMC) of the
 // pp-ladder are not mixed with other users of the same tile shape.
-template <int WM, int WN, int WAVES_M, int WAVES_N, int BK, bool A_KC, bool B_KC, int VEC, int TAG = 0>
+template <int WM, int WN, int WAVES_M, int WAVES_N, int BK, bool A_KC, bool B_KC, int VEC, int TAG = 0, int MODE = 0>
 __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64, (WM * WN <= 16) ? 2 : 1)
     dgemm_mfma_kernel(GemmKArgs g) {
   const long long t_start = g.cyc ? clock64() : 0;
@@ -216,8 +264,9 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64, (WM * WN <= 16) ? 2 : 1
   // Operand staging is one tile deep for A and TWO tiles deep for B by default (DB): the B tile of step kt + 2 is requested before the
   // MFMAs of step kt and only stored to LDS at the end of step kt + 1 -- a full tile more for the HBM latency; A (re-read by every
   // column tile, L2 resident) stays one deep where the accumulators leave no registers for a second slot (the 7 x 2 and 4 x 4 wave tiles).
-  constexpr int DA = (VEC == 2 && (WM * WN <= 8 || (WM == 6 && WN == 2))) ? 2 : 1;   // small wave tiles and the 6 x 2 ladder tile have the registers
-  constexpr int DB = (VEC == 2 && WM < 14) ? 2 : 1;    // (the scalar-load variants and the 14 x 1 wave tile would spill)
+  // (MODE 1 refills the one register set right after its LDS stores, a full tile before the next ones: no second set needed)
+  constexpr int DA = (MODE == 0 && VEC == 2 && (WM * WN <= 8 || (WM == 6 && WN == 2))) ? 2 : 1;   // small wave tiles and the 6 x 2 ladder tile have the registers
+  constexpr int DB = (MODE == 0 && VEC == 2 && WM < 14) ? 2 : 1;    // (the scalar-load variants and the 14 x 1 wave tile would spill)
   double ra[DA][NCH_A][VEC], rb[DB][NCH_B][VEC];
   const int nk = (kend - kbeg + BK - 1) / BK;
 
@@ -244,46 +293,119 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64, (WM * WN <= 16) ? 2 : 1
   stage_load<BN, BK, B_KC, VEC, T, NCH_B>(rb[0], B, g.ldb, n0, kbeg, g.N, kend, tid);
   stage_store<BM, BK, A_KC, VEC, T, NCH_A>(ra[0], sA0, tid);
   stage_store<BN, BK, B_KC, VEC, T, NCH_B>(rb[0], sB0, tid);
-  if (DA == 2) fetch_a(ra[DA - 1], 1);
-  if (DB == 2) fetch_b(rb[DB - 1], 1);
+  if (DA == 2 || MODE == 1) fetch_a(ra[DA - 1], 1);
+  if (DB == 2 || MODE == 1) fetch_b(rb[DB - 1], 1);
   __syncthreads();
 
   const int fr = lane & 15, fk = lane >> 4;
+  if constexpr (MODE == 1) {
+    static_assert(VEC == 2, "MODE 1 uses the vector staging path");
+    constexpr int NKS = BK / 4;
+    static_assert(NKS >= 2 && NKS % 2 == 0, "the B fragment sets alternate per k-step");
+    // LDS byte addresses of this lane's fragment origin in the two buffers; fragment (row block i, k-step ks) is a constant offset away
+    const unsigned ldsA[2] = {lds_byte_address(sA0 + ImgA::off(wm * WM * 16 + fr, fk)), lds_byte_address(sA1 + ImgA::off(wm * WM * 16 + fr, fk))};
+    const unsigned ldsB[2] = {lds_byte_address(sB0 + ImgB::off(wn * WN * 16 + fr, fk)), lds_byte_address(sB1 + ImgB::off(wn * WN * 16 + fr, fk))};
+    double a[WM], b[2][WN];
+    // fragments of (tile 0, k-step 0): B first, then A row by row (LDS returns in order)
+    static_for<0, WN>([&](auto j) { lds_read_f64<ImgB::off(decltype(j)::value * 16, 0) * 8>(b[0][decltype(j)::value], ldsB[0]); });
+    static_for<0, WM>([&](auto i) { lds_read_f64<ImgA::off(decltype(i)::value * 16, 0) * 8>(a[decltype(i)::value], ldsA[0]); });
+    // one k-step of tile parity P: MFMAs of k-step KS on the fragments in registers, reads for the following k-step (same tile, or k-step
+    // 0 of the next tile from the other buffer) issued underneath.  The very last k-step of the slice issues them too -- they read
+    // whatever the other buffer holds and are never used -- so that the loop body is one straight instruction stream (a second copy of
+    // the k-step without the reads makes the register allocator shuffle the accumulators between the two copies and spill).
+    auto kstep = [&](auto ks_c, auto p_c, auto&& after_row) {
+      constexpr int KS = decltype(ks_c)::value, P = decltype(p_c)::value;
+      constexpr int S = KS & 1;                                   // B fragment set in use
+      constexpr int KSn = (KS + 1) % NKS, Pn = (KS + 1 < NKS) ? P : 1 - P;
+      static_for<0, WN>([&](auto j) { lds_read_f64<ImgB::off(decltype(j)::value * 16, KSn * 4) * 8>(b[S ^ 1][decltype(j)::value], ldsB[Pn]); });
+      static_for<0, WM>([&](auto i) {
+        constexpr int I = decltype(i)::value;
+        // LDS operations issued after the read of a[I]: the later rows of its own k-step, the next B set and the refills of the rows
+        // already consumed in this k-step -- WM - 1 + WN in all, whatever I is (LDS stores slipped in between only make the wait stricter)
+        constexpr int NW = WM + WN - 1;
+        if constexpr (I == 0) static_for<0, WN>([&](auto j) { lds_wait<NW>(b[S][decltype(j)::value]); });
+        lds_wait<NW>(a[I]);
+#pragma unroll
+        for (int j = 0; j < WN; ++j) acc[I][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[I], b[S][j], acc[I][j], 0, 0, 0);
+        lds_read_f64<ImgA::off(I * 16, KSn * 4) * 8>(a[I], ldsA[Pn]);
+        after_row(ks_c, i);
+      });
+    };
+    // The LDS stores of tile kt + 1 (other buffer: its last readers passed the previous barrier) are spread one chunk at a time behind
+    // the MFMA rows of k-step NKS - 2 instead of one burst in front of the barrier, where eight waves queue on the LDS store path with
+    // the matrix pipe idle.  Past the end of the slice they store stale registers into a buffer nobody reads.
+    constexpr int NCH = NCH_A + NCH_B, NSLOT = WM;
+    auto tile = [&](auto parity, int kt) {
+      constexpr int P = decltype(parity)::value;
+      double* nA = P ? sA0 : sA1;
+      double* nB = P ? sB0 : sB1;
+      auto stores = [&](auto ks_c, auto i_c) {
+        constexpr int KS = decltype(ks_c)::value, I = decltype(i_c)::value;
+        if constexpr (KS == NKS - 2) {
+          constexpr int slot = I;
+          // chunks c with c * NSLOT / NCH == slot (several per slot when there are more chunks than rows)
+          static_for<0, NCH>([&](auto c_c) {
+            constexpr int C = decltype(c_c)::value;
+            if constexpr ((C * NSLOT) / NCH == slot) {
+              if constexpr (C < NCH_A) stage_store_chunk<BM, BK, A_KC, VEC, T, NCH_A, C>(ra[0], nA, tid);
+              else stage_store_chunk<BN, BK, B_KC, VEC, T, NCH_B, C - NCH_A>(rb[0], nB, tid);
+            }
+          });
+        }
+      };
+      static_for<0, NKS - 1>([&](auto ks) { kstep(ks, parity, stores); });
+      // the staging registers are free again: request tile kt + 2 now -- it is stored during k-step NKS - 2 of the NEXT tile, NKS - 1
+      // k-steps of MFMAs away (the loads behind the vmcnt wait of this tile's stores were issued that long ago)
+      fetch_a(ra[0], kt + 2);
+      fetch_b(rb[0], kt + 2);
+      __syncthreads();   // (also drains this wave's fragment reads of k-step NKS - 1: nobody reads this tile's buffer after the barrier)
+      kstep(std::integral_constant<int, NKS - 1>{}, parity, stores);
+    };
+    for (int kt = 0; kt < nk; kt += 2) {
+      tile(std::integral_constant<int, 0>{}, kt);
+      if (kt + 1 < nk) tile(std::integral_constant<int, 1>{}, kt + 1);
+    }
+    // the run-ahead reads of the final k-step are still in flight: let them land before the fragment registers are reused
+    static_for<0, WN>([&](auto j) { lds_wait<0>(b[0][decltype(j)::value]); lds_wait<0>(b[1][decltype(j)::value]); });
+    static_for<0, WM>([&](auto i) { lds_wait<0>(a[decltype(i)::value]); });
+  } else {
   // one k-tile; P = kt & 1 is a compile-time parity so that every register slot index is static
-  auto step = [&](auto parity, int kt) {
-    constexpr int P = decltype(parity)::value;
-    const double* sA = P ? sA1 : sA0;
-    const double* sB = P ? sB1 : sB0;
-    double* nA = P ? sA0 : sA1;
-    double* nB = P ? sB0 : sB1;
-    // requests for the tile DA / DB steps ahead (tile kt + 2 lands in slot P, tile kt + 1 of a one-deep operand in slot 0)
-    fetch_a(ra[DA == 2 ? P : 0], kt + DA);
-    fetch_b(rb[DB == 2 ? P : 0], kt + DB);
+    auto step = [&](auto parity, int kt) {
+      constexpr int P = decltype(parity)::value;
+      const double* sA = P ? sA1 : sA0;
+      const double* sB = P ? sB1 : sB0;
+      double* nA = P ? sA0 : sA1;
+      double* nB = P ? sB0 : sB1;
+      // requests for the tile DA / DB steps ahead (tile kt + 2 lands in slot P, tile kt + 1 of a one-deep operand in slot 0)
+      fetch_a(ra[DA == 2 ? P : 0], kt + DA);
+      fetch_b(rb[DB == 2 ? P : 0], kt + DB);
 #pragma unroll
-    for (int ks = 0; ks < BK / 4; ++ks) {
-      const int kk = ks * 4 + fk;
-      double a[WM], b[WN];
-      // B fragments first, then A row by row: LDS returns in order, so the MFMAs of row i only wait for a[0..i] (partial lgkmcnt)
-      // and the later fragment reads land under the earlier rows' MFMAs
+      for (int ks = 0; ks < BK / 4; ++ks) {
+        const int kk = ks * 4 + fk;
+        double a[WM], b[WN];
+        // B fragments first, then A row by row: LDS returns in order, so the MFMAs of row i only wait for a[0..i] (partial lgkmcnt)
+        // and the later fragment reads land under the earlier rows' MFMAs
 #pragma unroll
-      for (int j = 0; j < WN; ++j) b[j] = sB[ImgB::off((wn * WN + j) * 16 + fr, kk)];
+        for (int j = 0; j < WN; ++j) b[j] = sB[ImgB::off((wn * WN + j) * 16 + fr, kk)];
 #pragma unroll
-      for (int i = 0; i < WM; ++i) a[i] = sA[ImgA::off((wm * WM + i) * 16 + fr, kk)];
+        for (int i = 0; i < WM; ++i) a[i] = sA[ImgA::off((wm * WM + i) * 16 + fr, kk)];
 #pragma unroll
-      for (int i = 0; i < WM; ++i)
+        for (int i = 0; i < WM; ++i)
 #pragma unroll
-        for (int j = 0; j < WN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < WN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+      if (kt + 1 < nk) {      // tile kt + 1 (requested one or two steps ago) -> the other LDS buffer
+        stage_store<BM, BK, A_KC, VEC, T, NCH_A>(ra[DA == 2 ? 1 - P : 0], nA, tid);
+        stage_store<BN, BK, B_KC, VEC, T, NCH_B>(rb[DB == 2 ? 1 - P : 0], nB, tid);
+      }
+      __syncthreads();
+    };
+    for (int kt = 0; kt < nk; kt += 2) {
+      step(std::integral_constant<int, 0>{}, kt);
+      if (kt + 1 < nk) step(std::integral_constant<int, 1>{}, kt + 1);
     }
-    if (kt + 1 < nk) {      // tile kt + 1 (requested one or two steps ago) -> the other LDS buffer
-      stage_store<BM, BK, A_KC, VEC, T, NCH_A>(ra[DA == 2 ? 1 - P : 0], nA, tid);
-      stage_store<BN, BK, B_KC, VEC, T, NCH_B>(rb[DB == 2 ? 1 - P : 0], nB, tid);
-    }
-    __syncthreads();
-  };
-  for (int kt = 0; kt < nk; kt += 2) {
-    step(std::integral_constant<int, 0>{}, kt);
-    if (kt + 1 < nk) step(std::integral_constant<int, 1>{}, kt + 1);
+
   }
 
   // epilogue: D reg r of lane l -> row (l>>4)+4r, col l&15 of the 16x16 tile
@@ -351,7 +473,7 @@ static long long* g_gemm_cyc = nullptr;          // QEMB_GEMM_TRACE: per-workgro
 static long long g_gemm_cyc_cap = 0, g_gemm_cyc_blocks = 0;
 static bool g_gemm_cyc_on = false;
 
-template <int WM, int WN, int WAVES_M, int WAVES_N, int BK, bool A_KC, bool B_KC, int VEC, int TAG = 0>
+template <int WM, int WN, int WAVES_M, int WAVES_N, int BK, bool A_KC, bool B_KC, int VEC, int TAG = 0, int MODE = 0>
 static int launch_cfg(const GemmDesc& d, hipStream_t s) {
   constexpr int BM = WM * 16 * WAVES_M, BN = WN * 16 * WAVES_N;
   using ImgA = LdsImage<BM, BK, A_KC>;
@@ -390,7 +512,7 @@ static int launch_cfg(const GemmDesc& d, hipStream_t s) {
     g.C = ws; g.ldc = d.N; g.strideC = d.M * d.N; g.alpha = 1.0; g.beta = 0.0;
   }
   const size_t lds = 2 * (size_t)(ImgA::SIZE + ImgB::SIZE) * sizeof(double);
-  auto kern = dgemm_mfma_kernel<WM, WN, WAVES_M, WAVES_N, BK, A_KC, B_KC, VEC, TAG>;
+  auto kern = dgemm_mfma_kernel<WM, WN, WAVES_M, WAVES_N, BK, A_KC, B_KC, VEC, TAG, MODE>;
   static std::atomic<bool> attr_set{false};   // benign if two threads both set the attribute once
   if (!attr_set) {
     HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -416,13 +538,14 @@ static int launch_cfg(const GemmDesc& d, hipStream_t s) {
   return QEMB_OK;
 }
 
-template <int WM, int WN, int WAVES_M, int WAVES_N, int BK, int TAG = 0>
+template <int WM, int WN, int WAVES_M, int WAVES_N, int BK, int TAG = 0, int MODE = 0>
 static int launch_layout(const GemmDesc& d, hipStream_t s, bool vec2) {
   const bool a = d.a_kcontig != 0, b = d.b_kcontig != 0;
+  // (the scalar-load variants keep the classic main loop)
 #define QEMB_GEMM_CASE(AK, BKC)                                                                \
   if (a == AK && b == BKC)                                                                      \
-    return vec2 ? launch_cfg<WM, WN, WAVES_M, WAVES_N, BK, AK, BKC, 2, TAG>(d, s)                \
-                : launch_cfg<WM, WN, WAVES_M, WAVES_N, BK, AK, BKC, 1, TAG>(d, s);
+    return vec2 ? launch_cfg<WM, WN, WAVES_M, WAVES_N, BK, AK, BKC, 2, TAG, MODE>(d, s)          \
+                : launch_cfg<WM, WN, WAVES_M, WAVES_N, BK, AK, BKC, 1, TAG, 0>(d, s);
   QEMB_GEMM_CASE(true, true)
   QEMB_GEMM_CASE(true, false)
   QEMB_GEMM_CASE(false, true)
@@ -557,20 +680,28 @@ static int dev_gemm_dispatch(const GemmDesc& d) {
   else cfg = 2;
   if (d.cfg >= 0) cfg = d.cfg;
   if (t_gemm_force_cfg >= 0) cfg = t_gemm_force_cfg;
+  // The large tiles run the MODE 1 main loop (explicit one-k-step-ahead LDS fragment reads, LDS stores spread behind the MFMA rows) when
+  // the operands allow 16-byte loads; their scalar-load variants, the single-column wave tiles and the small / skinny tiles, which are
+  // latency or HBM bound and want the two-tiles-deep register prefetch, keep the classic loop.
   switch (cfg) {
-    case 0: return launch_layout<4, 4, 2, 2, 16>(d, s, vec2);   // 128 x 128, 4 waves
-    case 1: return launch_layout<2, 2, 2, 2, 16>(d, s, vec2);   //  64 x  64, 4 waves
+    case 0: return launch_layout<4, 4, 2, 2, 16, 0, 1>(d, s, vec2);   // 128 x 128, 4 waves
+    case 1: return launch_layout<2, 2, 2, 2, 16, 0, 1>(d, s, vec2);   //  64 x  64, 4 waves
     case 2: return launch_layout<1, 1, 2, 2, 32>(d, s, vec2);   //  32 x  32, 4 waves
-    case 4: return launch_layout<4, 4, 2, 4, 16>(d, s, vec2);   // 128 x 256, 8 waves
+    case 4: return launch_layout<4, 4, 2, 4, 16, 0, 1>(d, s, vec2);   // 128 x 256, 8 waves
     case 10: return launch_layout<14, 1, 1, 8, 16>(d, s, vec2); // 224 x 128, 8 waves: all packed (i>=j) rows of o = 20 in ONE tile
     case 11: return launch_layout<7, 1, 1, 8, 16>(d, s, vec2);  // 112 x 128, 8 waves
     case 12: return launch_layout<4, 1, 1, 8, 16>(d, s, vec2);  //  64 x 128, 8 waves
-    case 13: return launch_layout<7, 2, 2, 4, 16>(d, s, vec2);  // 224 x 128, 8 waves as 2 x 4: 9 LDS fragment reads per 14 MFMAs (15 for cfg 10)
-    case 15: return launch_layout<6, 2, 2, 4, 16>(d, s, vec2);  // 192 x 128, 8 waves as 2 x 4 (the 190 antisymmetric pair rows of o = 20)
+    case 13: return launch_layout<7, 2, 2, 4, 16, 0, 1>(d, s, vec2);  // 224 x 128, 8 waves as 2 x 4: 9 LDS fragment reads per 14 MFMAs (15 for cfg 10)
+    case 15: return launch_layout<6, 2, 2, 4, 16, 0, 1>(d, s, vec2);  // 192 x 128, 8 waves as 2 x 4 (the 190 antisymmetric pair rows of o = 20)
     case 20: return launch_layout<4, 1, 2, 2, 16>(d, s, vec2);   // 128 x  32, 4 waves: tall products with N = n_occ (the t1 contractions of ovvv)
     case 21: return launch_layout<1, 4, 2, 2, 16>(d, s, vec2);   //  32 x 128, 4 waves: the same with M = n_occ
-    case 23: return launch_layout<7, 2, 2, 4, 16, 1>(d, s, vec2);   // = 13 under its own kernel symbol (pp-ladder, + pairs)
-    case 25: return launch_layout<6, 2, 2, 4, 16, 1>(d, s, vec2);   // = 15 under its own kernel symbol (pp-ladder, - pairs)
+    case 23: return launch_layout<7, 2, 2, 4, 16, 1, 1>(d, s, vec2);   // = 13 under its own kernel symbol (pp-ladder, + pairs)
+    case 25: return launch_layout<6, 2, 2, 4, 16, 1, 1>(d, s, vec2);   // = 15 under its own kernel symbol (pp-ladder, - pairs)
+    // the classic main loop of the same tiles, kept addressable for A/B measurements (tools/gemm_modes.py)
+    case 200: return launch_layout<4, 4, 2, 2, 16>(d, s, vec2);
+    case 204: return launch_layout<4, 4, 2, 4, 16>(d, s, vec2);
+    case 213: return launch_layout<7, 2, 2, 4, 16>(d, s, vec2);
+    case 215: return launch_layout<6, 2, 2, 4, 16>(d, s, vec2);
     default: set_error("dev_gemm: unknown tile config"); return QEMB_ERR_ARG;
   }
 }
