@@ -94,11 +94,23 @@ static int rhf_loop(int n, int o, const double* h, const double* eri, const doub
     QTRY(density_from_mos(n, o, C, dm));
   }
   res->cycles = cyc + (res->converged ? 1 : 0);
-  // canonical orbitals of the Fock matrix of the final density (PySCF does the same extra diagonalisation)
-  QTRY(build_jk(n, eri, dm, J, K, eri_s4));
-  QTRY(dcopy(n2, h, F)); QTRY(axpby(n2, 1.0, J, 1.0, F)); QTRY(axpby(n2, -0.5, K, 1.0, F));
-  QTRY(dcopy(n2, F, Fd));
-  QTRY(dev_jacobi_eigh(n, Fd, eps, C, nullptr));
+  // canonical orbitals of the Fock matrix of the final density (PySCF does the same extra diagonalisation).  On the converged exit F
+  // already IS the Fock matrix of dm (the loop left between the convergence test and the density update): no third J/K build.
+  if (!res->converged) {
+    QTRY(build_jk(n, eri, dm, J, K, eri_s4));
+    QTRY(dcopy(n2, h, F)); QTRY(axpby(n2, 1.0, J, 1.0, F)); QTRY(axpby(n2, -0.5, K, 1.0, F));
+  }
+  if (have_prev) {
+    // in the orbitals of the last cycle the converged Fock matrix is diagonal up to the SCF residual: the Jacobi sweeps need two or
+    // three passes instead of the eight of a cold start
+    QTRY(gemm_nn(n, n, n, 1.0, F, Cprev, 0.0, tmp));
+    QTRY(gemm_tn(n, n, n, 1.0, Cprev, tmp, 0.0, Fd));
+    QTRY(dev_jacobi_eigh(n, Fd, eps, V, nullptr));
+    QTRY(gemm_nn(n, n, n, 1.0, Cprev, V, 0.0, C));
+  } else {
+    QTRY(dcopy(n2, F, Fd));
+    QTRY(dev_jacobi_eigh(n, Fd, eps, C, nullptr));
+  }
   QTRY(density_from_mos(n, o, C, dm));
   return 0;
 }

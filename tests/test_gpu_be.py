@@ -387,3 +387,28 @@ def test_h8_ccpvdz_hf_in_hf_and_oneshot_be2_vs_molecular_ccsd(qlib):
     assert abs(be.hf_err) < 1e-9
     e, _ = be.oneshot()
     assert abs(e - out["e_corr_mo"]) < 2e-3, (e, out["e_corr_mo"])
+
+
+def test_mp2_and_ccsd_model_jacobians_match_reference(qlib):
+    """jac_solver="MP2" / "CCSD" (optqn.py:437-461; jac_utils.py:162-178, cpmp2_utils.py:94-133): the density responses assembled
+    from device-exported MO blocks == the reference's own functions (tests/golden/jac.npz)."""
+    from test_hostlogic_be import _check_jacobian_models
+    _check_jacobian_models(qlib)
+
+
+def test_octane_matching_with_correlated_model_jacobians(qlib):
+    """Octane BE2 density matching started from the MP2- and CCSD-model Jacobians reaches the reference's golden energy
+    (tests/molbe_octane_test.py:32-36) like the HF Jacobian; how far each initial Jacobian is from the exact (central-difference)
+    CCSD one is printed."""
+    from quemb_amd.jacobian import get_be_error_jacobian
+    mf, be = _be("octane")
+    Jn = be.compute_numerical_jacobian("CCSD", False, 1, step_size=1e-4)
+    for js in ("HF", "MP2", "CCSD"):
+        J0 = get_be_error_jacobian(be.fobj.n_frag, be.Fobjs, jac_solver=js, opts=be.opts)
+        print(f"octane BE2 initial Jacobian {js:4s}: |J0 - J_numerical|_max = {np.abs(J0 - Jn).max():.3e}  (|J_numerical|_max = {np.abs(Jn).max():.3e})")
+    for js in ("MP2", "CCSD"):
+        mf2, be2 = _be("octane")
+        be2.optimize(solver="CCSD", jac_solver=js)
+        print(f"octane BE2 matching with the {js} Jacobian: {be2.beopt.iter} QN iterations")
+        assert be2.beopt.err < 1e-6
+        assert abs(be2.ebe_tot - (-310.3347211309688)) < 5e-6

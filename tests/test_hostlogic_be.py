@@ -502,3 +502,46 @@ def test_every_exported_entry_point_is_declared_in_the_public_header():
     bound = set(re.findall(r'f\("(qemb_[a-z0-9_]+)"', (ROOT / "quemb_amd" / "_lib.py").read_text()))
     missing = sorted(f for f in exported | bound if not re.search(r"\b%s\s*\(" % f, header))
     assert not missing, missing
+
+
+def _check_jacobian_models(lib):
+    """MP2 / CCSD-model density responses on device-exported MO blocks against the reference's own functions (tests/golden/jac.npz,
+    tests/golden/make_golden_jac.py: get_dPccsdurlx_batch_u, get_dPmp2_batch_r, cphf_kernel_batch run on the same inputs)."""
+    from quemb_amd.fragsolver import DeviceFragment, default_opts
+    from quemb_amd.jacobian import MoBlocks, dP_ccsd_model, dP_mp2_model
+    g = np.load(GOLDEN / "jac.npz")
+    for c in range(3):
+        k = lambda s: g[f"c{c}_{s}"]
+        n, o = int(k("n")), int(k("o"))
+        fr = DeviceFragment(n, min(4, n), lib=lib)
+        fr.set_eri_s4(oeri.pack_s4(k("eri")))
+        opts = default_opts(lib, scf_conv_tol=1e-13, scf_conv_tol_grad=1e-9)
+        mo = MoBlocks(fr, o, k("h"), None, opts=opts)
+        assert np.abs(mo.moe - k("moe")).max() < 1e-9
+        us = mo.cphf(k("vpots"))
+        Co, Cv = mo.C[:, :o], mo.C[:, o:]
+        dP_hf = np.array([-(Co @ u @ Cv.T) - (Co @ u @ Cv.T).T for u in us])
+        assert np.abs(dP_hf - k("dP_hf")).max() < 1e-9
+        assert np.abs(dP_ccsd_model(mo, k("vpots")) - k("dP_ccsd")).max() < 1e-8
+        assert np.abs(dP_mp2_model(mo, k("vpots")) - k("dP_mp2")).max() < 1e-8
+        # the device's own CPHF entry point gives the same HF response
+        assert np.abs(fr.cphf(o, k("h"), k("vpots"), opts=opts) - k("dP_hf")).max() < 1e-8
+        fr.free()
+
+
+def test_mp2_and_ccsd_model_jacobians_match_reference(hlib):
+    _check_jacobian_models(hlib)
+
+
+def test_h8_density_matching_with_correlated_model_jacobians(hlib):
+    """BE.optimize(jac_solver="MP2" | "CCSD") (mbe.py:849, optqn.py:258-262) converges H8 BE2 to the same matched energy as jac_solver="HF"."""
+    be = _h8(hlib)[2]
+    be.optimize(solver="CCSD", jac_solver="HF", conv_tol=1e-7)
+    e_hf, it_hf = be.e_corr, be.beopt.iter
+    for js in ("MP2", "CCSD"):
+        b2 = _h8(hlib)[2]
+        b2.optimize(solver="CCSD", jac_solver=js, conv_tol=1e-7)
+        assert b2.beopt.err < 1e-7 and abs(b2.e_corr - e_hf) < 1e-7, (js, b2.e_corr, e_hf)
+        assert b2.beopt.iter <= it_hf + 6
+    with pytest.raises(NotImplementedError):
+        _h8(hlib)[2].optimize(solver="CCSD", jac_solver="FCI")
