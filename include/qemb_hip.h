@@ -163,6 +163,13 @@ int qemb_schmidt_svd(const double* rdm, int N, const int64_t* frag_idx, int n_f,
 /* Frags.get_nsocc (molbe/pfrag.py:208-239): Cproj = TA^T S C_occ (n x nocc) -> P (n x n, nullable),
  * nsocc, initial fragment MOs (n x n)                                                                  */
 int qemb_nsocc_guess(const double* Cproj, int n, int nocc, double* P, int* nsocc, double* mo_coeffs);
+/* ---------------------------------------------------------------- AO screening (semi-sparse DF) --- */
+/* int |chi_a| |chi_b| of unnormalised uncontracted Cartesian Gaussians by Gauss-Hermite quadrature: the primitive stage of
+ * approx_S_abs (molbe/eri_sparse_DF.py:733-865, :928-959; numba on the host in the reference).  nsh primitive shells (l <= 4, exponent,
+ * centre xyz[3s..], first Cartesian function cart0[s], components in libcint order); roots / weights of the nroots-point rule;
+ * out: ncart x ncart (host).  The contraction to |c|^T s |c| and the reachability lists are host logic (eri_sparse_DF.py).           */
+int qemb_abs_overlap_prim(int nsh, const int* l, const double* ex, const double* xyz, const int64_t* cart0, int64_t ncart, int nroots,
+                          const double* roots, const double* weights, double* out);
 /* plain host-in/host-out matrix product on the device: C(MxN) = op(A) op(B) (convenience for TA = W @ TA_lo_eo) */
 int qemb_matmul(int64_t M, int64_t N, int64_t K, const double* A, int transA, const double* B, int transB, double* C);
 

@@ -142,6 +142,7 @@ def _declare(lib):
     f("qemb_schmidt_svd", I, P, I, LP, I, D, P, I, IP, IP)
     f("qemb_nsocc_guess", I, P, I, I, P, IP, P)
     f("qemb_matmul", I, L, L, L, P, I, P, I, P)
+    f("qemb_abs_overlap_prim", I, I, P, P, P, P, L, I, P, P, P)
     return lib
 
 

@@ -342,6 +342,21 @@ int qemb_nsocc_guess(const double* Cproj, int n, int nocc, double* P, int* nsocc
   if (!Cproj || !nsocc || !mo) { set_error("qemb_nsocc_guess: null argument"); return QEMB_ERR_ARG; }
   return nsocc_guess(Cproj, n, nocc, P, nsocc, mo);
 }
+int qemb_abs_overlap_prim(int nsh, const int* l, const double* ex, const double* xyz, const int64_t* cart0, int64_t ncart, int nroots,
+                          const double* roots, const double* weights, double* out) {
+  if (nsh <= 0 || ncart <= 0 || nroots <= 0 || !l || !ex || !xyz || !cart0 || !roots || !weights || !out) { set_error("qemb_abs_overlap_prim: bad arguments"); return QEMB_ERR_ARG; }
+  for (int i = 0; i < nsh; ++i) if (l[i] < 0 || l[i] > 4 || ex[i] <= 0.0) { set_error("qemb_abs_overlap_prim: shells need 0 <= l <= 4 and a positive exponent"); return QEMB_ERR_ARG; }
+  DBuf dex, dxyz, droots, dw, dout, dl, dc0;      // (int arrays ride in double-sized buffers)
+  int rc;
+  if ((rc = dex.alloc(nsh)) || (rc = dxyz.alloc(3 * (int64_t)nsh)) || (rc = droots.alloc(nroots)) || (rc = dw.alloc(nroots)) ||
+      (rc = dout.alloc(ncart * ncart)) || (rc = dl.alloc((nsh + 1) / 2 + 1)) || (rc = dc0.alloc(nsh))) return rc;
+  if ((rc = dev_h2d(dex, ex, sizeof(double) * nsh)) || (rc = dev_h2d(dxyz, xyz, sizeof(double) * 3 * nsh)) ||
+      (rc = dev_h2d(droots, roots, sizeof(double) * nroots)) || (rc = dev_h2d(dw, weights, sizeof(double) * nroots)) ||
+      (rc = dev_h2d(dl, l, sizeof(int) * nsh)) || (rc = dev_h2d(dc0, cart0, sizeof(int64_t) * nsh))) return rc;
+  if ((rc = dev_fill(dout, ncart * ncart, 0.0))) return rc;
+  if ((rc = dev_abs_overlap_prim(nsh, reinterpret_cast<const int*>(dl.p), dex, dxyz, reinterpret_cast<const int64_t*>(dc0.p), ncart, nroots, droots, dw, dout))) return rc;
+  return dev_d2h(out, dout, sizeof(double) * ncart * ncart);
+}
 int qemb_matmul(int64_t M, int64_t N, int64_t K, const double* A, int transA, const double* B, int transB, double* C) {
   DBuf dA, dB, dC;
   int rc;

@@ -183,6 +183,13 @@ int dev_threshold_mask(int64_t n, const double* x, double eps, double* out);
 // x[r*cols + c] *= m[c]   for r < rows   (broadcast a mask / scale row over a batch of rows)
 int dev_mul_bcast_rows(int64_t rows, int64_t cols, double* x, const double* m);
 
+// Absolute overlap int |chi_a| |chi_b| of UNNORMALISED uncontracted Cartesian Gaussians chi = x^i y^j z^k exp(-alpha r^2) by Gauss-Hermite
+// quadrature per Cartesian direction (molbe/eri_sparse_DF.py:733-812 `_primitive_overlap`, :815-865 `_primitive_overlap_matrix`): the
+// screening matrix of the semi-sparse DF pipeline.  nsh primitive shells with angular momentum l[s] <= 4, exponent ex[s], centre
+// xyz[3s..3s+2] and first Cartesian function cart0[s] (components in libcint order, cart_components()); out: ncart x ncart row-major.
+int dev_abs_overlap_prim(int nsh, const int* l, const double* ex, const double* xyz, const int64_t* cart0, int64_t ncart, int nroots,
+                         const double* roots, const double* weights, double* out);
+
 // dst[r, 0:len] = idx[r] >= 0 ? src[idx[r]*ld + 0:len] : 0   (row gather; idx is an int64 array ON THE DEVICE; dst rows are len long)
 int dev_gather_rows(int64_t nrows, int64_t len, const int64_t* idx_dev, const double* src, int64_t ld, double* dst);
 // x[r, 0:len] *= s[r]

@@ -365,6 +365,83 @@ int dev_timer_live_events(int slot) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// absolute overlap of primitive Cartesian Gaussians (screening matrix of the semi-sparse DF pipeline)
+// ------------------------------------------------------------------------------------------------
+// One workgroup per primitive shell pair (i >= j).  Per Cartesian direction d the quadrature sums I_d[p][q] = sum_n w_n |xa_d^p xb_d^q|
+// (p <= l_i, q <= l_j) are accumulated by the threads over the roots and reduced across the workgroup; every component pair of the
+// two shells is then the product Ix[ix][jx] Iy[iy][jy] Iz[iz][jz] times the Gaussian-product prefactor.
+__global__ void __launch_bounds__(256) abs_overlap_prim_kernel(int nsh, const int* __restrict__ l, const double* __restrict__ ex,
+                                                               const double* __restrict__ xyz, const long long* __restrict__ cart0,
+                                                               long long ncart, int nroots, const double* __restrict__ roots,
+                                                               const double* __restrict__ weights, double* __restrict__ out) {
+  constexpr int LM = 5;   // l <= 4
+  __shared__ double part[4][3 * LM * LM];
+  __shared__ double I[3][LM][LM];
+  const int i = blockIdx.x, j = blockIdx.y;
+  if (j > i) return;
+  const int li = l[i], lj = l[j];
+  const double ai = ex[i], aj = ex[j], aij = ai + aj, scale = 1.0 / sqrt(aij);
+  double Ra[3], Rb[3], Rp[3], r2 = 0.0;
+  for (int d = 0; d < 3; ++d) {
+    Ra[d] = xyz[3 * i + d]; Rb[d] = xyz[3 * j + d];
+    Rp[d] = (ai * Ra[d] + aj * Rb[d]) / aij;
+    r2 += (Ra[d] - Rb[d]) * (Ra[d] - Rb[d]);
+  }
+  double acc[3][LM][LM];
+  for (int d = 0; d < 3; ++d) for (int p = 0; p < LM; ++p) for (int q = 0; q < LM; ++q) acc[d][p][q] = 0.0;
+  for (int n = threadIdx.x; n < nroots; n += blockDim.x) {
+    const double w = weights[n], t = roots[n] * scale;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const double xa = fabs(t + Rp[d] - Ra[d]), xb = fabs(t + Rp[d] - Rb[d]);
+      double pa = 1.0;
+#pragma unroll
+      for (int p = 0; p < LM; ++p) {
+        double pb = pa * w;
+#pragma unroll
+        for (int q = 0; q < LM; ++q) { acc[d][p][q] += pb; pb *= xb; }
+        pa *= xa;
+      }
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int d = 0; d < 3; ++d) for (int p = 0; p < LM; ++p) for (int q = 0; q < LM; ++q) {
+    double v = acc[d][p][q];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if (lane == 0) part[wave][(d * LM + p) * LM + q] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3 * LM * LM) {
+    const int t = threadIdx.x;
+    (&I[0][0][0])[t] = part[0][t] + part[1][t] + part[2][t] + part[3][t];
+  }
+  __syncthreads();
+  const double fac = scale * scale * scale * exp(-(ai * aj / aij) * r2);
+  const int nfi = (li + 1) * (li + 2) / 2, nfj = (lj + 1) * (lj + 2) / 2;
+  for (int t = threadIdx.x; t < nfi * nfj; t += blockDim.x) {
+    const int ci = t / nfj, cj = t % nfj;
+    // component index -> (lx, ly, lz) in libcint order: lx from l down to 0, ly from l - lx down to 0
+    int ix = li, iy = 0, iz = 0, c = ci;
+    for (ix = li; ix >= 0; --ix) { const int cnt = li - ix + 1; if (c < cnt) { iy = li - ix - c; iz = li - ix - iy; break; } c -= cnt; }
+    int jx = lj, jy = 0, jz = 0; c = cj;
+    for (jx = lj; jx >= 0; --jx) { const int cnt = lj - jx + 1; if (c < cnt) { jy = lj - jx - c; jz = lj - jx - jy; break; } c -= cnt; }
+    const double v = I[0][ix][jx] * I[1][iy][jy] * I[2][iz][jz] * fac;
+    out[(cart0[i] + ci) * ncart + cart0[j] + cj] = v;
+    out[(cart0[j] + cj) * ncart + cart0[i] + ci] = v;
+  }
+}
+int dev_abs_overlap_prim(int nsh, const int* l, const double* ex, const double* xyz, const int64_t* cart0, int64_t ncart, int nroots,
+                         const double* roots, const double* weights, double* out) {
+  REQUIRE_INIT();
+  if (nsh <= 0) return QEMB_OK;
+  hipLaunchKernelGGL(abs_overlap_prim_kernel, dim3((unsigned)nsh, (unsigned)nsh), dim3(256), 0, g_stream, nsh, l, ex, xyz,
+                     (const long long*)cart0, (long long)ncart, nroots, roots, weights, out);
+  HIP_TRY(hipGetLastError());
+  return QEMB_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // fill
 // ------------------------------------------------------------------------------------------------
 __global__ void fill_kernel(double* x, long long n, double v) {

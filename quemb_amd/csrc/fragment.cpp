@@ -33,7 +33,12 @@ void Fragment::set_energy_data(const double* h1, const double* veff0, const doub
 int Fragment::run_scf(int o, const double* h, const double* dm0, const ScfOptions& opt, double* X0, ScfResult* sres, bool warm) {
   const int64_t n2 = (int64_t)n_ * n_;
   o_ = o;
-  const bool c_guess = warm && have_C_ && C_.p && dm0;
+  // The orbitals of this fragment's previous solve (any sweep) serve as the basis in which the Jacobi eigensolver starts: the Fock
+  // matrix of the new sweep is nearly diagonal there (heff moves by a matching step), so the first diagonalisation needs two sweeps
+  // instead of eight.  Only the eigensolver's starting point changes -- the SCF still starts from dm0 -- so this does not depend on
+  // `warm` (which is about reusing amplitudes, i.e. results).
+  (void)warm;
+  const bool c_guess = have_C_ && C_.p && dm0 && o == c_nocc_;
   if (!c_guess) { have_C_ = false; QTRY(C_.alloc(n2)); }
   QTRY(eps_.alloc(n_)); QTRY(dm_.alloc(n2)); QTRY(J_.alloc(n2)); QTRY(K_.alloc(n2));
   DBuf hd;
@@ -48,6 +53,7 @@ int Fragment::run_scf(int o, const double* h, const double* dm0, const ScfOption
   }
   const int rc = rhf_device(n_, o, hd, X0, dm_, opt, C_, eps_, J_, K_, sres, eri_s4_, c_guess);
   have_C_ = (rc == 0 && sres->converged);
+  c_nocc_ = o;
   return rc;
 }
 
@@ -303,10 +309,10 @@ int Fragment::solve(int o, const double* h, const double* dm0, const FragmentOpt
     QTRY(t_prev_.alloc(na));
     QTRY(dcopy(na, cc_->t1(), t_prev_));
     t_prev_o_ = o;
-    // the next sweep may drive this fragment from a host thread bound to ANOTHER execution context (stream): the kept amplitudes,
-    // multipliers and orbitals must be complete before this call returns (no inter-stream ordering exists otherwise)
-    QTRY(dev_sync());
   }
+  // the next sweep may drive this fragment from a host thread bound to ANOTHER execution context (stream): the kept amplitudes,
+  // multipliers and orbitals must be complete before this call returns (no inter-stream ordering exists otherwise)
+  QTRY(dev_sync());
   cc_.reset();
   return 0;
 }

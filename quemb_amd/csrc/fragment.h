@@ -71,7 +71,7 @@ class Fragment {
 
  private:
   int run_scf(int o, const double* h, const double* dm0, const ScfOptions& opt, double* X0, ScfResult* sres, bool warm = false);
-  bool have_C_ = false;    // C_ holds the orbitals of a converged earlier solve (eigensolver warm start when opt.warm_start)
+  bool have_C_ = false; int c_nocc_ = -1;    // C_ holds the orbitals of a converged earlier solve with c_nocc_ occupied orbitals (the Jacobi eigensolver starts in that basis)
   int n_, nf_, o_ = -1;
   DBuf eri_s4_;
   std::vector<double> h1_, veff0_, veff_;

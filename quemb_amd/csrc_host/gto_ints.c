@@ -1,4 +1,4 @@
-/* gto_ints.c -- minimal Gaussian integral generator (s and p Cartesian shells) for libqemb_gto.so.
+/* gto_ints.c -- minimal Gaussian integral generator (Cartesian shells: s, p, d orbital functions; up to g auxiliary functions) for libqemb_gto.so.
  *
  * Role: the INTEGRAL SOURCE upstream of the hot path.  The reference obtains
  * hcore, S, (mu nu|ka la), (mu nu|P) and (P|Q) from PySCF/libcint (molbe/mbe.py:361-373,
@@ -11,9 +11,9 @@
 #include <stdlib.h>
 #include <string.h>
 
-#define MAXL 1          /* s and p */
+#define MAXLPAIR 4       /* largest angular momentum of a function PAIR: d + d, or one g auxiliary function */
 #define MAXPRIM 8
-#define LTOT (4 * MAXL) /* max total angular momentum in an ERI */
+#define LTOT (2 * MAXLPAIR) /* max total angular momentum in an ERI: (dd|dd), (dd|g), (g|g) */
 
 typedef struct {
   double ctr[3];
@@ -149,8 +149,8 @@ void gto_one_electron(int nbf, const bf_t* bf, int natm, const double* atm_xyz, 
     }
 }
 
-/* primitive-pair data: exponent sum, centre, Hermite coefficients per direction (t <= 2) times the contraction coefs */
-typedef struct { double p, P[3], Ex[3], Ey[3], Ez[3], c; int tx, ty, tz; } ppair_t;
+/* primitive-pair data: exponent sum, centre, Hermite coefficients per direction (t <= MAXLPAIR) times the contraction coefs */
+typedef struct { double p, P[3], Ex[MAXLPAIR + 1], Ey[MAXLPAIR + 1], Ez[MAXLPAIR + 1], c; int tx, ty, tz; } ppair_t;
 
 static int build_pairs(const bf_t* a, const bf_t* b, ppair_t* out) {
   int n = 0;
@@ -161,7 +161,7 @@ static int build_pairs(const bf_t* a, const bf_t* b, ppair_t* out) {
       q->p = ea + eb;
       for (int d = 0; d < 3; ++d) q->P[d] = (ea * a->ctr[d] + eb * b->ctr[d]) / q->p;
       q->tx = a->lmn[0] + b->lmn[0]; q->ty = a->lmn[1] + b->lmn[1]; q->tz = a->lmn[2] + b->lmn[2];
-      for (int t = 0; t < 3; ++t) {
+      for (int t = 0; t <= MAXLPAIR; ++t) {
         q->Ex[t] = Ecoef(a->lmn[0], b->lmn[0], t, a->ctr[0] - b->ctr[0], ea, eb);
         q->Ey[t] = Ecoef(a->lmn[1], b->lmn[1], t, a->ctr[1] - b->ctr[1], ea, eb);
         q->Ez[t] = Ecoef(a->lmn[2], b->lmn[2], t, a->ctr[2] - b->ctr[2], ea, eb);
@@ -263,4 +263,26 @@ void gto_eri_2c(int naux, const bf_t* aux, double* out /* naux*naux */) {
   }
 }
 
+/* (ab|P) for a LIST of orbital pairs (the stored unique pairs of the semi-sparse tensor, molbe/eri_sparse_DF.py:410-494):
+ * out[pair][P], npairs x naux row-major -- one auxiliary vector per pair, the layout of SemiSparseSym3DTensor.unique_dense_data */
+void gto_eri_3c_pairs(int nbf, const bf_t* bf, int naux, const bf_t* aux, long npairs, const int* pi, const int* pj, double* out) {
+  (void)nbf;
+  bf_t unit; memset(&unit, 0, sizeof(unit)); unit.nprim = 1; unit.ex[0] = 0.0; unit.co[0] = 1.0;
+  /* the auxiliary "pairs" (function x unit s function at the same centre) are the same for every orbital pair: build them once */
+  ppair_t* auxp = (ppair_t*)malloc(sizeof(ppair_t) * (size_t)naux * MAXPRIM);
+  int* nauxp = (int*)malloc(sizeof(int) * (size_t)naux);
+  for (int P = 0; P < naux; ++P) {
+    bf_t u = unit; memcpy(u.ctr, aux[P].ctr, sizeof(u.ctr));
+    nauxp[P] = build_pairs(&aux[P], &u, auxp + (size_t)P * MAXPRIM);
+  }
+#pragma omp parallel for schedule(dynamic)
+  for (long x = 0; x < npairs; ++x) {
+    ppair_t ab[MAXPRIM * MAXPRIM];
+    const int nab = build_pairs(&bf[pi[x]], &bf[pj[x]], ab);
+    for (int P = 0; P < naux; ++P) out[x * naux + P] = eri_from_pairs(ab, nab, auxp + (size_t)P * MAXPRIM, nauxp[P]);
+  }
+  free(auxp); free(nauxp);
+}
+
+int gto_max_l_pair(void) { return MAXLPAIR; }
 size_t gto_bf_size(void) { return sizeof(bf_t); }

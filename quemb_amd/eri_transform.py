@@ -18,7 +18,7 @@ from . import _lib
 from ._lib import c_vp, check
 
 #: new `int_transform` literals next to the reference's IntTransforms (molbe/mbe.py:63-71)
-HIP_INT_TRANSFORMS = ("in-core-hip", "int-direct-DF-hip", "sparse-DF-hip")
+HIP_INT_TRANSFORMS = ("in-core-hip", "int-direct-DF-hip", "sparse-DF-hip", "on-fly-sparse-DF-hip")
 
 
 def _arr(a):

@@ -32,7 +32,7 @@ def initialize_pot(n_frag, relAO_per_edge):
 class BE:
     def __init__(self, mf, fobj, *, lo_method="lowdin", thr_bath=1.0e-10, int_transform="in-core-hip", auxbasis=None,
                  df_ints=None, nproc=1, ompnum=1, initialize_fragment_idx=None, solver_opts=None, lib=None, distribute=True, nstreams=1,
-                 eri_file=None, scratch_dir=None, restart=False, schmidt_method="subspace"):
+                 eri_file=None, scratch_dir=None, restart=False, schmidt_method="subspace", MO_coeff_epsilon=1e-5, AO_coeff_epsilon=1e-10):
         if lo_method != "lowdin":
             raise NotImplementedError("only lo_method='lowdin' is mirrored (localisation is upstream of the hot path)")
         if restart:
@@ -41,6 +41,8 @@ class BE:
         self.thr_bath = thr_bath
         self.schmidt_method = schmidt_method      # 'eigh' = reference formulation, 'subspace' = same bath, O(N_env n_f nocc)
         self.int_transform = int_transform
+        self.auxbasis = auxbasis
+        self.MO_coeff_epsilon, self.AO_coeff_epsilon = float(MO_coeff_epsilon), float(AO_coeff_epsilon)      # mbe.py:191-192
         self.opts = solver_opts
         self.nstreams = int(nstreams)             # fragments in flight at once on this GPU (solver.map_fragments)
         self.unrestricted = False
@@ -134,6 +136,20 @@ class BE:
             for I in idx:
                 ao.transform(self.Fobjs[I].TA, frag=self.Fobjs[I].dev, want_host=False)
             ao.free()
+        elif it in ("int-direct-DF-hip", "sparse-DF-hip", "on-fly-sparse-DF-hip") and self._df_ints is None:
+            # from the geometry alone, like the reference's "int-direct-DF" / "sparse-DF(-gpu)" / "on-fly-sparse-DF(-gpu)" branches
+            # (mbe.py:1049-1110): auxiliary molecule, (P|Q), (mu nu|P) from the integral source, AO screening, device transform
+            from . import eri_sparse_DF as sdf
+            if not self.auxbasis:
+                raise ValueError("`auxbasis` has to be defined.")                # mbe.py:1050
+            frs = [self.Fobjs[I] for I in idx]
+            if it == "int-direct-DF-hip":
+                sdf.integral_direct_DF_hip(self.mf, frs, self.auxbasis, lib=self.lib)
+            else:
+                self.df_stats = {}
+                self.S_abs = sdf.transform_sparse_DF_integral_hip(self.mf, frs, self.auxbasis, AO_coeff_epsilon=self.AO_coeff_epsilon,
+                                                                  MO_coeff_epsilon=self.MO_coeff_epsilon, lib=self.lib,
+                                                                  precompute_P_mu_nu=(it == "sparse-DF-hip"), stats=self.df_stats)
         elif it in ("int-direct-DF-hip", "sparse-DF-hip"):
             # df_ints: (ints, j2c, layout) or a dict(ints=, layout= | int_P_mu_nu=, j2c= | L_PQ=, S_abs=, MO_coeff_epsilon=).
             # "sparse-DF-hip" applies the MO-coefficient screening of the reference's semi-sparse transform

@@ -363,4 +363,37 @@ int dev_tri_inverse_lower(int64_t n64, const double* L, double* X) {
   return 0;
 }
 
+int dev_abs_overlap_prim(int nsh, const int* l, const double* ex, const double* xyz, const int64_t* cart0, int64_t ncart, int nroots,
+                         const double* roots, const double* weights, double* out) {
+  for (int i = 0; i < nsh; ++i) for (int j = 0; j <= i; ++j) {
+    const int li = l[i], lj = l[j];
+    const double ai = ex[i], aj = ex[j], aij = ai + aj, scale = 1.0 / std::sqrt(aij);
+    double I[3][5][5] = {}, r2 = 0.0;
+    for (int d = 0; d < 3; ++d) {
+      const double Ra = xyz[3 * i + d], Rb = xyz[3 * j + d], Rp = (ai * Ra + aj * Rb) / aij;
+      r2 += (Ra - Rb) * (Ra - Rb);
+      for (int n = 0; n < nroots; ++n) {
+        const double x = roots[n] * scale + Rp, xa = std::fabs(x - Ra), xb = std::fabs(x - Rb);
+        double pa = 1.0;
+        for (int p = 0; p <= li; ++p) { double pb = pa * weights[n]; for (int q = 0; q <= lj; ++q) { I[d][p][q] += pb; pb *= xb; } pa *= xa; }
+      }
+    }
+    const double fac = scale * scale * scale * std::exp(-(ai * aj / aij) * r2);
+    int ci = 0;
+    for (int ix = li; ix >= 0; --ix) for (int iy = li - ix; iy >= 0; --iy) {
+      const int iz = li - ix - iy;
+      int cj = 0;
+      for (int jx = lj; jx >= 0; --jx) for (int jy = lj - jx; jy >= 0; --jy) {
+        const int jz = lj - jx - jy;
+        const double v = I[0][ix][jx] * I[1][iy][jy] * I[2][iz][jz] * fac;
+        out[(cart0[i] + ci) * ncart + cart0[j] + cj] = v;
+        out[(cart0[j] + cj) * ncart + cart0[i] + ci] = v;
+        ++cj;
+      }
+      ++ci;
+    }
+  }
+  return 0;
+}
+
 }  // namespace qemb

@@ -412,3 +412,24 @@ def test_octane_matching_with_correlated_model_jacobians(qlib):
         print(f"octane BE2 matching with the {js} Jacobian: {be2.beopt.iter} QN iterations")
         assert be2.beopt.err < 1e-6
         assert abs(be2.ebe_tot - (-310.3347211309688)) < 5e-6
+
+
+def test_abs_overlap_quadrature_and_reachability_on_the_device(qlib):
+    """approx_S_abs (molbe/eri_sparse_DF.py:928-959) with the primitive quadrature on the device, _get_AO_per_AO (:224-240):
+    against the restatement of oracle/qemb_oracle/sparse_df.py (itself checked against a grid integral, tests/test_oracle_sparse_df.py)."""
+    from test_oracle_sparse_df import check_abs_overlap_and_reachability
+    check_abs_overlap_and_reachability(qlib)
+
+
+def test_sparse_df_from_geometry_h8_and_octane(qlib):
+    """int_transform = "sparse-DF-hip" / "on-fly-sparse-DF-hip" / "int-direct-DF-hip" with an auxiliary basis and nothing else (the
+    reference's sparse-DF(-gpu) / on-fly-sparse-DF(-gpu) / int-direct-DF branches, mbe.py:1049-1110): auxiliary molecule, (P|Q), AO
+    screening, semi-sparse (P|mu nu) fill, device transform.  H8 and octane / STO-3G with even-tempered auxiliary sets up to d on H and
+    f on C (the reference's own `weigend` goldens, tests/test_eri_sparse_DF.py:32-54, need the def2-universal-jfit table, which this
+    image does not hold)."""
+    from helpers import GOLDEN
+    from test_oracle_sparse_df import check_sparse_df_from_geometry
+    errs = check_sparse_df_from_geometry(qlib)
+    print(f"H8 BE2 one-shot: |E(DF) - E(in-core)| = {errs[0]:.3e} (s aux on H) -> {errs[1]:.3e} (s,p,d aux on H)")
+    errs = check_sparse_df_from_geometry(qlib, atoms=str(GOLDEN / "octane.xyz"), frag_key="test_autogen_octane_be2", tol=1e-8)
+    print(f"octane BE2 one-shot: |E(DF) - E(in-core)| = {errs[0]:.3e} (H: s, C: s,p) -> {errs[1]:.3e} (H: s,p,d, C: s,p,d,f)")
