@@ -412,7 +412,7 @@ def main():
             "ccsd_iterations_per_fragment": n_iter_total / max(n_frag_total, 1),
             "mean_e_corr_per_sweep": ecorr_sum / args.steps,
             "residual_norm": float(ernorm),
-            "roofline": {"bound": "mfma", "kernel": "dgemm_mfma_kernel<7,2,2,4,16,true,true,2,1> (+ pairs, 224x128 tile) and <6,2,2,4,16,true,true,2,1> (- pairs, 192x128): pp-ladder over (+/-) packed pairs, M=npair(o) N=K=npair(v), split-K + slab reduce",
+            "roofline": {"bound": "mfma", "kernel": "dgemm_mfma_kernel<7,2,2,4,16,true,true,2,1,1> (+ pairs, 224x128 tile) and <6,2,2,4,16,true,true,2,1,1> (- pairs, 192x128): pp-ladder over (+/-) packed pairs, M=npair(o) N=K=npair(v), split-K + slab reduce",
                          "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_MFMA_TFLOPS,
                          # one pp-ladder = TWO dispatches of this kernel ((+) and (-) pair blocks); per-dispatch averages:
                          "traffic": None if traffic is None else traffic / 2.0, "traffic_source": traffic_source,

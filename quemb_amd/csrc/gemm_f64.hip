@@ -25,6 +25,7 @@
 //    logical tile order, m-tiles fastest, so the m-tiles that share one streamed B panel (W_vvvv for
 //    the ladder: 12.8 GB) run on one XCD at the same time and the panel is fetched from HBM once.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <atomic>
 #include <cstdint>
 #include <cstdio>
@@ -213,6 +214,14 @@ __device__ __forceinline__ void stage_store_chunk(const double (&reg)[NCH][VEC],
   } else {
     dst[0] = reg[C][0];
   }
+}
+
+// the value held by the neighbouring lane (lane ^ 1): two DPP moves (quad_perm [1,0,3,2]) on the halves of the double
+__device__ __forceinline__ double lane_swap_neighbour(double x) {
+  const unsigned long long u = __double_as_longlong(x);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(u & 0xffffffffu), 0xB1, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(u >> 32), 0xB1, 0xF, 0xF, false);
+  return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
 }
 
 // TAG does not change the code: it gives a call site its own kernel symbol so that profiles (rocprofv3 --stats, PMC) of the
@@ -410,19 +419,54 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64, (WM * WN <= 16) ? 2 : 1
 
   // epilogue: D reg r of lane l -> row (l>>4)+4r, col l&15 of the 16x16 tile
   const double alpha = g.alpha, beta = g.beta;
+  // A lane owns four ROWS of one column: the natural store is four 8-byte stores per 16 x 16 tile, and short-K products (the quarter
+  // transforms, K ~ 220: 14 k-tiles per 224 x 128 tile) are then bound by the ISSUE of their 56 store instructions per lane, not by
+  // bytes.  Neighbouring lanes (columns 2c, 2c+1) trade two values each -- the even lane keeps rows +0/+4, the odd lane rows +8/+12 --
+  // so that every lane stores two 16-byte pairs: half the store instructions, 1 KB instead of 512 B per wave instruction.
+  const bool wide = ((g.ldc & 1) == 0) && ((g.N & 1) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0);
+  if (wide) {
+    const bool odd = (fr & 1) != 0;
 #pragma unroll
-  for (int i = 0; i < WM; ++i) {
+    for (int i = 0; i < WM; ++i) {
 #pragma unroll
-    for (int j = 0; j < WN; ++j) {
-      const int col = n0 + (wn * WN + j) * 16 + fr;
+      for (int j = 0; j < WN; ++j) {
+        const d4 v = acc[i][j];
+        const double r0 = lane_swap_neighbour(odd ? v[0] : v[2]), r1 = lane_swap_neighbour(odd ? v[1] : v[3]);
+        const d2 pa = odd ? d2{r0, v[2]} : d2{v[0], r0};
+        const d2 pb = odd ? d2{r1, v[3]} : d2{v[1], r1};
+        const int col = n0 + (wn * WN + j) * 16 + (fr & ~1);
+        const int row = m0 + (wm * WM + i) * 16 + fk + (odd ? 8 : 0);
+        if (col < g.N) {
+          if (row < g.M) {
+            d2* p = reinterpret_cast<d2*>(C + (long long)row * g.ldc + col);
+            d2 o = {alpha * pa[0], alpha * pa[1]};
+            if (beta != 0.0) { const d2 c = *p; o[0] += beta * c[0]; o[1] += beta * c[1]; }
+            *p = o;
+          }
+          if (row + 4 < g.M) {
+            d2* p = reinterpret_cast<d2*>(C + (long long)(row + 4) * g.ldc + col);
+            d2 o = {alpha * pb[0], alpha * pb[1]};
+            if (beta != 0.0) { const d2 c = *p; o[0] += beta * c[0]; o[1] += beta * c[1]; }
+            *p = o;
+          }
+        }
+      }
+    }
+  } else {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = m0 + (wm * WM + i) * 16 + fk + 4 * r;
-        if (row < g.M && col < g.N) {
-          double* p = C + (long long)row * g.ldc + col;
-          double v = alpha * acc[i][j][r];
-          if (beta != 0.0) v += beta * (*p);
-          *p = v;
+    for (int i = 0; i < WM; ++i) {
+#pragma unroll
+      for (int j = 0; j < WN; ++j) {
+        const int col = n0 + (wn * WN + j) * 16 + fr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = m0 + (wm * WM + i) * 16 + fk + 4 * r;
+          if (row < g.M && col < g.N) {
+            double* p = C + (long long)row * g.ldc + col;
+            double v = alpha * acc[i][j][r];
+            if (beta != 0.0) v += beta * (*p);
+            *p = v;
+          }
         }
       }
     }

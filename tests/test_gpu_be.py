@@ -361,9 +361,12 @@ def test_concurrent_streams_give_identical_results(qlib):
     assert r1[2][0] == r3[2][0]
     for a, b in zip(be1.Fobjs, be3.Fobjs):
         assert np.array_equal(a._rdm1, b._rdm1) and np.array_equal(a.t1, b.t1)
-    # a second pass (warm block caches, contexts reused) and the optimiser on top of it
+    # a second pass (warm block caches, contexts reused) and the optimiser on top of it.  (The fragment RHF starts its Jacobi
+    # eigensolver in the orbitals of the fragment's previous solve, so a REPEATED sweep agrees to rounding, not bit for bit;
+    # serial against concurrent, above, is bitwise.)
     r3b = be_func(None, be3.Fobjs, be3.Nocc, "CCSD", be3.enuc, eeval=True, return_vec=True, opts=be3.opts, nstreams=3)
-    assert r3b[2][0] == r3[2][0]
+    r1b = be_func(None, be1.Fobjs, be1.Nocc, "CCSD", be1.enuc, eeval=True, return_vec=True, opts=be1.opts)
+    assert abs(r3b[2][0] - r3[2][0]) < 1e-13 and r3b[2][0] == r1b[2][0]
     opt = be3.optimize(solver="CCSD", only_chem=False)
     assert opt.err < 1e-6 and abs(be3.e_corr - (-0.5499514850769742)) < 5e-6
 

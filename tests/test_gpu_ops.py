@@ -539,8 +539,8 @@ def test_gemm_skinny_batched_as_in_update_amps(qlib):
     assert np.abs(dC.numpy((o, o, v * v)) - ref).max() < 1e-11
 
 
-@pytest.mark.parametrize("n,cfg", [(220, 13), (200, 13), (193, 13)])
-def test_gemm_mo_transform_products_at_bench_size(qlib, n, cfg):
+@pytest.mark.parametrize("n,cfg,big", [(220, 13, True), (200, 13, False), (193, 13, False), (201, 4, True)])
+def test_gemm_mo_transform_products_at_bench_size(qlib, n, cfg, big):
     """the two product shapes of mo_transform (ccsd.cpp:49-65) at 192 < n <= 224 with the 224 x 128 tile: the TN quarter transform
     Out[x',(rest)] = C[x,x'] In[(rest),x] (M = K = n, N long) and the batched slab products (M = N = K = n, batch = pairs)."""
     rng = np.random.default_rng(n)
@@ -552,7 +552,7 @@ def test_gemm_mo_transform_products_at_bench_size(qlib, n, cfg):
         # A(m,k) = C[k*n + m] (not k-contiguous), B(k,nn) = X[nn*n + k] (k-contiguous)
         check(qlib.qemb_op_gemm(n, ncol, n, 1.0, dC.ptr, n, 0, 0, dX.ptr, n, 1, 0, 0.0, dO.ptr, ncol, 0, 1))
         assert np.abs(dO.numpy((n, ncol)) - Cm.T @ X.T).max() < 1e-11 * n
-        nb = 37
+        nb = 520 if big else 37
         S = rng.standard_normal((nb, n, n))
         dS, dR = DeviceBuffer.from_numpy(S), DeviceBuffer(nb * n * n)
         check(qlib.qemb_op_gemm(n, n, n, 1.0, dS.ptr, n, 1, n * n, dC.ptr, n, 0, 0, 0.0, dR.ptr, n, n * n, nb))     # slab . C

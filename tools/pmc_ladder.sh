@@ -14,7 +14,7 @@ out = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     f = glob.glob(f"gpurun_out/pmc_{c}/*/*counter_collection.csv")[0]
     vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f))
-            if ("dgemm_mfma_kernel<7, 2, 2, 4, 16, true, true, 2, 1>" in r["Kernel_Name"] or "dgemm_mfma_kernel<6, 2, 2, 4, 16, true, true, 2, 1>" in r["Kernel_Name"])
+            if ("dgemm_mfma_kernel<7, 2, 2, 4, 16, true, true, 2, 1" in r["Kernel_Name"] or "dgemm_mfma_kernel<6, 2, 2, 4, 16, true, true, 2, 1" in r["Kernel_Name"])
             and r["Counter_Name"] == c]
     # one ladder = two GEMM dispatches (+ and - pair blocks): "hbm_bytes_per_launch" below is per LADDER (pair of dispatches)
     out[c + "_KB_mean"] = 2.0 * sum(vals) / max(len(vals), 1); out[c + "_launches"] = len(vals) // 2

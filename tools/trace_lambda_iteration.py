@@ -4,7 +4,7 @@ import csv, glob, sys
 files = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)
 rows = list(csv.DictReader(open(files[0])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-lad = [i for i, r in enumerate(rows) if "<7, 2, 2, 4, 16, true, true, 2, 1>" in r["Kernel_Name"]]
+lad = [i for i, r in enumerate(rows) if "<7, 2, 2, 4, 16, true, true, 2, 1" in r["Kernel_Name"]]
 # the densities pass after the last iteration also applies the ladder: step back a few launches to sit inside the iterations
 a, b = lad[-7], lad[-5]
 agg = {}
