@@ -1,0 +1,29 @@
+#!/bin/bash
+# The round's judged profiles in one gpurun call (run from the repo root on the GPU box): writes everything under gpurun_out/prof_<tag>/.
+#   bash tools/profile_round.sh r02
+set -e
+TAG=${1:-rXX}
+OUT=gpurun_out/prof_$TAG
+export TMPDIR=/tmp
+mkdir -p $OUT
+# 1. the bench command, one fragment in flight: per-kernel durations of kernels that own the device (agreement with the HIP-event timers)
+rm -rf gpurun_out/kt1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kt1 -- python bench.py --nstreams 1 --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_nstreams1.json 2> $OUT/bench_nstreams1.err
+cp gpurun_out/kt1/*/*kernel_stats.csv $OUT/bench_nstreams1_kernel_stats.csv
+rm -rf gpurun_out/kt1
+# 2. the default bench command (three fragments in flight: kernels of different streams overlap, durations are contended)
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kt3 -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_default.json 2> $OUT/bench_default.err
+cp gpurun_out/kt3/*/*kernel_stats.csv $OUT/bench_default_kernel_stats.csv
+rm -rf gpurun_out/kt3
+# 3. one CCSD iteration, kernel by kernel
+rocprofv3 --kernel-trace --output-format csv -d gpurun_out/kt -- python tools/frag_bench.py 220 20 > $OUT/frag_bench.log 2>&1
+python tools/trace_iteration.py gpurun_out/kt > $OUT/iteration_kernel_trace.txt
+rm -rf gpurun_out/kt
+# 4. HBM traffic of the ladder dispatches (FETCH_SIZE / WRITE_SIZE, separate passes)
+bash tools/pmc_ladder.sh > $OUT/pmc_ladder.log 2>&1
+cp gpurun_out/pmc_ladder.json $OUT/pmc_ladder.json
+# 5. SQ / GRBM counters of the GEMM main-loop variants
+bash tools/gemm_pmc.sh > $OUT/gemm_pmc.txt 2>&1
+cp gpurun_out/gemm_pmc.json $OUT/gemm_pmc.json
+python tools/gemm_modes.py 5 > $OUT/gemm_modes.jsonl 2>&1
+echo done
