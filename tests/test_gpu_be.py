@@ -1,5 +1,7 @@
 """-m gpu: ERI transforms, Schmidt decomposition and the whole BE driver on the MI355X against the oracle and the
 reference's end-to-end golden energies (H8 and octane, STO-3G)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -436,3 +438,71 @@ def test_sparse_df_from_geometry_h8_and_octane(qlib):
     print(f"H8 BE2 one-shot: |E(DF) - E(in-core)| = {errs[0]:.3e} (s aux on H) -> {errs[1]:.3e} (s,p,d aux on H)")
     errs = check_sparse_df_from_geometry(qlib, atoms=str(GOLDEN / "octane.xyz"), frag_key="test_autogen_octane_be2", tol=1e-8)
     print(f"octane BE2 one-shot: |E(DF) - E(in-core)| = {errs[0]:.3e} (H: s, C: s,p) -> {errs[1]:.3e} (H: s,p,d, C: s,p,d,f)")
+
+
+def test_transforms_at_survey_sizes(qlib):
+    """BASELINE configs[3] at its full size: the dense AO -> fragment transform at N_ao = 256 (s8 input) and the
+    density-fitted one at N_ao = 512, n_aux = 1000, both to an n = 220 fragment, against a NumPy evaluation of the same integrals
+    through their factorised form (ij|kl) = sum_P b_P,ij b_P,kl, b = TA^T B TA (with (P|Q)^-1/2 folded in for DF)."""
+    from quemb_amd import eri_transform as et
+    rng = np.random.default_rng(20260803)
+    n = 220
+    iln = np.tril_indices(n)
+    # ---- a3: dense, 8-fold packed input
+    N = 256
+    npair = N * (N + 1) // 2
+    B = 0.06 * rng.standard_normal((64, npair))
+    s4 = B.T @ B
+    s8 = s4[np.tril_indices(npair)]
+    del s4
+    TA = np.linalg.qr(rng.standard_normal((N, N)))[0][:, :n].copy()
+    ao = et.AOEri(s8, N, lib=qlib)
+    out = ao.transform(TA, want_host=True)
+    ao.free()
+    il = np.tril_indices(N)
+    Bf = np.zeros((64, N, N)); Bf[:, il[0], il[1]] = B; Bf = Bf + Bf.transpose(0, 2, 1); Bf[:, np.arange(N), np.arange(N)] *= 0.5
+    b = np.einsum("Ppq,pi,qj->Pij", Bf, TA, TA, optimize=True)[:, iln[0], iln[1]]
+    ref = b.T @ b
+    assert np.abs(out - ref).max() < 1e-11 * max(1.0, np.abs(ref).max())
+    # ---- a4: density fitted, n_aux = 1000
+    N, naux = 512, 1000
+    npair = N * (N + 1) // 2
+    ints = 0.06 * rng.standard_normal((naux, npair))
+    A = rng.standard_normal((naux, naux)) / np.sqrt(naux)
+    j2c = A @ A.T + np.eye(naux)
+    TA = np.linalg.qr(rng.standard_normal((N, N)))[0][:, :n].copy()
+    df = et.DFContext(j2c=j2c, lib=qlib)
+    df.set_ints(ints, N, layout="packed")
+    out = df.transform(TA, want_host=True)
+    df.free()
+    il = np.tril_indices(N)
+    Bf = np.zeros((naux, N, N)); Bf[:, il[0], il[1]] = ints; Bf = Bf + Bf.transpose(0, 2, 1); Bf[:, np.arange(N), np.arange(N)] *= 0.5
+    b = np.einsum("Ppq,pi,qj->Pij", Bf, TA, TA, optimize=True)[:, iln[0], iln[1]]
+    bp = np.linalg.solve(np.linalg.cholesky(j2c), b)
+    ref = bp.T @ bp
+    assert np.abs(out - ref).max() < 1e-11 * max(1.0, np.abs(ref).max())
+
+
+def test_rccl_all_reduce_branch_single_rank(qlib):
+    """The `nccl` (= RCCL) branch of be_parallel.all_reduce_sum -- device tensor, all-reduce, failure slot -- on a one-rank process
+    group (the boxes of this pool have one GPU; the 8-GPU run is the driver's): values survive the round trip and a rank-local
+    failure comes back as RankFailure."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from quemb_amd import be_parallel
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        buf = np.arange(37, dtype=np.float64) * 0.5
+        keep = buf.copy()
+        be_parallel.all_reduce_sum(buf, force=True)
+        assert np.array_equal(buf, keep)
+        with pytest.raises(be_parallel.RankFailure):
+            be_parallel.all_reduce_sum(buf, error=ValueError("fragment 3 did not converge"), force=True)
+        assert dist.get_backend() == "nccl"
+    finally:
+        dist.destroy_process_group()
