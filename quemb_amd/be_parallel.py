@@ -7,6 +7,11 @@ role of `order_by_size`, molbe/fragment.py:68-70), every rank keeps its fragment
 the ONLY exchange per sweep is one sum-all-reduce (RCCL over xGMI under backend "nccl") of the residual buffer
     [edge_vals (n_match), cen_vals (n_match), sum centre diag, e1, e2, ec, n_iter]
 where each rank writes the slots its fragments own (ErrorMap) and zeros elsewhere -- a few kB, latency bound.
+
+Process set-up for RCCL: create the process group (`dist.init_process_group("nccl", device_id=...)`, or at least `torch.cuda.init()`)
+BEFORE the first `quemb_amd` call that touches the device.  torch and libqemb_hip.so each bring a HIP runtime under one SONAME; loaded in
+that order they share torch's, the other way round `torch.cuda` finds no device afterwards (measured on the MI355X boxes of this pool).
+bench.py and tests/conftest.py follow that order.
 """
 
 from __future__ import annotations
