@@ -45,6 +45,11 @@ int qemb_set_gemm_splitk(int enabled);    /* automatic split-K for few-tile / lo
  * 13/15/23/25), a multiple of it otherwise.  Synchronises; a measuring aid for bench.py / tools, not part of the solver path.        */
 int qemb_op_gemm_probe(int64_t M, int64_t N, int64_t K, const double* A, int64_t lda, int a_kcontig, const double* B, int64_t ldb, int b_kcontig,
                        double* C, int64_t ldc, int cfg, int ksplit, double* ms, double* clock_ghz, int64_t* workgroups);
+/* diagnostic tile configurations 313 / 315 / 304 (8-wave tiles, both operands K-contiguous): per-wave s_memtime sums of one launch, averaged over its
+ * waves: out7 = [cycles in k-steps 0..2 of the tiles, from there to past the per-tile barrier, in the last k-step, kernel ms, wave entry -> end of the
+ * main loop, wave entry -> exit, workgroups] (sums over the k-tiles of a wave) */
+int qemb_op_gemm_stamps(int64_t M, int64_t N, int64_t K, const double* A, int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc, int cfg,
+                        int ksplit, double* out7);
 int qemb_set_gemm_ksplit(int ksplit);      /* explicit split-K factor for qemb_op_gemm (0 = automatic) */
 /* out[sum ik*so[k]] = alpha*in[sum ik*si[k]] + beta*out[...], 0<=ik<dim[k], 4 dims                  */
 int qemb_op_copy4(const int64_t dim[4], const double* in, const int64_t si[4], double* out,

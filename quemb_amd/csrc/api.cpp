@@ -54,6 +54,11 @@ int qemb_op_gemm_probe(int64_t M, int64_t N, int64_t K, const double* A, int64_t
   if (workgroups) *workgroups = wg;
   return rc;
 }
+int qemb_op_gemm_stamps(int64_t M, int64_t N, int64_t K, const double* A, int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc, int cfg, int ksplit,
+                        double* out7) {
+  GemmDesc g{M, N, K, 1.0, 0.0, A, lda, 1, 0, B, ldb, 1, 0, C, ldc, 0, 1, cfg, ksplit};
+  return dev_gemm_stamps(g, 8, out7);
+}
 int qemb_set_gemm_ksplit(int ks) { g_test_ksplit = ks; return QEMB_OK; }
 int qemb_set_gemm_config(int cfg) { dev_gemm_set_force_cfg(cfg); return QEMB_OK; }
 #ifndef QEMB_HOSTCHECK

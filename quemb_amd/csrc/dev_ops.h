@@ -94,6 +94,8 @@ void dev_gemm_set_force_cfg(int cfg);
 void dev_gemm_set_auto_splitk(int enabled);
 // one product timed on its own with the sustained shader clock read back (see gemm_f64.hip); syncs the stream -- a measuring aid
 int dev_gemm_probe(const GemmDesc& g, double* ms, double* ghz, long long* workgroups);
+// diagnostic tile configurations (3xx): per-wave s_memtime sums around the per-tile barrier, averaged over the waves of one launch
+int dev_gemm_stamps(const GemmDesc& g, int waves_per_wg, double* out7);
 
 // ---- strided tensor copy / add (up to 4 dims) -------------------------------------------------
 // out[i0*so[0]+i1*so[1]+i2*so[2]+i3*so[3]] = alpha * in[i0*si[0]+...+i3*si[3]] + beta * out[...]

@@ -54,6 +54,7 @@ struct GemmKArgs {
   int tiles_m, tiles_n;
   int ksplit, kchunk;      // split-K: blockIdx.y = batch * ksplit + slice; slice s covers k in [s*kchunk, (s+1)*kchunk)
   double alpha, beta;
+  long long* cyc2;         // TAG == 2: prologue stamps
   long long* cyc;          // debugging (QEMB_GEMM_TRACE): per-workgroup shader-clock ticks, or nullptr
 };
 
@@ -229,7 +230,7 @@ __device__ __forceinline__ double lane_swap_neighbour(double x) {
 template <int WM, int WN, int WAVES_M, int WAVES_N, int BK, bool A_KC, bool B_KC, int VEC, int TAG = 0, int MODE = 0>
 __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64, (WM * WN <= 16) ? 2 : 1)
     dgemm_mfma_kernel(GemmKArgs g) {
-  const long long t_start = g.cyc ? clock64() : 0;
+  const long long t_start = g.cyc ? (long long)__builtin_amdgcn_s_memtime() : 0;
   constexpr int BM = WM * 16 * WAVES_M;
   constexpr int BN = WN * 16 * WAVES_N;
   constexpr int T = WAVES_M * WAVES_N * 64;
@@ -298,13 +299,18 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64, (WM * WN <= 16) ? 2 : 1
   };
 
   // prologue: tile 0 -> LDS buffer 0; with a two-deep operand, tile 1 is already requested
+  long long pst[4] = {0, 0, 0, 0};     // TAG == 2: prologue stamps
+  if constexpr (TAG == 2) pst[0] = __builtin_amdgcn_s_memtime();
   stage_load<BM, BK, A_KC, VEC, T, NCH_A>(ra[0], A, g.lda, m0, kbeg, g.M, kend, tid);
   stage_load<BN, BK, B_KC, VEC, T, NCH_B>(rb[0], B, g.ldb, n0, kbeg, g.N, kend, tid);
   stage_store<BM, BK, A_KC, VEC, T, NCH_A>(ra[0], sA0, tid);
   stage_store<BN, BK, B_KC, VEC, T, NCH_B>(rb[0], sB0, tid);
+  if constexpr (TAG == 2) pst[1] = __builtin_amdgcn_s_memtime();
   if (DA == 2 || MODE == 1) fetch_a(ra[DA - 1], 1);
   if (DB == 2 || MODE == 1) fetch_b(rb[DB - 1], 1);
+  if constexpr (TAG == 2) pst[2] = __builtin_amdgcn_s_memtime();
   __syncthreads();
+  if constexpr (TAG == 2) pst[3] = __builtin_amdgcn_s_memtime();
 
   const int fr = lane & 15, fk = lane >> 4;
   if constexpr (MODE == 1) {
@@ -322,6 +328,7 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64, (WM * WN <= 16) ? 2 : 1
     // 0 of the next tile from the other buffer) issued underneath.  The very last k-step of the slice issues them too -- they read
     // whatever the other buffer holds and are never used -- so that the loop body is one straight instruction stream (a second copy of
     // the k-step without the reads makes the register allocator shuffle the accumulators between the two copies and spill).
+    long long st_work = 0, st_bar = 0, st_last = 0, st_t0 = 0;   // TAG == 2 (diagnostic instantiation): per-wave s_memtime stamps
     auto kstep = [&](auto ks_c, auto p_c, auto&& after_row) {
       constexpr int KS = decltype(ks_c)::value, P = decltype(p_c)::value;
       constexpr int S = KS & 1;                                   // B fragment set in use
@@ -362,17 +369,30 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64, (WM * WN <= 16) ? 2 : 1
           });
         }
       };
+      long long ts0 = 0;
+      if constexpr (TAG == 2) ts0 = __builtin_amdgcn_s_memtime();
       static_for<0, NKS - 1>([&](auto ks) { kstep(ks, parity, stores); });
       // the staging registers are free again: request tile kt + 2 now -- it is stored during k-step NKS - 2 of the NEXT tile, NKS - 1
       // k-steps of MFMAs away (the loads behind the vmcnt wait of this tile's stores were issued that long ago)
       fetch_a(ra[0], kt + 2);
       fetch_b(rb[0], kt + 2);
+      long long ts1 = 0;
+      if constexpr (TAG == 2) ts1 = __builtin_amdgcn_s_memtime();
       __syncthreads();   // (also drains this wave's fragment reads of k-step NKS - 1: nobody reads this tile's buffer after the barrier)
+      if constexpr (TAG == 2) { const long long ts2 = __builtin_amdgcn_s_memtime(); st_work += ts1 - ts0; st_bar += ts2 - ts1; st_t0 = ts2; }
       kstep(std::integral_constant<int, NKS - 1>{}, parity, stores);
+      if constexpr (TAG == 2) st_last += __builtin_amdgcn_s_memtime() - st_t0;
     };
     for (int kt = 0; kt < nk; kt += 2) {
       tile(std::integral_constant<int, 0>{}, kt);
       if (kt + 1 < nk) tile(std::integral_constant<int, 1>{}, kt + 1);
+    }
+    if constexpr (TAG == 2) {
+      if (g.cyc && lane == 0) {     // [workgroup][wave][3]: cycles in k-steps 0..NKS-2 (+ LDS stores), at the barrier (+ fetch issue), in the last k-step
+        long long* o = g.cyc + (((long long)blockIdx.y * gridDim.x + blockIdx.x) * (WAVES_M * WAVES_N) + wave) * 4;
+        o[0] = st_work; o[1] = st_bar; o[2] = st_last; o[3] = (long long)__builtin_amdgcn_s_memtime() - t_start;   // o[3]: kernel entry -> end of the main loop
+        if (g.cyc2) { long long* q = g.cyc2 + (((long long)blockIdx.y * gridDim.x + blockIdx.x) * (WAVES_M * WAVES_N) + wave) * 4; q[0] = pst[0] - t_start; q[1] = pst[1] - pst[0]; q[2] = pst[2] - pst[1]; q[3] = pst[3] - pst[2]; }
+      }
     }
     // the run-ahead reads of the final k-step are still in flight: let them land before the fragment registers are reused
     static_for<0, WN>([&](auto j) { lds_wait<0>(b[0][decltype(j)::value]); lds_wait<0>(b[1][decltype(j)::value]); });
@@ -471,7 +491,8 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64, (WM * WN <= 16) ? 2 : 1
       }
     }
   }
-  if (g.cyc && threadIdx.x == 0) g.cyc[(long long)blockIdx.y * gridDim.x + blockIdx.x] = clock64() - t_start;
+  if (TAG != 2 && g.cyc && threadIdx.x == 0) g.cyc[(long long)blockIdx.y * gridDim.x + blockIdx.x] = (long long)__builtin_amdgcn_s_memtime() - t_start;
+  if (TAG == 2 && g.cyc && lane == 0) g.cyc[(long long)gridDim.x * gridDim.y * (WAVES_M * WAVES_N) * 4 + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * (WAVES_M * WAVES_N) + wave] = (long long)__builtin_amdgcn_s_memtime() - t_start;   // whole wave lifetime
 }
 
 // C[b][m][n] = alpha * sum_s ws[b][s][m][n] + beta * C   (fixed summation order: deterministic)
@@ -530,7 +551,7 @@ static int launch_cfg(const GemmDesc& d, hipStream_t s) {
   g.tiles_m = (int)((d.M + BM - 1) / BM);
   g.tiles_n = (int)((d.N + BN - 1) / BN);
   g.alpha = d.alpha; g.beta = d.beta;
-  g.cyc = nullptr;
+  g.cyc = nullptr; g.cyc2 = nullptr;
   // split-K when the output has too few tiles to occupy 256 CUs but K is long (the o x v, o x o, v x v shaped
   // CCSD intermediates contract over o*v^2 ... v^2 indices)
   g.ksplit = 1; g.kchunk = g.K > 0 ? g.K : 1;
@@ -564,7 +585,7 @@ static int launch_cfg(const GemmDesc& d, hipStream_t s) {
   }
   dim3 grid((unsigned)(g.tiles_m * g.tiles_n), (unsigned)(d.batch * g.ksplit), 1);
   dim3 block(WAVES_M * WAVES_N * 64, 1, 1);
-  if (g_gemm_cyc_on && g_gemm_cyc && (long long)grid.x * grid.y <= g_gemm_cyc_cap) { g.cyc = g_gemm_cyc; g_gemm_cyc_blocks = (long long)grid.x * grid.y; }
+  if (g_gemm_cyc_on && g_gemm_cyc && (long long)grid.x * grid.y * (TAG == 2 ? 72 : 1) <= g_gemm_cyc_cap) { g.cyc = g_gemm_cyc; g_gemm_cyc_blocks = (long long)grid.x * grid.y; if (TAG == 2) g.cyc2 = g_gemm_cyc + (long long)grid.x * grid.y * (WAVES_M * WAVES_N) * 5; }
   hipLaunchKernelGGL(kern, grid, block, lds, s, g);
   if (g.ksplit > 1) {
     const long long mn = d.M * d.N;
@@ -688,6 +709,38 @@ int dev_gemm_probe(const GemmDesc& d, double* ms_out, double* ghz_out, long long
   return rc;
 }
 
+// One launch of a diagnostic (TAG 2) tile configuration; returns the per-wave stamp sums averaged over all waves:
+// out[0] = cycles in k-steps 0..NKS-2, out[1] = cycles from there to past the barrier, out[2] = cycles in the last k-step, out[3] = kernel ms
+int dev_gemm_stamps(const GemmDesc& d, int waves_per_wg, double* out) {
+  hipStream_t s = hip_stream();
+  if (!g_gemm_cyc) { g_gemm_cyc_cap = 1 << 20; if (hipMalloc((void**)&g_gemm_cyc, sizeof(long long) * g_gemm_cyc_cap) != hipSuccess) { g_gemm_cyc = nullptr; set_error("dev_gemm_stamps: no buffer"); return QEMB_ERR_ALLOC; } }
+  HIP_TRY(hipMemsetAsync(g_gemm_cyc, 0, sizeof(long long) * g_gemm_cyc_cap, s));
+  hipEvent_t t0, t1;
+  HIP_TRY(hipEventCreate(&t0)); HIP_TRY(hipEventCreate(&t1));
+  g_gemm_cyc_blocks = 0; g_gemm_cyc_on = true;
+  (void)hipEventRecord(t0, s);
+  const int rc = dev_gemm_dispatch(d);
+  (void)hipEventRecord(t1, s);
+  (void)hipEventSynchronize(t1);
+  g_gemm_cyc_on = false;
+  float ms = 0.f; (void)hipEventElapsedTime(&ms, t0, t1);
+  (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
+  if (rc) return rc;
+  const size_t nw_ = (size_t)g_gemm_cyc_blocks * waves_per_wg;
+  std::vector<long long> h(nw_ * 9);
+  HIP_TRY(hipMemcpy(h.data(), g_gemm_cyc, sizeof(long long) * h.size(), hipMemcpyDeviceToHost));
+  double sum[5] = {0, 0, 0, 0, 0};
+  for (size_t w = 0; w < nw_; ++w) { for (int k = 0; k < 4; ++k) sum[k] += (double)h[w * 4 + k]; sum[4] += (double)h[nw_ * 4 + w]; }
+  const double nw = (double)nw_;
+  for (int k = 0; k < 3; ++k) out[k] = nw > 0 ? sum[k] / nw : 0.0;
+  out[4] = nw > 0 ? sum[3] / nw : 0.0;      // entry -> end of main loop
+  out[5] = nw > 0 ? sum[4] / nw : 0.0;      // entry -> exit
+  out[6] = (double)g_gemm_cyc_blocks;
+  for (int k = 0; k < 4; ++k) { double t = 0; for (size_t w = 0; w < nw_; ++w) t += (double)h[nw_ * 5 + w * 4 + k]; out[7 + k] = nw > 0 ? t / nw : 0.0; }
+  out[3] = ms;
+  return QEMB_OK;
+}
+
 // QEMB_GEMM_TRACE=1: every product goes through dev_gemm_probe and is logged -- a debugging aid, not a mode to run in
 int dev_gemm(const GemmDesc& d) {
   static const bool trace = std::getenv("QEMB_GEMM_TRACE") != nullptr;
@@ -742,6 +795,10 @@ static int dev_gemm_dispatch(const GemmDesc& d) {
     case 23: return launch_layout<7, 2, 2, 4, 16, 1, 1>(d, s, vec2);   // = 13 under its own kernel symbol (pp-ladder, + pairs)
     case 25: return launch_layout<6, 2, 2, 4, 16, 1, 1>(d, s, vec2);   // = 15 under its own kernel symbol (pp-ladder, - pairs)
     // the classic main loop of the same tiles, kept addressable for A/B measurements (tools/gemm_modes.py)
+    // diagnostic instantiations (TAG 2): per-wave s_memtime stamps around the per-tile barrier, read by qemb_op_gemm_stamps
+    case 313: return launch_layout<7, 2, 2, 4, 16, 2, 1>(d, s, vec2);
+    case 315: return launch_layout<6, 2, 2, 4, 16, 2, 1>(d, s, vec2);
+    case 304: return launch_layout<4, 4, 2, 4, 16, 2, 1>(d, s, vec2);
     case 200: return launch_layout<4, 4, 2, 2, 16>(d, s, vec2);
     case 204: return launch_layout<4, 4, 2, 4, 16>(d, s, vec2);
     case 213: return launch_layout<7, 2, 2, 4, 16>(d, s, vec2);

@@ -22,6 +22,7 @@ static thread_local std::string g_err;
 void set_error(const std::string& m) { g_err = m; }
 const char* last_error() { return g_err.c_str(); }
 const char* dev_backend_name() { return "hostcheck"; }
+int dev_gemm_stamps(const GemmDesc&, int, double*) { set_error("dev_gemm_stamps: not available in the hostcheck build"); return QEMB_ERR_DEVICE; }
 void dev_gemm_set_force_cfg(int) {}
 void dev_gemm_set_auto_splitk(int) {}
 

@@ -31,7 +31,8 @@ def _gemm(lib, A, B, Cm, alpha, beta, a_kc, b_kc, batch=1, cfg=-1):
 
 @pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 4, 10, 11, 12, 200, 204])
 @pytest.mark.parametrize("a_kc,b_kc", [(1, 1), (1, 0), (0, 1), (0, 0)])
-@pytest.mark.parametrize("shape", [(128, 128, 64), (400, 300, 200), (37, 53, 29), (441, 441, 441), (1, 220, 96), (130, 258, 18)])
+@pytest.mark.parametrize("shape", [(128, 128, 64), (400, 300, 200), (37, 53, 29), (441, 441, 441), (1, 220, 96), (130, 258, 18),
+                                   (66, 130, 6), (64, 64, 16), (50, 70, 5)])      # the last three: a single k-tile (no second LDS buffer is ever filled)
 def test_gemm_matches_numpy(qlib, cfg, a_kc, b_kc, shape):
     M, N, K = shape
     rng = np.random.default_rng(1234 + M + 7 * N + 13 * K)
