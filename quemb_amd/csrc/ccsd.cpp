@@ -52,7 +52,10 @@ int mo_transform(int n, int o, int nf, const double* eri_s4, double* X0, double*
   // the last two quarter transforms act on the n x n slab of every pair (r's'): two batched GEMMs, slab <- C^T slab C, which
   // leave the pair index IN FRONT -- every gather below then reads contiguous runs
   const int64_t n2 = (int64_t)n * n;
-  QTRY(gemm(n, n, n, 1.0, X0, n, true, C, n, false, 0.0, X1, n, np, n2, 0, n2, tcfg));      // X1[(r's')][P][q'] = sum_q X0[..][P][q] C[q,q']
+  // X1[(r's')][P][q'] = sum_q X0[..][P][q] C[q,q']: the slabs are contiguous, so this is ONE tall product over the np * n rows ((r's'),P) with
+  // all n columns in a 128 x 224 tile (as a batch of n x n x n products on the 224 x 128 tile the second column tile is 72 % padding at n = 220)
+  if (n > 192 && n <= 224) { QTRY(gemm(np * n, n, n, 1.0, X0, n, true, C, n, false, 0.0, X1, n, 1, 0, 0, 0, 34)); }
+  else QTRY(gemm(n, n, n, 1.0, X0, n, true, C, n, false, 0.0, X1, n, np, n2, 0, n2, tcfg));
   if (nf > 0 && build_T34) {   // every (P q'|r' s') as T34[q'][r'][s'][P]: the operand of CcLambda::densities
     QTRY(out.T34.alloc((int64_t)n * n * n * nf));
     QTRY(dev_extract_pf_t(n, X1, 0, 0, 0, 0, n, n, n, nf, out.T34));

@@ -343,7 +343,8 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64, (WM * WN <= 16) ? 2 : 1
         lds_wait<NW>(a[I]);
 #pragma unroll
         for (int j = 0; j < WN; ++j) acc[I][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[I], b[S][j], acc[I][j], 0, 0, 0);
-        lds_read_f64<ImgA::off(I * 16, KSn * 4) * 8>(a[I], ldsA[Pn]);
+        if constexpr (!((TAG == 4 || TAG == 5) && (I & 1)))     // (ablation instantiations 4 / 5: every other A fragment is not re-read)
+          lds_read_f64<ImgA::off(I * 16, KSn * 4) * 8>(a[I], ldsA[Pn]);
         after_row(ks_c, i);
       });
     };
@@ -374,8 +375,10 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64, (WM * WN <= 16) ? 2 : 1
       static_for<0, NKS - 1>([&](auto ks) { kstep(ks, parity, stores); });
       // the staging registers are free again: request tile kt + 2 now -- it is stored during k-step NKS - 2 of the NEXT tile, NKS - 1
       // k-steps of MFMAs away (the loads behind the vmcnt wait of this tile's stores were issued that long ago)
-      fetch_a(ra[0], kt + 2);
-      fetch_b(rb[0], kt + 2);
+      if constexpr (TAG != 3 && TAG != 5) {     // (ablation instantiations 3 / 5: no global loads in the main loop)
+        fetch_a(ra[0], kt + 2);
+        fetch_b(rb[0], kt + 2);
+      }
       long long ts1 = 0;
       if constexpr (TAG == 2) ts1 = __builtin_amdgcn_s_memtime();
       __syncthreads();   // (also drains this wave's fragment reads of k-step NKS - 1: nobody reads this tile's buffer after the barrier)
@@ -775,6 +778,8 @@ static int dev_gemm_dispatch(const GemmDesc& d) {
   else if (t64 >= 256) cfg = 1;
   else if (d.M >= 128 && d.N >= 128 && d.K >= 4096) cfg = 1;   // few tiles but a long K: split-K supplies the workgroups (200 x 200 x 80000: 0.24 vs 0.29 ms)
   else cfg = 2;
+  // tall products with 193..224 columns: ONE 224-wide column tile (128 x 224) instead of two 128-wide ones, 12.5 % of which would be padding
+  if (vec2 && d.N > 192 && d.N <= 224 && d.M >= 128 * 512) cfg = 34;
   if (d.cfg >= 0) cfg = d.cfg;
   if (t_gemm_force_cfg >= 0) cfg = t_gemm_force_cfg;
   // The large tiles run the MODE 1 main loop (explicit one-k-step-ahead LDS fragment reads, LDS stores spread behind the MFMA rows) when
@@ -790,6 +795,8 @@ static int dev_gemm_dispatch(const GemmDesc& d) {
     case 12: return launch_layout<4, 1, 1, 8, 16>(d, s, vec2);  //  64 x 128, 8 waves
     case 13: return launch_layout<7, 2, 2, 4, 16, 0, 1>(d, s, vec2);  // 224 x 128, 8 waves as 2 x 4: 9 LDS fragment reads per 14 MFMAs (15 for cfg 10)
     case 15: return launch_layout<6, 2, 2, 4, 16, 0, 1>(d, s, vec2);  // 192 x 128, 8 waves as 2 x 4 (the 190 antisymmetric pair rows of o = 20)
+    case 33: return launch_layout<7, 2, 1, 4, 16, 0, 1>(d, s, vec2);  // 112 x 128, 4 waves, TWO workgroups per CU (66 KB of LDS each): short-K products
+    case 34: return launch_layout<2, 7, 4, 2, 16, 0, 1>(d, s, vec2);  // 128 x 224, 8 waves as 4 x 2 (2 x 7 MFMA tiles per wave): tall products with 192 < N <= 224
     case 20: return launch_layout<4, 1, 2, 2, 16>(d, s, vec2);   // 128 x  32, 4 waves: tall products with N = n_occ (the t1 contractions of ovvv)
     case 21: return launch_layout<1, 4, 2, 2, 16>(d, s, vec2);   //  32 x 128, 4 waves: the same with M = n_occ
     case 23: return launch_layout<7, 2, 2, 4, 16, 1, 1>(d, s, vec2);   // = 13 under its own kernel symbol (pp-ladder, + pairs)
@@ -799,6 +806,14 @@ static int dev_gemm_dispatch(const GemmDesc& d) {
     case 313: return launch_layout<7, 2, 2, 4, 16, 2, 1>(d, s, vec2);
     case 315: return launch_layout<6, 2, 2, 4, 16, 2, 1>(d, s, vec2);
     case 304: return launch_layout<4, 4, 2, 4, 16, 2, 1>(d, s, vec2);
+    // ablation instantiations (WRONG results by construction; tools/gemm_ablation.py): 3 = no global loads in the main loop, 4 = half of the
+    // A fragment reads, 5 = both -- what the clock the chip holds under the kernel owes to HBM / L2 traffic and to LDS reads
+    case 413: return launch_layout<7, 2, 2, 4, 16, 3, 1>(d, s, vec2);
+    case 513: return launch_layout<7, 2, 2, 4, 16, 4, 1>(d, s, vec2);
+    case 613: return launch_layout<7, 2, 2, 4, 16, 5, 1>(d, s, vec2);
+    case 404: return launch_layout<4, 4, 2, 4, 16, 3, 1>(d, s, vec2);
+    case 504: return launch_layout<4, 4, 2, 4, 16, 4, 1>(d, s, vec2);
+    case 604: return launch_layout<4, 4, 2, 4, 16, 5, 1>(d, s, vec2);
     case 200: return launch_layout<4, 4, 2, 2, 16>(d, s, vec2);
     case 204: return launch_layout<4, 4, 2, 4, 16>(d, s, vec2);
     case 213: return launch_layout<7, 2, 2, 4, 16>(d, s, vec2);

@@ -29,7 +29,7 @@ def _gemm(lib, A, B, Cm, alpha, beta, a_kc, b_kc, batch=1, cfg=-1):
     return dC.numpy(Cm.shape)
 
 
-@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 4, 10, 11, 12, 200, 204])
+@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 4, 10, 11, 12, 33, 34, 200, 204])
 @pytest.mark.parametrize("a_kc,b_kc", [(1, 1), (1, 0), (0, 1), (0, 0)])
 @pytest.mark.parametrize("shape", [(128, 128, 64), (400, 300, 200), (37, 53, 29), (441, 441, 441), (1, 220, 96), (130, 258, 18),
                                    (66, 130, 6), (64, 64, 16), (50, 70, 5)])      # the last three: a single k-tile (no second LDS buffer is ever filled)
@@ -481,7 +481,7 @@ def test_gather_and_scale_rows(qlib):
 # cfg 15 / 25: 192 x 128 tile (6 x 2 per wave) -- the (-) pair block (M = 190);
 # cfg 20 / 21: 128 x 32 / 32 x 128 tiles -- the products with an n_occ-sized side (ccsd.cpp:249).
 # 23 / 25 are 13 / 15 under the ladder's own kernel symbol (ccsd.cpp:217), i.e. separately compiled instantiations.
-@pytest.mark.parametrize("cfg,M", [(13, 210), (23, 210), (13, 224), (13, 220), (15, 190), (25, 190), (15, 192), (23, 97), (213, 210), (215, 190)])
+@pytest.mark.parametrize("cfg,M", [(13, 210), (23, 210), (13, 224), (13, 220), (15, 190), (25, 190), (15, 192), (23, 97), (213, 210), (215, 190), (33, 220), (33, 112), (33, 113)])
 @pytest.mark.parametrize("a_kc,b_kc", [(1, 1), (1, 0), (0, 1), (0, 0)])
 @pytest.mark.parametrize("ks", [0, 8])
 def test_gemm_ladder_tile_configs(qlib, cfg, M, a_kc, b_kc, ks):
@@ -540,7 +540,20 @@ def test_gemm_skinny_batched_as_in_update_amps(qlib):
     assert np.abs(dC.numpy((o, o, v * v)) - ref).max() < 1e-11
 
 
-@pytest.mark.parametrize("n,cfg,big", [(220, 13, True), (200, 13, False), (193, 13, False), (201, 4, True)])
+@pytest.mark.parametrize("n", [220, 224, 200, 193])
+@pytest.mark.parametrize("a_kc,b_kc", [(1, 0), (1, 1), (0, 0)])
+def test_gemm_tall_products_on_the_128x224_tile(qlib, n, a_kc, b_kc):
+    """cfg 34: M long, 192 < N <= 224 columns in ONE tile (the flat slab . C product of mo_transform), K = n with a k-tail."""
+    rng = np.random.default_rng(34 + n + a_kc + 2 * b_kc)
+    M = 5 * 128 + 77
+    A = rng.standard_normal((1, M, n)); B = rng.standard_normal((1, n, n)); C0 = rng.standard_normal((1, M, n))
+    got = _gemm(qlib, A, B, C0, 1.0, 0.0, a_kc, b_kc, cfg=34)
+    assert np.abs(got - A @ B).max() < 1e-11 * n
+    got = _gemm(qlib, A, B, C0, -0.5, 2.0, a_kc, b_kc, cfg=34)
+    assert np.abs(got - (-0.5 * (A @ B) + 2.0 * C0)).max() < 1e-11 * n
+
+
+@pytest.mark.parametrize("n,cfg,big", [(220, 13, True), (200, 13, False), (193, 13, False), (201, 4, True), (220, 33, True), (222, 33, False)])
 def test_gemm_mo_transform_products_at_bench_size(qlib, n, cfg, big):
     """the two product shapes of mo_transform (ccsd.cpp:49-65) at 192 < n <= 224 with the 224 x 128 tile: the TN quarter transform
     Out[x',(rest)] = C[x,x'] In[(rest),x] (M = K = n, N long) and the batched slab products (M = N = K = n, batch = pairs)."""
