@@ -148,6 +148,24 @@ int qemb_df_transform(qemb_df_t df, const double* TA, int n, double* out_s4_host
 int qemb_df_transform_screened(qemb_df_t df, const double* TA, int n, const double* S_abs, double MO_coeff_epsilon,
                                double* out_s4_host, qemb_frag_t frag);
 
+/* Gamma-point periodic (CC-GDF) variant of the direct DF transform, kbe/eri_onthefly.py:48-241.
+ * qemb_df_create_pbc: _j2c_cholesky_or_eig (:19-45) -- the periodic metric may be indefinite: Cholesky when it succeeds (*ischol = 1),
+ *   otherwise the fit matrix V d^{-1/2} V^T over the eigenvalues d > 1e-14 (*ischol = 0); bb = L^{-1} b or bb = fit b (:222-227).
+ * qemb_df_alloc_ints: zeroed fitted tensor (L|mu nu), real and imaginary part (`pqL_frag`, :152-155, held once at the AO level:
+ *   TA^T [sum_G F (G|mu nu)] TA = sum_G F (TA^T (G|mu nu) TA), so the per-fragment transform of every plane-wave block is not needed).
+ * qemb_df_add_pw_block: += sum_G F[L,G] (G|mu nu) for nG plane waves (:176-199); F = ft_ao(chgcell, Gv)^H as naux x nG (re, im),
+ *   (G|mu nu) = ft_aopair * coulG^* as nG x N x N (re, im).
+ * qemb_df_add_rs_block: rows [p0, p1) += the real-space block (aux_e2(auxcell) - aux_e2(chgcell), :85-103, :201-217) as (p1-p0) x N x N.
+ * qemb_df_pw_imag_absmax: max |Im (L|mu nu)| -- zero for a +-G symmetric mesh; the host mirror reproduces the reference's
+ *   `Imaginary part of ERI is larger than 1e-6` check (:231-236) from it.   qemb_df_pw_select: the tensor qemb_df_transform reads
+ *   (0 = real part, 1 = imaginary part, 2 = their sum: Re / Im of bb^T bb follow from three real transforms).                      */
+int qemb_df_create_pbc(int naux, const double* j2c, qemb_df_t* out, int* ischol);
+int qemb_df_alloc_ints(qemb_df_t df, int N);
+int qemb_df_add_pw_block(qemb_df_t df, int nG, const double* F_re, const double* F_im, const double* pw_re, const double* pw_im);
+int qemb_df_add_rs_block(qemb_df_t df, int p0, int p1, const double* block);
+int qemb_df_pw_imag_absmax(qemb_df_t df, double* out);
+int qemb_df_pw_select(qemb_df_t df, int part);
+
 /* ---------------------------------------------------------------- Schmidt decomposition ---------- */
 /* schmidt_decomposition(mo_coeff, nocc, AO_in_frag, thr_bath) -> (TA_lo_eo, n_f, n_b), molbe/pfrag.py:403-411.
  * lmo: N x nmo row-major; TA_lo_eo: caller buffer N x ld (ld >= n_f + n_b; 2*n_f always suffices).      */

@@ -133,6 +133,12 @@ def _declare(lib):
     f("qemb_ao2mo_dense", I, V, P, I, P, V)
     f("qemb_df_create", I, I, P, C.POINTER(c_vp))
     f("qemb_lpq_upload", I, P, I, C.POINTER(c_vp))
+    f("qemb_df_create_pbc", I, I, P, C.POINTER(c_vp), IP)
+    f("qemb_df_alloc_ints", I, V, I)
+    f("qemb_df_add_pw_block", I, V, I, P, P, P, P)
+    f("qemb_df_add_rs_block", I, V, I, I, P)
+    f("qemb_df_pw_imag_absmax", I, V, C.POINTER(C.c_double))
+    f("qemb_df_pw_select", I, V, I)
     f("qemb_df_free", I, V)
     f("qemb_df_set_ints", I, V, I, P, I)
     f("qemb_df_set_ints_semisparse", I, V, I, L, P, P, P, P)

@@ -12,7 +12,9 @@
 //   tensor, so the reference's memory-driven aux blocking (eri_onthefly.py:18-42) is not needed.
 #include "ao2mo.h"
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
+#include <vector>
 
 namespace qemb {
 
@@ -84,16 +86,109 @@ int DfContext::set_cholesky_factor(int naux_, const double* Lh) {
   QTRY(Linv.alloc((int64_t)naux * naux));
   return dev_tri_inverse_lower(naux, L, Linv);
 }
-int DfContext::set_ints_Lpq(int N_, const double* h) {
+int DfContext::set_metric_pbc(int naux_, const double* j2c, int* ischol) {
+  naux = naux_;
+  DBuf A, w, V;
+  const int64_t n2 = (int64_t)naux * naux;
+  QTRY(A.alloc(n2));
+  QTRY(dev_h2d(A, j2c, sizeof(double) * n2));
+  QTRY(Linv.alloc(n2));
+  int rc = dev_cholesky_lower(naux, A);
+  if (rc == QEMB_OK) { if (ischol) *ischol = 1; return dev_tri_inverse_lower(naux, A, Linv); }
+  if (rc != QEMB_ERR_NUMERIC) return rc;
+  // not positive definite: (P|Q)^{-1/2} restricted to the eigenvalues above 1e-14   (kbe/eri_onthefly.py:40-45)
+  if (ischol) *ischol = 0;
+  QTRY(dev_h2d(A, j2c, sizeof(double) * n2));
+  QTRY(w.alloc(naux)); QTRY(V.alloc(n2));
+  QTRY(dev_jacobi_eigh(naux, A, w, V, nullptr));
+  {  // The Jacobi driver diagonalises A + sigma (Gershgorin shift): its eigenvalues carry an absolute error of eps * sigma, too coarse for the
+     // reference's ABSOLUTE cut at 1e-14.  Take them again as Rayleigh quotients v^T A v with the unshifted metric (second order in the
+     // eigenvector error; rounding ~ eps * |A|, what LAPACK's eigh delivers).
+    DBuf AV, D;
+    QTRY(AV.alloc(n2)); QTRY(D.alloc(n2));
+    QTRY(dev_h2d(A, j2c, sizeof(double) * n2));
+    QTRY(gemm(naux, naux, naux, 1.0, A, naux, true, V, naux, false, 0.0, AV, naux));
+    QTRY(gemm(naux, naux, naux, 1.0, V, naux, false, AV, naux, false, 0.0, D, naux));
+    Copy4Desc c{};
+    c.dim[0] = 1; c.dim[1] = 1; c.dim[2] = 1; c.dim[3] = naux;
+    c.in = D; c.si[0] = 0; c.si[1] = 0; c.si[2] = 0; c.si[3] = naux + 1;
+    c.out = w; c.so[0] = 0; c.so[1] = 0; c.so[2] = 0; c.so[3] = 1; c.alpha = 1.0; c.beta = 0.0;
+    QTRY(dev_copy4(c));
+  }
+  std::vector<double> d(naux);
+  QTRY(dev_d2h(d.data(), w, sizeof(double) * naux));
+  for (double& x : d) x = (x > 1e-14) ? 1.0 / std::sqrt(std::sqrt(x)) : 0.0;      // columns scaled by d^{-1/4}: Vs Vs^T = V d^{-1/2} V^T
+  QTRY(dev_h2d(w, d.data(), sizeof(double) * naux));
+  QTRY(dev_mul_bcast_rows(naux, naux, V, w));
+  return gemm(naux, naux, naux, 1.0, V, naux, true, V, naux, true, 0.0, Linv, naux);
+}
+int DfContext::alloc_ints(int N_) {
+  if (naux <= 0) { set_error("DfContext: set the metric first"); return QEMB_ERR_ARG; }
+  if (N_ <= 0) { set_error("DfContext::alloc_ints: N must be positive"); return QEMB_ERR_ARG; }
   N = N_;
   Usp.release(); n_unique = 0;
+  const int64_t sz = (int64_t)naux * N * N;
+  QTRY(Lpq.alloc(sz)); QTRY(Lpq_im.alloc(sz));
+  Lpq_sum.release(); Lact = nullptr;
+  QTRY(dev_fill(Lpq, sz, 0.0));
+  return dev_fill(Lpq_im, sz, 0.0);
+}
+int DfContext::add_rs_block(int p0, int p1, const double* h) {
+  if (!Lpq.p || !Lpq_im.p) { set_error("DfContext::add_rs_block: alloc_ints first"); return QEMB_ERR_ARG; }
+  if (p0 < 0 || p1 > naux || p0 >= p1 || !h) { set_error("DfContext::add_rs_block: need 0 <= p0 < p1 <= naux"); return QEMB_ERR_ARG; }
+  const int64_t n2 = (int64_t)N * N, sz = (int64_t)(p1 - p0) * n2;
+  DBuf tmp;
+  QTRY(tmp.alloc(sz));
+  QTRY(dev_h2d(tmp, h, sizeof(double) * sz));
+  return axpby(sz, 1.0, tmp, 1.0, Lpq.p + (int64_t)p0 * n2);
+}
+int DfContext::add_pw_block(int nG, const double* F_re, const double* F_im, const double* pw_re, const double* pw_im) {
+  if (!Lpq.p || !Lpq_im.p) { set_error("DfContext::add_pw_block: alloc_ints first"); return QEMB_ERR_ARG; }
+  if (nG <= 0 || !F_re || !F_im || !pw_re || !pw_im) { set_error("DfContext::add_pw_block: bad arguments"); return QEMB_ERR_ARG; }
+  const int64_t n2 = (int64_t)N * N;
+  DBuf fr, fi, pr, pi;
+  QTRY(fr.alloc((int64_t)naux * nG)); QTRY(fi.alloc((int64_t)naux * nG));
+  QTRY(pr.alloc((int64_t)nG * n2)); QTRY(pi.alloc((int64_t)nG * n2));
+  QTRY(dev_h2d(fr, F_re, sizeof(double) * naux * nG)); QTRY(dev_h2d(fi, F_im, sizeof(double) * naux * nG));
+  QTRY(dev_h2d(pr, pw_re, sizeof(double) * nG * n2)); QTRY(dev_h2d(pi, pw_im, sizeof(double) * nG * n2));
+  // (F_re + i F_im)(P_re + i P_im): four real products over the plane waves of the block   (kbe/eri_onthefly.py:196-199)
+  QTRY(gemm(naux, n2, nG, 1.0, fr, nG, true, pr, n2, false, 1.0, Lpq, n2));
+  QTRY(gemm(naux, n2, nG, -1.0, fi, nG, true, pi, n2, false, 1.0, Lpq, n2));
+  QTRY(gemm(naux, n2, nG, 1.0, fr, nG, true, pi, n2, false, 1.0, Lpq_im, n2));
+  return gemm(naux, n2, nG, 1.0, fi, nG, true, pr, n2, false, 1.0, Lpq_im, n2);
+}
+int DfContext::imag_absmax(double* out) const {
+  if (!Lpq_im.p || !out) { set_error("DfContext::imag_absmax: no plane-wave accumulation on this context"); return QEMB_ERR_ARG; }
+  DBuf r;
+  QTRY(r.alloc(1));
+  QTRY(dev_absmax((int64_t)naux * N * N, Lpq_im, r));
+  return dev_d2h(out, r, sizeof(double));
+}
+int DfContext::select_part(int part) {
+  if (part == 0) { Lact = nullptr; return QEMB_OK; }
+  if (!Lpq.p || !Lpq_im.p) { set_error("DfContext::select_part: no plane-wave accumulation on this context"); return QEMB_ERR_ARG; }
+  if (part == 1) { Lact = Lpq_im.p; return QEMB_OK; }
+  if (part == 2) {
+    const int64_t sz = (int64_t)naux * N * N;
+    QTRY(Lpq_sum.alloc(sz));
+    QTRY(dcopy(sz, Lpq, Lpq_sum));
+    QTRY(axpby(sz, 1.0, Lpq_im, 1.0, Lpq_sum));
+    Lact = Lpq_sum.p;
+    return QEMB_OK;
+  }
+  set_error("DfContext::select_part: part must be 0, 1 or 2");
+  return QEMB_ERR_ARG;
+}
+int DfContext::set_ints_Lpq(int N_, const double* h) {
+  N = N_;
+  Usp.release(); n_unique = 0; Lact = nullptr; Lpq_im.release(); Lpq_sum.release();
   if (naux <= 0) { set_error("DfContext: set the metric first"); return QEMB_ERR_ARG; }
   QTRY(Lpq.alloc((int64_t)naux * N * N));
   return dev_h2d(Lpq, h, sizeof(double) * naux * N * N);
 }
 int DfContext::set_ints_pqL(int N_, const double* h) {
   N = N_;
-  Usp.release(); n_unique = 0;
+  Usp.release(); n_unique = 0; Lact = nullptr; Lpq_im.release(); Lpq_sum.release();
   if (naux <= 0) { set_error("DfContext: set the metric first"); return QEMB_ERR_ARG; }
   DBuf tmp;
   const int64_t n2 = (int64_t)N * N;
@@ -105,7 +200,7 @@ int DfContext::set_ints_pqL(int N_, const double* h) {
 }
 int DfContext::set_ints_packed(int N_, const double* h) {
   N = N_;
-  Usp.release(); n_unique = 0;
+  Usp.release(); n_unique = 0; Lact = nullptr; Lpq_im.release(); Lpq_sum.release();
   if (naux <= 0) { set_error("DfContext: set the metric first"); return QEMB_ERR_ARG; }
   DBuf tmp;
   QTRY(tmp.alloc((int64_t)naux * npair(N)));
@@ -128,7 +223,7 @@ int DfContext::set_ints_semisparse(int N_, int64_t n_unique_, const double* uniq
   reach_ptr.assign(ptr, ptr + N + 1);
   reach_nu.assign(nu, nu + ptr[N]);
   reach_off.assign(off, off + ptr[N]);
-  Lpq.release();
+  Lpq.release(); Lact = nullptr; Lpq_im.release(); Lpq_sum.release();
   QTRY(Usp.alloc(std::max<int64_t>(1, n_unique * naux)));
   return n_unique > 0 ? dev_h2d(Usp, unique_host, sizeof(double) * n_unique * naux) : QEMB_OK;
 }
@@ -245,7 +340,7 @@ int DfContext::transform(const double* TA, int n, double* out_s4, const double* 
   QTRY(bp.alloc((int64_t)naux * np)); QTRY(bb.alloc((int64_t)naux * np));
   TimerScope lap_DF(TIMER_DF);
   // T1[L,i,nu] = sum_mu TA[mu,i] (L|mu nu)              (eri_onthefly.py:134, batched over L)
-  QTRY(gemm(n, N, N, 1.0, TA, n, false, Lpq, N, false, 0.0, T1, N, naux, 0, (int64_t)N * N, (int64_t)n * N));
+  QTRY(gemm(n, N, N, 1.0, TA, n, false, Lact ? Lact : Lpq.p, N, false, 0.0, T1, N, naux, 0, (int64_t)N * N, (int64_t)n * N));
   if (S_abs) {
     // semi-sparse semantics (eri_sparse_DF.cpp:443-532): AO_by_MO[i] = {mu : |S_abs TA|(mu,i) >= eps}; (P|mu i) exists
     // only for mu in AO_by_MO[i].  Pair screening of (P|mu nu) itself arrives as zeros in the packed input.

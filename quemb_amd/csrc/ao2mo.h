@@ -27,6 +27,19 @@ class DfContext {
   DBuf Lpq;     // (P|mu nu) as [naux][N][N]
   int set_metric(int naux_, const double* j2c_host);              // Cholesky on the device, then invert
   int set_cholesky_factor(int naux_, const double* L_host);       // caller supplies L (lower), just invert
+  // Periodic metric (kbe/eri_onthefly.py:19-45 _j2c_cholesky_or_eig): Cholesky when (P|Q) is positive definite, otherwise the fit matrix
+  // V_+ d_+^{-1/2} V_+^T over the eigenpairs with d > 1e-14.  Either way `Linv` ends up as the matrix bb = Linv b is formed with.
+  int set_metric_pbc(int naux_, const double* j2c_host, int* ischol);
+  // Gamma-point CC-GDF accumulation of the fitted 3-index tensor at the AO level (kbe/eri_onthefly.py:160-217):
+  //   (L|mu nu) = sum_G F[L,G] (G|mu nu)  +  real-space block rows;   F = ft_ao(chgcell, Gv)^H, (G|mu nu) = ft_aopair * coulG^*
+  // The sum over G is complex; its real part lands in Lpq, its imaginary part (zero for a +-G symmetric mesh) in Lpq_im.
+  int alloc_ints(int N_);
+  int add_rs_block(int p0, int p1, const double* block_host);     // rows [p0, p1) of (L|mu nu) += block (p1 - p0, N, N)
+  int add_pw_block(int nG, const double* F_re, const double* F_im, const double* pw_re, const double* pw_im);   // F: naux x nG, pw: nG x N x N
+  int imag_absmax(double* out_host) const;
+  int select_part(int part);      // which 3-index tensor `transform` reads: 0 real part (default), 1 imaginary part, 2 their sum
+  DBuf Lpq_im, Lpq_sum;
+  const double* Lact = nullptr;
   int set_ints_pqL(int N_, const double* pqL_host);               // (N, N, naux) as produced by getints3c
   int set_ints_Lpq(int N_, const double* Lpq_host);               // (naux, N, N)
   int set_ints_packed(int N_, const double* P_munu_packed_host);  // (naux, npair(N)), mu >= nu

@@ -288,6 +288,34 @@ int qemb_lpq_upload(const double* L, int naux, qemb_df_t* out) {
   *out = d;
   return QEMB_OK;
 }
+int qemb_df_create_pbc(int naux, const double* j2c, qemb_df_t* out, int* ischol) {
+  if (naux <= 0 || !j2c || !out) { set_error("qemb_df_create_pbc: bad arguments"); return QEMB_ERR_ARG; }
+  DfContext* d = new DfContext();
+  int rc = d->set_metric_pbc(naux, j2c, ischol);
+  if (rc) { delete d; return rc; }
+  *out = d;
+  return QEMB_OK;
+}
+int qemb_df_alloc_ints(qemb_df_t df, int N) {
+  if (!df) { set_error("qemb_df_alloc_ints: null handle"); return QEMB_ERR_ARG; }
+  return reinterpret_cast<DfContext*>(df)->alloc_ints(N);
+}
+int qemb_df_add_pw_block(qemb_df_t df, int nG, const double* F_re, const double* F_im, const double* pw_re, const double* pw_im) {
+  if (!df) { set_error("qemb_df_add_pw_block: null handle"); return QEMB_ERR_ARG; }
+  return reinterpret_cast<DfContext*>(df)->add_pw_block(nG, F_re, F_im, pw_re, pw_im);
+}
+int qemb_df_add_rs_block(qemb_df_t df, int p0, int p1, const double* block) {
+  if (!df) { set_error("qemb_df_add_rs_block: null handle"); return QEMB_ERR_ARG; }
+  return reinterpret_cast<DfContext*>(df)->add_rs_block(p0, p1, block);
+}
+int qemb_df_pw_imag_absmax(qemb_df_t df, double* out) {
+  if (!df) { set_error("qemb_df_pw_imag_absmax: null handle"); return QEMB_ERR_ARG; }
+  return reinterpret_cast<DfContext*>(df)->imag_absmax(out);
+}
+int qemb_df_pw_select(qemb_df_t df, int part) {
+  if (!df) { set_error("qemb_df_pw_select: null handle"); return QEMB_ERR_ARG; }
+  return reinterpret_cast<DfContext*>(df)->select_part(part);
+}
 int qemb_df_free(qemb_df_t df) { delete reinterpret_cast<DfContext*>(df); return QEMB_OK; }
 int qemb_df_set_ints(qemb_df_t df, int N, const double* ints, int layout) {
   if (!df || !ints || N <= 0) { set_error("qemb_df_set_ints: bad arguments"); return QEMB_ERR_ARG; }

@@ -168,6 +168,49 @@ class DFContext:
         self.h = h
         self.nao = None
 
+    @classmethod
+    def periodic(cls, j2c, lib=None):
+        """Context for the Gamma-point CC-GDF transform (kbe/eri_onthefly.py:160-164): the metric goes through `_j2c_cholesky_or_eig`
+        (:19-45) on the device; `ischol` says which branch was taken."""
+        self = cls.__new__(cls)
+        self.lib = lib or _lib.init()
+        j2c = _arr(j2c)
+        self.naux = j2c.shape[0]
+        h, ischol = c_vp(), C.c_int(-1)
+        check(self.lib.qemb_df_create_pbc(self.naux, j2c.ctypes.data, C.byref(h), C.byref(ischol)), "qemb_df_create_pbc", self.lib)
+        self.h, self.nao, self.ischol = h, None, bool(ischol.value)
+        return self
+
+    def alloc_ints(self, nao: int):
+        """zeroed fitted tensor (L|mu nu) (real and imaginary part) for `add_pw_block` / `add_rs_block`"""
+        check(self.lib.qemb_df_alloc_ints(self.h, int(nao)), "qemb_df_alloc_ints", self.lib)
+        self.nao = int(nao)
+
+    def add_pw_block(self, F, pw):
+        """(L|mu nu) += sum_G F[L,G] (G|mu nu): F = ft_ao(chgcell, Gv_block).conj().T (naux, nG), pw = ft_aopair(cell, Gv_block) * coulG.conj()
+        (nG, N, N), both complex   (kbe/eri_onthefly.py:176-199)"""
+        F = np.asarray(F); pw = np.asarray(pw)
+        nG = F.shape[1]
+        if self.nao is None or F.shape[0] != self.naux or pw.shape != (nG, self.nao, self.nao):
+            raise ValueError("DFContext.add_pw_block: alloc_ints first; F is (naux, nG) and pw (nG, N, N)")
+        Fr, Fi, Pr, Pi = _arr(F.real), _arr(F.imag), _arr(pw.real), _arr(pw.imag)
+        check(self.lib.qemb_df_add_pw_block(self.h, nG, Fr.ctypes.data, Fi.ctypes.data, Pr.ctypes.data, Pi.ctypes.data), "qemb_df_add_pw_block", self.lib)
+
+    def add_rs_block(self, p0: int, block):
+        """rows [p0, p0 + len(block)) of (L|mu nu) += block (real, (p1 - p0, N, N))   (kbe/eri_onthefly.py:201-217)"""
+        block = _arr(block)
+        if self.nao is None or block.shape[1:] != (self.nao, self.nao):
+            raise ValueError("DFContext.add_rs_block: alloc_ints first; block is (p1 - p0, N, N)")
+        check(self.lib.qemb_df_add_rs_block(self.h, int(p0), int(p0) + block.shape[0], block.ctypes.data), "qemb_df_add_rs_block", self.lib)
+
+    def imag_absmax(self) -> float:
+        out = C.c_double()
+        check(self.lib.qemb_df_pw_imag_absmax(self.h, C.byref(out)), "qemb_df_pw_imag_absmax", self.lib)
+        return out.value
+
+    def select_part(self, part: int):
+        check(self.lib.qemb_df_pw_select(self.h, int(part)), "qemb_df_pw_select", self.lib)
+
     def set_ints(self, ints, nao: int, layout: str = "pqL"):
         """layout: 'pqL' (N,N,naux) as getints3c returns, 'Lpq' (naux,N,N), 'packed' (naux, npair(N))."""
         code = {"pqL": 0, "Lpq": 1, "packed": 2}[layout]

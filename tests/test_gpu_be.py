@@ -419,6 +419,39 @@ def test_octane_matching_with_correlated_model_jacobians(qlib):
         assert abs(be2.ebe_tot - (-310.3347211309688)) < 5e-6
 
 
+def test_periodic_direct_df_matches_reference_outputs(qlib):
+    """kbe/eri_onthefly.py:19-45, :48-241 (Gamma-point CC-GDF: Cholesky / eigenvalue fit of the metric, plane-wave and real-space
+    accumulation, fit, bb^T bb, imaginary-part test) on the device against the reference's own outputs (tests/golden/kbe_df.npz)."""
+    from test_kbe_df import check_periodic_df, check_periodic_df_argument_errors
+    check_periodic_df(qlib)
+    check_periodic_df_argument_errors(qlib)
+
+
+def test_periodic_direct_df_beyond_one_tile_and_into_a_fragment(qlib):
+    """the same path at sizes past one GEMM tile (indefinite metric: eigenvalue fit through the device Jacobi solver), against the
+    oracle restatement; the ERIs written straight into a device fragment are the ones returned to the host."""
+    from qemb_oracle import kbe_df
+    from quemb_amd import kbe_eri_onthefly as keo
+    from quemb_amd.fragsolver import DeviceFragment
+    from test_kbe_df import big_case
+    src, TAs = big_case()
+    ref, ischol = kbe_df.integral_direct_DF(src, TAs, 16, 7)
+    assert not ischol
+
+    class F:
+        pass
+    frs = []
+    for TA in TAs:
+        f = F(); f.TA = TA; f.dev = DeviceFragment(TA.shape[1], 3, lib=qlib); frs.append(f)
+    host = keo.integral_direct_DF(src, frs, pw_step=32, aux_step=25, lib=qlib, want_host=True)
+    assert keo.integral_direct_DF(src, frs, pw_step=1000, aux_step=1000, lib=qlib) is None
+    for f, e, r in zip(frs, host, ref):
+        assert np.abs(e - r).max() < 1e-9 * np.abs(r).max()
+        assert np.abs(e - e.T).max() < 1e-12 * np.abs(r).max()
+        assert np.abs(f.dev.get_eri_s4() - r).max() < 1e-9 * np.abs(r).max()
+        f.dev.free()
+
+
 def test_abs_overlap_quadrature_and_reachability_on_the_device(qlib):
     """approx_S_abs (molbe/eri_sparse_DF.py:928-959) with the primitive quadrature on the device, _get_AO_per_AO (:224-240):
     against the restatement of oracle/qemb_oracle/sparse_df.py (itself checked against a grid integral, tests/test_oracle_sparse_df.py)."""
