@@ -7,6 +7,7 @@ import pytest
 
 from helpers import synthetic_fragment
 from qemb_oracle import be, ccsd, eri, rdm, scf
+from quemb_amd import eri_transform as et
 from quemb_amd.fragsolver import DeviceFragment, default_opts
 
 pytestmark = pytest.mark.gpu
@@ -212,3 +213,44 @@ def test_mo_transform_at_bench_tile(qlib, n, o):
     eo, ev = fr.ccsd_export("eo", (o,)), fr.ccsd_export("ev", (v,))
     assert np.abs(np.concatenate([eo, ev]) - r["mo_energy"]).max() < 1e-9
     fr.free()
+
+
+def test_full_size_fragment_is_invariant_under_a_rotation_of_the_embedding_basis(qlib):
+    """BASELINE configs[2] size (n = 220, n_occ = 20), checked through a size-independent property: rotating the embedding orbitals by
+    an orthogonal Q -- the ERIs through the dense transform of row a3 (qemb_ao2mo_dense with TA = Q, N = n = 220), h -> Q^T h Q --
+    leaves the fragment RHF energy and E_corr unchanged and turns the 1-RDM into Q^T rdm1 Q.  The whole chain a3 -> a7 -> a8 -> a9
+    at full size, two independent solves (different orbitals, different integrals in memory)."""
+    from quemb_amd._lib import DeviceBuffer, check
+    n, o, naux = 220, 20, 330
+    rng = np.random.default_rng(20260803)
+    B = 0.03 * rng.standard_normal((naux, n, n)); B = 0.5 * (B + B.transpose(0, 2, 1))
+    il = np.tril_indices(n)
+    Bp = np.ascontiguousarray(B[:, il[0], il[1]])
+    npair = Bp.shape[1]
+    dB, d4 = DeviceBuffer.from_numpy(Bp), DeviceBuffer(npair * npair)
+    check(qlib.qemb_op_gemm(npair, npair, naux, 1.0, dB.ptr, npair, 0, 0, dB.ptr, npair, 0, 0, 0.0, d4.ptr, npair, 0, 1))
+    dB.free()
+    A = rng.standard_normal((n, n))
+    h = np.diag(2.0 * np.arange(n)) + 0.3 * 0.5 * (A + A.T)
+    fr = DeviceFragment(n, 22)
+    fr.set_eri_s4_dev(d4.ptr); d4.free()
+    out = fr.solve(o, h, opts=default_opts(), eeval=False)
+    eri = fr.get_eri_s4()
+    Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    ao = et.AOEri(eri, n, lib=qlib)
+    del eri
+    fr2 = DeviceFragment(n, 22)
+    ao.transform(Q, frag=fr2, want_host=False)
+    ao.free()
+    out2 = fr2.solve(o, Q.T @ h @ Q, opts=default_opts(), eeval=False)
+    assert out["n_iter"] > 5 and abs(out["e_corr_mo"]) > 1.0          # a correlated, converged problem
+    assert abs(out2["e_scf"] - out["e_scf"]) < 1e-9 * abs(out["e_scf"]), (out["e_scf"], out2["e_scf"])
+    assert abs(out2["e_corr_mo"] - out["e_corr_mo"]) < 1e-8, (out["e_corr_mo"], out2["e_corr_mo"])
+    assert np.abs(out2["rdm1_emb"] - Q.T @ out["rdm1_emb"] @ Q).max() < 1e-8
+    # a spot check of the rotated integrals themselves against the DF factor: (00|00), (n-1 0|5 3)
+    Bq = np.einsum("Ppq,pi,qj->Pij", B, Q, Q, optimize=True)
+    e2 = fr2.get_eri_s4()
+    pr = lambda i, j: i * (i + 1) // 2 + j
+    for (i, j, k, l) in ((0, 0, 0, 0), (n - 1, 0, 5, 3), (100, 37, 219, 218)):
+        assert abs(e2[pr(i, j), pr(k, l)] - Bq[:, i, j] @ Bq[:, k, l]) < 1e-11
+    fr.free(); fr2.free()
