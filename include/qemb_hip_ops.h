@@ -80,6 +80,9 @@ int qemb_op_unpack_s8_to_s4(int64_t n, const double* s8, double* s4);
 int qemb_op_mirror_lower(int64_t n, double* A, int64_t lda);
 /* exchange matrix K[p,r] = sum (pq|rs) D[q,s] from the half-unpacked tensor H[P(p,q)][r][s] (scf.hf.dot_eri_dm's K at helper.py:64) */
 int qemb_op_k_from_pairs(int64_t n, const double* H, const double* D, double* K);
+/* the same K and the packed Coulomb vector Jp[P(p,q)] = sum_{r>=s} (pq|rs) Dp[P(r,s)] in ONE pass over the 4-fold packed block S4
+ * (J and K of scf.hf.dot_eri_dm, helper.py:64); Dp = D + D^T off the diagonal, D on it, packed; Dp / Jp may be null; n <= 1024 */
+int qemb_op_jk_from_packed(int64_t n, const double* S4, const double* D, const double* Dp, double* Jp, double* K);
 /* (+/-) pair packing of the last two indices of in[rows][v][v] (Op: c >= d sums, Om: c > d differences; rows padded to ldp / ldm)
  * and the inverse scatter of packed pair ROWS: out[i,j,:] = Xp + Xm, out[j,i,:] = Xp - Xm */
 int qemb_op_pack_pm_cols(int64_t rows, int64_t v, const double* in, double* Op, int64_t ldp, double* Om, int64_t ldm);

@@ -85,6 +85,7 @@ def _declare(lib):
     f("qemb_op_pack_pair_rows", I, L, L, P, P)
     f("qemb_op_mirror_lower", I, L, P, L)
     f("qemb_op_k_from_pairs", I, L, P, P, P)
+    f("qemb_op_jk_from_packed", I, L, P, P, P, P, P)
     f("qemb_op_pack_pm_cols", I, L, L, P, P, L, P, L)
     f("qemb_op_scatter_pm_rows", I, L, L, P, P, P)
     f("qemb_op_lincomb2", I, L, D, P, D, P, D, P)

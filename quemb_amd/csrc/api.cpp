@@ -101,6 +101,7 @@ int qemb_ctx_count(int n) { return dev_ctx_count(n); }
 int qemb_ctx_bind(int k) { return dev_ctx_bind(k); }
 int qemb_ctx_timer_read(int ctx, int slot, double* total_ms, int64_t* count, int reset) { return dev_ctx_timer_read(ctx, slot, total_ms, count, reset); }
 int qemb_op_k_from_pairs(int64_t n, const double* H, const double* D, double* K) { return dev_k_from_pairs(n, H, D, K); }
+int qemb_op_jk_from_packed(int64_t n, const double* S4, const double* D, const double* Dp, double* Jp, double* K) { return dev_jk_from_packed(n, S4, D, Dp, Jp, K); }
 int qemb_op_pack_pm_cols(int64_t rows, int64_t v, const double* in, double* Op, int64_t ldp, double* Om, int64_t ldm) { return dev_pack_pm_cols(rows, v, in, Op, ldp, Om, ldm); }
 int qemb_op_scatter_pm_rows(int64_t o, int64_t ncols, const double* Xp, const double* Xm, double* out) { return dev_scatter_pm_rows(o, ncols, Xp, Xm, out); }
 int qemb_op_lincomb2(int64_t n, double a, const double* x, double b, const double* y, double beta, double* out) {

@@ -135,6 +135,9 @@ int dev_mirror_lower(int64_t n, double* A, int64_t lda);
 // K[p,r] = sum_{q,s} (pq|rs) D[q,s] from the half-unpacked tensor H[P(p,q)][r][s] (p >= q rows only, npair(n) x n x n):
 // row (p,q) feeds K[p,:] with D[q,:] and, for p != q, K[q,:] with D[p,:].  Deterministic (per-row partials, fixed-order sum).
 int dev_k_from_pairs(int64_t n, const double* H, const double* D, double* K);
+// The same K and, in the same pass, the packed Coulomb vector Jp[P(p,q)] = sum_{r>=s} (pq|rs) Dp[P(r,s)] from the 4-fold packed block
+// S4[P(p,q)][P(r,s)] (half the bytes of H; Dp = D + D^T off the diagonal, D on it, packed).  Jp and Dp may be null (K only).  n <= 1024.
+int dev_jk_from_packed(int64_t n, const double* S4, const double* D, const double* Dp, double* Jp, double* K);
 
 // ---- pair-packed MO transformation helpers ---------------------------------------------------------------------------
 // out[P(x,y), c] = in[(x*n + y), c] for x >= y  (row gather of an (n*n) x ncols matrix; ncols-long rows)

@@ -1348,6 +1348,112 @@ int dev_k_from_pairs(int64_t n, const double* H, const double* D, double* K) {
   return QEMB_OK;
 }
 
+// Coulomb AND exchange matrix in ONE pass over the 4-fold packed block S4[P(p,q)][P(r,s)] (a quarter of the n^4 tensor, half of the
+// pair-row tensor dev_k_from_pairs reads, and the Coulomb product no longer needs its own pass).  One workgroup per packed row (p,q): the
+// row is the lower triangle of the symmetric slab M[r,s] = (pq|rs), streamed ONCE from memory straight into registers -- wave w takes the
+// rows r = w, w + 4, ..., lanes run over s <= r (contiguous) -- and every element is used for both halves of the symmetric product
+//   y[r] = sum_{s<=r} M[r,s] d[s]  (reduced over the lanes of the wave that owns row r)
+//        + sum_{s>r} M[s,r] d[s]   (accumulated by the lane that owns column r, over the rows its wave walks; the four waves' column
+//                                    sums are added in a fixed order at the end)
+// for d = D[q,:] (feeds K[p,:]) and d = D[p,:] (feeds K[q,:]), and for Jp[pq] = sum_{r>=s} M[r,s] Dp[rs], Dp = D + D^T off the diagonal.
+// No LDS in the main loop, no atomics, every sum in a fixed order (run-to-run bitwise identical, like dev_k_from_pairs).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_take_f64(double x) {      // the value of another lane (DPP pattern CTRL); 0 in rows ROW_MASK leaves out
+  const unsigned long long u = __double_as_longlong(x);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(u & 0xffffffffu), CTRL, ROW_MASK, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(u >> 32), CTRL, ROW_MASK, 0xF, false);
+  return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
+}
+// sum over the 64 lanes without the LDS crossbar (__shfl_down = ds_bpermute: 12 LDS operations per double): butterfly inside each row of
+// 16 lanes (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror), then row_bcast:15 into rows 1 / 3 and row_bcast:31 into rows 2 / 3;
+// lane 63 holds the total, read back as a wave-uniform value
+__device__ __forceinline__ double wave_sum_dpp(double v) {
+  v += dpp_take_f64<0xB1, 0xF>(v);
+  v += dpp_take_f64<0x4E, 0xF>(v);
+  v += dpp_take_f64<0x141, 0xF>(v);
+  v += dpp_take_f64<0x140, 0xF>(v);
+  v += dpp_take_f64<0x142, 0xA>(v);
+  v += dpp_take_f64<0x143, 0xC>(v);
+  const unsigned long long u = __double_as_longlong(v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(u & 0xffffffffu), 63), hi = (unsigned)__builtin_amdgcn_readlane((int)(u >> 32), 63);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+template <int NK>      // NK = ceil(n / 64) column slots per lane
+__global__ void __launch_bounds__(256) jk_packed_stage1(int n, const double* __restrict__ S4, const double* __restrict__ D,
+                                                        const double* __restrict__ Dp, double* __restrict__ Jp, double* __restrict__ P1,
+                                                        double* __restrict__ P2) {
+  extern __shared__ double sm[];
+  double* yl1 = sm; double* yl2 = sm + n; double* part = sm + 2 * n;      // part[wave][2][n]; jw behind it
+  double* jw = part + 8 * n;
+  const long long np = (long long)n * (n + 1) / 2, pq = blockIdx.x;
+  long long p, q; unpair_ge(pq, p, q);
+  const double* __restrict__ row = S4 + pq * np;
+  const double* __restrict__ Dq = D + q * n;
+  const double* __restrict__ Dpr = D + p * n;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double dq[NK], dp[NK], uq[NK], up[NK], ja = 0.0;
+#pragma unroll
+  for (int k = 0; k < NK; ++k) {
+    const int s = lane + 64 * k;
+    dq[k] = s < n ? Dq[s] : 0.0; dp[k] = s < n ? Dpr[s] : 0.0; uq[k] = 0.0; up[k] = 0.0;
+  }
+  for (int r = wave; r < n; r += 4) {
+    const int rb = r * (r + 1) / 2;                 // < 2^31 for n <= 1024
+    const double dq_r = Dq[r], dp_r = Dpr[r];       // wave-uniform
+    double a1 = 0.0, a2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+      if (64 * k <= r) {                            // wave-uniform
+        const int s = lane + 64 * k;
+        if (s <= r) {
+          const double x = row[rb + s];
+          a1 += x * dq[k]; a2 += x * dp[k];
+          if (Jp) ja += x * Dp[rb + s];
+          if (s < r) { uq[k] += x * dq_r; up[k] += x * dp_r; }
+        }
+      }
+    }
+    a1 = wave_sum_dpp(a1); a2 = wave_sum_dpp(a2);
+    if (lane == 0) { yl1[r] = a1; yl2[r] = a2; }
+  }
+#pragma unroll
+  for (int k = 0; k < NK; ++k) {
+    const int s = lane + 64 * k;
+    if (s < n) { part[(wave * 2 + 0) * n + s] = uq[k]; part[(wave * 2 + 1) * n + s] = up[k]; }
+  }
+  ja = wave_sum_dpp(ja);
+  if (lane == 0) jw[wave] = ja;
+  __syncthreads();
+  for (int s = tid; s < n; s += 256) {
+    P1[pq * n + s] = yl1[s] + ((part[0 * n + s] + part[2 * n + s]) + (part[4 * n + s] + part[6 * n + s]));
+    P2[pq * n + s] = yl2[s] + ((part[1 * n + s] + part[3 * n + s]) + (part[5 * n + s] + part[7 * n + s]));
+  }
+  if (Jp && tid == 0) Jp[pq] = (jw[0] + jw[1]) + (jw[2] + jw[3]);
+}
+
+int dev_jk_from_packed(int64_t n, const double* S4, const double* D, const double* Dp, double* Jp, double* K) {
+  REQUIRE_INIT();
+  if (n <= 0) return QEMB_OK;
+  if (n > 1024) { set_error("dev_jk_from_packed: n > 1024 (use dev_k_from_pairs)"); return QEMB_ERR_ARG; }
+  const long long np = n * (n + 1) / 2;
+  int rc = ensure_ws((size_t)2 * np * n * sizeof(double));
+  if (rc) return rc;
+  double* P1 = g_ws; double* P2 = g_ws + np * n;
+  const size_t lds = (size_t)(10 * n + 8) * sizeof(double);
+  const int nk = (int)((n + 63) / 64);
+  auto launch = [&](auto kern) {
+    hipLaunchKernelGGL(kern, dim3((unsigned)np), dim3(256), lds, g_stream, (int)n, S4, D, Dp, Jp, P1, P2);
+  };
+  if (nk <= 1) launch(jk_packed_stage1<1>);
+  else if (nk <= 2) launch(jk_packed_stage1<2>);
+  else if (nk <= 4) launch(jk_packed_stage1<4>);
+  else if (nk <= 8) launch(jk_packed_stage1<8>);
+  else launch(jk_packed_stage1<16>);
+  if (K) hipLaunchKernelGGL(k_pairs_stage2, dim3((unsigned)n), dim3(256), 0, g_stream, (long long)n, (const double*)P1, (const double*)P2, K);
+  HIP_TRY(hipGetLastError());
+  return QEMB_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // packed-pair transforms.  pair(i,j) = i(i+1)/2 + j, i >= j  (reference shared/helper.py:260-276)
 // ------------------------------------------------------------------------------------------------

@@ -13,6 +13,25 @@ namespace qemb {
 
 int build_jk(int n, const double* eri, const double* dm, double* J, double* K, const double* eri_s4) {
   const int64_t n2 = (int64_t)n * n;
+  if (eri_s4 && n <= 1024 && (J || K)) {
+    // J and K in ONE pass over the 4-fold packed block (4.7 GB at n = 220; the Coulomb product over it plus the exchange build over
+    // the 9.4 GB pair-row tensor were two passes, 3.1 ms -> 1.1 ms per build)
+    const int64_t np = (int64_t)n * (n + 1) / 2;
+    DBuf D2, Dp, Jp;
+    if (J) {
+      QTRY(D2.alloc(n2)); QTRY(Dp.alloc(np)); QTRY(Jp.alloc(np));
+      QTRY(perm4(D2, dm, 1, 1, n, n, 0, 1, 3, 2));            // D^T
+      QTRY(axpby(n2, 1.0, dm, 1.0, D2));                      // D + D^T
+      Copy4Desc c{};
+      c.dim[0] = 1; c.dim[1] = 1; c.dim[2] = 1; c.dim[3] = n;
+      c.in = dm; c.si[3] = n + 1; c.out = D2; c.so[3] = n + 1; c.alpha = 1.0; c.beta = 0.0;
+      QTRY(dev_copy4(c));                                     // diagonal back to D[r,r]
+      QTRY(dev_pack_tril_rows(1, n, D2, Dp));
+    }
+    QTRY(dev_jk_from_packed(n, eri_s4, dm, J ? Dp.p : nullptr, J ? Jp.p : nullptr, K));
+    if (J) QTRY(dev_unpack_tril_rows(1, n, Jp, J));
+    return 0;
+  }
   if (J && eri_s4) {
     // J from the 4-fold packed block (a quarter of the bytes): Jp = eri_s4 . Dp, Dp[rs] = D[r,s] + D[s,r] (r > s), D[r,r]
     const int64_t np = (int64_t)n * (n + 1) / 2;

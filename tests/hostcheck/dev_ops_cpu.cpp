@@ -129,6 +129,22 @@ int dev_k_from_pairs(int64_t n, const double* H, const double* D, double* K) {
   }
   return 0;
 }
+int dev_jk_from_packed(int64_t n, const double* S4, const double* D, const double* Dp, double* Jp, double* K) {
+  const int64_t np = n * (n + 1) / 2;
+  if (K) std::fill(K, K + n * n, 0.0);
+  for (int64_t p = 0; p < n; ++p) for (int64_t q = 0; q <= p; ++q) {
+    const double* row = S4 + pidx(p, q) * np;
+    if (Jp) { double a = 0.0; for (int64_t i = 0; i < np; ++i) a += row[i] * Dp[i]; Jp[pidx(p, q)] = a; }
+    if (!K) continue;
+    for (int64_t r = 0; r < n; ++r) {
+      double a1 = 0.0, a2 = 0.0;
+      for (int64_t s = 0; s < n; ++s) { const double x = row[pidx(r, s)]; a1 += x * D[q * n + s]; a2 += x * D[p * n + s]; }
+      K[p * n + r] += a1;
+      if (p != q) K[q * n + r] += a2;
+    }
+  }
+  return 0;
+}
 int dev_pack_pair_rows(int64_t n, int64_t ncols, const double* in, double* out) {
   for (int64_t x = 0; x < n; ++x) for (int64_t y = 0; y <= x; ++y) std::copy(in + (x * n + y) * ncols, in + (x * n + y + 1) * ncols, out + pidx(x, y) * ncols);
   return 0;

@@ -396,6 +396,40 @@ def test_k_from_pairs_and_unpack(qlib, n):
     assert np.abs(dK.numpy((n, n)) - ref).max() < 1e-11 * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.parametrize("n", [1, 3, 17, 70, 131, 220, 300])
+def test_jk_from_packed_block(qlib, n):
+    """J and K in one pass over the 4-fold packed block (scf.cpp build_jk) == the dense contractions; n = 131 / 220 / 300 span several
+    LDS chunks and (300) two column owners per thread; a non-symmetric D on purpose; K only; run-to-run bitwise identical."""
+    rng = np.random.default_rng(1000 + n)
+    il = np.tril_indices(n)
+    npair = len(il[0])
+    if n <= 70:
+        eri = _sym_eri(n, rng)
+        s4 = np.ascontiguousarray(eri[il][:, il[0], il[1]])
+    else:                       # (pq|rs) = sum_P B B at sizes where the dense tensor is too big for einsum on the host
+        Bp = rng.standard_normal((5, npair))
+        s4 = Bp.T @ Bp
+    D = rng.standard_normal((n, n))
+    Ds = D + D.T - np.diag(np.diag(D))
+    Dp = np.ascontiguousarray(Ds[il])
+    d4, dD, dDp = DeviceBuffer.from_numpy(s4), DeviceBuffer.from_numpy(D), DeviceBuffer.from_numpy(Dp)
+    dJ, dK, dK2 = DeviceBuffer(npair), DeviceBuffer(n * n), DeviceBuffer(n * n)
+    check(qlib.qemb_op_jk_from_packed(n, d4.ptr, dD.ptr, dDp.ptr, dJ.ptr, dK.ptr))
+    check(qlib.qemb_op_jk_from_packed(n, d4.ptr, dD.ptr, None, None, dK2.ptr))
+    K, K2, Jp = dK.numpy((n, n)), dK2.numpy((n, n)), dJ.numpy((npair,))
+    assert np.array_equal(K, K2)
+    Jref = s4 @ Dp
+    assert np.abs(Jp - Jref).max() < 1e-11 * max(1.0, np.abs(Jref).max())
+    if n <= 70:
+        Kref = np.einsum("pqrs,qs->pr", eri, D)
+    else:                       # K[p,r] = sum_P (B_P D B_P^T)[p,r] with the symmetric matrices B_P
+        Bf = np.zeros((5, n, n)); Bf[:, il[0], il[1]] = Bp; Bf = Bf + Bf.transpose(0, 2, 1) - np.einsum("pii->pi", Bf)[:, :, None] * np.eye(n)
+        Kref = np.einsum("Ppq,qs,Prs->pr", Bf, D, Bf, optimize=True)
+    assert np.abs(K - Kref).max() < 1e-11 * max(1.0, np.abs(Kref).max())
+    check(qlib.qemb_op_jk_from_packed(n, d4.ptr, dD.ptr, dDp.ptr, dJ.ptr, dK2.ptr))
+    assert np.array_equal(dK2.numpy((n, n)), K) and np.array_equal(dJ.numpy((npair,)), Jp)
+
+
 def test_pm_pair_packing_roundtrip_and_lincomb(qlib):
     rng = np.random.default_rng(9)
     rows, v, o, ncols = 5, 7, 4, 6
