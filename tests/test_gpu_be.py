@@ -452,6 +452,16 @@ def test_periodic_direct_df_beyond_one_tile_and_into_a_fragment(qlib):
         f.dev.free()
 
 
+def test_periodic_driver_matches_the_supercell(qlib):
+    """BASELINE configs[4] (periodic BE2 with k-points) on the model the image allows: the k-point driver (kbe_pbe.BE, mirror of
+    kbe/pbe.py) on a ring of 4 cells x 3 orbitals with 4 k-points against the molecular driver on the 12-orbital supercell -- HF-in-HF,
+    one-shot and density-matched CCSD energies per cell, matched potentials; then the Gamma-point int-direct-DF branch."""
+    from test_kbe_pbe import check_gamma_point_driver_with_direct_df, check_periodic_driver
+    check_periodic_driver(qlib)
+    check_periodic_driver(qlib, nk=3, nlo=3)
+    check_gamma_point_driver_with_direct_df(qlib)
+
+
 def test_abs_overlap_quadrature_and_reachability_on_the_device(qlib):
     """approx_S_abs (molbe/eri_sparse_DF.py:928-959) with the primitive quadrature on the device, _get_AO_per_AO (:224-240):
     against the restatement of oracle/qemb_oracle/sparse_df.py (itself checked against a grid integral, tests/test_oracle_sparse_df.py)."""
