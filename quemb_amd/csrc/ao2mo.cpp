@@ -59,10 +59,10 @@ int ao2mo_dense(const AoEri& ao, const double* TA, int n, double* out_s4) {
   const int tcfg = (n > 192 && n <= 224) ? 13 : -1;   // one 224 x 128 tile instead of two padded 128-row tiles
   QTRY(dev_unpack_tril_rows(npN, N, ao.s4, W1));                                                   // [mn][k][l]
   QTRY(gemm(n, npN * N, N, 1.0, TA, n, false, W1, N, true, 0.0, W2, npN * N, 1, 0, 0, 0, tcfg));                     // [l'][mn][k]
-  QTRY(gemm(n, (int64_t)n * npN, N, 1.0, TA, n, false, W2, N, true, 0.0, W1, (int64_t)n * npN, 1, 0, 0, 0, tcfg));   // [k'][l'][mn]
+  QTRY(gemm_quarter_lower_rows(n, npN, N, TA, W2, W1));                                            // [k'][l'][mn], rows k' >= l' only
   QTRY(dev_unpack_tril_pair_rows(n, N, W1, W2));                                                   // keep k' >= l' rows, unpack mn: W2 = [(kl)][m][n]
   QTRY(gemm(n, npn * N, N, 1.0, TA, n, false, W2, N, true, 0.0, W1, npn * N, 1, 0, 0, 0, tcfg));                     // [j'][(kl)][m]
-  QTRY(gemm(n, (int64_t)n * npn, N, 1.0, TA, n, false, W1, N, true, 0.0, W2, (int64_t)n * npn, 1, 0, 0, 0, tcfg));   // [i'][j'][(kl)]
+  QTRY(gemm_quarter_lower_rows(n, npn, N, TA, W1, W2));                                            // [i'][j'][(kl)], rows i' >= j' only
   QTRY(dev_pack_pair_rows(n, npn, W2, out_s4));
   QTRY(lap_AO2MO.close());
   return 0;

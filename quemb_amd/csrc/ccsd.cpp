@@ -47,22 +47,7 @@ int mo_transform(int n, int o, int nf, const double* eri_s4, double* X0, double*
   // 193..224 rows fit ONE 224 x 128 tile (1.8 % padding instead of the 14 % of two 128-row tiles at n = 220)
   const int tcfg = (n > 192 && n <= 224) ? 13 : -1;
   QTRY(gemm(n, ncol, n, 1.0, C, n, false, X1, n, true, 0.0, X0, ncol, 1, 0, 0, 0, tcfg));
-  if (tcfg == 13) {
-    // Only the rows r' >= s' of X1[r'][s'][pq] are read below (the result is symmetric in r', s'): for the columns of s' in [s0, s1) the rows
-    // r' < s0 are not computed.  The boundaries s0 = n - T walk down the row-tile heights T that exist as tile configurations, so every block
-    // fills its tiles: 61 % of the MFMA work of the full product at n = 220 (the operand X0 is still streamed once).
-    static const struct { int rows, cfg; } tiles[] = {{224, 13}, {192, 15}, {128, 4}, {112, 33}, {64, 12}};
-    int s0 = 0;
-    for (int t = 0; t < 5 && s0 < n; ++t) {
-      const int s1 = (t + 1 < 5) ? std::min(n, std::max(s0, n - tiles[t + 1].rows)) : n;
-      if (s1 > s0)
-        QTRY(gemm(n - s0, (int64_t)(s1 - s0) * np, n, 1.0, C + s0, n, false, X0 + (int64_t)s0 * np * n, n, true, 0.0,
-                  X1 + (int64_t)s0 * ncol + (int64_t)s0 * np, ncol, 1, 0, 0, 0, tiles[t].cfg));
-      s0 = s1;
-    }
-  } else {
-    QTRY(gemm(n, ncol, n, 1.0, C, n, false, X0, n, true, 0.0, X1, ncol, 1, 0, 0, 0, tcfg));
-  }
+  QTRY(gemm_quarter_lower_rows(n, np, n, C, X0, X1));     // X1[r'][s'][pq], only the rows r' >= s' (all that is read below)
   QTRY(dev_unpack_tril_pair_rows(n, n, X1, X0));      // keep r' >= s' rows AND unpack pq, one pass: X0 = [(r's')][p][q]
   // the last two quarter transforms act on the n x n slab of every pair (r's'): two batched GEMMs, slab <- C^T slab C, which
   // leave the pair index IN FRONT -- every gather below then reads contiguous runs
