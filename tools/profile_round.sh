@@ -18,6 +18,7 @@ rm -rf gpurun_out/kt3
 # 3. one CCSD iteration, kernel by kernel
 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/kt -- python tools/frag_bench.py 220 20 > $OUT/frag_bench.log 2>&1
 python tools/trace_iteration.py gpurun_out/kt > $OUT/iteration_kernel_trace.txt
+python tools/trace_solve.py gpurun_out/kt > $OUT/solve_phases.txt
 rm -rf gpurun_out/kt
 # 4. HBM traffic of the ladder dispatches (FETCH_SIZE / WRITE_SIZE, separate passes)
 bash tools/pmc_ladder.sh > $OUT/pmc_ladder.log 2>&1

@@ -19,10 +19,8 @@ it_ns = per[len(per) // 2]
 cut = max(k for k in range(1, len(lad)) if starts[k] - starts[k - 1] > 2.5 * it_ns)        # first ladder of the last solve
 prev_last = lad[cut - 1]
 first, last = lad[cut], lad[-1]
-# end of the previous solve's tail: the unpack kernel that opens a solve
-open_idx = max(i for i in range(prev_last, first) if "unpack_tril" in rows[i]["Kernel_Name"] or "jk_packed" in rows[i]["Kernel_Name"] and i < prev_last + 400) if any(("unpack_tril" in rows[i]["Kernel_Name"]) for i in range(prev_last, first)) else prev_last + 1
+# the unpack of the packed ERIs into pair rows opens a solve
 open_idx = min(i for i in range(prev_last, first) if "unpack_tril" in rows[i]["Kernel_Name"])
-
 
 def phase(label, a, b):
     t0, t1 = int(rows[a]["Start_Timestamp"]), int(rows[b - 1]["End_Timestamp"])
