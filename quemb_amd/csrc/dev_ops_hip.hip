@@ -1435,6 +1435,7 @@ int dev_jk_from_packed(int64_t n, const double* S4, const double* D, const doubl
   REQUIRE_INIT();
   if (n <= 0) return QEMB_OK;
   if (n > 1024) { set_error("dev_jk_from_packed: n > 1024 (use dev_k_from_pairs)"); return QEMB_ERR_ARG; }
+  if (!S4 || !D || (Jp && !Dp) || (!Jp && !K)) { set_error("dev_jk_from_packed: bad arguments"); return QEMB_ERR_ARG; }
   const long long np = n * (n + 1) / 2;
   int rc = ensure_ws((size_t)2 * np * n * sizeof(double));
   if (rc) return rc;

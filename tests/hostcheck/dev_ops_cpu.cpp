@@ -130,6 +130,9 @@ int dev_k_from_pairs(int64_t n, const double* H, const double* D, double* K) {
   return 0;
 }
 int dev_jk_from_packed(int64_t n, const double* S4, const double* D, const double* Dp, double* Jp, double* K) {
+  if (n <= 0) return 0;
+  if (n > 1024) { set_error("dev_jk_from_packed: n > 1024 (use dev_k_from_pairs)"); return QEMB_ERR_ARG; }
+  if (!S4 || !D || (Jp && !Dp) || (!Jp && !K)) { set_error("dev_jk_from_packed: bad arguments"); return QEMB_ERR_ARG; }
   const int64_t np = n * (n + 1) / 2;
   if (K) std::fill(K, K + n * n, 0.0);
   for (int64_t p = 0; p < n; ++p) for (int64_t q = 0; q <= p; ++q) {

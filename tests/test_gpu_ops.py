@@ -430,6 +430,17 @@ def test_jk_from_packed_block(qlib, n):
     assert np.array_equal(dK2.numpy((n, n)), K) and np.array_equal(dJ.numpy((npair,)), Jp)
 
 
+def test_jk_from_packed_block_argument_errors(qlib):
+    from quemb_amd._lib import QembError
+    d = DeviceBuffer(16)
+    with pytest.raises(QembError):
+        check(qlib.qemb_op_jk_from_packed(1025, d.ptr, d.ptr, None, None, d.ptr))       # n > 1024: the pair-row path is the one to use
+    with pytest.raises(QembError):
+        check(qlib.qemb_op_jk_from_packed(2, d.ptr, d.ptr, None, d.ptr, d.ptr))          # Jp without Dp
+    with pytest.raises(QembError):
+        check(qlib.qemb_op_jk_from_packed(2, d.ptr, d.ptr, None, None, None))            # nothing to compute
+
+
 def test_pm_pair_packing_roundtrip_and_lincomb(qlib):
     rng = np.random.default_rng(9)
     rows, v, o, ncols = 5, 7, 4, 6
