@@ -36,7 +36,11 @@ int qemb_timer_live_events(int slot);      /* event pairs held by the calling co
 int qemb_op_gemm(int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t lda, int a_kcontig,
                  int64_t strideA, const double* B, int64_t ldb, int b_kcontig, int64_t strideB, double beta,
                  double* C, int64_t ldc, int64_t strideC, int64_t batch);
-int qemb_set_gemm_config(int cfg);         /* -1 = automatic tile choice; >=0 forces a tile config  */
+/* -1 = automatic tile choice; 0..99 force a tile configuration (calling host thread only); 2xx = the round-1 main loop of the same tiles
+ * (A/B measurements); 3xx = diagnostic instantiations that stamp s_memtime (qemb_op_gemm_stamps); 4xx / 5xx / 6xx = ABLATION instantiations
+ * that leave memory traffic out and return WRONG products by construction (tools/gemm_ablation.py) -- measurement aids, reachable through
+ * this hook only, never selected by the dispatcher or by any driver.                                                                      */
+int qemb_set_gemm_config(int cfg);
 /* calibration: sustained v_mfma_f64_16x16x4_f64 rate of the chip, registers only (TFLOP/s)           */
 int qemb_mfma_f64_peak(int iters, int blocks_per_cu, double* tflops);
 int qemb_set_gemm_splitk(int enabled);    /* automatic split-K for few-tile / long-K products (default on) */
