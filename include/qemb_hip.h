@@ -91,7 +91,8 @@ int qemb_frag_set_energy_data(qemb_frag_t f, const double* h1, const double* vef
 int qemb_frag_jk(qemb_frag_t f, const double* P, double* J, double* K);
 /* one fragment of the sweep.  h = fock + heff (n x n); dm0 n x n or NULL; eeval: also fragment energies.
  * outputs (any may be NULL): mo_coeff n*n, mo_energy n, rdm1_emb n*n (= C rdm1 C^T / 2, Frags._rdm1),
- * rdm1_mo n*n (Frags.rdm1__), t1 o*v, t2 o*o*v*v, e_frag[3] = [e1,e2,ec], scalars.                     */
+ * rdm1_mo n*n (Frags.rdm1__), t1 o*v, t2 o*o*v*v, e_frag[3] = [e1,e2,ec], scalars.  0 < nsocc <= n; nsocc == n (no virtual
+ * orbitals) returns the mean-field results with E_corr = 0 and empty amplitudes, as PySCF's CCSD does.   */
 int qemb_frag_solve(qemb_frag_t f, int nsocc, const double* h, const double* dm0, const qemb_solver_opts* opts,
                     int eeval, double* mo_coeff, double* mo_energy, double* rdm1_emb, double* rdm1_mo, double* t1,
                     double* t2, double* e_frag, double* e_corr_mo, double* e_scf, double* ebe_hf, int* n_iter,

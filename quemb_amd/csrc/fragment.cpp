@@ -182,8 +182,11 @@ int Fragment::ccsd_iterate(int niter, double* e_corr, double* normt) {
 int Fragment::solve(int o, const double* h, const double* dm0, const FragmentOptions& opt, int eeval, FragmentResult* res,
                     double* mo_coeff, double* mo_energy, double* rdm1_emb, double* rdm1_mo, double* t1_out, double* t2_out) {
   if (!eri_s4_.p) { set_error("Fragment: ERIs not set"); return QEMB_ERR_ARG; }
-  if (o <= 0 || o >= n_) { set_error("Fragment: need 0 < nsocc < n"); return QEMB_ERR_ARG; }
+  if (o <= 0 || o > n_) { set_error("Fragment: need 0 < nsocc <= n"); return QEMB_ERR_ARG; }
   const int n = n_, v = n - o;
+  // nsocc == n: an embedding space without virtual orbitals.  PySCF's CCSD then has empty amplitude arrays and returns E_corr = 0; the
+  // sweep body needs the mean-field results only (density = 2 I in any orthonormal basis, no correlation contribution to the energies).
+  const bool no_virtuals = (v == 0);
   const int64_t n2 = (int64_t)n * n;
   cc_.reset();
   // ---- fragment RHF on the half-unpacked tensor [P(p,q)][r][s] (kept: it is the first operand of the MO transformation)
@@ -198,6 +201,10 @@ int Fragment::solve(int o, const double* h, const double* dm0, const FragmentOpt
   QTRY(dev_d2h(C.data(), C_, sizeof(double) * n2));
   QTRY(dev_d2h(eps.data(), eps_, sizeof(double) * n));
   // ---- integrals + CCSD
+  if (no_virtuals) {
+    X1.release();
+    res->e_corr_mo = 0.0; res->n_iter = 0; res->ccsd_converged = true; res->lambda_iters = 0;
+  } else {
   QTRY(X0.alloc(mo_transform_work(n)));
   MoIntegrals ints;
   QTRY(mo_transform(n, o, eeval ? nf_ : 0, eri_s4_, X0, X1, C_, ints, /*build_Vl=*/false, /*build_T34=*/opt.relax_density != 0,
@@ -214,14 +221,19 @@ int Fragment::solve(int o, const double* h, const double* dm0, const FragmentOpt
   QTRY(cc_->kernel(opt.cc, &res->e_corr_mo, &res->n_iter, &conv));
   res->ccsd_converged = conv;
   if (!conv) { set_error("CCSD did not converge in max_cycle iterations"); return QEMB_ERR_NOCONV; }
+  }
   // ---- amplitudes to the host as requested; unrelaxed 1-RDM (depends on t1 only)
   std::vector<double> t1((size_t)o * v);
-  QTRY(dev_d2h(t1.data(), cc_->t1(), sizeof(double) * o * v));
+  if (!no_virtuals) QTRY(dev_d2h(t1.data(), cc_->t1(), sizeof(double) * o * v));
   if (t1_out) std::memcpy(t1_out, t1.data(), sizeof(double) * o * v);
-  if (t2_out) QTRY(dev_d2h(t2_out, cc_->t2(), sizeof(double) * (int64_t)o * o * v * v));
+  if (t2_out && !no_virtuals) QTRY(dev_d2h(t2_out, cc_->t2(), sizeof(double) * (int64_t)o * o * v * v));
   // ---- relax_density: Lambda equations, response 1-RDM and the contraction of the response 2-RDM with the fragment ERIs
   std::vector<double> dm1r, Imat;
-  if (opt.relax_density) {
+  if (opt.relax_density && no_virtuals) {
+    dm1r.assign((size_t)n2, 0.0);
+    for (int i = 0; i < n; ++i) dm1r[(size_t)i * n + i] = 2.0;
+    if (eeval) Imat.assign((size_t)n * nf_, 0.0);
+  } else if (opt.relax_density) {
     CcLambda lam(*cc_);
     QTRY(lam.setup());
     if (opt.warm_start && z_prev_.p && z_prev_o_ == o) QTRY(lam.set_guess(z_prev_));
@@ -266,7 +278,8 @@ int Fragment::solve(int o, const double* h, const double* dm0, const FragmentOpt
   if (eeval) {
     if (h1_.empty() || veff0_.empty()) { set_error("Fragment: set_energy_data(h1, veff0, ...) before an energy evaluation"); return QEMB_ERR_ARG; }
     std::vector<double> Z1, Z2;
-    if (!opt.relax_density) QTRY(cc_->energy_intermediates(Z1, Z2));
+    if (!opt.relax_density && !no_virtuals) QTRY(cc_->energy_intermediates(Z1, Z2));
+    if (no_virtuals) { Z1.assign((size_t)o * nf_, 0.0); Z2.clear(); }
     std::vector<double> e1((size_t)nf_, 0.0), e2((size_t)nf_, 0.0), ec((size_t)nf_, 0.0);
     for (int P = 0; P < nf_; ++P) {
       double s1 = 0, sc = 0;
@@ -304,7 +317,7 @@ int Fragment::solve(int o, const double* h, const double* dm0, const FragmentOpt
     }
   }
   // ---- keep amplitudes for a warm start of the next sweep
-  if (opt.keep_amplitudes || opt.warm_start) {
+  if ((opt.keep_amplitudes || opt.warm_start) && !no_virtuals) {
     const int64_t na = cc_->n_amp();
     QTRY(t_prev_.alloc(na));
     QTRY(dcopy(na, cc_->t1(), t_prev_));

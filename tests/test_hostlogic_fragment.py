@@ -156,3 +156,36 @@ def test_lambda_nonconvergence_is_an_error(hlib):
         fr.solve(2, h, opts=default_opts(hlib, relax_density=1, lambda_max_cycle=1), eeval=False)
     out = fr.solve(2, h, opts=default_opts(hlib, relax_density=1), eeval=False)     # and the handle is still usable
     assert out["lambda_iters"] > 1
+
+
+def check_fragment_without_virtual_orbitals(lib):
+    """nsocc == n (solver.py:829-946 on a mean field with no virtuals: PySCF's CCSD has empty amplitudes, E_corr = 0): the sweep body
+    returns the mean-field results -- E_scf of the full density 2 I, rdm1 = 2 I (MO) / I (embedding), zero correlation contributions to
+    the fragment energies, the fragment HF energy of update_ebe_hf -- with and without relax_density, and a later solve with virtuals on
+    the same fragment object is unaffected."""
+    from qemb_oracle import scf as oscf
+    from quemb_amd.fragsolver import DeviceFragment, default_opts
+    for n in (1, 3, 4):
+        h, e1 = synthetic_fragment(n, max(1, n - 1), 40 + n)
+        vj, vk = oscf.get_jk(e1, 2.0 * np.eye(n))
+        e_hf = float(np.sum((h + 0.5 * (vj - 0.5 * vk)) * 2.0 * np.eye(n)))
+        fr = DeviceFragment(n, 1, lib=lib)
+        fr.set_eri_s4(eri.pack_s4(e1))
+        fr.set_energy_data(h, 0.3 * h, 0.2 * h, 1.0, [0])
+        for relax in (0, 1):
+            out = fr.solve(n, h, opts=default_opts(lib, relax_density=relax), eeval=True, want_t2=True)
+            assert out["e_corr_mo"] == 0.0 and out["n_iter"] == 0 and out["t1"].size == 0 and out["t2"].size == 0
+            assert abs(out["e_scf"] - e_hf) < 1e-10
+            assert np.abs(out["rdm1_mo"] - 2.0 * np.eye(n)).max() < 1e-14 and np.abs(out["rdm1_emb"] - np.eye(n)).max() < 1e-12
+            assert np.abs(np.asarray(out["e_frag"])).max() == 0.0
+            # update_ebe_hf (pfrag.py:327-400) for the centre 0 with D = Co Co^T = I:  2 h1_00 + veff_00 + (J - K/2)_00 of dm = 2 I
+            e_be = 2.0 * h[0, 0] + 0.2 * h[0, 0] + vj[0, 0] - 0.5 * vk[0, 0]
+            assert abs(out["ebe_hf"] - e_be) < 1e-10, (out["ebe_hf"], e_be)
+        if n > 1:
+            ok = fr.solve(n - 1, h, eeval=False)
+            assert ok["n_iter"] > 0 or n == 2
+        fr.free()
+
+
+def test_fragment_without_virtual_orbitals(hlib):
+    check_fragment_without_virtual_orbitals(hlib)
