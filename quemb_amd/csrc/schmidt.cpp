@@ -18,7 +18,7 @@ namespace qemb {
 // with leading dimension ld_out >= n_f + n_b (caller gives N x ld_out).  Returns n_b.
 int schmidt_eigh(const double* lmo, int N, int nmo, int nocc, const int64_t* frag, int n_f, double thr, double* TA_out,
                  int ld_out, int* n_b_out, int* sweeps_out) {
-  if (N <= 0 || nocc <= 0 || nocc > nmo || n_f <= 0 || n_f >= N) { set_error("schmidt: bad dimensions"); return QEMB_ERR_ARG; }
+  if (N <= 0 || nocc <= 0 || nocc > nmo || n_f <= 0 || n_f > N) { set_error("schmidt: bad dimensions"); return QEMB_ERR_ARG; }
   std::vector<char> isfrag((size_t)N, 0);
   for (int k = 0; k < n_f; ++k) {
     if (frag[k] < 0 || frag[k] >= N || isfrag[(size_t)frag[k]]) { set_error("schmidt: bad fragment index list"); return QEMB_ERR_ARG; }
@@ -27,6 +27,16 @@ int schmidt_eigh(const double* lmo, int N, int nmo, int nocc, const int64_t* fra
   std::vector<int> env;
   for (int i = 0; i < N; ++i) if (!isfrag[(size_t)i]) env.push_back(i);
   const int ne = (int)env.size();
+  if (ne == 0) {
+    // the fragment is the whole system: the environment block is 0 x 0, no bath (numpy's eigh of the empty block at pfrag.py:468 returns
+    // empty arrays); TA_lo_eo is the identity in fragment order
+    *n_b_out = 0;
+    if (sweeps_out) *sweeps_out = 0;
+    if (n_f > ld_out) { set_error("schmidt: output buffer too narrow for n_f + n_b columns"); return QEMB_ERR_ARG; }
+    for (int i = 0; i < N; ++i) for (int c = 0; c < ld_out; ++c) TA_out[(size_t)i * ld_out + c] = 0.0;
+    for (int k = 0; k < n_f; ++k) TA_out[(size_t)frag[k] * ld_out + k] = 1.0;
+    return 0;
+  }
   // C_env = rows of the occupied LMO block that belong to the environment; Denv = C_env C_env^T  (pfrag.py:448-465)
   std::vector<double> cenv((size_t)ne * nocc);
   for (int r = 0; r < ne; ++r) for (int k = 0; k < nocc; ++k) cenv[(size_t)r * nocc + k] = lmo[(size_t)env[(size_t)r] * nmo + k];
@@ -58,7 +68,7 @@ int schmidt_eigh(const double* lmo, int N, int nmo, int nocc, const int64_t* fra
 // project D_env on that basis (n_f x n_f), diagonalise the projection, rotate back.
 int schmidt_subspace(const double* lmo, int N, int nmo, int nocc, const int64_t* frag, int n_f, double thr, double* TA_out,
                      int ld_out, int* n_b_out, int* sweeps_out) {
-  if (N <= 0 || nocc <= 0 || nocc > nmo || n_f <= 0 || n_f >= N) { set_error("schmidt: bad dimensions"); return QEMB_ERR_ARG; }
+  if (N <= 0 || nocc <= 0 || nocc > nmo || n_f <= 0 || n_f > N) { set_error("schmidt: bad dimensions"); return QEMB_ERR_ARG; }
   std::vector<char> isfrag((size_t)N, 0);
   for (int k = 0; k < n_f; ++k) {
     if (frag[k] < 0 || frag[k] >= N || isfrag[(size_t)frag[k]]) { set_error("schmidt: bad fragment index list"); return QEMB_ERR_ARG; }
@@ -67,6 +77,16 @@ int schmidt_subspace(const double* lmo, int N, int nmo, int nocc, const int64_t*
   std::vector<int> env;
   for (int i = 0; i < N; ++i) if (!isfrag[(size_t)i]) env.push_back(i);
   const int ne = (int)env.size();
+  if (ne == 0) {
+    // the fragment is the whole system: the environment block is 0 x 0, no bath (numpy's eigh of the empty block at pfrag.py:468 returns
+    // empty arrays); TA_lo_eo is the identity in fragment order
+    *n_b_out = 0;
+    if (sweeps_out) *sweeps_out = 0;
+    if (n_f > ld_out) { set_error("schmidt: output buffer too narrow for n_f + n_b columns"); return QEMB_ERR_ARG; }
+    for (int i = 0; i < N; ++i) for (int c = 0; c < ld_out; ++c) TA_out[(size_t)i * ld_out + c] = 0.0;
+    for (int k = 0; k < n_f; ++k) TA_out[(size_t)frag[k] * ld_out + k] = 1.0;
+    return 0;
+  }
   if (ne < n_f) return schmidt_eigh(lmo, N, nmo, nocc, frag, n_f, thr, TA_out, ld_out, n_b_out, sweeps_out);
   std::vector<double> cenv((size_t)ne * nocc), cf((size_t)n_f * nocc);
   for (int r = 0; r < ne; ++r) for (int k = 0; k < nocc; ++k) cenv[(size_t)r * nocc + k] = lmo[(size_t)env[(size_t)r] * nmo + k];
@@ -114,7 +134,7 @@ int schmidt_subspace(const double* lmo, int N, int nmo, int nocc, const int64_t*
 // rdm: N x N (host, real).  kbe/solver.py:9-46.
 int schmidt_svd(const double* rdm, int N, const int64_t* frag_in, int n_f, double thr, double* TA_out, int ld_out, int* n_b_out,
                 int* sweeps_out) {
-  if (N <= 0 || n_f <= 0 || n_f >= N) { set_error("schmidt_svd: bad dimensions"); return QEMB_ERR_ARG; }
+  if (N <= 0 || n_f <= 0 || n_f > N) { set_error("schmidt_svd: bad dimensions"); return QEMB_ERR_ARG; }
   std::vector<int> frag((size_t)n_f);
   std::vector<char> isfrag((size_t)N, 0);
   for (int k = 0; k < n_f; ++k) {
@@ -125,7 +145,31 @@ int schmidt_svd(const double* rdm, int N, const int64_t* frag_in, int n_f, doubl
   std::vector<int> env;
   for (int i = 0; i < N; ++i) if (!isfrag[(size_t)i]) env.push_back(i);
   const int ne = (int)env.size();
-  if (ne < n_f) { set_error("schmidt_svd: environment smaller than the fragment"); return QEMB_ERR_ARG; }
+  if (ne < n_f) {
+    // a wide block (fewer environment than fragment sites; scipy's svd takes any shape): the left vectors of G are the right vectors of
+    // G^T (n_f x ne), which the one-sided Jacobi solver (rows >= columns) takes.  An empty environment has no bath.
+    int nb = 0;
+    std::vector<double> s((size_t)ne), V((size_t)ne * ne);
+    if (ne > 0) {
+      std::vector<double> Gt((size_t)n_f * ne);
+      for (int k = 0; k < n_f; ++k) for (int r = 0; r < ne; ++r) Gt[(size_t)k * ne + r] = rdm[(size_t)env[(size_t)r] * N + frag[(size_t)k]];
+      DBuf dG, ds, dU, dV;
+      QTRY(dG.alloc((int64_t)n_f * ne)); QTRY(ds.alloc(ne)); QTRY(dU.alloc((int64_t)n_f * ne)); QTRY(dV.alloc((int64_t)ne * ne));
+      QTRY(dev_h2d(dG, Gt.data(), sizeof(double) * n_f * ne));
+      QTRY(dev_jacobi_svd(n_f, ne, dG, ds, dU, dV, sweeps_out));
+      QTRY(dev_d2h(s.data(), ds, sizeof(double) * ne));
+      QTRY(dev_d2h(V.data(), dV, sizeof(double) * ne * ne));
+      for (int k = 0; k < ne; ++k) if (s[(size_t)k] >= thr) ++nb;
+    } else if (sweeps_out) {
+      *sweeps_out = 0;
+    }
+    *n_b_out = nb;
+    if (n_f + nb > ld_out) { set_error("schmidt_svd: output buffer too narrow"); return QEMB_ERR_ARG; }
+    for (int i = 0; i < N; ++i) for (int c = 0; c < ld_out; ++c) TA_out[(size_t)i * ld_out + c] = 0.0;
+    for (int k = 0; k < n_f; ++k) TA_out[(size_t)frag[(size_t)k] * ld_out + k] = 1.0;
+    for (int r = 0; r < ne; ++r) for (int b = 0; b < nb; ++b) TA_out[(size_t)env[(size_t)r] * ld_out + n_f + b] = V[(size_t)r * ne + b];
+    return 0;
+  }
   std::vector<double> G((size_t)ne * n_f);
   for (int r = 0; r < ne; ++r) for (int k = 0; k < n_f; ++k) G[(size_t)r * n_f + k] = rdm[(size_t)env[(size_t)r] * N + frag[(size_t)k]];    // :37
   DBuf dG, ds, dU;

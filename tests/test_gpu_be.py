@@ -462,6 +462,12 @@ def test_periodic_driver_matches_the_supercell(qlib):
     check_gamma_point_driver_with_direct_df(qlib)
 
 
+def test_whole_system_fragment_is_the_molecular_ccsd(qlib):
+    from test_hostlogic_be import check_schmidt_svd_wide_and_empty_environment, check_whole_system_fragment
+    check_whole_system_fragment(qlib)
+    check_schmidt_svd_wide_and_empty_environment(qlib)
+
+
 def test_abs_overlap_quadrature_and_reachability_on_the_device(qlib):
     """approx_S_abs (molbe/eri_sparse_DF.py:928-959) with the primitive quadrature on the device, _get_AO_per_AO (:224-240):
     against the restatement of oracle/qemb_oracle/sparse_df.py (itself checked against a grid integral, tests/test_oracle_sparse_df.py)."""
