@@ -225,7 +225,7 @@ int Fragment::solve(int o, const double* h, const double* dm0, const FragmentOpt
   // ---- amplitudes to the host as requested; unrelaxed 1-RDM (depends on t1 only)
   std::vector<double> t1((size_t)o * v);
   if (!no_virtuals) QTRY(dev_d2h(t1.data(), cc_->t1(), sizeof(double) * o * v));
-  if (t1_out) std::memcpy(t1_out, t1.data(), sizeof(double) * o * v);
+  if (t1_out && !t1.empty()) std::memcpy(t1_out, t1.data(), sizeof(double) * o * v);
   if (t2_out && !no_virtuals) QTRY(dev_d2h(t2_out, cc_->t2(), sizeof(double) * (int64_t)o * o * v * v));
   // ---- relax_density: Lambda equations, response 1-RDM and the contraction of the response 2-RDM with the fragment ERIs
   std::vector<double> dm1r, Imat;
