@@ -22,8 +22,10 @@
 //  * f64 MFMA lane maps (guide cdna_hip_programming.md §3):  A: lane l holds A[row=l&15][k=l>>4];
 //    B: lane l holds B[k=l>>4][col=l&15];  D: reg r of lane l is D[row=(l>>4)+4r][col=l&15].
 //  * blockIdx -> tile map is XCD aware: the 8 XCDs (private L2 each) get contiguous chunks of the
-//    logical tile order, m-tiles fastest, so the m-tiles that share one streamed B panel (W_vvvv for
-//    the ladder: 12.8 GB) run on one XCD at the same time and the panel is fetched from HBM once.
+//    logical tile order, m-tiles fastest, so the m-tiles that share one streamed B panel (the (+/-) pair-packed
+//    W_vvvv operands of the ladder: 3.2 GB each) run on one XCD at the same time and the panel is fetched from HBM once.
+//  * the large tiles run the MODE 1 main loop (explicit ds_read_b64 fragment reads one k-step ahead, LDS stores spread behind
+//    the MFMA rows, barrier before the last k-step; see the comment above it); DESIGN.md section 4 has the measurements.
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <atomic>
