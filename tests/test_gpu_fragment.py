@@ -259,3 +259,35 @@ def test_full_size_fragment_is_invariant_under_a_rotation_of_the_embedding_basis
     for (i, j, k, l) in ((0, 0, 0, 0), (n - 1, 0, 5, 3), (100, 37, 219, 218)):
         assert abs(e2[pr(i, j), pr(k, l)] - Bq[:, i, j] @ Bq[:, k, l]) < 1e-11
     fr.free(); fr2.free()
+
+
+def test_fragment_larger_than_the_benchmark_size(qlib):
+    """n = 300, n_occ = 30 (n_virt = 270): past every tile configuration tuned for the benchmark -- 465 packed pair rows (no single-tile
+    ladder), n > 224 (two row tiles in the MO transformation), ov = 8100 ring products -- checked through the size-independent property of
+    the full-size test: an orthogonal rotation of the embedding basis (here applied to the density-fitting factor the ERIs are built
+    from) leaves the fragment RHF energy and E_corr unchanged and rotates the 1-RDM."""
+    from quemb_amd._lib import DeviceBuffer, check
+    n, o, naux = 300, 30, 240
+    rng = np.random.default_rng(300)
+    B = 0.022 * rng.standard_normal((naux, n, n)); B = 0.5 * (B + B.transpose(0, 2, 1))
+    A = rng.standard_normal((n, n))
+    h = np.diag(2.0 * np.arange(n)) + 0.3 * 0.5 * (A + A.T)
+    Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    il = np.tril_indices(n)
+    npair = len(il[0])
+    outs = []
+    for Bx, hx in ((B, h), (np.einsum("Ppq,pi,qj->Pij", B, Q, Q, optimize=True), Q.T @ h @ Q)):
+        Bp = np.ascontiguousarray(Bx[:, il[0], il[1]])
+        dB, d4 = DeviceBuffer.from_numpy(Bp), DeviceBuffer(npair * npair)
+        check(qlib.qemb_op_gemm(npair, npair, naux, 1.0, dB.ptr, npair, 0, 0, dB.ptr, npair, 0, 0, 0.0, d4.ptr, npair, 0, 1))
+        dB.free()
+        fr = DeviceFragment(n, 22)
+        fr.set_eri_s4_dev(d4.ptr); d4.free()
+        outs.append(fr.solve(o, hx, opts=default_opts(), eeval=False))
+        fr.free()
+        check(qlib.qemb_trim())
+    a, b = outs
+    assert a["n_iter"] > 5 and abs(a["e_corr_mo"]) > 1.0
+    assert abs(a["e_scf"] - b["e_scf"]) < 1e-9 * abs(a["e_scf"])
+    assert abs(a["e_corr_mo"] - b["e_corr_mo"]) < 1e-8, (a["e_corr_mo"], b["e_corr_mo"])
+    assert np.abs(b["rdm1_emb"] - Q.T @ a["rdm1_emb"] @ Q).max() < 1e-8
