@@ -195,9 +195,17 @@ int CcsdSolver::set_amps(const double* t1d, const double* t2d) {
 // tile configuration and K split for the "few packed pair rows x many columns" GEMMs (ladder, tau-side dressing)
 static void pick_pair_gemm(int64_t rows, int64_t cols, int& cfg, int& ks) {
   cfg = -1; ks = 0;
-  if (rows > 224 || cols < 2048) return;
-  cfg = rows <= 64 ? 12 : (rows <= 112 ? 11 : (rows <= 192 ? 15 : 13));
-  const int64_t tiles = (cols + 127) / 128;
+  if (cols < 2048) return;
+  int64_t tiles;
+  if (rows > 224) {
+    // more packed pair rows than one tile holds (n_occ > 20): 128-row tiles of the 128 x 256 configuration, K split like below.  (The
+    // dispatcher's own choice for "few tiles" is the 64 x 64 tile, a quarter of the rate on these long-K products.)
+    cfg = 4;
+    tiles = ((rows + 127) / 128) * ((cols + 255) / 256);
+  } else {
+    cfg = rows <= 64 ? 12 : (rows <= 112 ? 11 : (rows <= 192 ? 15 : 13));
+    tiles = (cols + 127) / 128;
+  }
   double best = 0.0;
   for (int c = 1; c <= 8; ++c) {
     const int64_t units = tiles * c, rounds = (units + 255) / 256;

@@ -153,9 +153,17 @@ static int trim_all_contexts() {
   for (DevCtx* c : all) trim_ctx_locked(*c);
   return QEMB_OK;
 }
-// Cached blocks of one context are capped (QEMB_POOL_CAP_GB, default 96): beyond it a released block goes back to the driver.
+// Cached blocks of one context are capped (QEMB_POOL_CAP_GB; default: half of the device's memory, 144 GB on an MI355X -- the working
+// set of an n = 300 fragment solve, 2 x 32.5 GB of transform buffers + the 21 GB ladder operands, stays parked between solves): beyond it a
+// released block goes back to the driver.  An allocation that fails trims every context's parked blocks and retries (dev_alloc).
 static size_t pool_cap_bytes() {
-  static const size_t cap = [] { const char* e = std::getenv("QEMB_POOL_CAP_GB"); const double gb = e ? std::atof(e) : 96.0; return (size_t)(gb * (double)(1ull << 30)); }();
+  static const size_t cap = [] {
+    const char* e = std::getenv("QEMB_POOL_CAP_GB");
+    if (e) return (size_t)(std::atof(e) * (double)(1ull << 30));
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || total_b == 0) return (size_t)96 << 30;
+    return total_b / 2;
+  }();
   return cap;
 }
 int dev_alloc(void** p, size_t bytes) {
