@@ -198,10 +198,16 @@ static void pick_pair_gemm(int64_t rows, int64_t cols, int& cfg, int& ks) {
   if (cols < 2048) return;
   int64_t tiles;
   if (rows > 224) {
-    // more packed pair rows than one tile holds (n_occ > 20): 128-row tiles of the 128 x 256 configuration, K split like below.  (The
-    // dispatcher's own choice for "few tiles" is the 64 x 64 tile, a quarter of the rate on these long-K products.)
-    cfg = 4;
-    tiles = ((rows + 127) / 128) * ((cols + 255) / 256);
+    // more packed pair rows than one tile holds (n_occ > 20): the row-tile height with the least padding among the configurations that
+    // exist (ties: the taller tile), K split like below.  (The dispatcher's own choice for "few tiles" is the 64 x 64 tile, a quarter of
+    // the rate on these long-K products.)
+    static const struct { int rows, cfg, cols; } cand[] = {{224, 13, 128}, {192, 15, 128}, {160, 35, 128}, {128, 4, 256}, {112, 33, 128}};
+    int64_t best_pad = -1;
+    tiles = 0;
+    for (const auto& c : cand) {
+      const int64_t mt = (rows + c.rows - 1) / c.rows, pad = mt * c.rows;
+      if (best_pad < 0 || pad < best_pad) { best_pad = pad; cfg = c.cfg; tiles = mt * ((cols + c.cols - 1) / c.cols); }
+    }
   } else {
     cfg = rows <= 64 ? 12 : (rows <= 112 ? 11 : (rows <= 192 ? 15 : 13));
     tiles = (cols + 127) / 128;

@@ -799,6 +799,7 @@ static int dev_gemm_dispatch(const GemmDesc& d) {
     case 15: return launch_layout<6, 2, 2, 4, 16, 0, 1>(d, s, vec2);  // 192 x 128, 8 waves as 2 x 4 (the 190 antisymmetric pair rows of o = 20)
     case 33: return launch_layout<7, 2, 1, 4, 16, 0, 1>(d, s, vec2);  // 112 x 128, 4 waves, TWO workgroups per CU (66 KB of LDS each): short-K products
     case 34: return launch_layout<2, 7, 4, 2, 16, 0, 1>(d, s, vec2);  // 128 x 224, 8 waves as 4 x 2 (2 x 7 MFMA tiles per wave): tall products with 192 < N <= 224
+    case 35: return launch_layout<5, 2, 2, 4, 16, 0, 1>(d, s, vec2);  // 160 x 128, 8 waves as 2 x 4 (5 x 2 MFMA tiles per wave): pair-row counts that 160 divides well (465 = npair(30))
     case 20: return launch_layout<4, 1, 2, 2, 16>(d, s, vec2);   // 128 x  32, 4 waves: tall products with N = n_occ (the t1 contractions of ovvv)
     case 21: return launch_layout<1, 4, 2, 2, 16>(d, s, vec2);   //  32 x 128, 4 waves: the same with M = n_occ
     case 23: return launch_layout<7, 2, 2, 4, 16, 1, 1>(d, s, vec2);   // = 13 under its own kernel symbol (pp-ladder, + pairs)

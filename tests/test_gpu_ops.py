@@ -29,7 +29,7 @@ def _gemm(lib, A, B, Cm, alpha, beta, a_kc, b_kc, batch=1, cfg=-1):
     return dC.numpy(Cm.shape)
 
 
-@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 4, 10, 11, 12, 33, 34, 200, 204])
+@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 4, 10, 11, 12, 33, 34, 35, 200, 204])
 @pytest.mark.parametrize("a_kc,b_kc", [(1, 1), (1, 0), (0, 1), (0, 0)])
 @pytest.mark.parametrize("shape", [(128, 128, 64), (400, 300, 200), (37, 53, 29), (441, 441, 441), (1, 220, 96), (130, 258, 18),
                                    (66, 130, 6), (64, 64, 16), (50, 70, 5)])      # the last three: a single k-tile (no second LDS buffer is ever filled)
@@ -526,7 +526,7 @@ def test_gather_and_scale_rows(qlib):
 # cfg 15 / 25: 192 x 128 tile (6 x 2 per wave) -- the (-) pair block (M = 190);
 # cfg 20 / 21: 128 x 32 / 32 x 128 tiles -- the products with an n_occ-sized side (ccsd.cpp:249).
 # 23 / 25 are 13 / 15 under the ladder's own kernel symbol (ccsd.cpp:217), i.e. separately compiled instantiations.
-@pytest.mark.parametrize("cfg,M", [(13, 210), (23, 210), (13, 224), (13, 220), (15, 190), (25, 190), (15, 192), (23, 97), (213, 210), (215, 190), (33, 220), (33, 112), (33, 113)])
+@pytest.mark.parametrize("cfg,M", [(13, 210), (23, 210), (13, 224), (13, 220), (15, 190), (25, 190), (15, 192), (23, 97), (213, 210), (215, 190), (33, 220), (33, 112), (33, 113), (35, 160), (35, 465), (35, 161)])
 @pytest.mark.parametrize("a_kc,b_kc", [(1, 1), (1, 0), (0, 1), (0, 0)])
 @pytest.mark.parametrize("ks", [0, 8])
 def test_gemm_ladder_tile_configs(qlib, cfg, M, a_kc, b_kc, ks):
