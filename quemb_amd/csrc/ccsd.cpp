@@ -196,21 +196,14 @@ int CcsdSolver::set_amps(const double* t1d, const double* t2d) {
 static void pick_pair_gemm(int64_t rows, int64_t cols, int& cfg, int& ks) {
   cfg = -1; ks = 0;
   if (cols < 2048) return;
-  int64_t tiles;
-  if (rows > 224) {
-    // more packed pair rows than one tile holds (n_occ > 20): the row-tile height with the least padding among the configurations that
-    // exist (ties: the taller tile), K split like below.  (The dispatcher's own choice for "few tiles" is the 64 x 64 tile, a quarter of
-    // the rate on these long-K products.)
-    static const struct { int rows, cfg, cols; } cand[] = {{224, 13, 128}, {192, 15, 128}, {160, 35, 128}, {128, 4, 256}, {112, 33, 128}};
-    int64_t best_pad = -1;
-    tiles = 0;
-    for (const auto& c : cand) {
-      const int64_t mt = (rows + c.rows - 1) / c.rows, pad = mt * c.rows;
-      if (best_pad < 0 || pad < best_pad) { best_pad = pad; cfg = c.cfg; tiles = mt * ((cols + c.cols - 1) / c.cols); }
-    }
-  } else {
-    cfg = rows <= 64 ? 12 : (rows <= 112 ? 11 : (rows <= 192 ? 15 : 13));
-    tiles = (cols + 127) / 128;
+  // the row-tile height with the least padding among the configurations that exist (ties: the taller tile): n_occ = 20 gets the
+  // 224-row tile for its 210 symmetric and the 192-row tile for its 190 antisymmetric pairs; n_occ = 30 three 160-row tiles for 465; ...
+  // (The dispatcher's own choice for "few tiles" would be the 64 x 64 tile, a quarter of the rate on these long-K products.)
+  static const struct { int rows, cfg, cols; } cand[] = {{224, 13, 128}, {192, 15, 128}, {160, 35, 128}, {128, 4, 256}, {112, 11, 128}, {64, 12, 128}};
+  int64_t best_pad = -1, tiles = 0;
+  for (const auto& c : cand) {
+    const int64_t mt = (rows + c.rows - 1) / c.rows, pad = mt * c.rows;
+    if (best_pad < 0 || pad < best_pad) { best_pad = pad; cfg = c.cfg; tiles = mt * ((cols + c.cols - 1) / c.cols); }
   }
   double best = 0.0;
   for (int c = 1; c <= 8; ++c) {

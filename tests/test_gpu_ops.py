@@ -526,7 +526,7 @@ def test_gather_and_scale_rows(qlib):
 # cfg 15 / 25: 192 x 128 tile (6 x 2 per wave) -- the (-) pair block (M = 190);
 # cfg 20 / 21: 128 x 32 / 32 x 128 tiles -- the products with an n_occ-sized side (ccsd.cpp:249).
 # 23 / 25 are 13 / 15 under the ladder's own kernel symbol (ccsd.cpp:217), i.e. separately compiled instantiations.
-@pytest.mark.parametrize("cfg,M", [(13, 210), (23, 210), (13, 224), (13, 220), (15, 190), (25, 190), (15, 192), (23, 97), (213, 210), (215, 190), (33, 220), (33, 112), (33, 113), (35, 160), (35, 465), (35, 161)])
+@pytest.mark.parametrize("cfg,M", [(13, 210), (23, 210), (13, 224), (13, 220), (15, 190), (25, 190), (15, 192), (23, 97), (213, 210), (215, 190), (33, 220), (33, 112), (33, 113), (35, 160), (35, 465), (35, 161), (35, 153), (35, 136), (4, 120), (4, 128), (11, 105), (12, 45)])
 @pytest.mark.parametrize("a_kc,b_kc", [(1, 1), (1, 0), (0, 1), (0, 0)])
 @pytest.mark.parametrize("ks", [0, 8])
 def test_gemm_ladder_tile_configs(qlib, cfg, M, a_kc, b_kc, ks):
