@@ -1,3 +1,5 @@
+"""GPU: wall time of the fragment RHF alone (cold from the core guess, then warm from the previous density with a 1e-3 change of h)
+at n = 220, 260, 300 -- the Jacobi rounds are one launch each above n = 96, so this is where their launch count shows."""
 import sys, time
 sys.path.insert(0, ".")
 import numpy as np
