@@ -28,6 +28,7 @@ extern "C" {
 #define QEMB_ERR_DEVICE (-3)
 #define QEMB_ERR_NOCONV (-4)
 #define QEMB_ERR_NUMERIC (-5)
+#define QEMB_WARN_NOCONV 1       /* only with strict_convergence = 0: results returned, but a solve did not converge */
 
 /* ---------------------------------------------------------------- library / device ------------- */
 int qemb_init(int device);                 /* select the GPU, create the library stream            */
@@ -73,6 +74,10 @@ typedef struct {
                               * rdm1_mo / rdm1_emb and the relaxed with_dm1=False 2-RDM in e_frag (default 0)          */
   double lambda_conv_tol;    /* |dz|               default 1e-8  (PySCF solve_lambda 1e-5)          */
   int lambda_max_cycle;      /*                    default 100                                      */
+  int strict_convergence;    /* 1 (default): a fragment RHF / CCSD / Lambda solve that does not converge is an error, status
+                              * QEMB_ERR_NOCONV, no outputs.  0: the reference's behaviour -- PySCF warns and carries on with what it
+                              * has (helper.py:128-149, solver.py:905-912): every output is filled from the unconverged state and the
+                              * call returns QEMB_WARN_NOCONV (> 0); qemb_last_error() says which solve it was.            */
 } qemb_solver_opts;
 void qemb_default_opts(qemb_solver_opts* opts);
 

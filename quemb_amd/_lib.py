@@ -30,7 +30,8 @@ class SolverOpts(C.Structure):
     _fields_ = [("cc_conv_tol", C.c_double), ("cc_conv_tol_normt", C.c_double), ("cc_max_cycle", C.c_int),
                 ("cc_diis_space", C.c_int), ("scf_conv_tol", C.c_double), ("scf_conv_tol_grad", C.c_double),
                 ("scf_max_cycle", C.c_int), ("scf_diis_space", C.c_int), ("warm_start", C.c_int), ("verbose", C.c_int),
-                ("relax_density", C.c_int), ("lambda_conv_tol", C.c_double), ("lambda_max_cycle", C.c_int)]
+                ("relax_density", C.c_int), ("lambda_conv_tol", C.c_double), ("lambda_max_cycle", C.c_int),
+                ("strict_convergence", C.c_int)]
 
 
 _lib = None
@@ -173,8 +174,16 @@ def declare(cdll):
     return _declare(cdll)
 
 
+class ConvergenceWarning(RuntimeWarning):
+    """A fragment solve did not converge and `strict_convergence = 0` asked for PySCF's behaviour (warn, carry on)."""
+
+
 def check(rc: int, what: str = "", lib=None):
-    if rc != 0:
+    if rc > 0:          # QEMB_WARN_NOCONV: results were returned
+        import warnings
+        msg = (lib or load()).qemb_last_error().decode(errors="replace")
+        warnings.warn(ConvergenceWarning(f"{what or 'libqemb_hip call'}: {msg}"), stacklevel=3)
+    elif rc != 0:
         msg = (lib or load()).qemb_last_error().decode(errors="replace")
         raise QembError(f"{what or 'libqemb_hip call'} failed (status {rc}): {msg}")
 

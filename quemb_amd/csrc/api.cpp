@@ -143,6 +143,7 @@ void qemb_default_opts(qemb_solver_opts* o) {
   o->warm_start = 0; o->verbose = 0;
   LambdaOptions l;
   o->relax_density = 0; o->lambda_conv_tol = l.conv_tol; o->lambda_max_cycle = l.max_cycle;
+  o->strict_convergence = 1;
 }
 static FragmentOptions to_opts(const qemb_solver_opts* o) {
   FragmentOptions f;
@@ -154,6 +155,7 @@ static FragmentOptions to_opts(const qemb_solver_opts* o) {
     f.warm_start = o->warm_start;
     f.relax_density = o->relax_density; f.lam.conv_tol = o->lambda_conv_tol; f.lam.max_cycle = o->lambda_max_cycle;
     f.lam.diis_space = o->cc_diis_space; f.lam.verbose = o->verbose;
+    f.strict = o->strict_convergence;
   }
   return f;
 }
@@ -192,12 +194,12 @@ int qemb_frag_solve(qemb_frag_t f, int nsocc, const double* h, const double* dm0
   if (n_iter) *n_iter = r.n_iter;
   if (scf_cycles) *scf_cycles = r.scf_cycles;
   FRAG(f)->last_lambda_iters = r.lambda_iters;
-  if (rc) return rc;
+  if (rc < 0) return rc;
   if (e_frag) { e_frag[0] = r.e_frag[0]; e_frag[1] = r.e_frag[1]; e_frag[2] = r.e_frag[2]; }
   if (e_corr_mo) *e_corr_mo = r.e_corr_mo;
   if (e_scf) *e_scf = r.e_scf;
   if (ebe_hf) *ebe_hf = r.ebe_hf;
-  return QEMB_OK;
+  return rc;        // QEMB_OK, or QEMB_WARN_NOCONV with strict_convergence = 0
 }
 int qemb_frag_lambda_iters(qemb_frag_t f, int* n_iter) { CHECK_FRAG(f); if (n_iter) *n_iter = FRAG(f)->last_lambda_iters; return QEMB_OK; }
 int qemb_frag_scf(qemb_frag_t f, int nsocc, const double* h, const double* dm0, const qemb_solver_opts* opts, double* mo_coeff,
@@ -231,10 +233,10 @@ int qemb_ccsd_solve(int n, int nsocc, int n_f, const double* h, const double* er
   FragmentResult r;
   rc = fr.solve(nsocc, h, dm0, to_opts(opts), eeval, &r, mo_coeff, mo_energy, rdm1_emb, nullptr, t1, t2);
   if (n_iter) *n_iter = r.n_iter;
-  if (rc) return rc;
+  if (rc < 0) return rc;
   if (e_frag && eeval) { e_frag[0] = r.e_frag[0]; e_frag[1] = r.e_frag[1]; e_frag[2] = r.e_frag[2]; }
   if (e_corr_mo) *e_corr_mo = r.e_corr_mo;
-  return QEMB_OK;
+  return rc;
 }
 int qemb_frag_prepare_ccsd(qemb_frag_t f, int nsocc, const double* h, const double* dm0, const qemb_solver_opts* opts) {
   CHECK_FRAG(f); return FRAG(f)->prepare_ccsd(nsocc, h, dm0, to_opts(opts));

@@ -196,7 +196,12 @@ int Fragment::solve(int o, const double* h, const double* dm0, const FragmentOpt
   ScfResult sres;
   QTRY(run_scf(o, h, dm0, opt.scf, X1, &sres, opt.warm_start != 0));
   res->scf_converged = sres.converged; res->scf_cycles = sres.cycles; res->e_scf = sres.e_tot;
-  if (!sres.converged) { set_error("fragment SCF did not converge (also not with level shift 0.2)"); return QEMB_ERR_NOCONV; }
+  bool unconverged = false;
+  if (!sres.converged) {
+    set_error("fragment SCF did not converge (also not with level shift 0.2)");
+    if (opt.strict) return QEMB_ERR_NOCONV;
+    unconverged = true;
+  }
   std::vector<double> C((size_t)n2), eps((size_t)n), J((size_t)n2), K((size_t)n2);
   QTRY(dev_d2h(C.data(), C_, sizeof(double) * n2));
   QTRY(dev_d2h(eps.data(), eps_, sizeof(double) * n));
@@ -220,7 +225,11 @@ int Fragment::solve(int o, const double* h, const double* dm0, const FragmentOpt
   bool conv = false;
   QTRY(cc_->kernel(opt.cc, &res->e_corr_mo, &res->n_iter, &conv));
   res->ccsd_converged = conv;
-  if (!conv) { set_error("CCSD did not converge in max_cycle iterations"); return QEMB_ERR_NOCONV; }
+  if (!conv) {
+    set_error("CCSD did not converge in max_cycle iterations");
+    if (opt.strict) return QEMB_ERR_NOCONV;
+    unconverged = true;
+  }
   }
   // ---- amplitudes to the host as requested; unrelaxed 1-RDM (depends on t1 only)
   std::vector<double> t1((size_t)o * v);
@@ -239,7 +248,11 @@ int Fragment::solve(int o, const double* h, const double* dm0, const FragmentOpt
     if (opt.warm_start && z_prev_.p && z_prev_o_ == o) QTRY(lam.set_guess(z_prev_));
     bool lconv = false;
     QTRY(lam.kernel(opt.lam, &res->lambda_iters, &lconv));
-    if (!lconv) { set_error("CCSD Lambda equations did not converge in max_cycle iterations"); return QEMB_ERR_NOCONV; }
+    if (!lconv) {
+      set_error("CCSD Lambda equations did not converge in max_cycle iterations");
+      if (opt.strict) return QEMB_ERR_NOCONV;
+      unconverged = true;
+    }
     dm1r.assign((size_t)n2, 0.0);
     if (eeval) Imat.assign((size_t)n * nf_, 0.0);
     QTRY(lam.densities(dm1r.data(), eeval ? cc_->integrals().T34.p : nullptr, nf_, eeval ? Imat.data() : nullptr));
@@ -327,7 +340,7 @@ int Fragment::solve(int o, const double* h, const double* dm0, const FragmentOpt
   // multipliers and orbitals must be complete before this call returns (no inter-stream ordering exists otherwise)
   QTRY(dev_sync());
   cc_.reset();
-  return 0;
+  return unconverged ? QEMB_WARN_NOCONV : 0;
 }
 
 }  // namespace qemb

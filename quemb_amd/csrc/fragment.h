@@ -18,6 +18,7 @@ struct FragmentOptions {
   int keep_amplitudes = 1; // keep t1/t2 resident after the solve
   int relax_density = 0;   // solve_ccsd(relax=True), solver.py:925-939: Lambda equations + response densities
   LambdaOptions lam;
+  int strict = 1;          // 0: non-convergence is reported (QEMB_WARN_NOCONV) instead of being an error, like PySCF's warnings
 };
 
 struct FragmentResult {

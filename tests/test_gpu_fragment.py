@@ -170,6 +170,11 @@ def test_fragment_without_virtual_orbitals(qlib):
     check_fragment_without_virtual_orbitals(qlib)
 
 
+def test_non_strict_convergence_returns_results_with_a_warning(qlib):
+    from test_hostlogic_fragment import check_non_strict_convergence
+    check_non_strict_convergence(qlib)
+
+
 @pytest.mark.parametrize("n,o", [(200, 80), (222, 150)])
 def test_mo_transform_at_bench_tile(qlib, n, o):
     """192 < n <= 224: mo_transform (ccsd.cpp:48) runs its quarter transforms on the 224 x 128 tile (tcfg = 13), as at the benchmark's

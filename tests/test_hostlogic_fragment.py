@@ -111,6 +111,39 @@ def test_warm_start_and_errors(hlib):
     assert abs(a["e_corr_mo"] - b["e_corr_mo"]) < 1e-9 and b["n_iter"] <= 3
     with pytest.raises(QembError):
         fr.solve(o, h, opts=default_opts(hlib, cc_max_cycle=1), eeval=False)   # non-convergence is an error
+    check_non_strict_convergence(hlib)
+
+
+def check_non_strict_convergence(lib):
+    """strict_convergence = 0: the reference's behaviour (PySCF warns and carries on, helper.py:128-149, solver.py:905-912) -- the
+    unconverged CCSD / Lambda / RHF state is returned with a ConvergenceWarning instead of an error."""
+    import warnings
+    from quemb_amd._lib import ConvergenceWarning
+    from quemb_amd.fragsolver import DeviceFragment, default_opts
+    n, o, nf = 6, 2, 2
+    h, e1, h1, veff0, veff = _problem(n, o, nf, 5)
+    fr = DeviceFragment(n, nf, lib=lib)
+    fr.set_eri_s4(eri.pack_s4(e1))
+    fr.set_energy_data(h1, veff0, veff, 1.0, [0])
+    ref = fr.solve(o, h, eeval=True)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        out = fr.solve(o, h, opts=default_opts(lib, cc_max_cycle=2, strict_convergence=0), eeval=True)
+    assert any(issubclass(x.category, ConvergenceWarning) and "CCSD did not converge" in str(x.message) for x in w)
+    assert out["n_iter"] == 2 and 1e-9 < abs(out["e_corr_mo"] - ref["e_corr_mo"]) < 0.1 * abs(ref["e_corr_mo"])
+    assert np.abs(out["rdm1_emb"] - ref["rdm1_emb"]).max() < 0.1 and np.isfinite(np.asarray(out["e_frag"])).all()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        out = fr.solve(o, h, opts=default_opts(lib, relax_density=1, lambda_max_cycle=1, strict_convergence=0), eeval=True)
+    assert any("Lambda" in str(x.message) for x in w) and abs(out["e_corr_mo"] - ref["e_corr_mo"]) < 1e-9
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        out = fr.solve(o, h, opts=default_opts(lib, scf_max_cycle=1, strict_convergence=0), eeval=False)
+    assert any(issubclass(x.category, ConvergenceWarning) for x in w)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")          # a converged solve raises no warning
+        fr.solve(o, h, opts=default_opts(lib, strict_convergence=0), eeval=True)
+    fr.free()
 
 
 @pytest.mark.parametrize("n,o,nf,cen", [(6, 2, 3, [0, 1]), (8, 3, 3, [1]), (7, 4, 2, [0])])
