@@ -179,3 +179,6 @@ class BE(mbe.BE):
             self.hf_err = self.hf_etot - self.ebe_hf
             if self.rank == 0:
                 print(f"HF-in-HF error                 :  {self.hf_err:>.4e} Ha", flush=True)
+
+    def rdm1_fullbasis(self, *a, **kw):
+        raise NotImplementedError("kbe.BE has no rdm1_fullbasis either (kbe/pbe.py): the fragment densities live in the supercell embedding bases")
