@@ -1,5 +1,6 @@
 """GPU: symmetric eigensolver (wavefront Jacobi) accuracy and time at the sizes of a fragment Fock matrix, cold and from a nearly
-diagonal start, with all rounds in one launch (default) and with one launch per round (QEMB_JACOBI_FUSED=0 in the environment)."""
+diagonal start.  (profiles/r02_jacobi_fused_experiment.jsonl was taken with an experiment build that also had an all-rounds-in-one-launch
+kernel, selected unless QEMB_JACOBI_FUSED=0; the shipped library has the one-launch-per-round path only and ignores the variable.)"""
 import ctypes as C
 import json
 import os
