@@ -238,6 +238,10 @@ int dev_unpack_tril_pair_rows(int64_t nr, int64_t n, const double* in, double* f
 // A (n x n, symmetric, row-major, overwritten) -> eigenvalues w[n] ascending and eigenvectors in the
 // COLUMNS of V (n x n row-major).  sweeps_out (host int*) may be null.
 int dev_jacobi_eigh(int64_t n, double* A, double* w, double* V, int* sweeps_out);
+// The same with an early stop: the sweeps end once the largest normalised off-diagonal element met during a sweep is below `stop_below`
+// (what is left after that sweep is its square).  dev_jacobi_eigh uses 1e-10 -- nothing above the rotation threshold is left; a caller
+// that will diagonalise again anyway (the cycles of an SCF before the last) can stop a sweep earlier.
+int dev_jacobi_eigh_until(int64_t n, double* A, double* w, double* V, int* sweeps_out, double stop_below);
 // One-sided Jacobi SVD of G (m x n row-major, m >= n), overwritten by U*diag(s) columns;
 // s[n] descending, V (n x n) right vectors in columns, U (m x n) left vectors in columns.
 int dev_jacobi_svd(int64_t m, int64_t n, double* G, double* s, double* U, double* V, int* sweeps_out);

@@ -198,7 +198,7 @@ __global__ void __launch_bounds__(256) gather_rows_to_cols_kernel(int nrow, long
     out[c * ldo + i] = sc * src[c];
 }
 
-static int jacobi_rows(int nvec, int64_t len, double* W, int64_t ldw, double* Vt, double floor2, int* sweeps_out) {
+static int jacobi_rows(int nvec, int64_t len, double* W, int64_t ldw, double* Vt, double floor2, int* sweeps_out, double stop_below = 1.0e-10) {
   hipStream_t s = hip_stream();
   if (nvec < 2) { if (sweeps_out) *sweeps_out = 0; return QEMB_OK; }
   const int np = (nvec % 2 == 0) ? nvec : nvec + 1;
@@ -238,7 +238,7 @@ static int jacobi_rows(int nvec, int64_t len, double* W, int64_t ldw, double* Vt
     // after it is O(eps^2).  Below eps = 1e-10 the next sweep would find nothing above `tol` (~3e-15) to rotate -- it would be the
     // confirming no-op sweep, np - 1 launches that change no bit -- so it is not run.
     double offmax; std::memcpy(&offmax, &bits, sizeof(double));
-    if (offmax < 1.0e-10) { conv = true; ++sweep; break; }
+    if (offmax < stop_below) { conv = true; ++sweep; break; }
   }
   (void)dev_free(d_off);
   if (sweeps_out) *sweeps_out = sweep;
@@ -246,7 +246,8 @@ static int jacobi_rows(int nvec, int64_t len, double* W, int64_t ldw, double* Vt
   return QEMB_OK;
 }
 
-int dev_jacobi_eigh(int64_t n64, double* A, double* w, double* V, int* sweeps_out) {
+int dev_jacobi_eigh(int64_t n64, double* A, double* w, double* V, int* sweeps_out) { return dev_jacobi_eigh_until(n64, A, w, V, sweeps_out, 1.0e-10); }
+int dev_jacobi_eigh_until(int64_t n64, double* A, double* w, double* V, int* sweeps_out, double stop_below) {
   hipStream_t s = hip_stream();
   if (!s) { set_error("libqemb_hip: call qemb_init(device) first"); return QEMB_ERR_DEVICE; }
   const int n = (int)n64;
@@ -265,7 +266,7 @@ int dev_jacobi_eigh(int64_t n64, double* A, double* w, double* V, int* sweeps_ou
   const double sigma = 1.0625 * gersh + 1.0e-300;
   hipLaunchKernelGGL(add_diag_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, A, (long long)n, sigma);
   hipLaunchKernelGGL(set_identity_kernel, dim3((unsigned)(((long long)n * n + 255) / 256)), dim3(256), 0, s, n, Vt);
-  int rc = jacobi_rows(n, n, A, n, Vt, 0.0, sweeps_out);
+  int rc = jacobi_rows(n, n, A, n, Vt, 0.0, sweeps_out, stop_below);
   if (rc == QEMB_OK) {
     // Rayleigh quotients lambda_i + sigma = W_i . Vt_i
     hipLaunchKernelGGL(rowdot_kernel, dim3(n), dim3(256), 0, s, n, (long long)n, A, (long long)n, Vt, (long long)n, tmp);

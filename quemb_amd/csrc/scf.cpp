@@ -103,10 +103,12 @@ static int rhf_loop(int n, int o, const double* h, const double* eri, const doub
       // rotate into the previous cycle's orbitals first: the Jacobi sweeps start from a nearly diagonal matrix
       QTRY(gemm_nn(n, n, n, 1.0, Fd, Cprev, 0.0, tmp));
       QTRY(gemm_tn(n, n, n, 1.0, Cprev, tmp, 0.0, Fd));
-      QTRY(dev_jacobi_eigh(n, Fd, eps, V, nullptr));
+      // (an SCF cycle that is followed by another diagonalisation does not need the last sweep: stopping once the largest rotation of a
+      //  sweep is below 1e-7 leaves off-diagonal elements of ~1e-14 relative size, far inside what the next cycle corrects)
+      QTRY(dev_jacobi_eigh_until(n, Fd, eps, V, nullptr, 1.0e-7));
       QTRY(gemm_nn(n, n, n, 1.0, Cprev, V, 0.0, C));
     } else {
-      QTRY(dev_jacobi_eigh(n, Fd, eps, C, nullptr));
+      QTRY(dev_jacobi_eigh_until(n, Fd, eps, C, nullptr, 1.0e-7));
     }
     QTRY(dcopy(n2, C, Cprev));
     have_prev = true;

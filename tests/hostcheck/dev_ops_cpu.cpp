@@ -321,6 +321,8 @@ int dev_pack_tril_rows(int64_t rows, int64_t n, const double* f, double* p) {
 }
 
 // cyclic two-sided Jacobi (independent of the product's one-sided formulation)
+int dev_jacobi_eigh(int64_t n64, double* A, double* w, double* V, int* sweeps_out);
+int dev_jacobi_eigh_until(int64_t n64, double* A, double* w, double* V, int* sweeps_out, double) { return dev_jacobi_eigh(n64, A, w, V, sweeps_out); }
 int dev_jacobi_eigh(int64_t n64, double* A, double* w, double* V, int* sweeps_out) {
   const int n = (int)n64;
   std::vector<double> a(A, A + (size_t)n * n), v((size_t)n * n, 0.0);
