@@ -8,6 +8,7 @@
 // They are written for coalescing (16-byte lanes where the layout allows, LDS-tiled transposes when the
 // contiguous dimension changes) rather than reshaped into GEMMs.
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <algorithm>
 #include <cstdint>
 #include <cstdlib>
@@ -721,11 +722,66 @@ __global__ void __launch_bounds__(256) small_k_update_kernel(long long M, long l
     }
   }
 }
+// The same update on the matrix pipe (M, N >= 16, K <= 64): 2 K M N flop per batch entry is
+// 6.4 GFLOP for the rank-n_occ updates of the o^2 v^2 tensors -- 100 us of FP64 VALU time, which is what the tile version above and a
+// VALU strip version both take, twice the HBM time of the 256 MB they move.  B[z] (K x N) and the
+// A columns of the strip are small and cache resident; wave w owns the 16-column tiles w, w + 4, ... for both 16-row halves of the strip
+// (v_mfma_f64_16x16x4_f64: A lane l holds A[row = l & 15][k = l >> 4], B lane l holds B[k = l >> 4][col = l & 15], D reg r of lane l is
+// D[row = (l >> 4) + 4 r][col = l & 15]); the read-modify-write of C is 16 lanes x 8 B = 128 contiguous bytes per row.
+typedef double d4v __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) small_k_update_mfma_kernel(int M, int N, int K, double alpha, const double* __restrict__ A, long long sA,
+                                                                  const double* __restrict__ B, long long sB, double* __restrict__ C, long long sC) {
+  // no LDS, no barrier: one wave per (32-row strip, 16-column tile); it fetches its fragments straight from memory (A and B are small and
+  // cache resident) and has the C values it will update in flight while the MFMAs run
+  const int NT = (N + 15) >> 4, MT = (M + 31) >> 5;
+  const int lane = threadIdx.x & 63, fr = lane & 15, fk = lane >> 4;
+  const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (item >= MT * NT) return;
+  const int m0 = (item / NT) * 32, col = (item % NT) * 16 + fr;
+  const long long z = blockIdx.y;
+  const double* __restrict__ Az = A + z * sA;
+  const double* __restrict__ Bz = B + z * sB;
+  double* __restrict__ Cz = C + z * sC;
+  const int ra = m0 + fr, rb = ra + 16;
+  const bool cin = col < N;
+  double c0[4], c1[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int ma = m0 + fk + 4 * r, mb = ma + 16;
+    c0[r] = (cin && ma < M) ? Cz[(long long)ma * N + col] : 0.0;
+    c1[r] = (cin && mb < M) ? Cz[(long long)mb * N + col] : 0.0;
+  }
+  d4v acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+  for (int k0 = 0; k0 < K; k0 += 4) {
+    const int k = k0 + fk;
+    const bool kin = k < K;
+    const double b = (kin && cin) ? Bz[(long long)k * N + col] : 0.0;
+    const double a0 = (kin && ra < M) ? Az[(long long)k * M + ra] : 0.0;
+    const double a1 = (kin && rb < M) ? Az[(long long)k * M + rb] : 0.0;
+    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b, acc1, 0, 0, 0);
+  }
+  if (cin) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ma = m0 + fk + 4 * r, mb = ma + 16;
+      if (ma < M) Cz[(long long)ma * N + col] = c0[r] + alpha * acc0[r];
+      if (mb < M) Cz[(long long)mb * N + col] = c1[r] + alpha * acc1[r];
+    }
+  }
+}
 int dev_small_k_update(int64_t batch, int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t sA, const double* B, int64_t sB,
                        double* C, int64_t sC) {
   REQUIRE_INIT();
   if (batch <= 0 || M <= 0 || N <= 0 || K <= 0) return QEMB_OK;
   if (batch > 65535) { set_error("dev_small_k_update: batch too large"); return QEMB_ERR_ARG; }
+  if (N >= 16 && M >= 16 && K <= 64 && M <= (1 << 20) && N <= (1 << 20)) {
+    const long long items = ((M + 31) / 32) * ((N + 15) / 16);
+    hipLaunchKernelGGL(small_k_update_mfma_kernel, dim3((unsigned)((items + 3) / 4), (unsigned)batch), dim3(256), 0, g_stream, (int)M, (int)N, (int)K, alpha,
+                       A, (long long)sA, B, (long long)sB, C, (long long)sC);
+    HIP_TRY(hipGetLastError());
+    return QEMB_OK;
+  }
   const long long tiles_m = (M + 31) / 32, tiles_n = (N + 31) / 32;
   hipLaunchKernelGGL(small_k_update_kernel, dim3((unsigned)(tiles_m * tiles_n), (unsigned)batch), dim3(256), 0, g_stream, (long long)M, (long long)N, (long long)K, alpha,
                      A, (long long)sA, B, (long long)sB, C, (long long)sC, (int)tiles_n);

@@ -501,6 +501,20 @@ def test_ccsd_single_pass_kernels(qlib, o, v):
         assert np.abs(dC.numpy((batch, M, N)) - ref).max() < 1e-12 * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.parametrize("shape", [(37, 200, 200, 20, False, True), (5, 70, 64, 32, True, False), (4, 33, 129, 7, False, False), (3, 200, 256, 20, False, True),
+                                   (2, 100, 257, 20, False, True), (6, 31, 63, 5, False, False), (400, 200, 200, 20, False, True)])
+def test_small_k_update_strip_and_tile_variants(qlib, shape):
+    """C[z] += alpha A[z]^T B[z] with K <= 32: the 32-row strip kernel (64 <= N <= 256) and the 32 x 32 tile kernel on both sides of its
+    limits; the last shape is the rank-n_occ update of the o^2 v^2 tensor at the benchmark size."""
+    batch, M, N, K, sharedA, sharedB = shape
+    rng = np.random.default_rng(batch + 3 * M + 5 * N + 7 * K)
+    A = rng.standard_normal((1 if sharedA else batch, K, M)); B = rng.standard_normal((1 if sharedB else batch, K, N)); C0 = rng.standard_normal((batch, M, N))
+    dA, dB, dC = DeviceBuffer.from_numpy(A), DeviceBuffer.from_numpy(B), DeviceBuffer.from_numpy(C0)
+    check(qlib.qemb_op_small_k_update(batch, M, N, K, 1.3, dA.ptr, 0 if sharedA else K * M, dB.ptr, 0 if sharedB else K * N, dC.ptr, M * N))
+    ref = C0 + 1.3 * np.einsum("zkm,zkn->zmn", np.broadcast_to(A, (batch, K, M)), np.broadcast_to(B, (batch, K, N)))
+    assert np.abs(dC.numpy((batch, M, N)) - ref).max() < 1e-12 * max(1.0, np.abs(ref).max())
+
+
 def test_gather_and_scale_rows(qlib):
     rng = np.random.default_rng(12)
     src = rng.standard_normal((9, 13))                       # rows of 13 with ld 13; gather 11 columns of each
