@@ -36,7 +36,7 @@ bytes_of = {   # kernel-name fragment -> (algorithmic bytes of one large call, w
     "lincomb_kernel": (3 * N2, "a x + b y on o^2 v^2 tensors (two reads + one write; the DIIS extrapolation reads six)"),
     "ccsd_ph_layouts_kernel": (7 * N2, "t2 -> T, T', u, u~, T'~, Theta layouts in one pass"),
     "ccsd_finish_t2_kernel": (4 * N2, "(t2n + ovov + U + U^T) / D"),
-    "small_k_update_kernel": (2 * N2, "rank-n_occ update of an o^2 v^2 tensor (r/w)"),
+    "small_k_update": (2 * N2, "rank-n_occ update of an o^2 v^2 tensor (r/w), MFMA"),
     "dot_many_stage1": (7 * N2, "DIIS: the new error vector against the six stored ones"),
     "splitk_reduce_kernel": ((8 + 1) * npo * npv * 8, "deterministic sum of 8 split-K slabs of the ladder"),
 }
