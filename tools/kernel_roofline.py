@@ -33,7 +33,7 @@ bytes_of = {   # kernel-name fragment -> (algorithmic bytes of one large call, w
     "pack_pm_cols_kernel": ((o * v * v * v + o * v * (npv + nmv)) * 8, "(+/-) packed images of the ovvv block"),
     "ladder_scatter_pm_kernel": (2 * N2 + (npo * npv + nmo * nmv) * 8, "ladder result -> t2 (r/w t2 + read R+/R-)"),
     "ladder_pack_tau_kernel": (N2 + (npo * npv + nmo * nmv) * 8, "tau -> (+/-) packed pair rows"),
-    "lincomb_kernel": (3 * N2, "a x + b y on o^2 v^2 tensors (two reads + one write; the DIIS extrapolation reads six)"),
+    "lincomb_kernel": (7 * N2, "DIIS extrapolation of the o^2 v^2 amplitudes: six stored vectors in, one out (the large calls of this kernel)"),
     "ccsd_ph_layouts_kernel": (7 * N2, "t2 -> T, T', u, u~, T'~, Theta layouts in one pass"),
     "ccsd_finish_t2_kernel": (4 * N2, "(t2n + ovov + U + U^T) / D"),
     "small_k_update": (2 * N2, "rank-n_occ update of an o^2 v^2 tensor (r/w), MFMA"),
