@@ -1027,20 +1027,23 @@ __global__ void __launch_bounds__(256) ladder_pack_tau_kernel(long long o, long 
   const double* t = tau + (i * o + j) * v * v;
   double* tp = Tp + ij * ldp;
   double* tm = (i > j) ? Tm + (i * (i - 1) / 2 + j) * ldm : nullptr;
-  for (long long cd = threadIdx.x; cd < ldp; cd += blockDim.x) {
+  // blockIdx.y: a slice of the packed (c,d) range -- one workgroup per pair (ij) alone is 210 workgroups at n_occ = 20, fewer than the chip has CUs
+  const long long chunk = (ldp + gridDim.y - 1) / gridDim.y, cd0 = blockIdx.y * chunk, cd1 = (cd0 + chunk < ldp) ? cd0 + chunk : ldp;
+  for (long long cd = cd0 + threadIdx.x; cd < cd1; cd += blockDim.x) {
     if (cd >= np) { tp[cd] = 0.0; continue; }
     long long c, d; unpair_ge(cd, c, d);
     const double x = t[c * v + d], y = t[d * v + c];
     tp[cd] = (c == d) ? 0.25 * (x + y) : 0.5 * (x + y);
     if (tm && c > d) tm[c * (c - 1) / 2 + d] = 0.5 * (x - y);
   }
-  if (tm) for (long long q = nm + threadIdx.x; q < ldm; q += blockDim.x) tm[q] = 0.0;
+  if (tm && blockIdx.y == 0) for (long long q = nm + threadIdx.x; q < ldm; q += blockDim.x) tm[q] = 0.0;
 }
 int dev_ladder_pack_tau(int64_t o, int64_t v, const double* tau, double* Tp, int64_t ldp, double* Tm, int64_t ldm) {
   REQUIRE_INIT();
   const long long npo = o * (o + 1) / 2;
   if (npo <= 0 || v <= 0) return QEMB_OK;
-  hipLaunchKernelGGL(ladder_pack_tau_kernel, dim3((unsigned)npo), dim3(256), 0, g_stream, (long long)o, (long long)v, tau, Tp, (long long)ldp, Tm, (long long)ldm);
+  const unsigned slices = (unsigned)std::max<long long>(1, std::min<long long>(16, ldp / 2048));
+  hipLaunchKernelGGL(ladder_pack_tau_kernel, dim3((unsigned)npo, slices), dim3(256), 0, g_stream, (long long)o, (long long)v, tau, Tp, (long long)ldp, Tm, (long long)ldm);
   HIP_TRY(hipGetLastError());
   return QEMB_OK;
 }
