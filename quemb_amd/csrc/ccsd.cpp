@@ -135,6 +135,10 @@ int CcsdSolver::setup(MoIntegrals&& ints, const double* mo_energy_dev) {
     QTRY(OVp_.alloc(nov * I_.ldp)); QTRY(OVm_.alloc(nov * I_.ldm));
     QTRY(dev_pack_pm_cols(nov, v, OVl, OVp_, I_.ldp, OVm_, I_.ldm));
   }
+  // G+-[(k,l)][P/Q(c,d)] = ovov[kcld] +- ovov[kdlc]: Woooo += ovov[kcld] tau[ijcd] then runs over the packed (c,d) pairs against the
+  // packed tau rows the ladder builds anyway -- half the flops of the dense (oo) x (oo) x (vv) product
+  QTRY(Gp_.alloc(oo * I_.ldp)); QTRY(Gm_.alloc(oo * I_.ldm));
+  QTRY(dev_pack_pm_cols(oo, v, OVoovv_, Gp_, I_.ldp, Gm_, I_.ldm));
   QTRY(perm4(oooo_p_, I_.oooo, o, o, o, o, 0, 2, 1, 3));                 // oooo_p[k,l,i,j] = oooo[k,i,l,j]
   // (ovvo / oovv stay resident: 2 x 128 MB at n = 220 buy two permutation passes per iteration)
   // ---- amplitudes and work space
@@ -150,6 +154,7 @@ int CcsdSolver::setup(MoIntegrals&& ints, const double* mo_energy_dev) {
     const int64_t npo = o * (o + 1) / 2, nmo = std::max<int64_t>(o * (o - 1) / 2, 1);
     QTRY(LTp_.alloc(npo * I_.ldp)); QTRY(LRp_.alloc(npo * I_.ldp)); QTRY(LTm_.alloc(nmo * I_.ldm)); QTRY(LRm_.alloc(nmo * I_.ldm));
     QTRY(Xp_.alloc(npo * nov)); QTRY(Xm_.alloc(nmo * nov));
+    QTRY(Xwp_.alloc(npo * oo)); QTRY(Xwm_.alloc(nmo * oo)); QTRY(Xw_.alloc(oo * oo));
     QTRY(ZB_.alloc(N2)); QTRY(ZC_.alloc(N2));
   }
   first_ = true;
@@ -215,12 +220,12 @@ static void pick_pair_gemm(int64_t rows, int64_t cols, int& cfg, int& ks) {
 }
 
 // pp-ladder through the (+/-) pair-packed operands (see the comment in update_amps)
-int CcsdSolver::apply_ladder(const double* x, double* out) {
+int CcsdSolver::apply_ladder(const double* x, double* out, bool rows_packed) {
   const int64_t o = o_, v = v_;
   {
     const int64_t npo = o * (o + 1) / 2, nmo = o * (o - 1) / 2, npv = v * (v + 1) / 2, nmv = v * (v - 1) / 2;
     const int64_t ldp = I_.ldp, ldm = I_.ldm;
-    QTRY(dev_ladder_pack_tau(o, v, x, LTp_, ldp, LTm_, ldm));
+    if (!rows_packed) QTRY(dev_ladder_pack_tau(o, v, x, LTp_, ldp, LTm_, ldm));
     int cfg, ks;
     TimerScope lap_LADDER(TIMER_LADDER);
     pick_pair_gemm(npo, npv, cfg, ks);
@@ -277,7 +282,28 @@ int CcsdSolver::update_amps(double* t1n, double* t2n) {
   // (the bare ovov[i,a,j,b] term is added by the finishing kernel)
   // Woooo[k,l,i,j]
   QTRY(dcopy(oo * oo, oooo_p_, Wo_));
-  QTRY(gemm_nt(oo, oo, vv, 1.0, OVoovv_, tau_, 1.0, Wo_));                         // ovov[kcld] tau[ijcd]
+  {  // + ovov[kcld] tau[ijcd] over the (+/-) packed (c,d) pairs:  X[ij] = Xp + Xm, X[ji] = Xp - Xm (i > j),
+     //   Xp[P(ij),(kl)] = sum_{c>=d} LTp[P(ij),P(cd)] G+[(kl),P(cd)],  Xm[Q(ij),(kl)] = sum_{c>d} LTm G-   (LTp carries 1/2 on c = d, G+ is doubled there)
+    const int64_t npo = o * (o + 1) / 2, nmo = o * (o - 1) / 2, nmv = v * (v - 1) / 2;
+    QTRY(dev_ladder_pack_tau(o, v, tau_, LTp_, I_.ldp, LTm_, I_.ldm));     // the packed tau rows: also read by the ladder and by the tau-side dressing below
+    // 64 x 64 tiles and enough K slices for ~2 workgroups per CU (the output is only npair(o) x o^2)
+    auto split = [&](int64_t rows, int64_t K, int& cfg, int& ks) {
+      cfg = -1; ks = 0;
+      if (K < 2048) return;
+      const int64_t tiles = ((rows + 63) / 64) * ((oo + 63) / 64);
+      cfg = 1;
+      ks = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(64, K / 256), (512 + tiles - 1) / tiles));
+    };
+    int cfg, ks;
+    split(npo, I_.ldp, cfg, ks);
+    QTRY(gemm(npo, oo, I_.ldp, 1.0, LTp_, I_.ldp, true, Gp_, I_.ldp, true, 0.0, Xwp_, oo, 1, 0, 0, 0, cfg, ks));
+    if (nmo > 0) {
+      if (nmv > 0) { split(nmo, I_.ldm, cfg, ks); QTRY(gemm(nmo, oo, I_.ldm, 1.0, LTm_, I_.ldm, true, Gm_, I_.ldm, true, 0.0, Xwm_, oo, 1, 0, 0, 0, cfg, ks)); }
+      else QTRY(dev_fill(Xwm_, nmo * oo, 0.0));
+    }
+    QTRY(dev_scatter_pm_rows(o, oo, Xwp_, Xwm_, Xw_));                               // Xw[i,j,k,l]
+    QTRY(perm4(Wo_, Xw_, o, o, o, o, 2, 3, 0, 1, 1.0, 1.0));                         // Wo[k,l,i,j] += Xw[i,j,k,l]
+  }
   QTRY(gemm(o, oo, v, 1.0, t1, v, true, I_.ovoo, oo, false, 0.0, O1_, oo, o, 0, v * oo, o * oo));   // O1[l,j,k,i]
   QTRY(perm4(Wo_, O1_, o, o, o, o, 2, 0, 3, 1, 1.0, 1.0));                         // + ovoo[lcki] t1[jc]
   QTRY(perm4(Wo_, O1_, o, o, o, o, 0, 2, 1, 3, 1.0, 1.0));                         // + ovoo[kclj] t1[ic]
@@ -289,7 +315,7 @@ int CcsdSolver::update_amps(double* t1n, double* t2n) {
   // are computed -- 2 npair(o) npair(v)^2 + 2 npair'(o) npair'(v)^2 flops = 1/4 of the dense 2 o^2 v^4 -- and the
   // operands Vp, Vm (6.4 GB together at v = 200) are each streamed ONCE through a tile that holds every packed (ij) row
   // (224 x 128, 8 waves), K split over workgroups to fill whole rounds of the 256 CUs.
-  QTRY(apply_ladder(tau_, t2n));
+  QTRY(apply_ladder(tau_, t2n, /*rows_packed=*/true));
 
   // ---- T2 equation: terms that enter as P(X) accumulate in U
   // Lvv'[a,c] t2[ijcb] enters as its P-partner t2[ijac] Lvv'[b,c] (U is only used as U + U^T(ji,ba)): ONE (o^2 v) x v x v product

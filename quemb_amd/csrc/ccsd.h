@@ -50,7 +50,7 @@ class CcsdSolver {
   // copy a named integral block to the host (measurement / debugging): oooo ovoo ovov ovvv Vl W1base W2base eo ev
   int export_block(const char* name, double* host, int64_t nelem);
   // out[i,j,a,b] += sum_cd (ac|bd) x[i,j,c,d] through the (+/-) pair-packed operands; x must satisfy x[j,i,d,c] = x[i,j,c,d]
-  int apply_ladder(const double* x, double* out);
+  int apply_ladder(const double* x, double* out, bool rows_packed = false);   // rows_packed: LTp_/LTm_ already hold the packed rows of x
   const MoIntegrals& integrals() const { return I_; }
   double* t1() { return amp_.p; }
   double* t2() { return amp_.p + (int64_t)o_ * v_; }
@@ -73,6 +73,8 @@ class CcsdSolver {
   DBuf tau_, T_, Tp_, S_, W1_, W2_, W12_, W12b_, R_, U_, G1_, G2_;
   DBuf LTp_, LTm_, LRp_, LRm_;   // (+/-) packed ladder: tau combinations and results
   DBuf Xp_, Xm_;                 // (+/-) packed rows of X[i,j,k,a] = tau[ijcd] ovvv[kdac]
+  DBuf Gp_, Gm_;                 // (+/-) pair-packed images over (c,d) of ovov[k,c,l,d], one row per (k,l): the Woooo build contracts packed tau rows
+  DBuf Xwp_, Xwm_, Xw_;          // its (+/-) packed result rows [P(ij)][(kl)] and their expansion [i,j,k,l]
   DBuf ZB_, ZC_;                 // ZB[k,c,a,i] = ovvv[kcad] t1[id],  ZC[k,i,a,c] = t1[id] ovvv[kdac]  (one ovvv pass each per iteration)
   DBuf Foo_, Fvv_, Fov_, Z_, Y_, Ytmp_, Loo_, Lvv_, Q_, Wo_, O1_, X_, scal_;
   std::vector<DeviceDIIS> diis_;
