@@ -155,6 +155,8 @@ int CcsdSolver::setup(MoIntegrals&& ints, const double* mo_energy_dev) {
     QTRY(LTp_.alloc(npo * I_.ldp)); QTRY(LRp_.alloc(npo * I_.ldp)); QTRY(LTm_.alloc(nmo * I_.ldm)); QTRY(LRm_.alloc(nmo * I_.ldm));
     QTRY(Xp_.alloc(npo * nov)); QTRY(Xm_.alloc(nmo * nov));
     QTRY(Xwp_.alloc(npo * oo)); QTRY(Xwm_.alloc(nmo * oo)); QTRY(Xw_.alloc(oo * oo));
+    lwp_ = npo + (npo & 1); lwm_ = std::max<int64_t>(2, nmo + (nmo & 1));
+    QTRY(WAp_.alloc(npo * lwp_)); QTRY(WAm_.alloc(nmo * lwm_)); QTRY(HRp_.alloc(npo * I_.ldp)); QTRY(HRm_.alloc(nmo * I_.ldm));
     QTRY(ZB_.alloc(N2)); QTRY(ZC_.alloc(N2));
   }
   first_ = true;
@@ -220,7 +222,7 @@ static void pick_pair_gemm(int64_t rows, int64_t cols, int& cfg, int& ks) {
 }
 
 // pp-ladder through the (+/-) pair-packed operands (see the comment in update_amps)
-int CcsdSolver::apply_ladder(const double* x, double* out, bool rows_packed) {
+int CcsdSolver::apply_ladder(const double* x, double* out, bool rows_packed, bool hh) {
   const int64_t o = o_, v = v_;
   {
     const int64_t npo = o * (o + 1) / 2, nmo = o * (o - 1) / 2, npv = v * (v + 1) / 2, nmv = v * (v - 1) / 2;
@@ -237,7 +239,19 @@ int CcsdSolver::apply_ladder(const double* x, double* out, bool rows_packed) {
       QTRY(gemm(nmo, nmv, ldm, 1.0, LTm_, ldm, true, I_.Vm, ldm, true, 0.0, LRm_, ldm, 1, 0, 0, 0, cfg, ks));
     }
     QTRY(lap_LADDER.close());
-    QTRY(dev_ladder_scatter_pm(o, v, LRp_, ldp, LRm_, ldm, out));
+    if (hh) {
+      // hole-hole ladder on the same packed rows, now as the RIGHT operand (K = packed occupied pairs):
+      //   HR+[P(ij),P(ab)] = sum_{k>=l} WA+[P(ij),P(kl)] LTp[P(kl),P(ab)],   HR-[Q(ij),Q(ab)] = sum_{k>l} WA-[Q(ij),Q(kl)] LTm[Q(kl),Q(ab)]
+      // -- a quarter of the flops of the dense o^2 x v^2 x o^2 product; the scatter adds them to the pp-ladder rows (doubling the a = b
+      // columns of HR+: LTp carries 1/2 there) and writes the sum as the first contribution to `out`
+      static const struct { int rows, cfg; } cand[] = {{224, 13}, {192, 15}, {160, 35}, {128, 0}, {64, 1}};
+      auto tile_for = [&](int64_t rows) { int best = -1; int64_t pad = -1; for (const auto& c : cand) { const int64_t q = (rows + c.rows - 1) / c.rows * c.rows; if (pad < 0 || q < pad) { pad = q; best = c.cfg; } } return best; };
+      QTRY(gemm(npo, npv, npo, 1.0, WAp_, lwp_, true, LTp_, ldp, false, 0.0, HRp_, ldp, 1, 0, 0, 0, npv >= 2048 ? tile_for(npo) : -1));
+      if (nmo > 0 && nmv > 0) QTRY(gemm(nmo, nmv, nmo, 1.0, WAm_, lwm_, true, LTm_, ldm, false, 0.0, HRm_, ldm, 1, 0, 0, 0, nmv >= 2048 ? tile_for(nmo) : -1));
+      QTRY(dev_ladder_scatter_pm2(o, v, LRp_, ldp, LRm_, ldm, HRp_, (nmo > 0 && nmv > 0) ? HRm_.p : nullptr, 1, out));
+    } else {
+      QTRY(dev_ladder_scatter_pm(o, v, LRp_, ldp, LRm_, ldm, out));
+    }
   }
   return 0;
 }
@@ -307,7 +321,7 @@ int CcsdSolver::update_amps(double* t1n, double* t2n) {
   QTRY(gemm(o, oo, v, 1.0, t1, v, true, I_.ovoo, oo, false, 0.0, O1_, oo, o, 0, v * oo, o * oo));   // O1[l,j,k,i]
   QTRY(perm4(Wo_, O1_, o, o, o, o, 2, 0, 3, 1, 1.0, 1.0));                         // + ovoo[lcki] t1[jc]
   QTRY(perm4(Wo_, O1_, o, o, o, o, 0, 2, 1, 3, 1.0, 1.0));                         // + ovoo[kclj] t1[ic]
-  QTRY(gemm_tn(oo, vv, oo, 1.0, Wo_, tau_, 0.0, t2n));                             // Woooo[klij] tau[klab]  (first writer of t2n)
+  QTRY(dev_pack_w_pm(o, Wo_, WAp_, lwp_, WAm_, lwm_));                             // Woooo[klij] tau[klab]: with the ladder below, through packed pairs
   // pp-ladder (the dominant kernel)
   // R_ijab = sum_cd (ac|bd) tau_ijcd through pair-packed symmetric / antisymmetric combinations:
   //   R = R+ + R-,  R+[P(ij),P(ab)] = sum_{c>=d} Vp[P(ab),P(cd)] Tp[P(ij),P(cd)],  R-[Q(ij),Q(ab)] = sum_{c>d} Vm Tm,
@@ -315,7 +329,7 @@ int CcsdSolver::update_amps(double* t1n, double* t2n) {
   // are computed -- 2 npair(o) npair(v)^2 + 2 npair'(o) npair'(v)^2 flops = 1/4 of the dense 2 o^2 v^4 -- and the
   // operands Vp, Vm (6.4 GB together at v = 200) are each streamed ONCE through a tile that holds every packed (ij) row
   // (224 x 128, 8 waves), K split over workgroups to fill whole rounds of the 256 CUs.
-  QTRY(apply_ladder(tau_, t2n, /*rows_packed=*/true));
+  QTRY(apply_ladder(tau_, t2n, /*rows_packed=*/true, /*hh=*/true));               // (first writer of t2n)
 
   // ---- T2 equation: terms that enter as P(X) accumulate in U
   // Lvv'[a,c] t2[ijcb] enters as its P-partner t2[ijac] Lvv'[b,c] (U is only used as U + U^T(ji,ba)): ONE (o^2 v) x v x v product

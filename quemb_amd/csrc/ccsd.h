@@ -50,7 +50,9 @@ class CcsdSolver {
   // copy a named integral block to the host (measurement / debugging): oooo ovoo ovov ovvv Vl W1base W2base eo ev
   int export_block(const char* name, double* host, int64_t nelem);
   // out[i,j,a,b] += sum_cd (ac|bd) x[i,j,c,d] through the (+/-) pair-packed operands; x must satisfy x[j,i,d,c] = x[i,j,c,d]
-  int apply_ladder(const double* x, double* out, bool rows_packed = false);   // rows_packed: LTp_/LTm_ already hold the packed rows of x
+  // rows_packed: LTp_/LTm_ already hold the packed rows of x.  hh: also add the hole-hole ladder Woooo[klij] x[klab] from the packed images
+  // WAp_/WAm_ of Woooo, and ASSIGN the sum to out (first writer) instead of accumulating
+  int apply_ladder(const double* x, double* out, bool rows_packed = false, bool hh = false);
   const MoIntegrals& integrals() const { return I_; }
   double* t1() { return amp_.p; }
   double* t2() { return amp_.p + (int64_t)o_ * v_; }
@@ -75,6 +77,8 @@ class CcsdSolver {
   DBuf Xp_, Xm_;                 // (+/-) packed rows of X[i,j,k,a] = tau[ijcd] ovvv[kdac]
   DBuf Gp_, Gm_;                 // (+/-) pair-packed images over (c,d) of ovov[k,c,l,d], one row per (k,l): the Woooo build contracts packed tau rows
   DBuf Xwp_, Xwm_, Xw_;          // its (+/-) packed result rows [P(ij)][(kl)] and their expansion [i,j,k,l]
+  DBuf WAp_, WAm_, HRp_, HRm_;   // hole-hole ladder: (+/-) packed images of Woooo and its packed result rows
+  int64_t lwp_ = 0, lwm_ = 0;    // leading dimensions of WAp_ / WAm_
   DBuf ZB_, ZC_;                 // ZB[k,c,a,i] = ovvv[kcad] t1[id],  ZC[k,i,a,c] = t1[id] ovvv[kdac]  (one ovvv pass each per iteration)
   DBuf Foo_, Fvv_, Fov_, Z_, Y_, Ytmp_, Loo_, Lvv_, Q_, Wo_, O1_, X_, scal_;
   std::vector<DeviceDIIS> diis_;

@@ -169,6 +169,15 @@ int dev_scatter_pm_rows(int64_t o, int64_t ncols, const double* Xp, const double
 // CCSD doubles update, last step in one pass:  t2n[i,j,a,b] = (t2n[i,j,a,b] + OV[i,j,a,b] + U[i,j,a,b] + U[j,i,b,a]) / (eo[i]+eo[j]-ev[a]-ev[b])
 int dev_ccsd_finish_t2(int64_t o, int64_t v, double* t2n, const double* U, const double* OV, const double* eo, const double* ev);
 int dev_ladder_scatter_pm(int64_t o, int64_t v, const double* Rp, int64_t ldp, const double* Rm, int64_t ldm, double* t2);
+// The same with a second pair of packed results added on the way (Hp, Hm; same layouts): p = Rp + f Hp, m = Rm + Hm, where f = 2 on the
+// a = b columns and 1 elsewhere -- the hole-hole ladder contracts the packed tau rows, which carry 1/2 on their a = b entries, as its
+// RIGHT operand.  assign != 0: t2 = ... instead of t2 += ... (every element of t2 is written).
+int dev_ladder_scatter_pm2(int64_t o, int64_t v, const double* Rp, int64_t ldp, const double* Rm, int64_t ldm, const double* Hp, const double* Hm,
+                           int assign, double* t2);
+// (+/-) pair-packed images of W[k,l,i,j] (o^4, symmetric under (k,l,i,j) -> (l,k,j,i)) for the hole-hole ladder R[ij,ab] = W[klij] tau[klab]:
+//   Ap[P(ij)][P(kl)] = W[klij] + W[klji] (k > l), W[kkij] (k = l), i >= j;   Am[Q(ij)][Q(kl)] = W[klij] - W[klji], k > l, i > j
+// (row-major with leading dimensions lda_p >= npair(o), lda_m >= npair'(o); padding columns zeroed)
+int dev_pack_w_pm(int64_t o, const double* W, double* Ap, int64_t lda_p, double* Am, int64_t lda_m);
 // The particle-hole layouts of t2 for the ring terms, all from ONE pass over t2 (t2: [o][o][v][v]; every output [o][v][o][v]):
 //   T [k,c,j,b] = t2[k,j,c,b]        Tp[k,c,j,b] = t2[k,j,b,c]        S = 2 T - Tp
 //   Ut[k,c,j,b] = S  - 2 t1[j,c] t1[k,b]        Tpt[k,c,j,b] = Tp + 2 t1[j,c] t1[k,b]

@@ -1133,7 +1133,8 @@ int dev_ccsd_finish_t2(int64_t o, int64_t v, double* t2n, const double* U, const
 // grid (lower-triangle 32 x 32 tiles of (a,b), npair(o)): the tile of R+/R- is staged through LDS so that both the [a][b] image
 // and its mirror [b][a] are updated in 256-byte runs, for t2[i,j] and t2[j,i].
 __global__ void __launch_bounds__(256) ladder_scatter_pm_kernel(long long o, long long v, const double* __restrict__ Rp, long long ldp,
-                                                               const double* __restrict__ Rm, long long ldm, double* __restrict__ t2) {
+                                                               const double* __restrict__ Rm, long long ldm, double* __restrict__ t2,
+                                                               const double* __restrict__ Hp, const double* __restrict__ Hm, int assign) {
   __shared__ double sp[32][33], sm[32][33];
   const long long ij = blockIdx.y;
   long long i, j; unpair_ge(ij, i, j);
@@ -1141,6 +1142,8 @@ __global__ void __launch_bounds__(256) ladder_scatter_pm_kernel(long long o, lon
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const double* rp = Rp + ij * ldp;
   const double* rm = (i > j) ? Rm + (i * (i - 1) / 2 + j) * ldm : nullptr;
+  const double* hp = Hp ? Hp + ij * ldp : nullptr;
+  const double* hm = (Hm && i > j) ? Hm + (i * (i - 1) / 2 + j) * ldm : nullptr;
   double* tij = t2 + (i * o + j) * v * v;
   double* tji = t2 + (j * o + i) * v * v;
 #pragma unroll
@@ -1150,7 +1153,8 @@ __global__ void __launch_bounds__(256) ladder_scatter_pm_kernel(long long o, lon
     double p = 0.0, m = 0.0;
     if (a < v && b <= a) {
       p = rp[a * (a + 1) / 2 + b];
-      if (rm && b < a) m = rm[a * (a - 1) / 2 + b];
+      if (hp) p += (a == b ? 2.0 : 1.0) * hp[a * (a + 1) / 2 + b];
+      if (rm && b < a) { m = rm[a * (a - 1) / 2 + b]; if (hm) m += hm[a * (a - 1) / 2 + b]; }
     }
     sp[aa][tx] = p; sm[aa][tx] = m;
   }
@@ -1162,27 +1166,68 @@ __global__ void __launch_bounds__(256) ladder_scatter_pm_kernel(long long o, lon
       const long long a = ta * 32 + aa, b = tb * 32 + tx;
       if (a < v && b <= a) {
         const double p = sp[aa][tx], m = sm[aa][tx];
-        tij[a * v + b] += p + m;
-        if (i != j) tji[a * v + b] += p - m;
+        if (assign) { tij[a * v + b] = p + m; if (i != j) tji[a * v + b] = p - m; }
+        else { tij[a * v + b] += p + m; if (i != j) tji[a * v + b] += p - m; }
       }
     }
     {  // mirror [b][a], b < a: destination row r = tb*32 + aa, column c = ta*32 + tx holds the element (a = c, b = r)
       const long long r = tb * 32 + aa, c = ta * 32 + tx;
       if (c < v && r < c) {
         const double p = sp[tx][aa], m = sm[tx][aa];
-        tij[r * v + c] += p - m;
-        if (i != j) tji[r * v + c] += p + m;
+        if (assign) { tij[r * v + c] = p - m; if (i != j) tji[r * v + c] = p + m; }
+        else { tij[r * v + c] += p - m; if (i != j) tji[r * v + c] += p + m; }
       }
     }
   }
 }
-int dev_ladder_scatter_pm(int64_t o, int64_t v, const double* Rp, int64_t ldp, const double* Rm, int64_t ldm, double* t2) {
+int dev_ladder_scatter_pm2(int64_t o, int64_t v, const double* Rp, int64_t ldp, const double* Rm, int64_t ldm, const double* Hp, const double* Hm,
+                           int assign, double* t2) {
   REQUIRE_INIT();
   const long long npo = o * (o + 1) / 2;
   if (npo <= 0 || v <= 0) return QEMB_OK;
   if (npo > 65535) { set_error("dev_ladder_scatter_pm: too many pairs"); return QEMB_ERR_ARG; }
   const long long nt = (v + 31) / 32;
-  hipLaunchKernelGGL(ladder_scatter_pm_kernel, dim3((unsigned)(nt * (nt + 1) / 2), (unsigned)npo), dim3(256), 0, g_stream, (long long)o, (long long)v, Rp, (long long)ldp, Rm, (long long)ldm, t2);
+  hipLaunchKernelGGL(ladder_scatter_pm_kernel, dim3((unsigned)(nt * (nt + 1) / 2), (unsigned)npo), dim3(256), 0, g_stream, (long long)o, (long long)v, Rp, (long long)ldp, Rm, (long long)ldm, t2,
+                     Hp, Hm, assign);
+  HIP_TRY(hipGetLastError());
+  return QEMB_OK;
+}
+int dev_ladder_scatter_pm(int64_t o, int64_t v, const double* Rp, int64_t ldp, const double* Rm, int64_t ldm, double* t2) {
+  return dev_ladder_scatter_pm2(o, v, Rp, ldp, Rm, ldm, nullptr, nullptr, 0, t2);
+}
+// one thread per (P(ij), P(kl)) / (Q(ij), Q(kl)) entry of the packed images of W[k,l,i,j]
+__global__ void __launch_bounds__(256) pack_w_pm_kernel(long long o, const double* __restrict__ W, double* __restrict__ Ap, long long lda_p,
+                                                        double* __restrict__ Am, long long lda_m) {
+  const long long npo = o * (o + 1) / 2, nmo = o * (o - 1) / 2;
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < npo * lda_p) {
+    const long long ij = t / lda_p, kl = t - ij * lda_p;
+    double x = 0.0;
+    if (kl < npo) {
+      long long i, j, k, l; unpair_ge(ij, i, j); unpair_ge(kl, k, l);
+      const double a = W[((k * o + l) * o + i) * o + j];
+      x = (k == l) ? a : a + W[((k * o + l) * o + j) * o + i];
+    }
+    Ap[t] = x;
+  }
+  if (Am && t < nmo * lda_m) {
+    const long long ij = t / lda_m, kl = t - ij * lda_m;
+    double x = 0.0;
+    if (kl < nmo) {
+      long long i, j, k, l;           // strictly lower pairs: Q(i,j) = i(i-1)/2 + j, i > j  ==  pair_ge of (i-1, j)
+      unpair_ge(ij, i, j); ++i; unpair_ge(kl, k, l); ++k;
+      x = W[((k * o + l) * o + i) * o + j] - W[((k * o + l) * o + j) * o + i];
+    }
+    Am[t] = x;
+  }
+}
+int dev_pack_w_pm(int64_t o, const double* W, double* Ap, int64_t lda_p, double* Am, int64_t lda_m) {
+  REQUIRE_INIT();
+  if (o <= 0) return QEMB_OK;
+  const long long npo = o * (o + 1) / 2, nmo = o * (o - 1) / 2;
+  if (lda_p < npo || (nmo > 0 && lda_m < nmo)) { set_error("dev_pack_w_pm: leading dimension too small"); return QEMB_ERR_ARG; }
+  const long long tot = std::max<long long>(npo * lda_p, nmo * lda_m);
+  hipLaunchKernelGGL(pack_w_pm_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, g_stream, (long long)o, W, Ap, (long long)lda_p, nmo > 0 ? Am : nullptr, (long long)lda_m);
   HIP_TRY(hipGetLastError());
   return QEMB_OK;
 }

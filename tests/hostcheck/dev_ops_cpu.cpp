@@ -208,13 +208,31 @@ int dev_ladder_pack_tau(int64_t o, int64_t v, const double* tau, double* Tp, int
   }
   return 0;
 }
-int dev_ladder_scatter_pm(int64_t o, int64_t v, const double* Rp, int64_t ldp, const double* Rm, int64_t ldm, double* t2) {
+int dev_ladder_scatter_pm2(int64_t o, int64_t v, const double* Rp, int64_t ldp, const double* Rm, int64_t ldm, const double* Hp, const double* Hm,
+                           int assign, double* t2) {
+  if (assign) std::fill(t2, t2 + o * o * v * v, 0.0);
   for (int64_t i = 0; i < o; ++i) for (int64_t j = 0; j <= i; ++j) for (int64_t a = 0; a < v; ++a) for (int64_t b = 0; b <= a; ++b) {
-    const double p = Rp[(i * (i + 1) / 2 + j) * ldp + a * (a + 1) / 2 + b];
-    const double m = (i > j && a > b) ? Rm[(i * (i - 1) / 2 + j) * ldm + a * (a - 1) / 2 + b] : 0.0;
+    const int64_t ip = (i * (i + 1) / 2 + j) * ldp + a * (a + 1) / 2 + b, im = (i > j && a > b) ? (i * (i - 1) / 2 + j) * ldm + a * (a - 1) / 2 + b : -1;
+    double p = Rp[ip], m = im >= 0 ? Rm[im] : 0.0;
+    if (Hp) p += (a == b ? 2.0 : 1.0) * Hp[ip];
+    if (Hm && im >= 0) m += Hm[im];
     t2[((i * o + j) * v + a) * v + b] += p + m;
     if (a != b) t2[((i * o + j) * v + b) * v + a] += p - m;
     if (i != j) { t2[((j * o + i) * v + a) * v + b] += p - m; if (a != b) t2[((j * o + i) * v + b) * v + a] += p + m; }
+  }
+  return 0;
+}
+int dev_ladder_scatter_pm(int64_t o, int64_t v, const double* Rp, int64_t ldp, const double* Rm, int64_t ldm, double* t2) {
+  return dev_ladder_scatter_pm2(o, v, Rp, ldp, Rm, ldm, nullptr, nullptr, 0, t2);
+}
+int dev_pack_w_pm(int64_t o, const double* W, double* Ap, int64_t lda_p, double* Am, int64_t lda_m) {
+  const int64_t npo = o * (o + 1) / 2, nmo = o * (o - 1) / 2;
+  auto w = [&](int64_t k, int64_t l, int64_t i, int64_t j) { return W[((k * o + l) * o + i) * o + j]; };
+  std::fill(Ap, Ap + npo * lda_p, 0.0);
+  if (nmo > 0) std::fill(Am, Am + nmo * lda_m, 0.0);
+  for (int64_t i = 0; i < o; ++i) for (int64_t j = 0; j <= i; ++j) for (int64_t k = 0; k < o; ++k) for (int64_t l = 0; l <= k; ++l) {
+    Ap[(i * (i + 1) / 2 + j) * lda_p + k * (k + 1) / 2 + l] = (k == l) ? w(k, l, i, j) : w(k, l, i, j) + w(k, l, j, i);
+    if (i > j && k > l) Am[(i * (i - 1) / 2 + j) * lda_m + k * (k - 1) / 2 + l] = w(k, l, i, j) - w(k, l, j, i);
   }
   return 0;
 }
