@@ -781,7 +781,9 @@ static int dev_gemm_dispatch(const GemmDesc& d) {
   else if (d.M >= 128 && d.N >= 128 && d.K >= 4096) cfg = 1;   // few tiles but a long K: split-K supplies the workgroups (200 x 200 x 80000: 0.24 vs 0.29 ms)
   else cfg = 2;
   // tall products with 193..224 columns: ONE 224-wide column tile (128 x 224) instead of two 128-wide ones, 12.5 % of which would be padding
-  if (vec2 && d.N > 192 && d.N <= 224 && d.M >= 128 * 512) cfg = 34;
+  // (from ~1000 row tiles on: with fewer, two 128 x 128 workgroups per CU overlap their short-K prologues and epilogues better -- U = t2 . Lvv,
+  //  625 row tiles, K = 200: 156 us against 163 us)
+  if (vec2 && d.N > 192 && d.N <= 224 && d.M >= 128 * 1024) cfg = 34;
   if (d.cfg >= 0) cfg = d.cfg;
   if (t_gemm_force_cfg >= 0) cfg = t_gemm_force_cfg;
   // The large tiles run the MODE 1 main loop (explicit one-k-step-ahead LDS fragment reads, LDS stores spread behind the MFMA rows) when
