@@ -91,6 +91,12 @@ int qemb_op_jk_from_packed(int64_t n, const double* S4, const double* D, const d
  * and the inverse scatter of packed pair ROWS: out[i,j,:] = Xp + Xm, out[j,i,:] = Xp - Xm */
 int qemb_op_pack_pm_cols(int64_t rows, int64_t v, const double* in, double* Op, int64_t ldp, double* Om, int64_t ldm);
 int qemb_op_scatter_pm_rows(int64_t o, int64_t ncols, const double* Xp, const double* Xm, double* out);
+/* hole-hole ladder through packed pairs: the (+/-) packed images of W[k,l,i,j] (Ap[P(ij)][P(kl)] = W[klij] + W[klji], W[kkij] on k = l;
+ * Am[Q(ij)][Q(kl)] = W[klij] - W[klji]) and the scatter of TWO pairs of packed result rows, p = Rp + f Hp (f = 2 on a = b), m = Rm + Hm,
+ * assigned to (assign != 0) or accumulated into t2 */
+int qemb_op_pack_w_pm(int64_t o, const double* W, double* Ap, int64_t lda_p, double* Am, int64_t lda_m);
+int qemb_op_ladder_scatter_pm2(int64_t o, int64_t v, const double* Rp, int64_t ldp, const double* Rm, int64_t ldm, const double* Hp, const double* Hm,
+                               int assign, double* t2);
 int qemb_op_lincomb2(int64_t n, double a, const double* x, double b, const double* y, double beta, double* out);   /* out = a x + b y + beta out */
 /* Single-pass kernels of the CCSD amplitude update (csrc/ccsd.cpp), device pointers:
  *   small_k_update: C[z][m][n] += alpha sum_k A[z][k][m] B[z][k][n]  (K = n_occ; batch strides sA / sB / sC, 0 shares an operand)

@@ -89,6 +89,8 @@ def _declare(lib):
     f("qemb_op_jk_from_packed", I, L, P, P, P, P, P)
     f("qemb_op_pack_pm_cols", I, L, L, P, P, L, P, L)
     f("qemb_op_scatter_pm_rows", I, L, L, P, P, P)
+    f("qemb_op_pack_w_pm", I, L, P, P, L, P, L)
+    f("qemb_op_ladder_scatter_pm2", I, L, L, P, L, P, L, P, P, I, P)
     f("qemb_op_lincomb2", I, L, D, P, D, P, D, P)
     f("qemb_op_small_k_update", I, L, L, L, L, D, P, L, P, L, P, L)
     f("qemb_op_ccsd_ph_layouts", I, L, L, P, P, P, P, P, P, P, P)

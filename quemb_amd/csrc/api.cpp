@@ -104,6 +104,9 @@ int qemb_op_k_from_pairs(int64_t n, const double* H, const double* D, double* K)
 int qemb_op_jk_from_packed(int64_t n, const double* S4, const double* D, const double* Dp, double* Jp, double* K) { return dev_jk_from_packed(n, S4, D, Dp, Jp, K); }
 int qemb_op_pack_pm_cols(int64_t rows, int64_t v, const double* in, double* Op, int64_t ldp, double* Om, int64_t ldm) { return dev_pack_pm_cols(rows, v, in, Op, ldp, Om, ldm); }
 int qemb_op_scatter_pm_rows(int64_t o, int64_t ncols, const double* Xp, const double* Xm, double* out) { return dev_scatter_pm_rows(o, ncols, Xp, Xm, out); }
+int qemb_op_pack_w_pm(int64_t o, const double* W, double* Ap, int64_t lda_p, double* Am, int64_t lda_m) { return dev_pack_w_pm(o, W, Ap, lda_p, Am, lda_m); }
+int qemb_op_ladder_scatter_pm2(int64_t o, int64_t v, const double* Rp, int64_t ldp, const double* Rm, int64_t ldm, const double* Hp, const double* Hm,
+                               int assign, double* t2) { return dev_ladder_scatter_pm2(o, v, Rp, ldp, Rm, ldm, Hp, Hm, assign, t2); }
 int qemb_op_lincomb2(int64_t n, double a, const double* x, double b, const double* y, double beta, double* out) {
   const double c[2] = {a, b};
   const double* xs[2] = {x, y};

@@ -515,6 +515,36 @@ def test_small_k_update_strip_and_tile_variants(qlib, shape):
     assert np.abs(dC.numpy((batch, M, N)) - ref).max() < 1e-12 * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.parametrize("o,v", [(1, 3), (2, 1), (4, 5), (7, 40)])
+def test_hole_hole_ladder_through_packed_pairs(qlib, o, v):
+    """R[ij,ab] = W[klij] tau[klab] (W symmetric under (k,l,i,j) -> (l,k,j,i)) from the (+/-) packed images of W, the packed tau rows as the
+    right operand and the two-pair scatter: == the dense contraction; assign and accumulate modes."""
+    rng = np.random.default_rng(10 * o + v)
+    W = rng.standard_normal((o, o, o, o)); W = W + W.transpose(1, 0, 3, 2)
+    tau = rng.standard_normal((o, o, v, v)); tau = tau + tau.transpose(1, 0, 3, 2)
+    npo, nmo, npv, nmv = o * (o + 1) // 2, o * (o - 1) // 2, v * (v + 1) // 2, v * (v - 1) // 2
+    ldp, ldm = npv + (npv & 1), max(nmv + (nmv & 1), 2)
+    lwp, lwm = npo + (npo & 1), max(nmo + (nmo & 1), 2)
+    dW, dtau = DeviceBuffer.from_numpy(W), DeviceBuffer.from_numpy(tau)
+    dAp, dAm = DeviceBuffer(npo * lwp), DeviceBuffer(max(nmo, 1) * lwm)
+    check(qlib.qemb_op_pack_w_pm(o, dW.ptr, dAp.ptr, lwp, dAm.ptr, lwm))
+    dTp, dTm = DeviceBuffer(npo * ldp), DeviceBuffer(max(nmo, 1) * ldm)
+    check(qlib.qemb_op_ladder_pack_tau(o, v, dtau.ptr, dTp.ptr, ldp, dTm.ptr, ldm))
+    dHp, dHm = DeviceBuffer(npo * ldp), DeviceBuffer(max(nmo, 1) * ldm)
+    check(qlib.qemb_op_gemm(npo, npv, npo, 1.0, dAp.ptr, lwp, 1, 0, dTp.ptr, ldp, 0, 0, 0.0, dHp.ptr, ldp, 0, 1))
+    if nmo and nmv:
+        check(qlib.qemb_op_gemm(nmo, nmv, nmo, 1.0, dAm.ptr, lwm, 1, 0, dTm.ptr, ldm, 0, 0, 0.0, dHm.ptr, ldm, 0, 1))
+    zero_p, zero_m = DeviceBuffer.from_numpy(np.zeros(npo * ldp)), DeviceBuffer.from_numpy(np.zeros(max(nmo, 1) * ldm))
+    ref = np.einsum("klij,klab->ijab", W, tau)
+    base = rng.standard_normal((o, o, v, v))
+    d2 = DeviceBuffer.from_numpy(base)
+    check(qlib.qemb_op_ladder_scatter_pm2(o, v, zero_p.ptr, ldp, zero_m.ptr, ldm, dHp.ptr, dHm.ptr if (nmo and nmv) else None, 1, d2.ptr))
+    assert np.abs(d2.numpy(ref.shape) - ref).max() < 1e-12 * max(1.0, np.abs(ref).max())          # assign: the old content is gone
+    d3 = DeviceBuffer.from_numpy(base)
+    check(qlib.qemb_op_ladder_scatter_pm2(o, v, zero_p.ptr, ldp, zero_m.ptr, ldm, dHp.ptr, dHm.ptr if (nmo and nmv) else None, 0, d3.ptr))
+    assert np.abs(d3.numpy(ref.shape) - (base + ref)).max() < 1e-12 * max(1.0, np.abs(ref).max())
+
+
 def test_gather_and_scale_rows(qlib):
     rng = np.random.default_rng(12)
     src = rng.standard_normal((9, 13))                       # rows of 13 with ld 13; gather 11 columns of each
