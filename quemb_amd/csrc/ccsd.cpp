@@ -135,6 +135,13 @@ int CcsdSolver::setup(MoIntegrals&& ints, const double* mo_energy_dev) {
     QTRY(OVp_.alloc(nov * I_.ldp)); QTRY(OVm_.alloc(nov * I_.ldm));
     QTRY(dev_pack_pm_cols(nov, v, OVl, OVp_, I_.ldp, OVm_, I_.ldm));
   }
+  // (kd|ac) is symmetric in (a,c): the pass ZC[k,i,a,c] = t1[id] ovvv[kdac] reads the block packed over that pair -- half the bytes of an
+  // HBM-bound pass -- and its result is unpacked afterwards (a tenth of the bytes)
+  {
+    const int64_t npv = v * (v + 1) / 2;
+    QTRY(ovvv_pk_.alloc(o * v * npv)); QTRY(ZCp_.alloc(oo * npv));
+    QTRY(dev_pack_tril_rows(o * v, v, I_.ovvv, ovvv_pk_));
+  }
   // G+-[(k,l)][P/Q(c,d)] = ovov[kcld] +- ovov[kdlc]: Woooo += ovov[kcld] tau[ijcd] then runs over the packed (c,d) pairs against the
   // packed tau rows the ladder builds anyway -- half the flops of the dense (oo) x (oo) x (vv) product
   QTRY(Gp_.alloc(oo * I_.ldp)); QTRY(Gm_.alloc(oo * I_.ldm));
@@ -277,7 +284,12 @@ int CcsdSolver::update_amps(double* t1n, double* t2n) {
   //  HBM-bound passes MFMA-bound)
   const int cfg_tall = (o <= 32) ? 20 : -1, cfg_wide = (o <= 32) ? 21 : -1;
   QTRY(gemm(o * vv, o, v, 1.0, I_.ovvv, v, true, t1, v, true, 0.0, ZB_, o, 1, 0, 0, 0, cfg_tall));     // ZB[k,c,a,i] = ovvv[kcad] t1[id]
-  QTRY(gemm(o, vv, v, 1.0, t1, v, true, I_.ovvv, vv, false, 0.0, ZC_, vv, o, 0, v * vv, o * vv, cfg_wide));   // ZC[k,i,a,c] = t1[id] ovvv[kdac]
+  {  // ZC[k,i,a,c] = t1[id] ovvv[kdac], symmetric in (a,c): on the pair-packed block, then unpacked
+    const int64_t npv = v * (v + 1) / 2;
+    const bool vec_ok = (npv % 2) == 0;     // (the 32 x 128 tile wants 16-byte aligned rows; odd npair(v): the dispatcher's choice)
+    QTRY(gemm(o, npv, v, 1.0, t1, v, true, ovvv_pk_, npv, false, 0.0, ZCp_, npv, o, 0, v * npv, o * npv, vec_ok ? cfg_wide : -1));
+    QTRY(dev_unpack_tril_rows(oo, v, ZCp_, ZC_));
+  }
   QTRY(dev_ccsd_y_traces(o, v, ZC_, ZB_, Y_));                                       // Y[a,c] = 2 sum_k ZC[k,k,a,c] - sum_k ZB[k,c,a,k]
   QTRY(dcopy(oo, Foo_, Loo_)); QTRY(axpby(oo, 1.0, Z_, 1.0, Loo_));                // Loo' = Foo' + Z
   QTRY(dcopy(vv, Fvv_, Lvv_)); QTRY(axpby(vv, 1.0, Y_, 1.0, Lvv_));                // Lvv' = Fvv' + Y

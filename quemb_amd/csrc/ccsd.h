@@ -75,6 +75,7 @@ class CcsdSolver {
   DBuf tau_, T_, Tp_, S_, W1_, W2_, W12_, W12b_, R_, U_, G1_, G2_;
   DBuf LTp_, LTm_, LRp_, LRm_;   // (+/-) packed ladder: tau combinations and results
   DBuf Xp_, Xm_;                 // (+/-) packed rows of X[i,j,k,a] = tau[ijcd] ovvv[kdac]
+  DBuf ovvv_pk_, ZCp_;           // ovvv[k,d,(a>=c)] packed over its symmetric pair, and the packed result of its t1 contraction
   DBuf Gp_, Gm_;                 // (+/-) pair-packed images over (c,d) of ovov[k,c,l,d], one row per (k,l): the Woooo build contracts packed tau rows
   DBuf Xwp_, Xwm_, Xw_;          // its (+/-) packed result rows [P(ij)][(kl)] and their expansion [i,j,k,l]
   DBuf WAp_, WAm_, HRp_, HRm_;   // hole-hole ladder: (+/-) packed images of Woooo and its packed result rows
