@@ -274,7 +274,30 @@ int CcsdSolver::update_amps(double* t1n, double* t2n) {
   QTRY(dev_ccsd_ph_layouts(o, v, t2, t1, T_, Tp_, S_, W12_, W12b_, R_));   // R_: Th[i,k,d,c] = 2 t2[ikcd] - t2[ikdc], scratch until the rings
 
   // ---- one- and two-index intermediates (energy-shifted: Foo - eps, Fvv - eps, ...)
-  QTRY(gemm_nt(o, o, o * vv, 1.0, Loovv_, tau_, 0.0, Foo_));                       // Foo'[k,i]
+  {  // Xw[i,j,k,l] = ovov[kcld] tau[ijcd] (the quadratic part of Woooo, added to it below) over the (+/-) packed (c,d) pairs:  X[ij] = Xp + Xm, X[ji] = Xp - Xm (i > j),
+     //   Xp[P(ij),(kl)] = sum_{c>=d} LTp[P(ij),P(cd)] G+[(kl),P(cd)],  Xm[Q(ij),(kl)] = sum_{c>d} LTm G-   (LTp carries 1/2 on c = d, G+ is doubled there)
+    const int64_t npo = o * (o + 1) / 2, nmo = o * (o - 1) / 2, nmv = v * (v - 1) / 2;
+    QTRY(dev_ladder_pack_tau(o, v, tau_, LTp_, I_.ldp, LTm_, I_.ldm));     // the packed tau rows: also read by the ladder and by the tau-side dressing below
+    // 64 x 64 tiles and enough K slices for ~2 workgroups per CU (the output is only npair(o) x o^2)
+    auto split = [&](int64_t rows, int64_t K, int& cfg, int& ks) {
+      cfg = -1; ks = 0;
+      if (K < 2048) return;
+      const int64_t tiles = ((rows + 63) / 64) * ((oo + 63) / 64);
+      cfg = 1;
+      ks = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(64, K / 256), (512 + tiles - 1) / tiles));
+    };
+    int cfg, ks;
+    split(npo, I_.ldp, cfg, ks);
+    QTRY(gemm(npo, oo, I_.ldp, 1.0, LTp_, I_.ldp, true, Gp_, I_.ldp, true, 0.0, Xwp_, oo, 1, 0, 0, 0, cfg, ks));
+    if (nmo > 0) {
+      if (nmv > 0) { split(nmo, I_.ldm, cfg, ks); QTRY(gemm(nmo, oo, I_.ldm, 1.0, LTm_, I_.ldm, true, Gm_, I_.ldm, true, 0.0, Xwm_, oo, 1, 0, 0, 0, cfg, ks)); }
+      else QTRY(dev_fill(Xwm_, nmo * oo, 0.0));
+    }
+    QTRY(dev_scatter_pm_rows(o, oo, Xwp_, Xwm_, Xw_));                               // Xw[i,j,k,l]
+  }
+  // Foo'[k,i] = sum_{lcd} (2 ovov[kcld] - ovov[kdlc]) tau[ilcd] = sum_l (2 Xw[i,l,k,l] - Xw[l,i,k,l]): a partial trace of Xw instead of
+  // a pass over two o^2 v^2 tensors
+  QTRY(dev_foo_from_x(o, Xw_, Foo_));
   QTRY(gemm(v, v, oo * v, -1.0, tau_, v, false, Loovv_, v, false, 0.0, Fvv_, v, 1, 0, 0, 0, (v <= 256) ? 1 : -1));   // Fvv'[a,c]  (64 x 64 tiles: split-K supplies the blocks)
   QTRY(dev_gemv_rows(nov, nov, Lovov_, nov, t1, Fov_, 1.0, 0.0));                  // Fov[k,c]
   QTRY(dev_contract_mid(1, nov, oo, Lovoo_, t1, Z_, oo, 1.0, 0.0));                // Z[k,i]
@@ -308,28 +331,7 @@ int CcsdSolver::update_amps(double* t1n, double* t2n) {
   // (the bare ovov[i,a,j,b] term is added by the finishing kernel)
   // Woooo[k,l,i,j]
   QTRY(dcopy(oo * oo, oooo_p_, Wo_));
-  {  // + ovov[kcld] tau[ijcd] over the (+/-) packed (c,d) pairs:  X[ij] = Xp + Xm, X[ji] = Xp - Xm (i > j),
-     //   Xp[P(ij),(kl)] = sum_{c>=d} LTp[P(ij),P(cd)] G+[(kl),P(cd)],  Xm[Q(ij),(kl)] = sum_{c>d} LTm G-   (LTp carries 1/2 on c = d, G+ is doubled there)
-    const int64_t npo = o * (o + 1) / 2, nmo = o * (o - 1) / 2, nmv = v * (v - 1) / 2;
-    QTRY(dev_ladder_pack_tau(o, v, tau_, LTp_, I_.ldp, LTm_, I_.ldm));     // the packed tau rows: also read by the ladder and by the tau-side dressing below
-    // 64 x 64 tiles and enough K slices for ~2 workgroups per CU (the output is only npair(o) x o^2)
-    auto split = [&](int64_t rows, int64_t K, int& cfg, int& ks) {
-      cfg = -1; ks = 0;
-      if (K < 2048) return;
-      const int64_t tiles = ((rows + 63) / 64) * ((oo + 63) / 64);
-      cfg = 1;
-      ks = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(64, K / 256), (512 + tiles - 1) / tiles));
-    };
-    int cfg, ks;
-    split(npo, I_.ldp, cfg, ks);
-    QTRY(gemm(npo, oo, I_.ldp, 1.0, LTp_, I_.ldp, true, Gp_, I_.ldp, true, 0.0, Xwp_, oo, 1, 0, 0, 0, cfg, ks));
-    if (nmo > 0) {
-      if (nmv > 0) { split(nmo, I_.ldm, cfg, ks); QTRY(gemm(nmo, oo, I_.ldm, 1.0, LTm_, I_.ldm, true, Gm_, I_.ldm, true, 0.0, Xwm_, oo, 1, 0, 0, 0, cfg, ks)); }
-      else QTRY(dev_fill(Xwm_, nmo * oo, 0.0));
-    }
-    QTRY(dev_scatter_pm_rows(o, oo, Xwp_, Xwm_, Xw_));                               // Xw[i,j,k,l]
-    QTRY(perm4(Wo_, Xw_, o, o, o, o, 2, 3, 0, 1, 1.0, 1.0));                         // Wo[k,l,i,j] += Xw[i,j,k,l]
-  }
+  QTRY(perm4(Wo_, Xw_, o, o, o, o, 2, 3, 0, 1, 1.0, 1.0));                           // + ovov[kcld] tau[ijcd]: Wo[k,l,i,j] += Xw[i,j,k,l] (formed at the top)
   QTRY(gemm(o, oo, v, 1.0, t1, v, true, I_.ovoo, oo, false, 0.0, O1_, oo, o, 0, v * oo, o * oo));   // O1[l,j,k,i]
   QTRY(perm4(Wo_, O1_, o, o, o, o, 2, 0, 3, 1, 1.0, 1.0));                         // + ovoo[lcki] t1[jc]
   QTRY(perm4(Wo_, O1_, o, o, o, o, 0, 2, 1, 3, 1.0, 1.0));                         // + ovoo[kclj] t1[ic]

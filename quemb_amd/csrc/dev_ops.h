@@ -178,6 +178,9 @@ int dev_ladder_scatter_pm2(int64_t o, int64_t v, const double* Rp, int64_t ldp, 
 //   Ap[P(ij)][P(kl)] = W[klij] + W[klji] (k > l), W[kkij] (k = l), i >= j;   Am[Q(ij)][Q(kl)] = W[klij] - W[klji], k > l, i > j
 // (row-major with leading dimensions lda_p >= npair(o), lda_m >= npair'(o); padding columns zeroed)
 int dev_pack_w_pm(int64_t o, const double* W, double* Ap, int64_t lda_p, double* Am, int64_t lda_m);
+// F[k,i] = sum_l (2 X[i,l,k,l] - X[l,i,k,l]) for X[i,j,k,l] (o^4): the occupied-occupied intermediate sum_{lcd} (2 ovov[kcld] - ovov[kdlc]) tau[ilcd]
+// as a partial trace of X[i,j,k,l] = sum_cd ovov[kcld] tau[ijcd], which the Woooo build forms anyway
+int dev_foo_from_x(int64_t o, const double* X, double* F);
 // The particle-hole layouts of t2 for the ring terms, all from ONE pass over t2 (t2: [o][o][v][v]; every output [o][v][o][v]):
 //   T [k,c,j,b] = t2[k,j,c,b]        Tp[k,c,j,b] = t2[k,j,b,c]        S = 2 T - Tp
 //   Ut[k,c,j,b] = S  - 2 t1[j,c] t1[k,b]        Tpt[k,c,j,b] = Tp + 2 t1[j,c] t1[k,b]

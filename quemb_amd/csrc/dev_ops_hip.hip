@@ -1221,6 +1221,21 @@ __global__ void __launch_bounds__(256) pack_w_pm_kernel(long long o, const doubl
     Am[t] = x;
   }
 }
+__global__ void __launch_bounds__(256) foo_from_x_kernel(long long o, const double* __restrict__ X, double* __restrict__ F) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= o * o) return;
+  const long long k = t / o, i = t - k * o;
+  double s = 0.0;
+  for (long long l = 0; l < o; ++l) s += 2.0 * X[((i * o + l) * o + k) * o + l] - X[((l * o + i) * o + k) * o + l];
+  F[t] = s;
+}
+int dev_foo_from_x(int64_t o, const double* X, double* F) {
+  REQUIRE_INIT();
+  if (o <= 0) return QEMB_OK;
+  hipLaunchKernelGGL(foo_from_x_kernel, dim3((unsigned)((o * o + 255) / 256)), dim3(256), 0, g_stream, (long long)o, X, F);
+  HIP_TRY(hipGetLastError());
+  return QEMB_OK;
+}
 int dev_pack_w_pm(int64_t o, const double* W, double* Ap, int64_t lda_p, double* Am, int64_t lda_m) {
   REQUIRE_INIT();
   if (o <= 0) return QEMB_OK;

@@ -225,6 +225,14 @@ int dev_ladder_scatter_pm2(int64_t o, int64_t v, const double* Rp, int64_t ldp, 
 int dev_ladder_scatter_pm(int64_t o, int64_t v, const double* Rp, int64_t ldp, const double* Rm, int64_t ldm, double* t2) {
   return dev_ladder_scatter_pm2(o, v, Rp, ldp, Rm, ldm, nullptr, nullptr, 0, t2);
 }
+int dev_foo_from_x(int64_t o, const double* X, double* F) {
+  for (int64_t k = 0; k < o; ++k) for (int64_t i = 0; i < o; ++i) {
+    double s = 0.0;
+    for (int64_t l = 0; l < o; ++l) s += 2.0 * X[((i * o + l) * o + k) * o + l] - X[((l * o + i) * o + k) * o + l];
+    F[k * o + i] = s;
+  }
+  return 0;
+}
 int dev_pack_w_pm(int64_t o, const double* W, double* Ap, int64_t lda_p, double* Am, int64_t lda_m) {
   const int64_t npo = o * (o + 1) / 2, nmo = o * (o - 1) / 2;
   auto w = [&](int64_t k, int64_t l, int64_t i, int64_t j) { return W[((k * o + l) * o + i) * o + j]; };
