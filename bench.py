@@ -2,7 +2,12 @@
 """bench.py -- fragment-sweep throughput of the MI355X hot path.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+N > 1 without WORLD_SIZE in the environment: this process only LAUNCHES -- it starts N fresh rank processes (RANK / LOCAL_RANK / WORLD_SIZE /
+MASTER_ADDR / MASTER_PORT set, one per GPU) before touching the GPU itself, forwards rank 0's JSON line and fails if any rank fails; the
+reference starts its own worker pool the same way (molbe/be_parallel.py:484-513).  Under an external launcher
+(python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...) the ranks are already there and --gpus must equal
+WORLD_SIZE.  The ranks talk through the library's own RCCL communicator (qemb_comm_*, quemb_amd/comm.py); QEMB_DIST_BACKEND=nccl|gloo selects a
+torch.distributed process group instead (gloo: rehearsal of several ranks on one card / on the CPU mock).
 
 Workload (BASELINE.json configs[2], the one the metric's n_occ/n_virt and the 1/2/4/8-GPU scaling are quoted on;
 configs[1] -- octane BE2 -- is a parity case in tests/): F synthetic fragments PER GPU (weak scaling), each
@@ -65,7 +70,74 @@ def parse():
     ap.add_argument("--cpu-worker", type=str, default=None, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-nproc", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--roofline-iters", type=int, default=8, help="single-stream CCSD iterations of the roofline pass")
+    ap.add_argument("--master-port", type=int, default=0, help="rendezvous port handed to the ranks this process launches (0: a free one)")
+    ap.add_argument("--lib", type=str, default=None, help=argparse.SUPPRESS)   # tests only: run the host logic on tests/hostcheck's mock library
     return ap.parse_args()
+
+
+# ------------------------------------------------------------------------------------------------------------ launcher
+def launch_ranks(args):
+    """--gpus N > 1 and no WORLD_SIZE: start N fresh rank processes of this script and wait for them.  Nothing in this process has
+    touched the GPU (no torch, no library call), and it never execs: the ranks are children (subprocess), each with its own device.
+    Rank 0's stdout (the JSON line) is forwarded; a failing rank ends the others and makes this process fail."""
+    import shutil
+    import socket
+    import subprocess
+    import tempfile
+    n = args.gpus
+    port = args.master_port
+    if not port:
+        sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    rdv_dir = tempfile.mkdtemp(prefix="qemb_rdv_")
+    base = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                QEMB_RDV_FILE=os.path.join(rdv_dir, "comm_id"), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, str(Path(__file__).resolve())] + sys.argv[1:]
+    procs = []
+    try:
+        for r in range(n):
+            env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+            procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+        log(f"launched {n} ranks (pids {[p.pid for p in procs]}), rendezvous {base['QEMB_RDV_FILE']}")
+        out0 = None
+        failed = None
+        pending = set(range(n))
+        import threading
+        box = {}
+        t = threading.Thread(target=lambda: box.setdefault("out", procs[0].stdout.read()), daemon=True)
+        t.start()
+        while pending and failed is None:
+            for r in sorted(pending):
+                rc = procs[r].poll()
+                if rc is None:
+                    continue
+                pending.discard(r)
+                if rc != 0:
+                    failed = (r, rc)
+                    break
+            time.sleep(0.05)
+        if failed is not None:
+            for r in pending:                     # the exact processes this launcher started, nothing else
+                procs[r].terminate()
+            for r in pending:
+                try:
+                    procs[r].wait(20)
+                except subprocess.TimeoutExpired:
+                    procs[r].kill()
+            print(f"bench.py: rank {failed[0]} exited with status {failed[1]}; the other ranks were stopped", file=sys.stderr, flush=True)
+            return 1
+        t.join(10)
+        out0 = box.get("out", "")
+        sys.stdout.write(out0)
+        sys.stdout.flush()
+        if not any(ln.startswith("{") for ln in out0.splitlines()):
+            print("bench.py: rank 0 printed no JSON line", file=sys.stderr, flush=True)
+            return 1
+        return 0
+    finally:
+        for p in procs:                           # interrupted launcher: do not leave ranks behind
+            if p.poll() is None:
+                p.terminate()
+        shutil.rmtree(rdv_dir, ignore_errors=True)
 
 
 # ------------------------------------------------------------------------------------------------------------ workload
@@ -79,8 +151,8 @@ def make_device_eris(lib, n, seed, scale):
     il = np.tril_indices(n)
     Bp = np.ascontiguousarray(B[:, il[0], il[1]])
     npair = Bp.shape[1]
-    dB = DeviceBuffer.from_numpy(Bp)
-    d4 = DeviceBuffer(npair * npair)
+    dB = DeviceBuffer.from_numpy(Bp, lib=lib)
+    d4 = DeviceBuffer(npair * npair, lib=lib)
     check(lib.qemb_op_gemm(npair, npair, naux, 1.0, dB.ptr, npair, 0, 0, dB.ptr, npair, 0, 0, 0.0, d4.ptr, npair, 0, 1))
     dB.free()
     A = rng.standard_normal((n, n))
@@ -293,32 +365,65 @@ def main():
     args = parse()
     if args.cpu_worker:
         return cpu_worker(args.cpu_worker, args.nocc, args.cpu_iters, args.cpu_nproc)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args)                 # this process stays off the GPU; the ranks are its children
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); lrank = int(os.environ.get("LOCAL_RANK", "0"))
-    import torch
-    dist = None
-    # QEMB_DIST_BACKEND=gloo + several ranks on one card is a rehearsal mode for 1-GPU boxes (RCCL refuses duplicate GPUs)
-    backend = os.environ.get("QEMB_DIST_BACKEND", "nccl")
-    ndev = max(torch.cuda.device_count(), 1)
-    lrank = lrank % ndev
-    if world > 1:
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: under an external launcher start exactly --gpus ranks "
+                         "(or unset WORLD_SIZE and let bench.py launch them)")
+    # Transport between the ranks: "rccl" = the library's own communicator (qemb_comm_*, no torch in the process);
+    # "nccl" / "gloo" = a torch.distributed group (gloo + several ranks on one card is a rehearsal mode for 1-GPU boxes: RCCL refuses duplicate GPUs)
+    backend = os.environ.get("QEMB_DIST_BACKEND", "rccl")
+    if backend not in ("rccl", "nccl", "gloo"):
+        raise SystemExit(f"QEMB_DIST_BACKEND={backend}: expected rccl, nccl or gloo")
+    dist = torch = None
+    if world > 1 and backend != "rccl":
+        import torch                              # before libqemb_hip.so: see quemb_amd/be_parallel.py on the load order
         import torch.distributed as dist
-        if backend == "nccl" or torch.cuda.is_available():
+        lrank = lrank % max(torch.cuda.device_count(), 1)
+        if torch.cuda.is_available():
             torch.cuda.set_device(lrank)
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", lrank))
         else:
-            dist.init_process_group(backend=backend)
-    from quemb_amd import _lib
+            dist.init_process_group(backend="gloo")
+    from quemb_amd import _lib, comm
     from quemb_amd.be_parallel import be_func_parallel, fragment_cost, partition_fragments
     from quemb_amd.fragsolver import default_opts
     from quemb_amd.solver import ErrorMap, be_func
-    lib = _lib.init(lrank)
+    if args.lib:                                  # tests only (tests/test_bench_launcher.py): the drivers on the scalar mock device layer
+        lib = _lib.declare(C.CDLL(args.lib))
+        _lib.check(lib.qemb_init(0), "qemb_init", lib)
+    else:
+        lib = _lib.init(lrank)
+    if world > 1 and backend == "rccl":
+        comm.init_from_env(lib)
+        log(f"communicator up: {world} ranks ({lib.qemb_backend().decode()})")
+
+    def barrier():
+        if world > 1:
+            comm.barrier(lib) if backend == "rccl" else dist.barrier()
+
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        if backend == "rccl":
+            return float(comm.all_reduce(lib, np.array([x]), comm.MAX)[0])
+        tt = torch.tensor([x], dtype=torch.float64, device=torch.device("cuda", lrank) if backend == "nccl" else torch.device("cpu"))
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
+
+    def sync():
+        """every stream of this rank's device idle (hipDeviceSynchronize: what torch.cuda.synchronize() does)"""
+        _lib.check(lib.qemb_device_sync(), "qemb_device_sync", lib)
     n, o, F = args.n, args.nocc, args.frags_per_gpu
     v = n - o
     nf = min(22, n // 2)
     if nf < 2 * N_EDGE:
         raise SystemExit(f"--n {n}: the synthetic ring needs at least {2 * N_EDGE} fragment sites (n >= {4 * N_EDGE})")
-    opts = default_opts()
+    opts = default_opts(lib)
     F_total = F * world
     owner = partition_fragments([fragment_cost(n, o)] * F_total, world)     # the product's LPT partition (equal costs: F per rank)
 
@@ -329,7 +434,6 @@ def main():
     emap = ErrorMap(frs)
     pot = [0.0] * npot
     Nocc = float(F_total * N_EDGE) * 1.0
-    sync = torch.cuda.synchronize if torch.cuda.is_available() else (lambda: None)
     nctx = lib.qemb_ctx_count(args.nstreams + 1) if args.nstreams > 1 else 1
     stats = {}
 
@@ -347,23 +451,16 @@ def main():
     for s in range(8):
         read_timer(lib, s, nctx, reset=1)
     stats.clear()
-    if world > 1:
-        dist.barrier()
-    lib.qemb_sync(); sync()
+    barrier()
+    sync()
     t0 = time.perf_counter()
     ecorr_sum = 0.0
     for _ in range(args.steps):
         ernorm, ervec, (ecorr, _) = sweep()
         ecorr_sum += ecorr
-    lib.qemb_sync(); sync()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        comm_dev = torch.device("cuda", lrank) if backend == "nccl" else torch.device("cpu")
-        tt = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    sync()
+    barrier()
+    dt = max_over_ranks(time.perf_counter() - t0)
     # stats["ccsd_iterations"] is summed over ranks inside the sweep's all-reduce when world > 1
     n_iter_total = float(stats.get("ccsd_iterations", 0)); n_frag_total = float(stats.get("fragments", 0))
 
@@ -404,7 +501,10 @@ def main():
                                    "own RHF/CCSD diverges there for n > ~100, DESIGN.md), one be_func / be_func_parallel sweep per step "
                                    "(update_heff + fragment RHF + MO transform + RCCSD to |dE|<1e-10 + 1-RDM + energies per fragment, solve_error, 1 all-reduce)",
                        "fragments_per_gpu": F, "n_occ": o, "n_virt": v, "fragments_in_flight_per_gpu": args.nstreams,
-                       "parallelism": f"fragments sharded over {world} GPU(s) by the LPT partition, 1 RCCL all-reduce per sweep",
+                       "parallelism": f"fragments sharded over {world} GPU(s) by the LPT partition, 1 all-reduce per sweep",
+                       "transport": None if world == 1 else {"rccl": "library communicator: ncclAllReduce on a persistent RCCL communicator (qemb_comm_allreduce)",
+                                                             "nccl": "torch.distributed nccl (RCCL)", "gloo": "torch.distributed gloo (rehearsal)"}[backend]
+                                    + (" [hostcheck mock: shared-memory transport]" if args.lib else ""),
                        "fragments_per_rank": [owner.count(r) for r in range(world)],
                        "allreduce_bytes_per_sweep": stats.get("allreduce_bytes_per_sweep", 0 if world == 1 else None),
                        "residual_slots": int(2 * emap.n_match + 5)},
@@ -453,10 +553,11 @@ def main():
                 res["parity_n220"] = dict(e_corr_device=e_dev, e_corr_oracle=e_cpu, updates=args.cpu_iters,
                                           what="E_corr after the same number of plain (no DIIS) RCCSD amplitude updates from the MP2 guess, fragment 0 (n=220): device vs oracle/qemb_oracle/ccsd_lean.py on the device-exported MO integrals")
         print(json.dumps(res), flush=True)
+    barrier()
     if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        comm.destroy(lib) if backend == "rccl" else dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

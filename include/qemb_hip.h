@@ -34,7 +34,8 @@ extern "C" {
 int qemb_init(int device);                 /* select the GPU, create the library stream            */
 const char* qemb_last_error(void);
 const char* qemb_backend(void);            /* "hip-gfx950"                                         */
-int qemb_sync(void);
+int qemb_sync(void);                      /* the calling thread's stream (execution context)      */
+int qemb_device_sync(void);               /* every stream of the device                           */
 int qemb_mem_info(size_t* free_bytes, size_t* total_bytes);
 
 /* raw device buffers (for callers that keep tensors resident, e.g. bench.py / multi-fragment sweeps) */
@@ -118,6 +119,23 @@ int qemb_ccsd_solve(int n, int nsocc, int n_f, const double* h, const double* er
                     const qemb_solver_opts* opts, const double* h1, const double* veff0, double weight,
                     const int* centers, int ncenter, double* mo_coeff, double* mo_energy, double* t1, double* t2,
                     double* rdm1_emb, double* e_frag, double* e_corr_mo, int* n_iter);
+/* ---------------------------------------------------------------- multi-GPU exchange -------------- */
+/* One process per GPU; fragments are sharded over the ranks and the ONLY exchange of a sweep is one all-reduce of the residual buffer
+ * [edge values, centre values, sum centre diag, e1, e2, ec, n_iter, failure flag] -- what be_func_parallel gets back from its pathos pool
+ * as pickled result tuples (molbe/be_parallel.py:484-517) before solve_error reads Fobjs[j]._rdm1 (molbe/solver.py:683-778); SURVEY.md 8(e).
+ * The communicator is RCCL (xGMI inside a node), created once per process on the device and stream of qemb_init, and needs no Python
+ * package: qemb_comm_unique_id on ONE rank -> the 128 bytes travel to every rank out of band (file, socket, MPI_Bcast, a torch store...)
+ * -> qemb_comm_init(rank, world, id) on every rank (collective).  Buffers are HOST buffers, reduced in place; every rank receives the
+ * bit-identical result.  Without qemb_comm_init the process is a world of one: info reports (0, 1), all-reduce fails.                  */
+#define QEMB_COMM_ID_BYTES 128
+#define QEMB_COMM_SUM 0
+#define QEMB_COMM_MAX 1
+int qemb_comm_unique_id(void* id_out /* QEMB_COMM_ID_BYTES */);
+int qemb_comm_init(int rank, int world, const void* id);
+int qemb_comm_info(int* rank, int* world);
+int qemb_comm_allreduce(double* host_buf, int64_t n, int op);
+int qemb_comm_destroy(void);
+
 /* ---------------------------------------------------------------- AO -> fragment ERI transforms -- */
 /* Dense: replaces `ao2mo.incore.full(eri_, TA, compact=True)` of BE._eri_transform "in-core"
  * (molbe/mbe.py:1035-1039).  The AO tensor is uploaded once per system and stays resident.            */

@@ -49,6 +49,7 @@ def _declare(lib):
     f("qemb_last_error", C.c_char_p)
     f("qemb_backend", C.c_char_p)
     f("qemb_sync", I)
+    f("qemb_device_sync", I)
     f("qemb_mem_info", I, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t))
     f("qemb_malloc", I, C.POINTER(c_vp), C.c_size_t)
     f("qemb_free", I, V)
@@ -109,6 +110,11 @@ def _declare(lib):
     f("qemb_op_jacobi_svd", I, L, L, P, P, P, P, C.POINTER(I))
     f("qemb_op_cholesky_lower", I, L, P)
     f("qemb_op_tri_inverse_lower", I, L, P, P)
+    f("qemb_comm_unique_id", I, P)
+    f("qemb_comm_init", I, I, I, P)
+    f("qemb_comm_info", I, C.POINTER(I), C.POINTER(I))
+    f("qemb_comm_allreduce", I, P, L, I)
+    f("qemb_comm_destroy", I)
     # ---- fragment solver
     OP = C.POINTER(SolverOpts)
     IP = C.POINTER(I)
@@ -215,9 +221,9 @@ class DeviceBuffer:
         self.ptr = p.value
 
     @classmethod
-    def from_numpy(cls, a: np.ndarray):
+    def from_numpy(cls, a: np.ndarray, lib=None):
         a = np.ascontiguousarray(a, dtype=np.float64)
-        b = cls(a.size)
+        b = cls(a.size, lib=lib)
         b.upload(a)
         return b
 

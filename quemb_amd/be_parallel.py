@@ -1,17 +1,19 @@
-"""be_func_parallel -- the fragment sweep sharded over GPUs (one process per GPU, torch.distributed).
+"""be_func_parallel -- the fragment sweep sharded over GPUs (one process per GPU).
 
 Reference: molbe/be_parallel.py:413-553 farms `run_solver` out to a `pathos.ProcessPool(nproc // ompnum)`
 (:484-513) and pickles (e_f, mo_coeff, rdm1, rdm2s, rdm1_tmp) back through pipes (:517) -- rdm2s is n^4 doubles.
 Here fragments are statically partitioned over ranks (longest-processing-time by the o^2 v^4 ladder cost, the
 role of `order_by_size`, molbe/fragment.py:68-70), every rank keeps its fragments' ERIs resident on its GPU, and
-the ONLY exchange per sweep is one sum-all-reduce (RCCL over xGMI under backend "nccl") of the residual buffer
+the ONLY exchange per sweep is one sum-all-reduce (RCCL over xGMI) of the residual buffer
     [edge_vals (n_match), cen_vals (n_match), sum centre diag, e1, e2, ec, n_iter]
 where each rank writes the slots its fragments own (ErrorMap) and zeros elsewhere -- a few kB, latency bound.
 
-Process set-up for RCCL: create the process group (`dist.init_process_group("nccl", device_id=...)`, or at least `torch.cuda.init()`)
-BEFORE the first `quemb_amd` call that touches the device.  torch and libqemb_hip.so each bring a HIP runtime under one SONAME; loaded in
-that order they share torch's, the other way round `torch.cuda` finds no device afterwards (measured on the MI355X boxes of this pool).
-bench.py and tests/conftest.py follow that order.
+Transport, in order of preference:
+  1. the library's own communicator (`quemb_amd.comm`, C ABI qemb_comm_*: ncclAllReduce on a persistent RCCL communicator and the
+     library's stream) -- no Python dependency beyond ctypes; `comm.init_from_env(lib)` after `_lib.init(LOCAL_RANK)`;
+  2. an initialised `torch.distributed` process group (gloo on CPU -- tests/test_distributed_gloo.py -- or nccl), for callers that
+     already run under torch.  With torch AND libqemb_hip.so in one process, import torch first: both bring a HIP runtime under one
+     SONAME; loaded in that order they share torch's, the other way round `torch.cuda` finds no device afterwards (measured on this pool).
 """
 
 from __future__ import annotations
@@ -31,7 +33,15 @@ def _dist():
     return None
 
 
+def _libcomm():
+    from . import comm
+    return comm.active()
+
+
 def world():
+    c = _libcomm()
+    if c:
+        return c[1], c[2]
     d = _dist()
     return (d.get_rank(), d.get_world_size()) if d else (0, 1)
 
@@ -63,32 +73,38 @@ def all_reduce_sum(buf: np.ndarray, device=None, error: BaseException | None = N
     `error` is the exception this rank caught while filling `buf` (None if it succeeded).  A fragment failure (SCF / CCSD
     non-convergence, allocation failure, ...) is local to one rank; if that rank simply raised, the others would wait in the
     collective forever.  So the failure count travels in one extra slot of the SAME all-reduce and every rank raises after it."""
-    d = _dist()
-    if d is None or (d.get_world_size() == 1 and not force):      # force: run the collective also on a one-rank group (tests)
+    c = _libcomm()
+    d = None if c else _dist()
+    if c is None and (d is None or (d.get_world_size() == 1 and not force)):      # force: run the collective also on a one-rank group (tests)
         if error is not None:
             raise error
         return buf
-    import torch
     ext = np.append(np.asarray(buf, dtype=np.float64).ravel(), 0.0 if error is None else 1.0)
     if error is not None:
         ext[:-1] = 0.0
-    backend = d.get_backend()
-    if backend == "nccl":
-        if device is None:
-            from . import _lib
-            idx = _lib._initialised_device if _lib._initialised_device is not None else torch.cuda.current_device()
-            device = torch.device("cuda", idx)
-        t = torch.from_numpy(ext).to(device)
-        d.all_reduce(t, op=d.ReduceOp.SUM)
-        ext = t.cpu().numpy()
-    else:
-        t = torch.from_numpy(ext)
-        d.all_reduce(t, op=d.ReduceOp.SUM)
+    if c is not None:                       # the library's RCCL communicator (qemb_comm_allreduce)
+        from . import comm
+        comm.all_reduce(c[0], ext, comm.SUM)
+        rank_, ws_ = c[1], c[2]
+    else:                                   # a torch.distributed group the caller created
+        import torch
+        rank_, ws_ = d.get_rank(), d.get_world_size()
+        if d.get_backend() == "nccl":
+            if device is None:
+                from . import _lib
+                idx = _lib._initialised_device if _lib._initialised_device is not None else torch.cuda.current_device()
+                device = torch.device("cuda", idx)
+            t = torch.from_numpy(ext).to(device)
+            d.all_reduce(t, op=d.ReduceOp.SUM)
+            ext = t.cpu().numpy()
+        else:
+            t = torch.from_numpy(ext)
+            d.all_reduce(t, op=d.ReduceOp.SUM)
     nfail = int(round(ext[-1]))
     if nfail:
-        msg = f"{nfail} of {d.get_world_size()} rank(s) failed in this step"
+        msg = f"{nfail} of {ws_} rank(s) failed in this step"
         if error is not None:
-            raise RankFailure(f"{msg}; rank {d.get_rank()}: {error}") from error
+            raise RankFailure(f"{msg}; rank {rank_}: {error}") from error
         raise RankFailure(msg + " (this rank succeeded)")
     buf.reshape(-1)[:] = ext[:-1]
     return buf

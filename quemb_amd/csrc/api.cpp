@@ -27,6 +27,7 @@ int qemb_init(int device) { return dev_init(device); }
 const char* qemb_last_error(void) { return last_error(); }
 const char* qemb_backend(void) { return dev_backend_name(); }
 int qemb_sync(void) { return dev_sync(); }
+int qemb_device_sync(void) { return dev_sync_device(); }
 int qemb_mem_info(size_t* f, size_t* t) { return dev_mem_info(f, t); }
 int qemb_malloc(void** p, size_t bytes) { return dev_alloc(p, bytes); }
 int qemb_free(void* p) { return dev_free(p); }
@@ -97,6 +98,11 @@ int qemb_op_contract_mid(int64_t outer, int64_t mid, int64_t inner, const double
 int qemb_op_unpack_s4(int64_t n, const double* s4, double* s1) { return dev_unpack_s4(n, s4, s1); }
 int qemb_op_pack_s4(int64_t n, const double* s1, double* s4) { return dev_pack_s4(n, s1, s4); }
 int qemb_op_unpack_s8_to_s4(int64_t n, const double* s8, double* s4) { return dev_unpack_s8_to_s4(n, s8, s4); }
+int qemb_comm_unique_id(void* id) { return dev_comm_unique_id(id); }
+int qemb_comm_init(int rank, int world, const void* id) { return dev_comm_init(rank, world, id); }
+int qemb_comm_info(int* rank, int* world) { return dev_comm_info(rank, world); }
+int qemb_comm_allreduce(double* buf, int64_t n, int op) { return dev_comm_allreduce(buf, n, op); }
+int qemb_comm_destroy(void) { return dev_comm_destroy(); }
 int qemb_ctx_count(int n) { return dev_ctx_count(n); }
 int qemb_ctx_bind(int k) { return dev_ctx_bind(k); }
 int qemb_ctx_timer_read(int ctx, int slot, double* total_ms, int64_t* count, int reset) { return dev_ctx_timer_read(ctx, slot, total_ms, count, reset); }

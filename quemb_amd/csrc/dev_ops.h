@@ -26,6 +26,7 @@ const char* last_error();
 // ---- device / memory -----------------------------------------------------------------------
 int dev_init(int device);            // select device, create the library stream
 int dev_sync();                      // wait for the calling thread's stream
+int dev_sync_device();               // wait for every stream of the device (hipDeviceSynchronize)
 // Execution contexts: one HIP stream + workspaces + block cache each.  dev_ctx_count(n) makes contexts 0..n-1 available
 // (0 = default) and returns how many exist; dev_ctx_bind(k) binds the CALLING host thread to context k.
 int dev_ctx_count(int n);
@@ -257,6 +258,19 @@ int dev_jacobi_eigh_until(int64_t n, double* A, double* w, double* V, int* sweep
 // One-sided Jacobi SVD of G (m x n row-major, m >= n), overwritten by U*diag(s) columns;
 // s[n] descending, V (n x n) right vectors in columns, U (m x n) left vectors in columns.
 int dev_jacobi_svd(int64_t m, int64_t n, double* G, double* s, double* U, double* V, int* sweeps_out);
+
+// ---- the one exchange of the sharded sweep: a persistent communicator, one process per GPU ----------------
+// The reference has no communication backend: be_func_parallel pickles whole result tuples back through pathos pipes
+// (molbe/be_parallel.py:484-517).  Here each rank drives one GPU and the only exchange per sweep is an all-reduce of a few kB.
+// Product: RCCL (ncclAllReduce, ncclDouble) on the default context's stream, communicator created once (comm_rccl.hip).
+// dev_comm_unique_id: 128 opaque bytes made by ONE rank and handed to every rank out of band (file, socket, MPI, ...).
+enum { COMM_ID_BYTES = 128, COMM_SUM = 0, COMM_MAX = 1 };
+int dev_comm_unique_id(void* id128);
+int dev_comm_init(int rank, int world, const void* id128);
+int dev_comm_info(int* rank, int* world);                    // 0 / 1 without a communicator
+// in place on a HOST buffer of n doubles; every rank gets the identical result
+int dev_comm_allreduce(double* host_buf, int64_t n, int op);
+int dev_comm_destroy();
 
 // ---- Cholesky / triangular inverse (DF metric) ---------------------------------------------------------
 // A (n x n SPD row-major) -> L lower triangular with A = L L^T (upper part zeroed), in place

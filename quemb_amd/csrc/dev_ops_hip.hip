@@ -122,6 +122,7 @@ int dev_ctx_bind(int k) {
   do { if (!g_stream) { set_error("libqemb_hip: call qemb_init(device) first"); return QEMB_ERR_DEVICE; } } while (0)
 
 int dev_sync() { REQUIRE_INIT(); HIP_TRY(hipStreamSynchronize(g_stream)); return QEMB_OK; }
+int dev_sync_device() { REQUIRE_INIT(); HIP_TRY(hipDeviceSynchronize()); return QEMB_OK; }
 // ---- caching allocator --------------------------------------------------------------------------------------
 // Every fragment solve allocates the same handful of multi-GB buffers (two n^4 ping-pong tensors, the v^4 ladder
 // operand, ...).  hipMalloc / hipFree of such blocks cost ~0.1 s each and hipFree synchronises the device, so

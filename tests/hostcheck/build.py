@@ -15,7 +15,7 @@ def build(force=False):
     # QEMB_HOSTCHECK_LIB: use a prebuilt variant instead (e.g. an -fsanitize=address,undefined build, see tests/hostcheck/README)
     if os.environ.get("QEMB_HOSTCHECK_LIB"):
         return Path(os.environ["QEMB_HOSTCHECK_LIB"])
-    srcs = sorted(CSRC.glob("*.cpp")) + [HERE / "dev_ops_cpu.cpp"]
+    srcs = sorted(CSRC.glob("*.cpp")) + [HERE / "dev_ops_cpu.cpp", HERE / "comm_shm.cpp"]
     deps = srcs + sorted(CSRC.glob("*.h")) + sorted(CSRC.glob("*.inc")) + [CSRC.parent.parent / "include" / "qemb_hip.h", CSRC.parent.parent / "include" / "qemb_hip_ops.h"]
     def fresh():
         return OUT.exists() and all(OUT.stat().st_mtime > d.stat().st_mtime for d in deps)
@@ -27,7 +27,7 @@ def build(force=False):
         if fresh() and not force:
             return OUT
         tmp = OUT.with_suffix(f".tmp{os.getpid()}.so")
-        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fopenmp", "-Wl,--no-undefined", "-DQEMB_HOSTCHECK", f"-I{CSRC}", "-o", str(tmp)] + [str(s) for s in srcs]
+        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fopenmp", "-Wl,--no-undefined", "-DQEMB_HOSTCHECK", f"-I{CSRC}", "-o", str(tmp)] + [str(s) for s in srcs] + ["-lrt"]
         try:
             subprocess.run(cmd, check=True)
             os.replace(tmp, OUT)

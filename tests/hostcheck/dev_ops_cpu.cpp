@@ -28,6 +28,7 @@ void dev_gemm_set_auto_splitk(int) {}
 
 int dev_init(int) { return 0; }
 int dev_sync() { return 0; }
+int dev_sync_device() { return QEMB_OK; }
 int dev_alloc(void** p, size_t bytes) { *p = std::malloc(bytes ? bytes : 16); if (!*p) { set_error("malloc failed"); return QEMB_ERR_ALLOC; } return 0; }
 int dev_free(void* p) { std::free(p); return 0; }
 int dev_trim() { return 0; }

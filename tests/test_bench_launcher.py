@@ -1,0 +1,123 @@
+"""CPU: `bench.py --gpus N` starts N ranks itself (no external launcher), the ranks meet through the library's communicator
+(quemb_amd/comm.py; on the hostcheck mock the shared-memory stand-in of the RCCL transport, tests/hostcheck/comm_shm.cpp) or through
+torch.distributed gloo, and the JSON line reports what ran.  Also the rendezvous of comm.init_from_env on its own."""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT / "tests" / "hostcheck"))
+
+SMALL = ["--steps", "1", "--warmup", "0", "--frags-per-gpu", "2", "--n", "24", "--nocc", "4", "--nstreams", "1", "--no-cpu-baseline"]
+
+
+def _mock():
+    import build as hc_build
+    return str(hc_build.build())
+
+
+def _env(**kw):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "QEMB_RDV_FILE", "QEMB_DIST_BACKEND")}
+    env.update(kw)
+    return env
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("backend", ["rccl", "gloo"])
+def test_bench_gpus_2_launches_two_ranks(backend):
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", *SMALL, "--lib", _mock()], env=_env(QEMB_DIST_BACKEND=backend),
+                       capture_output=True, text=True, timeout=280)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout            # ONE JSON line, from rank 0
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2
+    assert r["config"]["fragments_per_rank"] == [2, 2]
+    assert r["config"]["allreduce_bytes_per_sweep"] > 0
+    assert r["scaling"] == "weak" and r["steps"] == 1 and r["warmup"] == 0
+    assert r["value"] > 0 and r["fragments_per_s"] > 0
+    assert ("library communicator" in r["config"]["transport"]) == (backend == "rccl")
+
+
+@pytest.mark.timeout(300)
+def test_two_ranks_give_the_single_rank_energies():
+    """the same 4-fragment ring on 1 rank and on 2: identical sweep energy and residual (the all-reduced buffer is the only coupling)"""
+    outs = []
+    for gpus, fpg in ((1, 4), (2, 2)):
+        args = [a for a in SMALL]
+        args[args.index("--frags-per-gpu") + 1] = str(fpg)
+        p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", str(gpus), *args, "--lib", _mock()], env=_env(),
+                           capture_output=True, text=True, timeout=280)
+        assert p.returncode == 0, p.stderr[-2000:]
+        outs.append(json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0]))
+    a, b = outs
+    assert a["n_gpus"] == 1 and b["n_gpus"] == 2
+    assert abs(a["mean_e_corr_per_sweep"] - b["mean_e_corr_per_sweep"]) < 1e-12
+    assert abs(a["residual_norm"] - b["residual_norm"]) < 1e-12
+    assert a["ccsd_iterations_per_fragment"] == b["ccsd_iterations_per_fragment"]
+
+
+def test_gpus_must_match_world_size():
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "1", *SMALL, "--lib", _mock()],
+                       env=_env(RANK="0", LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999"),
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and "WORLD_SIZE=2" in p.stderr
+
+
+@pytest.mark.timeout(120)
+def test_failing_rank_fails_the_launcher():
+    args = [a for a in SMALL]
+    args[args.index("--n") + 1] = "20"        # too small for the synthetic ring: every rank exits with an error
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", *args, "--lib", _mock()], env=_env(), capture_output=True, text=True,
+                       timeout=100)
+    assert p.returncode != 0
+    assert "exited with status" in p.stderr and not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+
+
+_RANK_SCRIPT = r"""
+import ctypes as C, os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from quemb_amd import _lib, comm, be_parallel
+lib = _lib.declare(C.CDLL(sys.argv[2]))
+_lib.check(lib.qemb_init(0), "qemb_init", lib)
+rank, world = comm.init_from_env(lib)
+assert comm.info(lib) == (rank, world) and be_parallel.world() == (rank, world)
+x = np.arange(5, dtype=np.float64) * (rank + 1)
+comm.all_reduce(lib, x)
+m = comm.all_reduce(lib, np.array([float(rank), -float(rank)]), comm.MAX)
+big = np.full(40000, float(rank + 1)); comm.all_reduce(lib, big)          # longer than one pass of the mock transport
+buf = np.array([1.0 + rank, 2.0]); be_parallel.all_reduce_sum(buf)
+try:
+    be_parallel.all_reduce_sum(np.zeros(2), error=ValueError("boom") if rank == 1 else None)
+    fail = "none"
+except be_parallel.RankFailure as e:
+    fail = str(e)
+comm.barrier(lib); comm.destroy(lib)
+assert comm.info(lib) == (0, 1) and comm.active() is None
+print(repr((x.tolist(), m.tolist(), float(big.min()), float(big.max()), buf.tolist(), fail)))
+"""
+
+
+@pytest.mark.timeout(120)
+def test_rendezvous_without_a_launcher_file():
+    """comm.init_from_env with only RANK / WORLD_SIZE / MASTER_PORT: the ranks of one launch share a parent process, which names the file"""
+    world = 3
+    procs = [subprocess.Popen([sys.executable, "-c", _RANK_SCRIPT, str(ROOT), _mock()],
+                              env=_env(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT="23456"),
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=100) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-2000:]
+    tot = sum(range(1, world + 1))
+    for r, (so, _) in enumerate(outs):
+        x, m, bmin, bmax, buf, fail = eval(so.strip().splitlines()[-1])
+        assert x == (np.arange(5.0) * tot).tolist() and m == [world - 1.0, 0.0]
+        assert bmin == bmax == float(tot)
+        assert buf == [float(tot), 2.0 * world]
+        assert "1 of 3 rank(s) failed" in fail and (("this rank succeeded" in fail) == (r != 1))

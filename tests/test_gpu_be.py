@@ -7,7 +7,7 @@ import pytest
 
 from helpers import GOLDEN
 from qemb_oracle import eri as oeri
-from quemb_amd import eri_transform as et
+from quemb_amd import _lib, eri_transform as et
 
 pytestmark = pytest.mark.gpu
 
@@ -555,3 +555,41 @@ def test_rccl_all_reduce_branch_single_rank(qlib):
         assert dist.get_backend() == "nccl"
     finally:
         dist.destroy_process_group()
+
+
+def test_library_rccl_communicator_single_rank(qlib):
+    """qemb_comm_* on the real RCCL (include/qemb_hip.h): id, communicator on the library's device and stream, sum / max all-reduce of
+    host buffers through the pinned staging path (also one longer than the first staging allocation), be_parallel picking the
+    communicator up, the failure slot, destroy.  One rank: the boxes of this pool have one GPU; N > 1 is the driver's 8-GPU run."""
+    from quemb_amd import be_parallel, comm
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    assert comm.info(qlib) == (0, 1) and comm.active() is None
+    uid = comm.unique_id(qlib)
+    assert len(uid) == comm.ID_BYTES and uid != bytes(comm.ID_BYTES)
+    comm.init(qlib, 0, 1, uid)
+    try:
+        assert comm.info(qlib) == (0, 1)
+        x = np.linspace(-3.0, 7.0, 341)
+        keep = x.copy()
+        assert np.array_equal(comm.all_reduce(qlib, x), keep)
+        assert np.array_equal(comm.all_reduce(qlib, x, comm.MAX), keep)
+        big = np.random.default_rng(3).standard_normal(200_000)
+        assert np.array_equal(comm.all_reduce(qlib, big.copy()), big)
+        comm.barrier(qlib)
+        with pytest.raises(_lib.QembError):
+            comm.init(qlib, 0, 1, uid)                       # one communicator per process
+        comm._force_single = True                            # run be_parallel's collective on the one-rank communicator
+        try:
+            assert be_parallel.world() == (0, 1)
+            buf = np.arange(37, dtype=np.float64) * 0.5
+            be_parallel.all_reduce_sum(buf)
+            assert np.array_equal(buf, np.arange(37) * 0.5)
+            with pytest.raises(be_parallel.RankFailure):
+                be_parallel.all_reduce_sum(buf, error=ValueError("fragment 3 did not converge"))
+        finally:
+            comm._force_single = False
+    finally:
+        comm.destroy(qlib)
+    assert comm.active() is None
+    with pytest.raises(_lib.QembError):
+        comm.all_reduce(qlib, np.zeros(3))                   # no communicator: loud
