@@ -65,9 +65,12 @@ def parse():
     ap.add_argument("--nocc", type=int, default=20)
     ap.add_argument("--scale", type=float, default=0.03)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-iters", type=int, default=3, help="amplitude updates per worker timed by the CPU baseline")
+    ap.add_argument("--cpu-iters", type=int, default=2, help="amplitude updates per worker timed by the CPU baseline")
     ap.add_argument("--cpu-ompnum", type=int, default=4, help="BLAS threads per CPU worker (the reference's `ompnum`)")
+    ap.add_argument("--full-n", type=int, default=FULL_N, help="fragment size of the full-solve CPU baseline sample")
+    ap.add_argument("--full-nocc", type=int, default=FULL_O)
     ap.add_argument("--cpu-worker", type=str, default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-mode", type=str, default="updates", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-nproc", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--roofline-iters", type=int, default=8, help="single-stream CCSD iterations of the roofline pass")
     ap.add_argument("--master-port", type=int, default=0, help="rendezvous port handed to the ranks this process launches (0: a free one)")
@@ -210,57 +213,139 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(fr, h, dm0, o, opts, iters, ompnum, timeout_s=420):
-    """QuEmb's own CPU shape (molbe/be_parallel.py:484-513: a pool of nproc = cores // ompnum worker processes, OMP_NUM_THREADS =
-    ompnum each, one fragment per worker at a time) with the oracle ('port': oracle/qemb_oracle/ccsd_lean.py, NumPy/BLAS) as the
-    per-fragment solver, timed on a BOUNDED sample of the same workload: every worker runs `iters` full RCCSD amplitude updates of
-    fragment 0 of this rank from the MP2 guess (the fragments of the sweep are statistically identical; the MO integrals are
-    exported from the device once and shared through /dev/shm so no CPU time goes into re-deriving inputs).
-    Also returns the device's energy after the SAME `iters` plain (no DIIS) updates for the full-size parity field."""
-    import shutil
+FULL_N, FULL_O, FULL_NF = 132, 12, 22      # the fragment size of the FULL-SOLVE CPU baseline (a whole n = 220 solve takes minutes per CPU worker); --full-n / --full-nocc
+
+
+def full_solve_fragment(i, scale):
+    """inputs of one whole-fragment solve of the baseline sample: the synthetic family of the timed workload at n = 132, n_occ = 12
+    (what the reference's pool worker receives, molbe/be_parallel.py:40-60)"""
+    n = FULL_N
+    rng = np.random.default_rng(SEED0 + 1000 + i)
+    B = scale * (220.0 / n) ** 0.5 * rng.standard_normal((3 * n, n, n))      # same Coulomb strength per orbital as the n = 220 family
+    B = 0.5 * (B + B.transpose(0, 2, 1))
+    il = np.tril_indices(n)
+    Bp = np.ascontiguousarray(B[:, il[0], il[1]])
+    A = rng.standard_normal((n, n)); V = rng.standard_normal((n, n))
+    return dict(h=np.diag(2.0 * np.arange(n)) + 0.15 * (A + A.T), veff0=0.05 * (V + V.T), s4=Bp.T @ Bp)
+
+
+def cpu_pool_run(d, mode, nproc, ompnum, extra, timeout_s):
+    """one timed run of the CPU pool in a child process (never touches the GPU); returns the child's JSON or an error string"""
     import subprocess
+    env = dict(os.environ, OMP_NUM_THREADS=str(ompnum), OPENBLAS_NUM_THREADS=str(ompnum), MKL_NUM_THREADS=str(ompnum))
+    try:
+        p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--cpu-worker", d, "--cpu-mode", mode, "--cpu-nproc", str(nproc)] + extra,
+                           env=env, capture_output=True, text=True, timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        return f"pool exceeded {timeout_s} s"
+    if p.returncode != 0:
+        return f"pool failed: {p.stderr[-400:]}"
+    return json.loads(p.stdout.strip().splitlines()[-1])
+
+
+def cpu_baseline(lib, fr, h, dm0, o, opts, iters, ompnum, scale, budget_s=150):
+    """QuEmb's own CPU shape -- a pool of nproc worker processes with OMP_NUM_THREADS = ompnum each, one whole fragment per worker at a time
+    (molbe/be_parallel.py:484-513; defaults nproc = 1, ompnum = 4, mbe.py:850-851) -- with the oracle ('port') as the per-fragment solver.
+
+    (1) FULL SOLVES (cpu_baseline.value): every worker runs the reference worker's whole job on one fragment -- fragment RHF -> four-index
+        transformation -> RCCSD with DIIS to |dE| < 1e-10 -> 1-RDM -> 2-RDM and fragment energies (oracle/qemb_oracle/worker.py =
+        run_solver, be_parallel.py:40-307) -- at n = 132, n_occ = 12 (n = 220 takes minutes per worker: outside a default bench run), in two
+        settings: the reference's defaults (1 worker x 4 threads) and every usable core (cores // 4 workers x 4 threads).  The GPU solves the
+        SAME fragments through the product call (qemb_frag_solve) for the figure beside it, and the energies are compared.
+    (2) AT THE BENCHMARKED SIZE: `iters` plain amplitude updates per worker on fragment 0 of the timed workload (n = 220), MO integrals
+        exported from the device (the CPU number of rounds 1-2; also returns both energies for the full-size parity field)."""
+    import shutil
     import tempfile
+    from quemb_amd.fragsolver import DeviceFragment
+    cores = usable_cores()
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    info = dict(unit="CCSD iterations/s", kind="port", os_cpu_count=os.cpu_count(), ompnum=ompnum, value=None, cores=None)
+    # ---- (1) whole fragments
+    nproc_all = max(1, cores // ompnum)
+    d = tempfile.mkdtemp(prefix="qemb_bench_full_", dir=base)
+    try:
+        gpu = []
+        cen = list(range(FULL_NF // 4, FULL_NF // 2))
+        t_gpu = 0.0
+        for i in range(nproc_all):
+            f = full_solve_fragment(i, scale)
+            np.savez(os.path.join(d, f"frag{i}.npz"), o=FULL_O, nf=FULL_NF, cen=np.array(cen), **f)
+            dfr = DeviceFragment(FULL_N, FULL_NF, lib=lib)
+            dfr.set_eri_s4(f["s4"])
+            dfr.set_energy_data(f["h"], f["veff0"], None, 1.0, cen)
+            if i == 0:
+                dfr.solve(FULL_O, f["h"], None, opts=opts, eeval=True)           # warm-up (allocations, hipGraph instantiation)
+            lib.qemb_sync(); t0 = time.perf_counter()
+            out = dfr.solve(FULL_O, f["h"], None, opts=opts, eeval=True)
+            lib.qemb_sync(); t_gpu += time.perf_counter() - t0
+            gpu.append((out["n_iter"], out["e_corr_mo"], list(out["e_frag"])))
+            dfr.free()
+        log(f"cpu_baseline: {nproc_all} whole fragments (n={FULL_N}, n_occ={FULL_O}) on the GPU in {t_gpu:.2f} s; CPU pools next")
+        full = dict(n=FULL_N, n_occ=FULL_O, n_virt=FULL_N - FULL_O,
+                    work="fragment RHF -> 4-index transformation -> RCCSD (DIIS, |dE|<1e-10) -> 1-RDM -> 2-RDM + fragment energies, one whole fragment per worker "
+                         "(oracle/qemb_oracle/worker.py = run_solver, molbe/be_parallel.py:40-307)",
+                    gpu_same_fragments=dict(iterations_per_s=sum(g[0] for g in gpu) / t_gpu, fragments_per_s=len(gpu) / t_gpu, fragments=len(gpu),
+                                            how="the same fragments through qemb_frag_solve (eeval), one at a time on one stream"))
+        for key, nproc in (("reference_defaults_nproc1_ompnum4", 1), ("all_cores", nproc_all)):
+            r = cpu_pool_run(d, "full", nproc, ompnum, [], budget_s)
+            if isinstance(r, str):
+                full[key] = dict(value=None, note=r, nproc=nproc, ompnum=ompnum)
+                continue
+            err = max(abs(e - gpu[i][1]) for i, e in enumerate(r["e_corr"]))
+            erf = max(abs(a - b) for i, ef in enumerate(r["e_frag"]) for a, b in zip(ef, gpu[i][2]))
+            full[key] = dict(iterations_per_s=r["iterations"] / r["pool_wall_s"], fragments_per_s=nproc / r["pool_wall_s"], nproc=nproc, ompnum=ompnum,
+                             threads=nproc * ompnum, pool_wall_s=r["pool_wall_s"], iterations=r["iterations"], slowest_worker_s=r["slowest_worker_s"],
+                             max_abs_e_corr_diff_vs_gpu_Eh=err, max_abs_e_frag_diff_vs_gpu_Eh=erf)
+        info["full_solve"] = full
+        best = full.get("all_cores", {})
+        if best.get("iterations_per_s"):
+            info.update(value=best["iterations_per_s"], cores=best["threads"], fragments_per_s=best["fragments_per_s"],
+                        sample=f"{best['nproc']} whole synthetic fragments of the timed family at n={FULL_N}, n_occ={FULL_O} (a whole n=220 solve takes minutes per CPU "
+                               f"worker), one per worker process, {ompnum} BLAS threads each: fragment RHF + 4-index transformation + RCCSD with DIIS to |dE|<1e-10 + "
+                               "RDMs + fragment energies (oracle/qemb_oracle/worker.py); value = all CCSD iterations / pool wall time. "
+                               "full_solve.reference_defaults_nproc1_ompnum4 = the reference's default pool; full_solve.gpu_same_fragments = this GPU on the same fragments; "
+                               "n220_amplitude_updates = the CPU at the benchmarked size")
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    # ---- (2) the benchmarked size: plain amplitude updates on the device-exported MO integrals of fragment 0
     n = fr.n
     v = n - o
     fr.prepare_ccsd(o, h, dm0, opts=opts)
     e_dev, _ = fr.ccsd_iterate(iters)          # plain Jacobi updates from the MP2 guess (no DIIS outside CcsdSolver::kernel)
     shapes = dict(oooo=(o, o, o, o), ovoo=(o, v, o, o), ovov=(o, v, o, v), ovvv=(o, v, v, v), Vl=(v, v, v, v),
                   W1base=(o, v, o, v), W2base=(o, v, o, v), eo=(o,), ev=(v,))
-    cores = usable_cores()
-    nproc = max(1, cores // ompnum)
-    base = "/dev/shm" if os.path.isdir("/dev/shm") else None
     d = tempfile.mkdtemp(prefix="qemb_bench_", dir=base)
-    info = dict(unit="CCSD iterations/s", cores=cores, os_cpu_count=os.cpu_count(), nproc=nproc, ompnum=ompnum, kind="port")
+    e_cpu = None
     try:
         for name, shp in shapes.items():
             np.save(os.path.join(d, name + ".npy"), fr.ccsd_export(name, shp))
-        log(f"cpu_baseline: integrals exported to {d}; pool of {nproc} worker(s) x {ompnum} thread(s), {iters} amplitude update(s) each")
-        env = dict(os.environ, OMP_NUM_THREADS=str(ompnum), OPENBLAS_NUM_THREADS=str(ompnum), MKL_NUM_THREADS=str(ompnum))
-        p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--cpu-worker", d, "--cpu-iters", str(iters), "--nocc", str(o),
-                            "--cpu-nproc", str(nproc)], env=env, capture_output=True, text=True, timeout=timeout_s)
-        if p.returncode != 0:
-            info.update(value=None, sample=f"worker failed: {p.stderr[-400:]}")
-            return info, e_dev, None
-        r = json.loads(p.stdout.strip().splitlines()[-1])
-        info.update(value=r["iterations_per_s"],
-                    sample=f"fragment 0 of the timed workload (n_occ={o}, n_virt={v}), MO integrals exported from the device and shared; "
-                           f"{nproc} worker processes x {iters} full RCCSD amplitude updates each from the MP2 guess "
-                           f"(oracle/qemb_oracle/ccsd_lean.py, NumPy/BLAS, OMP_NUM_THREADS={ompnum}); value = all updates / slowest worker's time",
-                    s_per_iteration_per_worker=r["s_per_iteration_per_worker"], pool_wall_s=r["pool_wall_s"],
-                    e_corr_after_sample=r["e_corr"])
-        # second figure: ONE process with every core as BLAS threads (round 1's baseline)
-        env1 = dict(os.environ, OMP_NUM_THREADS=str(cores), OPENBLAS_NUM_THREADS=str(cores), MKL_NUM_THREADS=str(cores))
-        p1 = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--cpu-worker", d, "--cpu-iters", str(max(1, iters - 1)), "--nocc", str(o),
-                             "--cpu-nproc", "1"], env=env1, capture_output=True, text=True, timeout=timeout_s)
-        if p1.returncode == 0:
-            r1 = json.loads(p1.stdout.strip().splitlines()[-1])
-            info["single_process_all_threads"] = dict(value=r1["iterations_per_s"], threads=cores, s_per_iteration=r1["s_per_iteration_per_worker"])
-        return info, e_dev, r["e_corr"]
-    except subprocess.TimeoutExpired:
-        info.update(value=None, sample=f"worker exceeded {timeout_s} s")
-        return info, e_dev, None
+        log(f"cpu_baseline: n={n} integrals exported to {d}; pool of {nproc_all} worker(s) x {ompnum} thread(s), {iters} amplitude update(s) each")
+        r = cpu_pool_run(d, "updates", nproc_all, ompnum, ["--cpu-iters", str(iters), "--nocc", str(o)], budget_s)
+        if isinstance(r, str):
+            info["n220_amplitude_updates"] = dict(value=None, note=r)
+        else:
+            e_cpu = r["e_corr"]
+            info["n220_amplitude_updates"] = dict(
+                value=r["iterations_per_s"], unit="plain RCCSD amplitude updates/s", nproc=nproc_all, ompnum=ompnum, threads=nproc_all * ompnum,
+                s_per_iteration_per_worker=r["s_per_iteration_per_worker"], pool_wall_s=r["pool_wall_s"], e_corr_after_sample=e_cpu,
+                sample=f"fragment 0 of the timed workload (n_occ={o}, n_virt={v}), MO integrals exported from the device and shared; {nproc_all} worker processes x "
+                       f"{iters} full RCCSD amplitude updates each from the MP2 guess (oracle/qemb_oracle/ccsd_lean.py, no RHF / transformation / DIIS / RDMs)")
+            if info["value"] is None:      # the full-solve pools did not finish: fall back to the same-size figure, labelled as such
+                info.update(value=r["iterations_per_s"], cores=nproc_all * ompnum, sample=info["n220_amplitude_updates"]["sample"])
     finally:
         shutil.rmtree(d, ignore_errors=True)
+    return info, e_dev, e_cpu
+
+
+def _cpu_full_task(args):
+    """one worker of the full-solve pool: the reference worker's whole job on one fragment"""
+    d, i = args
+    sys.path.insert(0, str(ROOT / "oracle"))
+    from qemb_oracle import worker
+    z = np.load(os.path.join(d, f"frag{i}.npz"))
+    t0 = time.perf_counter()
+    out = worker.run_solver(z["h"], None, z["s4"], int(z["o"]), int(z["nf"]), (1.0, [int(c) for c in z["cen"]]), z["h"], z["veff0"], eeval=True)
+    return time.perf_counter() - t0, int(out["n_iter"]), float(out["e_corr"]), [float(x) for x in out["e_f"]], bool(out["converged"])
 
 
 def _cpu_pool_task(args):
@@ -275,30 +360,33 @@ def _cpu_pool_task(args):
     oovv = np.ascontiguousarray(W2.transpose(2, 0, 1, 3))     # oovv[k,i,a,c] = W2base[i,a,k,c]
     er = ccsd_lean.LeanEris.from_blocks(o, np.concatenate([eo, ev]), np.array(ld("oooo")), np.array(ld("ovoo")), np.array(ld("ovov")),
                                         oovv, ovvo, ld("ovvv"), ld("Vl"))
-    eia = eo[:, None] - ev[None, :]
-    t1 = np.zeros((o, len(ev))); t2 = er.ovov.transpose(0, 2, 1, 3) / (eia[:, None, :, None] + eia[None, :, None, :])
+    t1, t2 = ccsd_lean.init_amps(er)
     t0 = time.perf_counter()
     for _ in range(iters):
         t1, t2 = ccsd_lean.update_amps(t1, t2, er)
     dt = time.perf_counter() - t0
-    tau = t2 + np.einsum("ia,jb->ijab", t1, t1)
-    e = float(np.sum((2 * er.ovov.transpose(0, 2, 1, 3) - er.ovov.transpose(0, 2, 3, 1)) * tau))
-    return dt, e
+    return dt, ccsd_lean.energy(t1, t2, er)
 
 
-def cpu_worker(d, o, iters, nproc):
+def cpu_worker(d, mode, o, iters, nproc):
     """child process of cpu_baseline (never touches the GPU): runs the worker pool and prints one JSON line"""
     import multiprocessing as mp
+    task, jobs = (_cpu_full_task, [(d, i) for i in range(nproc)]) if mode == "full" else (_cpu_pool_task, [(d, o, iters)] * nproc)
     t0 = time.perf_counter()
     if nproc <= 1:
-        res = [_cpu_pool_task((d, o, iters))]
+        res = [task(jobs[0])]
     else:
         with mp.get_context("spawn").Pool(nproc) as pool:
-            res = pool.map(_cpu_pool_task, [(d, o, iters)] * nproc, chunksize=1)
+            res = pool.map(task, jobs, chunksize=1)
     wall = time.perf_counter() - t0
     slowest = max(r[0] for r in res)
-    print(json.dumps(dict(iterations_per_s=len(res) * iters / slowest, s_per_iteration_per_worker=slowest / iters, pool_wall_s=wall,
-                          e_corr=res[0][1])), flush=True)
+    if mode == "full":
+        assert all(r[4] for r in res), "a CPU fragment solve did not converge"
+        print(json.dumps(dict(pool_wall_s=wall, slowest_worker_s=slowest, iterations=sum(r[1] for r in res), e_corr=[r[2] for r in res],
+                              e_frag=[r[3] for r in res])), flush=True)
+    else:
+        print(json.dumps(dict(iterations_per_s=len(res) * iters / slowest, s_per_iteration_per_worker=slowest / iters, pool_wall_s=wall,
+                              e_corr=res[0][1])), flush=True)
 
 
 # ------------------------------------------------------------------------------------------------------------ probes
@@ -362,9 +450,12 @@ def roofline_pass(lib, fr, h, dm0, o, opts, iters):
 
 # ------------------------------------------------------------------------------------------------------------ main
 def main():
+    global FULL_N, FULL_O, FULL_NF
     args = parse()
+    FULL_N, FULL_O = args.full_n, args.full_nocc
+    FULL_NF = min(FULL_NF, FULL_N // 2)
     if args.cpu_worker:
-        return cpu_worker(args.cpu_worker, args.nocc, args.cpu_iters, args.cpu_nproc)
+        return cpu_worker(args.cpu_worker, args.cpu_mode, args.nocc, args.cpu_iters, args.cpu_nproc)
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -546,7 +637,7 @@ def main():
             except Exception as e:  # noqa: BLE001
                 res["parity_max_abs_err_Eh"] = f"probe failed: {e}"
             if not args.no_cpu_baseline:
-                info, e_dev, e_cpu = cpu_baseline(fr0.dev, h0, dm00, o, opts, args.cpu_iters, args.cpu_ompnum)
+                info, e_dev, e_cpu = cpu_baseline(lib, fr0.dev, h0, dm00, o, opts, args.cpu_iters, args.cpu_ompnum, args.scale)
                 res["cpu_baseline"] = info
                 # full-size parity: the device and the oracle run the SAME args.cpu_iters plain amplitude updates on the same n = 220 fragment
                 res["parity_n220_abs_err_Eh"] = None if e_cpu is None else abs(e_dev - e_cpu)

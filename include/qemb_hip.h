@@ -61,6 +61,9 @@ int qemb_ctx_bind(int k);
  * -> get_frag_energy (helper.py:220-339).  The 2-RDM is never materialised: its contraction with the
  * fragment ERIs is evaluated from t1/t2 directly (identical result).                      */
 typedef struct {
+  uint32_t struct_size;      /* sizeof(qemb_solver_opts) of the header the caller was built against; qemb_default_opts sets it and
+                              * every entry point that takes options rejects another value (QEMB_ERR_ARG): a binding whose field
+                              * list has drifted from this header fails loudly instead of reading flags out of padding           */
   double cc_conv_tol;        /* |dE_corr|          default 1e-10 (PySCF 1e-7)                      */
   double cc_conv_tol_normt;  /* |dt|               default 1e-8  (PySCF 1e-5)                      */
   int cc_max_cycle;          /*                    default 100   (PySCF 50)                        */
@@ -80,7 +83,7 @@ typedef struct {
                               * has (helper.py:128-149, solver.py:905-912): every output is filled from the unconverged state and the
                               * call returns QEMB_WARN_NOCONV (> 0); qemb_last_error() says which solve it was.            */
 } qemb_solver_opts;
-void qemb_default_opts(qemb_solver_opts* opts);
+void qemb_default_opts(qemb_solver_opts* opts);   /* always start from this; then change single fields */
 
 typedef void* qemb_frag_t;   /* opaque: one fragment with its ERIs resident in HBM                   */
 int qemb_frag_create(int n, int n_f, qemb_frag_t* out);

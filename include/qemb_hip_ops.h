@@ -54,6 +54,9 @@ int qemb_op_gemm_probe(int64_t M, int64_t N, int64_t K, const double* A, int64_t
  * main loop, wave entry -> exit, workgroups] (sums over the k-tiles of a wave) */
 int qemb_op_gemm_stamps(int64_t M, int64_t N, int64_t K, const double* A, int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc, int cfg,
                         int ksplit, double* out7);
+/* the tile configuration and split-K factor the CCSD driver picks for a product of `rows` packed pair rows by `cols` columns (pp-ladder,
+ * tau-side dressing): introspection for tests and tools, no device call */
+int qemb_pair_gemm_choice(int64_t rows, int64_t cols, int* cfg, int* ksplit);
 int qemb_set_gemm_ksplit(int ksplit);      /* explicit split-K factor for qemb_op_gemm (0 = automatic) */
 /* out[sum ik*so[k]] = alpha*in[sum ik*si[k]] + beta*out[...], 0<=ik<dim[k], 4 dims                  */
 int qemb_op_copy4(const int64_t dim[4], const double* in, const int64_t si[4], double* out,

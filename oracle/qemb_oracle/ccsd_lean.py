@@ -100,3 +100,38 @@ def update_amps(t1, t2, er):
     t2n += U + U.transpose(1, 0, 3, 2)
     eia = eo[:, None] - ev[None, :]
     return t1n / eia, t2n / (eia[:, None, :, None] + eia[None, :, None, :])
+
+
+def init_amps(er):
+    """MP2 amplitudes (pyscf cc/ccsd.py init_amps with a diagonal Fock matrix): t1 = 0, t2 = ovov / D."""
+    o = er.nocc
+    eo, ev = er.mo_energy[:o], er.mo_energy[o:]
+    eia = eo[:, None] - ev[None, :]
+    return np.zeros((o, len(ev))), er.ovov.transpose(0, 2, 1, 3) / (eia[:, None, :, None] + eia[None, :, None, :])
+
+
+def energy(t1, t2, er):
+    tau = t2 + np.einsum("ia,jb->ijab", t1, t1)
+    ov = er.ovov.transpose(0, 2, 1, 3)
+    return float(2.0 * np.sum(ov * tau) - np.sum(ov.transpose(0, 1, 3, 2) * tau))
+
+
+def kernel(er, conv_tol=1e-10, conv_tol_normt=1e-8, max_cycle=100, diis_space=6):
+    """`ccsd.kernel` (pyscf cc/ccsd.py control flow: MP2 guess, DIIS on [t1; t2] from the first cycle, |dE| and |dt| tests) on the
+    lean update.  Returns (converged, e_corr, t1, t2, n_iter)."""
+    from .ccsd import DIIS
+    t1, t2 = init_amps(er)
+    o, v = t1.shape
+    ecc = energy(t1, t2, er)
+    adiis = DIIS(diis_space)
+    conv, it = False, 0
+    for it in range(1, max_cycle + 1):
+        t1n, t2n = update_amps(t1, t2, er)
+        normt = np.sqrt(np.linalg.norm(t1n - t1) ** 2 + np.linalg.norm(t2n - t2) ** 2)
+        vec = adiis.update(np.concatenate([t1n.ravel(), t2n.ravel()]))
+        t1 = vec[: o * v].reshape(o, v); t2 = vec[o * v:].reshape(o, o, v, v)
+        eold, ecc = ecc, energy(t1, t2, er)
+        if abs(ecc - eold) < conv_tol and normt < conv_tol_normt:
+            conv = True
+            break
+    return conv, ecc, t1, t2, it

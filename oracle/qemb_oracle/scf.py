@@ -23,13 +23,16 @@ def get_veff(eri, dm, S, TA, hf_veff):
     return Veff0 - Veff_, Veff0
 
 
-def rhf(h1, eri, nocc, dm0=None, max_cycle=50, conv_tol=1e-12, conv_tol_grad=1e-8, diis_space=8):
+def rhf(h1, eri, nocc, dm0=None, max_cycle=50, conv_tol=1e-12, conv_tol_grad=1e-8, diis_space=8, jk=None):
     """Restates get_scfObj (molbe/helper.py:73-151): closed-shell RHF in an orthonormal basis (S = I) with
     hcore = h1, 8-fold ERIs, nelec = 2*nocc, optional dm0, <= 50 cycles, commutator DIIS.  PySCF's
     default conv_tol is 1e-9; the oracle converges tighter so that it is a fixed point, not a trajectory.
+    `jk(dm) -> (J, K)` replaces the dense contraction for fragments whose n^4 tensor should not be formed (eri may then be None).
     Returns dict(mo_coeff, mo_energy, mo_occ, e_tot, converged, dm)."""
     n = h1.shape[0]
-    e1 = restore_s1(eri, n)
+    if jk is None:
+        e1 = restore_s1(eri, n)
+        jk = lambda dm: get_jk(e1, dm)
     if dm0 is None:
         w, c = np.linalg.eigh(h1)
         dm = 2.0 * c[:, :nocc] @ c[:, :nocc].T
@@ -39,7 +42,7 @@ def rhf(h1, eri, nocc, dm0=None, max_cycle=50, conv_tol=1e-12, conv_tol_grad=1e-
     e_old = None
     conv = False
     for cyc in range(max_cycle):
-        J, K = get_jk(e1, dm)
+        J, K = jk(dm)
         F = h1 + J - 0.5 * K
         e_tot = 0.5 * np.einsum("ij,ji->", h1 + F, dm)
         err = F @ dm - dm @ F
@@ -67,7 +70,7 @@ def rhf(h1, eri, nocc, dm0=None, max_cycle=50, conv_tol=1e-12, conv_tol_grad=1e-
         w, c = np.linalg.eigh(Fd)
         dm = 2.0 * c[:, :nocc] @ c[:, :nocc].T
     # canonical orbitals of the converged Fock matrix
-    J, K = get_jk(e1, dm)
+    J, K = jk(dm)
     F = h1 + J - 0.5 * K
     w, c = np.linalg.eigh(F)
     occ = np.zeros(n); occ[:nocc] = 2.0

@@ -27,7 +27,7 @@ class QembError(RuntimeError):
 
 class SolverOpts(C.Structure):
     """qemb_solver_opts (include/qemb_hip.h)."""
-    _fields_ = [("cc_conv_tol", C.c_double), ("cc_conv_tol_normt", C.c_double), ("cc_max_cycle", C.c_int),
+    _fields_ = [("struct_size", C.c_uint32), ("cc_conv_tol", C.c_double), ("cc_conv_tol_normt", C.c_double), ("cc_max_cycle", C.c_int),
                 ("cc_diis_space", C.c_int), ("scf_conv_tol", C.c_double), ("scf_conv_tol_grad", C.c_double),
                 ("scf_max_cycle", C.c_int), ("scf_diis_space", C.c_int), ("warm_start", C.c_int), ("verbose", C.c_int),
                 ("relax_density", C.c_int), ("lambda_conv_tol", C.c_double), ("lambda_max_cycle", C.c_int),
@@ -68,6 +68,7 @@ def _declare(lib):
     f("qemb_set_gemm_config", I, I)
     f("qemb_set_gemm_splitk", I, I)
     f("qemb_set_gemm_ksplit", I, I)
+    f("qemb_pair_gemm_choice", I, L, L, C.POINTER(I), C.POINTER(I))
     f("qemb_op_ladder_pack_vvvv", I, L, L, P, P, L, P, L)
     f("qemb_op_ladder_pack_tau", I, L, L, P, P, L, P, L)
     f("qemb_op_ladder_scatter_pm", I, L, L, P, L, P, L, P)

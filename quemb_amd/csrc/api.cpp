@@ -4,6 +4,7 @@
 #include <cstring>
 #include "../../include/qemb_hip_ops.h"
 #include "dev_ops.h"
+#include "ccsd.h"
 #include "fragment.h"
 #include "ao2mo.h"
 
@@ -67,6 +68,13 @@ int qemb_mfma_f64_peak(int iters, int blocks_per_cu, double* tflops) { return de
 #else
 int qemb_mfma_f64_peak(int, int, double*) { set_error("not available in the hostcheck build"); return QEMB_ERR_DEVICE; }
 #endif
+int qemb_pair_gemm_choice(int64_t rows, int64_t cols, int* cfg, int* ksplit) {
+  int c = -1, k = 0;
+  pick_pair_gemm(rows, cols, c, k);
+  if (cfg) *cfg = c;
+  if (ksplit) *ksplit = k;
+  return QEMB_OK;
+}
 int qemb_set_gemm_splitk(int enabled) { dev_gemm_set_auto_splitk(enabled); return QEMB_OK; }
 int qemb_op_copy4(const int64_t dim[4], const double* in, const int64_t si[4], double* out, const int64_t so[4],
                   double alpha, double beta) {
@@ -147,6 +155,8 @@ int qemb_op_tri_inverse_lower(int64_t n, const double* L, double* Linv) { return
 // ---------------------------------------------------------------- fragment solver ----------------
 void qemb_default_opts(qemb_solver_opts* o) {
   CcsdOptions c; ScfOptions s;
+  memset(o, 0, sizeof *o);
+  o->struct_size = (uint32_t)sizeof(qemb_solver_opts);
   o->cc_conv_tol = c.conv_tol; o->cc_conv_tol_normt = c.conv_tol_normt; o->cc_max_cycle = c.max_cycle; o->cc_diis_space = c.diis_space;
   o->scf_conv_tol = s.conv_tol; o->scf_conv_tol_grad = s.conv_tol_grad; o->scf_max_cycle = s.max_cycle; o->scf_diis_space = s.diis_space;
   o->warm_start = 0; o->verbose = 0;
@@ -168,6 +178,16 @@ static FragmentOptions to_opts(const qemb_solver_opts* o) {
   }
   return f;
 }
+// NULL options = defaults; anything else must carry the size of THIS header's struct (set by qemb_default_opts)
+#define CHECK_OPTS(o)                                                                                                     \
+  do {                                                                                                                    \
+    if ((o) && (o)->struct_size != (uint32_t)sizeof(qemb_solver_opts)) {                                                  \
+      set_error("qemb_solver_opts.struct_size is " + std::to_string((o)->struct_size) + ", this library expects " +       \
+                std::to_string(sizeof(qemb_solver_opts)) + ": initialise the struct with qemb_default_opts() (binding built " \
+                "against another qemb_hip.h?)");                                                                          \
+      return QEMB_ERR_ARG;                                                                                                \
+    }                                                                                                                     \
+  } while (0)
 #define FRAG(f) (reinterpret_cast<Fragment*>(f))
 #define CHECK_FRAG(f) do { if (!(f)) { set_error("null fragment handle"); return QEMB_ERR_ARG; } } while (0)
 
@@ -196,7 +216,7 @@ int qemb_frag_jk(qemb_frag_t f, const double* P, double* J, double* K) { CHECK_F
 int qemb_frag_solve(qemb_frag_t f, int nsocc, const double* h, const double* dm0, const qemb_solver_opts* opts, int eeval,
                     double* mo_coeff, double* mo_energy, double* rdm1_emb, double* rdm1_mo, double* t1, double* t2,
                     double* e_frag, double* e_corr_mo, double* e_scf, double* ebe_hf, int* n_iter, int* scf_cycles) {
-  CHECK_FRAG(f);
+  CHECK_FRAG(f); CHECK_OPTS(opts);
   if (!h) { set_error("qemb_frag_solve: h is NULL"); return QEMB_ERR_ARG; }
   FragmentResult r;
   int rc = FRAG(f)->solve(nsocc, h, dm0, to_opts(opts), eeval, &r, mo_coeff, mo_energy, rdm1_emb, rdm1_mo, t1, t2);
@@ -213,7 +233,7 @@ int qemb_frag_solve(qemb_frag_t f, int nsocc, const double* h, const double* dm0
 int qemb_frag_lambda_iters(qemb_frag_t f, int* n_iter) { CHECK_FRAG(f); if (n_iter) *n_iter = FRAG(f)->last_lambda_iters; return QEMB_OK; }
 int qemb_frag_scf(qemb_frag_t f, int nsocc, const double* h, const double* dm0, const qemb_solver_opts* opts, double* mo_coeff,
                   double* mo_energy, double* J, double* K, double* e_scf, int* converged, int* cycles) {
-  CHECK_FRAG(f);
+  CHECK_FRAG(f); CHECK_OPTS(opts);
   if (!h) { set_error("qemb_frag_scf: h is NULL"); return QEMB_ERR_ARG; }
   ScfResult r;
   int rc = FRAG(f)->scf_only(nsocc, h, dm0, to_opts(opts).scf, mo_coeff, mo_energy, J, K, &r);
@@ -225,7 +245,7 @@ int qemb_frag_scf(qemb_frag_t f, int nsocc, const double* h, const double* dm0, 
 }
 int qemb_frag_cphf(qemb_frag_t f, int nsocc, const double* h, const double* dm0, const qemb_solver_opts* opts, const double* vpots,
                    int npot, double* dPs) {
-  CHECK_FRAG(f);
+  CHECK_FRAG(f); CHECK_OPTS(opts);
   if (!h || !vpots || !dPs) { set_error("qemb_frag_cphf: null argument"); return QEMB_ERR_ARG; }
   return FRAG(f)->cphf_response(nsocc, h, dm0, to_opts(opts).scf, vpots, npot, dPs);
 }
@@ -234,6 +254,7 @@ int qemb_ccsd_solve(int n, int nsocc, int n_f, const double* h, const double* er
                     int ncenter, double* mo_coeff, double* mo_energy, double* t1, double* t2, double* rdm1_emb, double* e_frag,
                     double* e_corr_mo, int* n_iter) {
   if (n <= 0 || n_f < 0 || n_f > n || !eri_s4) { set_error("qemb_ccsd_solve: bad arguments"); return QEMB_ERR_ARG; }
+  CHECK_OPTS(opts);
   Fragment fr(n, n_f);
   int rc = fr.set_eri_s4_host(eri_s4);
   if (rc) return rc;
@@ -248,7 +269,7 @@ int qemb_ccsd_solve(int n, int nsocc, int n_f, const double* h, const double* er
   return rc;
 }
 int qemb_frag_prepare_ccsd(qemb_frag_t f, int nsocc, const double* h, const double* dm0, const qemb_solver_opts* opts) {
-  CHECK_FRAG(f); return FRAG(f)->prepare_ccsd(nsocc, h, dm0, to_opts(opts));
+  CHECK_FRAG(f); CHECK_OPTS(opts); return FRAG(f)->prepare_ccsd(nsocc, h, dm0, to_opts(opts));
 }
 int qemb_frag_ccsd_iterate(qemb_frag_t f, int niter, double* e, double* nt) { CHECK_FRAG(f); return FRAG(f)->ccsd_iterate(niter, e, nt); }
 int qemb_frag_ccsd_export(qemb_frag_t f, const char* name, double* host, int64_t nelem) { CHECK_FRAG(f); return FRAG(f)->ccsd_export(name, host, nelem); }

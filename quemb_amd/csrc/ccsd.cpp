@@ -207,17 +207,23 @@ int CcsdSolver::set_amps(const double* t1d, const double* t2d) {
 }
 
 // tile configuration and K split for the "few packed pair rows x many columns" GEMMs (ladder, tau-side dressing)
-static void pick_pair_gemm(int64_t rows, int64_t cols, int& cfg, int& ks) {
+void pick_pair_gemm(int64_t rows, int64_t cols, int& cfg, int& ks) {
   cfg = -1; ks = 0;
   if (cols < 2048) return;
-  // the row-tile height with the least padding among the configurations that exist (ties: the taller tile): n_occ = 20 gets the
-  // 224-row tile for its 210 symmetric and the 192-row tile for its 190 antisymmetric pairs; n_occ = 30 three 160-row tiles for 465; ...
-  // (The dispatcher's own choice for "few tiles" would be the 64 x 64 tile, a quarter of the rate on these long-K products.)
-  static const struct { int rows, cfg, cols; } cand[] = {{224, 13, 128}, {192, 15, 128}, {160, 35, 128}, {128, 4, 256}, {112, 11, 128}, {64, 12, 128}};
-  int64_t best_pad = -1, tiles = 0;
+  // the row-tile height with the least ESTIMATED TIME among the configurations that exist: padded rows weighted by what a row costs on
+  // that tile relative to the 7 x 2 / 6 x 2 wave tiles (the single-column wave tiles 11 / 12 read 8 / 5 LDS fragments per 7 / 4 MFMAs and
+  // run at ~0.8 / ~0.6 of their rate on these long-K products; profiles/r01_gemm_microbench_ladder_tiles.jsonl).  n_occ = 20 gets the
+  // 224-row tile for its 210 symmetric and the 192-row tile for its 190 antisymmetric pairs; n_occ = 30 three 160-row tiles for 465;
+  // n_occ = 40 (820 rows) four 224-row tiles, not thirteen 64-row ones.  (The dispatcher's own choice for "few tiles" would be the
+  // 64 x 64 tile, a quarter of the rate.)
+  static const struct { int rows, cfg, cols; double cost; } cand[] = {{224, 13, 128, 1.0}, {192, 15, 128, 1.0}, {160, 35, 128, 1.03}, {128, 4, 256, 1.0},
+                                                                      {112, 11, 128, 1.25}, {64, 12, 128, 1.6}};
+  double best_cost = -1.0;
+  int64_t tiles = 0;
   for (const auto& c : cand) {
-    const int64_t mt = (rows + c.rows - 1) / c.rows, pad = mt * c.rows;
-    if (best_pad < 0 || pad < best_pad) { best_pad = pad; cfg = c.cfg; tiles = mt * ((cols + c.cols - 1) / c.cols); }
+    const int64_t mt = (rows + c.rows - 1) / c.rows;
+    const double cost = (double)(mt * c.rows) * c.cost;
+    if (best_cost < 0 || cost < best_cost - 1e-9) { best_cost = cost; cfg = c.cfg; tiles = mt * ((cols + c.cols - 1) / c.cols); }
   }
   double best = 0.0;
   for (int c = 1; c <= 8; ++c) {

@@ -97,4 +97,6 @@ class CcsdSolver {
   double ecc_ = 0.0;
 };
 
+// tile configuration and split-K factor CcsdSolver picks for a "few packed pair rows x many columns" product (introspection for tests / tools)
+void pick_pair_gemm(int64_t rows, int64_t cols, int& cfg, int& ks);
 }  // namespace qemb

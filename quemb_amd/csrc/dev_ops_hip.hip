@@ -1570,14 +1570,18 @@ int dev_jk_from_packed(int64_t n, const double* S4, const double* D, const doubl
   double* P1 = g_ws; double* P2 = g_ws + np * n;
   const size_t lds = (size_t)(10 * n + 8) * sizeof(double);
   const int nk = (int)((n + 63) / 64);
+  hipError_t attr_err = hipSuccess;
   auto launch = [&](auto kern) {
-    hipLaunchKernelGGL(kern, dim3((unsigned)np), dim3(256), lds, g_stream, (int)n, S4, D, Dp, Jp, P1, P2);
+    // n > 818 needs more than the 64 KB of dynamic LDS a kernel gets by default (82 KB at n = 1024; a CU has 160 KB)
+    if (lds > 64 * 1024) attr_err = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (attr_err == hipSuccess) hipLaunchKernelGGL(kern, dim3((unsigned)np), dim3(256), lds, g_stream, (int)n, S4, D, Dp, Jp, P1, P2);
   };
   if (nk <= 1) launch(jk_packed_stage1<1>);
   else if (nk <= 2) launch(jk_packed_stage1<2>);
   else if (nk <= 4) launch(jk_packed_stage1<4>);
   else if (nk <= 8) launch(jk_packed_stage1<8>);
   else launch(jk_packed_stage1<16>);
+  HIP_TRY(attr_err);
   if (K) hipLaunchKernelGGL(k_pairs_stage2, dim3((unsigned)n), dim3(256), 0, g_stream, (long long)n, (const double*)P1, (const double*)P2, K);
   HIP_TRY(hipGetLastError());
   return QEMB_OK;

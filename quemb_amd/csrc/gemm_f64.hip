@@ -786,6 +786,12 @@ static int dev_gemm_dispatch(const GemmDesc& d) {
   if (vec2 && d.N > 192 && d.N <= 224 && d.M >= 128 * 1024) cfg = 34;
   if (d.cfg >= 0) cfg = d.cfg;
   if (t_gemm_force_cfg >= 0) cfg = t_gemm_force_cfg;
+  // 3xx (s_memtime stamps) and 4xx-6xx (ablation: WRONG products by construction) exist for tools/ only: unreachable unless the process
+  // says it is a measurement run
+  if (cfg >= 300) {
+    static const bool diag = std::getenv("QEMB_GEMM_DIAGNOSTICS") != nullptr;
+    if (!diag) { set_error("dev_gemm: tile configs >= 300 are diagnostic instantiations (set QEMB_GEMM_DIAGNOSTICS=1 in a measurement run)"); return QEMB_ERR_ARG; }
+  }
   // The large tiles run the MODE 1 main loop (explicit one-k-step-ahead LDS fragment reads, LDS stores spread behind the MFMA rows) when
   // the operands allow 16-byte loads; their scalar-load variants, the single-column wave tiles and the small / skinny tiles, which are
   // latency or HBM bound and want the two-tiles-deep register prefetch, keep the classic loop.
@@ -806,7 +812,9 @@ static int dev_gemm_dispatch(const GemmDesc& d) {
     case 21: return launch_layout<1, 4, 2, 2, 16>(d, s, vec2);   //  32 x 128, 4 waves: the same with M = n_occ
     case 23: return launch_layout<7, 2, 2, 4, 16, 1, 1>(d, s, vec2);   // = 13 under its own kernel symbol (pp-ladder, + pairs)
     case 25: return launch_layout<6, 2, 2, 4, 16, 1, 1>(d, s, vec2);   // = 15 under its own kernel symbol (pp-ladder, - pairs)
-    // the classic main loop of the same tiles, kept addressable for A/B measurements (tools/gemm_modes.py)
+    // the classic (MODE 0) main loop of EVERY tile that runs MODE 1 in production, cfg + 200: kept addressable for A/B measurements
+    // (tools/gemm_modes.py) and for the bit-for-bit comparison tests/test_gpu_ops.py::test_gemm_mode1_equals_classic_loop runs, so that a
+    // toolchain change that breaks the hand-counted LDS waits of MODE 1 is caught (same summation order: results must be identical)
     // diagnostic instantiations (TAG 2): per-wave s_memtime stamps around the per-tile barrier, read by qemb_op_gemm_stamps
     case 313: return launch_layout<7, 2, 2, 4, 16, 2, 1>(d, s, vec2);
     case 315: return launch_layout<6, 2, 2, 4, 16, 2, 1>(d, s, vec2);
@@ -820,9 +828,13 @@ static int dev_gemm_dispatch(const GemmDesc& d) {
     case 504: return launch_layout<4, 4, 2, 4, 16, 4, 1>(d, s, vec2);
     case 604: return launch_layout<4, 4, 2, 4, 16, 5, 1>(d, s, vec2);
     case 200: return launch_layout<4, 4, 2, 2, 16>(d, s, vec2);
+    case 201: return launch_layout<2, 2, 2, 2, 16>(d, s, vec2);
     case 204: return launch_layout<4, 4, 2, 4, 16>(d, s, vec2);
     case 213: return launch_layout<7, 2, 2, 4, 16>(d, s, vec2);
     case 215: return launch_layout<6, 2, 2, 4, 16>(d, s, vec2);
+    case 233: return launch_layout<7, 2, 1, 4, 16>(d, s, vec2);
+    case 234: return launch_layout<2, 7, 4, 2, 16>(d, s, vec2);
+    case 235: return launch_layout<5, 2, 2, 4, 16>(d, s, vec2);
     default: set_error("dev_gemm: unknown tile config"); return QEMB_ERR_ARG;
   }
 }

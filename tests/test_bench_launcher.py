@@ -121,3 +121,25 @@ def test_rendezvous_without_a_launcher_file():
         assert bmin == bmax == float(tot)
         assert buf == [float(tot), 2.0 * world]
         assert "1 of 3 rank(s) failed" in fail and (("this rank succeeded" in fail) == (r != 1))
+
+
+@pytest.mark.timeout(300)
+def test_cpu_baseline_runs_whole_fragments_in_both_pool_settings():
+    """bench.py's cpu_baseline on tiny sizes (mock device): full solves in the reference's default pool and in the all-cores pool, the
+    GPU-side figure on the same fragments, energies agreeing, and the amplitude-update sample at the timed size beside them."""
+    args = [a for a in SMALL if a != "--no-cpu-baseline"]
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "1", *args, "--full-n", "16", "--full-nocc", "3", "--lib", _mock()],
+                       env=_env(), capture_output=True, text=True, timeout=280)
+    assert p.returncode == 0, p.stderr[-2000:]
+    r = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    cb = r["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["unit"] == "CCSD iterations/s" and cb["value"] > 0 and cb["cores"] >= 4
+    fs = cb["full_solve"]
+    assert fs["reference_defaults_nproc1_ompnum4"]["nproc"] == 1 and fs["reference_defaults_nproc1_ompnum4"]["ompnum"] == 4
+    for key in ("reference_defaults_nproc1_ompnum4", "all_cores"):
+        assert fs[key]["iterations_per_s"] > 0 and fs[key]["fragments_per_s"] > 0
+        assert fs[key]["max_abs_e_corr_diff_vs_gpu_Eh"] < 1e-8 and fs[key]["max_abs_e_frag_diff_vs_gpu_Eh"] < 1e-8
+    assert cb["value"] == fs["all_cores"]["iterations_per_s"]
+    assert fs["gpu_same_fragments"]["fragments"] == fs["all_cores"]["nproc"]
+    assert cb["n220_amplitude_updates"]["value"] > 0
+    assert r["parity_n220_abs_err_Eh"] < 1e-10

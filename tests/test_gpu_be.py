@@ -593,3 +593,9 @@ def test_library_rccl_communicator_single_rank(qlib):
     assert comm.active() is None
     with pytest.raises(_lib.QembError):
         comm.all_reduce(qlib, np.zeros(3))                   # no communicator: loud
+
+
+def test_df_transform_matches_reference_integral_direct_DF(qlib):
+    """row a4 on the HIP library against the outputs of the reference's own integral_direct_DF (tests/golden/df.npz)"""
+    from test_df_golden import check_df_golden
+    check_df_golden(qlib)

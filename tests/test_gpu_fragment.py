@@ -165,6 +165,48 @@ def test_fragment_at_bench_tiles(qlib):
     fr.free()
 
 
+def test_bench_fragment_n220_against_oracle(qlib):
+    """THE benchmarked fragment (BASELINE configs[2]: n = 220, n_occ = 20, n_virt = 200; fragment 0 of bench.py's sweep, ERIs built on the
+    device from the DF factor exactly as bench.make_device_eris does) against the oracle's stored results (tests/golden/frag220.npz, written
+    by make_golden_frag220.py: ten minutes of NumPy): fragment RHF, the energy after 3 plain amplitude updates from the MP2 guess (the number
+    bench.py's parity field reports), and the converged DIIS solve -- E_corr, iteration count, 1-RDM."""
+    import ctypes as C
+    import sys
+    from helpers import GOLDEN
+    from quemb_amd._lib import DeviceBuffer, check
+    if str(GOLDEN) not in sys.path:
+        sys.path.insert(0, str(GOLDEN))
+    import make_golden_frag220 as mg
+    g = np.load(GOLDEN / "frag220.npz")
+    n, o = int(g["n"]), int(g["o"])
+    assert (n, o, int(g["seed"]), float(g["scale"])) == (mg.N, mg.O, mg.SEED, mg.SCALE) == (220, 20, 20260803, 0.03)
+    h, B = mg.bench_fragment(n, int(g["seed"]), float(g["scale"]))
+    il = np.tril_indices(n)
+    Bp = np.ascontiguousarray(B[:, il[0], il[1]])
+    npair = Bp.shape[1]
+    dB, d4 = DeviceBuffer.from_numpy(Bp), DeviceBuffer(npair * npair)
+    check(qlib.qemb_op_gemm(npair, npair, Bp.shape[0], 1.0, dB.ptr, npair, 0, 0, dB.ptr, npair, 0, 0, 0.0, d4.ptr, npair, 0, 1))
+    dB.free()
+    fr = DeviceFragment(n, 22)
+    fr.set_eri_s4_dev(d4.ptr); d4.free()
+    opts = default_opts(cc_conv_tol=1e-11, cc_conv_tol_normt=1e-9, scf_conv_tol=1e-12, scf_conv_tol_grad=1e-8)
+    r = fr.scf(o, h, None, opts=opts)
+    assert abs(r["e_scf"] - float(g["e_scf"])) < 1e-8 * max(1.0, abs(float(g["e_scf"])))
+    assert np.abs(r["mo_energy"] - g["mo_energy"]).max() < 1e-8
+    dm0 = 2.0 * r["mo_coeff"][:, :o] @ r["mo_coeff"][:, :o].T
+    # (i) plain updates, no DIIS: the same arithmetic in the same order of iterations as the oracle's loop
+    fr.prepare_ccsd(o, h, dm0, opts=opts)
+    e3, _ = fr.ccsd_iterate(3)
+    assert abs(e3 - float(g["e_corr_3_plain_updates"])) < 1e-9, (e3, float(g["e_corr_3_plain_updates"]))
+    # (ii) the product solve to convergence
+    out = fr.solve(o, h, dm0, opts=opts, eeval=False, want_t2=True)
+    assert abs(out["e_corr_mo"] - float(g["e_corr"])) < TOL_E, (out["e_corr_mo"], float(g["e_corr"]))
+    assert abs(out["n_iter"] - int(g["n_iter"])) <= 1
+    assert np.abs(out["rdm1_emb"] - g["rdm1_emb"]).max() < TOL_RDM
+    assert abs(np.linalg.norm(out["t1"]) - float(g["t1_norm"])) < 1e-7 and abs(np.linalg.norm(out["t2"]) - float(g["t2_norm"])) < 1e-7
+    fr.free()
+
+
 def test_fragment_without_virtual_orbitals(qlib):
     from test_hostlogic_fragment import check_fragment_without_virtual_orbitals
     check_fragment_without_virtual_orbitals(qlib)

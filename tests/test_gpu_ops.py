@@ -1,6 +1,7 @@
 """-m gpu: every device primitive of libqemb_hip (through the C ABI) against numpy on seeded inputs."""
 
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -23,9 +24,11 @@ def _gemm(lib, A, B, Cm, alpha, beta, a_kc, b_kc, batch=1, cfg=-1):
     lda = K if a_kc else M
     ldb = K if b_kc else N
     lib.qemb_set_gemm_config(cfg)
-    check(lib.qemb_op_gemm(M, N, K, alpha, dA.ptr, lda, int(a_kc), M * K, dB.ptr, ldb, int(b_kc), K * N, beta,
-                           dC.ptr, N, M * N, bsz), "gemm")
-    lib.qemb_set_gemm_config(-1)
+    try:
+        check(lib.qemb_op_gemm(M, N, K, alpha, dA.ptr, lda, int(a_kc), M * K, dB.ptr, ldb, int(b_kc), K * N, beta,
+                               dC.ptr, N, M * N, bsz), "gemm")
+    finally:
+        lib.qemb_set_gemm_config(-1)
     return dC.numpy(Cm.shape)
 
 
@@ -724,3 +727,34 @@ def test_device_timers_hold_a_bounded_number_of_events(qlib):
     assert cnt.value == 1001 and ms.value > 0.0
     assert qlib.qemb_timer_end(slot) != 0         # nothing open any more
     check(qlib.qemb_timer_reset(slot))
+
+
+# every tile configuration that runs the MODE 1 main loop in production (inline-asm ds_read_b64 + hand-counted s_waitcnt) against the
+# classic loop of the same tile (cfg + 200; 23 / 25 are 13 / 15 under the ladder's kernel symbol): same summation order, so the results
+# must be IDENTICAL -- a compiler that moves a fragment register between the asm read and its wait would show up here first.
+@pytest.mark.parametrize("cfg,classic,M,N", [(0, 200, 256, 384), (1, 201, 192, 192), (4, 204, 128, 512), (13, 213, 210, 2304), (23, 213, 210, 2304),
+                                             (15, 215, 190, 2304), (25, 215, 190, 2304), (33, 233, 220, 512), (34, 234, 640, 220), (35, 235, 465, 512)])
+@pytest.mark.parametrize("a_kc,b_kc", [(1, 1), (1, 0), (0, 1), (0, 0)])
+def test_gemm_mode1_equals_classic_loop(qlib, cfg, classic, M, N, a_kc, b_kc):
+    rng = np.random.default_rng(7 * cfg + a_kc + 2 * b_kc)
+    K = 1080                                   # 67.5 k-tiles of 16: odd tile count and a k-tail
+    A = rng.standard_normal((1, M, K)); B = rng.standard_normal((1, K, N)); C0 = rng.standard_normal((1, M, N))
+    for ks in (0, 4):
+        qlib.qemb_set_gemm_ksplit(ks)
+        try:
+            new = _gemm(qlib, A, B, C0, 0.75, -0.5, a_kc, b_kc, cfg=cfg)
+            old = _gemm(qlib, A, B, C0, 0.75, -0.5, a_kc, b_kc, cfg=classic)
+        finally:
+            qlib.qemb_set_gemm_ksplit(0)
+        assert np.array_equal(new, old), (cfg, classic, a_kc, b_kc, ks, np.abs(new - old).max())
+    assert np.abs(new - (0.75 * (A @ B) - 0.5 * C0)).max() < 1e-12 * K
+
+
+def test_diagnostic_gemm_configs_are_not_reachable(qlib):
+    """3xx (stamps) and 4xx-6xx (ablation, wrong by construction) are for tools/ with QEMB_GEMM_DIAGNOSTICS=1 only"""
+    if os.environ.get("QEMB_GEMM_DIAGNOSTICS"):
+        pytest.skip("diagnostics enabled in this environment")
+    A = np.ones((1, 64, 64)); B = np.ones((1, 64, 64)); C0 = np.zeros((1, 64, 64))
+    for cfg in (313, 413, 513, 613, 304, 404):
+        with pytest.raises(Exception, match="diagnostic"):
+            _gemm(qlib, A, B, C0, 1.0, 0.0, 1, 1, cfg=cfg)

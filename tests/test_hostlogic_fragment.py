@@ -222,3 +222,24 @@ def check_fragment_without_virtual_orbitals(lib):
 
 def test_fragment_without_virtual_orbitals(hlib):
     check_fragment_without_virtual_orbitals(hlib)
+
+
+def test_pair_gemm_tile_choice(hlib):
+    """the row tile of the pp-ladder / tau-dressing products is chosen by estimated time, not by least padding alone: the slow
+    single-column wave tiles (cfg 11 / 12) win only where they save much more than their rate costs."""
+    import ctypes as C
+    npair = lambda x: x * (x + 1) // 2
+
+    def choice(rows, cols=20100):
+        c, k = C.c_int(), C.c_int()
+        assert hlib.qemb_pair_gemm_choice(rows, cols, C.byref(c), C.byref(k)) == 0
+        return c.value, k.value
+    assert choice(npair(20))[0] == 13 and choice(190)[0] == 15            # the benchmarked fragment (o = 20): 224- and 192-row tiles
+    assert choice(npair(30))[0] == 35                                      # 465 rows: three 160-row tiles
+    assert choice(npair(40))[0] in (13, 4)                                 # 820 rows: 896 padded rows on a fast tile, NOT thirteen 64-row tiles
+    assert choice(npair(40) - 40)[0] in (13, 15, 35, 4)                    # 780 antisymmetric rows
+    assert choice(36)[0] == 12 and choice(100)[0] in (4, 11)                   # small fragments keep the small tiles
+    assert choice(210, cols=1000) == (-1, 0)                               # few columns: the dispatcher's own choice
+    for rows in (28, 105, 190, 210, 465, 820, 1275):
+        cfg, ks = choice(rows)
+        assert 1 <= ks <= 8

@@ -8,7 +8,9 @@ the MO transformation on the 224 x 128 tile (one 8-wave workgroup per CU) agains
 
     python tools/gemm_ablation.py [reps]
 """
+import os
 import sys
+os.environ.setdefault("QEMB_GEMM_DIAGNOSTICS", "1")   # this tool runs the ablation instantiations (tile configs 4xx-6xx)
 
 sys.path.insert(0, ".")
 from tools.gemm_modes import bench  # noqa: E402  (initialises the device)

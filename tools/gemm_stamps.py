@@ -3,6 +3,8 @@ s_memtime around the per-tile barrier; per tile of BK = 16 a wave issues (WM x W
     python tools/gemm_stamps.py
 """
 import ctypes as C
+import os
+os.environ.setdefault("QEMB_GEMM_DIAGNOSTICS", "1")   # this tool runs the stamping instantiations (tile configs 3xx)
 import json
 import sys
 
