@@ -1021,6 +1021,62 @@ int dev_ladder_pack_vvvv(int64_t n, int64_t o, const double* M, double* Vp, int6
   HIP_TRY(hipGetLastError());
   return QEMB_OK;
 }
+// (+/-) pair packing of the last two indices of v x v slabs through LDS tiles (round 3).  The element-wise kernels below read in[c][d] along d
+// but in[d][c] with a stride of v doubles -- one cache line per lane -- and spend a double-precision square root per element on the pair
+// index: 2.6 TB/s (pack_pm_cols), 3.8 TB/s (ladder_pack_tau).  Here a workgroup takes one pair of 32 x 32 tiles (tc >= td) of a slab: tile
+// (tc, td) and its mirror (td, tc) are both read along rows, the mirror is read transposed out of LDS, and each thread row writes 32
+// consecutive packed entries c(c+1)/2 + d.  MODE 0: Op = x + y, Om = x - y for every row.  MODE 1 (tau): the slab of packed row ij is
+// (i*o + j), Op = w (x + y) with w = 1/2 (1/4 on c = d), Om = (x - y)/2 only for i > j (row Q(i,j)).
+template <int MODE>
+__global__ void __launch_bounds__(256) pack_pm_tiled_kernel(long long rows, long long o, long long v, const double* __restrict__ in, double* __restrict__ Op,
+                                                            long long ldp, double* __restrict__ Om, long long ldm) {
+  __shared__ double tA[32][33], tB[32][33];
+  const long long np = v * (v + 1) / 2, nm = v * (v - 1) / 2;
+  long long tc, td; unpair_ge((long long)blockIdx.x, tc, td);
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const bool diag = (tc == td);
+  for (long long r = blockIdx.y; r < rows; r += gridDim.y) {
+    const double* t; double* tp = Op + r * ldp; double* tm;
+    if (MODE == 1) {
+      long long i, j; unpair_ge(r, i, j);
+      t = in + (i * o + j) * v * v;
+      tm = (i > j) ? Om + (i * (i - 1) / 2 + j) * ldm : nullptr;
+    } else {
+      t = in + r * v * v; tm = Om + r * ldm;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int rr = ty + 8 * k;
+      const long long c = tc * 32 + rr, d = td * 32 + tx;
+      tA[rr][tx] = (c < v && d < v) ? t[c * v + d] : 0.0;
+      if (!diag) {
+        const long long d2 = td * 32 + rr, c2 = tc * 32 + tx;
+        tB[rr][tx] = (d2 < v && c2 < v) ? t[d2 * v + c2] : 0.0;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int cc = ty + 8 * k;
+      const long long c = tc * 32 + cc, d = td * 32 + tx;
+      if (c < v && d <= c) {
+        const double x = tA[cc][tx], y = diag ? tA[tx][cc] : tB[tx][cc];
+        if (MODE == 1) {
+          tp[c * (c + 1) / 2 + d] = (c == d) ? 0.25 * (x + y) : 0.5 * (x + y);
+          if (tm && c > d) tm[c * (c - 1) / 2 + d] = 0.5 * (x - y);
+        } else {
+          tp[c * (c + 1) / 2 + d] = x + y;
+          if (c > d) tm[c * (c - 1) / 2 + d] = x - y;
+        }
+      }
+    }
+    if (blockIdx.x == 0) {      // padding columns of the row (leading dimensions are rounded up to even)
+      for (long long q = np + threadIdx.x; q < ldp; q += 256) tp[q] = 0.0;
+      if (tm) for (long long q = nm + threadIdx.x; q < ldm; q += 256) tm[q] = 0.0;
+    }
+    __syncthreads();
+  }
+}
 __global__ void __launch_bounds__(256) ladder_pack_tau_kernel(long long o, long long v, const double* __restrict__ tau,
                                                              double* __restrict__ Tp, long long ldp, double* __restrict__ Tm, long long ldm) {
   const long long ij = blockIdx.x, np = v * (v + 1) / 2, nm = v * (v - 1) / 2;
@@ -1043,6 +1099,13 @@ int dev_ladder_pack_tau(int64_t o, int64_t v, const double* tau, double* Tp, int
   REQUIRE_INIT();
   const long long npo = o * (o + 1) / 2;
   if (npo <= 0 || v <= 0) return QEMB_OK;
+  if (v >= 32) {
+    const long long nt = (v + 31) / 32;
+    hipLaunchKernelGGL(pack_pm_tiled_kernel<1>, dim3((unsigned)(nt * (nt + 1) / 2), (unsigned)std::min<long long>(npo, 65535)), dim3(256), 0, g_stream,
+                       npo, (long long)o, (long long)v, tau, Tp, (long long)ldp, Tm, (long long)ldm);
+    HIP_TRY(hipGetLastError());
+    return QEMB_OK;
+  }
   const unsigned slices = (unsigned)std::max<long long>(1, std::min<long long>(16, ldp / 2048));
   hipLaunchKernelGGL(ladder_pack_tau_kernel, dim3((unsigned)npo, slices), dim3(256), 0, g_stream, (long long)o, (long long)v, tau, Tp, (long long)ldp, Tm, (long long)ldm);
   HIP_TRY(hipGetLastError());
@@ -1068,6 +1131,13 @@ __global__ void __launch_bounds__(256) pack_pm_cols_kernel(long long rows, long 
 int dev_pack_pm_cols(int64_t rows, int64_t v, const double* in, double* Op, int64_t ldp, double* Om, int64_t ldm) {
   REQUIRE_INIT();
   if (rows <= 0 || v <= 0) return QEMB_OK;
+  if (v >= 32) {
+    const long long nt = (v + 31) / 32;
+    hipLaunchKernelGGL(pack_pm_tiled_kernel<0>, dim3((unsigned)(nt * (nt + 1) / 2), (unsigned)std::min<int64_t>(rows, 16384)), dim3(256), 0, g_stream,
+                       (long long)rows, 0LL, (long long)v, in, Op, (long long)ldp, Om, (long long)ldm);
+    HIP_TRY(hipGetLastError());
+    return QEMB_OK;
+  }
   hipLaunchKernelGGL(pack_pm_cols_kernel, dim3((unsigned)std::min<int64_t>(rows, 1 << 20)), dim3(256), 0, g_stream, (long long)rows, (long long)v, in, Op, (long long)ldp, Om, (long long)ldm);
   HIP_TRY(hipGetLastError());
   return QEMB_OK;
@@ -1559,6 +1629,128 @@ __global__ void __launch_bounds__(256) jk_packed_stage1(int n, const double* __r
   if (Jp && tid == 0) Jp[pq] = (jw[0] + jw[1]) + (jw[2] + jw[3]);
 }
 
+// Round 3: the same pass with enough bytes in flight to stream from HBM (the guide: ~72 KB per CU).  The kernel above keeps 8 bytes per lane
+// and one row per wave in flight and pays two 64-lane reductions per row: 3.05 TB/s.  Here a wave works on FOUR consecutive rows at a time,
+// one per 16-lane group; a lane holds the 16-byte piece (two columns) 2c + 32k of its row for every k, all NK2 pieces requested before the
+// first is used (with the matching pieces of the packed density for the Coulomb sum: up to 14 loads of 16 bytes per lane outstanding, 8 waves
+// per CU), and the row sums are reduced inside the 16-lane group with four row-local DPP steps for all four rows at once.  Column sums stay
+// in the lane that owns the column pair; the 16 (wave, group) partial vectors are added in a fixed order at the end.  Rows start at any
+// 8-byte offset: the 16-byte loads are issued at 8-byte alignment (global_load_dwordx4 needs dword alignment only).
+struct alignas(8) D2u { double x, y; };
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for_i(F&& f) {
+  if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for_i<I + 1, N>(f); }
+}
+__device__ __forceinline__ double row16_sum_dpp(double v) {      // total over the 16 lanes of a DPP row, in every lane of the row
+  v += dpp_take_f64<0xB1, 0xF>(v);
+  v += dpp_take_f64<0x4E, 0xF>(v);
+  v += dpp_take_f64<0x141, 0xF>(v);
+  v += dpp_take_f64<0x140, 0xF>(v);
+  return v;
+}
+// GL = lanes per row group (16: four rows per wave step, 32: two); NKS = ceil(n / (2 GL)) 16-byte column slots per lane
+template <int GL, int NKS, bool WITH_J>
+__global__ void __launch_bounds__(256, 2) jk_packed_rowgroups(int n, const double* __restrict__ S4, const double* __restrict__ D,
+                                                           const double* __restrict__ Dp, double* __restrict__ Jp, double* __restrict__ P1,
+                                                           double* __restrict__ P2) {
+  constexpr int G = 64 / GL, NSLOT = 4 * G, BAND = 2 * GL;      // row groups per wave; (wave, group) partial vectors; rows per band
+  extern __shared__ double sm[];
+  double* yl1 = sm; double* yl2 = sm + n; double* part = sm + 2 * n;      // part[(wave * G + group) * 2 + vector][n]; jw behind it
+  double* jw = part + 2 * NSLOT * n;
+  const long long np = (long long)n * (n + 1) / 2, pq = blockIdx.x;
+  long long p, q; unpair_ge(pq, p, q);
+  const double* __restrict__ row = S4 + pq * np;
+  const double* __restrict__ Dq = D + q * n;
+  const double* __restrict__ Dpr = D + p * n;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane / GL, c = lane % GL;
+  double dq[NKS][2], dp[NKS][2], uq[NKS][2], up[NKS][2], ja = 0.0;
+#pragma unroll
+  for (int k = 0; k < NKS; ++k) {
+    const int s = 2 * c + BAND * k;
+    dq[k][0] = s < n ? Dq[s] : 0.0; dq[k][1] = s + 1 < n ? Dq[s + 1] : 0.0;
+    dp[k][0] = s < n ? Dpr[s] : 0.0; dp[k][1] = s + 1 < n ? Dpr[s + 1] : 0.0;
+    uq[k][0] = uq[k][1] = up[k][0] = up[k][1] = 0.0;
+  }
+  // Band b = rows BAND b .. BAND (b+1) - 1 needs the slots k <= b only: one fully unrolled body per band (KM = b + 1 slots), so that every
+  // load of a wave step is issued before the first use and nothing is fetched beyond the triangle.  All loads are unconditional: addresses
+  // are clamped into the packed row (np - 2 at most: a 16-byte load never leaves it) and the values masked afterwards.
+  const int last = (int)np - 2;
+  auto band = [&](auto kmc, int b) {
+    constexpr int KM = decltype(kmc)::value;
+    constexpr int STEPS = BAND / G;                    // wave steps per band
+    const int qend = (STEPS * (b + 1) < (n + G - 1) / G) ? STEPS * (b + 1) : (n + G - 1) / G;
+    // step Q = rows G Q .. G Q + G - 1, one per lane group
+    auto fetch = [&](int Q, D2u (&x)[KM], D2u (&w)[KM]) {
+      const int r = G * Q + g, rb = r * (r + 1) / 2;   // < 2^31 for n <= 1024
+#pragma unroll
+      for (int k = 0; k < KM; ++k) {
+        const int at = rb + 2 * c + BAND * k, cl = at < last ? at : last;
+        x[k] = *reinterpret_cast<const D2u*>(row + cl);
+        if (WITH_J) w[k] = *reinterpret_cast<const D2u*>(Dp + cl);
+      }
+    };
+    auto consume = [&](int Q, const D2u (&x)[KM], const D2u (&w)[KM]) {
+      const int r = G * Q + g;
+      const bool valid = r < n;
+      const int rb = r * (r + 1) / 2;
+      const int rr = valid ? r : 0;
+      const double dq_r = valid ? Dq[rr] : 0.0, dp_r = valid ? Dpr[rr] : 0.0;
+      double a1 = 0.0, a2 = 0.0;
+#pragma unroll
+      for (int k = 0; k < KM; ++k) {
+        const int s = 2 * c + BAND * k, at = rb + s;
+        const bool shifted = at > last;               // only the very last element of the packed row: it arrived in the .y half
+        double xx = shifted ? x[k].y : x[k].x, xy = x[k].y;
+        double wx = 0.0, wy = 0.0;
+        if (WITH_J) { wx = shifted ? w[k].y : w[k].x; wy = w[k].y; }
+        xx = (valid && s <= r) ? xx : 0.0; xy = (valid && s + 1 <= r) ? xy : 0.0;
+        a1 += xx * dq[k][0]; a1 += xy * dq[k][1];
+        a2 += xx * dp[k][0]; a2 += xy * dp[k][1];
+        if (WITH_J) { ja += xx * wx; ja += xy * wy; }
+        const double cx = (s < r) ? xx : 0.0, cy = (s + 1 < r) ? xy : 0.0;      // the diagonal element belongs to the row sum only
+        uq[k][0] += cx * dq_r; uq[k][1] += cy * dq_r;
+        up[k][0] += cx * dp_r; up[k][1] += cy * dp_r;
+      }
+      a1 = row16_sum_dpp(a1); a2 = row16_sum_dpp(a2);
+      if (GL == 32) {       // row_bcast:15 into DPP rows 1 and 3: their lanes then hold the sum over the 32 lanes of the group
+        a1 += dpp_take_f64<0x142, 0xA>(a1); a2 += dpp_take_f64<0x142, 0xA>(a2);
+      }
+      if (c == GL - 1 && valid) { yl1[r] = a1; yl2[r] = a2; }
+    };
+    // (requesting the pieces of the wave's next step before the current one is consumed -- two register sets -- was measured: slower,
+    //  1.49 vs 1.32 ms at n = 220 with 32-lane groups, no gain with 16-lane groups; the pass is not latency bound)
+    for (int Q = STEPS * b + wave; Q < qend; Q += 4) {
+      D2u x[KM], w[KM];
+      fetch(Q, x, w);
+      consume(Q, x, w);
+    }
+  };
+  static_for_i<0, NKS>([&](auto kc) { band(std::integral_constant<int, decltype(kc)::value + 1>{}, decltype(kc)::value); });
+  const int slot = wave * G + g;
+#pragma unroll
+  for (int k = 0; k < NKS; ++k) {
+    const int s = 2 * c + BAND * k;
+    if (s < n) { part[(slot * 2 + 0) * n + s] = uq[k][0]; part[(slot * 2 + 1) * n + s] = up[k][0]; }
+    if (s + 1 < n) { part[(slot * 2 + 0) * n + s + 1] = uq[k][1]; part[(slot * 2 + 1) * n + s + 1] = up[k][1]; }
+  }
+  if (WITH_J) {
+    ja = wave_sum_dpp(ja);
+    if (lane == 0) jw[wave] = ja;
+  }
+  __syncthreads();
+  for (int s = tid; s < n; s += 256) {
+    double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+    for (int sl = 0; sl < NSLOT; sl += 4) {            // fixed order
+      t1 += (part[((sl + 0) * 2) * n + s] + part[((sl + 1) * 2) * n + s]) + (part[((sl + 2) * 2) * n + s] + part[((sl + 3) * 2) * n + s]);
+      t2 += (part[((sl + 0) * 2 + 1) * n + s] + part[((sl + 1) * 2 + 1) * n + s]) + (part[((sl + 2) * 2 + 1) * n + s] + part[((sl + 3) * 2 + 1) * n + s]);
+    }
+    P1[pq * n + s] = yl1[s] + t1;
+    P2[pq * n + s] = yl2[s] + t2;
+  }
+  if (WITH_J && tid == 0) Jp[pq] = (jw[0] + jw[1]) + (jw[2] + jw[3]);
+}
+
 int dev_jk_from_packed(int64_t n, const double* S4, const double* D, const double* Dp, double* Jp, double* K) {
   REQUIRE_INIT();
   if (n <= 0) return QEMB_OK;
@@ -1568,19 +1760,50 @@ int dev_jk_from_packed(int64_t n, const double* S4, const double* D, const doubl
   int rc = ensure_ws((size_t)2 * np * n * sizeof(double));
   if (rc) return rc;
   double* P1 = g_ws; double* P2 = g_ws + np * n;
-  const size_t lds = (size_t)(10 * n + 8) * sizeof(double);
-  const int nk = (int)((n + 63) / 64);
   hipError_t attr_err = hipSuccess;
-  auto launch = [&](auto kern) {
-    // n > 818 needs more than the 64 KB of dynamic LDS a kernel gets by default (82 KB at n = 1024; a CU has 160 KB)
-    if (lds > 64 * 1024) attr_err = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (attr_err == hipSuccess) hipLaunchKernelGGL(kern, dim3((unsigned)np), dim3(256), lds, g_stream, (int)n, S4, D, Dp, Jp, P1, P2);
-  };
-  if (nk <= 1) launch(jk_packed_stage1<1>);
-  else if (nk <= 2) launch(jk_packed_stage1<2>);
-  else if (nk <= 4) launch(jk_packed_stage1<4>);
-  else if (nk <= 8) launch(jk_packed_stage1<8>);
-  else launch(jk_packed_stage1<16>);
+  static const bool old_kernel = std::getenv("QEMB_JK_V1") != nullptr;      // A/B measurements (tools/hbm_kernels.py)
+  static const int gl = std::getenv("QEMB_JK_GL") ? std::atoi(std::getenv("QEMB_JK_GL")) : 16;      // 16: 1.28 ms, 32: 1.32 ms at n = 220
+  if (n >= 2 && n <= 448 && !old_kernel) {
+    // 32-lane row groups (two rows per wave step): 8 partial vectors; 16-lane groups (four rows): 16
+    const int nslot = gl == 16 ? 16 : 8;
+    const size_t lds = (size_t)((2 + 2 * nslot) * n + 8) * sizeof(double);   // n = 220: 31.7 KB (GL 32) / 59.9 KB (GL 16) per workgroup
+    auto launch = [&](auto kern) {
+      if (lds > 64 * 1024) attr_err = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (attr_err == hipSuccess) hipLaunchKernelGGL(kern, dim3((unsigned)np), dim3(256), lds, g_stream, (int)n, S4, D, Dp, Jp, P1, P2);
+    };
+#define QEMB_JK_CASE(GL, NKS) do { if (Jp) launch(jk_packed_rowgroups<GL, NKS, true>); else launch(jk_packed_rowgroups<GL, NKS, false>); } while (0)
+    if (gl == 16) {
+      const int nks = (int)((n + 31) / 32);
+      if (nks <= 1) QEMB_JK_CASE(16, 1);
+      else if (nks <= 2) QEMB_JK_CASE(16, 2);
+      else if (nks <= 4) QEMB_JK_CASE(16, 4);
+      else if (nks <= 7) QEMB_JK_CASE(16, 7);
+      else if (nks <= 10) QEMB_JK_CASE(16, 10);
+      else QEMB_JK_CASE(16, 14);
+    } else {
+      const int nks = (int)((n + 63) / 64);
+      if (nks <= 1) QEMB_JK_CASE(32, 1);
+      else if (nks <= 2) QEMB_JK_CASE(32, 2);
+      else if (nks <= 3) QEMB_JK_CASE(32, 3);
+      else if (nks <= 4) QEMB_JK_CASE(32, 4);
+      else if (nks <= 5) QEMB_JK_CASE(32, 5);
+      else QEMB_JK_CASE(32, 7);
+    }
+#undef QEMB_JK_CASE
+  } else {
+    const size_t lds = (size_t)(10 * n + 8) * sizeof(double);
+    const int nk = (int)((n + 63) / 64);
+    auto launch = [&](auto kern) {
+      // n > 818 would need more than the 64 KB of dynamic LDS a kernel gets by default (the packed block of such a fragment, > 0.9 TB, does not fit a device anyway)
+      if (lds > 64 * 1024) attr_err = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (attr_err == hipSuccess) hipLaunchKernelGGL(kern, dim3((unsigned)np), dim3(256), lds, g_stream, (int)n, S4, D, Dp, Jp, P1, P2);
+    };
+    if (nk <= 1) launch(jk_packed_stage1<1>);
+    else if (nk <= 2) launch(jk_packed_stage1<2>);
+    else if (nk <= 4) launch(jk_packed_stage1<4>);
+    else if (nk <= 8) launch(jk_packed_stage1<8>);
+    else launch(jk_packed_stage1<16>);
+  }
   HIP_TRY(attr_err);
   if (K) hipLaunchKernelGGL(k_pairs_stage2, dim3((unsigned)n), dim3(256), 0, g_stream, (long long)n, (const double*)P1, (const double*)P2, K);
   HIP_TRY(hipGetLastError());
@@ -1592,6 +1815,12 @@ int dev_jk_from_packed(int64_t n, const double* S4, const double* D, const doubl
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ long long pair_idx(long long i, long long j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
 
+// row walkers per tile of the tiled unpack: enough blocks for 8 per CU and some slack for the tail (QEMB_UNPACK_WALKERS overrides: A/B runs)
+static int64_t unpack_walkers(int64_t rows, int64_t ntiles) {
+  static const int64_t forced = std::getenv("QEMB_UNPACK_WALKERS") ? std::atoll(std::getenv("QEMB_UNPACK_WALKERS")) : 0;
+  const int64_t want = forced > 0 ? forced : 65535;      // one row per block measured best (profiles/r03_hbm_kernels.jsonl)
+  return std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(rows, 65535), want));
+}
 // Tiled triangular unpack: one workgroup per packed row, 32 x 32 tiles of the lower triangle staged through LDS so that
 // both the [k][l] image and its mirror [l][k] are written in 256-byte runs and every packed element is read once.
 // dup == 1: the row index is itself a pair (p >= q) of an s4 block; the n x n image goes to rows (p,q) and (q,p).
@@ -1652,7 +1881,7 @@ int dev_unpack_s4(int64_t n, const double* s4, double* s1) {
   if (n >= 32) {
     const int64_t np = n * (n + 1) / 2;
     const int64_t nt = (n + 31) / 32;
-    hipLaunchKernelGGL(unpack_tril_tiled_kernel, dim3((unsigned)(nt * (nt + 1) / 2), (unsigned)std::min<int64_t>(np, 65535)), dim3(256), 0, g_stream, (long long)np, (long long)n, s4, s1, 1, (long long)n);
+    hipLaunchKernelGGL(unpack_tril_tiled_kernel, dim3((unsigned)(nt * (nt + 1) / 2), (unsigned)unpack_walkers(np, nt * (nt + 1) / 2)), dim3(256), 0, g_stream, (long long)np, (long long)n, s4, s1, 1, (long long)n);
   } else {
     hipLaunchKernelGGL(unpack_s4_kernel, dim3((unsigned)std::min<int64_t>(n * n, 1 << 20)), dim3(256), 0, g_stream, (long long)n, s4, s1);
   }
@@ -1710,7 +1939,7 @@ int dev_unpack_tril_rows(int64_t rows, int64_t n, const double* packed, double* 
   if (n >= 32)
   {
     const int64_t nt = (n + 31) / 32;
-    hipLaunchKernelGGL(unpack_tril_tiled_kernel, dim3((unsigned)(nt * (nt + 1) / 2), (unsigned)std::min<int64_t>(rows, 65535)), dim3(256), 0, g_stream, (long long)rows, (long long)n, packed, full, 0, (long long)n);
+    hipLaunchKernelGGL(unpack_tril_tiled_kernel, dim3((unsigned)(nt * (nt + 1) / 2), (unsigned)unpack_walkers(rows, nt * (nt + 1) / 2)), dim3(256), 0, g_stream, (long long)rows, (long long)n, packed, full, 0, (long long)n);
   }
   else
     hipLaunchKernelGGL(unpack_tril_rows_kernel, dim3((unsigned)std::min<int64_t>(rows, 1 << 20)), dim3(256), 0, g_stream, (long long)rows, (long long)n, packed, full);
@@ -1732,7 +1961,7 @@ int dev_unpack_tril_pair_rows(int64_t nr, int64_t n, const double* in, double* f
     return rc;
   }
   const int64_t nt = (n + 31) / 32;
-  hipLaunchKernelGGL(unpack_tril_tiled_kernel, dim3((unsigned)(nt * (nt + 1) / 2), (unsigned)std::min<int64_t>(npr, 65535)), dim3(256), 0, g_stream, (long long)npr, (long long)n, in, full, 2, (long long)nr);
+  hipLaunchKernelGGL(unpack_tril_tiled_kernel, dim3((unsigned)(nt * (nt + 1) / 2), (unsigned)unpack_walkers(npr, nt * (nt + 1) / 2)), dim3(256), 0, g_stream, (long long)npr, (long long)n, in, full, 2, (long long)nr);
   HIP_TRY(hipGetLastError());
   return QEMB_OK;
 }

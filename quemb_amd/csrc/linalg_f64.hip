@@ -18,6 +18,7 @@
 #include <cmath>
 #include <cstdint>
 #include <numeric>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 #include "dev_ops.h"
@@ -158,6 +159,165 @@ __global__ void __launch_bounds__(1024) jacobi_small_kernel(double* Wg, long lon
   if (tid == 0) sweeps_out[0] = (sweep <= max_sweeps && !rotated) ? sweep : -1;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Block rounds (round 3): the same Hestenes rotations, grouped so that a workgroup keeps TWO blocks of B vectors (W rows and their Vt rows)
+// in LDS and applies every rotation between them -- B inner rounds of B disjoint pairs, one pair per wave, separated by workgroup barriers
+// -- before the vectors go back to memory.  A sweep is then nb - 1 launches (nb = ceil(nvec / B) blocks in a round-robin tournament) instead
+// of nvec - 1: 14 instead of 219 at nvec = 220, B = 16, and each launch does 16 (31 in the first round, which also rotates the pairs inside
+// each block) rounds of work out of LDS instead of one out of L2.  Same pairs per sweep, every pair exactly once; only the order differs.
+// (Used for 96 < nvec and 2 B (len + nvec) doubles fitting the LDS of a CU; the per-pair kernel above remains for longer vectors.)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double lin_dpp_f64(double x) {
+  const unsigned long long u = __double_as_longlong(x);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(u & 0xffffffffu), CTRL, ROW_MASK, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(u >> 32), CTRL, ROW_MASK, 0xF, false);
+  return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
+}
+__device__ __forceinline__ double wave_allsum(double v) {      // the sum over the 64 lanes, in every lane (wave-uniform), no LDS crossbar
+  v += lin_dpp_f64<0xB1, 0xF>(v);
+  v += lin_dpp_f64<0x4E, 0xF>(v);
+  v += lin_dpp_f64<0x141, 0xF>(v);
+  v += lin_dpp_f64<0x140, 0xF>(v);
+  v += lin_dpp_f64<0x142, 0xA>(v);
+  v += lin_dpp_f64<0x143, 0xC>(v);
+  const unsigned long long u = __double_as_longlong(v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(u & 0xffffffffu), 63), hi = (unsigned)__builtin_amdgcn_readlane((int)(u >> 32), 63);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+// plane rotation that annihilates g = <x,y> given a = <x,x>, b = <y,y>: the inner rotation (|theta| <= pi/4) in its half-angle form
+//   r = sqrt(d^2 + h^2), d = b - a, h = 2 g;  cos^2 = (1 + |d|/r)/2;  sin = sign(d) h / (2 r cos)
+// -- two reciprocal square roots instead of the three divisions and three square roots of the tangent form (the scalar arithmetic of a
+// rotation is serial work every lane of the wave waits for); same angle, cos^2 + sin^2 = 1 to rounding.
+__device__ __forceinline__ void jacobi_cs(double a, double b, double g, double& c, double& sn) {
+  const double d = b - a, h = 2.0 * g;
+  const double rinv = rsqrt(d * d + h * h);
+  const double c2 = 0.5 + 0.5 * fabs(d) * rinv;
+  const double cinv = rsqrt(c2);
+  c = c2 * cinv;
+  sn = (d >= 0.0 ? 0.5 : -0.5) * h * rinv * cinv;
+}
+// B = vectors per block = waves per workgroup; NPL = ceil((len + nvec) / 64) register slots per lane for one [W row | Vt row]
+template <int B, int NPL>
+__global__ void __launch_bounds__(B * 64) jacobi_block_round_kernel(double* __restrict__ W, long long ldw, int len, double* __restrict__ Vt, int nvec, int nb,
+                                                                    int nbp, int round, double tol, double floor2,
+                                                                    unsigned long long* __restrict__ offmax_bits) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  __shared__ double wg_off[B];
+  int P, Q;
+  rr_pair(nbp, round, blockIdx.x, P, Q);      // P < Q; Q == nb: the phantom block of an odd tournament
+  const bool haveQ = Q < nb;
+  const bool do_diag = (round == 0);          // every block plays exactly once in round 0: rotate the pairs INSIDE the blocks there
+  if (!haveQ && !do_diag) return;
+  const int ldr = len + nvec;                 // one row: the W row followed by its Vt row
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int rowsP = min(B, nvec - P * B), rowsQ = haveQ ? min(B, nvec - Q * B) : 0;
+  const double tol2 = tol * tol;
+  double off_seen = 0.0;
+  // LDS rows 0 .. B-1: block Q (the rows that travel between waves); rows B .. 2B-1: block P, only while round 0 rotates inside the blocks
+  auto load_row = [&](int gr, double* dst) {
+    const double* src = W + (long long)gr * ldw;
+    for (int i = lane; i < len; i += 64) dst[i] = src[i];
+    const double* vs = Vt + (long long)gr * nvec;
+    for (int i = lane; i < nvec; i += 64) dst[len + i] = vs[i];
+  };
+  auto store_row = [&](int gr, const double* src) {
+    double* dst = W + (long long)gr * ldw;
+    for (int i = lane; i < len; i += 64) dst[i] = src[i];
+    double* vd = Vt + (long long)gr * nvec;
+    for (int i = lane; i < nvec; i += 64) vd[i] = src[len + i];
+  };
+  if (wave < rowsQ) load_row(Q * B + wave, lds + (size_t)wave * ldr);
+  double pr[NPL];                             // this wave's P row, in registers for the whole launch
+  if (do_diag) {
+    if (wave < rowsP) load_row(P * B + wave, lds + (size_t)(B + wave) * ldr);
+    __syncthreads();
+    // pairs inside block Q (waves 0 .. B/2-1, LDS rows 0..) and inside block P (waves B/2 .. B-1, LDS rows B..): B - 1 round-robin rounds
+    const int h = wave / (B / 2), k = wave % (B / 2), nr = h == 0 ? rowsQ : rowsP;
+    for (int r = 0; r < B - 1; ++r) {
+      int p, q;
+      rr_pair(B, r, k, p, q);
+      if (q < nr) {
+        double* wp = lds + (size_t)(h * B + p) * ldr; double* wq = lds + (size_t)(h * B + q) * ldr;
+        double a = 0.0, b = 0.0, g = 0.0;
+        for (int i = lane; i < len; i += 64) { const double x = wp[i], y = wq[i]; a += x * x; b += y * y; g += x * y; }
+        a = wave_allsum(a); b = wave_allsum(b); g = wave_allsum(g);
+        if (a > floor2 && b > floor2 && g * g > tol2 * a * b) {
+          off_seen = fmax(off_seen, fabs(g) * rsqrt(a * b));
+          double c, sn; jacobi_cs(a, b, g, c, sn);
+          for (int i = lane; i < ldr; i += 64) { const double x = wp[i], y = wq[i]; wp[i] = c * x - sn * y; wq[i] = sn * x + c * y; }
+        }
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int k2 = 0; k2 < NPL; ++k2) { const int i = lane + 64 * k2; pr[k2] = (wave < rowsP && i < ldr) ? lds[(size_t)(B + wave) * ldr + i] : 0.0; }
+  } else {
+    const double* src = W + (long long)(P * B + (wave < rowsP ? wave : 0)) * ldw;
+    const double* vs = Vt + (long long)(P * B + (wave < rowsP ? wave : 0)) * nvec;
+#pragma unroll
+    for (int k2 = 0; k2 < NPL; ++k2) {
+      const int i = lane + 64 * k2;
+      pr[k2] = (wave < rowsP && i < ldr) ? (i < len ? src[i] : vs[i - len]) : 0.0;
+    }
+    __syncthreads();
+  }
+  if (haveQ) {
+    // pairs between the blocks: wave w keeps P row w and meets Q row (w + shift) % B in inner round `shift`; only the Q rows pass through LDS
+    double a = 0.0;                           // <p,p> of this wave's row: carried along (a' = c^2 a - 2 c s g + s^2 b after a rotation), recomputed every launch
+#pragma unroll
+    for (int k2 = 0; k2 < NPL; ++k2) { const int i = lane + 64 * k2; a += (i < len) ? pr[k2] * pr[k2] : 0.0; }
+    a = wave_allsum(a);
+    for (int shift = 0; shift < B; ++shift) {
+      const int qa = (wave + shift) % B;
+      if (wave < rowsP && qa < rowsQ) {
+        double* wq = lds + (size_t)qa * ldr;
+        double qr[NPL];
+        double b = 0.0, g = 0.0;
+#pragma unroll
+        for (int k2 = 0; k2 < NPL; ++k2) {
+          const int i = lane + 64 * k2;
+          qr[k2] = (i < ldr) ? wq[i] : 0.0;
+          if (i < len) { b += qr[k2] * qr[k2]; g += pr[k2] * qr[k2]; }
+        }
+        b = wave_allsum(b); g = wave_allsum(g);
+        if (a > floor2 && b > floor2 && g * g > tol2 * a * b) {
+          off_seen = fmax(off_seen, fabs(g) * rsqrt(a * b));
+          double c, sn; jacobi_cs(a, b, g, c, sn);
+#pragma unroll
+          for (int k2 = 0; k2 < NPL; ++k2) {
+            const int i = lane + 64 * k2;
+            const double x = pr[k2], y = qr[k2];
+            pr[k2] = c * x - sn * y;
+            if (i < ldr) wq[i] = sn * x + c * y;
+          }
+          a = 0.0;                            // (recomputed from the rotated row: no drift of the carried norm)
+#pragma unroll
+          for (int k2 = 0; k2 < NPL; ++k2) { const int i = lane + 64 * k2; a += (i < len) ? pr[k2] * pr[k2] : 0.0; }
+          a = wave_allsum(a);
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (wave < rowsQ) store_row(Q * B + wave, lds + (size_t)wave * ldr);
+  if (wave < rowsP) {
+    double* dst = W + (long long)(P * B + wave) * ldw;
+    double* vd = Vt + (long long)(P * B + wave) * nvec;
+#pragma unroll
+    for (int k2 = 0; k2 < NPL; ++k2) {
+      const int i = lane + 64 * k2;
+      if (i < len) dst[i] = pr[k2]; else if (i < ldr) vd[i - len] = pr[k2];
+    }
+  }
+  if (lane == 0) wg_off[wave] = off_seen;
+  __syncthreads();
+  if (tid == 0) {
+    double m = 0.0;
+    for (int w = 0; w < B; ++w) m = fmax(m, wg_off[w]);
+    if (m > 0.0) atomicMax(offmax_bits, (unsigned long long)__double_as_longlong(m));
+  }
+}
+
 // out[i] = sum_k X[i*ldx+k] * Y[i*ldy+k]
 __global__ void __launch_bounds__(256) rowdot_kernel(int nrow, long long len, const double* X, long long ldx, const double* Y, long long ldy, double* out) {
   __shared__ double sh[4];
@@ -223,10 +383,36 @@ static int jacobi_rows(int nvec, int64_t len, double* W, int64_t ldw, double* Vt
   QTRY_ALLOC(d_off, sizeof(unsigned long long));
   const double tol = std::max(1.0e-15, std::sqrt((double)len) * 2.22e-16);   // LAPACK dgesvj-style
   const int max_sweeps = 40;
+  // block rounds: the largest B in {16, 8, 4} whose two blocks (W rows + Vt rows) fit the LDS of a CU (QEMB_JACOBI_BLOCK=0: per-pair rounds, A/B runs)
+  static const bool blocks_enabled = !(std::getenv("QEMB_JACOBI_BLOCK") && std::atoi(std::getenv("QEMB_JACOBI_BLOCK")) == 0);
+  int B = 0;
+  if (Vt && blocks_enabled && len < (1 << 20)) {
+    static const int forced_b = std::getenv("QEMB_JACOBI_B") ? std::atoi(std::getenv("QEMB_JACOBI_B")) : 0;
+    for (int b : {16, 8, 4}) if ((forced_b == 0 || b <= forced_b) && nvec >= 2 * b && sizeof(double) * 2 * b * (size_t)(len + nvec) <= 150 * 1024) { B = b; break; }
+  }
+  const int nb = B ? (nvec + B - 1) / B : 0, nbp = (nb % 2 == 0) ? nb : nb + 1;
+  const size_t blk_lds = B ? sizeof(double) * 2 * B * (size_t)(len + nvec) : 0;
+  const int npl_need = B ? (int)((len + nvec + 63) / 64) : 0;
+  // one launch of a block round; the register slots per lane are a template parameter (smallest instantiation that holds a row)
+  auto launch_block_round = [&](int r) -> hipError_t {
+    hipError_t err = hipSuccess;
+    auto go = [&](auto kern, int bw) {
+      static std::atomic<bool> attr_set{false};   // per instantiation; benign if two threads both set it once
+      if (!attr_set) { err = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024); attr_set = true; }
+      if (err == hipSuccess) hipLaunchKernelGGL(kern, dim3(nbp / 2), dim3(bw * 64), blk_lds, s, W, (long long)ldw, (int)len, Vt, nvec, nb, nbp, r, tol, floor2, d_off);
+    };
+    if (B == 16) { if (npl_need <= 4) go(jacobi_block_round_kernel<16, 4>, 16); else if (npl_need <= 7) go(jacobi_block_round_kernel<16, 7>, 16); else go(jacobi_block_round_kernel<16, 10>, 16); }
+    else if (B == 8) { if (npl_need <= 7) go(jacobi_block_round_kernel<8, 7>, 8); else if (npl_need <= 12) go(jacobi_block_round_kernel<8, 12>, 8); else if (npl_need <= 15) go(jacobi_block_round_kernel<8, 15>, 8); else go(jacobi_block_round_kernel<8, 19>, 8); }
+    else { if (npl_need <= 7) go(jacobi_block_round_kernel<4, 7>, 4); else if (npl_need <= 24) go(jacobi_block_round_kernel<4, 24>, 4); else if (npl_need <= 30) go(jacobi_block_round_kernel<4, 30>, 4); else go(jacobi_block_round_kernel<4, 38>, 4); }
+    return err;
+  };
   int sweep = 0;
   bool conv = false;
   for (; sweep < max_sweeps; ++sweep) {
     HIP_TRY(hipMemsetAsync(d_off, 0, sizeof(unsigned long long), s));
+    if (B) {
+      for (int r = 0; r < nbp - 1; ++r) HIP_TRY(launch_block_round(r));
+    } else
     for (int r = 0; r < np - 1; ++r)
       hipLaunchKernelGGL(jacobi_round_kernel, dim3(np / 2), dim3(256), 0, s, W, (long long)ldw, (long long)len, Vt, nvec, np, r, tol, floor2, d_off);
     HIP_TRY(hipGetLastError());

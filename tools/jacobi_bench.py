@@ -15,7 +15,8 @@ from quemb_amd._lib import DeviceBuffer, check
 
 lib = _lib.init(0)
 rng = np.random.default_rng(1)
-for n in (97, 130, 220, 300, 511, 512, 600):
+sizes = [int(a) for a in sys.argv[1:]] or [97, 130, 220, 300, 511, 512, 600]
+for n in sizes:
     A = rng.standard_normal((n, n)); A = 0.5 * (A + A.T) + np.diag(np.arange(n) * 0.7)
     w_ref = np.linalg.eigvalsh(A)
     out = {}
@@ -32,4 +33,4 @@ for n in (97, 130, 220, 300, 511, 512, 600):
         out[label] = dict(ms=round(dt * 1e3, 3), sweeps=sw.value, residual=float(res), orth=float(orth), eig_err=float(np.abs(np.sort(w) - np.linalg.eigvalsh(M)).max()))
         for b in (dA, dw, dV):
             b.free()
-    print(json.dumps(dict(n=n, fused=os.environ.get("QEMB_JACOBI_FUSED", "1"), **out)), flush=True)
+    print(json.dumps(dict(n=n, block_rounds=os.environ.get("QEMB_JACOBI_BLOCK", "1"), **out)), flush=True)
