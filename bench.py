@@ -65,6 +65,7 @@ def parse():
     ap.add_argument("--nocc", type=int, default=20)
     ap.add_argument("--scale", type=float, default=0.03)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-octane", action="store_true", help="skip the small-fragment figure (octane BE2 sweep) beside the headline")
     ap.add_argument("--cpu-iters", type=int, default=2, help="amplitude updates per worker timed by the CPU baseline")
     ap.add_argument("--cpu-ompnum", type=int, default=4, help="BLAS threads per CPU worker (the reference's `ompnum`)")
     ap.add_argument("--full-n", type=int, default=FULL_N, help="fragment size of the full-solve CPU baseline sample")
@@ -448,6 +449,37 @@ def roofline_pass(lib, fr, h, dm0, o, opts, iters):
     return dict(ladder_ms=lad[0] / max(lad[1], 1), ladder_count=lad[1], rings_ms=ring[0] / max(ring[1], 1), iter_ms=it[0] / max(it[1], 1))
 
 
+def octane_sweeps(lib, reps=3):
+    """BASELINE configs[1] beside the headline: one octane/STO-3G BE2 sweep (six fragments of ~40 embedding orbitals; integrals, RHF and
+    fragmentation from the in-tree source, tests/golden/) through the product -- fragment by fragment, six fragments in flight on separate
+    streams, and all fragments in ONE lock-step batched call (qemb_frag_solve_batch: one grouped launch per operation of the CCSD update
+    for all fragments).  The three sweeps return bit-identical energies."""
+    from quemb_amd.fragpart import FragPart
+    from quemb_amd.integrals import RHF, Mole
+    from quemb_amd.mbe import BE
+    G = ROOT / "tests" / "golden"
+    mf = RHF(Mole(G / "octane.xyz")); mf.kernel()
+    out = {}
+    energies = []
+    for label, kw in (("serial", dict(nstreams=1)), ("streams6", dict(nstreams=6)), ("lockstep", dict(lockstep=True))):
+        be = BE(mf, FragPart.from_json(G / "fragmentation.json", "test_autogen_octane_be2"), distribute=False, lib=lib, **kw)
+        be.oneshot()
+        be.stats.clear()
+        lib.qemb_device_sync(); t0 = time.perf_counter()
+        for _ in range(reps):
+            e, _ = be.oneshot()
+        lib.qemb_device_sync()
+        out[label + "_ms"] = (time.perf_counter() - t0) / reps * 1e3
+        energies.append(e)
+        if label == "lockstep":
+            out["lockstep_launch_stats"] = {k: int(v) for k, v in be.stats.items() if k in ("merged_runs", "launches", "grouped_launches", "operations", "max_group")}
+    out["e_corr"] = energies[0]
+    out["bit_identical"] = bool(energies[0] == energies[1] == energies[2])
+    out["fragments"] = 6
+    out["what"] = "octane/STO-3G BE2 one-shot sweep (example/molbe_octane.py): fragment RHF + MO transformation + RCCSD + RDMs + energies for every fragment"
+    return out
+
+
 # ------------------------------------------------------------------------------------------------------------ main
 def main():
     global FULL_N, FULL_O, FULL_NF
@@ -636,6 +668,14 @@ def main():
                 res["parity_max_abs_err_Eh"] = parity_probe()
             except Exception as e:  # noqa: BLE001
                 res["parity_max_abs_err_Eh"] = f"probe failed: {e}"
+            if not args.no_octane and not args.lib:
+                log("small-fragment regime: octane BE2 sweeps")
+                try:
+                    oc = octane_sweeps(lib)
+                    res["octane_be2_sweep_ms"] = min(oc["streams6_ms"], oc["lockstep_ms"])
+                    res["octane_be2"] = oc
+                except Exception as e:  # noqa: BLE001
+                    res["octane_be2_sweep_ms"] = f"failed: {e}"
             if not args.no_cpu_baseline:
                 info, e_dev, e_cpu = cpu_baseline(lib, fr0.dev, h0, dm00, o, opts, args.cpu_iters, args.cpu_ompnum, args.scale)
                 res["cpu_baseline"] = info

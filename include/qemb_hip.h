@@ -106,6 +106,18 @@ int qemb_frag_solve(qemb_frag_t f, int nsocc, const double* h, const double* dm0
                     int eeval, double* mo_coeff, double* mo_energy, double* rdm1_emb, double* rdm1_mo, double* t1,
                     double* t2, double* e_frag, double* e_corr_mo, double* e_scf, double* ebe_hf, int* n_iter,
                     int* scf_cycles);
+/* Every fragment of a sweep in ONE call -- the "batched variant over a list of fragments per device" of the solver seam (the
+ * reference's pool of workers, molbe/be_parallel.py:484-517).  Small fragments (octane BE2: six fragments of ~40 orbitals) are bound by the
+ * NUMBER of dependent kernel launches, ~110 per CCSD iteration at 4-5 us each whatever the size: here the fragment RHF, the MO transformation
+ * and the density / energy evaluation run per fragment on one stream each, and the CCSD iterations of all fragments run in lock step -- every
+ * operation of the amplitude update is ONE grouped launch over all fragments still iterating.  Each fragment performs exactly the operations of
+ * qemb_frag_solve in the same order: results are bit-identical.  Arguments are arrays over the fragments (pointer arrays and their entries may
+ * be NULL where qemb_frag_solve allows NULL); e_frag is 3 * nfrag.  stats (nullable, 5 values): merged launch sequences run, launches they
+ * issued, of which grouped, recorded operations they covered, largest number of fragments in one sequence.                               */
+int qemb_frag_solve_batch(int nfrag, const qemb_frag_t* frags, const int* nsocc, const double* const* h, const double* const* dm0,
+                          const qemb_solver_opts* opts, int eeval, double* const* mo_coeff, double* const* mo_energy,
+                          double* const* rdm1_emb, double* const* rdm1_mo, double* const* t1, double* const* t2, double* e_frag,
+                          double* e_corr_mo, double* e_scf, double* ebe_hf, int* n_iter, int* scf_cycles, int64_t* stats);
 /* number of Lambda iterations of the last qemb_frag_solve with relax_density (0 otherwise) */
 int qemb_frag_lambda_iters(qemb_frag_t f, int* n_iter);
 /* fragment RHF only: get_scfObj(fock + heff, eri, nocc, dm0) of molbe/helper.py:73-151 as used by

@@ -130,6 +130,7 @@ def _declare(lib):
     f("qemb_frag_jk", I, V, P, P, P)
     f("qemb_frag_solve", I, V, I, P, P, OP, I, P, P, P, P, P, P, P, DP, DP, DP, IP, IP)
     f("qemb_frag_lambda_iters", I, P, C.POINTER(C.c_int))
+    f("qemb_frag_solve_batch", I, I, P, IP, P, P, OP, I, P, P, P, P, P, P, P, P, P, P, IP, IP, C.POINTER(L))
     f("qemb_frag_scf", I, V, I, P, P, OP, P, P, P, P, DP, IP, IP)
     f("qemb_frag_cphf", I, V, I, P, P, OP, P, I, P)
     f("qemb_ccsd_solve", I, I, I, I, P, P, P, OP, P, P, D, IP, I, P, P, P, P, P, P, DP, IP)

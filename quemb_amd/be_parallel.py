@@ -117,7 +117,7 @@ def all_reduce_bytes(n_values: int) -> int:
 
 def be_func_parallel(pot, Fobjs, Nocc, solver, enuc, solver_args=None, scratch_dir=None, only_chem=False, eeval=False,
                      relax_density=False, return_vec=False, use_cumulant=True, nproc=1, ompnum=1, *, owner=None, opts=None,
-                     stats=None, emap=None, nstreams=1):
+                     stats=None, emap=None, nstreams=1, lockstep=False):
     """Same return contract as be_func (molbe/be_parallel.py:413-553).  `Fobjs` is the full fragment list on every
     rank; only the fragments with owner[i] == rank need device state (fock / ERIs) on this rank."""
     if solver != "CCSD":
@@ -129,15 +129,10 @@ def be_func_parallel(pot, Fobjs, Nocc, solver, enuc, solver_args=None, scratch_d
     emap = emap or ErrorMap(Fobjs)
     nm = emap.n_match
     buf = np.zeros(2 * nm + 5)
-    from .solver import map_fragments
-
-    def one(f):
-        if pot is not None:
-            f.update_heff(pot, only_chem=only_chem)
-        return f.solve(opts=opts, eeval=eeval, use_cumulant=use_cumulant, relax_density=relax_density)
+    from .solver import solve_fragments
     err = None
     try:
-        for out in map_fragments(one, [Fobjs[i] for i in mine], nstreams):
+        for out in solve_fragments(pot, [Fobjs[i] for i in mine], only_chem, opts, eeval, use_cumulant, relax_density, nstreams, lockstep, stats):
             buf[2 * nm + 4] += out["n_iter"]
             if eeval:
                 buf[2 * nm + 1: 2 * nm + 4] += out["e_frag"]

@@ -2,6 +2,7 @@
 // Thin argument marshalling only; the work is in the drivers (ccsd.cpp, scf.cpp, ao2mo.cpp, schmidt.cpp)
 // and the device layer (dev_ops.h).
 #include <cstring>
+#include <vector>
 #include "../../include/qemb_hip_ops.h"
 #include "dev_ops.h"
 #include "ccsd.h"
@@ -229,6 +230,37 @@ int qemb_frag_solve(qemb_frag_t f, int nsocc, const double* h, const double* dm0
   if (e_scf) *e_scf = r.e_scf;
   if (ebe_hf) *ebe_hf = r.ebe_hf;
   return rc;        // QEMB_OK, or QEMB_WARN_NOCONV with strict_convergence = 0
+}
+int qemb_frag_solve_batch(int nfrag, const qemb_frag_t* frags, const int* nsocc, const double* const* h, const double* const* dm0,
+                          const qemb_solver_opts* opts, int eeval, double* const* mo_coeff, double* const* mo_energy,
+                          double* const* rdm1_emb, double* const* rdm1_mo, double* const* t1, double* const* t2, double* e_frag,
+                          double* e_corr_mo, double* e_scf, double* ebe_hf, int* n_iter, int* scf_cycles, int64_t* stats) {
+  if (nfrag < 0 || (nfrag > 0 && (!frags || !nsocc || !h))) { set_error("qemb_frag_solve_batch: bad arguments"); return QEMB_ERR_ARG; }
+  CHECK_OPTS(opts);
+  std::vector<Fragment*> frs; std::vector<int> o; std::vector<const double*> hs, dms; std::vector<Fragment::BatchOutputs> outs(nfrag);
+  for (int f = 0; f < nfrag; ++f) {
+    if (!frags[f] || !h[f]) { set_error("qemb_frag_solve_batch: null fragment handle or h"); return QEMB_ERR_ARG; }
+    for (int g = 0; g < f; ++g) if (frags[g] == frags[f]) { set_error("qemb_frag_solve_batch: the same fragment twice"); return QEMB_ERR_ARG; }
+    frs.push_back(FRAG(frags[f])); o.push_back(nsocc[f]); hs.push_back(h[f]); dms.push_back(dm0 ? dm0[f] : nullptr);
+    auto pick = [&](double* const* arr) { return arr ? arr[f] : nullptr; };
+    outs[f].mo_coeff = pick(mo_coeff); outs[f].mo_energy = pick(mo_energy); outs[f].rdm1_emb = pick(rdm1_emb);
+    outs[f].rdm1_mo = pick(rdm1_mo); outs[f].t1 = pick(t1); outs[f].t2 = pick(t2);
+  }
+  std::vector<FragmentResult> res;
+  LockstepStats st;
+  const int rc = Fragment::solve_batch(frs, o, hs, dms, to_opts(opts), eeval, res, outs, &st);
+  for (int f = 0; f < nfrag && f < (int)res.size(); ++f) {
+    if (n_iter) n_iter[f] = res[f].n_iter;
+    if (scf_cycles) scf_cycles[f] = res[f].scf_cycles;
+    frs[f]->last_lambda_iters = res[f].lambda_iters;
+    if (rc < 0) continue;
+    if (e_frag) for (int k = 0; k < 3; ++k) e_frag[3 * f + k] = res[f].e_frag[k];
+    if (e_corr_mo) e_corr_mo[f] = res[f].e_corr_mo;
+    if (e_scf) e_scf[f] = res[f].e_scf;
+    if (ebe_hf) ebe_hf[f] = res[f].ebe_hf;
+  }
+  if (stats) { stats[0] = st.merged_runs; stats[1] = st.launches; stats[2] = st.grouped; stats[3] = st.operations; stats[4] = st.max_group; }
+  return rc;
 }
 int qemb_frag_lambda_iters(qemb_frag_t f, int* n_iter) { CHECK_FRAG(f); if (n_iter) *n_iter = FRAG(f)->last_lambda_iters; return QEMB_OK; }
 int qemb_frag_scf(qemb_frag_t f, int nsocc, const double* h, const double* dm0, const qemb_solver_opts* opts, double* mo_coeff,

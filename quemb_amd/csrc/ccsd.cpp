@@ -15,6 +15,7 @@
 //   U accumulates every term that enters t2new as P(X) = X_ijab + X_jiba; it is symmetrised once.
 #include "ccsd.h"
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -419,11 +420,19 @@ int CcsdSolver::update_amps(double* t1n, double* t2n) {
 }
 
 int CcsdSolver::iterate(double* e_corr, double* normt) {
-  const int64_t na = n_amp();
   TimerScope lap_ITER(TIMER_ITER);
-  // Launch-bound regime (small fragments): record update_amps once (after one eager pass has settled every workspace)
-  // and replay it as a hipGraph.  Large fragments are GEMM bound and keep the eager path with its per-kernel timers.
-  // (hipGraph replay under rocprofv3's kernel tracing aborts inside the profiler on this ROCm: fall back to eager launches there)
+  QTRY(iterate_update(false, false, nullptr));
+  QTRY(iterate_post(e_corr, normt));
+  QTRY(lap_ITER.close());
+  return 0;
+}
+
+// The amplitude update of one iteration.  Launch-bound regime (small fragments): update_amps is recorded once (after one eager pass has
+// settled every workspace) and replayed -- as an executable hipGraph, or, in the lock-step sweep over several fragments (prefer_tape), as
+// a TAPE that dev_tape_run executes together with the other fragments' tapes.  defer_tape: when the tape exists, do not run it -- the
+// caller runs it grouped (*deferred = true).  Large fragments are GEMM bound and keep the eager path with its per-kernel timers.
+// (hipGraph replay under rocprofv3's kernel tracing aborts inside the profiler on this ROCm: fall back to eager launches there)
+int CcsdSolver::iterate_update(bool prefer_tape, bool defer_tape, bool* deferred) {
   static const bool graphs_enabled = [] {
     const char* e = std::getenv("QEMB_GRAPH");
     if (e) return e[0] != '0';
@@ -431,16 +440,29 @@ int CcsdSolver::iterate(double* e_corr, double* normt) {
     if (std::getenv("ROCP_TOOL_LIBRARIES") || (pre && std::strstr(pre, "rocprofiler"))) return false;
     return true;
   }();
+  static const bool tape_replay = std::getenv("QEMB_TAPE") != nullptr;      // diagnostic: replay the captured sequence through dev_tape_run (one tape)
+  if (deferred) *deferred = false;
   const bool small = (int64_t)o_ * o_ * v_ * v_ <= (int64_t)1 << 22;
   // With DIIS the new amplitudes and their error vector go straight into the storage of the next DIIS slot (no staging copies);
-  // the graph replay of small fragments has its output address baked in and keeps the staging buffer.
+  // the replay of small fragments has its output address baked in and keeps the staging buffer.
   const bool use_diis = !first_ && !diis_.empty();
-  double* out = (use_diis && !(graphs_enabled && small && graph_ok_)) ? diis_[0].next_x() : ampn_.p;
-  if (graphs_enabled && small && graph_ok_ && graph_) {
+  const bool replayable = graphs_enabled && small && graph_ok_;
+  double* out = (use_diis && !replayable) ? diis_[0].next_x() : ampn_.p;
+  last_out_ = out; last_use_diis_ = use_diis; last_replayable_ = replayable;
+  if (replayable && tape_) {
+    if (defer_tape && deferred) { *deferred = true; return 0; }
+    QTRY(dev_tape_run(&tape_, 1));
+  } else if (replayable && graph_) {
     QTRY(dev_graph_launch(graph_));
-  } else if (graphs_enabled && small && graph_ok_ && eager_iters_ >= 1) {
+  } else if (replayable && eager_iters_ >= 1) {
     const int rc = dev_graph_begin();
-    if (rc == 0) {
+    if (rc == 0 && (prefer_tape || tape_replay)) {
+      const int rc2 = update_amps(ampn_.p, ampn_.p + (int64_t)o_ * v_);
+      dev_tape_t t = nullptr;
+      const int rc3 = dev_tape_end(&t);
+      if (rc2 || rc3) { graph_ok_ = false; if (t) dev_tape_destroy(t); if (rc2) return rc2; if (rc3 < 0) return rc3; QTRY(update_amps(ampn_.p, ampn_.p + (int64_t)o_ * v_)); }
+      else { tape_ = t; QTRY(dev_tape_run(&tape_, 1)); }
+    } else if (rc == 0) {
       const int rc2 = update_amps(ampn_.p, ampn_.p + (int64_t)o_ * v_);
       dev_graph_t g = nullptr;
       const int rc3 = dev_graph_end(&g);
@@ -454,24 +476,159 @@ int CcsdSolver::iterate(double* e_corr, double* normt) {
     QTRY(update_amps(out, out + (int64_t)o_ * v_));
     ++eager_iters_;
   }
-  // diff = t_new - t (also the DIIS error vector: trial minus previously returned vector)
+  return 0;
+}
+
+// Lock-step sweeps: record the tape BEFORE the first iteration, on the fragment's own thread and stream (so that the fragments do this side
+// by side).  One eager update_amps into the staging buffer settles the workspaces -- it reads the amplitudes and writes only scratch, the
+// solver's state is what it was -- and the capture that follows records the launch sequence without executing it.  Every iteration of the
+// solve, the first included, then runs from the tape.  A fragment that is not in the replay regime (large, or graphs disabled) is left alone.
+int CcsdSolver::prepare_tape() {
+  const bool use_diis = false;
+  (void)use_diis;
+  bool deferred = false;
+  if (tape_ || !graph_ok_) return 0;
+  // same predicate as iterate_update
+  const bool small = (int64_t)o_ * o_ * v_ * v_ <= (int64_t)1 << 22;
+  static const bool graphs_enabled = [] {
+    const char* e = std::getenv("QEMB_GRAPH");
+    if (e) return e[0] != '0';
+    const char* pre = std::getenv("LD_PRELOAD");
+    if (std::getenv("ROCP_TOOL_LIBRARIES") || (pre && std::strstr(pre, "rocprofiler"))) return false;
+    return true;
+  }();
+  if (!(graphs_enabled && small)) return 0;
+  (void)deferred;
+  QTRY(update_amps(ampn_.p, ampn_.p + (int64_t)o_ * v_));      // dry pass: workspaces
+  ++eager_iters_;
+  const int rc = dev_graph_begin();
+  if (rc != 0) { graph_ok_ = false; return rc < 0 ? rc : 0; }
+  const int rc2 = update_amps(ampn_.p, ampn_.p + (int64_t)o_ * v_);
+  dev_tape_t t = nullptr;
+  const int rc3 = dev_tape_end(&t);
+  if (rc2 || rc3) { graph_ok_ = false; if (t) dev_tape_destroy(t); if (rc2) return rc2; return rc3 < 0 ? rc3 : 0; }
+  tape_ = t;
+  return 0;
+}
+
+// DIIS and energy of the iteration whose update iterate_update issued (or that ran as part of a grouped tape run), in three steps with a
+// wait of this context's stream between them (iterate_post); the lock-step sweep runs each step for all fragments before the next, so the
+// fragments' streams work side by side and the host waits once per step and fragment instead of serialising whole post phases.
+int CcsdSolver::iterate_post(double* e_corr, double* normt) {
+  QTRY(post_issue());
+  QTRY(dev_sync());
+  QTRY(post_extrapolate(normt));
+  QTRY(dev_sync());
+  return post_energy(e_corr);
+}
+// step 1: diff = t_new - t (also the DIIS error vector: trial minus previously returned vector); its Gram row on the way to the host
+int CcsdSolver::post_issue() {
+  const int64_t na = n_amp();
+  const bool use_diis = last_use_diis_;
+  double* out = last_out_;
+  if (!host_scal_) { void* q = nullptr; QTRY(dev_pinned_alloc(&q, 4 * sizeof(double))); host_scal_ = (double*)q; }
   double* err = use_diis ? diis_[0].next_e() : diff_.p;
   QTRY(lincomb2(na, 1.0, out, -1.0, amp_, err));
-  double nn = 0.0;
   if (use_diis) {
-    // |t_new - t|^2 is the diagonal of the DIIS Gram row (same reduction, same bits as dev_dot): no separate pass, no second sync
+    // |t_new - t|^2 is the diagonal of the DIIS Gram row (same reduction, same bits as dev_dot): no separate pass
     if (out != diis_[0].next_x()) QTRY(dcopy(na, out, diis_[0].next_x()));
-    QTRY(diis_[0].extrapolate_pushed(amp_, false, &nn));
+    QTRY(diis_[0].gram_issue());
   } else {
     QTRY(dev_dot(na, err, err, scal_.p + 1));
     QTRY(dcopy(na, out, amp_));
-    QTRY(dev_d2h(&nn, scal_.p + 1, sizeof(double)));
+    QTRY(dev_d2h_async(host_scal_ + 1, scal_.p + 1, sizeof(double)));
   }
+  return 0;
+}
+// step 2 (after a wait): the DIIS solve on the host, the extrapolated amplitudes, and the energy reduction on its way to the host
+int CcsdSolver::post_extrapolate(double* normt) {
+  double nn = 0.0;
+  if (last_use_diis_) QTRY(diis_[0].gram_finish(amp_, false, &nn));
+  else nn = host_scal_[1];
   first_ = false;
   *normt = std::sqrt(nn);
-  QTRY(energy(t1(), t2(), &ecc_));
+  // E = sum (2 ovov[iajb] - ovov[ibja]) tau[ijab] = <Loovv, tau>   (f_ov = 0)
+  QTRY(make_tau(t1(), t2(), tau_));
+  QTRY(dev_dot((int64_t)o_ * o_ * v_ * v_, Loovv_, tau_, scal_));
+  QTRY(dev_d2h_async(host_scal_, scal_, sizeof(double)));
+  return 0;
+}
+// step 3 (after a wait)
+int CcsdSolver::post_energy(double* e_corr) {
+  ecc_ = host_scal_[0];
   *e_corr = ecc_;
-  QTRY(lap_ITER.close());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Several fragments in LOCK STEP (the small-fragment regime: octane BE2 has six fragments of ~40 orbitals whose iterations are ~110
+// dependent launches of 4-5 us each, whatever the fragment count).  Control flow of CcsdSolver::kernel for every solver at once; per
+// iteration the update_amps launch sequences of all still-iterating fragments run as ONE merged sequence (dev_tape_run: the same kernel of
+// several fragments = one grouped launch), then each fragment does its own DIIS step and energy.  Every fragment performs exactly the
+// operations of its own kernel() in the same order -- results are bit-identical to the one-by-one sweep.
+// ctx[f]: the execution context (stream + workspaces) fragment f was prepared on and keeps for its own steps; the grouped launches run
+// on the calling thread's context, which is restored on return.
+int ccsd_kernel_lockstep(const std::vector<CcsdSolver*>& s, const std::vector<CcsdOptions>& opt, const std::vector<int>& ctx, int home_ctx,
+                         std::vector<double>& e_corr, std::vector<int>& n_iter, std::vector<char>& converged, LockstepStats* stats) {
+  const int F = (int)s.size();
+  e_corr.assign(F, 0.0); n_iter.assign(F, 0); converged.assign(F, 0);
+  std::vector<double> eold(F), e(F), normt(F, 0.0);
+  std::vector<char> active(F, 1);
+  struct Rebind { int home; ~Rebind() { (void)dev_ctx_bind(home); } } rebind{home_ctx};
+  for (int f = 0; f < F; ++f) {
+    QTRY(dev_ctx_bind(ctx[f]));
+    s[f]->diis_.clear();
+    if (opt[f].diis_space > 1) { s[f]->diis_.emplace_back(opt[f].diis_space, s[f]->n_amp()); QTRY(s[f]->diis_[0].init()); }
+    eold[f] = e[f] = s[f]->ecc_;
+  }
+  int max_cycle = 0;
+  for (int f = 0; f < F; ++f) max_cycle = std::max(max_cycle, opt[f].max_cycle);
+  for (int it = 1; it <= max_cycle; ++it) {
+    std::vector<dev_tape_t> tapes;
+    bool any = false;
+    for (int f = 0; f < F; ++f) {
+      if (!active[f]) continue;
+      any = true;
+      QTRY(dev_ctx_bind(ctx[f]));
+      bool deferred = false;
+      QTRY(s[f]->iterate_update(true, true, &deferred));
+      if (deferred) tapes.push_back(s[f]->tape_);
+    }
+    if (!any) break;
+    // the fragments' own streams must have finished what the tapes read (the previous post steps end with a host sync; an eager or
+    // capturing update above is followed by its own post step below, which syncs too) -- and the merged run must finish before the post steps
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
+    if (!tapes.empty()) {
+      QTRY(dev_ctx_bind(home_ctx));
+      QTRY(dev_tape_run(tapes.data(), (int)tapes.size()));
+      if (stats) {
+        long long l = 0, g = 0, ops = 0;
+        (void)dev_tape_last_stats(&l, &g, &ops);
+        stats->launches += l; stats->grouped += g; stats->operations += ops; stats->merged_runs += 1;
+        stats->max_group = std::max<long long>(stats->max_group, (long long)tapes.size());
+      }
+      QTRY(dev_sync());
+    }
+    const double t1 = now();
+    if (stats) stats->ms_tapes += t1 - t0;
+    struct PostTime { LockstepStats* st; double t1; double (*now)(); ~PostTime() { if (st) st->ms_post += now() - t1; } } post_time{stats, t1, +now};
+    for (int f = 0; f < F; ++f) if (active[f]) { QTRY(dev_ctx_bind(ctx[f])); QTRY(s[f]->post_issue()); }
+    for (int f = 0; f < F; ++f) if (active[f]) { QTRY(dev_ctx_bind(ctx[f])); QTRY(dev_sync()); QTRY(s[f]->post_extrapolate(&normt[f])); }
+    for (int f = 0; f < F; ++f) {
+      if (!active[f]) continue;
+      QTRY(dev_ctx_bind(ctx[f]));
+      QTRY(dev_sync());
+      QTRY(s[f]->post_energy(&e[f]));
+      n_iter[f] = it;
+      if (opt[f].verbose > 0) std::fprintf(stderr, "[qemb ccsd lockstep] frag %d cycle %3d  E(corr) = %.12f  dE = %.3e  |dt| = %.3e\n", f, it, e[f], e[f] - eold[f], normt[f]);
+      if (!std::isfinite(e[f])) { set_error("CCSD diverged (non-finite energy)"); return QEMB_ERR_NUMERIC; }
+      if (std::fabs(e[f] - eold[f]) < opt[f].conv_tol && normt[f] < opt[f].conv_tol_normt) { converged[f] = 1; active[f] = 0; }
+      else if (it >= opt[f].max_cycle) active[f] = 0;
+      eold[f] = e[f];
+    }
+  }
+  for (int f = 0; f < F; ++f) { e_corr[f] = e[f]; s[f]->diis_.clear(); }
   return 0;
 }
 

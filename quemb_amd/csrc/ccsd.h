@@ -37,13 +37,26 @@ int mo_transform(int n, int o, int nf, const double* eri_s4, double* X0, double*
 
 class CcLambda;
 
+struct LockstepStats { long long merged_runs = 0, launches = 0, grouped = 0, operations = 0, max_group = 0; double ms_tapes = 0.0, ms_post = 0.0; };
+class CcsdSolver;
+int ccsd_kernel_lockstep(const std::vector<CcsdSolver*>& s, const std::vector<CcsdOptions>& opt, const std::vector<int>& ctx, int home_ctx,
+                         std::vector<double>& e_corr, std::vector<int>& n_iter, std::vector<char>& converged, LockstepStats* stats);
+
 class CcsdSolver {
   friend class CcLambda;
+  friend int ccsd_kernel_lockstep(const std::vector<CcsdSolver*>&, const std::vector<CcsdOptions>&, const std::vector<int>&, int,
+                                  std::vector<double>&, std::vector<int>&, std::vector<char>&, LockstepStats*);
  public:
   int setup(MoIntegrals&& ints, const double* mo_energy_dev);
   int init_amps();                                  // MP2 guess (t1 = 0 for the diagonal Fock)
   int set_amps(const double* t1_dev, const double* t2_dev);   // warm start
   int iterate(double* e_corr, double* normt);       // one update_amps + DIIS + energy
+  int iterate_update(bool prefer_tape, bool defer_tape, bool* deferred);   // the two halves of iterate(), for the lock-step sweep
+  int iterate_post(double* e_corr, double* normt);
+  int post_issue();                                 // iterate_post in three steps (a wait of this context's stream between them)
+  int post_extrapolate(double* normt);
+  int post_energy(double* e_corr);
+  int prepare_tape();                               // record the update as a tape before the first iteration (lock-step sweeps)
   int kernel(const CcsdOptions& opt, double* e_corr, int* n_iter, bool* converged);
   // energy pieces of get_frag_energy that need t1,t2: Z1[i,P], Z2[a,P] (host outputs o*nf and v*nf)
   int energy_intermediates(std::vector<double>& Z1, std::vector<double>& Z2);
@@ -86,10 +99,14 @@ class CcsdSolver {
   bool first_ = true;
   // hipGraph of one update_amps (small fragments are launch bound: ~170 launches of a few microseconds each)
   dev_graph_t graph_ = nullptr;
+  dev_tape_t tape_ = nullptr;       // the same launch sequence as data (dev_tape_end): executed together with other fragments' tapes
   int eager_iters_ = 0;
   bool graph_ok_ = true;
+  double* last_out_ = nullptr;      // where iterate_update put the new amplitudes; iterate_post continues from there
+  double* host_scal_ = nullptr;     // pinned: [energy, |dt|^2] on their way back
+  bool last_use_diis_ = false, last_replayable_ = false;
  public:
-  ~CcsdSolver() { if (graph_) dev_graph_destroy(graph_); }
+  ~CcsdSolver() { if (graph_) dev_graph_destroy(graph_); if (tape_) dev_tape_destroy(tape_); if (host_scal_) dev_pinned_free(host_scal_); }
   CcsdSolver() = default;
   CcsdSolver(const CcsdSolver&) = delete;
   CcsdSolver& operator=(const CcsdSolver&) = delete;

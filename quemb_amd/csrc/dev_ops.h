@@ -36,6 +36,11 @@ int dev_free(void* p);                // parks the block in a free list (see dev
 int dev_trim();                       // release every parked block back to the driver
 int dev_h2d(void* dst, const void* src_host, size_t bytes);
 int dev_d2h(void* dst_host, const void* src, size_t bytes);
+// device -> PINNED host memory without waiting: the data are there after the next dev_sync of the calling context (lock-step sweeps read
+// the scalars of several fragments' streams with one wait each instead of one per transfer)
+int dev_d2h_async(void* dst_pinned, const void* src, size_t bytes);
+int dev_pinned_alloc(void** p, size_t bytes);
+int dev_pinned_free(void* p);
 int dev_d2d(void* dst, const void* src, size_t bytes);
 int dev_fill(double* x, int64_t n, double value);
 int dev_mem_info(size_t* free_b, size_t* total_b);
@@ -51,6 +56,17 @@ int dev_graph_end(dev_graph_t* out);
 int dev_graph_launch(dev_graph_t g);
 int dev_graph_destroy(dev_graph_t g);
 bool dev_capturing();
+// A capture can also end as a TAPE: the recorded launch sequence kept as data (kernel, grid, arguments; copies) instead of an executable
+// graph, so that the tapes of SEVERAL fragments can be executed together on one stream, position by position -- launches of the same kernel
+// at the same position become ONE grouped launch over all fragments (dev_tape_run).  Small fragments are bound by the number of dependent
+// launches (4-5 us each whatever their size): F fragments in lock step cost the launches of one.  dev_tape_end returns 1 (not an error) when the
+// backend cannot tape; the caller then keeps the per-fragment path.
+typedef void* dev_tape_t;
+int dev_tape_end(dev_tape_t* out);
+int dev_tape_run(const dev_tape_t* tapes, int n);          // on the calling thread's stream; the tapes stay valid and may be run again
+int dev_tape_destroy(dev_tape_t t);
+// counters of the calling thread's last dev_tape_run: launches issued, of which grouped, recorded operations covered
+int dev_tape_last_stats(long long* launches, long long* grouped, long long* operations);
 
 // ---- timing (HIP events on the library stream) ------------------------------------------------
 // A "lap" accumulates elapsed device time of every region bracketed with the same slot id.

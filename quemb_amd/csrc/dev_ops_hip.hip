@@ -16,9 +16,11 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <type_traits>
 #include <vector>
 #include "dev_ops.h"
 #include "hip_common.h"
+#include "grouped_launch.h"
 
 namespace qemb {
 
@@ -229,6 +231,13 @@ int dev_d2h(void* dst, const void* src, size_t bytes) {
   HIP_TRY(hipStreamSynchronize(g_stream));
   return QEMB_OK;
 }
+int dev_d2h_async(void* dst, const void* src, size_t bytes) {
+  REQUIRE_INIT();
+  HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, g_stream));
+  return QEMB_OK;
+}
+int dev_pinned_alloc(void** p, size_t bytes) { REQUIRE_INIT(); HIP_TRY(hipHostMalloc(p, bytes ? bytes : 16, hipHostMallocDefault)); return QEMB_OK; }
+int dev_pinned_free(void* p) { if (p) (void)hipHostFree(p); return QEMB_OK; }
 int dev_d2d(void* dst, const void* src, size_t bytes) {
   REQUIRE_INIT();
   HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, g_stream));
@@ -280,6 +289,214 @@ int dev_graph_end(dev_graph_t* out) {
 }
 int dev_graph_launch(dev_graph_t g) { REQUIRE_INIT(); HIP_TRY(hipGraphLaunch((hipGraphExec_t)g, g_stream)); return QEMB_OK; }
 int dev_graph_destroy(dev_graph_t g) { if (g) (void)hipGraphExecDestroy((hipGraphExec_t)g); return QEMB_OK; }
+
+// ---- grouped launches --------------------------------------------------------------------------------------------------------------
+// A kernel written as `__device__ name_body(BID, GDIM, args...)` + a one-line `__global__ name(args...)` wrapper can also run GROUPED: one
+// launch whose grid is the concatenation of the members' grids; a workgroup finds its member, takes that member's arguments from a table
+// in device memory and runs the body with its block index inside that member.  Kernels are registered by the address of their wrapper,
+// which is what a captured graph node carries.
+std::map<const void*, GroupInfo>& groupable() { static std::map<const void*, GroupInfo> m; return m; }
+void register_groupable_gemm();         // gemm_f64.hip
+static void register_groupable_kernels();   // end of this file (after the kernels)
+
+// ---- tapes: captured launch sequences executed together -------------------------------------------------------------------------------
+// A tape keeps the captured hipGraph alive (it owns the argument storage of its nodes) and lists the nodes in execution order.
+struct TapeNode {
+  hipGraphNodeType type;
+  hipKernelNodeParams k;        // type == Kernel
+  hipMemcpy3DParms cpy;         // type == Memcpy
+  hipMemsetParams set;          // type == Memset
+};
+struct Tape {
+  hipGraph_t graph = nullptr;
+  std::vector<TapeNode> nodes;
+};
+static thread_local long long t_tape_launches = 0, t_tape_grouped = 0, t_tape_ops = 0;
+
+int dev_tape_end(dev_tape_t* out) {
+  REQUIRE_INIT();
+  if (!g_capturing) { set_error("dev_tape_end: not capturing"); return QEMB_ERR_ARG; }
+  g_capturing = false;
+  hipGraph_t graph = nullptr;
+  HIP_TRY(hipStreamEndCapture(g_stream, &graph));
+  auto fail = [&](const std::string& why) { (void)hipGraphDestroy(graph); set_error("dev_tape_end: " + why); return 1; };     // 1: cannot tape (not an error)
+  size_t nn = 0;
+  if (hipGraphGetNodes(graph, nullptr, &nn) != hipSuccess) return fail("hipGraphGetNodes");
+  std::vector<hipGraphNode_t> nodes(nn);
+  if (nn && hipGraphGetNodes(graph, nodes.data(), &nn) != hipSuccess) return fail("hipGraphGetNodes");
+  // execution order: a single-stream capture is a chain; follow the edges from the root
+  size_t ne = 0;
+  if (hipGraphGetEdges(graph, nullptr, nullptr, &ne) != hipSuccess) return fail("hipGraphGetEdges");
+  std::vector<hipGraphNode_t> from(ne), to(ne);
+  if (ne && hipGraphGetEdges(graph, from.data(), to.data(), &ne) != hipSuccess) return fail("hipGraphGetEdges");
+  std::map<hipGraphNode_t, hipGraphNode_t> next;
+  std::map<hipGraphNode_t, int> indeg;
+  for (hipGraphNode_t x : nodes) indeg[x] = 0;
+  for (size_t e = 0; e < ne; ++e) {
+    if (next.count(from[e])) return fail("the captured sequence is not a chain");
+    next[from[e]] = to[e]; indeg[to[e]] += 1;
+  }
+  hipGraphNode_t cur = nullptr;
+  for (hipGraphNode_t x : nodes) if (indeg[x] == 0) { if (cur) return fail("the captured sequence has several roots"); cur = x; }
+  Tape* t = new Tape();
+  t->graph = graph;
+  for (size_t visited = 0; cur && visited < nn; ++visited) {
+    TapeNode tn{};
+    if (hipGraphNodeGetType(cur, &tn.type) != hipSuccess) { delete t; return fail("hipGraphNodeGetType"); }
+    if (tn.type == hipGraphNodeTypeKernel) {
+      if (hipGraphKernelNodeGetParams(cur, &tn.k) != hipSuccess || !tn.k.func || !tn.k.kernelParams) { delete t; return fail("kernel node without parameters"); }
+    } else if (tn.type == hipGraphNodeTypeMemcpy) {
+      if (hipGraphMemcpyNodeGetParams(cur, &tn.cpy) != hipSuccess) { delete t; return fail("hipGraphMemcpyNodeGetParams"); }
+    } else if (tn.type == hipGraphNodeTypeMemset) {
+      if (hipGraphMemsetNodeGetParams(cur, &tn.set) != hipSuccess) { delete t; return fail("hipGraphMemsetNodeGetParams"); }
+    } else if (tn.type != hipGraphNodeTypeEmpty) {
+      delete t; return fail("node type " + std::to_string((int)tn.type) + " cannot be taped");
+    }
+    if (tn.type != hipGraphNodeTypeEmpty) t->nodes.push_back(tn);
+    auto it = next.find(cur);
+    cur = (it == next.end()) ? nullptr : it->second;
+  }
+  if (t->nodes.size() > nn) { delete t; return fail("node walk did not terminate"); }
+  *out = t;
+  return QEMB_OK;
+}
+struct TapePlan;
+static void drop_plans_with(const void* tape);
+int dev_tape_destroy(dev_tape_t tp) {
+  Tape* t = (Tape*)tp;
+  if (t) { drop_plans_with(t); if (t->graph) (void)hipGraphDestroy(t->graph); delete t; }
+  return QEMB_OK;
+}
+static int tape_issue_single(const TapeNode& n, hipStream_t s) {
+  if (n.type == hipGraphNodeTypeKernel) {
+    HIP_TRY(hipLaunchKernel(n.k.func, n.k.gridDim, n.k.blockDim, n.k.kernelParams, n.k.sharedMemBytes, s));
+  } else if (n.type == hipGraphNodeTypeMemcpy) {
+    HIP_TRY(hipMemcpy3DAsync(&n.cpy, s));
+  } else if (n.type == hipGraphNodeTypeMemset) {
+    if (n.set.height <= 1) {
+      if (n.set.elementSize == 1) HIP_TRY(hipMemsetAsync(n.set.dst, (int)n.set.value, n.set.width, s));
+      else if (n.set.elementSize == 4) HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)n.set.dst, (int)n.set.value, n.set.width, s));
+      else { set_error("dev_tape_run: memset element size not handled"); return QEMB_ERR_ARG; }
+    } else { set_error("dev_tape_run: 2-D memset not handled"); return QEMB_ERR_ARG; }
+  }
+  t_tape_launches += 1;
+  return QEMB_OK;
+}
+// What one dev_tape_run of a given set of tapes issues: the launch plan is a function of the tapes alone, so it is built once per set
+// (tables uploaded once) and replayed on every later run of the same set.
+struct PlanStep {
+  bool grouped;
+  const TapeNode* single;       // !grouped
+  const GroupInfo* gi; size_t args_off; unsigned blocks; dim3 block; size_t lds;     // grouped: its argument block inside TapePlan::args
+};
+struct TapePlan {
+  std::vector<const void*> key;
+  std::vector<PlanStep> steps;
+  std::vector<unsigned char> args;      // argument blocks of the grouped launches (host memory: they are passed by value)
+  long long ops = 0, grouped = 0;
+};
+static std::mutex g_plan_mutex;
+static std::vector<TapePlan*> g_plans;        // small: one per distinct set of tapes that ran together
+
+static int build_plan(const dev_tape_t* tapes, int n, TapePlan** out) {
+  static std::once_flag once;
+  std::call_once(once, [] { register_groupable_kernels(); register_groupable_gemm(); });
+  static const bool grouping = !(std::getenv("QEMB_TAPE_GROUP") && std::atoi(std::getenv("QEMB_TAPE_GROUP")) == 0);
+  TapePlan* plan = new TapePlan();
+  for (int f = 0; f < n; ++f) plan->key.push_back(tapes[f]);
+  std::vector<unsigned char>& host = plan->args;
+  auto reserve = [&](size_t bytes) { const size_t off = (host.size() + 15) / 16 * 16; host.resize(off + bytes); return off; };
+  size_t longest = 0;
+  for (int f = 0; f < n; ++f) longest = std::max(longest, ((const Tape*)tapes[f])->nodes.size());
+  for (size_t i = 0; i < longest; ++i) {
+    std::vector<const TapeNode*> here;
+    for (int f = 0; f < n; ++f) { const Tape* t = (const Tape*)tapes[f]; if (i < t->nodes.size()) here.push_back(&t->nodes[i]); }
+    plan->ops += (long long)here.size();
+    std::vector<bool> done(here.size(), false);
+    for (size_t a = 0; a < here.size(); ++a) {
+      if (done[a]) continue;
+      const TapeNode* na = here[a];
+      std::vector<const TapeNode*> grp{na};
+      const GroupInfo* gi = nullptr;
+      if (grouping && na->type == hipGraphNodeTypeKernel) {
+        auto it = groupable().find(na->k.func);
+        if (it != groupable().end()) {
+          gi = &it->second;
+          for (size_t b = a + 1; b < here.size() && (int)grp.size() < GROUP_MAX; ++b) {
+            const TapeNode* nb = here[b];
+            if (!done[b] && nb->type == hipGraphNodeTypeKernel && nb->k.func == na->k.func && nb->k.blockDim.x == na->k.blockDim.x &&
+                nb->k.blockDim.y == na->k.blockDim.y && nb->k.blockDim.z == na->k.blockDim.z) { grp.push_back(nb); done[b] = true; }
+          }
+        }
+      }
+      done[a] = true;
+      PlanStep st{};
+      if (gi && grp.size() >= 2) {
+        st.grouped = true; st.gi = gi; st.block = na->k.blockDim; st.lds = 0;
+        st.args_off = reserve(gi->args_bytes);
+        std::vector<GroupMember> mem;
+        for (const TapeNode* x : grp) {
+          mem.push_back(GroupMember{x->k.kernelParams, x->k.gridDim.x, x->k.gridDim.y, x->k.gridDim.z});
+          st.lds = std::max<size_t>(st.lds, x->k.sharedMemBytes);
+        }
+        st.blocks = gi->build(host.data() + st.args_off, mem.data(), (int)mem.size());
+        plan->grouped += 1;
+        plan->steps.push_back(st);
+      } else {
+        for (const TapeNode* x : grp) { PlanStep s1{}; s1.grouped = false; s1.single = x; plan->steps.push_back(s1); }
+      }
+    }
+  }
+  *out = plan;
+  return QEMB_OK;
+}
+int dev_tape_run(const dev_tape_t* tapes, int n) {
+  REQUIRE_INIT();
+  if (g_capturing) { set_error("dev_tape_run: inside a capture"); return QEMB_ERR_ARG; }
+  if (n <= 0) return QEMB_OK;
+  TapePlan* plan = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(g_plan_mutex);
+    for (TapePlan* p : g_plans) {
+      if ((int)p->key.size() != n) continue;
+      bool same = true;
+      for (int f = 0; f < n && same; ++f) same = (p->key[f] == tapes[f]);
+      if (same) { plan = p; break; }
+    }
+    if (!plan) {
+      int rc = build_plan(tapes, n, &plan);
+      if (rc) return rc;
+      g_plans.push_back(plan);
+    }
+  }
+  t_tape_launches = 0; t_tape_grouped = plan->grouped; t_tape_ops = plan->ops;
+  for (const PlanStep& st : plan->steps) {
+    if (st.grouped) {
+      st.gi->launch(plan->args.data() + st.args_off, st.blocks, st.block, st.lds, g_stream);
+      t_tape_launches += 1;
+    } else {
+      int rc = tape_issue_single(*st.single, g_stream);
+      if (rc) return rc;
+    }
+  }
+  HIP_TRY(hipGetLastError());
+  return QEMB_OK;
+}
+static void drop_plans_with(const void* tape) {
+  std::lock_guard<std::mutex> lock(g_plan_mutex);
+  for (size_t i = 0; i < g_plans.size();) {
+    TapePlan* p = g_plans[i];
+    if (std::find(p->key.begin(), p->key.end(), tape) != p->key.end()) {
+      delete p; g_plans.erase(g_plans.begin() + i);
+    } else ++i;
+  }
+}
+int dev_tape_last_stats(long long* launches, long long* grouped, long long* operations) {
+  if (launches) *launches = t_tape_launches;
+  if (grouped) *grouped = t_tape_grouped;
+  if (operations) *operations = t_tape_ops;
+  return QEMB_OK;
+}
 
 // ---- timers -----------------------------------------------------------------------------------
 static bool timers_enabled() {
@@ -454,11 +671,12 @@ int dev_abs_overlap_prim(int nsh, const int* l, const double* ex, const double* 
 // ------------------------------------------------------------------------------------------------
 // fill
 // ------------------------------------------------------------------------------------------------
-__global__ void fill_kernel(double* x, long long n, double v) {
-  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long stride = (long long)gridDim.x * blockDim.x;
+__device__ __forceinline__ void fill_kernel_body(const uint3 BID, const uint3 GDIM, double* x, long long n, double v) {
+  long long i = (long long)BID.x * blockDim.x + threadIdx.x;
+  const long long stride = (long long)GDIM.x * blockDim.x;
   for (; i < n; i += stride) x[i] = v;
 }
+__global__ void fill_kernel(double* x, long long n, double v) { fill_kernel_body(make_uint3(blockIdx.x, blockIdx.y, blockIdx.z), make_uint3(gridDim.x, gridDim.y, gridDim.z), x, n, v); }
 int dev_fill(double* x, int64_t n, double value) {
   REQUIRE_INIT();
   if (n <= 0) return QEMB_OK;
@@ -479,14 +697,14 @@ struct Copy4K {
   const double* in; double* out; double alpha, beta; const double* base;
 };
 
-__global__ void __launch_bounds__(256) copy4_linear_kernel(Copy4K c) {
+__device__ __forceinline__ void copy4_linear_kernel_body(const uint3 BID, const uint3 GDIM, Copy4K c) {
   // x: combined (i2,i3) index, y: i1, z: i0 (both looped)
   const long long n23 = c.d2 * c.d3;
-  for (long long i0 = blockIdx.z; i0 < c.d0; i0 += gridDim.z) {
-    for (long long i1 = blockIdx.y; i1 < c.d1; i1 += gridDim.y) {
+  for (long long i0 = BID.z; i0 < c.d0; i0 += GDIM.z) {
+    for (long long i1 = BID.y; i1 < c.d1; i1 += GDIM.y) {
       const long long bi = i0 * c.si0 + i1 * c.si1, bo = i0 * c.so0 + i1 * c.so1;
-      for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n23;
-           t += (long long)gridDim.x * blockDim.x) {
+      for (long long t = (long long)BID.x * blockDim.x + threadIdx.x; t < n23;
+           t += (long long)GDIM.x * blockDim.x) {
         const long long i2 = t / c.d3, i3 = t - i2 * c.d3;
         const double v = c.alpha * c.in[bi + i2 * c.si2 + i3 * c.si3];
         const long long off = bo + i2 * c.so2 + i3 * c.so3;
@@ -495,15 +713,16 @@ __global__ void __launch_bounds__(256) copy4_linear_kernel(Copy4K c) {
     }
   }
 }
+__global__ void __launch_bounds__(256) copy4_linear_kernel(Copy4K c) { copy4_linear_kernel_body(make_uint3(blockIdx.x, blockIdx.y, blockIdx.z), make_uint3(gridDim.x, gridDim.y, gridDim.z), c); }
 
 // dims canonicalised so that si3 == 1 (input contiguous along i3) and so2 == 1 (output contiguous along i2)
-__global__ void __launch_bounds__(256) copy4_transpose_kernel(Copy4K c, int tiles3) {
+__device__ __forceinline__ void copy4_transpose_kernel_body(const uint3 BID, const uint3 GDIM, Copy4K c, int tiles3) {
   __shared__ double tile[32][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
-  const long long t2 = blockIdx.x / tiles3, t3 = blockIdx.x % tiles3;
+  const long long t2 = BID.x / tiles3, t3 = BID.x % tiles3;
   const long long base2 = t2 * 32, base3 = t3 * 32;
-  for (long long i0 = blockIdx.z; i0 < c.d0; i0 += gridDim.z) {
-    for (long long i1 = blockIdx.y; i1 < c.d1; i1 += gridDim.y) {
+  for (long long i0 = BID.z; i0 < c.d0; i0 += GDIM.z) {
+    for (long long i1 = BID.y; i1 < c.d1; i1 += GDIM.y) {
       const long long bi = i0 * c.si0 + i1 * c.si1, bo = i0 * c.so0 + i1 * c.so1;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -524,6 +743,7 @@ __global__ void __launch_bounds__(256) copy4_transpose_kernel(Copy4K c, int tile
     }
   }
 }
+__global__ void __launch_bounds__(256) copy4_transpose_kernel(Copy4K c, int tiles3) { copy4_transpose_kernel_body(make_uint3(blockIdx.x, blockIdx.y, blockIdx.z), make_uint3(gridDim.x, gridDim.y, gridDim.z), c, tiles3); }
 
 int dev_copy4(const Copy4Desc& cd) {
   REQUIRE_INIT();
@@ -570,17 +790,18 @@ struct Outer4K {
   long long d0, d1, d2, d3, su0, su2, sv1, sv3, so0, so1, so2, so3;
   const double* u; const double* v; double* out; double alpha, beta; const double* base;
 };
-__global__ void __launch_bounds__(256) outer4_kernel(Outer4K c) {
+__device__ __forceinline__ void outer4_kernel_body(const uint3 BID, const uint3 GDIM, Outer4K c) {
   const long long n23 = c.d2 * c.d3;
-  for (long long i0 = blockIdx.z; i0 < c.d0; i0 += gridDim.z)
-    for (long long i1 = blockIdx.y; i1 < c.d1; i1 += gridDim.y)
-      for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n23; t += (long long)gridDim.x * blockDim.x) {
+  for (long long i0 = BID.z; i0 < c.d0; i0 += GDIM.z)
+    for (long long i1 = BID.y; i1 < c.d1; i1 += GDIM.y)
+      for (long long t = (long long)BID.x * blockDim.x + threadIdx.x; t < n23; t += (long long)GDIM.x * blockDim.x) {
         const long long i2 = t / c.d3, i3 = t - i2 * c.d3;
         const double val = c.alpha * c.u[i0 * c.su0 + i2 * c.su2] * c.v[i1 * c.sv1 + i3 * c.sv3];
         const long long off = i0 * c.so0 + i1 * c.so1 + i2 * c.so2 + i3 * c.so3;
         c.out[off] = (c.beta != 0.0) ? val + c.beta * c.base[off] : val;
       }
 }
+__global__ void __launch_bounds__(256) outer4_kernel(Outer4K c) { outer4_kernel_body(make_uint3(blockIdx.x, blockIdx.y, blockIdx.z), make_uint3(gridDim.x, gridDim.y, gridDim.z), c); }
 int dev_outer4(const Outer4Desc& o) {
   REQUIRE_INIT();
   for (int k = 0; k < 4; ++k) if (o.dim[k] <= 0) return QEMB_OK;
@@ -592,19 +813,21 @@ int dev_outer4(const Outer4Desc& o) {
   return QEMB_OK;
 }
 
-__global__ void __launch_bounds__(256) div_denom_kernel(double* x, long long d0, long long d1, long long d2, long long d3,
+__device__ __forceinline__ void div_denom_kernel_body(const uint3 BID, const uint3 GDIM, double* x, long long d0, long long d1, long long d2, long long d3,
                                                         const double* ea, const double* eb, const double* ec, const double* ed) {
   const long long n23 = d2 * d3;
-  for (long long i0 = blockIdx.z; i0 < d0; i0 += gridDim.z)
-    for (long long i1 = blockIdx.y; i1 < d1; i1 += gridDim.y) {
+  for (long long i0 = BID.z; i0 < d0; i0 += GDIM.z)
+    for (long long i1 = BID.y; i1 < d1; i1 += GDIM.y) {
       const double e01 = ea[i0] + (eb ? eb[i1] : 0.0);
       double* row = x + (i0 * d1 + i1) * n23;
-      for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n23; t += (long long)gridDim.x * blockDim.x) {
+      for (long long t = (long long)BID.x * blockDim.x + threadIdx.x; t < n23; t += (long long)GDIM.x * blockDim.x) {
         const long long i2 = t / d3, i3 = t - i2 * d3;
         row[t] = row[t] / (e01 - ec[i2] - (ed ? ed[i3] : 0.0));
       }
     }
 }
+__global__ void __launch_bounds__(256) div_denom_kernel(double* x, long long d0, long long d1, long long d2, long long d3,
+                                                        const double* ea, const double* eb, const double* ec, const double* ed) { div_denom_kernel_body(make_uint3(blockIdx.x, blockIdx.y, blockIdx.z), make_uint3(gridDim.x, gridDim.y, gridDim.z), x, d0, d1, d2, d3, ea, eb, ec, ed); }
 int dev_div_denom(double* x, int64_t d0, int64_t d1, int64_t d2, int64_t d3, const double* ea, const double* eb, const double* ec, const double* ed) {
   REQUIRE_INIT();
   if (d0 <= 0 || d1 <= 0 || d2 <= 0 || d3 <= 0) return QEMB_OK;
@@ -644,13 +867,13 @@ int dev_mul_bcast_rows(int64_t rows, int64_t cols, double* x, const double* m) {
 
 // one 32 x 32 tile (c-range, b-range) of one (k, j) pair per workgroup: X = t2[k,j] is read as the tile and as the mirrored tile
 // (for the transposed outputs, through LDS), every output tile is written in rows of 32 contiguous doubles
-__global__ void __launch_bounds__(256) ccsd_ph_layouts_kernel(long long o, long long v, const double* __restrict__ t2, const double* __restrict__ t1,
+__device__ __forceinline__ void ccsd_ph_layouts_kernel_body(const uint3 BID, const uint3 GDIM, long long o, long long v, const double* __restrict__ t2, const double* __restrict__ t1,
                                                               double* __restrict__ T, double* __restrict__ Tp, double* __restrict__ S,
                                                               double* __restrict__ Ut, double* __restrict__ Tpt, double* __restrict__ Th, int tiles) {
   __shared__ double xt[32][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
-  const long long tc = blockIdx.x / tiles, tb = blockIdx.x % tiles;
-  const long long k = blockIdx.z, j = blockIdx.y;
+  const long long tc = BID.x / tiles, tb = BID.x % tiles;
+  const long long k = BID.z, j = BID.y;
   const double* __restrict__ X = t2 + (k * o + j) * v * v;
   // mirrored tile: rows b-range, columns c-range -> xt[b_local][c_local]
 #pragma unroll
@@ -677,6 +900,9 @@ __global__ void __launch_bounds__(256) ccsd_ph_layouts_kernel(long long o, long 
     }
   }
 }
+__global__ void __launch_bounds__(256) ccsd_ph_layouts_kernel(long long o, long long v, const double* __restrict__ t2, const double* __restrict__ t1,
+                                                              double* __restrict__ T, double* __restrict__ Tp, double* __restrict__ S,
+                                                              double* __restrict__ Ut, double* __restrict__ Tpt, double* __restrict__ Th, int tiles) { ccsd_ph_layouts_kernel_body(make_uint3(blockIdx.x, blockIdx.y, blockIdx.z), make_uint3(gridDim.x, gridDim.y, gridDim.z), o, v, t2, t1, T, Tp, S, Ut, Tpt, Th, tiles); }
 int dev_ccsd_ph_layouts(int64_t o, int64_t v, const double* t2, const double* t1, double* T, double* Tp, double* S, double* Ut, double* Tpt, double* Th) {
   REQUIRE_INIT();
   if (o <= 0 || v <= 0) return QEMB_OK;
@@ -688,14 +914,14 @@ int dev_ccsd_ph_layouts(int64_t o, int64_t v, const double* t2, const double* t1
   return QEMB_OK;
 }
 
-__global__ void __launch_bounds__(256) small_k_update_kernel(long long M, long long N, long long K, double alpha, const double* __restrict__ A, long long sA,
+__device__ __forceinline__ void small_k_update_kernel_body(const uint3 BID, const uint3 GDIM, long long M, long long N, long long K, double alpha, const double* __restrict__ A, long long sA,
                                                              const double* __restrict__ B, long long sB, double* __restrict__ C, long long sC, int tiles_n) {
   __shared__ double As[32][33], Bs[32][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  const long long tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+  const long long tm = BID.x / tiles_n, tn = BID.x % tiles_n;
   const long long m0 = tm * 32, n0 = tn * 32;
   {
-    const long long z = blockIdx.y;
+    const long long z = BID.y;
     const double* __restrict__ Az = A + z * sA;
     const double* __restrict__ Bz = B + z * sB;
     double* __restrict__ Cz = C + z * sC;
@@ -723,6 +949,8 @@ __global__ void __launch_bounds__(256) small_k_update_kernel(long long M, long l
     }
   }
 }
+__global__ void __launch_bounds__(256) small_k_update_kernel(long long M, long long N, long long K, double alpha, const double* __restrict__ A, long long sA,
+                                                             const double* __restrict__ B, long long sB, double* __restrict__ C, long long sC, int tiles_n) { small_k_update_kernel_body(make_uint3(blockIdx.x, blockIdx.y, blockIdx.z), make_uint3(gridDim.x, gridDim.y, gridDim.z), M, N, K, alpha, A, sA, B, sB, C, sC, tiles_n); }
 // The same update on the matrix pipe (M, N >= 16, K <= 64): 2 K M N flop per batch entry is
 // 6.4 GFLOP for the rank-n_occ updates of the o^2 v^2 tensors -- 100 us of FP64 VALU time, which is what the tile version above and a
 // VALU strip version both take, twice the HBM time of the 256 MB they move.  B[z] (K x N) and the
@@ -730,16 +958,16 @@ __global__ void __launch_bounds__(256) small_k_update_kernel(long long M, long l
 // (v_mfma_f64_16x16x4_f64: A lane l holds A[row = l & 15][k = l >> 4], B lane l holds B[k = l >> 4][col = l & 15], D reg r of lane l is
 // D[row = (l >> 4) + 4 r][col = l & 15]); the read-modify-write of C is 16 lanes x 8 B = 128 contiguous bytes per row.
 typedef double d4v __attribute__((ext_vector_type(4)));
-__global__ void __launch_bounds__(256) small_k_update_mfma_kernel(int M, int N, int K, double alpha, const double* __restrict__ A, long long sA,
+__device__ __forceinline__ void small_k_update_mfma_kernel_body(const uint3 BID, const uint3 GDIM, int M, int N, int K, double alpha, const double* __restrict__ A, long long sA,
                                                                   const double* __restrict__ B, long long sB, double* __restrict__ C, long long sC) {
   // no LDS, no barrier: one wave per (32-row strip, 16-column tile); it fetches its fragments straight from memory (A and B are small and
   // cache resident) and has the C values it will update in flight while the MFMAs run
   const int NT = (N + 15) >> 4, MT = (M + 31) >> 5;
   const int lane = threadIdx.x & 63, fr = lane & 15, fk = lane >> 4;
-  const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int item = BID.x * 4 + (threadIdx.x >> 6);
   if (item >= MT * NT) return;
   const int m0 = (item / NT) * 32, col = (item % NT) * 16 + fr;
-  const long long z = blockIdx.y;
+  const long long z = BID.y;
   const double* __restrict__ Az = A + z * sA;
   const double* __restrict__ Bz = B + z * sB;
   double* __restrict__ Cz = C + z * sC;
@@ -771,6 +999,8 @@ __global__ void __launch_bounds__(256) small_k_update_mfma_kernel(int M, int N, 
     }
   }
 }
+__global__ void __launch_bounds__(256) small_k_update_mfma_kernel(int M, int N, int K, double alpha, const double* __restrict__ A, long long sA,
+                                                                  const double* __restrict__ B, long long sB, double* __restrict__ C, long long sC) { small_k_update_mfma_kernel_body(make_uint3(blockIdx.x, blockIdx.y, blockIdx.z), make_uint3(gridDim.x, gridDim.y, gridDim.z), M, N, K, alpha, A, sA, B, sB, C, sC); }
 int dev_small_k_update(int64_t batch, int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t sA, const double* B, int64_t sB,
                        double* C, int64_t sC) {
   REQUIRE_INIT();
@@ -790,9 +1020,9 @@ int dev_small_k_update(int64_t batch, int64_t M, int64_t N, int64_t K, double al
   return QEMB_OK;
 }
 
-__global__ void __launch_bounds__(256) ccsd_y_traces_kernel(long long o, long long v, const double* __restrict__ ZC, const double* __restrict__ ZB,
+__device__ __forceinline__ void ccsd_y_traces_kernel_body(const uint3 BID, const uint3 GDIM, long long o, long long v, const double* __restrict__ ZC, const double* __restrict__ ZB,
                                                             double* __restrict__ Y) {
-  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long idx = (long long)BID.x * blockDim.x + threadIdx.x;
   if (idx >= v * v) return;
   const long long a = idx / v, c = idx % v;
   double s = 0.0;
@@ -800,6 +1030,8 @@ __global__ void __launch_bounds__(256) ccsd_y_traces_kernel(long long o, long lo
     s += 2.0 * ZC[((k * o + k) * v + a) * v + c] - ZB[((k * v + c) * v + a) * o + k];
   Y[idx] = s;
 }
+__global__ void __launch_bounds__(256) ccsd_y_traces_kernel(long long o, long long v, const double* __restrict__ ZC, const double* __restrict__ ZB,
+                                                            double* __restrict__ Y) { ccsd_y_traces_kernel_body(make_uint3(blockIdx.x, blockIdx.y, blockIdx.z), make_uint3(gridDim.x, gridDim.y, gridDim.z), o, v, ZC, ZB, Y); }
 int dev_ccsd_y_traces(int64_t o, int64_t v, const double* ZC, const double* ZB, double* Y) {
   REQUIRE_INIT();
   if (v <= 0) return QEMB_OK;
@@ -875,14 +1107,15 @@ int dev_mirror_lower(int64_t n, double* A, int64_t lda) {
 }
 
 struct LincombK { const double* x[8]; double c[8]; int n; };
-__global__ void __launch_bounds__(256) lincomb_kernel(long long n, LincombK k, double beta, double* __restrict__ out) {
-  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
+__device__ __forceinline__ void lincomb_kernel_body(const uint3 BID, const uint3 GDIM, long long n, LincombK k, double beta, double* __restrict__ out) {
+  for (long long t = (long long)BID.x * blockDim.x + threadIdx.x; t < n; t += (long long)GDIM.x * blockDim.x) {
     double acc = (beta != 0.0) ? beta * out[t] : 0.0;
 #pragma unroll
     for (int q = 0; q < 8; ++q) if (q < k.n) acc += k.c[q] * k.x[q][t];
     out[t] = acc;
   }
 }
+__global__ void __launch_bounds__(256) lincomb_kernel(long long n, LincombK k, double beta, double* __restrict__ out) { lincomb_kernel_body(make_uint3(blockIdx.x, blockIdx.y, blockIdx.z), make_uint3(gridDim.x, gridDim.y, gridDim.z), n, k, beta, out); }
 int dev_lincomb(int64_t n, int nterms, const double* coef, const double* const* xs, double beta, double* out) {
   REQUIRE_INIT();
   if (n <= 0) return QEMB_OK;
@@ -1077,15 +1310,15 @@ __global__ void __launch_bounds__(256) pack_pm_tiled_kernel(long long rows, long
     __syncthreads();
   }
 }
-__global__ void __launch_bounds__(256) ladder_pack_tau_kernel(long long o, long long v, const double* __restrict__ tau,
+__device__ __forceinline__ void ladder_pack_tau_kernel_body(const uint3 BID, const uint3 GDIM, long long o, long long v, const double* __restrict__ tau,
                                                              double* __restrict__ Tp, long long ldp, double* __restrict__ Tm, long long ldm) {
-  const long long ij = blockIdx.x, np = v * (v + 1) / 2, nm = v * (v - 1) / 2;
+  const long long ij = BID.x, np = v * (v + 1) / 2, nm = v * (v - 1) / 2;
   long long i, j; unpair_ge(ij, i, j);
   const double* t = tau + (i * o + j) * v * v;
   double* tp = Tp + ij * ldp;
   double* tm = (i > j) ? Tm + (i * (i - 1) / 2 + j) * ldm : nullptr;
-  // blockIdx.y: a slice of the packed (c,d) range -- one workgroup per pair (ij) alone is 210 workgroups at n_occ = 20, fewer than the chip has CUs
-  const long long chunk = (ldp + gridDim.y - 1) / gridDim.y, cd0 = blockIdx.y * chunk, cd1 = (cd0 + chunk < ldp) ? cd0 + chunk : ldp;
+  // BID.y: a slice of the packed (c,d) range -- one workgroup per pair (ij) alone is 210 workgroups at n_occ = 20, fewer than the chip has CUs
+  const long long chunk = (ldp + GDIM.y - 1) / GDIM.y, cd0 = BID.y * chunk, cd1 = (cd0 + chunk < ldp) ? cd0 + chunk : ldp;
   for (long long cd = cd0 + threadIdx.x; cd < cd1; cd += blockDim.x) {
     if (cd >= np) { tp[cd] = 0.0; continue; }
     long long c, d; unpair_ge(cd, c, d);
@@ -1093,8 +1326,10 @@ __global__ void __launch_bounds__(256) ladder_pack_tau_kernel(long long o, long 
     tp[cd] = (c == d) ? 0.25 * (x + y) : 0.5 * (x + y);
     if (tm && c > d) tm[c * (c - 1) / 2 + d] = 0.5 * (x - y);
   }
-  if (tm && blockIdx.y == 0) for (long long q = nm + threadIdx.x; q < ldm; q += blockDim.x) tm[q] = 0.0;
+  if (tm && BID.y == 0) for (long long q = nm + threadIdx.x; q < ldm; q += blockDim.x) tm[q] = 0.0;
 }
+__global__ void __launch_bounds__(256) ladder_pack_tau_kernel(long long o, long long v, const double* __restrict__ tau,
+                                                             double* __restrict__ Tp, long long ldp, double* __restrict__ Tm, long long ldm) { ladder_pack_tau_kernel_body(make_uint3(blockIdx.x, blockIdx.y, blockIdx.z), make_uint3(gridDim.x, gridDim.y, gridDim.z), o, v, tau, Tp, ldp, Tm, ldm); }
 int dev_ladder_pack_tau(int64_t o, int64_t v, const double* tau, double* Tp, int64_t ldp, double* Tm, int64_t ldm) {
   REQUIRE_INIT();
   const long long npo = o * (o + 1) / 2;
@@ -1142,19 +1377,20 @@ int dev_pack_pm_cols(int64_t rows, int64_t v, const double* in, double* Op, int6
   HIP_TRY(hipGetLastError());
   return QEMB_OK;
 }
-__global__ void __launch_bounds__(256) scatter_pm_rows_kernel(long long o, long long ncols, const double* __restrict__ Xp, const double* __restrict__ Xm, double* __restrict__ out) {
-  const long long ij = blockIdx.y;
+__device__ __forceinline__ void scatter_pm_rows_kernel_body(const uint3 BID, const uint3 GDIM, long long o, long long ncols, const double* __restrict__ Xp, const double* __restrict__ Xm, double* __restrict__ out) {
+  const long long ij = BID.y;
   long long i, j; unpair_ge(ij, i, j);
   const double* xp = Xp + ij * ncols;
   const double* xm = (i > j) ? Xm + (i * (i - 1) / 2 + j) * ncols : nullptr;
   double* oij = out + (i * o + j) * ncols;
   double* oji = out + (j * o + i) * ncols;
-  for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < ncols; c += (long long)gridDim.x * blockDim.x) {
+  for (long long c = (long long)BID.x * blockDim.x + threadIdx.x; c < ncols; c += (long long)GDIM.x * blockDim.x) {
     const double p = xp[c];
     if (xm) { const double m = xm[c]; oij[c] = p + m; oji[c] = p - m; }
     else oij[c] = p;
   }
 }
+__global__ void __launch_bounds__(256) scatter_pm_rows_kernel(long long o, long long ncols, const double* __restrict__ Xp, const double* __restrict__ Xm, double* __restrict__ out) { scatter_pm_rows_kernel_body(make_uint3(blockIdx.x, blockIdx.y, blockIdx.z), make_uint3(gridDim.x, gridDim.y, gridDim.z), o, ncols, Xp, Xm, out); }
 int dev_scatter_pm_rows(int64_t o, int64_t ncols, const double* Xp, const double* Xm, double* out) {
   REQUIRE_INIT();
   const long long npo = o * (o + 1) / 2;
@@ -1165,12 +1401,12 @@ int dev_scatter_pm_rows(int64_t o, int64_t ncols, const double* Xp, const double
   return QEMB_OK;
 }
 // grid (32 x 32 tiles of (a,b), o*o): U[j,i,b,a] is read with a fastest (coalesced) and transposed through LDS
-__global__ void __launch_bounds__(256) ccsd_finish_t2_kernel(long long o, long long v, double* __restrict__ t2n, const double* __restrict__ U,
+__device__ __forceinline__ void ccsd_finish_t2_kernel_body(const uint3 BID, const uint3 GDIM, long long o, long long v, double* __restrict__ t2n, const double* __restrict__ U,
                                                             const double* __restrict__ OV, const double* __restrict__ eo, const double* __restrict__ ev) {
   __shared__ double tile[32][33];
-  const long long ij = blockIdx.y, i = ij / o, j = ij - i * o;
+  const long long ij = BID.y, i = ij / o, j = ij - i * o;
   const long long nt = (v + 31) / 32;
-  const long long ta = blockIdx.x / nt, tb = blockIdx.x - ta * nt;
+  const long long ta = BID.x / nt, tb = BID.x - ta * nt;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const double* Uji = U + (j * o + i) * v * v;
 #pragma unroll
@@ -1192,6 +1428,8 @@ __global__ void __launch_bounds__(256) ccsd_finish_t2_kernel(long long o, long l
     }
   }
 }
+__global__ void __launch_bounds__(256) ccsd_finish_t2_kernel(long long o, long long v, double* __restrict__ t2n, const double* __restrict__ U,
+                                                            const double* __restrict__ OV, const double* __restrict__ eo, const double* __restrict__ ev) { ccsd_finish_t2_kernel_body(make_uint3(blockIdx.x, blockIdx.y, blockIdx.z), make_uint3(gridDim.x, gridDim.y, gridDim.z), o, v, t2n, U, OV, eo, ev); }
 int dev_ccsd_finish_t2(int64_t o, int64_t v, double* t2n, const double* U, const double* OV, const double* eo, const double* ev) {
   REQUIRE_INIT();
   if (o <= 0 || v <= 0) return QEMB_OK;
@@ -1203,13 +1441,13 @@ int dev_ccsd_finish_t2(int64_t o, int64_t v, double* t2n, const double* U, const
 }
 // grid (lower-triangle 32 x 32 tiles of (a,b), npair(o)): the tile of R+/R- is staged through LDS so that both the [a][b] image
 // and its mirror [b][a] are updated in 256-byte runs, for t2[i,j] and t2[j,i].
-__global__ void __launch_bounds__(256) ladder_scatter_pm_kernel(long long o, long long v, const double* __restrict__ Rp, long long ldp,
+__device__ __forceinline__ void ladder_scatter_pm_kernel_body(const uint3 BID, const uint3 GDIM, long long o, long long v, const double* __restrict__ Rp, long long ldp,
                                                                const double* __restrict__ Rm, long long ldm, double* __restrict__ t2,
                                                                const double* __restrict__ Hp, const double* __restrict__ Hm, int assign) {
   __shared__ double sp[32][33], sm[32][33];
-  const long long ij = blockIdx.y;
+  const long long ij = BID.y;
   long long i, j; unpair_ge(ij, i, j);
-  long long t = blockIdx.x, ta, tb; unpair_ge(t, ta, tb);            // tile row >= tile column
+  long long t = BID.x, ta, tb; unpair_ge(t, ta, tb);            // tile row >= tile column
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const double* rp = Rp + ij * ldp;
   const double* rm = (i > j) ? Rm + (i * (i - 1) / 2 + j) * ldm : nullptr;
@@ -1251,6 +1489,9 @@ __global__ void __launch_bounds__(256) ladder_scatter_pm_kernel(long long o, lon
     }
   }
 }
+__global__ void __launch_bounds__(256) ladder_scatter_pm_kernel(long long o, long long v, const double* __restrict__ Rp, long long ldp,
+                                                               const double* __restrict__ Rm, long long ldm, double* __restrict__ t2,
+                                                               const double* __restrict__ Hp, const double* __restrict__ Hm, int assign) { ladder_scatter_pm_kernel_body(make_uint3(blockIdx.x, blockIdx.y, blockIdx.z), make_uint3(gridDim.x, gridDim.y, gridDim.z), o, v, Rp, ldp, Rm, ldm, t2, Hp, Hm, assign); }
 int dev_ladder_scatter_pm2(int64_t o, int64_t v, const double* Rp, int64_t ldp, const double* Rm, int64_t ldm, const double* Hp, const double* Hm,
                            int assign, double* t2) {
   REQUIRE_INIT();
@@ -1267,10 +1508,10 @@ int dev_ladder_scatter_pm(int64_t o, int64_t v, const double* Rp, int64_t ldp, c
   return dev_ladder_scatter_pm2(o, v, Rp, ldp, Rm, ldm, nullptr, nullptr, 0, t2);
 }
 // one thread per (P(ij), P(kl)) / (Q(ij), Q(kl)) entry of the packed images of W[k,l,i,j]
-__global__ void __launch_bounds__(256) pack_w_pm_kernel(long long o, const double* __restrict__ W, double* __restrict__ Ap, long long lda_p,
+__device__ __forceinline__ void pack_w_pm_kernel_body(const uint3 BID, const uint3 GDIM, long long o, const double* __restrict__ W, double* __restrict__ Ap, long long lda_p,
                                                         double* __restrict__ Am, long long lda_m) {
   const long long npo = o * (o + 1) / 2, nmo = o * (o - 1) / 2;
-  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long t = (long long)BID.x * blockDim.x + threadIdx.x;
   if (t < npo * lda_p) {
     const long long ij = t / lda_p, kl = t - ij * lda_p;
     double x = 0.0;
@@ -1292,14 +1533,17 @@ __global__ void __launch_bounds__(256) pack_w_pm_kernel(long long o, const doubl
     Am[t] = x;
   }
 }
-__global__ void __launch_bounds__(256) foo_from_x_kernel(long long o, const double* __restrict__ X, double* __restrict__ F) {
-  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void __launch_bounds__(256) pack_w_pm_kernel(long long o, const double* __restrict__ W, double* __restrict__ Ap, long long lda_p,
+                                                        double* __restrict__ Am, long long lda_m) { pack_w_pm_kernel_body(make_uint3(blockIdx.x, blockIdx.y, blockIdx.z), make_uint3(gridDim.x, gridDim.y, gridDim.z), o, W, Ap, lda_p, Am, lda_m); }
+__device__ __forceinline__ void foo_from_x_kernel_body(const uint3 BID, const uint3 GDIM, long long o, const double* __restrict__ X, double* __restrict__ F) {
+  const long long t = (long long)BID.x * blockDim.x + threadIdx.x;
   if (t >= o * o) return;
   const long long k = t / o, i = t - k * o;
   double s = 0.0;
   for (long long l = 0; l < o; ++l) s += 2.0 * X[((i * o + l) * o + k) * o + l] - X[((l * o + i) * o + k) * o + l];
   F[t] = s;
 }
+__global__ void __launch_bounds__(256) foo_from_x_kernel(long long o, const double* __restrict__ X, double* __restrict__ F) { foo_from_x_kernel_body(make_uint3(blockIdx.x, blockIdx.y, blockIdx.z), make_uint3(gridDim.x, gridDim.y, gridDim.z), o, X, F); }
 int dev_foo_from_x(int64_t o, const double* X, double* F) {
   REQUIRE_INIT();
   if (o <= 0) return QEMB_OK;
@@ -1419,10 +1663,10 @@ int dev_absmax(int64_t n, const double* x, double* out_dev) {
 // ------------------------------------------------------------------------------------------------
 // J/K style contractions
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) gemv_rows_kernel(long long rows, long long cols, const double* T, long long ldt,
+__device__ __forceinline__ void gemv_rows_kernel_body(const uint3 BID, const uint3 GDIM, long long rows, long long cols, const double* T, long long ldt,
                                                         const double* x, double* y, double alpha, double beta) {
   __shared__ double sh[4];
-  for (long long r = blockIdx.x; r < rows; r += gridDim.x) {
+  for (long long r = BID.x; r < rows; r += GDIM.x) {
     const double* row = T + r * ldt;
     double acc = 0.0;
     for (long long c = threadIdx.x; c < cols; c += blockDim.x) acc += row[c] * x[c];
@@ -1430,6 +1674,8 @@ __global__ void __launch_bounds__(256) gemv_rows_kernel(long long rows, long lon
     if (threadIdx.x == 0) y[r] = (beta != 0.0) ? alpha * s + beta * y[r] : alpha * s;
   }
 }
+__global__ void __launch_bounds__(256) gemv_rows_kernel(long long rows, long long cols, const double* T, long long ldt,
+                                                        const double* x, double* y, double alpha, double beta) { gemv_rows_kernel_body(make_uint3(blockIdx.x, blockIdx.y, blockIdx.z), make_uint3(gridDim.x, gridDim.y, gridDim.z), rows, cols, T, ldt, x, y, alpha, beta); }
 int dev_gemv_rows(int64_t rows, int64_t cols, const double* T, int64_t ldt, const double* x, double* y, double alpha, double beta) {
   REQUIRE_INIT();
   if (rows <= 0) return QEMB_OK;
@@ -1465,13 +1711,13 @@ int dev_gemv_rows_batched(int64_t rows, int64_t cols, int64_t nbatch, const doub
 }
 
 // partial[p][chunk][r] = sum_{m in chunk} x[m] * T[p][m][r];  threads run along r (contiguous), blockIdx.z tiles r
-__global__ void __launch_bounds__(256) contract_mid_stage1(long long mid, long long inner, int nchunk, const double* __restrict__ T,
+__device__ __forceinline__ void contract_mid_stage1_body(const uint3 BID, const uint3 GDIM, long long mid, long long inner, int nchunk, const double* __restrict__ T,
                                                            const double* __restrict__ x, double* __restrict__ partial) {
-  const long long p = blockIdx.y;
-  const int ch = blockIdx.x;
+  const long long p = BID.y;
+  const int ch = BID.x;
   const long long m_per = (mid + nchunk - 1) / nchunk;
   const long long m0 = ch * m_per, m1 = (m0 + m_per < mid) ? m0 + m_per : mid;
-  for (long long r = (long long)blockIdx.z * blockDim.x + threadIdx.x; r < inner; r += (long long)gridDim.z * blockDim.x) {
+  for (long long r = (long long)BID.z * blockDim.x + threadIdx.x; r < inner; r += (long long)GDIM.z * blockDim.x) {
     double a0 = 0.0, a1 = 0.0;
     const double* base = T + (p * mid) * inner + r;
     long long m = m0;
@@ -1480,9 +1726,11 @@ __global__ void __launch_bounds__(256) contract_mid_stage1(long long mid, long l
     partial[(p * nchunk + ch) * inner + r] = a0 + a1;
   }
 }
-__global__ void __launch_bounds__(256) contract_mid_stage2(long long outer, long long inner, int nchunk, const double* partial,
+__global__ void __launch_bounds__(256) contract_mid_stage1(long long mid, long long inner, int nchunk, const double* __restrict__ T,
+                                                           const double* __restrict__ x, double* __restrict__ partial) { contract_mid_stage1_body(make_uint3(blockIdx.x, blockIdx.y, blockIdx.z), make_uint3(gridDim.x, gridDim.y, gridDim.z), mid, inner, nchunk, T, x, partial); }
+__device__ __forceinline__ void contract_mid_stage2_body(const uint3 BID, const uint3 GDIM, long long outer, long long inner, int nchunk, const double* partial,
                                                            double* Y, long long ldy, double alpha, double beta) {
-  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long t = (long long)BID.x * blockDim.x + threadIdx.x;
   if (t >= outer * inner) return;
   const long long p = t / inner, r = t - p * inner;
   double acc = 0.0;
@@ -1490,6 +1738,8 @@ __global__ void __launch_bounds__(256) contract_mid_stage2(long long outer, long
   double* y = Y + p * ldy + r;
   *y = (beta != 0.0) ? alpha * acc + beta * (*y) : alpha * acc;
 }
+__global__ void __launch_bounds__(256) contract_mid_stage2(long long outer, long long inner, int nchunk, const double* partial,
+                                                           double* Y, long long ldy, double alpha, double beta) { contract_mid_stage2_body(make_uint3(blockIdx.x, blockIdx.y, blockIdx.z), make_uint3(gridDim.x, gridDim.y, gridDim.z), outer, inner, nchunk, partial, Y, ldy, alpha, beta); }
 int dev_contract_mid(int64_t outer, int64_t mid, int64_t inner, const double* T, const double* x, double* Y, int64_t ldy, double alpha, double beta) {
   REQUIRE_INIT();
   if (outer <= 0 || inner <= 0) return QEMB_OK;
@@ -1825,14 +2075,14 @@ static int64_t unpack_walkers(int64_t rows, int64_t ntiles) {
 // both the [k][l] image and its mirror [l][k] are written in 256-byte runs and every packed element is read once.
 // dup == 1: the row index is itself a pair (p >= q) of an s4 block; the n x n image goes to rows (p,q) and (q,p).
 // dup == 2: the SOURCE rows are gathered: packed row r = pair (x,y), x >= y, is read from row x*n + y (pair-row selection fused in).
-__global__ void __launch_bounds__(256) unpack_tril_tiled_kernel(long long rows, long long n, const double* __restrict__ packed,
+__device__ __forceinline__ void unpack_tril_tiled_kernel_body(const uint3 BID, const uint3 GDIM, long long rows, long long n, const double* __restrict__ packed,
                                                                double* __restrict__ full, int dup, long long nr) {
   __shared__ double tile[32][33];
   const long long np = n * (n + 1) / 2, n2 = n * n;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  // blockIdx.x = lower-triangle tile (tk >= tl), blockIdx.y (looped) = packed row: every block moves one 32 x 32 tile
-  long long tt = blockIdx.x, tk, tl; unpair_ge(tt, tk, tl);
-  for (long long r = blockIdx.y; r < rows; r += gridDim.y) {
+  // BID.x = lower-triangle tile (tk >= tl), BID.y (looped) = packed row: every block moves one 32 x 32 tile
+  long long tt = BID.x, tk, tl; unpair_ge(tt, tk, tl);
+  for (long long r = BID.y; r < rows; r += GDIM.y) {
     const double* src = packed + r * np;
     double* dst0 = full + r * n2;
     double* dst1 = nullptr;
@@ -1862,6 +2112,8 @@ __global__ void __launch_bounds__(256) unpack_tril_tiled_kernel(long long rows, 
     __syncthreads();
   }
 }
+__global__ void __launch_bounds__(256) unpack_tril_tiled_kernel(long long rows, long long n, const double* __restrict__ packed,
+                                                               double* __restrict__ full, int dup, long long nr) { unpack_tril_tiled_kernel_body(make_uint3(blockIdx.x, blockIdx.y, blockIdx.z), make_uint3(gridDim.x, gridDim.y, gridDim.z), rows, n, packed, full, dup, nr); }
 
 // s1[i,j,k,l] = s4[pair(i,j), pair(k,l)];  one block row per (i,j), threads along (k,l)
 __global__ void __launch_bounds__(256) unpack_s4_kernel(long long n, const double* s4, double* s1) {
@@ -1925,14 +2177,15 @@ int dev_unpack_s8_to_s4(int64_t n, const double* s8, double* s4) {
   HIP_TRY(hipGetLastError());
   return QEMB_OK;
 }
-__global__ void __launch_bounds__(256) unpack_tril_rows_kernel(long long rows, long long n, const double* packed, double* full) {
+__device__ __forceinline__ void unpack_tril_rows_kernel_body(const uint3 BID, const uint3 GDIM, long long rows, long long n, const double* packed, double* full) {
   const long long np = n * (n + 1) / 2, n2 = n * n;
-  for (long long r = blockIdx.x; r < rows; r += gridDim.x)
+  for (long long r = BID.x; r < rows; r += GDIM.x)
     for (long long kl = threadIdx.x; kl < n2; kl += blockDim.x) {
       const long long k = kl / n, l = kl - k * n;
       full[r * n2 + kl] = packed[r * np + pair_idx(k, l)];
     }
 }
+__global__ void __launch_bounds__(256) unpack_tril_rows_kernel(long long rows, long long n, const double* packed, double* full) { unpack_tril_rows_kernel_body(make_uint3(blockIdx.x, blockIdx.y, blockIdx.z), make_uint3(gridDim.x, gridDim.y, gridDim.z), rows, n, packed, full); }
 int dev_unpack_tril_rows(int64_t rows, int64_t n, const double* packed, double* full) {
   REQUIRE_INIT();
   if (rows <= 0) return QEMB_OK;
@@ -1979,6 +2232,31 @@ int dev_pack_tril_rows(int64_t rows, int64_t n, const double* full, double* pack
   hipLaunchKernelGGL(pack_tril_rows_kernel, dim3((unsigned)std::min<int64_t>(rows, 1 << 20)), dim3(256), 0, g_stream, (long long)rows, (long long)n, full, packed);
   HIP_TRY(hipGetLastError());
   return QEMB_OK;
+}
+
+// every kernel of this file that exists in body + wrapper form (see "grouped launches" at the top)
+static void register_groupable_kernels() {
+  register_groupable<copy4_linear_kernel_body, 256, Copy4K>((const void*)copy4_linear_kernel);
+  register_groupable<copy4_transpose_kernel_body, 256, Copy4K, int>((const void*)copy4_transpose_kernel);
+  register_groupable<outer4_kernel_body, 256, Outer4K>((const void*)outer4_kernel);
+  register_groupable<div_denom_kernel_body, 256, double*, long long, long long, long long, long long, const double*, const double*, const double*, const double*>((const void*)div_denom_kernel);
+  register_groupable<ccsd_ph_layouts_kernel_body, 256, long long, long long, const double*, const double*, double*, double*, double*, double*, double*, double*, int>((const void*)ccsd_ph_layouts_kernel);
+  register_groupable<small_k_update_kernel_body, 256, long long, long long, long long, double, const double*, long long, const double*, long long, double*, long long, int>((const void*)small_k_update_kernel);
+  register_groupable<small_k_update_mfma_kernel_body, 256, int, int, int, double, const double*, long long, const double*, long long, double*, long long>((const void*)small_k_update_mfma_kernel);
+  register_groupable<ccsd_y_traces_kernel_body, 256, long long, long long, const double*, const double*, double*>((const void*)ccsd_y_traces_kernel);
+  register_groupable<lincomb_kernel_body, 256, long long, LincombK, double, double*>((const void*)lincomb_kernel);
+  register_groupable<ladder_pack_tau_kernel_body, 256, long long, long long, const double*, double*, long long, double*, long long>((const void*)ladder_pack_tau_kernel);
+  register_groupable<scatter_pm_rows_kernel_body, 256, long long, long long, const double*, const double*, double*>((const void*)scatter_pm_rows_kernel);
+  register_groupable<ccsd_finish_t2_kernel_body, 256, long long, long long, double*, const double*, const double*, const double*, const double*>((const void*)ccsd_finish_t2_kernel);
+  register_groupable<ladder_scatter_pm_kernel_body, 256, long long, long long, const double*, long long, const double*, long long, double*, const double*, const double*, int>((const void*)ladder_scatter_pm_kernel);
+  register_groupable<pack_w_pm_kernel_body, 256, long long, const double*, double*, long long, double*, long long>((const void*)pack_w_pm_kernel);
+  register_groupable<foo_from_x_kernel_body, 256, long long, const double*, double*>((const void*)foo_from_x_kernel);
+  register_groupable<gemv_rows_kernel_body, 256, long long, long long, const double*, long long, const double*, double*, double, double>((const void*)gemv_rows_kernel);
+  register_groupable<contract_mid_stage1_body, 256, long long, long long, int, const double*, const double*, double*>((const void*)contract_mid_stage1);
+  register_groupable<contract_mid_stage2_body, 256, long long, long long, int, const double*, double*, long long, double, double>((const void*)contract_mid_stage2);
+  register_groupable<unpack_tril_rows_kernel_body, 256, long long, long long, const double*, double*>((const void*)unpack_tril_rows_kernel);
+  register_groupable<unpack_tril_tiled_kernel_body, 256, long long, long long, const double*, double*, int, long long>((const void*)unpack_tril_tiled_kernel);
+  register_groupable<fill_kernel_body, 1024, double*, long long, double>((const void*)fill_kernel);
 }
 
 }  // namespace qemb

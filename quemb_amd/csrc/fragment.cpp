@@ -4,6 +4,11 @@
 // with the fragment ERIs resident in HBM between sweeps (the reference re-reads them from HDF5 every call:
 // helper.py:182-189, :303-304).
 #include "fragment.h"
+#include <string>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <thread>
 #include <cmath>
 #include <cstring>
 
@@ -181,6 +186,80 @@ int Fragment::ccsd_iterate(int niter, double* e_corr, double* normt) {
 
 int Fragment::solve(int o, const double* h, const double* dm0, const FragmentOptions& opt, int eeval, FragmentResult* res,
                     double* mo_coeff, double* mo_energy, double* rdm1_emb, double* rdm1_mo, double* t1_out, double* t2_out) {
+  QTRY(solve_begin(o, h, dm0, opt, eeval, res));
+  if (!sp_.no_virtuals) {
+    bool conv = false;
+    QTRY(cc_->kernel(opt.cc, &res->e_corr_mo, &res->n_iter, &conv));
+    res->ccsd_converged = conv;
+  }
+  return solve_end(mo_coeff, mo_energy, rdm1_emb, rdm1_mo, t1_out, t2_out);
+}
+
+// Several fragments in one call: the phases around the CCSD iterations (fragment RHF + MO transformation + set-up; amplitudes -> 1-RDM ->
+// energies) run per fragment on one host thread and execution context each, as solver.map_fragments does; the CCSD iterations of all
+// fragments run in LOCK STEP on the calling thread (ccsd_kernel_lockstep: one grouped launch per operation for all fragments).
+int Fragment::solve_batch(const std::vector<Fragment*>& frs, const std::vector<int>& o, const std::vector<const double*>& h,
+                          const std::vector<const double*>& dm0, const FragmentOptions& opt, int eeval, std::vector<FragmentResult>& res,
+                          const std::vector<BatchOutputs>& outs, LockstepStats* stats) {
+  const int F = (int)frs.size();
+  if (F == 0) return 0;
+  static const bool trace = std::getenv("QEMB_BATCH_TRACE") != nullptr;
+  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t_start = now();
+  res.assign(F, FragmentResult());
+  const int have = dev_ctx_count(F + 1);
+  if (have < 0) return have;
+  // a backend with a single execution context (the scalar mock of tests/hostcheck) runs the per-fragment phases one after the other
+  const bool threaded = have >= F + 1 && F > 1;
+  std::vector<int> rc(F, 0);
+  std::vector<std::string> msg(F);
+  auto per_fragment = [&](auto fn) {
+    if (threaded) {
+      std::vector<std::thread> th;
+      for (int f = 0; f < F; ++f) th.emplace_back([&, f] {
+        rc[f] = dev_ctx_bind(f + 1);
+        if (rc[f] == 0) rc[f] = fn(f);
+        if (rc[f] != 0) msg[f] = last_error();
+      });
+      for (auto& t : th) t.join();
+    } else {
+      for (int f = 0; f < F; ++f) { rc[f] = fn(f); if (rc[f] != 0) msg[f] = last_error(); }
+    }
+    int worst = 0;
+    for (int f = 0; f < F; ++f) if (rc[f] < 0 && worst == 0) { worst = rc[f]; set_error("fragment " + std::to_string(f) + ": " + msg[f]); }
+    return worst;
+  };
+  QTRY(per_fragment([&](int f) {
+    int r = frs[f]->solve_begin(o[f], h[f], dm0[f], opt, eeval, &res[f]);
+    if (r == 0 && frs[f]->cc_ && F > 1) r = frs[f]->cc_->prepare_tape();      // recorded side by side; a lone fragment keeps its executable graph
+    if (r == 0) r = dev_sync();                                               // the lock-step loop reads this fragment's buffers from another stream
+    return r;
+  }));
+  const double t_begin_done = now();
+  std::vector<CcsdSolver*> solvers; std::vector<int> idx, ctx; std::vector<CcsdOptions> copt;
+  for (int f = 0; f < F; ++f) if (!frs[f]->sp_.no_virtuals) { solvers.push_back(frs[f]->cc_.get()); idx.push_back(f); ctx.push_back(threaded ? f + 1 : 0); copt.push_back(opt.cc); }
+  if (!solvers.empty()) {
+    std::vector<double> e; std::vector<int> nit; std::vector<char> conv;
+    QTRY(ccsd_kernel_lockstep(solvers, copt, ctx, 0, e, nit, conv, stats));
+    for (size_t k = 0; k < idx.size(); ++k) { res[idx[k]].e_corr_mo = e[k]; res[idx[k]].n_iter = nit[k]; res[idx[k]].ccsd_converged = conv[k] != 0; }
+  }
+  const double t_lock_done = now();
+  int warn = 0;
+  std::vector<int> rc_end(F, 0);
+  const int worst = per_fragment([&](int f) {
+    rc_end[f] = frs[f]->solve_end(outs[f].mo_coeff, outs[f].mo_energy, outs[f].rdm1_emb, outs[f].rdm1_mo, outs[f].t1, outs[f].t2);
+    return rc_end[f];
+  });
+  if (trace) std::fprintf(stderr, "[qemb batch] %d fragments: begin %.2f ms, lock-step iterations %.2f ms (tapes %.2f, post %.2f), end %.2f ms\n", F,
+                          t_begin_done - t_start, t_lock_done - t_begin_done, stats ? stats->ms_tapes : 0.0, stats ? stats->ms_post : 0.0, now() - t_lock_done);
+  if (worst) return worst;
+  for (int f = 0; f < F; ++f) if (rc_end[f] > 0) { warn = rc_end[f]; set_error("fragment " + std::to_string(f) + ": " + msg[f]); }
+  return warn;
+}
+
+int Fragment::solve_begin(int o, const double* h, const double* dm0, const FragmentOptions& opt, int eeval, FragmentResult* res) {
+  sp_ = SolvePending();
+  sp_.o = o; sp_.opt = opt; sp_.eeval = eeval; sp_.res = res;
   if (!eri_s4_.p) { set_error("Fragment: ERIs not set"); return QEMB_ERR_ARG; }
   if (o <= 0 || o > n_) { set_error("Fragment: need 0 < nsocc <= n"); return QEMB_ERR_ARG; }
   const int n = n_, v = n - o;
@@ -196,13 +275,15 @@ int Fragment::solve(int o, const double* h, const double* dm0, const FragmentOpt
   ScfResult sres;
   QTRY(run_scf(o, h, dm0, opt.scf, X1, &sres, opt.warm_start != 0));
   res->scf_converged = sres.converged; res->scf_cycles = sres.cycles; res->e_scf = sres.e_tot;
-  bool unconverged = false;
+  bool& unconverged = sp_.unconverged;
+  sp_.no_virtuals = no_virtuals;
   if (!sres.converged) {
     set_error("fragment SCF did not converge (also not with level shift 0.2)");
     if (opt.strict) return QEMB_ERR_NOCONV;
     unconverged = true;
   }
-  std::vector<double> C((size_t)n2), eps((size_t)n), J((size_t)n2), K((size_t)n2);
+  std::vector<double>& C = sp_.C; std::vector<double>& eps = sp_.eps;
+  C.assign((size_t)n2, 0.0); eps.assign((size_t)n, 0.0);
   QTRY(dev_d2h(C.data(), C_, sizeof(double) * n2));
   QTRY(dev_d2h(eps.data(), eps_, sizeof(double) * n));
   // ---- integrals + CCSD
@@ -222,14 +303,23 @@ int Fragment::solve(int o, const double* h, const double* dm0, const FragmentOpt
   } else {
     QTRY(cc_->init_amps());
   }
-  bool conv = false;
-  QTRY(cc_->kernel(opt.cc, &res->e_corr_mo, &res->n_iter, &conv));
-  res->ccsd_converged = conv;
-  if (!conv) {
+  }
+  return 0;
+}
+
+int Fragment::solve_end(double* mo_coeff, double* mo_energy, double* rdm1_emb, double* rdm1_mo, double* t1_out, double* t2_out) {
+  const int o = sp_.o, n = n_, v = n - o, eeval = sp_.eeval;
+  const FragmentOptions& opt = sp_.opt;
+  FragmentResult* res = sp_.res;
+  const bool no_virtuals = sp_.no_virtuals;
+  bool unconverged = sp_.unconverged;
+  const int64_t n2 = (int64_t)n * n;
+  const std::vector<double>& C = sp_.C; const std::vector<double>& eps = sp_.eps;
+  std::vector<double> J((size_t)n2), K((size_t)n2);
+  if (!no_virtuals && !res->ccsd_converged) {
     set_error("CCSD did not converge in max_cycle iterations");
     if (opt.strict) return QEMB_ERR_NOCONV;
     unconverged = true;
-  }
   }
   // ---- amplitudes to the host as requested; unrelaxed 1-RDM (depends on t1 only)
   std::vector<double> t1((size_t)o * v);

@@ -49,6 +49,16 @@ class Fragment {
   // Outputs (host, nullable): mo_coeff n*n, mo_energy n, rdm1_emb n*n (= C rdm1 C^T / 2), rdm1_mo n*n, t1 o*v, t2 o*o*v*v.
   int solve(int o, const double* h, const double* dm0, const FragmentOptions& opt, int eeval, FragmentResult* res,
             double* mo_coeff, double* mo_energy, double* rdm1_emb, double* rdm1_mo, double* t1, double* t2);
+  // The same in three steps -- everything before the CCSD iterations, (the iterations: cc_->kernel or the lock-step loop of solve_batch),
+  // everything after -- so that several fragments can share the middle step.
+  int solve_begin(int o, const double* h, const double* dm0, const FragmentOptions& opt, int eeval, FragmentResult* res);
+  int solve_end(double* mo_coeff, double* mo_energy, double* rdm1_emb, double* rdm1_mo, double* t1, double* t2);
+  struct BatchOutputs { double *mo_coeff = nullptr, *mo_energy = nullptr, *rdm1_emb = nullptr, *rdm1_mo = nullptr, *t1 = nullptr, *t2 = nullptr; };
+  // every fragment of a sweep in one call: solve_begin / solve_end per fragment on its own execution context (host thread + stream),
+  // the CCSD iterations of all of them in lock step (one grouped launch per operation).  Results as from solve(), bit for bit.
+  static int solve_batch(const std::vector<Fragment*>& frs, const std::vector<int>& o, const std::vector<const double*>& h,
+                         const std::vector<const double*>& dm0, const FragmentOptions& opt, int eeval, std::vector<FragmentResult>& res,
+                         const std::vector<BatchOutputs>& outs, LockstepStats* stats);
   // Bench hooks: set up the CCSD problem once (SCF + transform), then time single iterations.
   int prepare_ccsd(int o, const double* h, const double* dm0, const FragmentOptions& opt);
   int ccsd_iterate(int niter, double* e_corr, double* normt);
@@ -78,6 +88,12 @@ class Fragment {
   std::vector<double> h1_, veff0_, veff_;
   double weight_ = 1.0;
   std::vector<int> centers_;
+  // what solve_begin hands to solve_end
+  struct SolvePending {
+    int o = 0, eeval = 0; FragmentOptions opt; FragmentResult* res = nullptr;
+    bool unconverged = false, no_virtuals = false;
+    std::vector<double> C, eps;
+  } sp_;
   // state of the last solve
   DBuf C_, eps_, dm_, J_, K_;
   std::unique_ptr<CcsdSolver> cc_;

@@ -36,6 +36,7 @@
 #include <vector>
 #include "dev_ops.h"
 #include "hip_common.h"
+#include "grouped_launch.h"
 
 namespace qemb {
 
@@ -230,8 +231,7 @@ __device__ __forceinline__ double lane_swap_neighbour(double x) {
 // TAG does not change the code: it gives a call site its own kernel symbol so that profiles (rocprofv3 --stats, PMC) of the
 // pp-ladder are not mixed with other users of the same tile shape.
 template <int WM, int WN, int WAVES_M, int WAVES_N, int BK, bool A_KC, bool B_KC, int VEC, int TAG = 0, int MODE = 0>
-__global__ void __launch_bounds__(WAVES_M* WAVES_N * 64, (WM * WN <= 16) ? 2 : 1)
-    dgemm_mfma_kernel(GemmKArgs g) {
+__device__ __forceinline__ void dgemm_mfma_body(const uint3 BID, const uint3 GDIM, GemmKArgs g) {
   const long long t_start = g.cyc ? (long long)__builtin_amdgcn_s_memtime() : 0;
   constexpr int BM = WM * 16 * WAVES_M;
   constexpr int BN = WN * 16 * WAVES_N;
@@ -254,18 +254,18 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64, (WM * WN <= 16) ? 2 : 1
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
   const int ntiles = g.tiles_m * g.tiles_n;
-  const int L = xcd_remap(blockIdx.x, ntiles);
+  const int L = xcd_remap(BID.x, ntiles);
   const int tm = L % g.tiles_m, tn = L / g.tiles_m;
   const int m0 = tm * BM, n0 = tn * BN;
 
-  const long long bz = blockIdx.y / g.ksplit;
-  const int kslice = blockIdx.y % g.ksplit;
+  const long long bz = BID.y / g.ksplit;
+  const int kslice = BID.y % g.ksplit;
   const int kbeg = kslice * g.kchunk;
   const int kend = (kbeg + g.kchunk < g.K) ? kbeg + g.kchunk : g.K;
   const double* __restrict__ A = g.A + bz * g.strideA;
   const double* __restrict__ B = g.B + bz * g.strideB;
   // with split-K every slice writes its own partial (C = workspace [batch][slice][M][N]); combined by splitk_reduce
-  double* __restrict__ C = g.C + (long long)blockIdx.y * g.strideC;
+  double* __restrict__ C = g.C + (long long)BID.y * g.strideC;
 
   d4 acc[WM][WN];
 #pragma unroll
@@ -394,9 +394,9 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64, (WM * WN <= 16) ? 2 : 1
     }
     if constexpr (TAG == 2) {
       if (g.cyc && lane == 0) {     // [workgroup][wave][3]: cycles in k-steps 0..NKS-2 (+ LDS stores), at the barrier (+ fetch issue), in the last k-step
-        long long* o = g.cyc + (((long long)blockIdx.y * gridDim.x + blockIdx.x) * (WAVES_M * WAVES_N) + wave) * 4;
+        long long* o = g.cyc + (((long long)BID.y * GDIM.x + BID.x) * (WAVES_M * WAVES_N) + wave) * 4;
         o[0] = st_work; o[1] = st_bar; o[2] = st_last; o[3] = (long long)__builtin_amdgcn_s_memtime() - t_start;   // o[3]: kernel entry -> end of the main loop
-        if (g.cyc2) { long long* q = g.cyc2 + (((long long)blockIdx.y * gridDim.x + blockIdx.x) * (WAVES_M * WAVES_N) + wave) * 4; q[0] = pst[0] - t_start; q[1] = pst[1] - pst[0]; q[2] = pst[2] - pst[1]; q[3] = pst[3] - pst[2]; }
+        if (g.cyc2) { long long* q = g.cyc2 + (((long long)BID.y * GDIM.x + BID.x) * (WAVES_M * WAVES_N) + wave) * 4; q[0] = pst[0] - t_start; q[1] = pst[1] - pst[0]; q[2] = pst[2] - pst[1]; q[3] = pst[3] - pst[2]; }
       }
     }
     // the run-ahead reads of the final k-step are still in flight: let them land before the fragment registers are reused
@@ -496,17 +496,23 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64, (WM * WN <= 16) ? 2 : 1
       }
     }
   }
-  if (TAG != 2 && g.cyc && threadIdx.x == 0) g.cyc[(long long)blockIdx.y * gridDim.x + blockIdx.x] = (long long)__builtin_amdgcn_s_memtime() - t_start;
-  if (TAG == 2 && g.cyc && lane == 0) g.cyc[(long long)gridDim.x * gridDim.y * (WAVES_M * WAVES_N) * 4 + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * (WAVES_M * WAVES_N) + wave] = (long long)__builtin_amdgcn_s_memtime() - t_start;   // whole wave lifetime
+  if (TAG != 2 && g.cyc && threadIdx.x == 0) g.cyc[(long long)BID.y * GDIM.x + BID.x] = (long long)__builtin_amdgcn_s_memtime() - t_start;
+  if (TAG == 2 && g.cyc && lane == 0) g.cyc[(long long)GDIM.x * GDIM.y * (WAVES_M * WAVES_N) * 4 + ((long long)BID.y * GDIM.x + BID.x) * (WAVES_M * WAVES_N) + wave] = (long long)__builtin_amdgcn_s_memtime() - t_start;   // whole wave lifetime
+}
+
+template <int WM, int WN, int WAVES_M, int WAVES_N, int BK, bool A_KC, bool B_KC, int VEC, int TAG = 0, int MODE = 0>
+__global__ void __launch_bounds__(WAVES_M* WAVES_N * 64, (WM * WN <= 16) ? 2 : 1)
+    dgemm_mfma_kernel(GemmKArgs g) {
+  dgemm_mfma_body<WM, WN, WAVES_M, WAVES_N, BK, A_KC, B_KC, VEC, TAG, MODE>(make_uint3(blockIdx.x, blockIdx.y, blockIdx.z), make_uint3(gridDim.x, gridDim.y, gridDim.z), g);
 }
 
 // C[b][m][n] = alpha * sum_s ws[b][s][m][n] + beta * C   (fixed summation order: deterministic)
-__global__ void __launch_bounds__(256) splitk_reduce_kernel(const double* __restrict__ ws, int S, long long M, long long N,
+__device__ __forceinline__ void splitk_reduce_kernel_body(const uint3 BID, const uint3 GDIM, const double* __restrict__ ws, int S, long long M, long long N,
                                                             double* __restrict__ C, long long ldc, long long strideC,
                                                             double alpha, double beta) {
   const long long mn = M * N;
-  const long long b = blockIdx.y;
-  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < mn; t += (long long)gridDim.x * blockDim.x) {
+  const long long b = BID.y;
+  for (long long t = (long long)BID.x * blockDim.x + threadIdx.x; t < mn; t += (long long)GDIM.x * blockDim.x) {
     double acc = 0.0;
     const double* p = ws + b * S * mn + t;
     for (int s = 0; s < S; ++s) acc += p[(long long)s * mn];
@@ -515,15 +521,18 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const double* __rest
     *c = (beta != 0.0) ? alpha * acc + beta * (*c) : alpha * acc;
   }
 }
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(const double* __restrict__ ws, int S, long long M, long long N,
+                                                            double* __restrict__ C, long long ldc, long long strideC,
+                                                            double alpha, double beta) { splitk_reduce_kernel_body(make_uint3(blockIdx.x, blockIdx.y, blockIdx.z), make_uint3(gridDim.x, gridDim.y, gridDim.z), ws, S, M, N, C, ldc, strideC, alpha, beta); }
 // Few outputs, many slabs (the o x o / v x v shaped intermediates with K = o v^2 split several hundred ways): one WAVE per
 // output element, lane l sums slabs l, l+64, ... and the 64 partial sums are combined in a fixed butterfly order.
-__global__ void __launch_bounds__(256) splitk_reduce_wave_kernel(const double* __restrict__ ws, int S, long long M, long long N,
+__device__ __forceinline__ void splitk_reduce_wave_kernel_body(const uint3 BID, const uint3 GDIM, const double* __restrict__ ws, int S, long long M, long long N,
                                                                  double* __restrict__ C, long long ldc, long long strideC,
                                                                  double alpha, double beta) {
   const long long mn = M * N;
-  const long long b = blockIdx.y;
+  const long long b = BID.y;
   const int lane = threadIdx.x & 63;
-  const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+  const long long wave = ((long long)BID.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((long long)GDIM.x * blockDim.x) >> 6;
   for (long long t = wave; t < mn; t += nwaves) {
     double acc = 0.0;
     const double* p = ws + b * S * mn + t;
@@ -537,6 +546,9 @@ __global__ void __launch_bounds__(256) splitk_reduce_wave_kernel(const double* _
     }
   }
 }
+__global__ void __launch_bounds__(256) splitk_reduce_wave_kernel(const double* __restrict__ ws, int S, long long M, long long N,
+                                                                 double* __restrict__ C, long long ldc, long long strideC,
+                                                                 double alpha, double beta) { splitk_reduce_wave_kernel_body(make_uint3(blockIdx.x, blockIdx.y, blockIdx.z), make_uint3(gridDim.x, gridDim.y, gridDim.z), ws, S, M, N, C, ldc, strideC, alpha, beta); }
 
 double* gemm_workspace(size_t bytes);   // dev_ops_hip.hip
 static long long* g_gemm_cyc = nullptr;          // QEMB_GEMM_TRACE: per-workgroup tick buffer of the traced launch
@@ -837,6 +849,27 @@ static int dev_gemm_dispatch(const GemmDesc& d) {
     case 235: return launch_layout<5, 2, 2, 4, 16>(d, s, vec2);
     default: set_error("dev_gemm: unknown tile config"); return QEMB_ERR_ARG;
   }
+}
+
+// grouped execution of several fragments' GEMMs in one launch (dev_ops_hip.hip "grouped launches"): registered there
+// (the tiles small fragments run on: 32 x 32, 64 x 64 and the skinny 128 x 32 / 32 x 128, every operand layout, 16- and 8-byte loads)
+template <int WM, int WN, int WAVES_M, int WAVES_N, int BK, int MODE>
+static void register_gemm_tile() {
+#define QEMB_REG(AK, BKC)                                                                                                                          \
+  register_groupable<dgemm_mfma_body<WM, WN, WAVES_M, WAVES_N, BK, AK, BKC, 2, 0, MODE>, WAVES_M * WAVES_N * 64, GemmKArgs>(                        \
+      (const void*)dgemm_mfma_kernel<WM, WN, WAVES_M, WAVES_N, BK, AK, BKC, 2, 0, MODE>);                                                           \
+  register_groupable<dgemm_mfma_body<WM, WN, WAVES_M, WAVES_N, BK, AK, BKC, 1, 0, 0>, WAVES_M * WAVES_N * 64, GemmKArgs>(                           \
+      (const void*)dgemm_mfma_kernel<WM, WN, WAVES_M, WAVES_N, BK, AK, BKC, 1, 0, 0>);
+  QEMB_REG(true, true) QEMB_REG(true, false) QEMB_REG(false, true) QEMB_REG(false, false)
+#undef QEMB_REG
+}
+void register_groupable_gemm() {
+  register_gemm_tile<1, 1, 2, 2, 32, 0>();     // cfg 2
+  register_gemm_tile<2, 2, 2, 2, 16, 1>();     // cfg 1
+  register_gemm_tile<4, 1, 2, 2, 16, 0>();     // cfg 20
+  register_gemm_tile<1, 4, 2, 2, 16, 0>();     // cfg 21
+  register_groupable<splitk_reduce_kernel_body, 256, const double*, int, long long, long long, double*, long long, long long, double, double>((const void*)splitk_reduce_kernel);
+  register_groupable<splitk_reduce_wave_kernel_body, 256, const double*, int, long long, long long, double*, long long, long long, double, double>((const void*)splitk_reduce_wave_kernel);
 }
 
 }  // namespace qemb

@@ -191,14 +191,18 @@ class DeviceDIIS {
   double* next_e() { return es_[count_ % space_]; }
   // err_dot (optional): <e, e> of the vector just pushed -- the diagonal of the Gram row this call computes anyway
   int extrapolate_pushed(double* x, bool x_holds_trial = false, double* err_dot = nullptr) {
+    QTRY(gram_issue());
+    QTRY(dev_sync());
+    return gram_finish(x, x_holds_trial, err_dot);
+  }
+  // The same in two halves, so that a caller driving several solvers can put ONE wait between them for all:
+  // gram_issue: the new row of the Gram matrix (one pass over the pushed error vector per eight stored ones) on its way to pinned host memory;
+  // gram_finish (after a dev_sync of this context): the small solve on the host and x = sum_i c_i x_i.
+  int gram_issue() {
     const int slot = count_ % space_;
-    // every early return below leaves the un-extrapolated trial vector in x
-    struct Fallback {
-      DeviceDIIS* d; double* x; int slot; bool armed;
-      ~Fallback() { if (armed) dcopy(d->n_, d->xs_[slot], x); }
-    } fb{this, x, slot, !x_holds_trial};
     ++count_;
     const int m = size();
+    if (!row_host_) { void* q = nullptr; QTRY(dev_pinned_alloc(&q, sizeof(double) * (space_ + 1))); row_host_ = (double*)q; }
     // refresh row/column `slot` of the Gram matrix
     for (int j0 = 0; j0 < m; j0 += 8) {   // one pass over the new error vector per eight stored ones
       const int cnt = std::min(8, m - j0);
@@ -206,8 +210,19 @@ class DeviceDIIS {
       for (int q = 0; q < cnt; ++q) ps[q] = es_[j0 + q].p;
       QTRY(dev_dot_many(n_, es_[slot], cnt, ps, scal_.p + j0));
     }
-    std::vector<double> row(m);
-    QTRY(dev_d2h(row.data(), scal_.p, sizeof(double) * m));
+    QTRY(dev_d2h_async(row_host_, scal_.p, sizeof(double) * m));
+    pending_slot_ = slot;
+    return 0;
+  }
+  int gram_finish(double* x, bool x_holds_trial = false, double* err_dot = nullptr) {
+    const int slot = pending_slot_;
+    // every early return below leaves the un-extrapolated trial vector in x
+    struct Fallback {
+      DeviceDIIS* d; double* x; int slot; bool armed;
+      ~Fallback() { if (armed) dcopy(d->n_, d->xs_[slot], x); }
+    } fb{this, x, slot, !x_holds_trial};
+    const int m = size();
+    const double* row = row_host_;
     for (int j = 0; j < m; ++j) { B_[(size_t)slot * space_ + j] = row[j]; B_[(size_t)j * space_ + slot] = row[j]; }
     if (err_dot) *err_dot = row[slot];
     if (m < 2) return 0;
@@ -238,6 +253,15 @@ class DeviceDIIS {
   std::vector<DBuf> xs_, es_;
   DBuf scal_;
   std::vector<double> B_;
+  double* row_host_ = nullptr;      // pinned: the Gram row on its way back (gram_issue -> gram_finish)
+  int pending_slot_ = 0;
+ public:
+  ~DeviceDIIS() { if (row_host_) dev_pinned_free(row_host_); }
+  DeviceDIIS(DeviceDIIS&& o) noexcept : space_(o.space_), n_(o.n_), count_(o.count_), xs_(std::move(o.xs_)), es_(std::move(o.es_)), scal_(std::move(o.scal_)),
+                                        B_(std::move(o.B_)), row_host_(o.row_host_), pending_slot_(o.pending_slot_) { o.row_host_ = nullptr; }
+  DeviceDIIS(const DeviceDIIS&) = delete;
+  DeviceDIIS& operator=(const DeviceDIIS&) = delete;
+  DeviceDIIS& operator=(DeviceDIIS&&) = delete;
 };
 
 }  // namespace qemb

@@ -146,3 +146,43 @@ class DeviceFragment:
             self.free()
         except Exception:
             pass
+
+
+def solve_batch(frags, nsoccs, hs, dm0s=None, opts: SolverOpts | None = None, eeval=True, want_t2=False, stats=None):
+    """qemb_frag_solve_batch: every fragment of `frags` (DeviceFragment objects of one library) in one call -- fragment RHF, MO transformation
+    and the density / energy evaluation per fragment on its own stream, the CCSD iterations of all fragments in lock step (one grouped
+    launch per operation).  Returns the list of dicts DeviceFragment.solve would return, bit for bit; `stats` (a dict) receives the
+    launch counters of the lock-step iterations."""
+    F = len(frags)
+    if F == 0:
+        return []
+    lib = frags[0].lib
+    opts = opts or default_opts(lib)
+    ns = [int(o) for o in nsoccs]
+    hs = [np.ascontiguousarray(h, dtype=np.float64) for h in hs]
+    dm0s = [None] * F if dm0s is None else [None if d is None else np.ascontiguousarray(d, dtype=np.float64) for d in dm0s]
+    outs = []
+    for fr, o in zip(frags, ns):
+        n, v = fr.n, fr.n - o
+        outs.append(dict(mo_coeff=np.empty((n, n)), mo_energy=np.empty(n), rdm1_emb=np.empty((n, n)), rdm1_mo=np.empty((n, n)),
+                         t1=np.empty((o, v)), t2=np.empty((o, o, v, v)) if want_t2 else None))
+    VP = C.c_void_p * F
+    arr = lambda xs: VP(*[None if x is None else x.ctypes.data for x in xs])
+    handles = VP(*[fr.h for fr in frags])
+    nso = (C.c_int * F)(*ns)
+    e_frag = np.zeros((F, 3)); ecorr = np.zeros(F); escf = np.zeros(F); ebehf = np.zeros(F)
+    nit = (C.c_int * F)(); ncyc = (C.c_int * F)(); st = (C.c_int64 * 5)()
+    check(lib.qemb_frag_solve_batch(F, handles, nso, arr(hs), arr(dm0s), C.byref(opts), int(bool(eeval)),
+                                    arr([o_["mo_coeff"] for o_ in outs]), arr([o_["mo_energy"] for o_ in outs]), arr([o_["rdm1_emb"] for o_ in outs]),
+                                    arr([o_["rdm1_mo"] for o_ in outs]), arr([o_["t1"] for o_ in outs]), arr([o_["t2"] for o_ in outs]),
+                                    e_frag.ctypes.data, ecorr.ctypes.data, escf.ctypes.data, ebehf.ctypes.data, nit, ncyc, st),
+          "qemb_frag_solve_batch", lib)
+    for f, (fr, o_) in enumerate(zip(frags, outs)):
+        nlam = C.c_int()
+        check(lib.qemb_frag_lambda_iters(fr.h, C.byref(nlam)), "qemb_frag_lambda_iters", lib)
+        o_.update(e_frag=e_frag[f].copy(), e_corr_mo=float(ecorr[f]), e_scf=float(escf[f]), ebe_hf=float(ebehf[f]), n_iter=int(nit[f]),
+                  scf_cycles=int(ncyc[f]), lambda_iters=nlam.value)
+    if stats is not None:
+        for k, name in enumerate(("merged_runs", "launches", "grouped_launches", "operations", "max_group")):
+            stats[name] = stats.get(name, 0) + int(st[k]) if name != "max_group" else max(stats.get(name, 0), int(st[k]))
+    return outs

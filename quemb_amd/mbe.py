@@ -31,7 +31,7 @@ def initialize_pot(n_frag, relAO_per_edge):
 
 class BE:
     def __init__(self, mf, fobj, *, lo_method="lowdin", thr_bath=1.0e-10, int_transform="in-core-hip", auxbasis=None,
-                 df_ints=None, nproc=1, ompnum=1, initialize_fragment_idx=None, solver_opts=None, lib=None, distribute=True, nstreams=1,
+                 df_ints=None, nproc=1, ompnum=1, initialize_fragment_idx=None, solver_opts=None, lib=None, distribute=True, nstreams=1, lockstep=False,
                  eri_file=None, scratch_dir=None, restart=False, schmidt_method="subspace", MO_coeff_epsilon=1e-5, AO_coeff_epsilon=1e-10):
         if lo_method != "lowdin":
             raise NotImplementedError("only lo_method='lowdin' is mirrored (localisation is upstream of the hot path)")
@@ -45,6 +45,7 @@ class BE:
         self.MO_coeff_epsilon, self.AO_coeff_epsilon = float(MO_coeff_epsilon), float(AO_coeff_epsilon)      # mbe.py:191-192
         self.opts = solver_opts
         self.nstreams = int(nstreams)             # fragments in flight at once on this GPU (solver.map_fragments)
+        self.lockstep = bool(lockstep)            # all fragments of a sweep in one batched call (solver.solve_fragments): the small-fragment regime
         self.unrestricted = False
         self.ebe_hf = 0.0
         self.ebe_tot = 0.0
@@ -250,8 +251,8 @@ class BE:
     def _sweep(self, pot, **kw):
         if self.world > 1:
             return be_func_parallel(pot, self.Fobjs, self.Nocc, "CCSD", self.enuc, owner=self.owner, opts=self.opts,
-                                    stats=self.stats, emap=self.emap, nstreams=self.nstreams, **kw)
-        return be_func(pot, self.Fobjs, self.Nocc, "CCSD", self.enuc, opts=self.opts, stats=self.stats, nstreams=self.nstreams, **kw)
+                                    stats=self.stats, emap=self.emap, nstreams=self.nstreams, lockstep=self.lockstep, **kw)
+        return be_func(pot, self.Fobjs, self.Nocc, "CCSD", self.enuc, opts=self.opts, stats=self.stats, nstreams=self.nstreams, lockstep=self.lockstep, **kw)
 
     def oneshot(self, solver="CCSD", use_cumulant=True, nproc=1, ompnum=1, solver_args=None):
         """mbe.py:1240-1310."""

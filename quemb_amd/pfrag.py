@@ -167,6 +167,12 @@ class Frags:
     def solve(self, opts=None, eeval=True, use_cumulant=True, want_t2=False, relax_density=False):
         """update_heff -> scf -> solve_ccsd -> rdm1 -> get_frag_energy for this fragment (solver.py:301-547).
         relax_density: solve_ccsd(relax=True) (solver.py:925-939) -- Lambda equations on the device, response densities."""
+        opts = self._solve_inputs(opts, eeval, relax_density)
+        out = self.dev.solve(self.nsocc, self.fock + self.heff, self.dm0, opts=opts, eeval=eeval, want_t2=want_t2)
+        return self._solve_outputs(out, eeval, use_cumulant)
+
+    def _solve_inputs(self, opts, eeval, relax_density):
+        """what has to be on the device before the solve call (shared with the lock-step sweep, solver.solve_fragments)"""
         if bool(relax_density) != bool(getattr(opts, "relax_density", 0) if opts is not None else 0):
             from ._lib import SolverOpts
             from .fragsolver import default_opts
@@ -175,7 +181,10 @@ class Frags:
         if eeval:
             w, cen = self.weight_and_relAO_per_center
             self.dev.set_energy_data(self.h1, self.veff0, self.veff, w, cen)
-        out = self.dev.solve(self.nsocc, self.fock + self.heff, self.dm0, opts=opts, eeval=eeval, want_t2=want_t2)
+        return opts
+
+    def _solve_outputs(self, out, eeval, use_cumulant):
+        """what solver.py:493-505 sets on the fragment object"""
         self.mo_coeffs = out["mo_coeff"]
         self.mo_energy = out["mo_energy"]
         self.t1 = out["t1"]

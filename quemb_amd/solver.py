@@ -130,22 +130,44 @@ def map_fragments(fn, frags, nstreams=1):
         return list(pool.map(fn, frags))
 
 
-def be_func(pot, Fobjs, Nocc, solver, enuc, solver_args=None, scratch_dir=None, only_chem=False, eeval=False,
-            relax_density=False, return_vec=False, use_cumulant=True, *, opts=None, stats=None, nstreams=1):
-    """molbe/solver.py:244-562 for solver == 'CCSD'.  `opts` (qemb_solver_opts), `stats` (dict collecting per-sweep
-    counters) and `nstreams` (fragments in flight at once, see map_fragments) are additions; everything else has the
-    reference's meaning."""
-    if solver != "CCSD":
-        raise ValueError("Solver not implemented")
-    total_e = [0.0, 0.0, 0.0]
-    n_iter = 0
+def solve_fragments(pot, frags, only_chem=False, opts=None, eeval=False, use_cumulant=True, relax_density=False, nstreams=1, lockstep=False,
+                    stats=None):
+    """The loop body of be_func (molbe/solver.py:301-547) for the fragments `frags`: update_heff, then the device solve of each.
+    nstreams > 1: that many fragments in flight on separate streams (map_fragments).  lockstep: ALL fragments in one library call
+    (qemb_frag_solve_batch) -- their CCSD iterations advance together, every operation one grouped launch; the small-fragment regime
+    (octane BE2 / BE3), where a fragment alone is bound by its ~110 dependent launches per iteration.  Same results, bit for bit."""
+    frags = list(frags)
+    if lockstep and len(frags) > 1:
+        from .fragsolver import solve_batch
+        o_list = []
+        for f in frags:
+            if pot is not None:
+                f.update_heff(pot, only_chem=only_chem)
+            assert f.fock is not None and f.heff is not None
+            o_list.append(f._solve_inputs(opts, eeval, relax_density))
+        # one options struct for the batch: the per-fragment ones differ at most by relax_density, which _solve_inputs set identically
+        outs = solve_batch([f.dev for f in frags], [f.nsocc for f in frags], [f.fock + f.heff for f in frags], [f.dm0 for f in frags],
+                           opts=o_list[0], eeval=eeval, stats=stats)
+        return [f._solve_outputs(out, eeval, use_cumulant) for f, out in zip(frags, outs)]
 
     def one(fobj):
         if pot is not None:
             fobj.update_heff(pot, only_chem=only_chem)
         assert fobj.fock is not None and fobj.heff is not None
         return fobj.solve(opts=opts, eeval=eeval, use_cumulant=use_cumulant, relax_density=relax_density)
-    for out in map_fragments(one, Fobjs, nstreams):
+    return map_fragments(one, frags, nstreams)
+
+
+def be_func(pot, Fobjs, Nocc, solver, enuc, solver_args=None, scratch_dir=None, only_chem=False, eeval=False,
+            relax_density=False, return_vec=False, use_cumulant=True, *, opts=None, stats=None, nstreams=1, lockstep=False):
+    """molbe/solver.py:244-562 for solver == 'CCSD'.  `opts` (qemb_solver_opts), `stats` (dict collecting per-sweep
+    counters), `nstreams` (fragments in flight at once, see map_fragments) and `lockstep` (all fragments in one batched call, see
+    solve_fragments) are additions; everything else has the reference's meaning."""
+    if solver != "CCSD":
+        raise ValueError("Solver not implemented")
+    total_e = [0.0, 0.0, 0.0]
+    n_iter = 0
+    for out in solve_fragments(pot, Fobjs, only_chem, opts, eeval, use_cumulant, relax_density, nstreams, lockstep, stats):
         n_iter += out["n_iter"]
         if eeval:
             total_e = [a + b for a, b in zip(total_e, out["e_frag"])]

@@ -34,12 +34,19 @@ int dev_free(void* p) { std::free(p); return 0; }
 int dev_trim() { return 0; }
 int dev_h2d(void* d, const void* s, size_t b) { std::memcpy(d, s, b); return 0; }
 int dev_d2h(void* d, const void* s, size_t b) { std::memcpy(d, s, b); return 0; }
+int dev_d2h_async(void* d, const void* s, size_t b) { std::memcpy(d, s, b); return 0; }
+int dev_pinned_alloc(void** p, size_t b) { *p = std::malloc(b ? b : 16); return *p ? 0 : QEMB_ERR_ALLOC; }
+int dev_pinned_free(void* p) { std::free(p); return 0; }
 int dev_d2d(void* d, const void* s, size_t b) { std::memmove(d, s, b); return 0; }
 int dev_fill(double* x, int64_t n, double v) { std::fill(x, x + n, v); return 0; }
 int dev_graph_begin() { return 1; }   // the mock cannot capture: drivers run eagerly
 int dev_graph_end(dev_graph_t*) { return QEMB_ERR_DEVICE; }
 int dev_graph_launch(dev_graph_t) { return QEMB_ERR_DEVICE; }
 int dev_graph_destroy(dev_graph_t) { return 0; }
+int dev_tape_end(dev_tape_t*) { return 1; }            // the mock executes eagerly: nothing to tape
+int dev_tape_run(const dev_tape_t*, int) { set_error("hostcheck: no tapes"); return QEMB_ERR_DEVICE; }
+int dev_tape_destroy(dev_tape_t) { return QEMB_OK; }
+int dev_tape_last_stats(long long* a, long long* b, long long* c) { if (a) *a = 0; if (b) *b = 0; if (c) *c = 0; return QEMB_OK; }
 bool dev_capturing() { return false; }
 int dev_mem_info(size_t* f, size_t* t) { *f = *t = (size_t)1 << 34; return 0; }
 

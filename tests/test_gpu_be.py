@@ -599,3 +599,23 @@ def test_df_transform_matches_reference_integral_direct_DF(qlib):
     """row a4 on the HIP library against the outputs of the reference's own integral_direct_DF (tests/golden/df.npz)"""
     from test_df_golden import check_df_golden
     check_df_golden(qlib)
+
+
+def test_lockstep_sweep_gives_identical_results(qlib):
+    """lockstep=True: every fragment of the octane BE2 sweep in ONE library call (qemb_frag_solve_batch) -- fragment phases per stream,
+    CCSD iterations of all six fragments in lock step with one grouped launch per operation.  Bit for bit the serial sweep; the density
+    matching on top of it reproduces the reference's golden energy."""
+    from quemb_amd.solver import be_func
+    mf, be1 = _be("octane")
+    mfl, bel = _be("octane", lockstep=True)
+    stats = {}
+    r1 = be_func(None, be1.Fobjs, be1.Nocc, "CCSD", be1.enuc, eeval=True, return_vec=True, opts=be1.opts)
+    rl = be_func(None, bel.Fobjs, bel.Nocc, "CCSD", bel.enuc, eeval=True, return_vec=True, opts=bel.opts, lockstep=True, stats=stats)
+    assert r1[0] == rl[0] and np.array_equal(np.asarray(r1[1]), np.asarray(rl[1]))
+    assert r1[2][0] == rl[2][0] and list(r1[2][1]) == list(rl[2][1])
+    for a, b in zip(be1.Fobjs, bel.Fobjs):
+        assert np.array_equal(a._rdm1, b._rdm1) and np.array_equal(a.t1, b.t1) and np.array_equal(a.mo_coeffs, b.mo_coeffs)
+    assert stats["max_group"] == len(bel.Fobjs) and stats["grouped_launches"] > 0
+    assert stats["launches"] * 3 < stats["operations"]          # the launch count of the iterations fell by more than 3x
+    opt = bel.optimize(solver="CCSD", only_chem=False)
+    assert opt.err < 1e-6 and abs(bel.e_corr - (-0.5499514850769742)) < 5e-6

@@ -338,3 +338,9 @@ def test_fragment_larger_than_the_benchmark_size(qlib):
     assert abs(a["e_scf"] - b["e_scf"]) < 1e-9 * abs(a["e_scf"])
     assert abs(a["e_corr_mo"] - b["e_corr_mo"]) < 1e-8, (a["e_corr_mo"], b["e_corr_mo"])
     assert np.abs(b["rdm1_emb"] - Q.T @ a["rdm1_emb"] @ Q).max() < 1e-8
+
+
+def test_solve_batch_lockstep_equals_one_by_one(qlib):
+    """qemb_frag_solve_batch on the HIP library: grouped launches of the lock-step CCSD iterations, results identical bit for bit"""
+    from test_hostlogic_fragment import check_solve_batch_equals_one_by_one
+    check_solve_batch_equals_one_by_one(qlib, sizes=((12, 4, 4), (16, 5, 5), (10, 3, 3), (14, 6, 4), (9, 9, 2), (20, 7, 6)), expect_grouped=True)

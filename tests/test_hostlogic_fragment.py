@@ -243,3 +243,47 @@ def test_pair_gemm_tile_choice(hlib):
     for rows in (28, 105, 190, 210, 465, 820, 1275):
         cfg, ks = choice(rows)
         assert 1 <= ks <= 8
+
+
+def check_solve_batch_equals_one_by_one(lib, sizes=((8, 3, 3), (10, 4, 4), (7, 2, 2), (9, 3, 3), (6, 6, 2)), expect_grouped=False):
+    """qemb_frag_solve_batch (fragment phases per stream, CCSD iterations in lock step) == qemb_frag_solve fragment by fragment, bit for bit:
+    fragments of different sizes (they converge in different iterations and drop out of the lock step one by one), one without virtual
+    orbitals, energies on.  On the GPU the lock-step iterations must have issued grouped launches."""
+    from quemb_amd.fragsolver import DeviceFragment, default_opts, solve_batch
+    frs, hs, outs_ref = [], [], []
+    opts = default_opts(lib)
+    for k, (n, o, nf) in enumerate(sizes):
+        h, e1, h1, veff0, veff = _problem(n, o, nf, 900 + k)
+        fr = DeviceFragment(n, nf, lib=lib)
+        fr.set_eri_s4(eri.pack_s4(e1))
+        fr.set_energy_data(h1, veff0, veff, 1.0, list(range(nf)))
+        frs.append(fr); hs.append(h)
+        outs_ref.append(fr.solve(o, h, None, opts=opts, eeval=True, want_t2=True))
+    stats = {}
+    outs = solve_batch(frs, [s[1] for s in sizes], hs, None, opts=opts, eeval=True, want_t2=True, stats=stats)
+    assert len({o["n_iter"] for o in outs_ref}) > 1          # the fragments do not all converge together
+    for a, b in zip(outs, outs_ref):
+        assert a["n_iter"] == b["n_iter"] and a["scf_cycles"] == b["scf_cycles"]
+        for key in ("e_corr_mo", "e_scf", "ebe_hf"):
+            assert a[key] == b[key], key
+        for key in ("e_frag", "mo_coeff", "mo_energy", "rdm1_emb", "rdm1_mo", "t1", "t2"):
+            assert np.array_equal(a[key], b[key]), key
+    if expect_grouped:
+        assert stats["merged_runs"] > 0 and stats["grouped_launches"] > 0 and stats["launches"] < stats["operations"]
+        assert stats["max_group"] >= 2
+    # a second batch over the same handles (new tapes, new plans) and a batch of one
+    outs2 = solve_batch(frs[:2], [s[1] for s in sizes[:2]], hs[:2], None, opts=opts, eeval=True)
+    assert outs2[0]["e_corr_mo"] == outs_ref[0]["e_corr_mo"] and outs2[1]["e_corr_mo"] == outs_ref[1]["e_corr_mo"]
+    one = solve_batch(frs[1:2], [sizes[1][1]], hs[1:2], None, opts=opts, eeval=True)
+    assert one[0]["e_corr_mo"] == outs_ref[1]["e_corr_mo"]
+    from quemb_amd._lib import QembError
+    with pytest.raises(QembError):
+        solve_batch([frs[0], frs[0]], [3, 3], [hs[0], hs[0]], None, opts=opts)       # the same fragment twice
+    with pytest.raises(QembError):
+        solve_batch(frs[:2], [3, 4], hs[:2], None, opts=default_opts(lib, cc_max_cycle=1))      # non-convergence is an error for the whole batch
+    for fr in frs:
+        fr.free()
+
+
+def test_solve_batch_equals_one_by_one(hlib):
+    check_solve_batch_equals_one_by_one(hlib)
