@@ -383,12 +383,13 @@ static int jacobi_rows(int nvec, int64_t len, double* W, int64_t ldw, double* Vt
   QTRY_ALLOC(d_off, sizeof(unsigned long long));
   const double tol = std::max(1.0e-15, std::sqrt((double)len) * 2.22e-16);   // LAPACK dgesvj-style
   const int max_sweeps = 40;
-  // block rounds: the largest B in {16, 8, 4} whose two blocks (W rows + Vt rows) fit the LDS of a CU (QEMB_JACOBI_BLOCK=0: per-pair rounds, A/B runs)
+  // block rounds when two blocks of 16 vectors fit registers + LDS (QEMB_JACOBI_BLOCK=0: per-pair rounds, A/B runs)
   static const bool blocks_enabled = !(std::getenv("QEMB_JACOBI_BLOCK") && std::atoi(std::getenv("QEMB_JACOBI_BLOCK")) == 0);
   int B = 0;
   if (Vt && blocks_enabled && len < (1 << 20)) {
-    static const int forced_b = std::getenv("QEMB_JACOBI_B") ? std::atoi(std::getenv("QEMB_JACOBI_B")) : 0;
-    for (int b : {16, 8, 4}) if ((forced_b == 0 || b <= forced_b) && nvec >= 2 * b && sizeof(double) * 2 * b * (size_t)(len + nvec) <= 150 * 1024) { B = b; break; }
+    // two blocks of 16 vectors, [W row | Vt row] <= 600 doubles (10 register slots per lane): eigh for 96 < n <= 300 (the fragment Fock matrices).  (Instantiations with 8 / 4 vectors per block and up to 38 slots were built and measured: an
+    // order of magnitude slower than their 16-vector counterpart at the same size and minutes of compile time; longer vectors keep the per-pair rounds.)
+    if (nvec >= 32 && len + nvec <= 600) B = 16;
   }
   const int nb = B ? (nvec + B - 1) / B : 0, nbp = (nb % 2 == 0) ? nb : nb + 1;
   const size_t blk_lds = B ? sizeof(double) * 2 * B * (size_t)(len + nvec) : 0;
@@ -401,9 +402,7 @@ static int jacobi_rows(int nvec, int64_t len, double* W, int64_t ldw, double* Vt
       if (!attr_set) { err = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024); attr_set = true; }
       if (err == hipSuccess) hipLaunchKernelGGL(kern, dim3(nbp / 2), dim3(bw * 64), blk_lds, s, W, (long long)ldw, (int)len, Vt, nvec, nb, nbp, r, tol, floor2, d_off);
     };
-    if (B == 16) { if (npl_need <= 4) go(jacobi_block_round_kernel<16, 4>, 16); else if (npl_need <= 7) go(jacobi_block_round_kernel<16, 7>, 16); else go(jacobi_block_round_kernel<16, 10>, 16); }
-    else if (B == 8) { if (npl_need <= 7) go(jacobi_block_round_kernel<8, 7>, 8); else if (npl_need <= 12) go(jacobi_block_round_kernel<8, 12>, 8); else if (npl_need <= 15) go(jacobi_block_round_kernel<8, 15>, 8); else go(jacobi_block_round_kernel<8, 19>, 8); }
-    else { if (npl_need <= 7) go(jacobi_block_round_kernel<4, 7>, 4); else if (npl_need <= 24) go(jacobi_block_round_kernel<4, 24>, 4); else if (npl_need <= 30) go(jacobi_block_round_kernel<4, 30>, 4); else go(jacobi_block_round_kernel<4, 38>, 4); }
+    if (npl_need <= 4) go(jacobi_block_round_kernel<16, 4>, 16); else if (npl_need <= 7) go(jacobi_block_round_kernel<16, 7>, 16); else go(jacobi_block_round_kernel<16, 10>, 16);
     return err;
   };
   int sweep = 0;

@@ -29,6 +29,9 @@ flops_of = {   # kernel-symbol fragment -> (executed flop of one large call, wha
 bytes_of = {   # kernel-name fragment -> (algorithmic bytes of one large call, what)
     "unpack_tril_tiled_kernel": ((npn * npn + npn * n * n) * 8, "packed rows -> unpacked n x n slabs (read packed + write unpacked)"),
     "jk_packed_stage1": (npn * npn * 8, "Coulomb + exchange matrix, one pass over the 4-fold packed block"),
+    "jk_packed_rowgroups": (npn * npn * 8, "Coulomb + exchange matrix, one pass over the 4-fold packed block (round 3: 16-lane row groups, 16-byte loads)"),
+    "pack_pm_tiled_kernel<0>": ((o * v * v * v + o * v * (npv + nmv)) * 8, "(+/-) packed images of the ovvv block through LDS tiles (round 3)"),
+    "pack_pm_tiled_kernel<1>": ((npo * v * v + npo * npv + nmo * nmv) * 8, "tau -> (+/-) packed pair rows through LDS tiles (round 3)"),
     "ladder_pack_vvvv_pf_kernel": (2 * (npv * npv + nmv * nmv) * 8, "(+/-) ladder operands from the pair-first MO tensor"),
     "pack_pm_cols_kernel": ((o * v * v * v + o * v * (npv + nmv)) * 8, "(+/-) packed images of the ovvv block"),
     "ladder_scatter_pm_kernel": (2 * N2 + (npo * npv + nmo * nmv) * 8, "ladder result -> t2 (r/w t2 + read R+/R-)"),
