@@ -31,6 +31,7 @@ struct MoIntegrals {
 // eri_s4: (npair x npair) 4-fold packed embedding-basis ERIs on the device (read only); X0, X1: two device work
 // buffers of mo_transform_work(n) = n^2 * npair doubles each; C: n x n MO coefficients (columns) on the device.
 // x1_is_unpacked: X1 already holds the half-unpacked tensor [P(p,q)][r][s] (it is consumed).
+int mo_slab_ld(int n);            // row stride of the unpacked n x n images inside X0 / X1 (>= n)
 int64_t mo_transform_work(int n);
 int mo_transform(int n, int o, int nf, const double* eri_s4, double* X0, double* X1, const double* C, MoIntegrals& out,
                  bool build_Vl = false, bool build_T34 = false, bool x1_is_unpacked = false);

@@ -1263,7 +1263,7 @@ int dev_ladder_pack_vvvv(int64_t n, int64_t o, const double* M, double* Vp, int6
 template <int MODE>
 __global__ void __launch_bounds__(256) pack_pm_tiled_kernel(long long rows, long long o, long long v, const double* __restrict__ in, double* __restrict__ Op,
                                                             long long ldp, double* __restrict__ Om, long long ldm) {
-  __shared__ double tA[32][33], tB[32][33];
+  __shared__ double tB[32][33];       // only the mirror tile goes through LDS; the straight tile stays in the registers of the threads that write it
   const long long np = v * (v + 1) / 2, nm = v * (v - 1) / 2;
   long long tc, td; unpair_ge((long long)blockIdx.x, tc, td);
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -1277,14 +1277,17 @@ __global__ void __launch_bounds__(256) pack_pm_tiled_kernel(long long rows, long
     } else {
       t = in + r * v * v; tm = Om + r * ldm;
     }
+    double xa[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int rr = ty + 8 * k;
       const long long c = tc * 32 + rr, d = td * 32 + tx;
-      tA[rr][tx] = (c < v && d < v) ? t[c * v + d] : 0.0;
+      xa[k] = (c < v && d < v) ? t[c * v + d] : 0.0;
       if (!diag) {
         const long long d2 = td * 32 + rr, c2 = tc * 32 + tx;
         tB[rr][tx] = (d2 < v && c2 < v) ? t[d2 * v + c2] : 0.0;
+      } else {
+        tB[rr][tx] = xa[k];
       }
     }
     __syncthreads();
@@ -1293,7 +1296,7 @@ __global__ void __launch_bounds__(256) pack_pm_tiled_kernel(long long rows, long
       const int cc = ty + 8 * k;
       const long long c = tc * 32 + cc, d = td * 32 + tx;
       if (c < v && d <= c) {
-        const double x = tA[cc][tx], y = diag ? tA[tx][cc] : tB[tx][cc];
+        const double x = xa[k], y = tB[tx][cc];
         if (MODE == 1) {
           tp[c * (c + 1) / 2 + d] = (c == d) ? 0.25 * (x + y) : 0.5 * (x + y);
           if (tm && c > d) tm[c * (c - 1) / 2 + d] = 0.5 * (x - y);
@@ -2076,9 +2079,11 @@ static int64_t unpack_walkers(int64_t rows, int64_t ntiles) {
 // dup == 1: the row index is itself a pair (p >= q) of an s4 block; the n x n image goes to rows (p,q) and (q,p).
 // dup == 2: the SOURCE rows are gathered: packed row r = pair (x,y), x >= y, is read from row x*n + y (pair-row selection fused in).
 __device__ __forceinline__ void unpack_tril_tiled_kernel_body(const uint3 BID, const uint3 GDIM, long long rows, long long n, const double* __restrict__ packed,
-                                                               double* __restrict__ full, int dup, long long nr) {
+                                                               double* __restrict__ full, int dup, long long nr, long long ld) {
+  // ld: row stride of the n x n images (>= n).  A stride that is a multiple of 16 doubles makes every 256-byte run of a tile start on a
+  // 128-byte line: n = 220 unpacks at 3.7 TB/s with ld = 220 (every run ends in two partially written lines) and at 5.7 with ld = 224.
   __shared__ double tile[32][33];
-  const long long np = n * (n + 1) / 2, n2 = n * n;
+  const long long np = n * (n + 1) / 2, n2 = n * ld;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   // BID.x = lower-triangle tile (tk >= tl), BID.y (looped) = packed row: every block moves one 32 x 32 tile
   long long tt = BID.x, tk, tl; unpair_ge(tt, tk, tl);
@@ -2094,26 +2099,34 @@ __device__ __forceinline__ void unpack_tril_tiled_kernel_body(const uint3 BID, c
       long long x, y; unpair_ge(r, x, y);
       src = packed + (x * nr + y) * np;
     }
+    // the straight image is written from the registers the tile arrived in (before the barrier: it does not need LDS);
+    // only the mirror image is read back transposed
+    double xr[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int kk = ty + 8 * i;
       const long long k = tk * 32 + kk, l = tl * 32 + tx;
-      tile[kk][tx] = (k < n && l <= k) ? src[k * (k + 1) / 2 + l] : 0.0;
+      xr[i] = (k < n && l <= k) ? src[k * (k + 1) / 2 + l] : 0.0;
+      tile[kk][tx] = xr[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int kk = ty + 8 * i;
+      const long long k = tk * 32 + kk, l = tl * 32 + tx;
+      if (k < n && l <= k) { dst0[k * ld + l] = xr[i]; if (dst1) dst1[k * ld + l] = xr[i]; }
     }
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int kk = ty + 8 * i;
-      const long long k = tk * 32 + kk, l = tl * 32 + tx;
-      if (k < n && l <= k) { const double x = tile[kk][tx]; dst0[k * n + l] = x; if (dst1) dst1[k * n + l] = x; }
       const long long lr = tl * 32 + kk, kc = tk * 32 + tx;
-      if (kc < n && lr < kc) { const double y = tile[tx][kk]; dst0[lr * n + kc] = y; if (dst1) dst1[lr * n + kc] = y; }
+      if (kc < n && lr < kc) { const double y = tile[tx][kk]; dst0[lr * ld + kc] = y; if (dst1) dst1[lr * ld + kc] = y; }
     }
     __syncthreads();
   }
 }
 __global__ void __launch_bounds__(256) unpack_tril_tiled_kernel(long long rows, long long n, const double* __restrict__ packed,
-                                                               double* __restrict__ full, int dup, long long nr) { unpack_tril_tiled_kernel_body(make_uint3(blockIdx.x, blockIdx.y, blockIdx.z), make_uint3(gridDim.x, gridDim.y, gridDim.z), rows, n, packed, full, dup, nr); }
+                                                               double* __restrict__ full, int dup, long long nr, long long ld) { unpack_tril_tiled_kernel_body(make_uint3(blockIdx.x, blockIdx.y, blockIdx.z), make_uint3(gridDim.x, gridDim.y, gridDim.z), rows, n, packed, full, dup, nr, ld); }
 
 // s1[i,j,k,l] = s4[pair(i,j), pair(k,l)];  one block row per (i,j), threads along (k,l)
 __global__ void __launch_bounds__(256) unpack_s4_kernel(long long n, const double* s4, double* s1) {
@@ -2133,7 +2146,7 @@ int dev_unpack_s4(int64_t n, const double* s4, double* s1) {
   if (n >= 32) {
     const int64_t np = n * (n + 1) / 2;
     const int64_t nt = (n + 31) / 32;
-    hipLaunchKernelGGL(unpack_tril_tiled_kernel, dim3((unsigned)(nt * (nt + 1) / 2), (unsigned)unpack_walkers(np, nt * (nt + 1) / 2)), dim3(256), 0, g_stream, (long long)np, (long long)n, s4, s1, 1, (long long)n);
+    hipLaunchKernelGGL(unpack_tril_tiled_kernel, dim3((unsigned)(nt * (nt + 1) / 2), (unsigned)unpack_walkers(np, nt * (nt + 1) / 2)), dim3(256), 0, g_stream, (long long)np, (long long)n, s4, s1, 1, (long long)n, (long long)n);
   } else {
     hipLaunchKernelGGL(unpack_s4_kernel, dim3((unsigned)std::min<int64_t>(n * n, 1 << 20)), dim3(256), 0, g_stream, (long long)n, s4, s1);
   }
@@ -2186,13 +2199,15 @@ __device__ __forceinline__ void unpack_tril_rows_kernel_body(const uint3 BID, co
     }
 }
 __global__ void __launch_bounds__(256) unpack_tril_rows_kernel(long long rows, long long n, const double* packed, double* full) { unpack_tril_rows_kernel_body(make_uint3(blockIdx.x, blockIdx.y, blockIdx.z), make_uint3(gridDim.x, gridDim.y, gridDim.z), rows, n, packed, full); }
-int dev_unpack_tril_rows(int64_t rows, int64_t n, const double* packed, double* full) {
+int dev_unpack_tril_rows(int64_t rows, int64_t n, const double* packed, double* full) { return dev_unpack_tril_rows_ld(rows, n, n, packed, full); }
+int dev_unpack_tril_rows_ld(int64_t rows, int64_t n, int64_t ld, const double* packed, double* full) {
   REQUIRE_INIT();
   if (rows <= 0) return QEMB_OK;
-  if (n >= 32)
+  if (ld < n) { set_error("dev_unpack_tril_rows_ld: ld < n"); return QEMB_ERR_ARG; }
+  if (n >= 32 || ld != n)
   {
     const int64_t nt = (n + 31) / 32;
-    hipLaunchKernelGGL(unpack_tril_tiled_kernel, dim3((unsigned)(nt * (nt + 1) / 2), (unsigned)unpack_walkers(rows, nt * (nt + 1) / 2)), dim3(256), 0, g_stream, (long long)rows, (long long)n, packed, full, 0, (long long)n);
+    hipLaunchKernelGGL(unpack_tril_tiled_kernel, dim3((unsigned)(nt * (nt + 1) / 2), (unsigned)unpack_walkers(rows, nt * (nt + 1) / 2)), dim3(256), 0, g_stream, (long long)rows, (long long)n, packed, full, 0, (long long)n, (long long)ld);
   }
   else
     hipLaunchKernelGGL(unpack_tril_rows_kernel, dim3((unsigned)std::min<int64_t>(rows, 1 << 20)), dim3(256), 0, g_stream, (long long)rows, (long long)n, packed, full);
@@ -2201,10 +2216,12 @@ int dev_unpack_tril_rows(int64_t rows, int64_t n, const double* packed, double* 
 }
 // full[P(x,y)][k][l] = in[(x*nr + y)][P(k,l)] for x >= y (x, y < nr; k, l < n): "keep the x >= y rows" and "unpack the pair column"
 // in one pass
-int dev_unpack_tril_pair_rows(int64_t nr, int64_t n, const double* in, double* full) {
+int dev_unpack_tril_pair_rows(int64_t nr, int64_t n, const double* in, double* full) { return dev_unpack_tril_pair_rows_ld(nr, n, n, in, full); }
+int dev_unpack_tril_pair_rows_ld(int64_t nr, int64_t n, int64_t ld, const double* in, double* full) {
   REQUIRE_INIT();
   const int64_t np = n * (n + 1) / 2, npr = nr * (nr + 1) / 2;
-  if (n < 32) {   // small problems: two simple passes through a staging buffer
+  if (ld < n) { set_error("dev_unpack_tril_pair_rows_ld: ld < n"); return QEMB_ERR_ARG; }
+  if (n < 32 && ld == n) {   // small problems: two simple passes through a staging buffer
     void* tmp = nullptr;
     int rc = dev_alloc(&tmp, sizeof(double) * (size_t)npr * np);
     if (rc) return rc;
@@ -2214,7 +2231,7 @@ int dev_unpack_tril_pair_rows(int64_t nr, int64_t n, const double* in, double* f
     return rc;
   }
   const int64_t nt = (n + 31) / 32;
-  hipLaunchKernelGGL(unpack_tril_tiled_kernel, dim3((unsigned)(nt * (nt + 1) / 2), (unsigned)unpack_walkers(npr, nt * (nt + 1) / 2)), dim3(256), 0, g_stream, (long long)npr, (long long)n, in, full, 2, (long long)nr);
+  hipLaunchKernelGGL(unpack_tril_tiled_kernel, dim3((unsigned)(nt * (nt + 1) / 2), (unsigned)unpack_walkers(npr, nt * (nt + 1) / 2)), dim3(256), 0, g_stream, (long long)npr, (long long)n, in, full, 2, (long long)nr, (long long)ld);
   HIP_TRY(hipGetLastError());
   return QEMB_OK;
 }
@@ -2255,7 +2272,7 @@ static void register_groupable_kernels() {
   register_groupable<contract_mid_stage1_body, 256, long long, long long, int, const double*, const double*, double*>((const void*)contract_mid_stage1);
   register_groupable<contract_mid_stage2_body, 256, long long, long long, int, const double*, double*, long long, double, double>((const void*)contract_mid_stage2);
   register_groupable<unpack_tril_rows_kernel_body, 256, long long, long long, const double*, double*>((const void*)unpack_tril_rows_kernel);
-  register_groupable<unpack_tril_tiled_kernel_body, 256, long long, long long, const double*, double*, int, long long>((const void*)unpack_tril_tiled_kernel);
+  register_groupable<unpack_tril_tiled_kernel_body, 256, long long, long long, const double*, double*, int, long long, long long>((const void*)unpack_tril_tiled_kernel);
   register_groupable<fill_kernel_body, 1024, double*, long long, double>((const void*)fill_kernel);
 }
 

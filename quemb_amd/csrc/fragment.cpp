@@ -66,8 +66,11 @@ int Fragment::hf_veff_from_dm(const double* P_host, double* J_host, double* K_ho
   if (!eri_s4_.p) { set_error("Fragment: ERIs not set"); return QEMB_ERR_ARG; }
   const int64_t n2 = (int64_t)n_ * n_;
   DBuf X0, P, J, K;
-  QTRY(X0.alloc(mo_transform_work(n_))); QTRY(P.alloc(n2)); QTRY(J.alloc(n2)); QTRY(K.alloc(n2));
-  QTRY(dev_unpack_tril_rows(npair(n_), n_, eri_s4_, X0));
+  QTRY(P.alloc(n2)); QTRY(J.alloc(n2)); QTRY(K.alloc(n2));
+  if (n_ > 1024) {      // (up to n = 1024 J and K come from the packed block in one pass: no half-unpacked tensor is needed)
+    QTRY(X0.alloc(mo_transform_work(n_)));
+    QTRY(dev_unpack_tril_rows(npair(n_), n_, eri_s4_, X0));
+  }
   QTRY(dev_h2d(P, P_host, sizeof(double) * n2));
   QTRY(build_jk(n_, X0, P, J, K, eri_s4_));
   QTRY(dev_d2h(J_host, J, sizeof(double) * n2));
@@ -81,8 +84,10 @@ int Fragment::scf_only(int o, const double* h, const double* dm0, const ScfOptio
   if (o <= 0 || o > n_) { set_error("Fragment: need 0 < nsocc <= n"); return QEMB_ERR_ARG; }
   const int64_t n2 = (int64_t)n_ * n_;
   DBuf X0;
-  QTRY(X0.alloc(mo_transform_work(n_)));
-  QTRY(dev_unpack_tril_rows(npair(n_), n_, eri_s4_, X0));     // half-unpacked [P(p,q)][r][s]
+  if (n_ > 1024) {      // (up to n = 1024 J and K come from the packed block in one pass: no half-unpacked tensor is needed)
+    QTRY(X0.alloc(mo_transform_work(n_)));
+    QTRY(dev_unpack_tril_rows(npair(n_), n_, eri_s4_, X0));     // half-unpacked [P(p,q)][r][s]
+  }
   QTRY(run_scf(o, h, dm0, opt, X0, sres));
   if (mo_coeff) QTRY(dev_d2h(mo_coeff, C_, sizeof(double) * n2));
   if (mo_energy) QTRY(dev_d2h(mo_energy, eps_, sizeof(double) * n_));
@@ -103,7 +108,7 @@ int Fragment::cphf_response(int o, const double* h, const double* dm0, const Scf
   const int64_t n2 = (int64_t)n * n, nov = (int64_t)o * v;
   DBuf X0, X1;
   QTRY(X1.alloc(mo_transform_work(n)));
-  QTRY(dev_unpack_tril_rows(npair(n), n, eri_s4_, X1));
+  QTRY(dev_unpack_tril_rows_ld(npair(n), n, mo_slab_ld(n), eri_s4_, X1));      // [P(p,q)][r][s], rows mo_slab_ld(n) apart (ccsd.cpp)
   ScfResult sres;
   QTRY(run_scf(o, h, dm0, opt, X1, &sres));
   if (!sres.converged) { set_error("cphf_response: fragment SCF did not converge"); return QEMB_ERR_NOCONV; }
@@ -165,7 +170,7 @@ int Fragment::prepare_ccsd(int o, const double* h, const double* dm0, const Frag
   cc_.reset();
   DBuf X0, X1;
   QTRY(X1.alloc(mo_transform_work(n_)));
-  QTRY(dev_unpack_tril_rows(npair(n_), n_, eri_s4_, X1));
+  QTRY(dev_unpack_tril_rows_ld(npair(n_), n_, mo_slab_ld(n_), eri_s4_, X1));
   ScfResult sres;
   QTRY(run_scf(o, h, dm0, opt.scf, X1, &sres));
   if (!sres.converged) { set_error("fragment SCF did not converge (also not with level shift 0.2)"); return QEMB_ERR_NOCONV; }
@@ -271,7 +276,7 @@ int Fragment::solve_begin(int o, const double* h, const double* dm0, const Fragm
   // ---- fragment RHF on the half-unpacked tensor [P(p,q)][r][s] (kept: it is the first operand of the MO transformation)
   DBuf X0, X1;
   QTRY(X1.alloc(mo_transform_work(n)));
-  QTRY(dev_unpack_tril_rows(npair(n), n, eri_s4_, X1));
+  QTRY(dev_unpack_tril_rows_ld(npair(n), n, mo_slab_ld(n), eri_s4_, X1));      // [P(p,q)][r][s], rows mo_slab_ld(n) apart (ccsd.cpp)
   ScfResult sres;
   QTRY(run_scf(o, h, dm0, opt.scf, X1, &sres, opt.warm_start != 0));
   res->scf_converged = sres.converged; res->scf_cycles = sres.cycles; res->e_scf = sres.e_tot;

@@ -102,70 +102,6 @@ __global__ void __launch_bounds__(256) jacobi_round_kernel(double* W, long long 
   }
 }
 
-// Single-workgroup variant for small problems (nvec, len <= JS_MAX): W and Vt live in LDS, every round is one pass of
-// the workgroup's 16 waves over the n/2 pairs (one pair per wave at a time), rounds and sweeps are separated by
-// __syncthreads instead of kernel launches.  A 41-orbital fragment Fock matrix (octane BE2) needs ~330 rounds per
-// eigh: one launch here instead of 330.
-constexpr int JS_MAX = 96;
-__global__ void __launch_bounds__(1024) jacobi_small_kernel(double* Wg, long long ldw, int len, double* Vtg, int nvec, int np,
-                                                            double tol, double floor2, int max_sweeps, int* sweeps_out) {
-  extern __shared__ __attribute__((aligned(16))) double lds[];
-  const int ldW = len + 1, ldV = nvec + 1;
-  double* W = lds;
-  double* V = lds + (size_t)nvec * ldW;
-  __shared__ int rotated;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
-  for (int t = tid; t < nvec * len; t += blockDim.x) W[(t / len) * ldW + (t % len)] = Wg[(long long)(t / len) * ldw + (t % len)];
-  for (int t = tid; t < nvec * nvec; t += blockDim.x) V[(t / nvec) * ldV + (t % nvec)] = Vtg[(long long)(t / nvec) * nvec + (t % nvec)];
-  __syncthreads();
-  int sweep = 0;
-  for (; sweep < max_sweeps; ++sweep) {
-    if (tid == 0) rotated = 0;
-    __syncthreads();
-    for (int r = 0; r < np - 1; ++r) {
-      for (int k = wave; k < np / 2; k += nwaves) {
-        int p, q;
-        rr_pair(np, r, k, p, q);
-        if (q >= nvec) continue;
-        double* wp = W + p * ldW; double* wq = W + q * ldW;
-        double a = 0.0, b = 0.0, g = 0.0;
-        for (int i = lane; i < len; i += 64) { const double x = wp[i], y = wq[i]; a += x * x; b += y * y; g += x * y; }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) { a += __shfl_xor(a, off, 64); b += __shfl_xor(b, off, 64); g += __shfl_xor(g, off, 64); }
-        double c = 1.0, sn = 0.0;
-        if (a > floor2 && b > floor2) {
-          const double rel = fabs(g) / sqrt(a * b);
-          if (rel > tol) {
-            const double zeta = (b - a) / (2.0 * g);
-            const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-            c = 1.0 / sqrt(1.0 + t * t); sn = c * t;
-          }
-        }
-        if (sn != 0.0) {
-          if (lane == 0) rotated = 1;
-          for (int i = lane; i < len; i += 64) { const double x = wp[i], y = wq[i]; wp[i] = c * x - sn * y; wq[i] = sn * x + c * y; }
-          double* vp = V + p * ldV; double* vq = V + q * ldV;
-          for (int i = lane; i < nvec; i += 64) { const double x = vp[i], y = vq[i]; vp[i] = c * x - sn * y; vq[i] = sn * x + c * y; }
-        }
-      }
-      __syncthreads();
-    }
-    const int any = rotated;
-    __syncthreads();
-    if (!any) { ++sweep; break; }
-  }
-  for (int t = tid; t < nvec * len; t += blockDim.x) Wg[(long long)(t / len) * ldw + (t % len)] = W[(t / len) * ldW + (t % len)];
-  for (int t = tid; t < nvec * nvec; t += blockDim.x) Vtg[(long long)(t / nvec) * nvec + (t % nvec)] = V[(t / nvec) * ldV + (t % nvec)];
-  if (tid == 0) sweeps_out[0] = (sweep <= max_sweeps && !rotated) ? sweep : -1;
-}
-
-// ------------------------------------------------------------------------------------------------
-// Block rounds (round 3): the same Hestenes rotations, grouped so that a workgroup keeps TWO blocks of B vectors (W rows and their Vt rows)
-// in LDS and applies every rotation between them -- B inner rounds of B disjoint pairs, one pair per wave, separated by workgroup barriers
-// -- before the vectors go back to memory.  A sweep is then nb - 1 launches (nb = ceil(nvec / B) blocks in a round-robin tournament) instead
-// of nvec - 1: 14 instead of 219 at nvec = 220, B = 16, and each launch does 16 (31 in the first round, which also rotates the pairs inside
-// each block) rounds of work out of LDS instead of one out of L2.  Same pairs per sweep, every pair exactly once; only the order differs.
-// (Used for 96 < nvec and 2 B (len + nvec) doubles fitting the LDS of a CU; the per-pair kernel above remains for longer vectors.)
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double lin_dpp_f64(double x) {
   const unsigned long long u = __double_as_longlong(x);
@@ -196,6 +132,62 @@ __device__ __forceinline__ void jacobi_cs(double a, double b, double g, double& 
   c = c2 * cinv;
   sn = (d >= 0.0 ? 0.5 : -0.5) * h * rinv * cinv;
 }
+// Single-workgroup variant for small problems (nvec, len <= JS_MAX): W and Vt live in LDS, every round is one pass of
+// the workgroup's 16 waves over the n/2 pairs (one pair per wave at a time), rounds and sweeps are separated by
+// __syncthreads instead of kernel launches.  A 41-orbital fragment Fock matrix (octane BE2) needs ~330 rounds per
+// eigh: one launch here instead of 330.
+constexpr int JS_MAX = 96;
+__global__ void __launch_bounds__(1024) jacobi_small_kernel(double* Wg, long long ldw, int len, double* Vtg, int nvec, int np,
+                                                            double tol, double floor2, int max_sweeps, int* sweeps_out) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int ldW = len + 1, ldV = nvec + 1;
+  double* W = lds;
+  double* V = lds + (size_t)nvec * ldW;
+  __shared__ int rotated;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+  for (int t = tid; t < nvec * len; t += blockDim.x) W[(t / len) * ldW + (t % len)] = Wg[(long long)(t / len) * ldw + (t % len)];
+  for (int t = tid; t < nvec * nvec; t += blockDim.x) V[(t / nvec) * ldV + (t % nvec)] = Vtg[(long long)(t / nvec) * nvec + (t % nvec)];
+  __syncthreads();
+  int sweep = 0;
+  for (; sweep < max_sweeps; ++sweep) {
+    if (tid == 0) rotated = 0;
+    __syncthreads();
+    for (int r = 0; r < np - 1; ++r) {
+      for (int k = wave; k < np / 2; k += nwaves) {
+        int p, q;
+        rr_pair(np, r, k, p, q);
+        if (q >= nvec) continue;
+        double* wp = W + p * ldW; double* wq = W + q * ldW;
+        double a = 0.0, b = 0.0, g = 0.0;
+        for (int i = lane; i < len; i += 64) { const double x = wp[i], y = wq[i]; a += x * x; b += y * y; g += x * y; }
+        a = wave_allsum(a); b = wave_allsum(b); g = wave_allsum(g);      // DPP: no LDS crossbar (round 3; 18 ds_bpermute per pair before)
+        double c = 1.0, sn = 0.0;
+        if (a > floor2 && b > floor2 && g * g > tol * tol * a * b) jacobi_cs(a, b, g, c, sn);      // half-angle form: two rsqrt (round 3)
+        if (sn != 0.0) {
+          if (lane == 0) rotated = 1;
+          for (int i = lane; i < len; i += 64) { const double x = wp[i], y = wq[i]; wp[i] = c * x - sn * y; wq[i] = sn * x + c * y; }
+          double* vp = V + p * ldV; double* vq = V + q * ldV;
+          for (int i = lane; i < nvec; i += 64) { const double x = vp[i], y = vq[i]; vp[i] = c * x - sn * y; vq[i] = sn * x + c * y; }
+        }
+      }
+      __syncthreads();
+    }
+    const int any = rotated;
+    __syncthreads();
+    if (!any) { ++sweep; break; }
+  }
+  for (int t = tid; t < nvec * len; t += blockDim.x) Wg[(long long)(t / len) * ldw + (t % len)] = W[(t / len) * ldW + (t % len)];
+  for (int t = tid; t < nvec * nvec; t += blockDim.x) Vtg[(long long)(t / nvec) * nvec + (t % nvec)] = V[(t / nvec) * ldV + (t % nvec)];
+  if (tid == 0) sweeps_out[0] = (sweep <= max_sweeps && !rotated) ? sweep : -1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Block rounds (round 3): the same Hestenes rotations, grouped so that a workgroup keeps TWO blocks of B vectors (W rows and their Vt rows)
+// in LDS and applies every rotation between them -- B inner rounds of B disjoint pairs, one pair per wave, separated by workgroup barriers
+// -- before the vectors go back to memory.  A sweep is then nb - 1 launches (nb = ceil(nvec / B) blocks in a round-robin tournament) instead
+// of nvec - 1: 14 instead of 219 at nvec = 220, B = 16, and each launch does 16 (31 in the first round, which also rotates the pairs inside
+// each block) rounds of work out of LDS instead of one out of L2.  Same pairs per sweep, every pair exactly once; only the order differs.
+// (Used for 96 < nvec and 2 B (len + nvec) doubles fitting the LDS of a CU; the per-pair kernel above remains for longer vectors.)
 // B = vectors per block = waves per workgroup; NPL = ceil((len + nvec) / 64) register slots per lane for one [W row | Vt row]
 template <int B, int NPL>
 __global__ void __launch_bounds__(B * 64) jacobi_block_round_kernel(double* __restrict__ W, long long ldw, int len, double* __restrict__ Vt, int nvec, int nb,

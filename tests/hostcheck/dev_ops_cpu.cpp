@@ -337,17 +337,19 @@ int dev_unpack_s8_to_s4(int64_t n, const double* s8, double* s4) {
   for (int64_t r = 0; r < np; ++r) for (int64_t c = 0; c < np; ++c) s4[r * np + c] = s8[pidx(r, c)];
   return 0;
 }
-int dev_unpack_tril_rows(int64_t rows, int64_t n, const double* p, double* f) {
+int dev_unpack_tril_rows_ld(int64_t rows, int64_t n, int64_t ld, const double* p, double* f) {
   const int64_t np = n * (n + 1) / 2;
-  for (int64_t r = 0; r < rows; ++r) for (int64_t k = 0; k < n; ++k) for (int64_t l = 0; l < n; ++l) f[(r * n + k) * n + l] = p[r * np + pidx(k, l)];
+  for (int64_t r = 0; r < rows; ++r) for (int64_t k = 0; k < n; ++k) for (int64_t l = 0; l < n; ++l) f[(r * n + k) * ld + l] = p[r * np + pidx(k, l)];
   return 0;
 }
-int dev_unpack_tril_pair_rows(int64_t nr, int64_t n, const double* in, double* f) {
+int dev_unpack_tril_rows(int64_t rows, int64_t n, const double* p, double* f) { return dev_unpack_tril_rows_ld(rows, n, n, p, f); }
+int dev_unpack_tril_pair_rows_ld(int64_t nr, int64_t n, int64_t ld, const double* in, double* f) {
   const int64_t np = n * (n + 1) / 2;
   for (int64_t x = 0; x < nr; ++x) for (int64_t y = 0; y <= x; ++y) for (int64_t k = 0; k < n; ++k) for (int64_t l = 0; l < n; ++l)
-    f[(pidx(x, y) * n + k) * n + l] = in[(x * nr + y) * np + pidx(k, l)];
+    f[(pidx(x, y) * n + k) * ld + l] = in[(x * nr + y) * np + pidx(k, l)];
   return 0;
 }
+int dev_unpack_tril_pair_rows(int64_t nr, int64_t n, const double* in, double* f) { return dev_unpack_tril_pair_rows_ld(nr, n, n, in, f); }
 int dev_pack_tril_rows(int64_t rows, int64_t n, const double* f, double* p) {
   const int64_t np = n * (n + 1) / 2;
   for (int64_t r = 0; r < rows; ++r) for (int64_t k = 0; k < n; ++k) for (int64_t l = 0; l <= k; ++l) p[r * np + pidx(k, l)] = f[(r * n + k) * n + l];

@@ -14,12 +14,14 @@ from quemb_amd import _lib
 from quemb_amd._lib import DeviceBuffer, check
 
 lib = _lib.init(0)
-n, o = 220, 20
+import os
+n, o = int(os.environ.get("QEMB_HBM_N", "220")), 20      # QEMB_HBM_N: another fragment size (alignment experiments)
 v = n - o
 npn, npo, nmo, npv, nmv, nov = n * (n + 1) // 2, o * (o + 1) // 2, o * (o - 1) // 2, v * (v + 1) // 2, v * (v - 1) // 2, o * v
 ldp, ldm = npv + (npv & 1), nmv + (nmv & 1)
 rng = np.random.default_rng(0)
 want = set(sys.argv[1:])
+print(json.dumps(dict(n=n, n_occ=o)), flush=True)
 
 
 def timed(f, reps=10):
