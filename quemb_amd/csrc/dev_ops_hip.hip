@@ -875,17 +875,23 @@ __device__ __forceinline__ void ccsd_ph_layouts_kernel_body(const uint3 BID, con
   const long long tc = BID.x / tiles, tb = BID.x % tiles;
   const long long k = BID.z, j = BID.y;
   const double* __restrict__ X = t2 + (k * o + j) * v * v;
+  // The b-ranges of the tiles are shifted so that the 32-double runs written to the five [k,c,j,b] outputs start on 128-byte lines: their
+  // rows start at ((k v + c) o + j) v doubles, which (when o v is a multiple of 16) is the same offset a = ((k v o + j) v) mod 16 into a line
+  // for every c of the tile.  Runs that straddle lines are completed by another workgroup later and cost a read-modify-write at the memory
+  // side: v = 200 ran at 3.8 TB/s against 4.9 for v = 192 / 208 before the shift (tools/align_experiment.py).
+  const long long a = ((o * v) % 16 == 0) ? ((k * v * o + j) * v) % 16 : 0;
+  const long long b0 = tb * 32 - a;
   // mirrored tile: rows b-range, columns c-range -> xt[b_local][c_local]
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const long long b = tb * 32 + ty + 8 * r, c = tc * 32 + tx;
-    xt[ty + 8 * r][tx] = (b < v && c < v) ? X[b * v + c] : 0.0;
+    const long long b = b0 + ty + 8 * r, c = tc * 32 + tx;
+    xt[ty + 8 * r][tx] = (b >= 0 && b < v && c < v) ? X[b * v + c] : 0.0;
   }
   __syncthreads();
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const long long c = tc * 32 + ty + 8 * r, b = tb * 32 + tx;
-    if (c < v && b < v) {
+    const long long c = tc * 32 + ty + 8 * r, b = b0 + tx;
+    if (c < v && b >= 0 && b < v) {
       const double x = X[c * v + b];                 // t2[k,j,c,b]
       const double xp = xt[tx][ty + 8 * r];          // t2[k,j,b,c]
       const double tt = 2.0 * t1[j * v + c] * t1[k * v + b];
@@ -907,8 +913,8 @@ int dev_ccsd_ph_layouts(int64_t o, int64_t v, const double* t2, const double* t1
   REQUIRE_INIT();
   if (o <= 0 || v <= 0) return QEMB_OK;
   if (o > 65535) { set_error("dev_ccsd_ph_layouts: too many occupied orbitals"); return QEMB_ERR_ARG; }
-  const long long tiles = (v + 31) / 32;
-  hipLaunchKernelGGL(ccsd_ph_layouts_kernel, dim3((unsigned)(tiles * tiles), (unsigned)o, (unsigned)o), dim3(256), 0, g_stream, (long long)o, (long long)v, t2, t1,
+  const long long tiles_c = (v + 31) / 32, tiles = (v + 15 + 31) / 32;      // b-tiles: one more may be needed for the line-aligning shift (<= 15)
+  hipLaunchKernelGGL(ccsd_ph_layouts_kernel, dim3((unsigned)(tiles_c * tiles), (unsigned)o, (unsigned)o), dim3(256), 0, g_stream, (long long)o, (long long)v, t2, t1,
                      T, Tp, S, Ut, Tpt, Th, (int)tiles);
   HIP_TRY(hipGetLastError());
   return QEMB_OK;

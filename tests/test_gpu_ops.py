@@ -475,9 +475,10 @@ def test_pm_pair_packing_roundtrip_and_lincomb(qlib):
     assert np.abs(dz.numpy() - (2.0 * x - 0.5 * y + 3.0 * z)).max() < 1e-14
 
 
-@pytest.mark.parametrize("o,v", [(1, 1), (3, 5), (4, 33), (7, 70)])
+@pytest.mark.parametrize("o,v", [(1, 1), (3, 5), (4, 33), (7, 70), (4, 36), (8, 50), (2, 200)])
 def test_ccsd_single_pass_kernels(qlib, o, v):
-    """The fused element-wise kernels of the amplitude update against NumPy, at sizes that are not multiples of the 32 x 32 tiles."""
+    """The fused element-wise kernels of the amplitude update against NumPy, at sizes that are not multiples of the 32 x 32 tiles; the last
+    three have o v a multiple of 16, where ph_layouts shifts its tile columns onto 128-byte lines (a different shift per (k, j))."""
     rng = np.random.default_rng(100 * o + v)
     t2 = rng.standard_normal((o, o, v, v)); t1 = rng.standard_normal((o, v))
     d2, d1 = DeviceBuffer.from_numpy(t2), DeviceBuffer.from_numpy(t1)
