@@ -236,8 +236,34 @@ int dev_d2h_async(void* dst, const void* src, size_t bytes) {
   HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, g_stream));
   return QEMB_OK;
 }
-int dev_pinned_alloc(void** p, size_t bytes) { REQUIRE_INIT(); HIP_TRY(hipHostMalloc(p, bytes ? bytes : 16, hipHostMallocDefault)); return QEMB_OK; }
-int dev_pinned_free(void* p) { if (p) (void)hipHostFree(p); return QEMB_OK; }
+// Pinned host blocks are small (a few scalars on their way back from the device) and short lived (one per DIIS object and solver):
+// hipHostMalloc / hipHostFree cost tens of microseconds each and the free waits for the device, so released blocks are parked by size
+// class and handed out again (process wide; never returned to the driver).
+static std::mutex g_pinned_mutex;
+static std::map<size_t, std::vector<void*>> g_pinned_free;
+static std::map<void*, size_t> g_pinned_live;
+int dev_pinned_alloc(void** p, size_t bytes) {
+  REQUIRE_INIT();
+  const size_t cls = (std::max<size_t>(bytes, 16) + 255) / 256 * 256;
+  {
+    std::lock_guard<std::mutex> lock(g_pinned_mutex);
+    auto it = g_pinned_free.find(cls);
+    if (it != g_pinned_free.end() && !it->second.empty()) { *p = it->second.back(); it->second.pop_back(); g_pinned_live[*p] = cls; return QEMB_OK; }
+  }
+  HIP_TRY(hipHostMalloc(p, cls, hipHostMallocDefault));
+  std::lock_guard<std::mutex> lock(g_pinned_mutex);
+  g_pinned_live[*p] = cls;
+  return QEMB_OK;
+}
+int dev_pinned_free(void* p) {
+  if (!p) return QEMB_OK;
+  std::lock_guard<std::mutex> lock(g_pinned_mutex);
+  auto it = g_pinned_live.find(p);
+  if (it == g_pinned_live.end()) return QEMB_OK;
+  g_pinned_free[it->second].push_back(p);
+  g_pinned_live.erase(it);
+  return QEMB_OK;
+}
 int dev_d2d(void* dst, const void* src, size_t bytes) {
   REQUIRE_INIT();
   HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, g_stream));
