@@ -110,6 +110,29 @@ int qemb_op_lincomb2(int64_t n, double a, const double* x, double b, const doubl
 int qemb_op_small_k_update(int64_t batch, int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t sA, const double* B, int64_t sB, double* C, int64_t sC);
 int qemb_op_ccsd_ph_layouts(int64_t o, int64_t v, const double* t2, const double* t1, double* T, double* Tp, double* S, double* Ut, double* Tpt, double* Th);
 int qemb_op_ccsd_y_traces(int64_t o, int64_t v, const double* ZC, const double* ZB, double* Y);
+/* Fused passes of the CCSD amplitude update (csrc/ccsd.cpp update_amps), device pointers:
+ *   copy4_two: qemb_op_copy4 with base (NULL: out) and a second output of the same pass, addressed like out: out2 = c2a in2 + c2b (value written to out)
+ *   scatter_pm_rows_add / ccsd_y_traces_add: the plain ops with an addend laid out like the result
+ *   pack_w_pm_sum: pack_w_pm of W[k,l,i,j] = Wp[k,l,i,j] + X[i,j,k,l] + O1[l,j,k,i] + O1[k,i,l,j], W never stored
+ *   ccsd_t1_small: t1n[i,a] = sum_c t1[i,c] Lvv[a,c] - sum_k Loo[k,i] t1[k,a] + sum_k (sum_c t1[i,c] Fov[k,c]) t1[k,a]
+ *   gemv_rows2: y = alpha (T1 x1 + T2 x2) + beta y
+ *   ccsd_finish_t2_rings: F[ijab] = U[ijab] + RS[iajb] - M[iajb] / 2 - M[ibja];  t2n[ijab] = t2n[jiba] = (t2n[ijab] + OV[ijab] + F[ijab] + F[jiba]) / D (i >= j);
+ *                         t1n[ia] /= eo[i] - ev[a] (t1n may be NULL) */
+int qemb_op_copy4_two(const int64_t dim[4], const double* in, const int64_t si[4], double* out, const int64_t so[4], double alpha, double beta, const double* base,
+                      double* out2, const double* in2, double c2a, double c2b);
+int qemb_op_scatter_pm_rows_add(int64_t o, int64_t ncols, const double* Xp, const double* Xm, double* out, const double* add);
+int qemb_op_ccsd_y_traces_add(int64_t o, int64_t v, const double* ZC, const double* ZB, double* Y, const double* add);
+int qemb_op_pack_w_pm_sum(int64_t o, const double* Wp, const double* X, const double* O1, double* Ap, int64_t lda_p, double* Am, int64_t lda_m);
+int qemb_op_ccsd_t1_small(int64_t o, int64_t v, const double* t1, const double* Lvv, const double* Loo, const double* Fov, double* t1n);
+int qemb_op_gemv_rows2(int64_t rows, int64_t cols, const double* T1, int64_t ld1, const double* x1, const double* T2, int64_t ld2, const double* x2, double* y, double alpha, double beta);
+int qemb_op_ccsd_finish_t2_rings(int64_t o, int64_t v, double* t2n, const double* U, const double* OV, const double* RS, const double* M, const double* eo, const double* ev, double* t1n);
+/* The two single-launch ends of a CCSD iteration (csrc/ccsd.cpp post_issue / post_extrapolate), device pointers except where noted:
+ *   diis_push: e = trial - prev, xcopy = trial (xcopy may be NULL), row[j] = <e, ys[j]> for j < m <= 8 with ys[self] == e; `ys` is a HOST array of
+ *              m device pointers; the row goes to row_dev (device, m doubles) and row_host (HOST, m doubles: the wrapper waits for it)
+ *   ccsd_extrapolate_energy: amp = sum_k coef[k] xs[k] over [t1 | t2] (coef: HOST, xs: HOST array of device pointers, nterms <= 8), tau = t2 + t1 (x) t1,
+ *              *e_host = <L, tau> (HOST double; the wrapper waits) */
+int qemb_op_diis_push(int64_t n, const double* trial, const double* prev, double* e, double* xcopy, int m, const double* const* ys, int self, double* row_dev, double* row_host);
+int qemb_op_ccsd_extrapolate_energy(int64_t o, int64_t v, int nterms, const double* coef, const double* const* xs, double* amp, const double* L, double* tau, double* e_host);
 int qemb_op_gather_rows(int64_t nrows, int64_t len, const int64_t* idx_dev, const double* src, int64_t ld, double* dst);
 int qemb_op_scale_rows(int64_t nrows, int64_t len, double* x, const double* s);
 /* pair-packed MO transformation helpers (half the flops of the four-index ao2mo.kernel call of PySCF's cc.ao2mo(), which

@@ -97,6 +97,15 @@ def _declare(lib):
     f("qemb_op_small_k_update", I, L, L, L, L, D, P, L, P, L, P, L)
     f("qemb_op_ccsd_ph_layouts", I, L, L, P, P, P, P, P, P, P, P)
     f("qemb_op_ccsd_y_traces", I, L, L, P, P, P)
+    f("qemb_op_copy4_two", I, C.POINTER(L), P, C.POINTER(L), P, C.POINTER(L), D, D, P, P, P, D, D)
+    f("qemb_op_scatter_pm_rows_add", I, L, L, P, P, P, P)
+    f("qemb_op_ccsd_y_traces_add", I, L, L, P, P, P, P)
+    f("qemb_op_pack_w_pm_sum", I, L, P, P, P, P, L, P, L)
+    f("qemb_op_ccsd_t1_small", I, L, L, P, P, P, P, P)
+    f("qemb_op_gemv_rows2", I, L, L, P, L, P, P, L, P, P, D, D)
+    f("qemb_op_ccsd_finish_t2_rings", I, L, L, P, P, P, P, P, P, P, P)
+    f("qemb_op_diis_push", I, L, P, P, P, P, I, P, I, P, P)
+    f("qemb_op_ccsd_extrapolate_energy", I, L, L, I, P, P, P, P, P, P)
     f("qemb_op_gather_rows", I, L, L, P, P, L, P)
     f("qemb_op_scale_rows", I, L, L, P, P)
     f("qemb_ctx_count", I, I)

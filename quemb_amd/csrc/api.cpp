@@ -134,6 +134,46 @@ int qemb_op_small_k_update(int64_t batch, int64_t M, int64_t N, int64_t K, doubl
 int qemb_op_ccsd_ph_layouts(int64_t o, int64_t v, const double* t2, const double* t1, double* T, double* Tp, double* S, double* Ut, double* Tpt, double* Th) {
   return dev_ccsd_ph_layouts(o, v, t2, t1, T, Tp, S, Ut, Tpt, Th);
 }
+int qemb_op_copy4_two(const int64_t dim[4], const double* in, const int64_t si[4], double* out, const int64_t so[4], double alpha, double beta, const double* base,
+                      double* out2, const double* in2, double c2a, double c2b) {
+  Copy4Desc c{};
+  for (int k = 0; k < 4; ++k) { c.dim[k] = dim[k]; c.si[k] = si[k]; c.so[k] = so[k]; }
+  c.in = in; c.out = out; c.alpha = alpha; c.beta = beta; c.base = base;
+  c.out2 = out2; c.in2 = in2; c.c2a = c2a; c.c2b = c2b;
+  return dev_copy4(c);
+}
+int qemb_op_scatter_pm_rows_add(int64_t o, int64_t ncols, const double* Xp, const double* Xm, double* out, const double* add) { return dev_scatter_pm_rows(o, ncols, Xp, Xm, out, add); }
+int qemb_op_ccsd_y_traces_add(int64_t o, int64_t v, const double* ZC, const double* ZB, double* Y, const double* add) { return dev_ccsd_y_traces(o, v, ZC, ZB, Y, add); }
+int qemb_op_pack_w_pm_sum(int64_t o, const double* Wp, const double* X, const double* O1, double* Ap, int64_t lda_p, double* Am, int64_t lda_m) {
+  return dev_pack_w_pm_sum(o, Wp, X, O1, Ap, lda_p, Am, lda_m);
+}
+int qemb_op_ccsd_t1_small(int64_t o, int64_t v, const double* t1, const double* Lvv, const double* Loo, const double* Fov, double* t1n) { return dev_ccsd_t1_small(o, v, t1, Lvv, Loo, Fov, t1n); }
+int qemb_op_gemv_rows2(int64_t rows, int64_t cols, const double* T1, int64_t ld1, const double* x1, const double* T2, int64_t ld2, const double* x2, double* y, double alpha, double beta) {
+  return dev_gemv_rows2(rows, cols, T1, ld1, x1, T2, ld2, x2, y, alpha, beta);
+}
+int qemb_op_ccsd_finish_t2_rings(int64_t o, int64_t v, double* t2n, const double* U, const double* OV, const double* RS, const double* M, const double* eo, const double* ev, double* t1n) {
+  return dev_ccsd_finish_t2_rings(o, v, t2n, U, OV, RS, M, eo, ev, t1n);
+}
+int qemb_op_diis_push(int64_t n, const double* trial, const double* prev, double* e, double* xcopy, int m, const double* const* ys, int self, double* row_dev, double* row_host) {
+  void* pin = nullptr;
+  QTRY(dev_pinned_alloc(&pin, sizeof(double) * 8));
+  int rc = dev_diis_push(n, trial, prev, e, xcopy, m, ys, self, row_dev, (double*)pin);
+  if (!rc) rc = dev_sync();
+  if (!rc) for (int j = 0; j < m; ++j) row_host[j] = ((double*)pin)[j];
+  dev_pinned_free(pin);
+  return rc;
+}
+int qemb_op_ccsd_extrapolate_energy(int64_t o, int64_t v, int nterms, const double* coef, const double* const* xs, double* amp, const double* L, double* tau, double* e_host) {
+  void* pin = nullptr;
+  DBuf e_dev;
+  QTRY(e_dev.alloc(1));
+  QTRY(dev_pinned_alloc(&pin, sizeof(double) * 8));
+  int rc = dev_ccsd_extrapolate_energy(o, v, nterms, coef, xs, amp, L, tau, e_dev, (double*)pin);
+  if (!rc) rc = dev_sync();
+  if (!rc) *e_host = *(double*)pin;
+  dev_pinned_free(pin);
+  return rc;
+}
 int qemb_op_ccsd_y_traces(int64_t o, int64_t v, const double* ZC, const double* ZB, double* Y) { return dev_ccsd_y_traces(o, v, ZC, ZB, Y); }
 int qemb_op_gather_rows(int64_t nrows, int64_t len, const int64_t* idx_dev, const double* src, int64_t ld, double* dst) { return dev_gather_rows(nrows, len, idx_dev, src, ld, dst); }
 int qemb_op_scale_rows(int64_t nrows, int64_t len, double* x, const double* s) { return dev_scale_rows(nrows, len, x, s); }

@@ -107,6 +107,7 @@ int mo_transform(int n, int o, int nf, const double* eri_s4, double* X0, double*
 }
 
 // ------------------------------------------------------------------------------------------------------------
+static void pick_xw_split(int64_t rows, int64_t oo, int64_t K, int& cfg, int& ks);
 int CcsdSolver::setup(MoIntegrals&& ints, const double* mo_energy_dev) {
   I_ = std::move(ints);
   o_ = I_.o; v_ = I_.v; nf_ = I_.nf;
@@ -165,9 +166,14 @@ int CcsdSolver::setup(MoIntegrals&& ints, const double* mo_energy_dev) {
   QTRY(O1_.alloc(oo * oo)); QTRY(X_.alloc(oo * nov)); QTRY(scal_.alloc(8));
   {
     const int64_t npo = o * (o + 1) / 2, nmo = std::max<int64_t>(o * (o - 1) / 2, 1);
-    QTRY(LTp_.alloc(npo * I_.ldp)); QTRY(LRp_.alloc(npo * I_.ldp)); QTRY(LTm_.alloc(nmo * I_.ldm)); QTRY(LRm_.alloc(nmo * I_.ldm));
-    QTRY(Xp_.alloc(npo * nov)); QTRY(Xm_.alloc(nmo * nov));
-    QTRY(Xwp_.alloc(npo * oo)); QTRY(Xwm_.alloc(nmo * oo)); QTRY(Xw_.alloc(oo * oo));
+    // (results of the split-K products keep one slab per K slice: the consumers add them up)
+    const int64_t npv = v * (v + 1) / 2, nmv = v * (v - 1) / 2;
+    auto slabs_pair = [&](int64_t rows, int64_t cols, int64_t K) { int cfg, ks; pick_pair_gemm(rows, cols, cfg, ks); return (int64_t)gemm_slab_count(K, ks); };
+    auto slabs_xw = [&](int64_t rows, int64_t K) { int cfg, ks; pick_xw_split(rows, oo, K, cfg, ks); return (int64_t)gemm_slab_count(K, ks); };
+    QTRY(LTp_.alloc(npo * I_.ldp)); QTRY(LRp_.alloc(std::max(npo * I_.ldp, slabs_pair(npo, npv, I_.ldp) * npo * npv)));
+    QTRY(LTm_.alloc(nmo * I_.ldm)); QTRY(LRm_.alloc(std::max(nmo * I_.ldm, slabs_pair(nmo, std::max<int64_t>(nmv, 1), I_.ldm) * nmo * std::max<int64_t>(nmv, 1))));
+    QTRY(Xp_.alloc(slabs_pair(npo, nov, I_.ldp) * npo * nov)); QTRY(Xm_.alloc(slabs_pair(nmo, nov, I_.ldm) * nmo * nov));
+    QTRY(Xwp_.alloc(slabs_xw(npo, I_.ldp) * npo * oo)); QTRY(Xwm_.alloc(slabs_xw(nmo, I_.ldm) * nmo * oo)); QTRY(Xw_.alloc(oo * oo));
     lwp_ = npo + (npo & 1); lwm_ = std::max<int64_t>(2, nmo + (nmo & 1));
     QTRY(WAp_.alloc(npo * lwp_)); QTRY(WAm_.alloc(nmo * lwm_)); QTRY(HRp_.alloc(npo * I_.ldp)); QTRY(HRm_.alloc(nmo * I_.ldm));
     QTRY(ZB_.alloc(N2)); QTRY(ZC_.alloc(N2));
@@ -240,6 +246,28 @@ void pick_pair_gemm(int64_t rows, int64_t cols, int& cfg, int& ks) {
   if (ks == 0) ks = (int)std::max<int64_t>(1, std::min<int64_t>(8, (1024 + tiles - 1) / tiles));
 }
 
+// C = A B^T (both operands K-contiguous) whose consumer adds the split-K slabs itself: with ks > 1 the slices' partial products stay in slabs
+// [S][M][N] at C (no reduction pass), else C is the plain product with leading dimension ldc
+struct SlabGemm { int S = 1; int64_t stride = 0, ld = 0; };
+static int gemm_slabs(int64_t M, int64_t N, int64_t K, const double* A, int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc, int cfg, int ks, SlabGemm& out) {
+  GemmDesc g{};
+  g.M = M; g.N = N; g.K = K; g.alpha = 1.0; g.beta = 0.0;
+  g.A = A; g.lda = lda; g.a_kcontig = 1; g.B = B; g.ldb = ldb; g.b_kcontig = 1;
+  g.C = C; g.ldc = ldc; g.batch = 1; g.cfg = cfg; g.ksplit = ks;
+  out.S = gemm_slab_count(K, ks);
+  if (out.S > 1) { g.keep_slabs = 1; out.stride = M * N; out.ld = N; }
+  else { out.stride = 0; out.ld = ldc; }
+  return dev_gemm(g);
+}
+// tile configuration and K split of the Xw products (output only npair(o) x o^2, K = packed virtual pairs): 64 x 64 tiles and enough K slices for
+// ~2 workgroups per CU
+static void pick_xw_split(int64_t rows, int64_t oo, int64_t K, int& cfg, int& ks) {
+  cfg = -1; ks = 0;
+  if (K < 2048) return;
+  const int64_t tiles = ((rows + 63) / 64) * ((oo + 63) / 64);
+  cfg = 1;
+  ks = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(64, K / 256), (512 + tiles - 1) / tiles));
+}
 // pp-ladder through the (+/-) pair-packed operands (see the comment in update_amps)
 int CcsdSolver::apply_ladder(const double* x, double* out, bool rows_packed, bool hh) {
   const int64_t o = o_, v = v_;
@@ -249,13 +277,15 @@ int CcsdSolver::apply_ladder(const double* x, double* out, bool rows_packed, boo
     if (!rows_packed) QTRY(dev_ladder_pack_tau(o, v, x, LTp_, ldp, LTm_, ldm));
     int cfg, ks;
     TimerScope lap_LADDER(TIMER_LADDER);
+    // (split over K, the slices' partial products stay in slabs that the scatter below adds up: no reduction pass over the packed results)
+    SlabGemm sp, sm;
     pick_pair_gemm(npo, npv, cfg, ks);
     if (cfg == 13 || cfg == 15) cfg += 10;      // same tiles under the ladder's own kernel symbol (profiles)
-    QTRY(gemm(npo, npv, ldp, 1.0, LTp_, ldp, true, I_.Vp, ldp, true, 0.0, LRp_, ldp, 1, 0, 0, 0, cfg, ks));
+    QTRY(gemm_slabs(npo, npv, ldp, LTp_, ldp, I_.Vp, ldp, LRp_, ldp, cfg, ks, sp));
     if (nmo > 0 && nmv > 0) {
       pick_pair_gemm(nmo, nmv, cfg, ks);
       if (cfg == 13 || cfg == 15) cfg += 10;
-      QTRY(gemm(nmo, nmv, ldm, 1.0, LTm_, ldm, true, I_.Vm, ldm, true, 0.0, LRm_, ldm, 1, 0, 0, 0, cfg, ks));
+      QTRY(gemm_slabs(nmo, nmv, ldm, LTm_, ldm, I_.Vm, ldm, LRm_, ldm, cfg, ks, sm));
     }
     QTRY(lap_LADDER.close());
     if (hh) {
@@ -267,16 +297,16 @@ int CcsdSolver::apply_ladder(const double* x, double* out, bool rows_packed, boo
       auto tile_for = [&](int64_t rows) { int best = -1; int64_t pad = -1; for (const auto& c : cand) { const int64_t q = (rows + c.rows - 1) / c.rows * c.rows; if (pad < 0 || q < pad) { pad = q; best = c.cfg; } } return best; };
       QTRY(gemm(npo, npv, npo, 1.0, WAp_, lwp_, true, LTp_, ldp, false, 0.0, HRp_, ldp, 1, 0, 0, 0, npv >= 2048 ? tile_for(npo) : -1));
       if (nmo > 0 && nmv > 0) QTRY(gemm(nmo, nmv, nmo, 1.0, WAm_, lwm_, true, LTm_, ldm, false, 0.0, HRm_, ldm, 1, 0, 0, 0, nmv >= 2048 ? tile_for(nmo) : -1));
-      QTRY(dev_ladder_scatter_pm2(o, v, LRp_, ldp, LRm_, ldm, HRp_, (nmo > 0 && nmv > 0) ? HRm_.p : nullptr, 1, out));
+      QTRY(dev_ladder_scatter_pm2(o, v, LRp_, sp.ld, LRm_, sm.ld, HRp_, (nmo > 0 && nmv > 0) ? HRm_.p : nullptr, 1, out, sp.S, sp.stride, sm.S, sm.stride, ldp, ldm));
     } else {
-      QTRY(dev_ladder_scatter_pm(o, v, LRp_, ldp, LRm_, ldm, out));
+      QTRY(dev_ladder_scatter_pm2(o, v, LRp_, sp.ld, LRm_, sm.ld, nullptr, nullptr, 0, out, sp.S, sp.stride, sm.S, sm.stride));
     }
   }
   return 0;
 }
 
 int CcsdSolver::update_amps(double* t1n, double* t2n) {
-  const int64_t o = o_, v = v_, nov = o * v, oo = o * o, vv = v * v, N2 = oo * vv;
+  const int64_t o = o_, v = v_, nov = o * v, oo = o * o, vv = v * v;
   const double* t1 = this->t1();
   const double* t2 = this->t2();
   // ---- amplitude layouts.  tau_ already holds tau(t1, t2): every change of the amplitudes (init_amps, set_amps, iterate) ends
@@ -290,29 +320,24 @@ int CcsdSolver::update_amps(double* t1n, double* t2n) {
      //   Xp[P(ij),(kl)] = sum_{c>=d} LTp[P(ij),P(cd)] G+[(kl),P(cd)],  Xm[Q(ij),(kl)] = sum_{c>d} LTm G-   (LTp carries 1/2 on c = d, G+ is doubled there)
     const int64_t npo = o * (o + 1) / 2, nmo = o * (o - 1) / 2, nmv = v * (v - 1) / 2;
     QTRY(dev_ladder_pack_tau(o, v, tau_, LTp_, I_.ldp, LTm_, I_.ldm));     // the packed tau rows: also read by the ladder and by the tau-side dressing below
-    // 64 x 64 tiles and enough K slices for ~2 workgroups per CU (the output is only npair(o) x o^2)
-    auto split = [&](int64_t rows, int64_t K, int& cfg, int& ks) {
-      cfg = -1; ks = 0;
-      if (K < 2048) return;
-      const int64_t tiles = ((rows + 63) / 64) * ((oo + 63) / 64);
-      cfg = 1;
-      ks = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(64, K / 256), (512 + tiles - 1) / tiles));
-    };
+    auto split = [&](int64_t rows, int64_t K, int& cfg, int& ks) { pick_xw_split(rows, oo, K, cfg, ks); };
     int cfg, ks;
+    SlabGemm sp, sm;
     split(npo, I_.ldp, cfg, ks);
-    QTRY(gemm(npo, oo, I_.ldp, 1.0, LTp_, I_.ldp, true, Gp_, I_.ldp, true, 0.0, Xwp_, oo, 1, 0, 0, 0, cfg, ks));
+    QTRY(gemm_slabs(npo, oo, I_.ldp, LTp_, I_.ldp, Gp_, I_.ldp, Xwp_, oo, cfg, ks, sp));
     if (nmo > 0) {
-      if (nmv > 0) { split(nmo, I_.ldm, cfg, ks); QTRY(gemm(nmo, oo, I_.ldm, 1.0, LTm_, I_.ldm, true, Gm_, I_.ldm, true, 0.0, Xwm_, oo, 1, 0, 0, 0, cfg, ks)); }
+      if (nmv > 0) { split(nmo, I_.ldm, cfg, ks); QTRY(gemm_slabs(nmo, oo, I_.ldm, LTm_, I_.ldm, Gm_, I_.ldm, Xwm_, oo, cfg, ks, sm)); }
       else QTRY(dev_fill(Xwm_, nmo * oo, 0.0));
     }
-    QTRY(dev_scatter_pm_rows(o, oo, Xwp_, Xwm_, Xw_));                               // Xw[i,j,k,l]
+    QTRY(dev_scatter_pm_rows(o, oo, Xwp_, Xwm_, Xw_, nullptr, sp.S, sp.stride, sm.S, sm.stride));      // Xw[i,j,k,l] (the K slices' slabs added on the way)
   }
+  // (Foo' and Z only ever enter as Loo' = Foo' + Z, Fvv' and Y as Lvv' = Fvv' + Y: each pair is accumulated in place)
   // Foo'[k,i] = sum_{lcd} (2 ovov[kcld] - ovov[kdlc]) tau[ilcd] = sum_l (2 Xw[i,l,k,l] - Xw[l,i,k,l]): a partial trace of Xw instead of
   // a pass over two o^2 v^2 tensors
-  QTRY(dev_foo_from_x(o, Xw_, Foo_));
+  QTRY(dev_foo_from_x(o, Xw_, Loo_));
   QTRY(gemm(v, v, oo * v, -1.0, tau_, v, false, Loovv_, v, false, 0.0, Fvv_, v, 1, 0, 0, 0, (v <= 256) ? 1 : -1));   // Fvv'[a,c]  (64 x 64 tiles: split-K supplies the blocks)
   QTRY(dev_gemv_rows(nov, nov, Lovov_, nov, t1, Fov_, 1.0, 0.0));                  // Fov[k,c]
-  QTRY(dev_contract_mid(1, nov, oo, Lovoo_, t1, Z_, oo, 1.0, 0.0));                // Z[k,i]
+  QTRY(dev_contract_mid(1, nov, oo, Lovoo_, t1, Loo_, oo, 1.0, 1.0));              // Loo' = Foo' + Z[k,i]
   // The two t1-contractions of ovvv are formed ONCE per iteration (each is one pass over the 1.28 GB block) and serve the
   // ring intermediates, the X1 term and -- through their k = i traces -- the Y intermediate:
   // (n_occ <= 32 columns / rows: 128 x 32 and 32 x 128 tiles instead of padding n_occ to a 64-wide tile, which made these
@@ -325,29 +350,23 @@ int CcsdSolver::update_amps(double* t1n, double* t2n) {
     QTRY(gemm(o, npv, v, 1.0, t1, v, true, ovvv_pk_, npv, false, 0.0, ZCp_, npv, o, 0, v * npv, o * npv, vec_ok ? cfg_wide : -1));
     QTRY(dev_unpack_tril_rows(oo, v, ZCp_, ZC_));
   }
-  QTRY(dev_ccsd_y_traces(o, v, ZC_, ZB_, Y_));                                       // Y[a,c] = 2 sum_k ZC[k,k,a,c] - sum_k ZB[k,c,a,k]
-  QTRY(dcopy(oo, Foo_, Loo_)); QTRY(axpby(oo, 1.0, Z_, 1.0, Loo_));                // Loo' = Foo' + Z
-  QTRY(dcopy(vv, Fvv_, Lvv_)); QTRY(axpby(vv, 1.0, Y_, 1.0, Lvv_));                // Lvv' = Fvv' + Y
+  QTRY(dev_ccsd_y_traces(o, v, ZC_, ZB_, Lvv_, Fvv_));                               // Lvv' = Fvv' + Y,  Y[a,c] = 2 sum_k ZC[k,k,a,c] - sum_k ZB[k,c,a,k]
 
   // ---- T1 equation
-  QTRY(gemm_nt(o, v, v, 1.0, t1, Lvv_, 0.0, t1n));                                 // (Fvv'+Y)_ac t1[ic]
-  QTRY(gemm_tn(o, v, o, -1.0, Loo_, t1, 1.0, t1n));                                // -(Foo'+Z)_ki t1[ka]
-  QTRY(gemm_nt(o, o, v, 1.0, t1, Fov_, 0.0, Q_));                                  // Q[i,k] = t1[ic] Fov[kc]
-  QTRY(gemm_nn(o, v, o, 1.0, Q_, t1, 1.0, t1n));                                   // Fov_kc t1[ic] t1[ka]
-  QTRY(dev_gemv_rows(nov, nov, S_, nov, Fov_, t1n, 1.0, 1.0));                     // Fov_kc (2 t2[kica] - t2[ikca])
-  QTRY(dev_gemv_rows(nov, nov, Lph1_, nov, t1, t1n, 1.0, 1.0));                    // (2 ovvo[kcai] - oovv[kiac]) t1[kc]
+  // (Fvv'+Y)_ac t1[ic] - (Foo'+Z)_ki t1[ka] + Fov_kc t1[ic] t1[ka]: four products of a few MFLOP, one launch
+  QTRY(dev_ccsd_t1_small(o, v, t1, Lvv_, Loo_, Fov_, t1n));
+  // + Fov_kc (2 t2[kica] - t2[ikca]) + (2 ovvo[kcai] - oovv[kiac]) t1[kc]: two passes over o^2 v^2 operands, one launch
+  QTRY(dev_gemv_rows2(nov, nov, S_, nov, Fov_, Lph1_, nov, t1, t1n, 1.0, 1.0));
   QTRY(gemm(o, v, o * vv, 1.0, R_, o * vv, true, I_.ovvv, v, false, 1.0, t1n, v, 1, 0, 0, 0, cfg_wide));     // (2 ovvv[kdac] - ovvv[kcad]) t2[ikcd]
   QTRY(gemm(o, v, o * v * o, -1.0, Lovoo_, o, false, T_, v, false, 1.0, t1n, v, 1, 0, 0, 0, cfg_wide));     // -(2 ovoo[lcki] - ovoo[kcli]) t2[klac]
 
   // ---- T2 equation: direct (unsymmetrised) part
   // (the bare ovov[i,a,j,b] term is added by the finishing kernel)
   // Woooo[k,l,i,j]
-  QTRY(dcopy(oo * oo, oooo_p_, Wo_));
-  QTRY(perm4(Wo_, Xw_, o, o, o, o, 2, 3, 0, 1, 1.0, 1.0));                           // + ovov[kcld] tau[ijcd]: Wo[k,l,i,j] += Xw[i,j,k,l] (formed at the top)
+  //   = oooo[kilj] + ovov[kcld] tau[ijcd] (Xw[i,j,k,l], formed at the top) + ovoo[lcki] t1[jc] (O1[l,j,k,i]) + ovoo[kclj] t1[ic] (O1[k,i,l,j])
+  // is never stored: its (+/-) pair-packed images -- Woooo[klij] tau[klab] goes with the ladder below, through packed pairs -- are formed from the four terms
   QTRY(gemm(o, oo, v, 1.0, t1, v, true, I_.ovoo, oo, false, 0.0, O1_, oo, o, 0, v * oo, o * oo));   // O1[l,j,k,i]
-  QTRY(perm4(Wo_, O1_, o, o, o, o, 2, 0, 3, 1, 1.0, 1.0));                         // + ovoo[lcki] t1[jc]
-  QTRY(perm4(Wo_, O1_, o, o, o, o, 0, 2, 1, 3, 1.0, 1.0));                         // + ovoo[kclj] t1[ic]
-  QTRY(dev_pack_w_pm(o, Wo_, WAp_, lwp_, WAm_, lwm_));                             // Woooo[klij] tau[klab]: with the ladder below, through packed pairs
+  QTRY(dev_pack_w_pm_sum(o, oooo_p_, Xw_, O1_, WAp_, lwp_, WAm_, lwm_));
   // pp-ladder (the dominant kernel)
   // R_ijab = sum_cd (ac|bd) tau_ijcd through pair-packed symmetric / antisymmetric combinations:
   //   R = R+ + R-,  R+[P(ij),P(ab)] = sum_{c>=d} Vp[P(ab),P(cd)] Tp[P(ij),P(cd)],  R-[Q(ij),Q(ab)] = sum_{c>d} Vm Tm,
@@ -366,13 +385,14 @@ int CcsdSolver::update_amps(double* t1n, double* t2n) {
      //   X[ij] = Xp + Xm, X[ji] = Xp - Xm (i > j),  Xp = LTp OVp^T (c >= d),  Xm = LTm OVm^T (c > d)
     const int64_t npo = o * (o + 1) / 2, nmo = o * (o - 1) / 2;
     int cfg, ks;
+    SlabGemm sp, sm;
     pick_pair_gemm(npo, nov, cfg, ks);
-    QTRY(gemm(npo, nov, I_.ldp, 1.0, LTp_, I_.ldp, true, OVp_, I_.ldp, true, 0.0, Xp_, nov, 1, 0, 0, 0, cfg, ks));
+    QTRY(gemm_slabs(npo, nov, I_.ldp, LTp_, I_.ldp, OVp_, I_.ldp, Xp_, nov, cfg, ks, sp));
     if (nmo > 0) {
       pick_pair_gemm(nmo, nov, cfg, ks);
-      QTRY(gemm(nmo, nov, I_.ldm, 1.0, LTm_, I_.ldm, true, OVm_, I_.ldm, true, 0.0, Xm_, nov, 1, 0, 0, 0, cfg, ks));
+      QTRY(gemm_slabs(nmo, nov, I_.ldm, LTm_, I_.ldm, OVm_, I_.ldm, Xm_, nov, cfg, ks, sm));
     }
-    QTRY(dev_scatter_pm_rows(o, nov, Xp_, Xm_, X_));
+    QTRY(dev_scatter_pm_rows(o, nov, Xp_, Xm_, X_, ovoo_ijka_, sp.S, sp.stride, sm.S, sm.stride));   // ... + ovoo[i,a,j,k]: the second term of A below, added on the way
   }
   //   X1 = (ovvv[iacb] - oovv[kibc] t1[ka]) t1[jc],   X2 = (ovvo[kcai] t1[jc] + ovoo[iajk]) t1[kb] (enters with a minus sign)
   QTRY(perm4(U_, ZB_, o, v, v, o, 0, 3, 1, 2, 1.0, 1.0));                          // U[i,j,a,b] += t1[jc] ovvv[i,a,b,c] = ZB[i,a,b,j]
@@ -381,7 +401,6 @@ int CcsdSolver::update_amps(double* t1n, double* t2n) {
   //   A = X[i,j,k,a] + ovoo[i,a,j,k] + (oovv[(k,j,a),c] t1[i,c]) + (t1[j,c] ovvo[k,c,a,i])
   QTRY(gemm(oo * v, o, v, 1.0, I_.oovv, v, true, t1, v, true, 0.0, G2_, o, 1, 0, 0, 0, cfg_tall));                                   // G2[k,j,a,i] = oovv[(kja),c] t1[ic]
   QTRY(gemm(o, v * o, v, 1.0, t1, v, true, I_.ovvo, v * o, false, 1.0, G2_, v * o, o, 0, v * v * o, o * v * o, cfg_wide));          //          += t1[jc] ovvo[k,c,a,i]
-  QTRY(axpby(o * oo * v, 1.0, ovoo_ijka_, 1.0, X_));
   QTRY(perm4(X_, G2_, o, o, v, o, 3, 1, 0, 2, 1.0, 1.0));                          // A[i,j,k,a] += G2[k,j,a,i]
   QTRY(dev_small_k_update(oo, v, v, o, -1.0, X_, nov, t1, 0, U_, vv));                 // U[ij][a][b] -= sum_k A[ij][k][a] t1[k][b]
   // ---- ph rings
@@ -406,21 +425,31 @@ int CcsdSolver::update_amps(double* t1n, double* t2n) {
   QTRY(ring(0.25, W12_, Lovov_, 1.0, W1_));                                        // + 1/4 u~ L
   //   W2[(ia),(kc)] = Wvovo[a,k,c,i]
   QTRY(dev_small_k_update(oo, v, v, o, -1.0, t1, 0, ovoo_kilc_, nov, ZC_, vv));     // ZC[k,i,a,c] -= sum_l t1[l,a] ovoo[l,c,k,i]
-  QTRY(perm4(W2_, ZC_, o, o, v, v, 1, 2, 0, 3, 1.0, 1.0, W2base_));                // W2 = W2base + t1[id] ovvv[kdac] - t1[la] ovoo[lcki]
-  // The Tp~ ovov_t product enters Wvoov with -1/4 and Wvovo with -1/2, so it cancels in Wvoov - Wvovo/2: form that
-  // combination first (R), then let the GEMM accumulate the product straight into Wvovo.
-  QTRY(lincomb2(N2, 1.0, W1_, -0.5, W2_, R_));                                     // R = Wvoov - Wvovo/2
+  // W2 = W2base + t1[id] ovvv[kdac] - t1[la] ovoo[lcki].  The Tp~ ovov_t product enters Wvoov with -1/4 and Wvovo with -1/2, so it cancels in
+  // Wvoov - Wvovo/2: that combination (R) is formed first -- as a second output of the pass that writes W2 -- then the GEMM accumulates the product
+  // straight into Wvovo.
+  {
+    Copy4Desc c{};
+    const int64_t d[4] = {o, o, v, v};       // ZC[k,i,a,c] -> [i,a,k,c]
+    const int perm[4] = {1, 2, 0, 3};
+    int64_t od[4], ostr[4];
+    for (int k = 0; k < 4; ++k) od[k] = d[perm[k]];
+    ostr[3] = 1; ostr[2] = od[3]; ostr[1] = od[3] * od[2]; ostr[0] = od[3] * od[2] * od[1];
+    c.in = ZC_; c.out = W2_; c.alpha = 1.0; c.beta = 1.0; c.base = W2base_;
+    c.si[3] = 1; c.si[2] = d[3]; c.si[1] = d[3] * d[2]; c.si[0] = d[3] * d[2] * d[1];
+    for (int k = 0; k < 4; ++k) { c.dim[k] = d[k]; c.so[perm[k]] = ostr[k]; }
+    c.out2 = R_; c.in2 = W1_; c.c2a = 1.0; c.c2b = -0.5;                            // R = Wvoov - Wvovo/2
+    QTRY(dev_copy4(c));
+  }
   QTRY(ring(-0.5, W12b_, ovov_t_, 1.0, W2_));                                       // Wvovo -= 1/2 Tp~ ovov_t
   // Update, also two products:  (2 Wvoov - Wvovo) T - Wvoov Tp = (Wvoov - Wvovo/2) u - (Wvovo Tp)/2  with T = (u + Tp)/2
+  // The two products stay where the GEMMs leave them ([i,a,j,b]); the finishing pass takes U[i,j,a,b] += RS[i,a,j,b] - A3[i,a,j,b] / 2 - A3[i,b,j,a] from there
   QTRY(ring(1.0, W2_, Tp_, 0.0, W1_));                                             // A3 = Wvovo[bkci] t2[kjac] at W1[i,b,j,a]
-  QTRY(perm4(U_, W1_, o, v, o, v, 0, 2, 3, 1, -1.0, 1.0));                         // U[i,j,a,b] -= A3[i,b,j,a]
-  QTRY(ring(1.0, R_, S_, -0.5, W1_));                                              // W1 = (Wvoov - Wvovo/2) u - A3/2
-  QTRY(perm4(U_, W1_, o, v, o, v, 0, 2, 1, 3, 1.0, 1.0));                          // [i,a,j,b] -> U[i,j,a,b]
+  QTRY(ring(1.0, R_, S_, 0.0, W12_));                                              // RS = (Wvoov - Wvovo/2) u   (W12_: its last reader was the first product)
   QTRY(lap_RINGS.close());
 
-  // ---- symmetrise and divide
-  QTRY(dev_div_denom(t1n, o, 1, v, 1, eo_, nullptr, ev_, nullptr));
-  QTRY(dev_ccsd_finish_t2(o, v, t2n, U_, OVoovv_, eo_, ev_));                      // (t2n + ovov + U + U^T(ji,ba)) / D in one pass
+  // ---- symmetrise and divide: (t2n + ovov + U' + U'^T(ji,ba)) / D in one pass over each (i >= j) pair of tiles, t1n / D on the way
+  QTRY(dev_ccsd_finish_t2_rings(o, v, t2n, U_, OVoovv_, W12_, W1_, eo_, ev_, t1n));
   return 0;
 }
 
@@ -521,42 +550,64 @@ int CcsdSolver::prepare_tape() {
 // fragments' streams work side by side and the host waits once per step and fragment instead of serialising whole post phases.
 int CcsdSolver::iterate_post(double* e_corr, double* normt) {
   QTRY(post_issue());
-  QTRY(dev_sync());
+  QTRY(post_wait(1));
   QTRY(post_extrapolate(normt));
-  QTRY(dev_sync());
+  QTRY(post_wait(2));
   return post_energy(e_corr);
 }
-// step 1: diff = t_new - t (also the DIIS error vector: trial minus previously returned vector); its Gram row on the way to the host
+// the wait after step 1 / 2: on the host word the fused launch publishes behind its results, else on the stream
+int CcsdSolver::post_wait(int step) {
+  if (!fused_post()) return dev_sync();
+  if (step == 1) return last_use_diis_ ? diis_[0].wait_row() : dev_wait_flag(host_scal_ + 3, seq_push_);
+  return dev_wait_flag(host_scal_ + 2, seq_energy_);
+}
+// (the fused launches take up to eight stored vectors and o^2 <= 16384 tiles; QEMB_POST_FUSED=0: the pass-by-pass form, for A/B runs)
+bool CcsdSolver::fused_post() const {
+  static const bool on = [] { const char* e = std::getenv("QEMB_POST_FUSED"); return !e || e[0] != '0'; }();
+  return on && !(last_use_diis_ && diis_[0].space() > 8) && (int64_t)o_ * o_ <= 16384 && v_ <= 4096;
+}
+// step 1: diff = t_new - t (also the DIIS error vector: trial minus previously returned vector) and its Gram row -- one launch whose last
+// workgroup leaves the row (|t_new - t|^2 is its diagonal element) in pinned host memory
 int CcsdSolver::post_issue() {
   const int64_t na = n_amp();
-  const bool use_diis = last_use_diis_;
   double* out = last_out_;
-  if (!host_scal_) { void* q = nullptr; QTRY(dev_pinned_alloc(&q, 4 * sizeof(double))); host_scal_ = (double*)q; }
-  double* err = use_diis ? diis_[0].next_e() : diff_.p;
-  QTRY(lincomb2(na, 1.0, out, -1.0, amp_, err));
-  if (use_diis) {
-    // |t_new - t|^2 is the diagonal of the DIIS Gram row (same reduction, same bits as dev_dot): no separate pass
-    if (out != diis_[0].next_x()) QTRY(dcopy(na, out, diis_[0].next_x()));
-    QTRY(diis_[0].gram_issue());
-  } else {
+  if (!host_scal_) { void* q = nullptr; QTRY(dev_pinned_alloc(&q, 4 * sizeof(double))); host_scal_ = (double*)q; for (int k = 0; k < 4; ++k) host_scal_[k] = 0.0; seq_push_ = seq_energy_ = 0; }
+  if (!fused_post()) {      // the general path, pass by pass
+    double* err = last_use_diis_ ? diis_[0].next_e() : diff_.p;
+    QTRY(lincomb2(na, 1.0, out, -1.0, amp_, err));
+    if (last_use_diis_) {
+      if (out != diis_[0].next_x()) QTRY(dcopy(na, out, diis_[0].next_x()));
+      return diis_[0].gram_issue();
+    }
     QTRY(dev_dot(na, err, err, scal_.p + 1));
     QTRY(dcopy(na, out, amp_));
-    QTRY(dev_d2h_async(host_scal_ + 1, scal_.p + 1, sizeof(double)));
+    return dev_d2h_async(host_scal_ + 1, scal_.p + 1, sizeof(double));
   }
-  return 0;
+  if (last_use_diis_) return diis_[0].push_diff_issue(out, amp_);
+  const double* self[1] = {diff_.p};
+  return dev_diis_push(na, out, amp_, diff_, amp_, 1, self, 0, scal_.p + 1, host_scal_ + 1, host_scal_ + 3, ++seq_push_);      // amp = t_new on the way
 }
-// step 2 (after a wait): the DIIS solve on the host, the extrapolated amplitudes, and the energy reduction on its way to the host
+// step 2 (after a wait): the DIIS solve on the host; the extrapolated amplitudes, their tau and the energy
+//   E = sum (2 ovov[iajb] - ovov[ibja]) tau[ijab] = <Loovv, tau>   (f_ov = 0)
+// in one launch (energy to pinned host memory)
 int CcsdSolver::post_extrapolate(double* normt) {
   double nn = 0.0;
-  if (last_use_diis_) QTRY(diis_[0].gram_finish(amp_, false, &nn));
-  else nn = host_scal_[1];
   first_ = false;
+  if (!fused_post()) {      // beyond what the fused launch takes: the general path
+    if (last_use_diis_) QTRY(diis_[0].gram_finish(amp_, false, &nn));
+    else nn = host_scal_[1];
+    *normt = std::sqrt(nn);
+    QTRY(make_tau(t1(), t2(), tau_));
+    QTRY(dev_dot((int64_t)o_ * o_ * v_ * v_, Loovv_, tau_, scal_));
+    return dev_d2h_async(host_scal_, scal_, sizeof(double));
+  }
+  double c[8] = {1.0};
+  const double* xs[8] = {amp_.p};
+  int m = 1;
+  if (last_use_diis_) QTRY(diis_[0].coefficients(&m, c, xs, &nn));
+  else nn = host_scal_[1];
   *normt = std::sqrt(nn);
-  // E = sum (2 ovov[iajb] - ovov[ibja]) tau[ijab] = <Loovv, tau>   (f_ov = 0)
-  QTRY(make_tau(t1(), t2(), tau_));
-  QTRY(dev_dot((int64_t)o_ * o_ * v_ * v_, Loovv_, tau_, scal_));
-  QTRY(dev_d2h_async(host_scal_, scal_, sizeof(double)));
-  return 0;
+  return dev_ccsd_extrapolate_energy(o_, v_, m, c, xs, amp_, Loovv_, tau_, scal_, host_scal_, host_scal_ + 2, ++seq_energy_);
 }
 // step 3 (after a wait)
 int CcsdSolver::post_energy(double* e_corr) {
@@ -633,11 +684,11 @@ int ccsd_kernel_lockstep(const std::vector<CcsdSolver*>& s, const std::vector<Cc
     if (stats) stats->ms_tapes += t1 - t0;
     struct PostTime { LockstepStats* st; double t1; double (*now)(); ~PostTime() { if (st) st->ms_post += now() - t1; } } post_time{stats, t1, +now};
     for (int f = 0; f < F; ++f) if (active[f]) { QTRY(dev_ctx_bind(ctx[f])); QTRY(s[f]->post_issue()); }
-    for (int f = 0; f < F; ++f) if (active[f]) { QTRY(dev_ctx_bind(ctx[f])); QTRY(dev_sync()); QTRY(s[f]->post_extrapolate(&normt[f])); }
+    for (int f = 0; f < F; ++f) if (active[f]) { QTRY(dev_ctx_bind(ctx[f])); QTRY(s[f]->post_wait(1)); QTRY(s[f]->post_extrapolate(&normt[f])); }
     for (int f = 0; f < F; ++f) {
       if (!active[f]) continue;
       QTRY(dev_ctx_bind(ctx[f]));
-      QTRY(dev_sync());
+      QTRY(s[f]->post_wait(2));
       QTRY(s[f]->post_energy(&e[f]));
       n_iter[f] = it;
       if (opt[f].verbose > 0) std::fprintf(stderr, "[qemb ccsd lockstep] frag %d cycle %3d  E(corr) = %.12f  dE = %.3e  |dt| = %.3e\n", f, it, e[f], e[f] - eold[f], normt[f]);

@@ -54,6 +54,8 @@ class CcsdSolver {
   int iterate(double* e_corr, double* normt);       // one update_amps + DIIS + energy
   int iterate_update(bool prefer_tape, bool defer_tape, bool* deferred);   // the two halves of iterate(), for the lock-step sweep
   int iterate_post(double* e_corr, double* normt);
+  bool fused_post() const;
+  int post_wait(int step);
   int post_issue();                                 // iterate_post in three steps (a wait of this context's stream between them)
   int post_extrapolate(double* normt);
   int post_energy(double* e_corr);
@@ -104,7 +106,8 @@ class CcsdSolver {
   int eager_iters_ = 0;
   bool graph_ok_ = true;
   double* last_out_ = nullptr;      // where iterate_update put the new amplitudes; iterate_post continues from there
-  double* host_scal_ = nullptr;     // pinned: [energy, |dt|^2] on their way back
+  double* host_scal_ = nullptr;     // pinned: [energy, |dt|^2] on their way back, then the words the fused launches publish behind them (energy step, push step)
+  unsigned long long seq_push_ = 0, seq_energy_ = 0;      // ... and their expected values
   bool last_use_diis_ = false, last_replayable_ = false;
  public:
   ~CcsdSolver() { if (graph_) dev_graph_destroy(graph_); if (tape_) dev_tape_destroy(tape_); if (host_scal_) dev_pinned_free(host_scal_); }

@@ -104,7 +104,17 @@ struct GemmDesc {
   int64_t batch;
   int cfg = -1;        // tile configuration override (-1: automatic)
   int ksplit = 0;      // split-K override (0: automatic)
+  // keep_slabs (needs ksplit > 1, alpha = 1, beta = 0, batch = 1): the K slices' partial products stay where they are -- C receives
+  // gemm_slab_count(K, ksplit) slabs [M][N] (ld = N, ldc ignored) and the consumer adds them up in slab order (what the reduction pass would do)
+  int keep_slabs = 0;
 };
+inline int gemm_slab_count(int64_t K, int ksplit) {      // the K slices dev_gemm cuts for an explicit ksplit (32-aligned chunks)
+  if (ksplit <= 1) return 1;
+  int64_t chunk = (K + ksplit - 1) / ksplit;
+  chunk = (chunk + 31) / 32 * 32;
+  const int64_t S = (K + chunk - 1) / chunk;
+  return S > 1 ? (int)S : 1;
+}
 int dev_gemm(const GemmDesc& g);
 // test / tuning hooks of the calling host thread: force a tile configuration (-1: automatic), switch the automatic split-K off
 void dev_gemm_set_force_cfg(int cfg);
@@ -124,6 +134,8 @@ struct Copy4Desc {
   double* out; int64_t so[4];
   double alpha, beta;
   const double* base = nullptr;   // out = alpha*in + beta*base, base addressed like out (nullptr: base = out, i.e. accumulate in place)
+  // optional second output of the same pass, addressed like out:  out2 = c2a * in2 + c2b * (the value written to out)
+  double* out2 = nullptr; const double* in2 = nullptr; double c2a = 0.0, c2b = 0.0;
 };
 int dev_copy4(const Copy4Desc& c);
 
@@ -182,19 +194,34 @@ int dev_ladder_pack_tau(int64_t o, int64_t v, const double* tau, double* Tp, int
 //   Op[r, P(c,d)] = in[r,c,d] + in[r,d,c] (c >= d),  Om[r, Q(c,d)] = in[r,c,d] - in[r,d,c] (c > d); rows padded with zeros to ldp / ldm
 int dev_pack_pm_cols(int64_t rows, int64_t v, const double* in, double* Op, int64_t ldp, double* Om, int64_t ldm);
 // out[i,j,:] = Xp[P(i,j),:] + Xm[Q(i,j),:],  out[j,i,:] = Xp[P(i,j),:] - Xm[Q(i,j),:]  (i > j),  out[i,i,:] = Xp[P(i,i),:]
-int dev_scatter_pm_rows(int64_t o, int64_t ncols, const double* Xp, const double* Xm, double* out);
+// add (laid out like out): out = scatter + add.  Sp / Sm > 1: Xp / Xm are split-K slabs (stride strideP / strideM apart) that are added up on the way, in slab order
+int dev_scatter_pm_rows(int64_t o, int64_t ncols, const double* Xp, const double* Xm, double* out, const double* add = nullptr, int Sp = 1, int64_t strideP = 0,
+                        int Sm = 1, int64_t strideM = 0);
 // CCSD doubles update, last step in one pass:  t2n[i,j,a,b] = (t2n[i,j,a,b] + OV[i,j,a,b] + U[i,j,a,b] + U[j,i,b,a]) / (eo[i]+eo[j]-ev[a]-ev[b])
 int dev_ccsd_finish_t2(int64_t o, int64_t v, double* t2n, const double* U, const double* OV, const double* eo, const double* ev);
+// The same with the two ring products taken in place (no transposing accumulation passes over U first) and the t1 denominators on the way:
+//   F[i,j,a,b] = U[i,j,a,b] + RS[i,a,j,b] - 1/2 M[i,a,j,b] - M[i,b,j,a]      (RS, M: [o][v][o][v])
+//   t2n[i,j,a,b] = t2n[j,i,b,a] = (t2n[i,j,a,b] + OV[i,j,a,b] + F[i,j,a,b] + F[j,i,b,a]) / (eo[i] + eo[j] - ev[a] - ev[b])   -- each (i >= j) pair of tiles once
+//   t1n[i,a] /= eo[i] - ev[a]   (t1n may be null)
+int dev_ccsd_finish_t2_rings(int64_t o, int64_t v, double* t2n, const double* U, const double* OV, const double* RS, const double* M, const double* eo, const double* ev, double* t1n);
 int dev_ladder_scatter_pm(int64_t o, int64_t v, const double* Rp, int64_t ldp, const double* Rm, int64_t ldm, double* t2);
 // The same with a second pair of packed results added on the way (Hp, Hm; same layouts): p = Rp + f Hp, m = Rm + Hm, where f = 2 on the
 // a = b columns and 1 elsewhere -- the hole-hole ladder contracts the packed tau rows, which carry 1/2 on their a = b entries, as its
 // RIGHT operand.  assign != 0: t2 = ... instead of t2 += ... (every element of t2 is written).
+// Sp / Sm > 1: Rp / Rm are split-K slabs (strideP / strideM apart, rows ldp / ldm long) that are added up on the way, in slab order; Hp / Hm keep
+// their own row lengths ldhp / ldhm (0: same as ldp / ldm).
 int dev_ladder_scatter_pm2(int64_t o, int64_t v, const double* Rp, int64_t ldp, const double* Rm, int64_t ldm, const double* Hp, const double* Hm,
-                           int assign, double* t2);
+                           int assign, double* t2, int Sp = 1, int64_t strideP = 0, int Sm = 1, int64_t strideM = 0, int64_t ldhp = 0, int64_t ldhm = 0);
 // (+/-) pair-packed images of W[k,l,i,j] (o^4, symmetric under (k,l,i,j) -> (l,k,j,i)) for the hole-hole ladder R[ij,ab] = W[klij] tau[klab]:
 //   Ap[P(ij)][P(kl)] = W[klij] + W[klji] (k > l), W[kkij] (k = l), i >= j;   Am[Q(ij)][Q(kl)] = W[klij] - W[klji], k > l, i > j
 // (row-major with leading dimensions lda_p >= npair(o), lda_m >= npair'(o); padding columns zeroed)
 int dev_pack_w_pm(int64_t o, const double* W, double* Ap, int64_t lda_p, double* Am, int64_t lda_m);
+// the same for W[k,l,i,j] = Wp[k,l,i,j] + X[i,j,k,l] + O1[l,j,k,i] + O1[k,i,l,j] formed on the fly (the Woooo intermediate of the CCSD update: never stored)
+int dev_pack_w_pm_sum(int64_t o, const double* Wp, const double* X, const double* O1, double* Ap, int64_t lda_p, double* Am, int64_t lda_m);
+// t1n[i,a] = sum_c t1[i,c] Lvv[a,c] - sum_k Loo[k,i] t1[k,a] + sum_k Q[i,k] t1[k,a],  Q[i,k] = sum_c t1[i,c] Fov[k,c]   (the four small products of the T1 equation)
+int dev_ccsd_t1_small(int64_t o, int64_t v, const double* t1, const double* Lvv, const double* Loo, const double* Fov, double* t1n);
+// y[r] = alpha (T1[r,:] . x1 + T2[r,:] . x2) + beta y[r]: two matrix-vector products in one pass
+int dev_gemv_rows2(int64_t rows, int64_t cols, const double* T1, int64_t ld1, const double* x1, const double* T2, int64_t ld2, const double* x2, double* y, double alpha, double beta);
 // F[k,i] = sum_l (2 X[i,l,k,l] - X[l,i,k,l]) for X[i,j,k,l] (o^4): the occupied-occupied intermediate sum_{lcd} (2 ovov[kcld] - ovov[kdlc]) tau[ilcd]
 // as a partial trace of X[i,j,k,l] = sum_cd ovov[kcld] tau[ijcd], which the Woooo build forms anyway
 int dev_foo_from_x(int64_t o, const double* X, double* F);
@@ -209,7 +236,7 @@ int dev_ccsd_ph_layouts(int64_t o, int64_t v, const double* t2, const double* t1
 int dev_small_k_update(int64_t batch, int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t sA, const double* B, int64_t sB,
                        double* C, int64_t sC);
 // Y[a,c] = 2 sum_k ZC[k,k,a,c] - sum_k ZB[k,c,a,k]   (ZC: [o][o][v][v], ZB: [o][v][v][o]; the k = i traces of the two ovvv.t1 products)
-int dev_ccsd_y_traces(int64_t o, int64_t v, const double* ZC, const double* ZB, double* Y);
+int dev_ccsd_y_traces(int64_t o, int64_t v, const double* ZC, const double* ZB, double* Y, const double* add = nullptr);   // add ([v][v]): Y = traces + add
 
 // ---- screening helpers of the semi-sparse DF transform ---------------------------------------------------------------
 // out[i] = (|x[i]| >= eps) ? 1 : 0
@@ -236,6 +263,21 @@ int dev_dot(int64_t n, const double* x, const double* y, double* out_dev);
 int dev_absmax(int64_t n, const double* x, double* out_dev);
 // out_dev[j] = <x, ys[j]> for j < m <= 8 in one pass over x (each result bit-identical to dev_dot)
 int dev_dot_many(int64_t n, const double* x, int m, const double* const* ys, double* out_dev);
+// DIIS push for an error vector that is a difference, ONE pass and one launch:  e[i] = trial[i] - prev[i],  xcopy[i] = trial[i] (xcopy may be
+// null, and may alias prev),  row[j] = <e, ys[j]> for j < m <= 8 with ys[self] == e (the new vector's own slot).  The row lands in row_dev AND in
+// the pinned host block row_host (written by the last workgroup of the launch: no copy node, valid after a wait of this context's stream).
+// Same partition and summation order as dev_dot / dev_dot_many.
+// flag_host (may be null): a pinned host word that receives `seq` AFTER the results (system-scope release): dev_wait_flag spins on it -- a
+// microsecond or two after the kernel's last store instead of the ~13 us of a stream wait.
+int dev_diis_push(int64_t n, const double* trial, const double* prev, double* e, double* xcopy, int m, const double* const* ys, int self,
+                  double* row_dev, double* row_host, void* flag_host = nullptr, unsigned long long seq = 0);
+// wait until the pinned host word holds `seq` (written by a kernel of THIS context's stream; a stream that has drained without writing it is an error)
+int dev_wait_flag(const void* flag_host, unsigned long long seq);
+// End of a CCSD iteration in one launch:  amp = sum_k coef[k] xs[k] over the packed amplitudes [t1 (o v) | t2 (o,o,v,v)] (nterms <= 8; amp may
+// be xs[0] when nterms == 1 and coef[0] == 1: nothing is rewritten),  tau = t2 + t1 (x) t1 of the NEW amplitudes,  E = <L, tau> to e_dev and to
+// the pinned host word e_host (last workgroup).  o * o <= 16384.
+int dev_ccsd_extrapolate_energy(int64_t o, int64_t v, int nterms, const double* coef, const double* const* xs, double* amp, const double* L,
+                                double* tau, double* e_dev, double* e_host, void* flag_host = nullptr, unsigned long long seq = 0);
 
 // ---- matrix-vector style contractions for J/K builds (HBM bound) -------------------------------
 // y[r] = alpha * sum_c T[r*ldt + c] * x[c] + beta*y[r]        r < rows, c < cols

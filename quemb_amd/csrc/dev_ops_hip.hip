@@ -93,7 +93,8 @@ int dev_init(int device) {
   }
   HIP_TRY(hipSetDevice(device));
   HIP_TRY(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
-  HIP_TRY(hipMalloc((void**)&c.partials, 8 * NPART * sizeof(double)));
+  HIP_TRY(hipMalloc((void**)&c.partials, (8 * NPART + 8) * sizeof(double)));
+  HIP_TRY(hipMemset(c.partials + 8 * NPART, 0, 8 * sizeof(double)));      // the "workgroups done" counter of the single-launch reductions
   g_device = device;
   return QEMB_OK;
 }
@@ -105,7 +106,8 @@ int dev_ctx_count(int n) {
   while ((int)g_extra_ctx.size() + 1 < n) {
     DevCtx* c = new DevCtx();
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipMalloc((void**)&c->partials, 8 * NPART * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&c->partials, (8 * NPART + 8) * sizeof(double));
+    if (e == hipSuccess) e = hipMemset(c->partials + 8 * NPART, 0, 8 * sizeof(double));
     if (e != hipSuccess) { delete c; set_error(std::string("dev_ctx_count: ") + hipGetErrorString(e)); return QEMB_ERR_DEVICE; }
     g_extra_ctx.push_back(c);
   }
@@ -251,6 +253,11 @@ int dev_pinned_alloc(void** p, size_t bytes) {
     if (it != g_pinned_free.end() && !it->second.empty()) { *p = it->second.back(); it->second.pop_back(); g_pinned_live[*p] = cls; return QEMB_OK; }
   }
   HIP_TRY(hipHostMalloc(p, cls, hipHostMallocDefault));
+  {  // kernels write their scalar results straight into these blocks (single-launch reductions): the host address must be the device address
+    void* dp = nullptr;
+    HIP_TRY(hipHostGetDevicePointer(&dp, *p, 0));
+    if (dp != *p) { (void)hipHostFree(*p); *p = nullptr; set_error("pinned host memory is not mapped at its host address on this platform"); return QEMB_ERR_DEVICE; }
+  }
   std::lock_guard<std::mutex> lock(g_pinned_mutex);
   g_pinned_live[*p] = cls;
   return QEMB_OK;
@@ -721,6 +728,7 @@ struct Copy4K {
   long long d0, d1, d2, d3;
   long long si0, si1, si2, si3, so0, so1, so2, so3;
   const double* in; double* out; double alpha, beta; const double* base;
+  double* out2; const double* in2; double c2a, c2b;      // optional second output of the pass (see Copy4Desc)
 };
 
 __device__ __forceinline__ void copy4_linear_kernel_body(const uint3 BID, const uint3 GDIM, Copy4K c) {
@@ -734,7 +742,9 @@ __device__ __forceinline__ void copy4_linear_kernel_body(const uint3 BID, const 
         const long long i2 = t / c.d3, i3 = t - i2 * c.d3;
         const double v = c.alpha * c.in[bi + i2 * c.si2 + i3 * c.si3];
         const long long off = bo + i2 * c.so2 + i3 * c.so3;
-        c.out[off] = (c.beta != 0.0) ? v + c.beta * c.base[off] : v;
+        const double w = (c.beta != 0.0) ? v + c.beta * c.base[off] : v;
+        c.out[off] = w;
+        if (c.out2) c.out2[off] = c.c2a * c.in2[off] + c.c2b * w;
       }
     }
   }
@@ -762,7 +772,9 @@ __device__ __forceinline__ void copy4_transpose_kernel_body(const uint3 BID, con
         if (i2 < c.d2 && i3 < c.d3) {
           const double v = c.alpha * tile[tx][ty + 8 * r];
           const long long off = bo + i2 * c.so2 + i3 * c.so3;
-          c.out[off] = (c.beta != 0.0) ? v + c.beta * c.base[off] : v;
+          const double w = (c.beta != 0.0) ? v + c.beta * c.base[off] : v;
+          c.out[off] = w;
+          if (c.out2) c.out2[off] = c.c2a * c.in2[off] + c.c2b * w;
         }
       }
       __syncthreads();
@@ -794,6 +806,8 @@ int dev_copy4(const Copy4Desc& cd) {
   c.si0 = si[0]; c.si1 = si[1]; c.si2 = si[2]; c.si3 = si[3];
   c.so0 = so[0]; c.so1 = so[1]; c.so2 = so[2]; c.so3 = so[3];
   c.in = cd.in; c.out = cd.out; c.alpha = cd.alpha; c.beta = cd.beta; c.base = cd.base ? cd.base : cd.out;
+  c.out2 = cd.out2; c.in2 = cd.in2; c.c2a = cd.c2a; c.c2b = cd.c2b;
+  if (c.out2 && !c.in2) { set_error("dev_copy4: second output without its input"); return QEMB_ERR_ARG; }
   if (c.d2 * c.d3 >= (1LL << 40)) { set_error("dev_copy4: inner extent too large"); return QEMB_ERR_ARG; }
   const unsigned gy = (unsigned)std::min<long long>(c.d1, 65535), gz = (unsigned)std::min<long long>(c.d0, 65535);
   if (transpose) {
@@ -1053,21 +1067,21 @@ int dev_small_k_update(int64_t batch, int64_t M, int64_t N, int64_t K, double al
 }
 
 __device__ __forceinline__ void ccsd_y_traces_kernel_body(const uint3 BID, const uint3 GDIM, long long o, long long v, const double* __restrict__ ZC, const double* __restrict__ ZB,
-                                                            double* __restrict__ Y) {
+                                                            double* __restrict__ Y, const double* __restrict__ add) {
   const long long idx = (long long)BID.x * blockDim.x + threadIdx.x;
   if (idx >= v * v) return;
   const long long a = idx / v, c = idx % v;
   double s = 0.0;
   for (long long k = 0; k < o; ++k)
     s += 2.0 * ZC[((k * o + k) * v + a) * v + c] - ZB[((k * v + c) * v + a) * o + k];
-  Y[idx] = s;
+  Y[idx] = add ? s + add[idx] : s;
 }
 __global__ void __launch_bounds__(256) ccsd_y_traces_kernel(long long o, long long v, const double* __restrict__ ZC, const double* __restrict__ ZB,
-                                                            double* __restrict__ Y) { ccsd_y_traces_kernel_body(make_uint3(blockIdx.x, blockIdx.y, blockIdx.z), make_uint3(gridDim.x, gridDim.y, gridDim.z), o, v, ZC, ZB, Y); }
-int dev_ccsd_y_traces(int64_t o, int64_t v, const double* ZC, const double* ZB, double* Y) {
+                                                            double* __restrict__ Y, const double* __restrict__ add) { ccsd_y_traces_kernel_body(make_uint3(blockIdx.x, blockIdx.y, blockIdx.z), make_uint3(gridDim.x, gridDim.y, gridDim.z), o, v, ZC, ZB, Y, add); }
+int dev_ccsd_y_traces(int64_t o, int64_t v, const double* ZC, const double* ZB, double* Y, const double* add) {
   REQUIRE_INIT();
   if (v <= 0) return QEMB_OK;
-  hipLaunchKernelGGL(ccsd_y_traces_kernel, dim3((unsigned)((v * v + 255) / 256)), dim3(256), 0, g_stream, (long long)o, (long long)v, ZC, ZB, Y);
+  hipLaunchKernelGGL(ccsd_y_traces_kernel, dim3((unsigned)((v * v + 255) / 256)), dim3(256), 0, g_stream, (long long)o, (long long)v, ZC, ZB, Y, add);
   HIP_TRY(hipGetLastError());
   return QEMB_OK;
 }
@@ -1412,26 +1426,46 @@ int dev_pack_pm_cols(int64_t rows, int64_t v, const double* in, double* Op, int6
   HIP_TRY(hipGetLastError());
   return QEMB_OK;
 }
-__device__ __forceinline__ void scatter_pm_rows_kernel_body(const uint3 BID, const uint3 GDIM, long long o, long long ncols, const double* __restrict__ Xp, const double* __restrict__ Xm, double* __restrict__ out) {
+// sum of the S split-K slabs of one element, in slab order (what the reduction pass forms); the common counts are spelled out so that their loads are
+// independent instructions the scheduler can issue together (a counted loop made the ladder scatter wait for each slab in turn: 56 -> 172 us)
+__device__ __forceinline__ double slab_sum(const double* __restrict__ p, int S, long long stride) {
+  switch (S) {
+    case 1: return p[0];
+    case 2: { const double a = p[0], b = p[stride]; return a + b; }
+    case 3: { const double a = p[0], b = p[stride], c = p[2 * stride]; return (a + b) + c; }
+    case 4: { const double a = p[0], b = p[stride], c = p[2 * stride], d = p[3 * stride]; return ((a + b) + c) + d; }
+    default: {
+      double acc = 0.0;
+      int sl = 0;
+      for (; sl + 4 <= S; sl += 4) { const double a = p[sl * stride], b = p[(sl + 1) * stride], c = p[(sl + 2) * stride], d = p[(sl + 3) * stride]; acc = (((acc + a) + b) + c) + d; }
+      for (; sl < S; ++sl) acc += p[sl * stride];
+      return acc;
+    }
+  }
+}
+__device__ __forceinline__ void scatter_pm_rows_kernel_body(const uint3 BID, const uint3 GDIM, long long o, long long ncols, const double* __restrict__ Xp, const double* __restrict__ Xm, double* __restrict__ out, const double* __restrict__ add,
+                                                            int Sp, long long strideP, int Sm, long long strideM) {
   const long long ij = BID.y;
   long long i, j; unpair_ge(ij, i, j);
   const double* xp = Xp + ij * ncols;
   const double* xm = (i > j) ? Xm + (i * (i - 1) / 2 + j) * ncols : nullptr;
   double* oij = out + (i * o + j) * ncols;
   double* oji = out + (j * o + i) * ncols;
+  const double* aij = add ? add + (i * o + j) * ncols : nullptr;
+  const double* aji = add ? add + (j * o + i) * ncols : nullptr;
   for (long long c = (long long)BID.x * blockDim.x + threadIdx.x; c < ncols; c += (long long)GDIM.x * blockDim.x) {
-    const double p = xp[c];
-    if (xm) { const double m = xm[c]; oij[c] = p + m; oji[c] = p - m; }
-    else oij[c] = p;
+    const double p = slab_sum(xp + c, Sp, strideP);         // (split-K slabs: the sum the reduction pass would have formed)
+    if (xm) { const double m = slab_sum(xm + c, Sm, strideM); oij[c] = add ? aij[c] + (p + m) : p + m; oji[c] = add ? aji[c] + (p - m) : p - m; }
+    else oij[c] = add ? aij[c] + p : p;
   }
 }
-__global__ void __launch_bounds__(256) scatter_pm_rows_kernel(long long o, long long ncols, const double* __restrict__ Xp, const double* __restrict__ Xm, double* __restrict__ out) { scatter_pm_rows_kernel_body(make_uint3(blockIdx.x, blockIdx.y, blockIdx.z), make_uint3(gridDim.x, gridDim.y, gridDim.z), o, ncols, Xp, Xm, out); }
-int dev_scatter_pm_rows(int64_t o, int64_t ncols, const double* Xp, const double* Xm, double* out) {
+__global__ void __launch_bounds__(256) scatter_pm_rows_kernel(long long o, long long ncols, const double* __restrict__ Xp, const double* __restrict__ Xm, double* __restrict__ out, const double* __restrict__ add, int Sp, long long strideP, int Sm, long long strideM) { scatter_pm_rows_kernel_body(make_uint3(blockIdx.x, blockIdx.y, blockIdx.z), make_uint3(gridDim.x, gridDim.y, gridDim.z), o, ncols, Xp, Xm, out, add, Sp, strideP, Sm, strideM); }
+int dev_scatter_pm_rows(int64_t o, int64_t ncols, const double* Xp, const double* Xm, double* out, const double* add, int Sp, int64_t strideP, int Sm, int64_t strideM) {
   REQUIRE_INIT();
   const long long npo = o * (o + 1) / 2;
   if (npo <= 0 || ncols <= 0) return QEMB_OK;
   if (npo > 65535) { set_error("dev_scatter_pm_rows: too many pairs"); return QEMB_ERR_ARG; }
-  hipLaunchKernelGGL(scatter_pm_rows_kernel, dim3((unsigned)std::min<long long>((ncols + 255) / 256, 64), (unsigned)npo), dim3(256), 0, g_stream, (long long)o, (long long)ncols, Xp, Xm, out);
+  hipLaunchKernelGGL(scatter_pm_rows_kernel, dim3((unsigned)std::min<long long>((ncols + 255) / 256, 64), (unsigned)npo), dim3(256), 0, g_stream, (long long)o, (long long)ncols, Xp, Xm, out, add, std::max(Sp, 1), (long long)strideP, std::max(Sm, 1), (long long)strideM);
   HIP_TRY(hipGetLastError());
   return QEMB_OK;
 }
@@ -1474,11 +1508,82 @@ int dev_ccsd_finish_t2(int64_t o, int64_t v, double* t2n, const double* U, const
   HIP_TRY(hipGetLastError());
   return QEMB_OK;
 }
+// finish_t2 with the two ring products taken where the GEMMs left them ([o][v][o][v]) and every (i >= j) PAIR of tiles handled once: the tile (ta,tb) of
+// t2n[i,j] and the tile (tb,ta) of t2n[j,i] are transposes of each other, so one workgroup reads the ten operand tiles, forms the 32 x 32 result once and
+// stores it both ways (the second through LDS).  grid (nt * nt tiles, npair(o)); a diagonal pair i == j does its tiles twice over (ta,tb) and (tb,ta): same values.
+__device__ __forceinline__ void ccsd_finish_t2_rings_kernel_body(const uint3 BID, const uint3 GDIM, long long o, long long v, double* __restrict__ t2n, const double* __restrict__ U,
+                                                                   const double* __restrict__ OV, const double* __restrict__ RS, const double* __restrict__ M,
+                                                                   const double* __restrict__ eo, const double* __restrict__ ev, double* __restrict__ t1n) {
+  __shared__ double tile[32][33];
+  long long i, j; unpair_ge((long long)BID.y, i, j);
+  const long long nt = (v + 31) / 32;
+  const long long ta = BID.x / nt, tb = BID.x - ta * nt;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const long long vv = v * v, ov = o * v;
+  const double* Uij = U + (i * o + j) * vv;
+  const double* Uji = U + (j * o + i) * vv;
+  // [o][v][o][v] operands: element [i,x,j,y] at (i * v + x) * ov + j * v + y
+  const double* RSij = RS + i * v * ov + j * v;
+  const double* RSji = RS + j * v * ov + i * v;
+  const double* Mij = M + i * v * ov + j * v;
+  const double* Mji = M + j * v * ov + i * v;
+  // transposed contributions, summed before the transpose: tile[bb][aa] = -M[i,b,j,a] + U[j,i,b,a] + RS[j,b,i,a] - 1/2 M[j,b,i,a]
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int bb = ty + 8 * k;
+    const long long b = tb * 32 + bb, a = ta * 32 + tx;
+    tile[bb][tx] = (a < v && b < v) ? ((Uji[b * v + a] + RSji[b * ov + a]) - 0.5 * Mji[b * ov + a]) - Mij[b * ov + a] : 0.0;
+  }
+  __syncthreads();
+  const double eij = eo[i] + eo[j];
+  double res[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int aa = ty + 8 * k;
+    const long long a = ta * 32 + aa, b = tb * 32 + tx;
+    res[k] = 0.0;
+    if (a < v && b < v) {
+      const long long idx = (i * o + j) * vv + a * v + b;
+      const double straight = ((Uij[a * v + b] + RSij[a * ov + b]) - 0.5 * Mij[a * ov + b]) - Mji[a * ov + b];
+      res[k] = (t2n[idx] + OV[idx] + straight + tile[tx][aa]) / (eij - ev[a] - ev[b]);
+      t2n[idx] = res[k];
+    }
+  }
+  if (i != j) {        // the partner tile t2n[j,i,b,a] = t2n[i,j,a,b], written in rows of b
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) tile[ty + 8 * k][tx] = res[k];      // tile[aa][bb]
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int bb = ty + 8 * k;
+      const long long b = tb * 32 + bb, a = ta * 32 + tx;
+      if (a < v && b < v) t2n[(j * o + i) * vv + b * v + a] = tile[tx][bb];
+    }
+  }
+  if (t1n && BID.x == 0 && BID.y == 0)
+    for (long long t = threadIdx.x; t < ov; t += blockDim.x) t1n[t] /= eo[t / v] - ev[t % v];
+}
+__global__ void __launch_bounds__(256) ccsd_finish_t2_rings_kernel(long long o, long long v, double* __restrict__ t2n, const double* __restrict__ U, const double* __restrict__ OV,
+                                                                  const double* __restrict__ RS, const double* __restrict__ M, const double* __restrict__ eo,
+                                                                  const double* __restrict__ ev, double* __restrict__ t1n) {
+  ccsd_finish_t2_rings_kernel_body(make_uint3(blockIdx.x, blockIdx.y, blockIdx.z), make_uint3(gridDim.x, gridDim.y, gridDim.z), o, v, t2n, U, OV, RS, M, eo, ev, t1n);
+}
+int dev_ccsd_finish_t2_rings(int64_t o, int64_t v, double* t2n, const double* U, const double* OV, const double* RS, const double* M, const double* eo, const double* ev, double* t1n) {
+  REQUIRE_INIT();
+  if (o <= 0 || v <= 0) return QEMB_OK;
+  const long long npo = o * (o + 1) / 2, nt = (v + 31) / 32;
+  if (npo > 65535) { set_error("dev_ccsd_finish_t2_rings: too many occupied pairs"); return QEMB_ERR_ARG; }
+  hipLaunchKernelGGL(ccsd_finish_t2_rings_kernel, dim3((unsigned)(nt * nt), (unsigned)npo), dim3(256), 0, g_stream, (long long)o, (long long)v, t2n, U, OV, RS, M, eo, ev, t1n);
+  HIP_TRY(hipGetLastError());
+  return QEMB_OK;
+}
 // grid (lower-triangle 32 x 32 tiles of (a,b), npair(o)): the tile of R+/R- is staged through LDS so that both the [a][b] image
 // and its mirror [b][a] are updated in 256-byte runs, for t2[i,j] and t2[j,i].
 __device__ __forceinline__ void ladder_scatter_pm_kernel_body(const uint3 BID, const uint3 GDIM, long long o, long long v, const double* __restrict__ Rp, long long ldp,
                                                                const double* __restrict__ Rm, long long ldm, double* __restrict__ t2,
-                                                               const double* __restrict__ Hp, const double* __restrict__ Hm, int assign) {
+                                                               const double* __restrict__ Hp, const double* __restrict__ Hm, int assign,
+                                                               int Sp, long long strideP, int Sm, long long strideM, long long ldhp, long long ldhm) {
   __shared__ double sp[32][33], sm[32][33];
   const long long ij = BID.y;
   long long i, j; unpair_ge(ij, i, j);
@@ -1486,8 +1591,8 @@ __device__ __forceinline__ void ladder_scatter_pm_kernel_body(const uint3 BID, c
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const double* rp = Rp + ij * ldp;
   const double* rm = (i > j) ? Rm + (i * (i - 1) / 2 + j) * ldm : nullptr;
-  const double* hp = Hp ? Hp + ij * ldp : nullptr;
-  const double* hm = (Hm && i > j) ? Hm + (i * (i - 1) / 2 + j) * ldm : nullptr;
+  const double* hp = Hp ? Hp + ij * ldhp : nullptr;
+  const double* hm = (Hm && i > j) ? Hm + (i * (i - 1) / 2 + j) * ldhm : nullptr;
   double* tij = t2 + (i * o + j) * v * v;
   double* tji = t2 + (j * o + i) * v * v;
 #pragma unroll
@@ -1496,9 +1601,9 @@ __device__ __forceinline__ void ladder_scatter_pm_kernel_body(const uint3 BID, c
     const long long a = ta * 32 + aa, b = tb * 32 + tx;
     double p = 0.0, m = 0.0;
     if (a < v && b <= a) {
-      p = rp[a * (a + 1) / 2 + b];
+      p = slab_sum(rp + a * (a + 1) / 2 + b, Sp, strideP);       // (split-K slabs: the sum the reduction pass would have formed)
       if (hp) p += (a == b ? 2.0 : 1.0) * hp[a * (a + 1) / 2 + b];
-      if (rm && b < a) { m = rm[a * (a - 1) / 2 + b]; if (hm) m += hm[a * (a - 1) / 2 + b]; }
+      if (rm && b < a) { m = slab_sum(rm + a * (a - 1) / 2 + b, Sm, strideM); if (hm) m += hm[a * (a - 1) / 2 + b]; }
     }
     sp[aa][tx] = p; sm[aa][tx] = m;
   }
@@ -1526,25 +1631,27 @@ __device__ __forceinline__ void ladder_scatter_pm_kernel_body(const uint3 BID, c
 }
 __global__ void __launch_bounds__(256) ladder_scatter_pm_kernel(long long o, long long v, const double* __restrict__ Rp, long long ldp,
                                                                const double* __restrict__ Rm, long long ldm, double* __restrict__ t2,
-                                                               const double* __restrict__ Hp, const double* __restrict__ Hm, int assign) { ladder_scatter_pm_kernel_body(make_uint3(blockIdx.x, blockIdx.y, blockIdx.z), make_uint3(gridDim.x, gridDim.y, gridDim.z), o, v, Rp, ldp, Rm, ldm, t2, Hp, Hm, assign); }
+                                                               const double* __restrict__ Hp, const double* __restrict__ Hm, int assign,
+                                                               int Sp, long long strideP, int Sm, long long strideM, long long ldhp, long long ldhm) { ladder_scatter_pm_kernel_body(make_uint3(blockIdx.x, blockIdx.y, blockIdx.z), make_uint3(gridDim.x, gridDim.y, gridDim.z), o, v, Rp, ldp, Rm, ldm, t2, Hp, Hm, assign, Sp, strideP, Sm, strideM, ldhp, ldhm); }
 int dev_ladder_scatter_pm2(int64_t o, int64_t v, const double* Rp, int64_t ldp, const double* Rm, int64_t ldm, const double* Hp, const double* Hm,
-                           int assign, double* t2) {
+                           int assign, double* t2, int Sp, int64_t strideP, int Sm, int64_t strideM, int64_t ldhp, int64_t ldhm) {
   REQUIRE_INIT();
   const long long npo = o * (o + 1) / 2;
   if (npo <= 0 || v <= 0) return QEMB_OK;
   if (npo > 65535) { set_error("dev_ladder_scatter_pm: too many pairs"); return QEMB_ERR_ARG; }
   const long long nt = (v + 31) / 32;
   hipLaunchKernelGGL(ladder_scatter_pm_kernel, dim3((unsigned)(nt * (nt + 1) / 2), (unsigned)npo), dim3(256), 0, g_stream, (long long)o, (long long)v, Rp, (long long)ldp, Rm, (long long)ldm, t2,
-                     Hp, Hm, assign);
+                     Hp, Hm, assign, std::max(Sp, 1), (long long)strideP, std::max(Sm, 1), (long long)strideM, (long long)(ldhp ? ldhp : ldp), (long long)(ldhm ? ldhm : ldm));
   HIP_TRY(hipGetLastError());
   return QEMB_OK;
 }
 int dev_ladder_scatter_pm(int64_t o, int64_t v, const double* Rp, int64_t ldp, const double* Rm, int64_t ldm, double* t2) {
   return dev_ladder_scatter_pm2(o, v, Rp, ldp, Rm, ldm, nullptr, nullptr, 0, t2);
 }
-// one thread per (P(ij), P(kl)) / (Q(ij), Q(kl)) entry of the packed images of W[k,l,i,j]
-__device__ __forceinline__ void pack_w_pm_kernel_body(const uint3 BID, const uint3 GDIM, long long o, const double* __restrict__ W, double* __restrict__ Ap, long long lda_p,
-                                                        double* __restrict__ Am, long long lda_m) {
+// one thread per (P(ij), P(kl)) / (Q(ij), Q(kl)) entry of the packed images of W[k,l,i,j]; W(k,l,i,j) is a functor: a stored tensor (pack_w_pm) or the
+// four-term sum that IS the Woooo intermediate (pack_w_pm_sum: oooo_p[k,l,i,j] + X[i,j,k,l] + O1[l,j,k,i] + O1[k,i,l,j], added in that order)
+template <class WF>
+__device__ __forceinline__ void pack_w_pm_any(const uint3 BID, long long o, WF W, double* __restrict__ Ap, long long lda_p, double* __restrict__ Am, long long lda_m) {
   const long long npo = o * (o + 1) / 2, nmo = o * (o - 1) / 2;
   const long long t = (long long)BID.x * blockDim.x + threadIdx.x;
   if (t < npo * lda_p) {
@@ -1552,8 +1659,8 @@ __device__ __forceinline__ void pack_w_pm_kernel_body(const uint3 BID, const uin
     double x = 0.0;
     if (kl < npo) {
       long long i, j, k, l; unpair_ge(ij, i, j); unpair_ge(kl, k, l);
-      const double a = W[((k * o + l) * o + i) * o + j];
-      x = (k == l) ? a : a + W[((k * o + l) * o + j) * o + i];
+      const double a = W(k, l, i, j);
+      x = (k == l) ? a : a + W(k, l, j, i);
     }
     Ap[t] = x;
   }
@@ -1563,13 +1670,26 @@ __device__ __forceinline__ void pack_w_pm_kernel_body(const uint3 BID, const uin
     if (kl < nmo) {
       long long i, j, k, l;           // strictly lower pairs: Q(i,j) = i(i-1)/2 + j, i > j  ==  pair_ge of (i-1, j)
       unpair_ge(ij, i, j); ++i; unpair_ge(kl, k, l); ++k;
-      x = W[((k * o + l) * o + i) * o + j] - W[((k * o + l) * o + j) * o + i];
+      x = W(k, l, i, j) - W(k, l, j, i);
     }
     Am[t] = x;
   }
 }
+__device__ __forceinline__ void pack_w_pm_kernel_body(const uint3 BID, const uint3 GDIM, long long o, const double* __restrict__ W, double* __restrict__ Ap, long long lda_p,
+                                                        double* __restrict__ Am, long long lda_m) {
+  pack_w_pm_any(BID, o, [=](long long k, long long l, long long i, long long j) { return W[((k * o + l) * o + i) * o + j]; }, Ap, lda_p, Am, lda_m);
+}
 __global__ void __launch_bounds__(256) pack_w_pm_kernel(long long o, const double* __restrict__ W, double* __restrict__ Ap, long long lda_p,
                                                         double* __restrict__ Am, long long lda_m) { pack_w_pm_kernel_body(make_uint3(blockIdx.x, blockIdx.y, blockIdx.z), make_uint3(gridDim.x, gridDim.y, gridDim.z), o, W, Ap, lda_p, Am, lda_m); }
+__device__ __forceinline__ void pack_w_pm_sum_kernel_body(const uint3 BID, const uint3 GDIM, long long o, const double* __restrict__ Wp, const double* __restrict__ X, const double* __restrict__ O1,
+                                                            double* __restrict__ Ap, long long lda_p, double* __restrict__ Am, long long lda_m) {
+  pack_w_pm_any(BID, o, [=](long long k, long long l, long long i, long long j) {
+    return ((Wp[((k * o + l) * o + i) * o + j] + X[((i * o + j) * o + k) * o + l]) + O1[((l * o + j) * o + k) * o + i]) + O1[((k * o + i) * o + l) * o + j]; }, Ap, lda_p, Am, lda_m);
+}
+__global__ void __launch_bounds__(256) pack_w_pm_sum_kernel(long long o, const double* __restrict__ Wp, const double* __restrict__ X, const double* __restrict__ O1,
+                                                            double* __restrict__ Ap, long long lda_p, double* __restrict__ Am, long long lda_m) {
+  pack_w_pm_sum_kernel_body(make_uint3(blockIdx.x, blockIdx.y, blockIdx.z), make_uint3(gridDim.x, gridDim.y, gridDim.z), o, Wp, X, O1, Ap, lda_p, Am, lda_m);
+}
 __device__ __forceinline__ void foo_from_x_kernel_body(const uint3 BID, const uint3 GDIM, long long o, const double* __restrict__ X, double* __restrict__ F) {
   const long long t = (long long)BID.x * blockDim.x + threadIdx.x;
   if (t >= o * o) return;
@@ -1583,6 +1703,16 @@ int dev_foo_from_x(int64_t o, const double* X, double* F) {
   REQUIRE_INIT();
   if (o <= 0) return QEMB_OK;
   hipLaunchKernelGGL(foo_from_x_kernel, dim3((unsigned)((o * o + 255) / 256)), dim3(256), 0, g_stream, (long long)o, X, F);
+  HIP_TRY(hipGetLastError());
+  return QEMB_OK;
+}
+int dev_pack_w_pm_sum(int64_t o, const double* Wp, const double* X, const double* O1, double* Ap, int64_t lda_p, double* Am, int64_t lda_m) {
+  REQUIRE_INIT();
+  if (o <= 0) return QEMB_OK;
+  const long long npo = o * (o + 1) / 2, nmo = o * (o - 1) / 2;
+  if (lda_p < npo || (nmo > 0 && lda_m < nmo)) { set_error("dev_pack_w_pm_sum: leading dimension too small"); return QEMB_ERR_ARG; }
+  const long long tot = std::max<long long>(npo * lda_p, nmo * lda_m);
+  hipLaunchKernelGGL(pack_w_pm_sum_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, g_stream, (long long)o, Wp, X, O1, Ap, (long long)lda_p, nmo > 0 ? Am : nullptr, (long long)lda_m);
   HIP_TRY(hipGetLastError());
   return QEMB_OK;
 }
@@ -1686,6 +1816,246 @@ int dev_dot_many(int64_t n, const double* x, int m, const double* const* ys, dou
   HIP_TRY(hipGetLastError());
   return QEMB_OK;
 }
+// ---- single-launch reductions: every workgroup leaves its partial sums, the LAST one to finish (device-scope counter) adds them up in the
+// fixed order of the two-stage reductions above and writes the result to device memory and to a pinned host word -- no second kernel, no copy
+// node.  The counter lives behind the context's partials and is left at zero.
+// finish: 2 = thread 0 alone fences (it is the only writer of the partials; its acquire fence empties the caches the whole workgroup reads through),
+// 0 = do not finish here (a second small kernel does, QEMB_POST_FINISH=0).  (Every THREAD fencing, the textbook form, costs ~90 us per launch
+// here -- each fence is an L2 write-back -- and made the fused launches slower than the five they replace.)
+__device__ __forceinline__ bool last_workgroup(unsigned* counter, unsigned total, int finish) {
+  __shared__ unsigned ticket;
+  if (finish == 0) return false;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();                                 // this workgroup's partials are visible device wide before its ticket is
+    ticket = atomicAdd(counter, 1u);
+    if (ticket == total - 1) __threadfence();        // ... and the last one sees everybody's
+  }
+  __syncthreads();
+  return ticket == total - 1;
+}
+__device__ __forceinline__ void publish_flag(unsigned long long* flag_host, unsigned long long seq) {   // one thread, after its result stores
+  if (!flag_host) return;
+  __threadfence_system();
+  __hip_atomic_store(flag_host, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+static int post_finish_mode() {
+  static const int m = [] { const char* e = std::getenv("QEMB_POST_FINISH"); return (e && e[0] == '2') ? 2 : 0; }();
+  return m;
+}
+// second kernel of the QEMB_POST_FINISH=0 form: out[j] = sum of the np partials of reduction j, j < m, to device and pinned host memory
+__global__ void __launch_bounds__(256) finish_partials_kernel(int m, int np, const double* __restrict__ partial, double* out_dev, double* out_host,
+                                                              unsigned long long* flag_host, unsigned long long seq) {
+  __shared__ double sh[4];
+  double acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {        // the loads of all m reductions are in flight together; same order of additions as one after the other
+    acc[j] = 0.0;
+    if (j < m) for (int i = threadIdx.x; i < np; i += blockDim.x) acc[j] += partial[(long long)j * np + i];
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    if (j >= m) break;
+    const double r = block_reduce<false>(acc[j], sh);
+    if (threadIdx.x == 0) { out_dev[j] = r; out_host[j] = r; }
+  }
+  if (threadIdx.x == 0) publish_flag(flag_host, seq);
+}
+int dev_wait_flag(const void* flag_host, unsigned long long seq) {
+  REQUIRE_INIT();
+  const unsigned long long* p = (const unsigned long long*)flag_host;
+  for (unsigned long spins = 1;; ++spins) {
+    if (__atomic_load_n(p, __ATOMIC_ACQUIRE) == seq) return QEMB_OK;
+    if ((spins & 0xffff) == 0) {       // now and then: has the stream drained (or failed) without the word arriving?
+      const hipError_t q = hipStreamQuery(g_stream);
+      if (q == hipSuccess) {
+        if (__atomic_load_n(p, __ATOMIC_ACQUIRE) == seq) return QEMB_OK;
+        set_error("dev_wait_flag: the stream has drained and the awaited word was never written");
+        return QEMB_ERR_DEVICE;
+      }
+      if (q != hipErrorNotReady) HIP_TRY(q);
+    }
+    __builtin_ia32_pause();
+  }
+}
+struct DiisPushK { const double* y[8]; int m, self; };
+// VEC2: two consecutive elements per thread and step through 16-byte accesses (n even, every vector 16-byte aligned).  All loads of a step are issued
+// before its stores: the vectors may alias each other (xcopy == prev in the first iteration), so a load written after a store would wait for it -- and
+// with it for the loads that fed the store: two dependent round trips to HBM per step instead of one.
+template <bool VEC2>
+__device__ __forceinline__ void diis_push_kernel_body(const uint3 BID, const uint3 GDIM, long long n, const double* trial, const double* prev, double* e, double* xcopy,
+                                                        DiisPushK k, double* partial, unsigned* counter, double* row_dev, double* row_host, int finish,
+                                                        unsigned long long* flag_host, unsigned long long seq) {
+  __shared__ double sh[4];
+  const int np = (int)GDIM.x;
+  constexpr int W = VEC2 ? 2 : 1;
+  double acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.0;
+  const long long nw = n / W;
+  for (long long i = (long long)BID.x * blockDim.x + threadIdx.x; i < nw; i += (long long)np * blockDim.x) {
+    double t[W], p[W], y[8][W];
+    if (VEC2) {
+      const double2 tt = reinterpret_cast<const double2*>(trial)[i], pp = reinterpret_cast<const double2*>(prev)[i];
+      t[0] = tt.x; t[W - 1] = tt.y; p[0] = pp.x; p[W - 1] = pp.y;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { y[j][0] = 0.0; y[j][W - 1] = 0.0; if (j < k.m && j != k.self) { const double2 yy = reinterpret_cast<const double2*>(k.y[j])[i]; y[j][0] = yy.x; y[j][W - 1] = yy.y; } }
+    } else {
+      t[0] = trial[i]; p[0] = prev[i];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { y[j][0] = 0.0; if (j < k.m && j != k.self) y[j][0] = k.y[j][i]; }
+    }
+    double ei[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) ei[w] = t[w] - p[w];
+    if (VEC2) {
+      reinterpret_cast<double2*>(e)[i] = make_double2(ei[0], ei[W - 1]);
+      if (xcopy) reinterpret_cast<double2*>(xcopy)[i] = make_double2(t[0], t[W - 1]);
+    } else {
+      e[i] = ei[0];
+      if (xcopy) xcopy[i] = t[0];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) if (j < k.m) {
+#pragma unroll
+      for (int w = 0; w < W; ++w) acc[j] += ei[w] * (j == k.self ? ei[w] : y[j][w]);
+    }
+  }
+  for (int j = 0; j < k.m; ++j) {
+    const double r = block_reduce<false>(acc[j], sh);
+    if (threadIdx.x == 0) partial[(long long)j * np + BID.x] = r;
+    __syncthreads();
+  }
+  if (!last_workgroup(counter, (unsigned)np, finish)) return;
+  for (int j = 0; j < k.m; ++j) {
+    double a = 0.0;
+    for (int i = threadIdx.x; i < np; i += blockDim.x) a += __builtin_nontemporal_load(partial + (long long)j * np + i);
+    const double r = block_reduce<false>(a, sh);
+    if (threadIdx.x == 0) { row_dev[j] = r; row_host[j] = r; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { *counter = 0u; publish_flag(flag_host, seq); }
+}
+template <bool VEC2>
+__global__ void __launch_bounds__(256) diis_push_kernel(long long n, const double* trial, const double* prev, double* e, double* xcopy, DiisPushK k, double* partial,
+                                                        unsigned* counter, double* row_dev, double* row_host, int finish, unsigned long long* flag_host, unsigned long long seq) {
+  diis_push_kernel_body<VEC2>(make_uint3(blockIdx.x, blockIdx.y, blockIdx.z), make_uint3(gridDim.x, gridDim.y, gridDim.z), n, trial, prev, e, xcopy, k, partial, counter, row_dev, row_host, finish, flag_host, seq);
+}
+int dev_diis_push(int64_t n, const double* trial, const double* prev, double* e, double* xcopy, int m, const double* const* ys, int self,
+                  double* row_dev, double* row_host, void* flag_host, unsigned long long seq) {
+  REQUIRE_INIT();
+  if (m <= 0 || m > 8 || self < 0 || self >= m) { set_error("dev_diis_push: 1 <= m <= 8 vectors, 0 <= self < m"); return QEMB_ERR_ARG; }
+  DiisPushK k{};
+  k.m = m; k.self = self;
+  bool vec2 = (n % 2 == 0);
+  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  vec2 = vec2 && al16(trial) && al16(prev) && al16(e) && (!xcopy || al16(xcopy));
+  for (int j = 0; j < m; ++j) { k.y[j] = ys[j]; vec2 = vec2 && al16(ys[j]); }
+  const int64_t nw = vec2 ? n / 2 : n;
+  const int np = (int)std::max<int64_t>(1, std::min<int64_t>((nw + 1023) / 1024, NPART));
+  if (vec2) hipLaunchKernelGGL(diis_push_kernel<true>, dim3(np), dim3(256), 0, g_stream, (long long)n, trial, prev, e, xcopy, k, g_partials, (unsigned*)(g_partials + 8 * NPART), row_dev, row_host, post_finish_mode(),
+                               (unsigned long long*)flag_host, seq);
+  else hipLaunchKernelGGL(diis_push_kernel<false>, dim3(np), dim3(256), 0, g_stream, (long long)n, trial, prev, e, xcopy, k, g_partials, (unsigned*)(g_partials + 8 * NPART), row_dev, row_host, post_finish_mode(),
+                          (unsigned long long*)flag_host, seq);
+  if (post_finish_mode() == 0) hipLaunchKernelGGL(finish_partials_kernel, dim3(1), dim3(256), 0, g_stream, m, np, (const double*)g_partials, row_dev, row_host, (unsigned long long*)flag_host, seq);
+  HIP_TRY(hipGetLastError());
+  return QEMB_OK;
+}
+struct ExtrapK { const double* x[8]; double c[8]; int n, write_amp; };
+// grid (o * o tiles (i,j), chunks of `rows` rows a): the workgroup forms the new t1[i, its rows] and t1[j, :] in LDS, then streams its rows of the tile --
+// every load of a step before the stores (amp may be x[0]), 16-byte accesses when v is even
+template <bool VEC2>
+__device__ __forceinline__ void ccsd_extrapolate_energy_kernel_body(const uint3 BID, const uint3 GDIM, int o, int v, int rows, ExtrapK k, double* amp, const double* __restrict__ L,
+                                                                      double* __restrict__ tau, double* partial, unsigned* counter, double* e_dev, double* e_host, int finish,
+                                                                      unsigned long long* flag_host, unsigned long long seq) {
+  extern __shared__ double t1rows[];                 // the new t1[i, a0 .. a1) and t1[j, :]
+  __shared__ double sh[4];
+  constexpr int W = VEC2 ? 2 : 1;
+  const int i = (int)BID.x / o, j = (int)BID.x - i * o;
+  const int a0 = (int)BID.y * rows, a1 = min(v, a0 + rows);
+  double* ti = t1rows;
+  double* tj = t1rows + rows;
+  for (int a = threadIdx.x; a < v + (a1 - a0); a += blockDim.x) {
+    const bool is_j = a < v;
+    const long long src = is_j ? (long long)j * v + a : (long long)i * v + a0 + (a - v);
+    double sacc = 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) if (q < k.n) sacc += k.c[q] * k.x[q][src];
+    if (is_j) { tj[a] = sacc; if (k.write_amp && i == 0 && BID.y == 0) amp[src] = sacc; }     // the (0, j) tiles' first chunks store the new t1[j, :]
+    else ti[a - v] = sacc;
+  }
+  __syncthreads();
+  const long long vv = (long long)v * v, off = (long long)BID.x * vv, nov = (long long)o * v;
+  const int vw = v / W;
+  double acc = 0.0;
+  for (int t = threadIdx.x; t < (a1 - a0) * vw; t += blockDim.x) {
+    const int ar = t / vw, bw = t - ar * vw;
+    const long long pos = off + (long long)(a0 + ar) * v + (long long)bw * W;
+    double xv[8][W], lv[W];
+    if (VEC2) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) if (q < k.n) { const double2 xx = *reinterpret_cast<const double2*>(k.x[q] + nov + pos); xv[q][0] = xx.x; xv[q][W - 1] = xx.y; }
+      const double2 ll = *reinterpret_cast<const double2*>(L + pos); lv[0] = ll.x; lv[W - 1] = ll.y;
+    } else {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) if (q < k.n) xv[q][0] = k.x[q][nov + pos];
+      lv[0] = L[pos];
+    }
+    double val[W], tv[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+      val[w] = 0.0;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) if (q < k.n) val[w] += k.c[q] * xv[q][w];
+      tv[w] = val[w] + ti[ar] * tj[bw * W + w];
+      acc += lv[w] * tv[w];
+    }
+    if (VEC2) {
+      if (k.write_amp) *reinterpret_cast<double2*>(amp + nov + pos) = make_double2(val[0], val[W - 1]);
+      *reinterpret_cast<double2*>(tau + pos) = make_double2(tv[0], tv[W - 1]);
+    } else {
+      if (k.write_amp) amp[nov + pos] = val[0];
+      tau[pos] = tv[0];
+    }
+  }
+  const unsigned np = GDIM.x * GDIM.y, me = BID.y * GDIM.x + BID.x;
+  const double r = block_reduce<false>(acc, sh);
+  if (threadIdx.x == 0) partial[me] = r;
+  if (!last_workgroup(counter, np, finish)) return;
+  double a = 0.0;
+  for (unsigned q = threadIdx.x; q < np; q += blockDim.x) a += __builtin_nontemporal_load(partial + q);
+  const double e = block_reduce<false>(a, sh);
+  if (threadIdx.x == 0) { e_dev[0] = e; e_host[0] = e; *counter = 0u; publish_flag(flag_host, seq); }
+}
+template <bool VEC2>
+__global__ void __launch_bounds__(256) ccsd_extrapolate_energy_kernel(int o, int v, int rows, ExtrapK k, double* amp, const double* __restrict__ L, double* __restrict__ tau,
+                                                                      double* partial, unsigned* counter, double* e_dev, double* e_host, int finish, unsigned long long* flag_host, unsigned long long seq) {
+  ccsd_extrapolate_energy_kernel_body<VEC2>(make_uint3(blockIdx.x, blockIdx.y, blockIdx.z), make_uint3(gridDim.x, gridDim.y, gridDim.z), o, v, rows, k, amp, L, tau, partial, counter, e_dev, e_host, finish, flag_host, seq);
+}
+int dev_ccsd_extrapolate_energy(int64_t o, int64_t v, int nterms, const double* coef, const double* const* xs, double* amp, const double* L,
+                                double* tau, double* e_dev, double* e_host, void* flag_host, unsigned long long seq) {
+  REQUIRE_INIT();
+  if (nterms <= 0 || nterms > 8 || o <= 0 || v <= 0 || o * o > 8 * NPART || v > 4096) { set_error("dev_ccsd_extrapolate_energy: 1 <= nterms <= 8, o^2 <= 16384, v <= 4096"); return QEMB_ERR_ARG; }
+  ExtrapK k{};
+  k.n = nterms;
+  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  bool vec2 = (v % 2 == 0) && ((o * v) % 2 == 0) && al16(amp) && al16(L) && al16(tau);
+  for (int q = 0; q < nterms; ++q) { k.x[q] = xs[q]; k.c[q] = coef[q]; vec2 = vec2 && al16(xs[q]); }
+  k.write_amp = !(nterms == 1 && xs[0] == amp && coef[0] == 1.0);
+  // (i,j) tiles of v x v, cut into row chunks of ~4000 elements while the partials fit: several thousand workgroups balance over the 256 CUs, and the
+  // t1 rows every workgroup forms first (v + rows values) stay a few per cent of what it streams
+  int64_t chunks = std::max<int64_t>(1, std::min<int64_t>({(v * v + 3999) / 4000, (int64_t)(8 * NPART) / (o * o), v}));
+  const int rows = (int)((v + chunks - 1) / chunks);
+  chunks = (v + rows - 1) / rows;
+  const size_t lds = (size_t)(v + rows) * sizeof(double);
+  if (vec2) hipLaunchKernelGGL(ccsd_extrapolate_energy_kernel<true>, dim3((unsigned)(o * o), (unsigned)chunks), dim3(256), lds, g_stream, (int)o, (int)v, rows, k, amp, L, tau,
+                               g_partials, (unsigned*)(g_partials + 8 * NPART), e_dev, e_host, post_finish_mode(), (unsigned long long*)flag_host, seq);
+  else hipLaunchKernelGGL(ccsd_extrapolate_energy_kernel<false>, dim3((unsigned)(o * o), (unsigned)chunks), dim3(256), lds, g_stream, (int)o, (int)v, rows, k, amp, L, tau,
+                          g_partials, (unsigned*)(g_partials + 8 * NPART), e_dev, e_host, post_finish_mode(), (unsigned long long*)flag_host, seq);
+  if (post_finish_mode() == 0) hipLaunchKernelGGL(finish_partials_kernel, dim3(1), dim3(256), 0, g_stream, 1, (int)(o * o * chunks), (const double*)g_partials, e_dev, e_host, (unsigned long long*)flag_host, seq);
+  HIP_TRY(hipGetLastError());
+  return QEMB_OK;
+}
 int dev_absmax(int64_t n, const double* x, double* out_dev) {
   REQUIRE_INIT();
   const int np = (int)std::max<int64_t>(1, std::min<int64_t>((n + 1023) / 1024, NPART));
@@ -1720,6 +2090,66 @@ int dev_gemv_rows(int64_t rows, int64_t cols, const double* T, int64_t ldt, cons
   return QEMB_OK;
 }
 
+// two matrix-vector products into one result, one pass: y[r] = alpha (T1[r,:] . x1 + T2[r,:] . x2) + beta y[r]
+__device__ __forceinline__ void gemv_rows2_kernel_body(const uint3 BID, const uint3 GDIM, long long rows, long long cols, const double* T1, long long ld1, const double* x1,
+                                                         const double* T2, long long ld2, const double* x2, double* y, double alpha, double beta) {
+  __shared__ double sh[4];
+  for (long long r = BID.x; r < rows; r += GDIM.x) {
+    const double* r1 = T1 + r * ld1;
+    const double* r2 = T2 + r * ld2;
+    double a1 = 0.0, a2 = 0.0;
+    for (long long c = threadIdx.x; c < cols; c += blockDim.x) { a1 += r1[c] * x1[c]; a2 += r2[c] * x2[c]; }
+    const double s = block_reduce<false>(a1 + a2, sh);
+    if (threadIdx.x == 0) y[r] = (beta != 0.0) ? alpha * s + beta * y[r] : alpha * s;
+  }
+}
+__global__ void __launch_bounds__(256) gemv_rows2_kernel(long long rows, long long cols, const double* T1, long long ld1, const double* x1, const double* T2, long long ld2, const double* x2,
+                                                         double* y, double alpha, double beta) {
+  gemv_rows2_kernel_body(make_uint3(blockIdx.x, blockIdx.y, blockIdx.z), make_uint3(gridDim.x, gridDim.y, gridDim.z), rows, cols, T1, ld1, x1, T2, ld2, x2, y, alpha, beta);
+}
+int dev_gemv_rows2(int64_t rows, int64_t cols, const double* T1, int64_t ld1, const double* x1, const double* T2, int64_t ld2, const double* x2, double* y, double alpha, double beta) {
+  REQUIRE_INIT();
+  if (rows <= 0) return QEMB_OK;
+  const unsigned grid = (unsigned)std::min<int64_t>(rows, 1 << 20);
+  hipLaunchKernelGGL(gemv_rows2_kernel, dim3(grid), dim3(256), 0, g_stream, (long long)rows, (long long)cols, T1, (long long)ld1, x1, T2, (long long)ld2, x2, y, alpha, beta);
+  HIP_TRY(hipGetLastError());
+  return QEMB_OK;
+}
+// The four small products of the T1 equation in one launch.  grid (o, chunks of 64 rows a): every workgroup forms Q[i,:] for its i (o dot products over v),
+// then one wave per row a:  t1n[i,a] = sum_c t1[i,c] Lvv[a,c] + sum_k (Q[i,k] - Loo[k,i]) t1[k,a]
+__device__ __forceinline__ void ccsd_t1_small_kernel_body(const uint3 BID, const uint3 GDIM, int o, int v, const double* __restrict__ t1, const double* __restrict__ Lvv,
+                                                            const double* __restrict__ Loo, const double* __restrict__ Fov, double* __restrict__ t1n) {
+  __shared__ double w[1024];              // Q[i,k] - Loo[k,i], k < o <= 1024
+  const int i = (int)BID.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const double* ti = t1 + (long long)i * v;
+  for (int k = wave; k < o; k += nw) {
+    double acc = 0.0;
+    for (int c = lane; c < v; c += 64) acc += ti[c] * Fov[(long long)k * v + c];
+    acc = wave_sum(acc);
+    if (lane == 0) w[k] = acc - Loo[(long long)k * o + i];
+  }
+  __syncthreads();
+  const int a1 = min(v, ((int)BID.y + 1) * 64);
+  for (int a = (int)BID.y * 64 + wave; a < a1; a += nw) {
+    double acc = 0.0;
+    for (int c = lane; c < v; c += 64) acc += ti[c] * Lvv[(long long)a * v + c];
+    for (int k = lane; k < o; k += 64) acc += w[k] * t1[(long long)k * v + a];
+    acc = wave_sum(acc);
+    if (lane == 0) t1n[(long long)i * v + a] = acc;
+  }
+}
+__global__ void __launch_bounds__(256) ccsd_t1_small_kernel(int o, int v, const double* __restrict__ t1, const double* __restrict__ Lvv, const double* __restrict__ Loo,
+                                                            const double* __restrict__ Fov, double* __restrict__ t1n) {
+  ccsd_t1_small_kernel_body(make_uint3(blockIdx.x, blockIdx.y, blockIdx.z), make_uint3(gridDim.x, gridDim.y, gridDim.z), o, v, t1, Lvv, Loo, Fov, t1n);
+}
+int dev_ccsd_t1_small(int64_t o, int64_t v, const double* t1, const double* Lvv, const double* Loo, const double* Fov, double* t1n) {
+  REQUIRE_INIT();
+  if (o <= 0 || v <= 0) return QEMB_OK;
+  if (o > 1024 || (v + 63) / 64 > 65535) { set_error("dev_ccsd_t1_small: n_occ <= 1024"); return QEMB_ERR_ARG; }
+  hipLaunchKernelGGL(ccsd_t1_small_kernel, dim3((unsigned)o, (unsigned)((v + 63) / 64)), dim3(256), 0, g_stream, (int)o, (int)v, t1, Lvv, Loo, Fov, t1n);
+  HIP_TRY(hipGetLastError());
+  return QEMB_OK;
+}
 __global__ void __launch_bounds__(256) gemv_rows_batched_kernel(long long rows, long long cols, long long nbatch, const double* __restrict__ T,
                                                                long long ldt, long long strideT, const double* __restrict__ x, long long stridex,
                                                                double* __restrict__ y, double alpha, double beta) {
@@ -2292,14 +2722,18 @@ static void register_groupable_kernels() {
   register_groupable<ccsd_ph_layouts_kernel_body, 256, long long, long long, const double*, const double*, double*, double*, double*, double*, double*, double*, int>((const void*)ccsd_ph_layouts_kernel);
   register_groupable<small_k_update_kernel_body, 256, long long, long long, long long, double, const double*, long long, const double*, long long, double*, long long, int>((const void*)small_k_update_kernel);
   register_groupable<small_k_update_mfma_kernel_body, 256, int, int, int, double, const double*, long long, const double*, long long, double*, long long>((const void*)small_k_update_mfma_kernel);
-  register_groupable<ccsd_y_traces_kernel_body, 256, long long, long long, const double*, const double*, double*>((const void*)ccsd_y_traces_kernel);
+  register_groupable<ccsd_y_traces_kernel_body, 256, long long, long long, const double*, const double*, double*, const double*>((const void*)ccsd_y_traces_kernel);
   register_groupable<lincomb_kernel_body, 256, long long, LincombK, double, double*>((const void*)lincomb_kernel);
   register_groupable<ladder_pack_tau_kernel_body, 256, long long, long long, const double*, double*, long long, double*, long long>((const void*)ladder_pack_tau_kernel);
-  register_groupable<scatter_pm_rows_kernel_body, 256, long long, long long, const double*, const double*, double*>((const void*)scatter_pm_rows_kernel);
+  register_groupable<scatter_pm_rows_kernel_body, 256, long long, long long, const double*, const double*, double*, const double*, int, long long, int, long long>((const void*)scatter_pm_rows_kernel);
   register_groupable<ccsd_finish_t2_kernel_body, 256, long long, long long, double*, const double*, const double*, const double*, const double*>((const void*)ccsd_finish_t2_kernel);
-  register_groupable<ladder_scatter_pm_kernel_body, 256, long long, long long, const double*, long long, const double*, long long, double*, const double*, const double*, int>((const void*)ladder_scatter_pm_kernel);
+  register_groupable<ladder_scatter_pm_kernel_body, 256, long long, long long, const double*, long long, const double*, long long, double*, const double*, const double*, int, int, long long, int, long long, long long, long long>((const void*)ladder_scatter_pm_kernel);
   register_groupable<pack_w_pm_kernel_body, 256, long long, const double*, double*, long long, double*, long long>((const void*)pack_w_pm_kernel);
+  register_groupable<pack_w_pm_sum_kernel_body, 256, long long, const double*, const double*, const double*, double*, long long, double*, long long>((const void*)pack_w_pm_sum_kernel);
   register_groupable<foo_from_x_kernel_body, 256, long long, const double*, double*>((const void*)foo_from_x_kernel);
+  register_groupable<gemv_rows2_kernel_body, 256, long long, long long, const double*, long long, const double*, const double*, long long, const double*, double*, double, double>((const void*)gemv_rows2_kernel);
+  register_groupable<ccsd_t1_small_kernel_body, 256, int, int, const double*, const double*, const double*, const double*, double*>((const void*)ccsd_t1_small_kernel);
+  register_groupable<ccsd_finish_t2_rings_kernel_body, 256, long long, long long, double*, const double*, const double*, const double*, const double*, const double*, const double*, double*>((const void*)ccsd_finish_t2_rings_kernel);
   register_groupable<gemv_rows_kernel_body, 256, long long, long long, const double*, long long, const double*, double*, double, double>((const void*)gemv_rows_kernel);
   register_groupable<contract_mid_stage1_body, 256, long long, long long, int, const double*, const double*, double*>((const void*)contract_mid_stage1);
   register_groupable<contract_mid_stage2_body, 256, long long, long long, int, const double*, double*, long long, double, double>((const void*)contract_mid_stage2);

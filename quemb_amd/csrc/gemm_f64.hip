@@ -573,6 +573,7 @@ static int launch_cfg(const GemmDesc& d, hipStream_t s) {
   // CCSD intermediates contract over o*v^2 ... v^2 indices)
   g.ksplit = 1; g.kchunk = g.K > 0 ? g.K : 1;
   const long long tiles = (long long)g.tiles_m * g.tiles_n * d.batch;
+  if (d.keep_slabs && (d.ksplit <= 1 || d.alpha != 1.0 || d.beta != 0.0 || d.batch != 1)) { set_error("dev_gemm: keep_slabs needs ksplit > 1, alpha = 1, beta = 0, batch = 1"); return QEMB_ERR_ARG; }
   if (d.ksplit > 1) {
     long long chunk = (d.K + d.ksplit - 1) / d.ksplit;
     chunk = (chunk + 31) / 32 * 32;
@@ -588,7 +589,10 @@ static int launch_cfg(const GemmDesc& d, hipStream_t s) {
       if (S > 1 && S * d.batch <= 65535) { g.ksplit = (int)S; g.kchunk = (int)chunk; }
     }
   }
-  if (g.ksplit > 1) {
+  if (d.keep_slabs) {      // the slices' partial products go straight to the caller's slabs (gemm_slab_count(K, ksplit) of them, also when that is one)
+    if (g.ksplit != gemm_slab_count(d.K, d.ksplit)) { set_error("dev_gemm: slab count mismatch"); return QEMB_ERR_ARG; }
+    g.ldc = d.N; g.strideC = d.M * d.N;
+  } else if (g.ksplit > 1) {
     double* ws = gemm_workspace(sizeof(double) * (size_t)d.batch * g.ksplit * d.M * d.N);
     if (!ws) return QEMB_ERR_ALLOC;
     g.C = ws; g.ldc = d.N; g.strideC = d.M * d.N; g.alpha = 1.0; g.beta = 0.0;
@@ -604,7 +608,7 @@ static int launch_cfg(const GemmDesc& d, hipStream_t s) {
   dim3 block(WAVES_M * WAVES_N * 64, 1, 1);
   if (g_gemm_cyc_on && g_gemm_cyc && (long long)grid.x * grid.y * (TAG == 2 ? 72 : 1) <= g_gemm_cyc_cap) { g.cyc = g_gemm_cyc; g_gemm_cyc_blocks = (long long)grid.x * grid.y; if (TAG == 2) g.cyc2 = g_gemm_cyc + (long long)grid.x * grid.y * (WAVES_M * WAVES_N) * 5; }
   hipLaunchKernelGGL(kern, grid, block, lds, s, g);
-  if (g.ksplit > 1) {
+  if (g.ksplit > 1 && !d.keep_slabs) {
     const long long mn = d.M * d.N;
     if (g.ksplit >= 128 && mn <= 65536) {
       const unsigned gx = (unsigned)((mn + 3) / 4 < 4096 ? (mn + 3) / 4 : 4096);      // 4 waves per block, one wave per element

@@ -202,7 +202,8 @@ class DeviceDIIS {
     const int slot = count_ % space_;
     ++count_;
     const int m = size();
-    if (!row_host_) { void* q = nullptr; QTRY(dev_pinned_alloc(&q, sizeof(double) * (space_ + 1))); row_host_ = (double*)q; }
+    QTRY(ensure_row_host());
+    flagged_ = false;
     // refresh row/column `slot` of the Gram matrix
     for (int j0 = 0; j0 < m; j0 += 8) {   // one pass over the new error vector per eight stored ones
       const int cnt = std::min(8, m - j0);
@@ -214,13 +215,34 @@ class DeviceDIIS {
     pending_slot_ = slot;
     return 0;
   }
-  int gram_finish(double* x, bool x_holds_trial = false, double* err_dot = nullptr) {
+  // The push for error vectors that are DIFFERENCES (e = trial - prev, the CCSD iteration), fused: one launch forms e in the next slot, stores
+  // the trial vector there (unless the producer wrote it in place: trial == next_x()) and sends the new Gram row to pinned host memory.
+  int push_diff_issue(const double* trial, const double* prev) {
+    const int slot = count_ % space_;
+    if (space_ > 8) {
+      QTRY(lincomb2(n_, 1.0, trial, -1.0, prev, es_[slot]));
+      if (trial != xs_[slot].p) QTRY(dcopy(n_, trial, xs_[slot]));
+      return gram_issue();
+    }
+    ++count_;
+    const int m = size();
+    QTRY(ensure_row_host());
+    const double* ps[8];
+    for (int q = 0; q < m; ++q) ps[q] = es_[q].p;
+    QTRY(dev_diis_push(n_, trial, prev, es_[slot], trial == xs_[slot].p ? nullptr : xs_[slot].p, m, ps, slot, scal_.p, row_host_, row_host_ + space_ + 1, ++seq_));
+    pending_slot_ = slot; flagged_ = true;
+    return 0;
+  }
+  // wait for the row of the last push: on the word the fused launch publishes after it (microseconds), else on the stream
+  int wait_row() {
+    if (flagged_) { flagged_ = false; return dev_wait_flag(row_host_ + space_ + 1, seq_); }
+    return dev_sync();
+  }
+  // After a wait: the Gram matrix takes the new row, the small system is solved on the host.  c / xs (room for `space` entries) receive the
+  // terms of x = sum_i c_i x_i; when there is nothing to extrapolate (one vector, singular or non-finite system) that is the trial vector itself.
+  int coefficients(int* nterms, double* c, const double** xs, double* err_dot = nullptr) {
     const int slot = pending_slot_;
-    // every early return below leaves the un-extrapolated trial vector in x
-    struct Fallback {
-      DeviceDIIS* d; double* x; int slot; bool armed;
-      ~Fallback() { if (armed) dcopy(d->n_, d->xs_[slot], x); }
-    } fb{this, x, slot, !x_holds_trial};
+    *nterms = 1; c[0] = 1.0; xs[0] = xs_[slot].p;
     const int m = size();
     const double* row = row_host_;
     for (int j = 0; j < m; ++j) { B_[(size_t)slot * space_ + j] = row[j]; B_[(size_t)j * space_ + slot] = row[j]; }
@@ -237,15 +259,21 @@ class DeviceDIIS {
     rhs[0] = 1.0;
     if (!solve_dense(m + 1, A, rhs)) return 0;   // singular: keep the un-extrapolated vector
     for (int i = 0; i < m; ++i) if (!std::isfinite(rhs[i + 1])) return 0;
-    for (int i0 = 0; i0 < m; i0 += 8) {   // x = sum_i c_i x_i in one pass per eight vectors
-      const int cnt = std::min(8, m - i0);
-      double c[8]; const double* ps[8];
-      for (int q = 0; q < cnt; ++q) { c[q] = rhs[i0 + q + 1]; ps[q] = xs_[i0 + q].p; }
-      QTRY(dev_lincomb(n_, cnt, c, ps, i0 == 0 ? 0.0 : 1.0, x));
-    }
-    fb.armed = false;
+    *nterms = m;
+    for (int i = 0; i < m; ++i) { c[i] = rhs[i + 1]; xs[i] = xs_[i].p; }
     return 0;
   }
+  int gram_finish(double* x, bool x_holds_trial = false, double* err_dot = nullptr) {
+    std::vector<double> c((size_t)space_);
+    std::vector<const double*> ps((size_t)space_);
+    int m = 0;
+    QTRY(coefficients(&m, c.data(), ps.data(), err_dot));
+    if (m == 1) return x_holds_trial ? 0 : dcopy(n_, ps[0], x);        // nothing to extrapolate: the trial vector
+    for (int i0 = 0; i0 < m; i0 += 8)     // x = sum_i c_i x_i in one pass per eight vectors
+      QTRY(dev_lincomb(n_, std::min(8, m - i0), c.data() + i0, ps.data() + i0, i0 == 0 ? 0.0 : 1.0, x));
+    return 0;
+  }
+  int space() const { return space_; }
   void reset() { count_ = 0; }
 
  private:
@@ -253,12 +281,23 @@ class DeviceDIIS {
   std::vector<DBuf> xs_, es_;
   DBuf scal_;
   std::vector<double> B_;
-  double* row_host_ = nullptr;      // pinned: the Gram row on its way back (gram_issue -> gram_finish)
+  double* row_host_ = nullptr;      // pinned: the Gram row on its way back (gram_issue -> gram_finish), space + 1 doubles, then the word the fused push publishes
+  unsigned long long seq_ = 0;      // ... its expected value (the block is zeroed when it is taken: recycled pinned blocks carry old words)
+  bool flagged_ = false;
   int pending_slot_ = 0;
+  int ensure_row_host() {
+    if (row_host_) return 0;
+    void* q = nullptr;
+    QTRY(dev_pinned_alloc(&q, sizeof(double) * (space_ + 2)));
+    row_host_ = (double*)q;
+    for (int i = 0; i < space_ + 2; ++i) row_host_[i] = 0.0;
+    seq_ = 0;
+    return 0;
+  }
  public:
   ~DeviceDIIS() { if (row_host_) dev_pinned_free(row_host_); }
   DeviceDIIS(DeviceDIIS&& o) noexcept : space_(o.space_), n_(o.n_), count_(o.count_), xs_(std::move(o.xs_)), es_(std::move(o.es_)), scal_(std::move(o.scal_)),
-                                        B_(std::move(o.B_)), row_host_(o.row_host_), pending_slot_(o.pending_slot_) { o.row_host_ = nullptr; }
+                                        B_(std::move(o.B_)), row_host_(o.row_host_), seq_(o.seq_), flagged_(o.flagged_), pending_slot_(o.pending_slot_) { o.row_host_ = nullptr; }
   DeviceDIIS(const DeviceDIIS&) = delete;
   DeviceDIIS& operator=(const DeviceDIIS&) = delete;
   DeviceDIIS& operator=(DeviceDIIS&&) = delete;

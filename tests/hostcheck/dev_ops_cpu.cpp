@@ -59,7 +59,14 @@ int dev_timer_reset(int s) { g_tot[s] = 0; g_cnt[s] = 0; return 0; }
 int dev_timer_live_events(int) { return 0; }
 
 int dev_gemm_probe(const GemmDesc&, double*, double*, long long*) { set_error("dev_gemm_probe: not available in the hostcheck build"); return QEMB_ERR_DEVICE; }
-int dev_gemm(const GemmDesc& g) {
+int dev_gemm(const GemmDesc& g0) {
+  GemmDesc g = g0;
+  if (g.keep_slabs) {      // slab form: the first slab receives the whole product, the others zeros (their sum is what the consumer forms)
+    if (g.ksplit <= 1 || g.alpha != 1.0 || g.beta != 0.0 || g.batch != 1) { set_error("dev_gemm: keep_slabs needs ksplit > 1, alpha = 1, beta = 0, batch = 1"); return QEMB_ERR_ARG; }
+    const int S = gemm_slab_count(g.K, g.ksplit);
+    std::fill(g.C + g.M * g.N, g.C + (int64_t)S * g.M * g.N, 0.0);
+    g.ldc = g.N;
+  }
   for (int64_t b = 0; b < g.batch; ++b) {
     const double* A = g.A + b * g.strideA; const double* B = g.B + b * g.strideB; double* C = g.C + b * g.strideC;
     // pack to contiguous row-major A(MxK), B(KxN) for a cache-friendly triple loop
@@ -81,7 +88,9 @@ int dev_copy4(const Copy4Desc& c) {
     const double v = c.alpha * c.in[i0 * c.si[0] + i1 * c.si[1] + i2 * c.si[2] + i3 * c.si[3]];
     const int64_t off = i0 * c.so[0] + i1 * c.so[1] + i2 * c.so[2] + i3 * c.so[3];
     const double* base = c.base ? c.base : c.out;
-    c.out[off] = (c.beta != 0.0) ? v + c.beta * base[off] : v;
+    const double w = (c.beta != 0.0) ? v + c.beta * base[off] : v;
+    c.out[off] = w;
+    if (c.out2) c.out2[off] = c.c2a * c.in2[off] + c.c2b * w;
   }
   return 0;
 }
@@ -195,11 +204,13 @@ int dev_pack_pm_cols(int64_t rows, int64_t v, const double* in, double* Op, int6
   }
   return 0;
 }
-int dev_scatter_pm_rows(int64_t o, int64_t ncols, const double* Xp, const double* Xm, double* out) {
+int dev_scatter_pm_rows(int64_t o, int64_t ncols, const double* Xp, const double* Xm, double* out, const double* add, int Sp, int64_t strideP, int Sm, int64_t strideM) {
   for (int64_t i = 0; i < o; ++i) for (int64_t j = 0; j <= i; ++j) for (int64_t c = 0; c < ncols; ++c) {
-    const double p = Xp[(i * (i + 1) / 2 + j) * ncols + c];
-    if (i > j) { const double m = Xm[(i * (i - 1) / 2 + j) * ncols + c]; out[(i * o + j) * ncols + c] = p + m; out[(j * o + i) * ncols + c] = p - m; }
-    else out[(i * o + j) * ncols + c] = p;
+    double p = 0.0;
+    for (int sl = 0; sl < std::max(Sp, 1); ++sl) p += Xp[sl * strideP + (i * (i + 1) / 2 + j) * ncols + c];
+    const int64_t ij = (i * o + j) * ncols + c, ji = (j * o + i) * ncols + c;
+    if (i > j) { double m = 0.0; for (int sl = 0; sl < std::max(Sm, 1); ++sl) m += Xm[sl * strideM + (i * (i - 1) / 2 + j) * ncols + c]; out[ij] = (add ? add[ij] : 0.0) + (p + m); out[ji] = (add ? add[ji] : 0.0) + (p - m); }
+    else out[ij] = (add ? add[ij] : 0.0) + p;
   }
   return 0;
 }
@@ -217,13 +228,18 @@ int dev_ladder_pack_tau(int64_t o, int64_t v, const double* tau, double* Tp, int
   return 0;
 }
 int dev_ladder_scatter_pm2(int64_t o, int64_t v, const double* Rp, int64_t ldp, const double* Rm, int64_t ldm, const double* Hp, const double* Hm,
-                           int assign, double* t2) {
+                           int assign, double* t2, int Sp, int64_t strideP, int Sm, int64_t strideM, int64_t ldhp, int64_t ldhm) {
   if (assign) std::fill(t2, t2 + o * o * v * v, 0.0);
+  if (!ldhp) ldhp = ldp;
+  if (!ldhm) ldhm = ldm;
   for (int64_t i = 0; i < o; ++i) for (int64_t j = 0; j <= i; ++j) for (int64_t a = 0; a < v; ++a) for (int64_t b = 0; b <= a; ++b) {
-    const int64_t ip = (i * (i + 1) / 2 + j) * ldp + a * (a + 1) / 2 + b, im = (i > j && a > b) ? (i * (i - 1) / 2 + j) * ldm + a * (a - 1) / 2 + b : -1;
-    double p = Rp[ip], m = im >= 0 ? Rm[im] : 0.0;
-    if (Hp) p += (a == b ? 2.0 : 1.0) * Hp[ip];
-    if (Hm && im >= 0) m += Hm[im];
+    const bool has_m = (i > j && a > b);
+    const int64_t cp = a * (a + 1) / 2 + b, cm = a * (a - 1) / 2 + b, rp = i * (i + 1) / 2 + j, rm = i * (i - 1) / 2 + j;
+    double p = 0.0, m = 0.0;
+    for (int sl = 0; sl < std::max(Sp, 1); ++sl) p += Rp[sl * strideP + rp * ldp + cp];
+    if (has_m) for (int sl = 0; sl < std::max(Sm, 1); ++sl) m += Rm[sl * strideM + rm * ldm + cm];
+    if (Hp) p += (a == b ? 2.0 : 1.0) * Hp[rp * ldhp + cp];
+    if (Hm && has_m) m += Hm[rm * ldhm + cm];
     t2[((i * o + j) * v + a) * v + b] += p + m;
     if (a != b) t2[((i * o + j) * v + b) * v + a] += p - m;
     if (i != j) { t2[((j * o + i) * v + a) * v + b] += p - m; if (a != b) t2[((j * o + i) * v + b) * v + a] += p + m; }
@@ -252,6 +268,40 @@ int dev_pack_w_pm(int64_t o, const double* W, double* Ap, int64_t lda_p, double*
   }
   return 0;
 }
+int dev_pack_w_pm_sum(int64_t o, const double* Wp, const double* X, const double* O1, double* Ap, int64_t lda_p, double* Am, int64_t lda_m) {
+  std::vector<double> W((size_t)(o * o * o * o));
+  for (int64_t k = 0; k < o; ++k) for (int64_t l = 0; l < o; ++l) for (int64_t i = 0; i < o; ++i) for (int64_t j = 0; j < o; ++j)
+    W[(size_t)(((k * o + l) * o + i) * o + j)] = ((Wp[((k * o + l) * o + i) * o + j] + X[((i * o + j) * o + k) * o + l]) + O1[((l * o + j) * o + k) * o + i]) + O1[((k * o + i) * o + l) * o + j];
+  return dev_pack_w_pm(o, W.data(), Ap, lda_p, Am, lda_m);
+}
+int dev_ccsd_t1_small(int64_t o, int64_t v, const double* t1, const double* Lvv, const double* Loo, const double* Fov, double* t1n) {
+  for (int64_t i = 0; i < o; ++i) {
+    std::vector<double> w((size_t)o);
+    for (int64_t k = 0; k < o; ++k) { double q = 0; for (int64_t c = 0; c < v; ++c) q += t1[i * v + c] * Fov[k * v + c]; w[(size_t)k] = q - Loo[k * o + i]; }
+    for (int64_t a = 0; a < v; ++a) {
+      double s = 0;
+      for (int64_t c = 0; c < v; ++c) s += t1[i * v + c] * Lvv[a * v + c];
+      for (int64_t k = 0; k < o; ++k) s += w[(size_t)k] * t1[k * v + a];
+      t1n[i * v + a] = s;
+    }
+  }
+  return 0;
+}
+int dev_ccsd_finish_t2_rings(int64_t o, int64_t v, double* t2n, const double* U, const double* OV, const double* RS, const double* M, const double* eo, const double* ev, double* t1n) {
+  const int64_t ov = o * v;
+  auto F = [&](int64_t i, int64_t j, int64_t a, int64_t b) {
+    return U[((i * o + j) * v + a) * v + b] + RS[(i * v + a) * ov + j * v + b] - 0.5 * M[(i * v + a) * ov + j * v + b] - M[(i * v + b) * ov + j * v + a];
+  };
+  for (int64_t i = 0; i < o; ++i) for (int64_t j = 0; j <= i; ++j) for (int64_t a = 0; a < v; ++a) for (int64_t b = 0; b < v; ++b) {
+    const int64_t idx = ((i * o + j) * v + a) * v + b;
+    if (i == j && b > a) continue;      // the diagonal pair: each (a,b),(b,a) couple once, from the lower triangle's inputs
+    const double r = (t2n[idx] + OV[idx] + F(i, j, a, b) + F(j, i, b, a)) / (eo[i] + eo[j] - ev[a] - ev[b]);
+    t2n[idx] = r;
+    t2n[((j * o + i) * v + b) * v + a] = r;
+  }
+  if (t1n) for (int64_t t = 0; t < ov; ++t) t1n[t] /= eo[t / v] - ev[t % v];
+  return 0;
+}
 int dev_ccsd_ph_layouts(int64_t o, int64_t v, const double* t2, const double* t1, double* T, double* Tp, double* S, double* Ut, double* Tpt, double* Th) {
   for (int64_t k = 0; k < o; ++k) for (int64_t c = 0; c < v; ++c) for (int64_t j = 0; j < o; ++j) for (int64_t b = 0; b < v; ++b) {
     const int64_t off = ((k * v + c) * o + j) * v + b;
@@ -270,11 +320,11 @@ int dev_small_k_update(int64_t batch, int64_t M, int64_t N, int64_t K, double al
   }
   return 0;
 }
-int dev_ccsd_y_traces(int64_t o, int64_t v, const double* ZC, const double* ZB, double* Y) {
+int dev_ccsd_y_traces(int64_t o, int64_t v, const double* ZC, const double* ZB, double* Y, const double* add) {
   for (int64_t a = 0; a < v; ++a) for (int64_t c = 0; c < v; ++c) {
     double s = 0.0;
     for (int64_t k = 0; k < o; ++k) s += 2.0 * ZC[((k * o + k) * v + a) * v + c] - ZB[((k * v + c) * v + a) * o + k];
-    Y[a * v + c] = s;
+    Y[a * v + c] = add ? s + add[a * v + c] : s;
   }
   return 0;
 }
@@ -297,9 +347,43 @@ int dev_dot_many(int64_t n, const double* x, int m, const double* const* ys, dou
   for (int j = 0; j < m; ++j) { double s = 0; for (int64_t i = 0; i < n; ++i) s += x[i] * ys[j][i]; o[j] = s; }
   return 0;
 }
+int dev_wait_flag(const void* flag_host, unsigned long long seq) { if (*(const unsigned long long*)flag_host == seq) return 0; set_error("dev_wait_flag: word not written"); return QEMB_ERR_DEVICE; }
+int dev_diis_push(int64_t n, const double* trial, const double* prev, double* e, double* xcopy, int m, const double* const* ys, int self, double* row_dev, double* row_host, void* flag_host, unsigned long long seq) {
+  if (m <= 0 || m > 8 || self < 0 || self >= m) { set_error("dev_diis_push: 1 <= m <= 8 vectors, 0 <= self < m"); return QEMB_ERR_ARG; }
+  for (int64_t i = 0; i < n; ++i) { const double t = trial[i]; e[i] = t - prev[i]; if (xcopy) xcopy[i] = t; }
+  for (int j = 0; j < m; ++j) { const double* y = (j == self) ? e : ys[j]; double s = 0; for (int64_t i = 0; i < n; ++i) s += e[i] * y[i]; row_dev[j] = s; row_host[j] = s; }
+  if (flag_host) *(unsigned long long*)flag_host = seq;
+  return 0;
+}
+int dev_ccsd_extrapolate_energy(int64_t o, int64_t v, int nterms, const double* coef, const double* const* xs, double* amp, const double* L, double* tau, double* e_dev, double* e_host, void* flag_host, unsigned long long seq) {
+  if (nterms <= 0 || nterms > 8) { set_error("dev_ccsd_extrapolate_energy: 1 <= nterms <= 8"); return QEMB_ERR_ARG; }
+  const int64_t nov = o * v, na = nov + o * o * v * v;
+  if (!(nterms == 1 && xs[0] == amp && coef[0] == 1.0)) {
+    std::vector<double> x((size_t)na);
+    for (int64_t t = 0; t < na; ++t) { double acc = 0.0; for (int q = 0; q < nterms; ++q) acc += coef[q] * xs[q][t]; x[(size_t)t] = acc; }
+    std::copy(x.begin(), x.end(), amp);
+  }
+  long double s = 0;
+  for (int64_t i = 0; i < o; ++i) for (int64_t j = 0; j < o; ++j) for (int64_t a = 0; a < v; ++a) for (int64_t b = 0; b < v; ++b) {
+    const int64_t idx = ((i * o + j) * v + a) * v + b;
+    tau[idx] = amp[nov + idx] + amp[i * v + a] * amp[j * v + b];
+    s += (long double)L[idx] * tau[idx];
+  }
+  *e_dev = (double)s; *e_host = (double)s;
+  if (flag_host) *(unsigned long long*)flag_host = seq;
+  return 0;
+}
 int dev_absmax(int64_t n, const double* x, double* o) { double m = 0; for (int64_t i = 0; i < n; ++i) m = std::max(m, std::fabs(x[i])); *o = m; return 0; }
 int dev_gemv_rows(int64_t rows, int64_t cols, const double* T, int64_t ldt, const double* x, double* y, double alpha, double beta) {
   for (int64_t r = 0; r < rows; ++r) { double s = 0; for (int64_t c = 0; c < cols; ++c) s += T[r * ldt + c] * x[c]; y[r] = (beta != 0.0) ? alpha * s + beta * y[r] : alpha * s; }
+  return 0;
+}
+int dev_gemv_rows2(int64_t rows, int64_t cols, const double* T1, int64_t ld1, const double* x1, const double* T2, int64_t ld2, const double* x2, double* y, double alpha, double beta) {
+  for (int64_t r = 0; r < rows; ++r) {
+    double s = 0;
+    for (int64_t c = 0; c < cols; ++c) s += T1[r * ld1 + c] * x1[c] + T2[r * ld2 + c] * x2[c];
+    y[r] = (beta != 0.0) ? alpha * s + beta * y[r] : alpha * s;
+  }
   return 0;
 }
 int dev_gemv_rows_batched(int64_t rows, int64_t cols, int64_t nbatch, const double* T, int64_t ldt, int64_t strideT, const double* x,

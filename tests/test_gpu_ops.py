@@ -505,6 +505,143 @@ def test_ccsd_single_pass_kernels(qlib, o, v):
         assert np.abs(dC.numpy((batch, M, N)) - ref).max() < 1e-12 * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.parametrize("o,v", [(1, 1), (2, 3), (4, 33), (7, 70), (21, 21), (5, 64), (3, 97)])
+def test_ccsd_update_fused_passes(qlib, o, v):
+    """The fused passes of update_amps against NumPy: Woooo packed from its four terms, the four small T1 products, the double matrix-vector pass,
+    the finishing pass that takes the ring products where the GEMMs leave them, the transposing pass with a second output, and the addends of
+    scatter_pm_rows / y_traces."""
+    rng = np.random.default_rng(31 * o + v)
+    nov = o * v
+    # --- pack_w_pm_sum == pack_w_pm of the summed tensor
+    Wp, X, O1 = (rng.standard_normal((o, o, o, o)) for _ in range(3))
+    W = Wp + X.transpose(2, 3, 0, 1) + O1.transpose(2, 0, 3, 1) + O1.transpose(0, 2, 1, 3)      # W[k,l,i,j] = Wp[klij] + X[ijkl] + O1[ljki] + O1[kilj]
+    npo, nmo = o * (o + 1) // 2, o * (o - 1) // 2
+    lwp, lwm = npo + (npo & 1), max(2, nmo + (nmo & 1))
+    bufs = [DeviceBuffer.from_numpy(a) for a in (Wp, X, O1, W)]
+    outs = [DeviceBuffer(npo * lwp), DeviceBuffer(max(nmo, 1) * lwm), DeviceBuffer(npo * lwp), DeviceBuffer(max(nmo, 1) * lwm)]
+    check(qlib.qemb_op_pack_w_pm_sum(o, bufs[0].ptr, bufs[1].ptr, bufs[2].ptr, outs[0].ptr, lwp, outs[1].ptr, lwm))
+    check(qlib.qemb_op_pack_w_pm(o, bufs[3].ptr, outs[2].ptr, lwp, outs[3].ptr, lwm))
+    assert np.abs(outs[0].numpy((npo, lwp)) - outs[2].numpy((npo, lwp))).max() < 1e-13
+    if nmo:
+        assert np.abs(outs[1].numpy((nmo, lwm)) - outs[3].numpy((nmo, lwm))).max() < 1e-13
+    # --- t1_small
+    t1, Fov = rng.standard_normal((o, v)), rng.standard_normal((o, v))
+    Lvv, Loo = rng.standard_normal((v, v)), rng.standard_normal((o, o))
+    d = [DeviceBuffer.from_numpy(a) for a in (t1, Lvv, Loo, Fov)]
+    dt1n = DeviceBuffer(nov)
+    check(qlib.qemb_op_ccsd_t1_small(o, v, d[0].ptr, d[1].ptr, d[2].ptr, d[3].ptr, dt1n.ptr))
+    ref = t1 @ Lvv.T - Loo.T @ t1 + (t1 @ Fov.T) @ t1
+    assert np.abs(dt1n.numpy((o, v)) - ref).max() < 1e-12 * max(1.0, np.abs(ref).max())
+    # --- gemv_rows2
+    T1, T2, x1, x2, y0 = rng.standard_normal((nov, nov)), rng.standard_normal((nov, nov)), rng.standard_normal(nov), rng.standard_normal(nov), rng.standard_normal(nov)
+    d = [DeviceBuffer.from_numpy(a) for a in (T1, x1, T2, x2, y0)]
+    check(qlib.qemb_op_gemv_rows2(nov, nov, d[0].ptr, nov, d[1].ptr, d[2].ptr, nov, d[3].ptr, d[4].ptr, 0.75, 1.0))
+    ref = 0.75 * (T1 @ x1 + T2 @ x2) + y0
+    assert np.abs(d[4].numpy((nov,)) - ref).max() < 1e-12 * max(1.0, np.abs(ref).max())
+    # --- finish_t2_rings (t2n and OV symmetric under (ij)(ab), as the ladder and the integrals leave them)
+    def sym(x):
+        return 0.5 * (x + x.transpose(1, 0, 3, 2))
+    t2n, OV = sym(rng.standard_normal((o, o, v, v))), sym(rng.standard_normal((o, o, v, v)))
+    U, RS, M = rng.standard_normal((o, o, v, v)), rng.standard_normal((o, v, o, v)), rng.standard_normal((o, v, o, v))
+    eo, ev = -1.0 - rng.random(o), 1.0 + rng.random(v)
+    t1n = rng.standard_normal((o, v))
+    F = U + RS.transpose(0, 2, 1, 3) - 0.5 * M.transpose(0, 2, 1, 3) - M.transpose(0, 2, 3, 1)
+    D = eo[:, None, None, None] + eo[None, :, None, None] - ev[None, None, :, None] - ev[None, None, None, :]
+    ref = (t2n + OV + F + F.transpose(1, 0, 3, 2)) / D
+    d = [DeviceBuffer.from_numpy(a) for a in (t2n, U, OV, RS, M, eo, ev, t1n)]
+    check(qlib.qemb_op_ccsd_finish_t2_rings(o, v, *[b.ptr for b in d]))
+    got = d[0].numpy((o, o, v, v))
+    assert np.abs(got - ref).max() < 1e-12 * max(1.0, np.abs(ref).max())
+    gt = got.transpose(1, 0, 3, 2)
+    assert all(np.array_equal(got[i, j], gt[i, j]) for i in range(o) for j in range(o) if i != j)      # pairs of tiles are stored both ways from one result
+    assert np.abs(got - gt).max() < 1e-13 * max(1.0, np.abs(ref).max())
+    assert np.abs(d[7].numpy((o, v)) - t1n / (eo[:, None] - ev[None, :])).max() < 1e-13
+    # --- transposing pass with base and second output: W2 = base + ZC[k,i,a,c] at [i,a,k,c],  R = W1 - W2 / 2
+    ZC, base, W1 = rng.standard_normal((o, o, v, v)), rng.standard_normal((o, v, o, v)), rng.standard_normal((o, v, o, v))
+    d = [DeviceBuffer.from_numpy(a) for a in (ZC, base, W1)]
+    dW2, dR = DeviceBuffer(o * o * v * v), DeviceBuffer(o * o * v * v)
+    perm = (1, 2, 0, 3)
+    out_shape = tuple(ZC.shape[p] for p in perm)
+    st = [int(np.prod(out_shape[k + 1:])) for k in range(4)]
+    ostr = [0] * 4
+    for k, p in enumerate(perm):
+        ostr[p] = st[k]
+    istr = [int(np.prod(ZC.shape[k + 1:])) for k in range(4)]
+    check(qlib.qemb_op_copy4_two(i64x4(ZC.shape), d[0].ptr, i64x4(istr), dW2.ptr, i64x4(ostr), 1.0, 1.0, d[1].ptr, dR.ptr, d[2].ptr, 1.0, -0.5))
+    W2_ref = base + ZC.transpose(perm)
+    assert np.abs(dW2.numpy(out_shape) - W2_ref).max() < 1e-14 and np.abs(dR.numpy(out_shape) - (W1 - 0.5 * W2_ref)).max() < 1e-14
+    # --- addends
+    ncols = 3 * v + 1
+    Xp, Xm, add = rng.standard_normal((npo, ncols)), rng.standard_normal((max(nmo, 1), ncols)), rng.standard_normal((o, o, ncols))
+    d = [DeviceBuffer.from_numpy(a) for a in (Xp, Xm, add)]
+    dO = DeviceBuffer(o * o * ncols)
+    check(qlib.qemb_op_scatter_pm_rows_add(o, ncols, d[0].ptr, d[1].ptr, dO.ptr, d[2].ptr))
+    ref = add.copy()
+    for i in range(o):
+        for j in range(i + 1):
+            p = Xp[i * (i + 1) // 2 + j]
+            if i > j:
+                m = Xm[i * (i - 1) // 2 + j]
+                ref[i, j] += p + m; ref[j, i] += p - m
+            else:
+                ref[i, j] += p
+    assert np.abs(dO.numpy((o, o, ncols)) - ref).max() < 1e-14
+    ZCt, ZBt, addv = rng.standard_normal((o, o, v, v)), rng.standard_normal((o, v, v, o)), rng.standard_normal((v, v))
+    d = [DeviceBuffer.from_numpy(a) for a in (ZCt, ZBt, addv)]
+    dY = DeviceBuffer(v * v)
+    check(qlib.qemb_op_ccsd_y_traces_add(o, v, d[0].ptr, d[1].ptr, dY.ptr, d[2].ptr))
+    assert np.abs(dY.numpy((v, v)) - (2.0 * np.einsum("kkac->ac", ZCt) - np.einsum("kcak->ac", ZBt) + addv)).max() < 1e-12
+
+
+@pytest.mark.parametrize("o,v,m", [(1, 1, 1), (3, 5, 2), (4, 33, 6), (7, 70, 8), (21, 21, 6), (20, 100, 6)])
+def test_ccsd_iteration_end_single_launch_kernels(qlib, o, v, m):
+    """diis_push (error vector, stored trial vector, Gram row) and ccsd_extrapolate_energy (amplitudes, tau, energy) -- one launch each, the last
+    workgroup finishing the reduction -- against NumPy; launched repeatedly so that the workgroup counter is seen to be left at zero."""
+    rng = np.random.default_rng(7 * o + v + m)
+    nov, n = o * v, o * v + o * o * v * v
+    trial, prev = rng.standard_normal(n), rng.standard_normal(n)
+    es = [rng.standard_normal(n) for _ in range(m)]
+    for self_slot in sorted({0, m - 1, m // 2}):
+        dtrial, dprev = DeviceBuffer.from_numpy(trial), DeviceBuffer.from_numpy(prev)
+        des = [DeviceBuffer.from_numpy(e) for e in es]
+        dx, drow = DeviceBuffer(n), DeviceBuffer(8)
+        ys = (C.c_void_p * m)(*[b.ptr for b in des])
+        row = (C.c_double * 8)()
+        for rep in range(3):
+            check(qlib.qemb_op_diis_push(n, dtrial.ptr, dprev.ptr, des[self_slot].ptr, dx.ptr, m, ys, self_slot, drow.ptr, row))
+            e_ref = trial - prev
+            ref = np.array([e_ref @ (e_ref if j == self_slot else es[j]) for j in range(m)])
+            got = np.array(row[:m])
+            assert np.abs(got - ref).max() < 1e-11 * max(1.0, np.abs(ref).max()), (rep, got, ref)
+            assert np.array_equal(drow.numpy((8,))[:m], got)
+        assert np.array_equal(des[self_slot].numpy((n,)), e_ref) and np.array_equal(dx.numpy((n,)), trial)
+        # in place: the stored copy of the trial vector aliases the previous vector (the first, DIIS-less iteration)
+        check(qlib.qemb_op_diis_push(n, dtrial.ptr, dprev.ptr, des[self_slot].ptr, dprev.ptr, 1, (C.c_void_p * 1)(des[self_slot].ptr), 0, drow.ptr, row))
+        assert np.array_equal(dprev.numpy((n,)), trial) and abs(row[0] - e_ref @ e_ref) < 1e-11 * max(1.0, e_ref @ e_ref)
+        for b in [dtrial, dprev, dx, drow] + des:
+            b.free()
+    xs = [rng.standard_normal(n) for _ in range(m)]
+    coef = rng.standard_normal(m)
+    L = rng.standard_normal(o * o * v * v)
+    dxs = [DeviceBuffer.from_numpy(x) for x in xs]
+    damp, dL, dtau = DeviceBuffer(n), DeviceBuffer.from_numpy(L), DeviceBuffer(o * o * v * v)
+    e = C.c_double()
+    amp_ref = sum(c * x for c, x in zip(coef, xs))
+    t1, t2 = amp_ref[:nov].reshape(o, v), amp_ref[nov:].reshape(o, o, v, v)
+    tau_ref = t2 + np.einsum("ia,jb->ijab", t1, t1)
+    for rep in range(3):
+        check(qlib.qemb_op_ccsd_extrapolate_energy(o, v, m, (C.c_double * m)(*coef), (C.c_void_p * m)(*[b.ptr for b in dxs]), damp.ptr, dL.ptr, dtau.ptr, C.byref(e)))
+        assert np.abs(damp.numpy((n,)) - amp_ref).max() < 1e-13 * max(1.0, np.abs(amp_ref).max())
+        assert np.abs(dtau.numpy((o, o, v, v)) - tau_ref).max() < 1e-12 * max(1.0, np.abs(tau_ref).max())
+        assert abs(e.value - L @ tau_ref.ravel()) < 1e-10 * max(1.0, np.abs(L).sum() ** 0.5 * np.abs(tau_ref).max())
+    # nothing to extrapolate, amplitudes already in place: only tau and the energy
+    amp0 = damp.numpy((n,)).copy()
+    check(qlib.qemb_op_ccsd_extrapolate_energy(o, v, 1, (C.c_double * 1)(1.0), (C.c_void_p * 1)(damp.ptr), damp.ptr, dL.ptr, dtau.ptr, C.byref(e)))
+    assert np.array_equal(damp.numpy((n,)), amp0)
+    t1, t2 = amp0[:nov].reshape(o, v), amp0[nov:].reshape(o, o, v, v)
+    assert abs(e.value - L @ (t2 + np.einsum("ia,jb->ijab", t1, t1)).ravel()) < 1e-10 * max(1.0, np.abs(L).sum() ** 0.5 * np.abs(tau_ref).max())
+
+
 @pytest.mark.parametrize("shape", [(37, 200, 200, 20, False, True), (5, 70, 64, 32, True, False), (4, 33, 129, 7, False, False), (3, 200, 256, 20, False, True),
                                    (2, 100, 257, 20, False, True), (6, 31, 63, 5, False, False), (400, 200, 200, 20, False, True)])
 def test_small_k_update_strip_and_tile_variants(qlib, shape):

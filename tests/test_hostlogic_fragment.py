@@ -93,6 +93,26 @@ def test_single_update_amps_matches_oracle(hlib):
         t1, t2 = t1n, t2n
 
 
+def test_update_amps_with_split_k_slabs(hlib):
+    """n_virt = 64: the packed pair index is 2080 long, past the threshold from which the pair products are split over K and leave their partial
+    products in slabs that the scatter kernels add up (no reduction pass) -- one update and its energy against the oracle."""
+    from quemb_amd.fragsolver import DeviceFragment, default_opts
+    n, o, nf = 67, 3, 2
+    h, e1, *_ = _problem(n, o, nf, 5)
+    fr = DeviceFragment(n, nf, lib=hlib)
+    fr.set_eri_s4(eri.pack_s4(e1))
+    opts = default_opts(hlib, scf_conv_tol=1e-13, scf_conv_tol_grad=1e-9)
+    fr.prepare_ccsd(o, h, opts=opts)
+    mf = scf.rhf(h, e1, o, conv_tol=1e-13, conv_tol_grad=1e-9)
+    eris = ccsd.Eris(e1, mf["mo_coeff"], o, mo_energy=mf["mo_energy"])
+    t1, t2 = ccsd.init_amps(eris)
+    e_g, nt_g = fr.ccsd_iterate(1)
+    t1n, t2n = ccsd.update_amps(t1, t2, eris)
+    e_o = ccsd.energy(t1n, t2n, eris)
+    nt_o = np.sqrt(np.linalg.norm(t1n - t1) ** 2 + np.linalg.norm(t2n - t2) ** 2)
+    assert abs(e_g - e_o) < 1e-11 and abs(nt_g - nt_o) < 1e-11
+
+
 def test_warm_start_and_errors(hlib):
     from quemb_amd._lib import QembError
     from quemb_amd.fragsolver import DeviceFragment, default_opts
