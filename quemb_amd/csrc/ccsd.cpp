@@ -126,6 +126,8 @@ int CcsdSolver::setup(MoIntegrals&& ints, const double* mo_energy_dev) {
   QTRY(perm4(OVoovv_, I_.ovov, o, v, o, v, 0, 2, 1, 3));                 // OVoovv[k,l,c,d] = ovov[k,c,l,d]
   QTRY(perm4(Lovoo_, I_.ovoo, o, v, o, o, 2, 1, 0, 3, -1.0, 0.0));       // -ovoo[k,c,l,i] at [l,c,k,i]
   QTRY(axpby(o * v * oo, 2.0, I_.ovoo, 1.0, Lovoo_));                    // Lovoo[l,c,k,i] = 2 ovoo[lcki] - ovoo[kcli]
+  QTRY(LovooT_.alloc(o * v * oo));
+  QTRY(perm4(LovooT_, Lovoo_, o, v, o, o, 2, 3, 0, 1));                  // ... at [k,i,l,c]: Z[k,i] = sum_lc Lovoo[lcki] t1[lc] is then one row-wise matrix-vector pass
   QTRY(ovoo_ijka_.alloc(o * v * oo));
   QTRY(perm4(ovoo_ijka_, I_.ovoo, o, v, o, o, 0, 2, 3, 1));               // ovoo[i,a,j,k] at [i,j,k,a]
   QTRY(ovoo_kilc_.alloc(o * v * oo));
@@ -337,7 +339,7 @@ int CcsdSolver::update_amps(double* t1n, double* t2n) {
   QTRY(dev_foo_from_x(o, Xw_, Loo_));
   QTRY(gemm(v, v, oo * v, -1.0, tau_, v, false, Loovv_, v, false, 0.0, Fvv_, v, 1, 0, 0, 0, (v <= 256) ? 1 : -1));   // Fvv'[a,c]  (64 x 64 tiles: split-K supplies the blocks)
   QTRY(dev_gemv_rows(nov, nov, Lovov_, nov, t1, Fov_, 1.0, 0.0));                  // Fov[k,c]
-  QTRY(dev_contract_mid(1, nov, oo, Lovoo_, t1, Loo_, oo, 1.0, 1.0));              // Loo' = Foo' + Z[k,i]
+  QTRY(dev_gemv_rows(oo, nov, LovooT_, nov, t1, Loo_, 1.0, 1.0));                  // Loo' = Foo' + Z[k,i]
   // The two t1-contractions of ovvv are formed ONCE per iteration (each is one pass over the 1.28 GB block) and serve the
   // ring intermediates, the X1 term and -- through their k = i traces -- the Y intermediate:
   // (n_occ <= 32 columns / rows: 128 x 32 and 32 x 128 tiles instead of padding n_occ to a 64-wide tile, which made these
@@ -517,7 +519,10 @@ int CcsdSolver::iterate_update(bool prefer_tape, bool defer_tape, bool* deferred
 // by side).  One eager update_amps into the staging buffer settles the workspaces -- it reads the amplitudes and writes only scratch, the
 // solver's state is what it was -- and the capture that follows records the launch sequence without executing it.  Every iteration of the
 // solve, the first included, then runs from the tape.  A fragment that is not in the replay regime (large, or graphs disabled) is left alone.
-int CcsdSolver::prepare_tape() {
+int CcsdSolver::prepare_tape(int peers) {
+  static const bool peer_hint = [] { const char* e = std::getenv("QEMB_LOCKSTEP_PEERS"); return e && e[0] != '0'; }();
+  struct Peers { bool on; ~Peers() { if (on) dev_gemm_set_peers(1); } } guard{peer_hint && peers > 1};
+  if (guard.on) dev_gemm_set_peers(peers);
   const bool use_diis = false;
   (void)use_diis;
   bool deferred = false;

@@ -59,7 +59,7 @@ class CcsdSolver {
   int post_issue();                                 // iterate_post in three steps (a wait of this context's stream between them)
   int post_extrapolate(double* normt);
   int post_energy(double* e_corr);
-  int prepare_tape();                               // record the update as a tape before the first iteration (lock-step sweeps)
+  int prepare_tape(int peers = 1);                               // record the update as a tape before the first iteration (lock-step sweeps)
   int kernel(const CcsdOptions& opt, double* e_corr, int* n_iter, bool* converged);
   // energy pieces of get_frag_energy that need t1,t2: Z1[i,P], Z2[a,P] (host outputs o*nf and v*nf)
   int energy_intermediates(std::vector<double>& Z1, std::vector<double>& Z2);
@@ -97,7 +97,7 @@ class CcsdSolver {
   DBuf WAp_, WAm_, HRp_, HRm_;   // hole-hole ladder: (+/-) packed images of Woooo and its packed result rows
   int64_t lwp_ = 0, lwm_ = 0;    // leading dimensions of WAp_ / WAm_
   DBuf ZB_, ZC_;                 // ZB[k,c,a,i] = ovvv[kcad] t1[id],  ZC[k,i,a,c] = t1[id] ovvv[kdac]  (one ovvv pass each per iteration)
-  DBuf Foo_, Fvv_, Fov_, Z_, Y_, Ytmp_, Loo_, Lvv_, Q_, Wo_, O1_, X_, scal_;
+  DBuf Foo_, Fvv_, Fov_, Z_, Y_, Ytmp_, Loo_, Lvv_, Q_, Wo_, O1_, X_, scal_, LovooT_;
   std::vector<DeviceDIIS> diis_;
   bool first_ = true;
   // hipGraph of one update_amps (small fragments are launch bound: ~170 launches of a few microseconds each)

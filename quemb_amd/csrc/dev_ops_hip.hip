@@ -1650,29 +1650,23 @@ int dev_ladder_scatter_pm(int64_t o, int64_t v, const double* Rp, int64_t ldp, c
 }
 // one thread per (P(ij), P(kl)) / (Q(ij), Q(kl)) entry of the packed images of W[k,l,i,j]; W(k,l,i,j) is a functor: a stored tensor (pack_w_pm) or the
 // four-term sum that IS the Woooo intermediate (pack_w_pm_sum: oooo_p[k,l,i,j] + X[i,j,k,l] + O1[l,j,k,i] + O1[k,i,l,j], added in that order)
+// grid (ceil(lda_p / 256), npair(o)): row P(ij) per BID.y, one thread per column P(kl).  W(k,l,i,j) and W(k,l,j,i) are read once and serve both images
+// (the (-) entry Q(ij),Q(kl) exists when i > j and k > l); the padding columns are zeroed by the threads past npair(o) / by the first thread of the row.
 template <class WF>
 __device__ __forceinline__ void pack_w_pm_any(const uint3 BID, long long o, WF W, double* __restrict__ Ap, long long lda_p, double* __restrict__ Am, long long lda_m) {
   const long long npo = o * (o + 1) / 2, nmo = o * (o - 1) / 2;
-  const long long t = (long long)BID.x * blockDim.x + threadIdx.x;
-  if (t < npo * lda_p) {
-    const long long ij = t / lda_p, kl = t - ij * lda_p;
-    double x = 0.0;
-    if (kl < npo) {
-      long long i, j, k, l; unpair_ge(ij, i, j); unpair_ge(kl, k, l);
-      const double a = W(k, l, i, j);
-      x = (k == l) ? a : a + W(k, l, j, i);
-    }
-    Ap[t] = x;
-  }
-  if (Am && t < nmo * lda_m) {
-    const long long ij = t / lda_m, kl = t - ij * lda_m;
-    double x = 0.0;
-    if (kl < nmo) {
-      long long i, j, k, l;           // strictly lower pairs: Q(i,j) = i(i-1)/2 + j, i > j  ==  pair_ge of (i-1, j)
-      unpair_ge(ij, i, j); ++i; unpair_ge(kl, k, l); ++k;
-      x = W(k, l, i, j) - W(k, l, j, i);
-    }
-    Am[t] = x;
+  long long i, j; unpair_ge((long long)BID.y, i, j);
+  const long long kl = (long long)BID.x * blockDim.x + threadIdx.x;
+  if (kl >= lda_p) return;
+  double* ap = Ap + (long long)BID.y * lda_p;
+  double* am = (Am && i > j) ? Am + (i * (i - 1) / 2 + j) * lda_m : nullptr;
+  if (kl >= npo) { ap[kl] = 0.0; return; }
+  long long k, l; unpair_ge(kl, k, l);
+  const double wa = W(k, l, i, j), wb = (k == l) ? 0.0 : W(k, l, j, i);
+  ap[kl] = (k == l) ? wa : wa + wb;
+  if (am) {
+    if (k > l) am[k * (k - 1) / 2 + l] = wa - wb;
+    if (kl == 0) for (long long c = nmo; c < lda_m; ++c) am[c] = 0.0;
   }
 }
 __device__ __forceinline__ void pack_w_pm_kernel_body(const uint3 BID, const uint3 GDIM, long long o, const double* __restrict__ W, double* __restrict__ Ap, long long lda_p,
@@ -1690,19 +1684,23 @@ __global__ void __launch_bounds__(256) pack_w_pm_sum_kernel(long long o, const d
                                                             double* __restrict__ Ap, long long lda_p, double* __restrict__ Am, long long lda_m) {
   pack_w_pm_sum_kernel_body(make_uint3(blockIdx.x, blockIdx.y, blockIdx.z), make_uint3(gridDim.x, gridDim.y, gridDim.z), o, Wp, X, O1, Ap, lda_p, Am, lda_m);
 }
+// one wave per output (k,i), lanes over l (then strides of 64): a thread per output walks l in a chain of L2 round trips (14.7 us at n_occ = 21)
+__device__ __forceinline__ double wave_sum_fwd(double v);
 __device__ __forceinline__ void foo_from_x_kernel_body(const uint3 BID, const uint3 GDIM, long long o, const double* __restrict__ X, double* __restrict__ F) {
-  const long long t = (long long)BID.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const long long t = (long long)BID.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (t >= o * o) return;
   const long long k = t / o, i = t - k * o;
   double s = 0.0;
-  for (long long l = 0; l < o; ++l) s += 2.0 * X[((i * o + l) * o + k) * o + l] - X[((l * o + i) * o + k) * o + l];
-  F[t] = s;
+  for (long long l = lane; l < o; l += 64) s += 2.0 * X[((i * o + l) * o + k) * o + l] - X[((l * o + i) * o + k) * o + l];
+  s = wave_sum_fwd(s);
+  if (lane == 0) F[t] = s;
 }
 __global__ void __launch_bounds__(256) foo_from_x_kernel(long long o, const double* __restrict__ X, double* __restrict__ F) { foo_from_x_kernel_body(make_uint3(blockIdx.x, blockIdx.y, blockIdx.z), make_uint3(gridDim.x, gridDim.y, gridDim.z), o, X, F); }
 int dev_foo_from_x(int64_t o, const double* X, double* F) {
   REQUIRE_INIT();
   if (o <= 0) return QEMB_OK;
-  hipLaunchKernelGGL(foo_from_x_kernel, dim3((unsigned)((o * o + 255) / 256)), dim3(256), 0, g_stream, (long long)o, X, F);
+  hipLaunchKernelGGL(foo_from_x_kernel, dim3((unsigned)((o * o + 3) / 4)), dim3(256), 0, g_stream, (long long)o, X, F);
   HIP_TRY(hipGetLastError());
   return QEMB_OK;
 }
@@ -1711,8 +1709,8 @@ int dev_pack_w_pm_sum(int64_t o, const double* Wp, const double* X, const double
   if (o <= 0) return QEMB_OK;
   const long long npo = o * (o + 1) / 2, nmo = o * (o - 1) / 2;
   if (lda_p < npo || (nmo > 0 && lda_m < nmo)) { set_error("dev_pack_w_pm_sum: leading dimension too small"); return QEMB_ERR_ARG; }
-  const long long tot = std::max<long long>(npo * lda_p, nmo * lda_m);
-  hipLaunchKernelGGL(pack_w_pm_sum_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, g_stream, (long long)o, Wp, X, O1, Ap, (long long)lda_p, nmo > 0 ? Am : nullptr, (long long)lda_m);
+  if (npo > 65535) { set_error("dev_pack_w_pm_sum: too many pairs"); return QEMB_ERR_ARG; }
+  hipLaunchKernelGGL(pack_w_pm_sum_kernel, dim3((unsigned)((lda_p + 255) / 256), (unsigned)npo), dim3(256), 0, g_stream, (long long)o, Wp, X, O1, Ap, (long long)lda_p, nmo > 0 ? Am : nullptr, (long long)lda_m);
   HIP_TRY(hipGetLastError());
   return QEMB_OK;
 }
@@ -1721,8 +1719,8 @@ int dev_pack_w_pm(int64_t o, const double* W, double* Ap, int64_t lda_p, double*
   if (o <= 0) return QEMB_OK;
   const long long npo = o * (o + 1) / 2, nmo = o * (o - 1) / 2;
   if (lda_p < npo || (nmo > 0 && lda_m < nmo)) { set_error("dev_pack_w_pm: leading dimension too small"); return QEMB_ERR_ARG; }
-  const long long tot = std::max<long long>(npo * lda_p, nmo * lda_m);
-  hipLaunchKernelGGL(pack_w_pm_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, g_stream, (long long)o, W, Ap, (long long)lda_p, nmo > 0 ? Am : nullptr, (long long)lda_m);
+  if (npo > 65535) { set_error("dev_pack_w_pm: too many pairs"); return QEMB_ERR_ARG; }
+  hipLaunchKernelGGL(pack_w_pm_kernel, dim3((unsigned)((lda_p + 255) / 256), (unsigned)npo), dim3(256), 0, g_stream, (long long)o, W, Ap, (long long)lda_p, nmo > 0 ? Am : nullptr, (long long)lda_m);
   HIP_TRY(hipGetLastError());
   return QEMB_OK;
 }
@@ -1730,6 +1728,11 @@ int dev_pack_w_pm(int64_t o, const double* W, double* Ap, int64_t lda_p, double*
 // ------------------------------------------------------------------------------------------------
 // reductions (deterministic: fixed grid, fixed tree)
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum_fwd(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);

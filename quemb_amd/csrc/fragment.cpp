@@ -236,7 +236,7 @@ int Fragment::solve_batch(const std::vector<Fragment*>& frs, const std::vector<i
   };
   QTRY(per_fragment([&](int f) {
     int r = frs[f]->solve_begin(o[f], h[f], dm0[f], opt, eeval, &res[f]);
-    if (r == 0 && frs[f]->cc_ && F > 1) r = frs[f]->cc_->prepare_tape();      // recorded side by side; a lone fragment keeps its executable graph
+    if (r == 0 && frs[f]->cc_ && F > 1) r = frs[f]->cc_->prepare_tape(F);      // recorded side by side; a lone fragment keeps its executable graph
     if (r == 0) r = dev_sync();                                               // the lock-step loop reads this fragment's buffers from another stream
     return r;
   }));

@@ -25,6 +25,7 @@ const char* dev_backend_name() { return "hostcheck"; }
 int dev_gemm_stamps(const GemmDesc&, int, double*) { set_error("dev_gemm_stamps: not available in the hostcheck build"); return QEMB_ERR_DEVICE; }
 void dev_gemm_set_force_cfg(int) {}
 void dev_gemm_set_auto_splitk(int) {}
+void dev_gemm_set_peers(int) {}
 
 int dev_init(int) { return 0; }
 int dev_sync() { return 0; }
