@@ -420,7 +420,11 @@ int CcsdSolver::update_amps(double* t1n, double* t2n) {
   // The right-hand operands of all four (ov)^3 products are symmetric matrices over (kc),(ld) -- L and ovov_t by the integral symmetry
   // (kc|ld) = (ld|kc), T' and u by t2[k,j,c,b] = t2[j,k,b,c] -- so each is passed in its K-contiguous (transposed) reading: both operands
   // of the GEMM are then staged through the conflict-free [row][BK+2] LDS image, on the 128 x 256 tile (512 tiles at ov = 4000: two per CU).
-  const int cfg_ring = (nov >= 2048) ? 4 : -1;
+  // (small fragments in a lock-step sweep, QEMB_LOCKSTEP_PEERS=1: `peers` products of this shape run in ONE grouped launch, enough to fill the chip with
+  //  64 x 64 tiles.  Measured on six octane fragments, o v = 441: 294 such workgroups on 256 CUs are SLOWER than the 1176 of the 32 x 32 tile the
+  //  dispatcher picks for a lone product -- 11.3 against 11.0 ms per sweep -- so the hint stays off.)
+  const int64_t ring_tiles64 = ((nov + 63) / 64) * ((nov + 63) / 64) * dev_gemm_peers();
+  const int cfg_ring = (nov >= 2048) ? 4 : (nov >= 256 && ring_tiles64 >= 200) ? 1 : -1;
   auto ring = [&](double al, const double* A, const double* Bsym, double be, double* C) {
     return gemm(nov, nov, nov, al, A, nov, true, Bsym, nov, true, be, C, nov, 1, 0, 0, 0, cfg_ring);
   };
@@ -520,7 +524,7 @@ int CcsdSolver::iterate_update(bool prefer_tape, bool defer_tape, bool* deferred
 // solver's state is what it was -- and the capture that follows records the launch sequence without executing it.  Every iteration of the
 // solve, the first included, then runs from the tape.  A fragment that is not in the replay regime (large, or graphs disabled) is left alone.
 int CcsdSolver::prepare_tape(int peers) {
-  static const bool peer_hint = [] { const char* e = std::getenv("QEMB_LOCKSTEP_PEERS"); return e && e[0] != '0'; }();
+  static const bool peer_hint = [] { const char* e = std::getenv("QEMB_LOCKSTEP_PEERS"); return e && e[0] != '0'; }();      // off: measured slower (below)
   struct Peers { bool on; ~Peers() { if (on) dev_gemm_set_peers(1); } } guard{peer_hint && peers > 1};
   if (guard.on) dev_gemm_set_peers(peers);
   const bool use_diis = false;

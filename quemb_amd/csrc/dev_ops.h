@@ -119,8 +119,10 @@ int dev_gemm(const GemmDesc& g);
 // test / tuning hooks of the calling host thread: force a tile configuration (-1: automatic), switch the automatic split-K off
 void dev_gemm_set_force_cfg(int cfg);
 void dev_gemm_set_auto_splitk(int enabled);
-// tile choice hint of the calling host thread: this many products of each shape will be launched together (grouped launches of a lock-step sweep)
+// hint of the calling host thread: this many products of each shape will be launched together (grouped launches of a lock-step sweep); read by callers
+// that choose a tile themselves (the ring products of small fragments)
 void dev_gemm_set_peers(int n);
+int dev_gemm_peers();
 // one product timed on its own with the sustained shader clock read back (see gemm_f64.hip); syncs the stream -- a measuring aid
 int dev_gemm_probe(const GemmDesc& g, double* ms, double* ghz, long long* workgroups);
 // diagnostic tile configurations (3xx): per-wave s_memtime sums around the per-tile barrier, averaged over the waves of one launch

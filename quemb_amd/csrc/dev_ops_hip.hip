@@ -329,6 +329,7 @@ int dev_graph_destroy(dev_graph_t g) { if (g) (void)hipGraphExecDestroy((hipGrap
 // in device memory and runs the body with its block index inside that member.  Kernels are registered by the address of their wrapper,
 // which is what a captured graph node carries.
 std::map<const void*, GroupInfo>& groupable() { static std::map<const void*, GroupInfo> m; return m; }
+bool group_xcd_mode() { static const bool on = [] { const char* e = std::getenv("QEMB_GROUP_XCD"); return e && e[0] != '0'; }(); return on; }
 void register_groupable_gemm();         // gemm_f64.hip
 static void register_groupable_kernels();   // end of this file (after the kernels)
 
@@ -817,7 +818,15 @@ int dev_copy4(const Copy4Desc& cd) {
   } else {
     const long long n23 = c.d2 * c.d3;
     const unsigned gx = (unsigned)std::min<long long>((n23 + 255) / 256, 1 << 20);
-    hipLaunchKernelGGL(copy4_linear_kernel, dim3(gx, gy, gz), dim3(256), 0, g_stream, c);
+    // small tensors: a workgroup per (i0, i1) slice of a few hundred elements is bound by workgroup dispatch (~4 ns each: 16 us for the 5464 of six
+    // octane fragments); the kernel strides over i1 / i0, so fewer workgroups each take several slices -- about four elements per thread
+    unsigned gy2 = gy, gz2 = gz;
+    const long long want = std::max<long long>(1, c.d0 * c.d1 * n23 / 1024);
+    if ((long long)gx * gy * gz > want) {
+      gz2 = (unsigned)std::max<long long>(1, std::min<long long>(gz, want / ((long long)gx * gy)));
+      if ((long long)gx * gy * gz2 > want) gy2 = (unsigned)std::max<long long>(1, std::min<long long>(gy, want / gx));
+    }
+    hipLaunchKernelGGL(copy4_linear_kernel, dim3(gx, gy2, gz2), dim3(256), 0, g_stream, c);
   }
   HIP_TRY(hipGetLastError());
   return QEMB_OK;
@@ -1072,8 +1081,15 @@ __device__ __forceinline__ void ccsd_y_traces_kernel_body(const uint3 BID, const
   if (idx >= v * v) return;
   const long long a = idx / v, c = idx % v;
   double s = 0.0;
-  for (long long k = 0; k < o; ++k)
-    s += 2.0 * ZC[((k * o + k) * v + a) * v + c] - ZB[((k * v + c) * v + a) * o + k];
+  long long k = 0;
+  for (; k + 4 <= o; k += 4) {      // four terms' loads in flight, added in order
+    double zc[4], zb[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { zc[q] = ZC[(((k + q) * o + (k + q)) * v + a) * v + c]; zb[q] = ZB[(((k + q) * v + c) * v + a) * o + (k + q)]; }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) s += 2.0 * zc[q] - zb[q];
+  }
+  for (; k < o; ++k) s += 2.0 * ZC[((k * o + k) * v + a) * v + c] - ZB[((k * v + c) * v + a) * o + k];
   Y[idx] = add ? s + add[idx] : s;
 }
 __global__ void __launch_bounds__(256) ccsd_y_traces_kernel(long long o, long long v, const double* __restrict__ ZC, const double* __restrict__ ZB,

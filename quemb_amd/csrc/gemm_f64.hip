@@ -49,6 +49,7 @@ static thread_local int t_gemm_force_cfg = -1;
 static thread_local int t_gemm_splitk_enabled = 1;
 static thread_local int t_gemm_peers = 1;
 void dev_gemm_set_peers(int n) { t_gemm_peers = n > 1 ? n : 1; }
+int dev_gemm_peers() { return t_gemm_peers; }
 void dev_gemm_set_force_cfg(int cfg) { t_gemm_force_cfg = cfg; }
 void dev_gemm_set_auto_splitk(int enabled) { t_gemm_splitk_enabled = enabled; }
 
@@ -517,7 +518,15 @@ __device__ __forceinline__ void splitk_reduce_kernel_body(const uint3 BID, const
   for (long long t = (long long)BID.x * blockDim.x + threadIdx.x; t < mn; t += (long long)GDIM.x * blockDim.x) {
     double acc = 0.0;
     const double* p = ws + b * S * mn + t;
-    for (int s = 0; s < S; ++s) acc += p[(long long)s * mn];
+    int s = 0;
+    for (; s + 8 <= S; s += 8) {      // eight slabs' loads in flight, added in slab order (a counted loop waits for every load in turn)
+      double x[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) x[q] = p[(long long)(s + q) * mn];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) acc += x[q];
+    }
+    for (; s < S; ++s) acc += p[(long long)s * mn];
     const long long m = t / N, n = t - m * N;
     double* c = C + b * strideC + m * ldc + n;
     *c = (beta != 0.0) ? alpha * acc + beta * (*c) : alpha * acc;
@@ -787,10 +796,8 @@ static int dev_gemm_dispatch(const GemmDesc& d) {
                     operand_vec2_ok(d.B, d.ldb, d.strideB, d.b_kcontig ? d.K : d.N);
   // tile choice: biggest tile that still gives the 256 CUs >= ~2 workgroups each; small problems
   // fall to 64x64 / 32x32 tiles so the grid is not a handful of blocks.
-  // (t_gemm_peers: products of this shape that the caller will launch TOGETHER -- the lock-step sweep records one tape per fragment and runs the
-  //  fragments' launches grouped, so the chip sees `peers` times the tiles)
-  const int64_t t128 = ((d.M + 127) / 128) * ((d.N + 127) / 128) * d.batch * t_gemm_peers;
-  const int64_t t64 = ((d.M + 63) / 64) * ((d.N + 63) / 64) * d.batch * t_gemm_peers;
+  const int64_t t128 = ((d.M + 127) / 128) * ((d.N + 127) / 128) * d.batch;
+  const int64_t t64 = ((d.M + 63) / 64) * ((d.N + 63) / 64) * d.batch;
   // padding waste of the two main tilings (zero rows still occupy MFMA slots): M = o^2 = 400 wastes 22 % with
   // 128-row tiles but 11 % with 64-row tiles, and the smaller tile wins on the ladder shape (profiles/r01_gemm_*).
   const double w128 = (double)(((d.M + 127) / 128) * 128) * (double)(((d.N + 127) / 128) * 128);

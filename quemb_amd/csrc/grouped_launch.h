@@ -20,8 +20,11 @@ template <class H, class... T> struct Pack<H, T...> {
 };
 // Everything a grouped launch needs travels in the kernel-argument segment (scalar loads, no table in device memory to chase): the first
 // block of every member in the concatenated grid, the members' own grids, and the members' argument packs.
+// xcd != 0: member f owns the blocks b with b % 8 == f (b / 8 is its block number): workgroups are dealt round-robin over the 8 XCDs, so one member's
+// workgroups share ONE XCD and its L2 -- the operands of a small fragment are fetched into one L2 instead of eight (placement is a matter of speed only:
+// nothing depends on where a block really runs).
 template <class P> struct GroupArgs {
-  int n;
+  int n, xcd;
   unsigned first[GROUP_MAX], gx[GROUP_MAX], gy[GROUP_MAX], gz[GROUP_MAX];
   P tab[GROUP_MAX];
 };
@@ -29,9 +32,16 @@ template <auto Body, int MAXT, class... A>
 __global__ void __launch_bounds__(MAXT) grouped_kernel(const GroupArgs<Pack<A...>> a) {
   const unsigned b = blockIdx.x;
   int f = 0;
+  unsigned lb;
+  if (a.xcd) {
+    f = (int)(b & 7u); lb = b >> 3;
+    if (f >= a.n || lb >= a.gx[f] * a.gy[f] * a.gz[f]) return;
+  } else {
 #pragma unroll
-  for (int k = 1; k < GROUP_MAX; ++k) f += (k < a.n && b >= a.first[k]) ? 1 : 0;
-  const unsigned lb = b - a.first[f], gx = a.gx[f], gy = a.gy[f];
+    for (int k = 1; k < GROUP_MAX; ++k) f += (k < a.n && b >= a.first[k]) ? 1 : 0;
+    lb = b - a.first[f];
+  }
+  const unsigned gx = a.gx[f], gy = a.gy[f];
   const uint3 bid = make_uint3(lb % gx, (lb / gx) % gy, lb / (gx * gy));
   const uint3 gdim = make_uint3(gx, gy, a.gz[f]);
   a.tab[f].call([&](const A&... x) { Body(bid, gdim, x...); });
@@ -44,6 +54,7 @@ struct GroupInfo {
   void (*launch)(const void* args, unsigned blocks, dim3 block, size_t lds, hipStream_t s);
 };
 std::map<const void*, GroupInfo>& groupable();      // dev_ops_hip.hip
+bool group_xcd_mode();                                // dev_ops_hip.hip (QEMB_GROUP_XCD)
 template <auto Body, int MAXT, class... A>
 static void register_groupable(const void* wrapper) {
   using P = Pack<A...>;
@@ -55,12 +66,13 @@ static void register_groupable(const void* wrapper) {
   gi.build = [](void* dst, const GroupMember* m, int n) -> unsigned {
     GA* a = new (dst) GA();
     a->n = n;
-    unsigned first = 0;
+    a->xcd = (group_xcd_mode() && n >= 3) ? 1 : 0;      // (one or two members: an XCD each would leave most of the chip idle)
+    unsigned first = 0, most = 0;
     for (int k = 0; k < GROUP_MAX; ++k) {
-      if (k < n) { a->first[k] = first; a->gx[k] = m[k].gx; a->gy[k] = m[k].gy; a->gz[k] = m[k].gz; a->tab[k].load(m[k].kernel_params); first += m[k].gx * m[k].gy * m[k].gz; }
+      if (k < n) { a->first[k] = first; a->gx[k] = m[k].gx; a->gy[k] = m[k].gy; a->gz[k] = m[k].gz; a->tab[k].load(m[k].kernel_params); first += m[k].gx * m[k].gy * m[k].gz; most = m[k].gx * m[k].gy * m[k].gz > most ? m[k].gx * m[k].gy * m[k].gz : most; }
       else { a->first[k] = 0xffffffffu; a->gx[k] = a->gy[k] = a->gz[k] = 1; a->tab[k] = a->tab[0]; }
     }
-    return first;
+    return a->xcd ? 8u * most : first;
   };
   gi.launch = [](const void* args, unsigned blocks, dim3 block, size_t lds, hipStream_t s) {
     hipLaunchKernelGGL((grouped_kernel<Body, MAXT, A...>), dim3(blocks), block, lds, s, *reinterpret_cast<const GA*>(args));

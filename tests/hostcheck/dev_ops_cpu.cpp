@@ -26,6 +26,7 @@ int dev_gemm_stamps(const GemmDesc&, int, double*) { set_error("dev_gemm_stamps:
 void dev_gemm_set_force_cfg(int) {}
 void dev_gemm_set_auto_splitk(int) {}
 void dev_gemm_set_peers(int) {}
+int dev_gemm_peers() { return 1; }
 
 int dev_init(int) { return 0; }
 int dev_sync() { return 0; }
