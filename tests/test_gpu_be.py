@@ -532,6 +532,44 @@ def test_transforms_at_survey_sizes(qlib):
     assert np.abs(out - ref).max() < 1e-11 * max(1.0, np.abs(ref).max())
 
 
+def test_semisparse_storage_at_survey_size(qlib):
+    """Row a5 at the size SURVEY 8(d) names for it (N_ao = 512, n_aux = 1000, fragment n = 220) on the SEMI-SPARSE storage itself: a banded
+    SemiSparseSym3DTensor (unique aux vectors + exch_reachable_with_offsets, ~25 partners per AO, two AOs without any) goes to the device
+    unexpanded; the transform -- plain, and with the reference's MO screening -- equals the one of the same integrals stored dense with zeros."""
+    from quemb_amd import eri_transform as et
+    rng = np.random.default_rng(20261004)
+    N, n, naux = 512, 220, 1000
+    width = rng.integers(4, 48, N)
+    d = np.abs(np.subtract.outer(np.arange(N), np.arange(N)))
+    stored = (d <= width[:, None]) & (d <= width[None, :])
+    stored[[100, 333], :] = False; stored[:, [100, 333]] = False
+    reach = [[int(nu) for nu in np.nonzero(stored[mu])[0]] for mu in range(N)]
+    il = np.tril_indices(N)
+    keep = stored[il]
+    packed = np.zeros((naux, il[0].size))
+    packed[:, keep] = 0.06 * rng.standard_normal((naux, int(keep.sum())))
+    # the mirror class from its sparse parts (no (naux, N, N) array is ever formed): unique pairs nu <= mu in offset order
+    t = et.SemiSparseSym3DTensor((naux, N, N), reach)
+    pair = il[0] * (il[0] + 1) // 2 + il[1]                       # == ravel_symmetric(mu, nu), nu <= mu
+    cols = np.array([t.offsets[int(p)] for p in pair[keep]])
+    assert cols.min() == 0 and np.unique(cols).size == cols.size == t.unique_dense_data.shape[1]
+    t.unique_dense_data[:, cols] = packed[:, keep]
+    A = rng.standard_normal((naux, naux)) / np.sqrt(naux)
+    j2c = A @ A.T + np.eye(naux)
+    TA = np.linalg.qr(rng.standard_normal((N, N)))[0][:, :n].copy()
+    S_abs = np.exp(-d / 6.0)
+    df = et.DFContext(j2c=j2c, lib=qlib); df.set_ints_semisparse(t)
+    dfd = et.DFContext(j2c=j2c, lib=qlib); dfd.set_ints(packed, N, layout="packed")
+    a, b = df.transform(TA, want_host=True), dfd.transform(TA, want_host=True)
+    scale = max(1.0, np.abs(b).max())
+    assert np.abs(a - b).max() < 1e-11 * scale
+    for eps in (1e-5, 3e-2):
+        a, b2 = df.transform(TA, S_abs=S_abs, MO_coeff_epsilon=eps), dfd.transform(TA, S_abs=S_abs, MO_coeff_epsilon=eps)
+        assert np.abs(a - b2).max() < 1e-11 * scale
+    assert np.abs(b2 - b).max() > 1e-9 * scale          # the coarser threshold did drop contributions
+    df.free(); dfd.free()
+
+
 def test_rccl_all_reduce_branch_single_rank(qlib):
     """The `nccl` (= RCCL) branch of be_parallel.all_reduce_sum -- device tensor, all-reduce, failure slot -- on a one-rank process
     group (the boxes of this pool have one GPU; the 8-GPU run is the driver's): values survive the round trip and a rank-local

@@ -34,14 +34,15 @@ bytes_of = {   # kernel-name fragment -> (algorithmic bytes of one large call, w
     "pack_pm_tiled_kernel<1>": ((npo * v * v + npo * npv + nmo * nmv) * 8, "tau -> (+/-) packed pair rows through LDS tiles (round 3)"),
     "ladder_pack_vvvv_pf_kernel": (2 * (npv * npv + nmv * nmv) * 8, "(+/-) ladder operands from the pair-first MO tensor"),
     "pack_pm_cols_kernel": ((o * v * v * v + o * v * (npv + nmv)) * 8, "(+/-) packed images of the ovvv block"),
-    "ladder_scatter_pm_kernel": (2 * N2 + (npo * npv + nmo * nmv) * 8, "ladder result -> t2 (r/w t2 + read R+/R-)"),
+    "ladder_scatter_pm_kernel": (N2 + (8 + 1) * (npo * npv + nmo * nmv) * 8, "ladder result -> t2: the 8 split-K slabs of R+/R- added on the way, + the hole-hole rows, t2 written (round 3: no reduction pass)"),
     "ladder_pack_tau_kernel": (N2 + (npo * npv + nmo * nmv) * 8, "tau -> (+/-) packed pair rows"),
-    "lincomb_kernel": (7 * N2, "DIIS extrapolation of the o^2 v^2 amplitudes: six stored vectors in, one out (the large calls of this kernel)"),
     "ccsd_ph_layouts_kernel": (7 * N2, "t2 -> T, T', u, u~, T'~, Theta layouts in one pass"),
-    "ccsd_finish_t2_kernel": (4 * N2, "(t2n + ovov + U + U^T) / D"),
+    "ccsd_finish_t2_rings_kernel": (6 * N2, "(t2n + ovov + U' + U'^T) / D with the two ring products read where the GEMMs leave them, each (i >= j) pair of tiles once (round 3)"),
+    "diis_push_kernel": (8 * N2, "DIIS push in one pass: e = t_new - t, Gram row against the five older error vectors (round 3)"),
+    "ccsd_extrapolate_energy_kernel": (9 * N2, "DIIS extrapolation (six vectors in), tau and the energy reduction in one pass (round 3)"),
+    "copy4_linear_kernel": (5 * N2, "W2 = W2base + ZC^T and R = Wvoov - Wvovo / 2 in one pass (the large calls of this kernel)"),
+    "copy4_transpose_kernel": (3 * N2, "transposing accumulation over an o^2 v^2 tensor (the large calls of this kernel)"),
     "small_k_update": (2 * N2, "rank-n_occ update of an o^2 v^2 tensor (r/w), MFMA"),
-    "dot_many_stage1": (7 * N2, "DIIS: the new error vector against the six stored ones"),
-    "splitk_reduce_kernel": ((8 + 1) * npo * npv * 8, "deterministic sum of 8 split-K slabs of the ladder"),
 }
 
 files = [f for a in sys.argv[1:] for f in glob.glob(a)]

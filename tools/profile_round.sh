@@ -29,6 +29,7 @@ python tools/transform_bench.py > $OUT/transform_bench.jsonl 2>&1
 QEMB_BATCH_TRACE=1 python tools/octane_quick.py 2>&1 | grep "RESULT\|qemb batch" > $OUT/octane_streams_lockstep.log
 QEMB_GRAPH=1 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/ktl -- python tools/octane_lockstep.py > $OUT/octane_lockstep.log 2>&1
 python tools/trace_lockstep.py gpurun_out/ktl > $OUT/octane_lockstep_trace.txt
+python tools/trace_lockstep_iteration.py gpurun_out/ktl > $OUT/octane_lockstep_iteration.txt
 rm -rf gpurun_out/ktl
 # 4. HBM traffic of the ladder dispatches (FETCH_SIZE / WRITE_SIZE, separate passes)
 bash tools/pmc_ladder.sh > $OUT/pmc_ladder.log 2>&1
