@@ -124,6 +124,13 @@ int qemb_op_scatter_pm_rows_add(int64_t o, int64_t ncols, const double* Xp, cons
 int qemb_op_ccsd_y_traces_add(int64_t o, int64_t v, const double* ZC, const double* ZB, double* Y, const double* add);
 int qemb_op_pack_w_pm_sum(int64_t o, const double* Wp, const double* X, const double* O1, double* Ap, int64_t lda_p, double* Am, int64_t lda_m);
 int qemb_op_ccsd_t1_small(int64_t o, int64_t v, const double* t1, const double* Lvv, const double* Loo, const double* Fov, double* t1n);
+/*   ccsd_t1_assemble: t1n = [ccsd_t1_small] + S[(ia),:] . Fov + Lph1[(ia),:] . t1 + sum_s PA[s] - sum_s PB[s]  (PA / PB: SA / SB slabs of o v doubles, strideA / strideB apart)
+ *   gemv_rows_two: two independent matrix-vector passes in one launch;  ccsd_y_traces_slabs: Y = traces + scale * sum of S slabs of `add` */
+int qemb_op_ccsd_t1_assemble(int64_t o, int64_t v, const double* t1, const double* Lvv, const double* Loo, const double* Fov, const double* S, const double* Lph1,
+                             const double* PA, int SA, int64_t strideA, const double* PB, int SB, int64_t strideB, double* t1n);
+int qemb_op_gemv_rows_two(int64_t rows1, int64_t cols1, const double* T1, int64_t ld1, const double* x1, double* y1, double a1, double b1,
+                          int64_t rows2, int64_t cols2, const double* T2, int64_t ld2, const double* x2, double* y2, double a2, double b2);
+int qemb_op_ccsd_y_traces_slabs(int64_t o, int64_t v, const double* ZC, const double* ZB, double* Y, const double* add, int S, int64_t stride, double scale);
 int qemb_op_gemv_rows2(int64_t rows, int64_t cols, const double* T1, int64_t ld1, const double* x1, const double* T2, int64_t ld2, const double* x2, double* y, double alpha, double beta);
 int qemb_op_ccsd_finish_t2_rings(int64_t o, int64_t v, double* t2n, const double* U, const double* OV, const double* RS, const double* M, const double* eo, const double* ev, double* t1n);
 /* The two single-launch ends of a CCSD iteration (csrc/ccsd.cpp post_issue / post_extrapolate), device pointers except where noted:

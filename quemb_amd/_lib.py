@@ -103,6 +103,9 @@ def _declare(lib):
     f("qemb_op_pack_w_pm_sum", I, L, P, P, P, P, L, P, L)
     f("qemb_op_ccsd_t1_small", I, L, L, P, P, P, P, P)
     f("qemb_op_gemv_rows2", I, L, L, P, L, P, P, L, P, P, D, D)
+    f("qemb_op_ccsd_t1_assemble", I, L, L, P, P, P, P, P, P, P, I, L, P, I, L, P)
+    f("qemb_op_gemv_rows_two", I, L, L, P, L, P, P, D, D, L, L, P, L, P, P, D, D)
+    f("qemb_op_ccsd_y_traces_slabs", I, L, L, P, P, P, P, I, L, D)
     f("qemb_op_ccsd_finish_t2_rings", I, L, L, P, P, P, P, P, P, P, P)
     f("qemb_op_diis_push", I, L, P, P, P, P, I, P, I, P, P)
     f("qemb_op_ccsd_extrapolate_energy", I, L, L, I, P, P, P, P, P, P)

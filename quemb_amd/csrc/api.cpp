@@ -148,6 +148,17 @@ int qemb_op_pack_w_pm_sum(int64_t o, const double* Wp, const double* X, const do
   return dev_pack_w_pm_sum(o, Wp, X, O1, Ap, lda_p, Am, lda_m);
 }
 int qemb_op_ccsd_t1_small(int64_t o, int64_t v, const double* t1, const double* Lvv, const double* Loo, const double* Fov, double* t1n) { return dev_ccsd_t1_small(o, v, t1, Lvv, Loo, Fov, t1n); }
+int qemb_op_ccsd_t1_assemble(int64_t o, int64_t v, const double* t1, const double* Lvv, const double* Loo, const double* Fov, const double* S, const double* Lph1,
+                             const double* PA, int SA, int64_t strideA, const double* PB, int SB, int64_t strideB, double* t1n) {
+  return dev_ccsd_t1_assemble(o, v, t1, Lvv, Loo, Fov, S, Lph1, PA, SA, strideA, PB, SB, strideB, t1n);
+}
+int qemb_op_gemv_rows_two(int64_t rows1, int64_t cols1, const double* T1, int64_t ld1, const double* x1, double* y1, double a1, double b1,
+                          int64_t rows2, int64_t cols2, const double* T2, int64_t ld2, const double* x2, double* y2, double a2, double b2) {
+  return dev_gemv_rows_two(rows1, cols1, T1, ld1, x1, y1, a1, b1, rows2, cols2, T2, ld2, x2, y2, a2, b2);
+}
+int qemb_op_ccsd_y_traces_slabs(int64_t o, int64_t v, const double* ZC, const double* ZB, double* Y, const double* add, int S, int64_t stride, double scale) {
+  return dev_ccsd_y_traces(o, v, ZC, ZB, Y, add, S, stride, scale);
+}
 int qemb_op_gemv_rows2(int64_t rows, int64_t cols, const double* T1, int64_t ld1, const double* x1, const double* T2, int64_t ld2, const double* x2, double* y, double alpha, double beta) {
   return dev_gemv_rows2(rows, cols, T1, ld1, x1, T2, ld2, x2, y, alpha, beta);
 }

@@ -108,6 +108,7 @@ int mo_transform(int n, int o, int nf, const double* eri_s4, double* X0, double*
 
 // ------------------------------------------------------------------------------------------------------------
 static void pick_xw_split(int64_t rows, int64_t oo, int64_t K, int& cfg, int& ks);
+static void pick_long_k(int64_t M, int64_t N, int64_t K, int tile_m, int tile_n, int cfg_in, int& cfg, int& ks);
 int CcsdSolver::setup(MoIntegrals&& ints, const double* mo_energy_dev) {
   I_ = std::move(ints);
   o_ = I_.o; v_ = I_.v; nf_ = I_.nf;
@@ -162,8 +163,19 @@ int CcsdSolver::setup(MoIntegrals&& ints, const double* mo_energy_dev) {
   QTRY(amp_.alloc(na)); QTRY(ampn_.alloc(na)); QTRY(diff_.alloc(na));
   for (DBuf* b : {&tau_, &T_, &Tp_, &S_, &W1_, &W2_, &W12_, &W12b_, &R_, &U_}) QTRY(b->alloc(N2));
   const int64_t NG = std::max<int64_t>(N2, oo * o * v);   // scratch also holds (o,o,v,o)-shaped temporaries
-  QTRY(G1_.alloc(NG)); QTRY(G2_.alloc(NG));
-  QTRY(Foo_.alloc(oo)); QTRY(Fvv_.alloc(vv)); QTRY(Fov_.alloc(nov)); QTRY(Z_.alloc(oo)); QTRY(Y_.alloc(vv));
+  QTRY(G2_.alloc(NG));
+  {  // split-K slabs of the few-output, long-K products stay where the slices wrote them (added up by y_traces / t1_assemble)
+    int cfg, ks;
+    pick_long_k(v, v, oo * v, 64, 64, (v <= 256) ? 1 : -1, cfg, ks);
+    QTRY(Fvv_.alloc((int64_t)gemm_slab_count(oo * v, ks) * vv));
+    const int cw = (o <= 32) ? 21 : -1;
+    pick_long_k(o, v, o * vv, 32, 128, cw, cfg, ks);
+    const int64_t sa = gemm_slab_count(o * vv, ks);
+    pick_long_k(o, v, o * v * o, 32, 128, cw, cfg, ks);
+    const int64_t sb = gemm_slab_count(o * v * o, ks);
+    QTRY(T1P_.alloc((sa + sb) * nov));
+  }
+  QTRY(Foo_.alloc(oo)); QTRY(Fov_.alloc(nov)); QTRY(Z_.alloc(oo)); QTRY(Y_.alloc(vv));
   QTRY(Ytmp_.alloc(vv)); QTRY(Loo_.alloc(oo)); QTRY(Lvv_.alloc(vv)); QTRY(Q_.alloc(oo)); QTRY(Wo_.alloc(oo * oo));
   QTRY(O1_.alloc(oo * oo)); QTRY(X_.alloc(oo * nov)); QTRY(scal_.alloc(8));
   {
@@ -251,10 +263,11 @@ void pick_pair_gemm(int64_t rows, int64_t cols, int& cfg, int& ks) {
 // C = A B^T (both operands K-contiguous) whose consumer adds the split-K slabs itself: with ks > 1 the slices' partial products stay in slabs
 // [S][M][N] at C (no reduction pass), else C is the plain product with leading dimension ldc
 struct SlabGemm { int S = 1; int64_t stride = 0, ld = 0; };
-static int gemm_slabs(int64_t M, int64_t N, int64_t K, const double* A, int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc, int cfg, int ks, SlabGemm& out) {
+static int gemm_slabs(int64_t M, int64_t N, int64_t K, const double* A, int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc, int cfg, int ks, SlabGemm& out,
+                      bool a_kc = true, bool b_kc = true) {
   GemmDesc g{};
   g.M = M; g.N = N; g.K = K; g.alpha = 1.0; g.beta = 0.0;
-  g.A = A; g.lda = lda; g.a_kcontig = 1; g.B = B; g.ldb = ldb; g.b_kcontig = 1;
+  g.A = A; g.lda = lda; g.a_kcontig = a_kc ? 1 : 0; g.B = B; g.ldb = ldb; g.b_kcontig = b_kc ? 1 : 0;
   g.C = C; g.ldc = ldc; g.batch = 1; g.cfg = cfg; g.ksplit = ks;
   out.S = gemm_slab_count(K, ks);
   if (out.S > 1) { g.keep_slabs = 1; out.stride = M * N; out.ld = N; }
@@ -269,6 +282,19 @@ static void pick_xw_split(int64_t rows, int64_t oo, int64_t K, int& cfg, int& ks
   const int64_t tiles = ((rows + 63) / 64) * ((oo + 63) / 64);
   cfg = 1;
   ks = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(64, K / 256), (512 + tiles - 1) / tiles));
+}
+// The K split dev_gemm would pick by itself for a product with `tiles` output tiles (gemm_f64.hip launch_cfg), spelled out so that the caller can keep the slabs
+static int auto_ksplit(int64_t tiles, int64_t K) {
+  if (tiles >= 256 || K < 1024) return 0;
+  int64_t S = (768 + tiles - 1) / tiles;
+  if (S > K / 256) S = K / 256;
+  return S > 1 ? (int)S : 0;
+}
+// few-output, long-K products (Fvv', the two ovvv / ovoo terms of the T1 equation): tile configuration and K split; cfg < 0: the dispatcher's own choice, no slabs
+static void pick_long_k(int64_t M, int64_t N, int64_t K, int tile_m, int tile_n, int cfg_in, int& cfg, int& ks) {
+  cfg = cfg_in; ks = 0;
+  if (cfg_in < 0) return;
+  ks = auto_ksplit(((M + tile_m - 1) / tile_m) * ((N + tile_n - 1) / tile_n), K);
 }
 // pp-ladder through the (+/-) pair-packed operands (see the comment in update_amps)
 int CcsdSolver::apply_ladder(const double* x, double* out, bool rows_packed, bool hh) {
@@ -337,9 +363,17 @@ int CcsdSolver::update_amps(double* t1n, double* t2n) {
   // Foo'[k,i] = sum_{lcd} (2 ovov[kcld] - ovov[kdlc]) tau[ilcd] = sum_l (2 Xw[i,l,k,l] - Xw[l,i,k,l]): a partial trace of Xw instead of
   // a pass over two o^2 v^2 tensors
   QTRY(dev_foo_from_x(o, Xw_, Loo_));
-  QTRY(gemm(v, v, oo * v, -1.0, tau_, v, false, Loovv_, v, false, 0.0, Fvv_, v, 1, 0, 0, 0, (v <= 256) ? 1 : -1));   // Fvv'[a,c]  (64 x 64 tiles: split-K supplies the blocks)
-  QTRY(dev_gemv_rows(nov, nov, Lovov_, nov, t1, Fov_, 1.0, 0.0));                  // Fov[k,c]
-  QTRY(dev_gemv_rows(oo, nov, LovooT_, nov, t1, Loo_, 1.0, 1.0));                  // Loo' = Foo' + Z[k,i]
+  // Fvv'[a,c] = -sum tau[klxa] Loovv[klxc]  (64 x 64 tiles: split-K supplies the blocks; the slabs are added up -- with the sign -- by the pass that forms Lvv' below)
+  SlabGemm sfvv;
+  double fvv_scale = -1.0;
+  {
+    int cfg, ks;
+    pick_long_k(v, v, oo * v, 64, 64, (v <= 256) ? 1 : -1, cfg, ks);
+    if (ks > 1) QTRY(gemm_slabs(v, v, oo * v, tau_, v, Loovv_, v, Fvv_, v, cfg, ks, sfvv, false, false));
+    else { QTRY(gemm(v, v, oo * v, -1.0, tau_, v, false, Loovv_, v, false, 0.0, Fvv_, v, 1, 0, 0, 0, cfg)); fvv_scale = 1.0; }
+  }
+  // Fov[k,c] = Lovov[(kc),:] . t1  and  Loo' = Foo' + Z[k,i], Z = LovooT[(ki),:] . t1: two matrix-vector passes, one launch
+  QTRY(dev_gemv_rows_two(nov, nov, Lovov_, nov, t1, Fov_, 1.0, 0.0, oo, nov, LovooT_, nov, t1, Loo_, 1.0, 1.0));
   // The two t1-contractions of ovvv are formed ONCE per iteration (each is one pass over the 1.28 GB block) and serve the
   // ring intermediates, the X1 term and -- through their k = i traces -- the Y intermediate:
   // (n_occ <= 32 columns / rows: 128 x 32 and 32 x 128 tiles instead of padding n_occ to a 64-wide tile, which made these
@@ -352,15 +386,28 @@ int CcsdSolver::update_amps(double* t1n, double* t2n) {
     QTRY(gemm(o, npv, v, 1.0, t1, v, true, ovvv_pk_, npv, false, 0.0, ZCp_, npv, o, 0, v * npv, o * npv, vec_ok ? cfg_wide : -1));
     QTRY(dev_unpack_tril_rows(oo, v, ZCp_, ZC_));
   }
-  QTRY(dev_ccsd_y_traces(o, v, ZC_, ZB_, Lvv_, Fvv_));                               // Lvv' = Fvv' + Y,  Y[a,c] = 2 sum_k ZC[k,k,a,c] - sum_k ZB[k,c,a,k]
+  QTRY(dev_ccsd_y_traces(o, v, ZC_, ZB_, Lvv_, Fvv_, sfvv.S, sfvv.stride, fvv_scale));                               // Lvv' = Fvv' + Y,  Y[a,c] = 2 sum_k ZC[k,k,a,c] - sum_k ZB[k,c,a,k]
 
   // ---- T1 equation
-  // (Fvv'+Y)_ac t1[ic] - (Foo'+Z)_ki t1[ka] + Fov_kc t1[ic] t1[ka]: four products of a few MFLOP, one launch
-  QTRY(dev_ccsd_t1_small(o, v, t1, Lvv_, Loo_, Fov_, t1n));
-  // + Fov_kc (2 t2[kica] - t2[ikca]) + (2 ovvo[kcai] - oovv[kiac]) t1[kc]: two passes over o^2 v^2 operands, one launch
-  QTRY(dev_gemv_rows2(nov, nov, S_, nov, Fov_, Lph1_, nov, t1, t1n, 1.0, 1.0));
-  QTRY(gemm(o, v, o * vv, 1.0, R_, o * vv, true, I_.ovvv, v, false, 1.0, t1n, v, 1, 0, 0, 0, cfg_wide));     // (2 ovvv[kdac] - ovvv[kcad]) t2[ikcd]
-  QTRY(gemm(o, v, o * v * o, -1.0, Lovoo_, o, false, T_, v, false, 1.0, t1n, v, 1, 0, 0, 0, cfg_wide));     // -(2 ovoo[lcki] - ovoo[kcli]) t2[klac]
+  // The two long-K terms first, as the slabs their K slices leave:  PA[i,a] = (2 ovvv[kdac] - ovvv[kcad]) t2[ikcd],  PB[i,a] = (2 ovoo[lcki] - ovoo[kcli]) t2[klac]
+  SlabGemm spa, spb;
+  double* PA = T1P_.p;
+  {
+    int cfg, ks;
+    pick_long_k(o, v, o * vv, 32, 128, cfg_wide, cfg, ks);
+    if (ks > 1) QTRY(gemm_slabs(o, v, o * vv, R_, o * vv, I_.ovvv, v, PA, v, cfg, ks, spa, true, false));
+    else { QTRY(gemm(o, v, o * vv, 1.0, R_, o * vv, true, I_.ovvv, v, false, 0.0, PA, v, 1, 0, 0, 0, cfg)); spa.S = 1; }
+  }
+  double* PB = PA + (int64_t)spa.S * nov;
+  {
+    int cfg, ks;
+    pick_long_k(o, v, o * v * o, 32, 128, cfg_wide, cfg, ks);
+    if (ks > 1) QTRY(gemm_slabs(o, v, o * v * o, Lovoo_, o, T_, v, PB, v, cfg, ks, spb, false, false));
+    else { QTRY(gemm(o, v, o * v * o, 1.0, Lovoo_, o, false, T_, v, false, 0.0, PB, v, 1, 0, 0, 0, cfg)); spb.S = 1; }
+  }
+  // t1n = (Fvv'+Y)_ac t1[ic] - (Foo'+Z)_ki t1[ka] + Fov_kc t1[ic] t1[ka] + Fov_kc (2 t2[kica] - t2[ikca]) + (2 ovvo[kcai] - oovv[kiac]) t1[kc] + PA - PB:
+  // the small products, the two passes over o^2 v^2 operands and the slab sums in one launch (a workgroup per element)
+  QTRY(dev_ccsd_t1_assemble(o, v, t1, Lvv_, Loo_, Fov_, S_, Lph1_, PA, spa.S, nov, PB, spb.S, nov, t1n));
 
   // ---- T2 equation: direct (unsymmetrised) part
   // (the bare ovov[i,a,j,b] term is added by the finishing kernel)

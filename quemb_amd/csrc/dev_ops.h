@@ -224,6 +224,14 @@ int dev_pack_w_pm(int64_t o, const double* W, double* Ap, int64_t lda_p, double*
 int dev_pack_w_pm_sum(int64_t o, const double* Wp, const double* X, const double* O1, double* Ap, int64_t lda_p, double* Am, int64_t lda_m);
 // t1n[i,a] = sum_c t1[i,c] Lvv[a,c] - sum_k Loo[k,i] t1[k,a] + sum_k Q[i,k] t1[k,a],  Q[i,k] = sum_c t1[i,c] Fov[k,c]   (the four small products of the T1 equation)
 int dev_ccsd_t1_small(int64_t o, int64_t v, const double* t1, const double* Lvv, const double* Loo, const double* Fov, double* t1n);
+// The whole right-hand side of the T1 equation in one launch, one workgroup per element (i,a):
+//   t1n[ia] = [the small products of dev_ccsd_t1_small] + S[(ia),:] . Fov + Lph1[(ia),:] . t1 + sum_s PA[s][(ia)] - sum_s PB[s][(ia)]
+// PA / PB: the two long-K products (ovvv . Theta, Lovoo . T) as the split-K slabs their GEMMs left (SA / SB of them, strideA / strideB apart)
+int dev_ccsd_t1_assemble(int64_t o, int64_t v, const double* t1, const double* Lvv, const double* Loo, const double* Fov, const double* S, const double* Lph1,
+                         const double* PA, int SA, int64_t strideA, const double* PB, int SB, int64_t strideB, double* t1n);
+// two independent matrix-vector passes in one launch: y1 = a1 T1 x1 + b1 y1 (rows1 x cols1) and y2 = a2 T2 x2 + b2 y2 (rows2 x cols2)
+int dev_gemv_rows_two(int64_t rows1, int64_t cols1, const double* T1, int64_t ld1, const double* x1, double* y1, double a1, double b1,
+                      int64_t rows2, int64_t cols2, const double* T2, int64_t ld2, const double* x2, double* y2, double a2, double b2);
 // y[r] = alpha (T1[r,:] . x1 + T2[r,:] . x2) + beta y[r]: two matrix-vector products in one pass
 int dev_gemv_rows2(int64_t rows, int64_t cols, const double* T1, int64_t ld1, const double* x1, const double* T2, int64_t ld2, const double* x2, double* y, double alpha, double beta);
 // F[k,i] = sum_l (2 X[i,l,k,l] - X[l,i,k,l]) for X[i,j,k,l] (o^4): the occupied-occupied intermediate sum_{lcd} (2 ovov[kcld] - ovov[kdlc]) tau[ilcd]
@@ -240,7 +248,8 @@ int dev_ccsd_ph_layouts(int64_t o, int64_t v, const double* t2, const double* t1
 int dev_small_k_update(int64_t batch, int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t sA, const double* B, int64_t sB,
                        double* C, int64_t sC);
 // Y[a,c] = 2 sum_k ZC[k,k,a,c] - sum_k ZB[k,c,a,k]   (ZC: [o][o][v][v], ZB: [o][v][v][o]; the k = i traces of the two ovvv.t1 products)
-int dev_ccsd_y_traces(int64_t o, int64_t v, const double* ZC, const double* ZB, double* Y, const double* add = nullptr);   // add ([v][v]): Y = traces + add
+// add ([v][v], or S split-K slabs of it `stride` apart that are added up in slab order): Y = traces + scale * add
+int dev_ccsd_y_traces(int64_t o, int64_t v, const double* ZC, const double* ZB, double* Y, const double* add = nullptr, int S = 1, int64_t stride = 0, double scale = 1.0);
 
 // ---- screening helpers of the semi-sparse DF transform ---------------------------------------------------------------
 // out[i] = (|x[i]| >= eps) ? 1 : 0

@@ -1075,8 +1075,25 @@ int dev_small_k_update(int64_t batch, int64_t M, int64_t N, int64_t K, double al
   return QEMB_OK;
 }
 
+// sum of the S split-K slabs of one element, in slab order (what the reduction pass forms); the common counts are spelled out so that their loads are
+// independent instructions the scheduler can issue together (a counted loop made the ladder scatter wait for each slab in turn: 56 -> 172 us)
+__device__ __forceinline__ double slab_sum(const double* __restrict__ p, int S, long long stride) {
+  switch (S) {
+    case 1: return p[0];
+    case 2: { const double a = p[0], b = p[stride]; return a + b; }
+    case 3: { const double a = p[0], b = p[stride], c = p[2 * stride]; return (a + b) + c; }
+    case 4: { const double a = p[0], b = p[stride], c = p[2 * stride], d = p[3 * stride]; return ((a + b) + c) + d; }
+    default: {
+      double acc = 0.0;
+      int sl = 0;
+      for (; sl + 4 <= S; sl += 4) { const double a = p[sl * stride], b = p[(sl + 1) * stride], c = p[(sl + 2) * stride], d = p[(sl + 3) * stride]; acc = (((acc + a) + b) + c) + d; }
+      for (; sl < S; ++sl) acc += p[sl * stride];
+      return acc;
+    }
+  }
+}
 __device__ __forceinline__ void ccsd_y_traces_kernel_body(const uint3 BID, const uint3 GDIM, long long o, long long v, const double* __restrict__ ZC, const double* __restrict__ ZB,
-                                                            double* __restrict__ Y, const double* __restrict__ add) {
+                                                            double* __restrict__ Y, const double* __restrict__ add, int S, long long stride, double scale) {
   const long long idx = (long long)BID.x * blockDim.x + threadIdx.x;
   if (idx >= v * v) return;
   const long long a = idx / v, c = idx % v;
@@ -1090,14 +1107,14 @@ __device__ __forceinline__ void ccsd_y_traces_kernel_body(const uint3 BID, const
     for (int q = 0; q < 4; ++q) s += 2.0 * zc[q] - zb[q];
   }
   for (; k < o; ++k) s += 2.0 * ZC[((k * o + k) * v + a) * v + c] - ZB[((k * v + c) * v + a) * o + k];
-  Y[idx] = add ? s + add[idx] : s;
+  Y[idx] = add ? s + scale * slab_sum(add + idx, S, stride) : s;
 }
 __global__ void __launch_bounds__(256) ccsd_y_traces_kernel(long long o, long long v, const double* __restrict__ ZC, const double* __restrict__ ZB,
-                                                            double* __restrict__ Y, const double* __restrict__ add) { ccsd_y_traces_kernel_body(make_uint3(blockIdx.x, blockIdx.y, blockIdx.z), make_uint3(gridDim.x, gridDim.y, gridDim.z), o, v, ZC, ZB, Y, add); }
-int dev_ccsd_y_traces(int64_t o, int64_t v, const double* ZC, const double* ZB, double* Y, const double* add) {
+                                                            double* __restrict__ Y, const double* __restrict__ add, int S, long long stride, double scale) { ccsd_y_traces_kernel_body(make_uint3(blockIdx.x, blockIdx.y, blockIdx.z), make_uint3(gridDim.x, gridDim.y, gridDim.z), o, v, ZC, ZB, Y, add, S, stride, scale); }
+int dev_ccsd_y_traces(int64_t o, int64_t v, const double* ZC, const double* ZB, double* Y, const double* add, int S, int64_t stride, double scale) {
   REQUIRE_INIT();
   if (v <= 0) return QEMB_OK;
-  hipLaunchKernelGGL(ccsd_y_traces_kernel, dim3((unsigned)((v * v + 255) / 256)), dim3(256), 0, g_stream, (long long)o, (long long)v, ZC, ZB, Y, add);
+  hipLaunchKernelGGL(ccsd_y_traces_kernel, dim3((unsigned)((v * v + 255) / 256)), dim3(256), 0, g_stream, (long long)o, (long long)v, ZC, ZB, Y, add, std::max(S, 1), (long long)stride, scale);
   HIP_TRY(hipGetLastError());
   return QEMB_OK;
 }
@@ -1441,23 +1458,6 @@ int dev_pack_pm_cols(int64_t rows, int64_t v, const double* in, double* Op, int6
   hipLaunchKernelGGL(pack_pm_cols_kernel, dim3((unsigned)std::min<int64_t>(rows, 1 << 20)), dim3(256), 0, g_stream, (long long)rows, (long long)v, in, Op, (long long)ldp, Om, (long long)ldm);
   HIP_TRY(hipGetLastError());
   return QEMB_OK;
-}
-// sum of the S split-K slabs of one element, in slab order (what the reduction pass forms); the common counts are spelled out so that their loads are
-// independent instructions the scheduler can issue together (a counted loop made the ladder scatter wait for each slab in turn: 56 -> 172 us)
-__device__ __forceinline__ double slab_sum(const double* __restrict__ p, int S, long long stride) {
-  switch (S) {
-    case 1: return p[0];
-    case 2: { const double a = p[0], b = p[stride]; return a + b; }
-    case 3: { const double a = p[0], b = p[stride], c = p[2 * stride]; return (a + b) + c; }
-    case 4: { const double a = p[0], b = p[stride], c = p[2 * stride], d = p[3 * stride]; return ((a + b) + c) + d; }
-    default: {
-      double acc = 0.0;
-      int sl = 0;
-      for (; sl + 4 <= S; sl += 4) { const double a = p[sl * stride], b = p[(sl + 1) * stride], c = p[(sl + 2) * stride], d = p[(sl + 3) * stride]; acc = (((acc + a) + b) + c) + d; }
-      for (; sl < S; ++sl) acc += p[sl * stride];
-      return acc;
-    }
-  }
 }
 __device__ __forceinline__ void scatter_pm_rows_kernel_body(const uint3 BID, const uint3 GDIM, long long o, long long ncols, const double* __restrict__ Xp, const double* __restrict__ Xm, double* __restrict__ out, const double* __restrict__ add,
                                                             int Sp, long long strideP, int Sm, long long strideM) {
@@ -2169,6 +2169,88 @@ int dev_ccsd_t1_small(int64_t o, int64_t v, const double* t1, const double* Lvv,
   HIP_TRY(hipGetLastError());
   return QEMB_OK;
 }
+// The right-hand side of the T1 equation, one workgroup per element r = (i,a): the o dot products Q[i,k] - Loo[k,i] first (waves over k), then every thread
+// strides over the two long rows S[r,:], Lph1[r,:], the short rows of the small products and the slabs of the two long-K products; one block sum.
+__device__ __forceinline__ void ccsd_t1_assemble_kernel_body(const uint3 BID, const uint3 GDIM, int o, int v, const double* __restrict__ t1, const double* __restrict__ Lvv,
+                                                               const double* __restrict__ Loo, const double* __restrict__ Fov, const double* __restrict__ Sm,
+                                                               const double* __restrict__ Lph1, const double* __restrict__ PA, int SA, long long strideA,
+                                                               const double* __restrict__ PB, int SB, long long strideB, double* __restrict__ t1n) {
+  __shared__ double w[1024];              // Q[i,k] - Loo[k,i], k < o <= 1024
+  __shared__ double sh[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const long long nov = (long long)o * v;
+  for (long long r = BID.x; r < nov; r += GDIM.x) {
+    const int i = (int)(r / v), a = (int)(r - (long long)i * v);
+    const double* ti = t1 + (long long)i * v;
+    for (int k = wave; k < o; k += nw) {
+      double acc = 0.0;
+      for (int c = lane; c < v; c += 64) acc += ti[c] * Fov[(long long)k * v + c];
+      acc = wave_sum(acc);
+      if (lane == 0) w[k] = acc - Loo[(long long)k * o + i];
+    }
+    const double* rs = Sm + r * nov;
+    const double* rl = Lph1 + r * nov;
+    double a1 = 0.0, a2 = 0.0;
+    for (long long c = threadIdx.x; c < nov; c += blockDim.x) { a1 += rs[c] * Fov[c]; a2 += rl[c] * t1[c]; }
+    double acc = a1 + a2;
+    for (int c = threadIdx.x; c < v; c += blockDim.x) acc += ti[c] * Lvv[(long long)a * v + c];
+    for (int sl = threadIdx.x; sl < SA; sl += blockDim.x) acc += PA[sl * strideA + r];
+    for (int sl = threadIdx.x; sl < SB; sl += blockDim.x) acc -= PB[sl * strideB + r];
+    __syncthreads();                      // w[] complete
+    for (int k = threadIdx.x; k < o; k += blockDim.x) acc += w[k] * t1[(long long)k * v + a];
+    const double tot = block_reduce<false>(acc, sh);
+    if (threadIdx.x == 0) t1n[r] = tot;
+  }
+}
+__global__ void __launch_bounds__(256) ccsd_t1_assemble_kernel(int o, int v, const double* __restrict__ t1, const double* __restrict__ Lvv, const double* __restrict__ Loo,
+                                                               const double* __restrict__ Fov, const double* __restrict__ Sm, const double* __restrict__ Lph1,
+                                                               const double* __restrict__ PA, int SA, long long strideA, const double* __restrict__ PB, int SB, long long strideB,
+                                                               double* __restrict__ t1n) {
+  ccsd_t1_assemble_kernel_body(make_uint3(blockIdx.x, blockIdx.y, blockIdx.z), make_uint3(gridDim.x, gridDim.y, gridDim.z), o, v, t1, Lvv, Loo, Fov, Sm, Lph1, PA, SA, strideA, PB, SB, strideB, t1n);
+}
+int dev_ccsd_t1_assemble(int64_t o, int64_t v, const double* t1, const double* Lvv, const double* Loo, const double* Fov, const double* S, const double* Lph1,
+                         const double* PA, int SA, int64_t strideA, const double* PB, int SB, int64_t strideB, double* t1n) {
+  REQUIRE_INIT();
+  if (o <= 0 || v <= 0) return QEMB_OK;
+  if (o > 1024) { set_error("dev_ccsd_t1_assemble: n_occ <= 1024"); return QEMB_ERR_ARG; }
+  hipLaunchKernelGGL(ccsd_t1_assemble_kernel, dim3((unsigned)std::min<int64_t>(o * v, 1 << 20)), dim3(256), 0, g_stream, (int)o, (int)v, t1, Lvv, Loo, Fov, S, Lph1,
+                     PA, std::max(SA, 0), (long long)strideA, PB, std::max(SB, 0), (long long)strideB, t1n);
+  HIP_TRY(hipGetLastError());
+  return QEMB_OK;
+}
+// two independent matrix-vector passes, one launch: the first rows1 workgroups take the first product, the rest the second
+__device__ __forceinline__ void gemv_rows_two_kernel_body(const uint3 BID, const uint3 GDIM, long long rows1, long long cols1, const double* T1, long long ld1, const double* x1, double* y1,
+                                                            double a1, double b1, long long rows2, long long cols2, const double* T2, long long ld2, const double* x2, double* y2,
+                                                            double a2, double b2) {
+  __shared__ double sh[4];
+  for (long long r = BID.x; r < rows1 + rows2; r += GDIM.x) {
+    const bool first = r < rows1;
+    const long long rr = first ? r : r - rows1, cols = first ? cols1 : cols2;
+    const double* row = first ? T1 + rr * ld1 : T2 + rr * ld2;
+    const double* x = first ? x1 : x2;
+    double acc = 0.0;
+    for (long long c = threadIdx.x; c < cols; c += blockDim.x) acc += row[c] * x[c];
+    const double s = block_reduce<false>(acc, sh);
+    if (threadIdx.x == 0) {
+      double* y = first ? y1 + rr : y2 + rr;
+      const double al = first ? a1 : a2, be = first ? b1 : b2;
+      *y = (be != 0.0) ? al * s + be * (*y) : al * s;
+    }
+  }
+}
+__global__ void __launch_bounds__(256) gemv_rows_two_kernel(long long rows1, long long cols1, const double* T1, long long ld1, const double* x1, double* y1, double a1, double b1,
+                                                            long long rows2, long long cols2, const double* T2, long long ld2, const double* x2, double* y2, double a2, double b2) {
+  gemv_rows_two_kernel_body(make_uint3(blockIdx.x, blockIdx.y, blockIdx.z), make_uint3(gridDim.x, gridDim.y, gridDim.z), rows1, cols1, T1, ld1, x1, y1, a1, b1, rows2, cols2, T2, ld2, x2, y2, a2, b2);
+}
+int dev_gemv_rows_two(int64_t rows1, int64_t cols1, const double* T1, int64_t ld1, const double* x1, double* y1, double a1, double b1,
+                      int64_t rows2, int64_t cols2, const double* T2, int64_t ld2, const double* x2, double* y2, double a2, double b2) {
+  REQUIRE_INIT();
+  if (rows1 + rows2 <= 0) return QEMB_OK;
+  hipLaunchKernelGGL(gemv_rows_two_kernel, dim3((unsigned)std::min<int64_t>(rows1 + rows2, 1 << 20)), dim3(256), 0, g_stream, (long long)rows1, (long long)cols1, T1, (long long)ld1, x1, y1, a1, b1,
+                     (long long)rows2, (long long)cols2, T2, (long long)ld2, x2, y2, a2, b2);
+  HIP_TRY(hipGetLastError());
+  return QEMB_OK;
+}
 __global__ void __launch_bounds__(256) gemv_rows_batched_kernel(long long rows, long long cols, long long nbatch, const double* __restrict__ T,
                                                                long long ldt, long long strideT, const double* __restrict__ x, long long stridex,
                                                                double* __restrict__ y, double alpha, double beta) {
@@ -2741,7 +2823,7 @@ static void register_groupable_kernels() {
   register_groupable<ccsd_ph_layouts_kernel_body, 256, long long, long long, const double*, const double*, double*, double*, double*, double*, double*, double*, int>((const void*)ccsd_ph_layouts_kernel);
   register_groupable<small_k_update_kernel_body, 256, long long, long long, long long, double, const double*, long long, const double*, long long, double*, long long, int>((const void*)small_k_update_kernel);
   register_groupable<small_k_update_mfma_kernel_body, 256, int, int, int, double, const double*, long long, const double*, long long, double*, long long>((const void*)small_k_update_mfma_kernel);
-  register_groupable<ccsd_y_traces_kernel_body, 256, long long, long long, const double*, const double*, double*, const double*>((const void*)ccsd_y_traces_kernel);
+  register_groupable<ccsd_y_traces_kernel_body, 256, long long, long long, const double*, const double*, double*, const double*, int, long long, double>((const void*)ccsd_y_traces_kernel);
   register_groupable<lincomb_kernel_body, 256, long long, LincombK, double, double*>((const void*)lincomb_kernel);
   register_groupable<ladder_pack_tau_kernel_body, 256, long long, long long, const double*, double*, long long, double*, long long>((const void*)ladder_pack_tau_kernel);
   register_groupable<scatter_pm_rows_kernel_body, 256, long long, long long, const double*, const double*, double*, const double*, int, long long, int, long long>((const void*)scatter_pm_rows_kernel);
@@ -2752,6 +2834,8 @@ static void register_groupable_kernels() {
   register_groupable<foo_from_x_kernel_body, 256, long long, const double*, double*>((const void*)foo_from_x_kernel);
   register_groupable<gemv_rows2_kernel_body, 256, long long, long long, const double*, long long, const double*, const double*, long long, const double*, double*, double, double>((const void*)gemv_rows2_kernel);
   register_groupable<ccsd_t1_small_kernel_body, 256, int, int, const double*, const double*, const double*, const double*, double*>((const void*)ccsd_t1_small_kernel);
+  register_groupable<ccsd_t1_assemble_kernel_body, 256, int, int, const double*, const double*, const double*, const double*, const double*, const double*, const double*, int, long long, const double*, int, long long, double*>((const void*)ccsd_t1_assemble_kernel);
+  register_groupable<gemv_rows_two_kernel_body, 256, long long, long long, const double*, long long, const double*, double*, double, double, long long, long long, const double*, long long, const double*, double*, double, double>((const void*)gemv_rows_two_kernel);
   register_groupable<ccsd_finish_t2_rings_kernel_body, 256, long long, long long, double*, const double*, const double*, const double*, const double*, const double*, const double*, double*>((const void*)ccsd_finish_t2_rings_kernel);
   register_groupable<gemv_rows_kernel_body, 256, long long, long long, const double*, long long, const double*, double*, double, double>((const void*)gemv_rows_kernel);
   register_groupable<contract_mid_stage1_body, 256, long long, long long, int, const double*, const double*, double*>((const void*)contract_mid_stage1);

@@ -289,6 +289,21 @@ int dev_ccsd_t1_small(int64_t o, int64_t v, const double* t1, const double* Lvv,
   }
   return 0;
 }
+int dev_ccsd_t1_assemble(int64_t o, int64_t v, const double* t1, const double* Lvv, const double* Loo, const double* Fov, const double* S, const double* Lph1,
+                         const double* PA, int SA, int64_t strideA, const double* PB, int SB, int64_t strideB, double* t1n) {
+  const int64_t nov = o * v;
+  std::vector<double> out((size_t)nov);
+  int rc = dev_ccsd_t1_small(o, v, t1, Lvv, Loo, Fov, out.data());
+  if (rc) return rc;
+  for (int64_t r = 0; r < nov; ++r) {
+    double s = out[(size_t)r];
+    for (int64_t c = 0; c < nov; ++c) s += S[r * nov + c] * Fov[c] + Lph1[r * nov + c] * t1[c];
+    for (int sl = 0; sl < SA; ++sl) s += PA[sl * strideA + r];
+    for (int sl = 0; sl < SB; ++sl) s -= PB[sl * strideB + r];
+    t1n[r] = s;
+  }
+  return 0;
+}
 int dev_ccsd_finish_t2_rings(int64_t o, int64_t v, double* t2n, const double* U, const double* OV, const double* RS, const double* M, const double* eo, const double* ev, double* t1n) {
   const int64_t ov = o * v;
   auto F = [&](int64_t i, int64_t j, int64_t a, int64_t b) {
@@ -322,11 +337,12 @@ int dev_small_k_update(int64_t batch, int64_t M, int64_t N, int64_t K, double al
   }
   return 0;
 }
-int dev_ccsd_y_traces(int64_t o, int64_t v, const double* ZC, const double* ZB, double* Y, const double* add) {
+int dev_ccsd_y_traces(int64_t o, int64_t v, const double* ZC, const double* ZB, double* Y, const double* add, int S, int64_t stride, double scale) {
   for (int64_t a = 0; a < v; ++a) for (int64_t c = 0; c < v; ++c) {
     double s = 0.0;
     for (int64_t k = 0; k < o; ++k) s += 2.0 * ZC[((k * o + k) * v + a) * v + c] - ZB[((k * v + c) * v + a) * o + k];
-    Y[a * v + c] = add ? s + add[a * v + c] : s;
+    if (add) { double t = 0.0; for (int sl = 0; sl < std::max(S, 1); ++sl) t += add[sl * stride + a * v + c]; s += scale * t; }
+    Y[a * v + c] = s;
   }
   return 0;
 }
@@ -387,6 +403,11 @@ int dev_gemv_rows2(int64_t rows, int64_t cols, const double* T1, int64_t ld1, co
     y[r] = (beta != 0.0) ? alpha * s + beta * y[r] : alpha * s;
   }
   return 0;
+}
+int dev_gemv_rows_two(int64_t rows1, int64_t cols1, const double* T1, int64_t ld1, const double* x1, double* y1, double a1, double b1,
+                      int64_t rows2, int64_t cols2, const double* T2, int64_t ld2, const double* x2, double* y2, double a2, double b2) {
+  int rc = dev_gemv_rows(rows1, cols1, T1, ld1, x1, y1, a1, b1);
+  return rc ? rc : dev_gemv_rows(rows2, cols2, T2, ld2, x2, y2, a2, b2);
 }
 int dev_gemv_rows_batched(int64_t rows, int64_t cols, int64_t nbatch, const double* T, int64_t ldt, int64_t strideT, const double* x,
                           int64_t stridex, double* y, double alpha, double beta) {

@@ -538,6 +538,21 @@ def test_ccsd_update_fused_passes(qlib, o, v):
     check(qlib.qemb_op_gemv_rows2(nov, nov, d[0].ptr, nov, d[1].ptr, d[2].ptr, nov, d[3].ptr, d[4].ptr, 0.75, 1.0))
     ref = 0.75 * (T1 @ x1 + T2 @ x2) + y0
     assert np.abs(d[4].numpy((nov,)) - ref).max() < 1e-12 * max(1.0, np.abs(ref).max())
+    # --- the whole T1 right-hand side in one launch: small products + the two long rows + slab sums
+    Sm, Lph1 = rng.standard_normal((nov, nov)), rng.standard_normal((nov, nov))
+    SA, SB = 5, 3
+    PA, PB = rng.standard_normal((SA, nov)), rng.standard_normal((SB, nov))
+    d2 = [DeviceBuffer.from_numpy(a) for a in (t1, Lvv, Loo, Fov, Sm, Lph1, PA, PB)]
+    check(qlib.qemb_op_ccsd_t1_assemble(o, v, d2[0].ptr, d2[1].ptr, d2[2].ptr, d2[3].ptr, d2[4].ptr, d2[5].ptr, d2[6].ptr, SA, nov, d2[7].ptr, SB, nov, dt1n.ptr))
+    ref = (t1 @ Lvv.T - Loo.T @ t1 + (t1 @ Fov.T) @ t1).ravel() + Sm @ Fov.ravel() + Lph1 @ t1.ravel() + PA.sum(0) - PB.sum(0)
+    assert np.abs(dt1n.numpy((nov,)) - ref).max() < 1e-11 * max(1.0, np.abs(ref).max())
+    # --- two independent matrix-vector passes in one launch
+    Ta, Tb = rng.standard_normal((nov, nov)), rng.standard_normal((o * o, nov))
+    xa, ya, yb = rng.standard_normal(nov), rng.standard_normal(nov), rng.standard_normal(o * o)
+    d2 = [DeviceBuffer.from_numpy(a) for a in (Ta, xa, ya, Tb, yb)]
+    check(qlib.qemb_op_gemv_rows_two(nov, nov, d2[0].ptr, nov, d2[1].ptr, d2[2].ptr, 1.0, 0.0, o * o, nov, d2[3].ptr, nov, d2[1].ptr, d2[4].ptr, 0.5, 1.0))
+    assert np.abs(d2[2].numpy((nov,)) - Ta @ xa).max() < 1e-12 * max(1.0, np.abs(Ta @ xa).max())
+    assert np.abs(d2[4].numpy((o * o,)) - (0.5 * (Tb @ xa) + yb)).max() < 1e-12 * max(1.0, np.abs(Tb @ xa).max())
     # --- finish_t2_rings (t2n and OV symmetric under (ij)(ab), as the ladder and the integrals leave them)
     def sym(x):
         return 0.5 * (x + x.transpose(1, 0, 3, 2))
@@ -591,6 +606,10 @@ def test_ccsd_update_fused_passes(qlib, o, v):
     dY = DeviceBuffer(v * v)
     check(qlib.qemb_op_ccsd_y_traces_add(o, v, d[0].ptr, d[1].ptr, dY.ptr, d[2].ptr))
     assert np.abs(dY.numpy((v, v)) - (2.0 * np.einsum("kkac->ac", ZCt) - np.einsum("kcak->ac", ZBt) + addv)).max() < 1e-12
+    slabs = rng.standard_normal((7, v, v))
+    dS = DeviceBuffer.from_numpy(slabs)
+    check(qlib.qemb_op_ccsd_y_traces_slabs(o, v, d[0].ptr, d[1].ptr, dY.ptr, dS.ptr, 7, v * v, -1.0))
+    assert np.abs(dY.numpy((v, v)) - (2.0 * np.einsum("kkac->ac", ZCt) - np.einsum("kcak->ac", ZBt) - slabs.sum(0))).max() < 1e-12
 
 
 @pytest.mark.parametrize("o,v,m", [(1, 1, 1), (3, 5, 2), (4, 33, 6), (7, 70, 8), (21, 21, 6), (20, 100, 6)])

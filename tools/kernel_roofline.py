@@ -40,8 +40,6 @@ bytes_of = {   # kernel-name fragment -> (algorithmic bytes of one large call, w
     "ccsd_finish_t2_rings_kernel": (6 * N2, "(t2n + ovov + U' + U'^T) / D with the two ring products read where the GEMMs leave them, each (i >= j) pair of tiles once (round 3)"),
     "diis_push_kernel": (8 * N2, "DIIS push in one pass: e = t_new - t, Gram row against the five older error vectors (round 3)"),
     "ccsd_extrapolate_energy_kernel": (9 * N2, "DIIS extrapolation (six vectors in), tau and the energy reduction in one pass (round 3)"),
-    "copy4_linear_kernel": (5 * N2, "W2 = W2base + ZC^T and R = Wvoov - Wvovo / 2 in one pass (the large calls of this kernel)"),
-    "copy4_transpose_kernel": (3 * N2, "transposing accumulation over an o^2 v^2 tensor (the large calls of this kernel)"),
     "small_k_update": (2 * N2, "rank-n_occ update of an o^2 v^2 tensor (r/w), MFMA"),
 }
 
