@@ -207,6 +207,12 @@ def test_bench_fragment_n220_against_oracle(qlib):
     fr.free()
 
 
+def test_wide_diis_space_takes_the_general_path(qlib):
+    """cc_diis_space = 10 > 8: the pass-by-pass end of the iteration on the device (the fused launches take up to eight stored vectors)."""
+    from test_hostlogic_fragment import check_wide_diis_space_takes_the_general_path
+    check_wide_diis_space_takes_the_general_path(qlib)
+
+
 def test_fragment_without_virtual_orbitals(qlib):
     from test_hostlogic_fragment import check_fragment_without_virtual_orbitals
     check_fragment_without_virtual_orbitals(qlib)

@@ -71,6 +71,28 @@ def test_fragment_solve_matches_oracle(hlib, n, o, nf, cen):
     assert np.abs(J - Jr).max() < 1e-11 and np.abs(K - Kr).max() < 1e-11
 
 
+def check_wide_diis_space_takes_the_general_path(lib):
+    """More stored DIIS vectors than the fused end-of-iteration launches take (eight): the pass-by-pass path (lincomb / dot_many / outer4 / reductions, stream waits)
+    runs instead and converges to the same amplitudes; the iteration counts differ (another extrapolation space), the fixed point does not."""
+    from quemb_amd.fragsolver import DeviceFragment, default_opts
+    n, o, nf = 9, 3, 3
+    h, e1, h1, veff0, veff = _problem(n, o, nf, 77)
+    outs = []
+    for space in (6, 10):
+        fr = DeviceFragment(n, nf, lib=lib)
+        fr.set_eri_s4(eri.pack_s4(e1))
+        fr.set_energy_data(h1, veff0, veff, 0.75, [0, 1])
+        opts = default_opts(lib, cc_conv_tol=1e-13, cc_conv_tol_normt=1e-11, scf_conv_tol=1e-13, scf_conv_tol_grad=1e-9, cc_diis_space=space)
+        outs.append(fr.solve(o, h, opts=opts, eeval=True))
+    a, b = outs
+    assert abs(a["e_corr_mo"] - b["e_corr_mo"]) < 1e-10 and np.abs(a["rdm1_emb"] - b["rdm1_emb"]).max() < 1e-8
+    assert np.allclose(a["e_frag"], b["e_frag"], atol=1e-9)
+
+
+def test_wide_diis_space_takes_the_general_path(hlib):
+    check_wide_diis_space_takes_the_general_path(hlib)
+
+
 def test_single_update_amps_matches_oracle(hlib):
     """One un-extrapolated amplitude update from the MP2 guess, then DIIS-free convergence to the same energy."""
     from quemb_amd.fragsolver import DeviceFragment, default_opts
