@@ -818,15 +818,7 @@ int dev_copy4(const Copy4Desc& cd) {
   } else {
     const long long n23 = c.d2 * c.d3;
     const unsigned gx = (unsigned)std::min<long long>((n23 + 255) / 256, 1 << 20);
-    // small tensors: a workgroup per (i0, i1) slice of a few hundred elements is bound by workgroup dispatch (~4 ns each: 16 us for the 5464 of six
-    // octane fragments); the kernel strides over i1 / i0, so fewer workgroups each take several slices -- about four elements per thread
-    unsigned gy2 = gy, gz2 = gz;
-    const long long want = std::max<long long>(1, c.d0 * c.d1 * n23 / 1024);
-    if ((long long)gx * gy * gz > want) {
-      gz2 = (unsigned)std::max<long long>(1, std::min<long long>(gz, want / ((long long)gx * gy)));
-      if ((long long)gx * gy * gz2 > want) gy2 = (unsigned)std::max<long long>(1, std::min<long long>(gy, want / gx));
-    }
-    hipLaunchKernelGGL(copy4_linear_kernel, dim3(gx, gy2, gz2), dim3(256), 0, g_stream, c);
+    hipLaunchKernelGGL(copy4_linear_kernel, dim3(gx, gy, gz), dim3(256), 0, g_stream, c);
   }
   HIP_TRY(hipGetLastError());
   return QEMB_OK;
