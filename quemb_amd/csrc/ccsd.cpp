@@ -108,7 +108,7 @@ int mo_transform(int n, int o, int nf, const double* eri_s4, double* X0, double*
 
 // ------------------------------------------------------------------------------------------------------------
 static void pick_xw_split(int64_t rows, int64_t oo, int64_t K, int& cfg, int& ks);
-static void pick_long_k(int64_t M, int64_t N, int64_t K, int tile_m, int tile_n, int cfg_in, int& cfg, int& ks);
+static void pick_long_k(int64_t M, int64_t N, int64_t K, int tile_m, int tile_n, int cfg_in, int& cfg, int& ks, bool many_slices);
 int CcsdSolver::setup(MoIntegrals&& ints, const double* mo_energy_dev) {
   I_ = std::move(ints);
   o_ = I_.o; v_ = I_.v; nf_ = I_.nf;
@@ -166,12 +166,12 @@ int CcsdSolver::setup(MoIntegrals&& ints, const double* mo_energy_dev) {
   QTRY(G2_.alloc(NG));
   {  // split-K slabs of the few-output, long-K products stay where the slices wrote them (added up by y_traces / t1_assemble)
     int cfg, ks;
-    pick_long_k(v, v, oo * v, 64, 64, (v <= 256) ? 1 : -1, cfg, ks);
+    pick_long_k(v, v, oo * v, 64, 64, (v <= 256) ? 1 : -1, cfg, ks, false);
     QTRY(Fvv_.alloc((int64_t)gemm_slab_count(oo * v, ks) * vv));
     const int cw = (o <= 32) ? 21 : -1;
-    pick_long_k(o, v, o * vv, 32, 128, cw, cfg, ks);
+    pick_long_k(o, v, o * vv, 32, 128, cw, cfg, ks, true);
     const int64_t sa = gemm_slab_count(o * vv, ks);
-    pick_long_k(o, v, o * v * o, 32, 128, cw, cfg, ks);
+    pick_long_k(o, v, o * v * o, 32, 128, cw, cfg, ks, true);
     const int64_t sb = gemm_slab_count(o * v * o, ks);
     QTRY(T1P_.alloc((sa + sb) * nov));
   }
@@ -291,10 +291,14 @@ static int auto_ksplit(int64_t tiles, int64_t K) {
   return S > 1 ? (int)S : 0;
 }
 // few-output, long-K products (Fvv', the two ovvv / ovoo terms of the T1 equation): tile configuration and K split; cfg < 0: the dispatcher's own choice, no slabs
-static void pick_long_k(int64_t M, int64_t N, int64_t K, int tile_m, int tile_n, int cfg_in, int& cfg, int& ks) {
+static void pick_long_k(int64_t M, int64_t N, int64_t K, int tile_m, int tile_n, int cfg_in, int& cfg, int& ks, bool many_slices = false) {
   cfg = cfg_in; ks = 0;
   if (cfg_in < 0) return;
   ks = auto_ksplit(((M + tile_m - 1) / tile_m) * ((N + tile_n - 1) / tile_n), K);
+  // a result of one tile (small fragments) whose consumer adds the slabs with all its threads (ccsd_t1_assemble): slices of ~64-96 k instead of ~288 -- a
+  // workgroup then runs 4-6 k-steps instead of 18, and there are hundreds of them (octane: 20 + 31 -> ~10 us each for the two T1 products).  (A scalar-FMA
+  // kernel for these shapes -- one workgroup per slice out of LDS, no padded MFMA tile -- was measured slower than the tiled kernel on the same slices.)
+  if (many_slices && ks > 1 && M <= 32 && N <= 32) ks = (int)std::min<int64_t>(512, K / 64);
 }
 // pp-ladder through the (+/-) pair-packed operands (see the comment in update_amps)
 int CcsdSolver::apply_ladder(const double* x, double* out, bool rows_packed, bool hh) {
@@ -394,14 +398,14 @@ int CcsdSolver::update_amps(double* t1n, double* t2n) {
   double* PA = T1P_.p;
   {
     int cfg, ks;
-    pick_long_k(o, v, o * vv, 32, 128, cfg_wide, cfg, ks);
+    pick_long_k(o, v, o * vv, 32, 128, cfg_wide, cfg, ks, true);
     if (ks > 1) QTRY(gemm_slabs(o, v, o * vv, R_, o * vv, I_.ovvv, v, PA, v, cfg, ks, spa, true, false));
     else { QTRY(gemm(o, v, o * vv, 1.0, R_, o * vv, true, I_.ovvv, v, false, 0.0, PA, v, 1, 0, 0, 0, cfg)); spa.S = 1; }
   }
   double* PB = PA + (int64_t)spa.S * nov;
   {
     int cfg, ks;
-    pick_long_k(o, v, o * v * o, 32, 128, cfg_wide, cfg, ks);
+    pick_long_k(o, v, o * v * o, 32, 128, cfg_wide, cfg, ks, true);
     if (ks > 1) QTRY(gemm_slabs(o, v, o * v * o, Lovoo_, o, T_, v, PB, v, cfg, ks, spb, false, false));
     else { QTRY(gemm(o, v, o * v * o, 1.0, Lovoo_, o, false, T_, v, false, 0.0, PB, v, 1, 0, 0, 0, cfg)); spb.S = 1; }
   }

@@ -505,6 +505,19 @@ def test_ccsd_single_pass_kernels(qlib, o, v):
         assert np.abs(dC.numpy((batch, M, N)) - ref).max() < 1e-12 * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.parametrize("shape", [(21, 21, 9261), (1, 32, 1024), (32, 32, 5000), (7, 3, 2049), (20, 31, 40000)])
+@pytest.mark.parametrize("a_kc,b_kc", [(1, 1), (1, 0), (0, 1), (0, 0)])
+def test_gemm_tiny_result_long_k(qlib, shape, a_kc, b_kc):
+    """Tiny results with a long K (the shapes of the Fvv' / T1 products of small fragments; split-K of a single tile): every operand layout, accumulate mode, odd
+    sizes.  (The skinny slab kernel those callers opt into is exercised by the small-fragment solves of test_gpu_fragment.py against the oracle.)"""
+    M, N, K = shape
+    rng = np.random.default_rng(M + 3 * N + K)
+    A = rng.standard_normal((1, M, K)); B = rng.standard_normal((1, K, N)); C0 = rng.standard_normal((1, M, N))
+    got = _gemm(qlib, A, B, C0, -0.7, 0.3, a_kc, b_kc)
+    ref = -0.7 * (A @ B) + 0.3 * C0
+    assert np.abs(got - ref).max() < 1e-11 * max(1.0, np.abs(ref).max())
+
+
 @pytest.mark.parametrize("o,v", [(1, 1), (2, 3), (4, 33), (7, 70), (21, 21), (5, 64), (3, 97)])
 def test_ccsd_update_fused_passes(qlib, o, v):
     """The fused passes of update_amps against NumPy: Woooo packed from its four terms, the four small T1 products, the double matrix-vector pass,
