@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <thread>
 #include <mutex>
 #include <string>
 #include <type_traits>
@@ -1887,6 +1888,7 @@ int dev_wait_flag(const void* flag_host, unsigned long long seq) {
       if (q != hipErrorNotReady) HIP_TRY(q);
     }
     __builtin_ia32_pause();
+    if ((spins & 0x7ff) == 0) std::this_thread::yield();      // several ranks x streams may share fewer cores than there are waiting threads
   }
 }
 struct DiisPushK { const double* y[8]; int m, self; };
