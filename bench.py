@@ -59,7 +59,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--frags-per-gpu", type=int, default=8)
-    ap.add_argument("--nstreams", type=int, default=3, help="fragments in flight per GPU (separate HIP streams, be_func(..., nstreams=k)); "
+    ap.add_argument("--cu-split", type=int, default=2, help="execution contexts on this many interleaved sets of compute units (qemb_ctx_partition; 0: whole chip each)")
+    ap.add_argument("--nstreams", type=int, default=4, help="fragments in flight per GPU (separate HIP streams, be_func(..., nstreams=k)); "
                     "the roofline of the ladder kernel is measured in a separate single-stream pass after the timed region")
     ap.add_argument("--n", type=int, default=220)
     ap.add_argument("--nocc", type=int, default=20)
@@ -562,6 +563,9 @@ def main():
     emap = ErrorMap(frs)
     pot = [0.0] * npot
     Nocc = float(F_total * N_EDGE) * 1.0
+    if args.nstreams > 1 and args.cu_split > 1 and not args.lib:
+        from quemb_amd.solver import set_cu_partition
+        set_cu_partition(lib, args.cu_split)
     nctx = lib.qemb_ctx_count(args.nstreams + 1) if args.nstreams > 1 else 1
     stats = {}
 
@@ -628,7 +632,7 @@ def main():
                                    f"n_occ={o} n_virt={v} (n={n}), DF-factorised ERIs naux={3 * n}, ERI scale={args.scale} (SURVEY 8d says 0.06: the oracle's "
                                    "own RHF/CCSD diverges there for n > ~100, DESIGN.md), one be_func / be_func_parallel sweep per step "
                                    "(update_heff + fragment RHF + MO transform + RCCSD to |dE|<1e-10 + 1-RDM + energies per fragment, solve_error, 1 all-reduce)",
-                       "fragments_per_gpu": F, "n_occ": o, "n_virt": v, "fragments_in_flight_per_gpu": args.nstreams,
+                       "fragments_per_gpu": F, "n_occ": o, "n_virt": v, "fragments_in_flight_per_gpu": args.nstreams, "cu_partition": (args.cu_split if args.nstreams > 1 else 0),
                        "parallelism": f"fragments sharded over {world} GPU(s) by the LPT partition, 1 all-reduce per sweep",
                        "transport": None if world == 1 else {"rccl": "library communicator: ncclAllReduce on a persistent RCCL communicator (qemb_comm_allreduce)",
                                                              "nccl": "torch.distributed nccl (RCCL)", "gloo": "torch.distributed gloo (rehearsal)"}[backend]
@@ -677,6 +681,9 @@ def main():
                 log("small-fragment regime: octane BE2 sweeps")
                 try:
                     import contextlib
+                    if args.nstreams > 1 and args.cu_split > 1:
+                        from quemb_amd.solver import set_cu_partition
+                        set_cu_partition(lib, 0)          # small fragments: every context on the whole chip again
                     with contextlib.redirect_stdout(sys.stderr):      # the BE driver prints its energies: stdout carries the ONE JSON line only
                         oc = octane_sweeps(lib)
                     res["octane_be2_sweep_ms"] = min(oc["streams6_ms"], oc["lockstep_ms"])

@@ -49,9 +49,13 @@ int qemb_d2d(void* dst, const void* src, size_t bytes);
 /* Execution contexts (one HIP stream + workspaces + block cache each; no reference counterpart -- the reference overlaps
  * fragments with a process pool, be_parallel.py:484).  qemb_ctx_count(n) makes contexts 0..n-1 available (0 = default) and
  * returns how many exist (or < 0); qemb_ctx_bind(k) binds the CALLING host thread to context k, so that several host
- * threads can each drive a fragment on their own stream (device timers of a context: qemb_ctx_timer_read, qemb_hip_ops.h). */
+ * threads can each drive a fragment on their own stream (device timers of a context: qemb_ctx_timer_read, qemb_hip_ops.h).
+ * qemb_ctx_partition(parts): contexts 1, 2, ... are spread over `parts` disjoint, interleaved sets of compute units (0 / 1: every context on the
+ * whole chip), so that the HBM-bound passes of one large fragment run beside the MFMA-bound products of another; existing contexts are drained and get
+ * new streams -- call it between sweeps, not while other threads are solving. */
 int qemb_ctx_count(int n);
 int qemb_ctx_bind(int k);
+int qemb_ctx_partition(int parts);
 
 /* ---------------------------------------------------------------- fragment solver (hot path) ----- */
 /* Replaces, per fragment, the body of be_func's loop -- molbe/solver.py:301-547 -- and its worker twin

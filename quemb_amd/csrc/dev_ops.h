@@ -31,6 +31,7 @@ int dev_sync_device();               // wait for every stream of the device (hip
 // (0 = default) and returns how many exist; dev_ctx_bind(k) binds the CALLING host thread to context k.
 int dev_ctx_count(int n);
 int dev_ctx_bind(int k);
+int dev_ctx_partition(int parts);
 int dev_alloc(void** p, size_t bytes);
 int dev_free(void* p);                // parks the block in a free list (see dev_trim)
 int dev_trim();                       // release every parked block back to the driver

@@ -102,6 +102,15 @@ def solve_ccsd(h, eri_s4, nsocc, dm0=None, *, n_frag=0, rdm_return=False, rdm2_r
     return out["t1"], out["t2"]
 
 
+def set_cu_partition(lib, parts):
+    """Spread the execution contexts that `map_fragments` creates from now on over `parts` disjoint, interleaved sets of compute units (qemb_ctx_partition; 0 or 1:
+    every context on the whole chip).  Two parts with four large fragments in flight let the HBM-bound passes of one fragment run beside the MFMA-bound products of
+    another: +0.7-2 % on the n = 220 sweep by box (small, launch-bound fragments lose: leave them on the whole chip).  Call it between sweeps: contexts that exist
+    are drained and get new streams."""
+    from ._lib import check
+    check(lib.qemb_ctx_partition(int(parts)), "qemb_ctx_partition", lib)
+
+
 def map_fragments(fn, frags, nstreams=1):
     """[fn(f) for f in frags], with up to `nstreams` fragments in flight at once: each worker thread is bound to its own
     execution context of the library (HIP stream + workspaces, qemb_ctx_bind), so fragments whose kernels are latency bound

@@ -131,6 +131,7 @@ int dev_lincomb(int64_t n, int nterms, const double* coef, const double* const* 
 int dev_ctx_timer_read(int k, int slot, double* total_ms, int64_t* count, int reset) { (void)k; (void)reset; return dev_timer_read(slot, total_ms, count); }
 int dev_ctx_count(int n) { (void)n; return 1; }
 int dev_ctx_bind(int k) { return k == 0 ? 0 : QEMB_ERR_ARG; }
+int dev_ctx_partition(int parts) { return (parts < 0 || parts > 8) ? QEMB_ERR_ARG : 0; }
 int dev_mirror_lower(int64_t n, double* A, int64_t lda) {
   for (int64_t r = 0; r < n; ++r) for (int64_t c = r + 1; c < n; ++c) A[r * lda + c] = A[c * lda + r];
   return 0;

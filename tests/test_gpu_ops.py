@@ -505,6 +505,44 @@ def test_ccsd_single_pass_kernels(qlib, o, v):
         assert np.abs(dC.numpy((batch, M, N)) - ref).max() < 1e-12 * max(1.0, np.abs(ref).max())
 
 
+def test_cu_partitioned_contexts_run_kernels(qlib):
+    """qemb_ctx_partition(2): contexts created afterwards live on interleaved halves of the compute units (CU-masked streams).  Two host threads, one per new
+    context, run a GEMM large enough to need several rounds of workgroups on half the chip; results equal NumPy and each other bit for bit."""
+    import threading
+    have = qlib.qemb_ctx_count(1)
+    assert have >= 1
+    check(qlib.qemb_ctx_partition(2))
+    try:
+        n = qlib.qemb_ctx_count(have + 2)
+        assert n >= have + 2
+        rng = np.random.default_rng(3)
+        A = rng.standard_normal((1, 700, 300)); B = rng.standard_normal((1, 300, 900)); C0 = np.zeros((1, 700, 900))
+        out, err = {}, []
+
+        def work(k):
+            try:
+                check(qlib.qemb_ctx_bind(k))
+                out[k] = _gemm(qlib, A, B, C0, 1.0, 0.0, 1, 0)
+            except Exception as e:  # noqa: BLE001
+                err.append(e)
+        ts = [threading.Thread(target=work, args=(have + i,)) for i in range(2)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        assert not err, err
+        ref = A @ B
+        assert np.abs(out[have] - ref).max() < 1e-11 * np.abs(ref).max() and np.array_equal(out[have], out[have + 1])
+        assert qlib.qemb_ctx_partition(9) < 0
+        check(qlib.qemb_ctx_partition(0))      # existing contexts are drained and get plain streams again; they keep working
+        out2 = {}
+        t = threading.Thread(target=lambda: (check(qlib.qemb_ctx_bind(have)), out2.update(r=_gemm(qlib, A, B, C0, 1.0, 0.0, 1, 0))))
+        t.start(); t.join()
+        assert np.array_equal(out2["r"], out[have])
+    finally:
+        check(qlib.qemb_ctx_partition(0))
+
+
 @pytest.mark.parametrize("shape", [(21, 21, 9261), (1, 32, 1024), (32, 32, 5000), (7, 3, 2049), (20, 31, 40000)])
 @pytest.mark.parametrize("a_kc,b_kc", [(1, 1), (1, 0), (0, 1), (0, 0)])
 def test_gemm_tiny_result_long_k(qlib, shape, a_kc, b_kc):
