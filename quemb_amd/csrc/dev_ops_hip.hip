@@ -106,7 +106,13 @@ int dev_init(int device) {
 // +0.7-2 % by box; contiguous halves measured worse than interleaved ones, three or four parts worse than two).  A runtime that refuses the mask gets a plain stream.
 static hipError_t create_ctx_stream(hipStream_t* stream, int j) {
   hipError_t e = hipErrorUnknown;
-  if (g_ctx_parts >= 2) {
+  // (under rocprofv3 the process crashed in its exit handlers when CU-masked streams existed -- and hung when they were destroyed from an atexit handler --, so a
+  //  profiled run keeps plain streams, as it keeps eager launches instead of graph replay)
+  static const bool profiled = [] {
+    const char* pre = std::getenv("LD_PRELOAD");
+    return std::getenv("ROCP_TOOL_LIBRARIES") != nullptr || (pre && std::strstr(pre, "rocprofiler"));
+  }();
+  if (g_ctx_parts >= 2 && !profiled) {
     hipDeviceProp_t prop;
     int ncu = 256;
     if (hipGetDeviceProperties(&prop, g_device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;

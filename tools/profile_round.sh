@@ -8,15 +8,15 @@ export TMPDIR=/tmp
 mkdir -p $OUT
 # 1. the bench command, one fragment in flight: per-kernel durations of kernels that own the device (agreement with the HIP-event timers)
 rm -rf gpurun_out/kt1
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kt1 -- python bench.py --nstreams 1 --steps 3 --warmup 1 --no-cpu-baseline --no-octane > $OUT/bench_nstreams1.json 2> $OUT/bench_nstreams1.err
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kt1 -- python bench.py --nstreams 1 --steps 3 --warmup 1 --no-cpu-baseline --no-octane > $OUT/bench_nstreams1.json 2> $OUT/bench_nstreams1.err || echo "rocprofv3 (nstreams 1) left with status $?"
 cp gpurun_out/kt1/*/*kernel_stats.csv $OUT/bench_nstreams1_kernel_stats.csv
 rm -rf gpurun_out/kt1
 # 2. the default bench command (three fragments in flight: kernels of different streams overlap, durations are contended)
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kt3 -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-octane > $OUT/bench_default.json 2> $OUT/bench_default.err
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kt3 -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-octane > $OUT/bench_default.json 2> $OUT/bench_default.err || echo "rocprofv3 (default) left with status $? (the profiler's own exit handlers; its CSV files are written before)"
 cp gpurun_out/kt3/*/*kernel_stats.csv $OUT/bench_default_kernel_stats.csv
 rm -rf gpurun_out/kt3
 # 3. one CCSD iteration, kernel by kernel
-rocprofv3 --kernel-trace --output-format csv -d gpurun_out/kt -- python tools/frag_bench.py 220 20 > $OUT/frag_bench.log 2>&1
+timeout -k 10 500 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/kt -- python tools/frag_bench.py 220 20 > $OUT/frag_bench.log 2>&1
 python tools/trace_iteration.py gpurun_out/kt > $OUT/iteration_kernel_trace.txt
 python tools/trace_solve.py gpurun_out/kt > $OUT/solve_phases.txt
 python tools/kernel_roofline.py "gpurun_out/kt/*/*kernel_trace.csv" > $OUT/kernel_roofline.jsonl
@@ -27,7 +27,7 @@ python tools/jacobi_bench.py 130 220 300 512 > $OUT/jacobi_bench.jsonl 2>&1
 QEMB_JACOBI_BLOCK=0 python tools/jacobi_bench.py 220 > $OUT/jacobi_bench_per_pair_rounds.jsonl 2>&1
 python tools/transform_bench.py > $OUT/transform_bench.jsonl 2>&1
 QEMB_BATCH_TRACE=1 python tools/octane_quick.py 2>&1 | grep "RESULT\|qemb batch" > $OUT/octane_streams_lockstep.log
-QEMB_GRAPH=1 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/ktl -- python tools/octane_lockstep.py > $OUT/octane_lockstep.log 2>&1
+QEMB_GRAPH=1 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/ktl -- python tools/octane_lockstep.py > $OUT/octane_lockstep.log 2>&1
 python tools/trace_lockstep.py gpurun_out/ktl > $OUT/octane_lockstep_trace.txt
 python tools/trace_lockstep_iteration.py gpurun_out/ktl > $OUT/octane_lockstep_iteration.txt
 rm -rf gpurun_out/ktl
