@@ -618,8 +618,10 @@ int CcsdSolver::iterate_post(double* e_corr, double* normt) {
 // the wait after step 1 / 2: on the host word the fused launch publishes behind its results, else on the stream
 int CcsdSolver::post_wait(int step) {
   if (!fused_post()) return dev_sync();
-  if (step == 1) return last_use_diis_ ? diis_[0].wait_row() : dev_wait_flag(host_scal_ + 3, seq_push_);
-  return dev_wait_flag(host_scal_ + 2, seq_energy_);
+  if (step == 1 && last_use_diis_) return diis_[0].wait_row();
+  QTRY(dev_wait_flag(step == 1 ? host_scal_ + 3 : host_scal_ + 2, step == 1 ? seq_push_ : seq_energy_));
+  post_pending_ = false;
+  return 0;
 }
 // (the fused launches take up to eight stored vectors and o^2 <= 16384 tiles; QEMB_POST_FUSED=0: the pass-by-pass form, for A/B runs)
 bool CcsdSolver::fused_post() const {
@@ -645,6 +647,7 @@ int CcsdSolver::post_issue() {
   }
   if (last_use_diis_) return diis_[0].push_diff_issue(out, amp_);
   const double* self[1] = {diff_.p};
+  post_pending_ = true;
   return dev_diis_push(na, out, amp_, diff_, amp_, 1, self, 0, scal_.p + 1, host_scal_ + 1, host_scal_ + 3, ++seq_push_);      // amp = t_new on the way
 }
 // step 2 (after a wait): the DIIS solve on the host; the extrapolated amplitudes, their tau and the energy
@@ -667,6 +670,7 @@ int CcsdSolver::post_extrapolate(double* normt) {
   if (last_use_diis_) QTRY(diis_[0].coefficients(&m, c, xs, &nn));
   else nn = host_scal_[1];
   *normt = std::sqrt(nn);
+  post_pending_ = true;
   return dev_ccsd_extrapolate_energy(o_, v_, m, c, xs, amp_, Loovv_, tau_, scal_, host_scal_, host_scal_ + 2, ++seq_energy_);
 }
 // step 3 (after a wait)

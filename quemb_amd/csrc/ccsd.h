@@ -108,9 +108,16 @@ class CcsdSolver {
   double* last_out_ = nullptr;      // where iterate_update put the new amplitudes; iterate_post continues from there
   double* host_scal_ = nullptr;     // pinned: [energy, |dt|^2] on their way back, then the words the fused launches publish behind them (energy step, push step)
   unsigned long long seq_push_ = 0, seq_energy_ = 0;      // ... and their expected values
+  bool post_pending_ = false;                             // a fused launch has been issued and not yet waited for
   bool last_use_diis_ = false, last_replayable_ = false;
  public:
-  ~CcsdSolver() { if (graph_) dev_graph_destroy(graph_); if (tape_) dev_tape_destroy(tape_); if (host_scal_) dev_pinned_free(host_scal_); }
+  // (a launch that will still write its result and sequence word into the pinned block -- a solve that left through an error between issue and wait -- must have
+  //  finished before the block is parked for the next solver: wait for the device in that case only)
+  ~CcsdSolver() {
+    if (graph_) dev_graph_destroy(graph_);
+    if (tape_) dev_tape_destroy(tape_);
+    if (host_scal_) { if (post_pending_) (void)dev_sync_device(); dev_pinned_free(host_scal_); }
+  }
   CcsdSolver() = default;
   CcsdSolver(const CcsdSolver&) = delete;
   CcsdSolver& operator=(const CcsdSolver&) = delete;

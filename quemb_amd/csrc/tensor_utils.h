@@ -295,7 +295,7 @@ class DeviceDIIS {
     return 0;
   }
  public:
-  ~DeviceDIIS() { if (row_host_) dev_pinned_free(row_host_); }
+  ~DeviceDIIS() { if (row_host_) { if (flagged_) (void)dev_sync_device(); dev_pinned_free(row_host_); } }      // (flagged_: a push was issued and never waited for -- an error exit)
   DeviceDIIS(DeviceDIIS&& o) noexcept : space_(o.space_), n_(o.n_), count_(o.count_), xs_(std::move(o.xs_)), es_(std::move(o.es_)), scal_(std::move(o.scal_)),
                                         B_(std::move(o.B_)), row_host_(o.row_host_), seq_(o.seq_), flagged_(o.flagged_), pending_slot_(o.pending_slot_) { o.row_host_ = nullptr; }
   DeviceDIIS(const DeviceDIIS&) = delete;
