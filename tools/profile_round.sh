@@ -27,6 +27,7 @@ python tools/jacobi_bench.py 130 220 300 512 > $OUT/jacobi_bench.jsonl 2>&1
 QEMB_JACOBI_BLOCK=0 python tools/jacobi_bench.py 220 > $OUT/jacobi_bench_per_pair_rounds.jsonl 2>&1
 python tools/transform_bench.py > $OUT/transform_bench.jsonl 2>&1
 QEMB_BATCH_TRACE=1 python tools/octane_quick.py 2>&1 | grep "RESULT\|qemb batch" > $OUT/octane_streams_lockstep.log
+python tools/octane_be3_sweeps.py 2>&1 | grep RESULT > $OUT/octane_be3_sweeps.log
 QEMB_GRAPH=1 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/ktl -- python tools/octane_lockstep.py > $OUT/octane_lockstep.log 2>&1
 python tools/trace_lockstep.py gpurun_out/ktl > $OUT/octane_lockstep_trace.txt
 python tools/trace_lockstep_iteration.py gpurun_out/ktl > $OUT/octane_lockstep_iteration.txt
