@@ -11,7 +11,7 @@ rm -rf gpurun_out/kt1
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kt1 -- python bench.py --nstreams 1 --steps 3 --warmup 1 --no-cpu-baseline --no-octane > $OUT/bench_nstreams1.json 2> $OUT/bench_nstreams1.err || echo "rocprofv3 (nstreams 1) left with status $?"
 cp gpurun_out/kt1/*/*kernel_stats.csv $OUT/bench_nstreams1_kernel_stats.csv
 rm -rf gpurun_out/kt1
-# 2. the default bench command (three fragments in flight: kernels of different streams overlap, durations are contended)
+# 2. the default bench command (four fragments in flight: kernels of different streams overlap, durations are contended; under the profiler the contexts keep plain streams)
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kt3 -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-octane > $OUT/bench_default.json 2> $OUT/bench_default.err || echo "rocprofv3 (default) left with status $? (the profiler's own exit handlers; its CSV files are written before)"
 cp gpurun_out/kt3/*/*kernel_stats.csv $OUT/bench_default_kernel_stats.csv
 rm -rf gpurun_out/kt3
