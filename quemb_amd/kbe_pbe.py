@@ -56,14 +56,15 @@ class KMeanField:
 
 class BE(mbe.BE):
     def __init__(self, mf: KMeanField, fobj, *, lo_method="lowdin", thr_bath=1.0e-10, int_transform="fragment-eris", eri_provider=None,
-                 df_source=None, unitcell=1, compute_hf=True, solver_opts=None, lib=None, distribute=True, nstreams=1, lockstep=False):
+                 df_source=None, unitcell=1, compute_hf=True, solver_opts=None, lib=None, distribute=True, nstreams=None, lockstep=None):
         if lo_method != "lowdin":
             raise NotImplementedError("only lo_method='lowdin' is mirrored (localisation is upstream of the hot path)")
         if getattr(fobj, "frozen_core", False):
             raise NotImplementedError("frozen core needs the mean-field potential of the core density from the periodic integral source")
         self.mf, self.fobj, self.lib = mf, fobj, lib
-        self.thr_bath, self.opts, self.nstreams = thr_bath, solver_opts, int(nstreams)
-        self.lockstep = bool(lockstep)
+        self.thr_bath, self.opts = thr_bath, solver_opts
+        self.nstreams = None if nstreams is None else int(nstreams)      # None: from the fragments' sizes at the first sweep (solver.sweep_mode)
+        self.lockstep = None if lockstep is None else bool(lockstep)
         self.int_transform, self.eri_provider, self.df_source = int_transform, eri_provider, df_source
         self.compute_hf = compute_hf
         self.unrestricted = False

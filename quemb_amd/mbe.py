@@ -31,7 +31,7 @@ def initialize_pot(n_frag, relAO_per_edge):
 
 class BE:
     def __init__(self, mf, fobj, *, lo_method="lowdin", thr_bath=1.0e-10, int_transform="in-core-hip", auxbasis=None,
-                 df_ints=None, nproc=1, ompnum=1, initialize_fragment_idx=None, solver_opts=None, lib=None, distribute=True, nstreams=1, lockstep=False,
+                 df_ints=None, nproc=1, ompnum=1, initialize_fragment_idx=None, solver_opts=None, lib=None, distribute=True, nstreams=None, lockstep=None,
                  eri_file=None, scratch_dir=None, restart=False, schmidt_method="subspace", MO_coeff_epsilon=1e-5, AO_coeff_epsilon=1e-10):
         if lo_method != "lowdin":
             raise NotImplementedError("only lo_method='lowdin' is mirrored (localisation is upstream of the hot path)")
@@ -44,8 +44,10 @@ class BE:
         self.auxbasis = auxbasis
         self.MO_coeff_epsilon, self.AO_coeff_epsilon = float(MO_coeff_epsilon), float(AO_coeff_epsilon)      # mbe.py:191-192
         self.opts = solver_opts
-        self.nstreams = int(nstreams)             # fragments in flight at once on this GPU (solver.map_fragments)
-        self.lockstep = bool(lockstep)            # all fragments of a sweep in one batched call (solver.solve_fragments): the small-fragment regime
+        # fragments in flight at once on this GPU (solver.map_fragments) / all fragments of a sweep in one batched call (solver.solve_fragments, the
+        # small-fragment regime).  None: chosen from the fragments' sizes at the first sweep (solver.sweep_mode)
+        self.nstreams = None if nstreams is None else int(nstreams)
+        self.lockstep = None if lockstep is None else bool(lockstep)
         self.unrestricted = False
         self.ebe_hf = 0.0
         self.ebe_tot = 0.0
@@ -249,6 +251,10 @@ class BE:
 
     # ------------------------------------------------------------------ sweeps
     def _sweep(self, pot, **kw):
+        if self.nstreams is None or self.lockstep is None:
+            from .solver import sweep_mode
+            mine = [f for i, f in enumerate(self.Fobjs) if self.world <= 1 or self.owner[i] == self.rank]
+            self.nstreams, self.lockstep = sweep_mode(mine, self.nstreams, self.lockstep)
         if self.world > 1:
             return be_func_parallel(pot, self.Fobjs, self.Nocc, "CCSD", self.enuc, owner=self.owner, opts=self.opts,
                                     stats=self.stats, emap=self.emap, nstreams=self.nstreams, lockstep=self.lockstep, **kw)

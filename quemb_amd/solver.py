@@ -102,6 +102,21 @@ def solve_ccsd(h, eri_s4, nsocc, dm0=None, *, n_frag=0, rdm_return=False, rdm2_r
     return out["t1"], out["t2"]
 
 
+def sweep_mode(frags, nstreams=None, lockstep=None):
+    """How the fragments of a sweep share the GPU when the caller leaves it open (BE(..., nstreams=None, lockstep=None)):
+    many small fragments (>= 5 of at most 64 embedding orbitals: launch bound) advance in lock step -- one grouped launch per operation for all of them;
+    otherwise several fragments are in flight on separate streams: up to six small ones, up to four of at most 256 orbitals, two beyond (device memory).
+    Measured on octane/STO-3G: BE2 (six fragments of ~42 orbitals) 40 ms serial, 18.3 ms six streams, 16.7 ms lock step; BE3 (four of ~55) 41 / 28 / 29 ms.
+    Every mode returns bit-identical results."""
+    frags = list(frags)
+    nmax = max((int(f.nao) for f in frags), default=0)
+    if lockstep is None:
+        lockstep = len(frags) >= 5 and nmax <= 64
+    if nstreams is None:
+        nstreams = 1 if len(frags) <= 1 else (min(6, len(frags)) if nmax <= 96 else min(4 if nmax <= 256 else 2, len(frags)))
+    return int(nstreams), bool(lockstep)
+
+
 def set_cu_partition(lib, parts):
     """Spread the execution contexts that `map_fragments` creates from now on over `parts` disjoint, interleaved sets of compute units (qemb_ctx_partition; 0 or 1:
     every context on the whole chip).  Two parts with four large fragments in flight let the HBM-bound passes of one fragment run beside the MFMA-bound products of
