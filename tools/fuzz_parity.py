@@ -7,10 +7,12 @@ from qemb_oracle import be, ccsd, ccsd_lambda, eri, rdm, scf
 from quemb_amd.fragsolver import DeviceFragment, default_opts
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 ncase = int(sys.argv[2]) if len(sys.argv) > 2 else 24
+nmin = int(sys.argv[3]) if len(sys.argv) > 3 else 3          # sizes: n in [nmin, nmax) -- 60 .. 100 reaches the split-K slab paths (packed pair index >= 2048)
+nmax = int(sys.argv[4]) if len(sys.argv) > 4 else 41
 worst = 0.0
 t0 = time.time()
 for case in range(ncase):
-    n = int(rng.integers(3, 41)); o = int(rng.integers(1, n)); nf = int(rng.integers(1, n + 1))
+    n = int(rng.integers(nmin, nmax)); o = int(rng.integers(1, n)); nf = int(rng.integers(1, n + 1))
     cen = sorted(set(int(x) for x in rng.integers(0, nf, size=min(nf, 3))))
     h, e1 = synthetic_fragment(n, o, 1000 + case, scale=0.05)
     mf = scf.rhf(h, e1, o, conv_tol=1e-12, conv_tol_grad=1e-8)
