@@ -720,6 +720,9 @@ int ccsd_kernel_lockstep(const std::vector<CcsdSolver*>& s, const std::vector<Cc
     // capturing update above is followed by its own post step below, which syncs too) -- and the merged run must finish before the post steps
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t0 = now();
+    bool batched_post = false;
+    int nactive = 0;
+    for (int f = 0; f < F; ++f) nactive += active[f] ? 1 : 0;
     if (!tapes.empty()) {
       // The merged sequence is issued as `nsplit` sequences of tapes.size() / nsplit members each, on the streams of the first nsplit
       // fragments' contexts: grouped launches of six small fragments are bound by workgroup dispatch (8-15 us each), two sequences of three
@@ -742,16 +745,31 @@ int ccsd_kernel_lockstep(const std::vector<CcsdSolver*>& s, const std::vector<Cc
         }
       }
       if (stats) stats->merged_runs += 1;
-      for (int c : run_ctx) { QTRY(dev_ctx_bind(c)); QTRY(dev_sync()); }
+      // Every active fragment ran in ONE merged sequence on the home stream and ends its iteration with the fused launches: those are collected and issued -- grouped,
+      // four launches for all fragments -- on the same stream, behind the merged run: no wait in between, and the host words tell when each fragment is through.
+      batched_post = (nsplit == 1 && nt == nactive);
+      for (int f = 0; f < F && batched_post; ++f) if (active[f] && !s[f]->fused_post()) batched_post = false;
+      if (!batched_post) for (int c : run_ctx) { QTRY(dev_ctx_bind(c)); QTRY(dev_sync()); }
     }
     const double t1 = now();
     if (stats) stats->ms_tapes += t1 - t0;
     struct PostTime { LockstepStats* st; double t1; double (*now)(); ~PostTime() { if (st) st->ms_post += now() - t1; } } post_time{stats, t1, +now};
-    for (int f = 0; f < F; ++f) if (active[f]) { QTRY(dev_ctx_bind(ctx[f])); QTRY(s[f]->post_issue()); }
-    for (int f = 0; f < F; ++f) if (active[f]) { QTRY(dev_ctx_bind(ctx[f])); QTRY(s[f]->post_wait(1)); QTRY(s[f]->post_extrapolate(&normt[f])); }
+    if (batched_post) {
+      struct Flush { bool open = false; ~Flush() { if (open) (void)dev_batch_flush(); } } guard;      // (an error exit must not leave the collector open)
+      QTRY(dev_ctx_bind(home_ctx));
+      QTRY(dev_batch_begin()); guard.open = true;
+      for (int f = 0; f < F; ++f) if (active[f]) QTRY(s[f]->post_issue());
+      guard.open = false; QTRY(dev_batch_flush());
+      QTRY(dev_batch_begin()); guard.open = true;
+      for (int f = 0; f < F; ++f) if (active[f]) { QTRY(s[f]->post_wait(1)); QTRY(s[f]->post_extrapolate(&normt[f])); }
+      guard.open = false; QTRY(dev_batch_flush());
+    } else {
+      for (int f = 0; f < F; ++f) if (active[f]) { QTRY(dev_ctx_bind(ctx[f])); QTRY(s[f]->post_issue()); }
+      for (int f = 0; f < F; ++f) if (active[f]) { QTRY(dev_ctx_bind(ctx[f])); QTRY(s[f]->post_wait(1)); QTRY(s[f]->post_extrapolate(&normt[f])); }
+    }
     for (int f = 0; f < F; ++f) {
       if (!active[f]) continue;
-      QTRY(dev_ctx_bind(ctx[f]));
+      if (!batched_post) QTRY(dev_ctx_bind(ctx[f]));
       QTRY(s[f]->post_wait(2));
       QTRY(s[f]->post_energy(&e[f]));
       n_iter[f] = it;

@@ -285,6 +285,11 @@ int dev_dot_many(int64_t n, const double* x, int m, const double* const* ys, dou
 // microsecond or two after the kernel's last store instead of the ~13 us of a stream wait.
 int dev_diis_push(int64_t n, const double* trial, const double* prev, double* e, double* xcopy, int m, const double* const* ys, int self,
                   double* row_dev, double* row_host, void* flag_host = nullptr, unsigned long long seq = 0);
+// Collected launches: between dev_batch_begin and dev_batch_flush the CALLING THREAD's dev_diis_push / dev_ccsd_extrapolate_energy calls are kept, not launched
+// (whatever context is bound at the time of the call); the flush issues them -- the same kernel of up to eight calls in one grouped launch -- on the stream of the
+// context bound at the flush.  The lock-step sweep ends an iteration of six fragments with four launches instead of twenty-four.
+int dev_batch_begin();
+int dev_batch_flush();
 // wait until the pinned host word holds `seq` (written by a kernel of THIS context's stream; a stream that has drained without writing it is an error)
 int dev_wait_flag(const void* flag_host, unsigned long long seq);
 // End of a CCSD iteration in one launch:  amp = sum_k coef[k] xs[k] over the packed amplitudes [t1 (o v) | t2 (o,o,v,v)] (nterms <= 8; amp may

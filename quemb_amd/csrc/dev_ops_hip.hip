@@ -1901,7 +1901,7 @@ static int post_finish_mode() {
   return m;
 }
 // second kernel of the QEMB_POST_FINISH=0 form: out[j] = sum of the np partials of reduction j, j < m, to device and pinned host memory
-__global__ void __launch_bounds__(256) finish_partials_kernel(int m, int np, const double* __restrict__ partial, double* out_dev, double* out_host,
+__device__ __forceinline__ void finish_partials_kernel_body(const uint3 BID, const uint3 GDIM, int m, int np, const double* __restrict__ partial, double* out_dev, double* out_host,
                                                               unsigned long long* flag_host, unsigned long long seq) {
   __shared__ double sh[4];
   double acc[8];
@@ -1917,6 +1917,10 @@ __global__ void __launch_bounds__(256) finish_partials_kernel(int m, int np, con
     if (threadIdx.x == 0) { out_dev[j] = r; out_host[j] = r; }
   }
   if (threadIdx.x == 0) publish_flag(flag_host, seq);
+}
+__global__ void __launch_bounds__(256) finish_partials_kernel(int m, int np, const double* __restrict__ partial, double* out_dev, double* out_host,
+                                                              unsigned long long* flag_host, unsigned long long seq) {
+  finish_partials_kernel_body(make_uint3(blockIdx.x, blockIdx.y, blockIdx.z), make_uint3(gridDim.x, gridDim.y, gridDim.z), m, np, partial, out_dev, out_host, flag_host, seq);
 }
 int dev_wait_flag(const void* flag_host, unsigned long long seq) {
   REQUIRE_INIT();
@@ -1937,6 +1941,33 @@ int dev_wait_flag(const void* flag_host, unsigned long long seq) {
   }
 }
 struct DiisPushK { const double* y[8]; int m, self; };
+struct ExtrapK { const double* x[8]; double c[8]; int n, write_amp; };
+// ---- collected launches: between dev_batch_begin and dev_batch_flush the calling thread's dev_diis_push / dev_ccsd_extrapolate_energy calls are not launched but
+// kept; the flush issues them as grouped launches (one per kernel for up to eight members) on the stream of the context bound THEN -- the lock-step sweep ends an
+// iteration of six fragments with four launches instead of twenty-four.  Every collected call gets its own partial-sum region.
+struct BatchEntry {
+  int kind;                 // 0 / 1: diis_push scalar / 16-byte; 2 / 3: extrapolate scalar / 16-byte
+  unsigned gx, gy; size_t lds;
+  // arguments, in kernel order (pointers into this entry are what the grouped launch reads)
+  long long n; const double* trial; const double* prev; double* e; double* xcopy; DiisPushK pk;
+  int o, v, rows; ExtrapK ek; double* amp; const double* L; double* tau;
+  double* partial; unsigned* counter; double* out_dev; double* out_host; int finish; unsigned long long* flag; unsigned long long seq;
+  int fin_m, fin_np;
+  void* params[16]; void* fparams[8];
+};
+struct BatchCollector { bool on = false; std::vector<BatchEntry> entries; double* scratch = nullptr; size_t scratch_regions = 0; };
+static thread_local BatchCollector t_batch;
+static constexpr size_t BATCH_REGION = 8 * NPART + 8;      // doubles per collected call
+static double* batch_region(size_t k) {
+  if (k >= t_batch.scratch_regions) {
+    const size_t want = std::max<size_t>(16, 2 * (k + 1));
+    double* p = nullptr;
+    if (hipMalloc((void**)&p, want * BATCH_REGION * sizeof(double)) != hipSuccess) return nullptr;
+    // (the old block, if any, may still be read by launches in flight: it is small and kept until the process ends)
+    t_batch.scratch = p; t_batch.scratch_regions = want;
+  }
+  return t_batch.scratch + k * BATCH_REGION;
+}
 // VEC2: two consecutive elements per thread and step through 16-byte accesses (n even, every vector 16-byte aligned).  All loads of a step are issued
 // before its stores: the vectors may alias each other (xcopy == prev in the first iteration), so a load written after a store would wait for it -- and
 // with it for the loads that fed the store: two dependent round trips to HBM per step instead of one.
@@ -2011,6 +2042,14 @@ int dev_diis_push(int64_t n, const double* trial, const double* prev, double* e,
   for (int j = 0; j < m; ++j) { k.y[j] = ys[j]; vec2 = vec2 && al16(ys[j]); }
   const int64_t nw = vec2 ? n / 2 : n;
   const int np = (int)std::max<int64_t>(1, std::min<int64_t>((nw + 1023) / 1024, NPART));
+  if (t_batch.on) {
+    BatchEntry b{};
+    b.kind = vec2 ? 1 : 0; b.gx = (unsigned)np; b.gy = 1; b.lds = 0;
+    b.n = n; b.trial = trial; b.prev = prev; b.e = e; b.xcopy = xcopy; b.pk = k;
+    b.out_dev = row_dev; b.out_host = row_host; b.finish = 0; b.flag = (unsigned long long*)flag_host; b.seq = seq; b.fin_m = m; b.fin_np = np;
+    t_batch.entries.push_back(b);
+    return QEMB_OK;
+  }
   if (vec2) hipLaunchKernelGGL(diis_push_kernel<true>, dim3(np), dim3(256), 0, g_stream, (long long)n, trial, prev, e, xcopy, k, g_partials, (unsigned*)(g_partials + 8 * NPART), row_dev, row_host, post_finish_mode(),
                                (unsigned long long*)flag_host, seq);
   else hipLaunchKernelGGL(diis_push_kernel<false>, dim3(np), dim3(256), 0, g_stream, (long long)n, trial, prev, e, xcopy, k, g_partials, (unsigned*)(g_partials + 8 * NPART), row_dev, row_host, post_finish_mode(),
@@ -2019,7 +2058,6 @@ int dev_diis_push(int64_t n, const double* trial, const double* prev, double* e,
   HIP_TRY(hipGetLastError());
   return QEMB_OK;
 }
-struct ExtrapK { const double* x[8]; double c[8]; int n, write_amp; };
 // grid (o * o tiles (i,j), chunks of `rows` rows a): the workgroup forms the new t1[i, its rows] and t1[j, :] in LDS, then streams its rows of the tile --
 // every load of a step before the stores (amp may be x[0]), 16-byte accesses when v is even
 template <bool VEC2>
@@ -2106,11 +2144,96 @@ int dev_ccsd_extrapolate_energy(int64_t o, int64_t v, int nterms, const double* 
   const int rows = (int)((v + chunks - 1) / chunks);
   chunks = (v + rows - 1) / rows;
   const size_t lds = (size_t)(v + rows) * sizeof(double);
+  if (t_batch.on) {
+    BatchEntry b{};
+    b.kind = vec2 ? 3 : 2; b.gx = (unsigned)(o * o); b.gy = (unsigned)chunks; b.lds = lds;
+    b.o = (int)o; b.v = (int)v; b.rows = rows; b.ek = k; b.amp = amp; b.L = L; b.tau = tau;
+    b.out_dev = e_dev; b.out_host = e_host; b.finish = 0; b.flag = (unsigned long long*)flag_host; b.seq = seq; b.fin_m = 1; b.fin_np = (int)(o * o * chunks);
+    t_batch.entries.push_back(b);
+    return QEMB_OK;
+  }
   if (vec2) hipLaunchKernelGGL(ccsd_extrapolate_energy_kernel<true>, dim3((unsigned)(o * o), (unsigned)chunks), dim3(256), lds, g_stream, (int)o, (int)v, rows, k, amp, L, tau,
                                g_partials, (unsigned*)(g_partials + 8 * NPART), e_dev, e_host, post_finish_mode(), (unsigned long long*)flag_host, seq);
   else hipLaunchKernelGGL(ccsd_extrapolate_energy_kernel<false>, dim3((unsigned)(o * o), (unsigned)chunks), dim3(256), lds, g_stream, (int)o, (int)v, rows, k, amp, L, tau,
                           g_partials, (unsigned*)(g_partials + 8 * NPART), e_dev, e_host, post_finish_mode(), (unsigned long long*)flag_host, seq);
   if (post_finish_mode() == 0) hipLaunchKernelGGL(finish_partials_kernel, dim3(1), dim3(256), 0, g_stream, 1, (int)(o * o * chunks), (const double*)g_partials, e_dev, e_host, (unsigned long long*)flag_host, seq);
+  HIP_TRY(hipGetLastError());
+  return QEMB_OK;
+}
+int dev_batch_begin() {
+  REQUIRE_INIT();
+  if (g_capturing || t_batch.on) { set_error("dev_batch_begin: capturing, or a batch is already open"); return QEMB_ERR_DEVICE; }
+  t_batch.on = true;
+  t_batch.entries.clear();
+  return QEMB_OK;
+}
+static void register_groupable_kernels();
+int dev_batch_flush() {
+  REQUIRE_INIT();
+  t_batch.on = false;
+  std::vector<BatchEntry> ent;
+  ent.swap(t_batch.entries);
+  if (ent.empty()) return QEMB_OK;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    register_groupable<diis_push_kernel_body<false>, 256, long long, const double*, const double*, double*, double*, DiisPushK, double*, unsigned*, double*, double*, int, unsigned long long*, unsigned long long>((const void*)diis_push_kernel<false>);
+    register_groupable<diis_push_kernel_body<true>, 256, long long, const double*, const double*, double*, double*, DiisPushK, double*, unsigned*, double*, double*, int, unsigned long long*, unsigned long long>((const void*)diis_push_kernel<true>);
+    register_groupable<ccsd_extrapolate_energy_kernel_body<false>, 256, int, int, int, ExtrapK, double*, const double*, double*, double*, unsigned*, double*, double*, int, unsigned long long*, unsigned long long>((const void*)ccsd_extrapolate_energy_kernel<false>);
+    register_groupable<ccsd_extrapolate_energy_kernel_body<true>, 256, int, int, int, ExtrapK, double*, const double*, double*, double*, unsigned*, double*, double*, int, unsigned long long*, unsigned long long>((const void*)ccsd_extrapolate_energy_kernel<true>);
+    register_groupable<finish_partials_kernel_body, 256, int, int, const double*, double*, double*, unsigned long long*, unsigned long long>((const void*)finish_partials_kernel);
+  });
+  if (!batch_region(ent.size() - 1)) { set_error("dev_batch_flush: scratch allocation failed"); return QEMB_ERR_ALLOC; }
+  const void* wrappers[4] = {(const void*)diis_push_kernel<false>, (const void*)diis_push_kernel<true>, (const void*)ccsd_extrapolate_energy_kernel<false>,
+                             (const void*)ccsd_extrapolate_energy_kernel<true>};
+  for (size_t k = 0; k < ent.size(); ++k) {
+    BatchEntry& b = ent[k];
+    b.partial = batch_region(k); b.counter = (unsigned*)(b.partial + 8 * NPART);
+    if (b.kind < 2) {
+      void* pp[13] = {&b.n, &b.trial, &b.prev, &b.e, &b.xcopy, &b.pk, &b.partial, &b.counter, &b.out_dev, &b.out_host, &b.finish, &b.flag, &b.seq};
+      std::memcpy(b.params, pp, sizeof(pp));
+    } else {
+      void* pp[14] = {&b.o, &b.v, &b.rows, &b.ek, &b.amp, &b.L, &b.tau, &b.partial, &b.counter, &b.out_dev, &b.out_host, &b.finish, &b.flag, &b.seq};
+      std::memcpy(b.params, pp, sizeof(pp));
+    }
+    void* fp[7] = {&b.fin_m, &b.fin_np, &b.partial, &b.out_dev, &b.out_host, &b.flag, &b.seq};
+    std::memcpy(b.fparams, fp, sizeof(fp));
+  }
+  std::vector<unsigned char> argbuf;
+  auto issue = [&](const void* func, const std::vector<BatchEntry*>& mem, bool finish_kernel) -> int {
+    for (size_t a = 0; a < mem.size(); a += GROUP_MAX) {
+      const size_t nb = std::min<size_t>(GROUP_MAX, mem.size() - a);
+      auto it = groupable().find(func);
+      if (nb >= 2 && it != groupable().end()) {
+        std::vector<GroupMember> gm;
+        size_t lds = 0;
+        for (size_t q = 0; q < nb; ++q) {
+          BatchEntry* b = mem[a + q];
+          gm.push_back(finish_kernel ? GroupMember{b->fparams, 1u, 1u, 1u} : GroupMember{b->params, b->gx, b->gy, 1u});
+          if (!finish_kernel) lds = std::max(lds, b->lds);
+        }
+        argbuf.resize(it->second.args_bytes + 16);
+        unsigned char* dst = (unsigned char*)(((uintptr_t)argbuf.data() + 15) & ~(uintptr_t)15);
+        const unsigned blocks = it->second.build(dst, gm.data(), (int)nb);
+        it->second.launch(dst, blocks, dim3(256), lds, g_stream);
+      } else {
+        for (size_t q = 0; q < nb; ++q) {
+          BatchEntry* b = mem[a + q];
+          if (finish_kernel) HIP_TRY(hipLaunchKernel(func, dim3(1), dim3(256), b->fparams, 0, g_stream));
+          else HIP_TRY(hipLaunchKernel(func, dim3(b->gx, b->gy), dim3(256), b->params, b->lds, g_stream));
+        }
+      }
+    }
+    return QEMB_OK;
+  };
+  for (int kind = 0; kind < 4; ++kind) {
+    std::vector<BatchEntry*> mem;
+    for (BatchEntry& b : ent) if (b.kind == kind) mem.push_back(&b);
+    if (mem.empty()) continue;
+    int rc = issue(wrappers[kind], mem, false);
+    if (rc) return rc;
+    rc = issue((const void*)finish_partials_kernel, mem, true);
+    if (rc) return rc;
+  }
   HIP_TRY(hipGetLastError());
   return QEMB_OK;
 }

@@ -366,6 +366,8 @@ int dev_dot_many(int64_t n, const double* x, int m, const double* const* ys, dou
   for (int j = 0; j < m; ++j) { double s = 0; for (int64_t i = 0; i < n; ++i) s += x[i] * ys[j][i]; o[j] = s; }
   return 0;
 }
+int dev_batch_begin() { return 0; }      // (the mock executes every call at once: nothing to collect)
+int dev_batch_flush() { return 0; }
 int dev_wait_flag(const void* flag_host, unsigned long long seq) { if (*(const unsigned long long*)flag_host == seq) return 0; set_error("dev_wait_flag: word not written"); return QEMB_ERR_DEVICE; }
 int dev_diis_push(int64_t n, const double* trial, const double* prev, double* e, double* xcopy, int m, const double* const* ys, int self, double* row_dev, double* row_host, void* flag_host, unsigned long long seq) {
   if (m <= 0 || m > 8 || self < 0 || self >= m) { set_error("dev_diis_push: 1 <= m <= 8 vectors, 0 <= self < m"); return QEMB_ERR_ARG; }
