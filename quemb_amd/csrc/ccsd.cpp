@@ -593,15 +593,22 @@ int CcsdSolver::prepare_tape(int peers) {
   }();
   if (!(graphs_enabled && small)) return 0;
   (void)deferred;
-  QTRY(update_amps(ampn_.p, ampn_.p + (int64_t)o_ * v_));      // dry pass: workspaces
-  ++eager_iters_;
-  const int rc = dev_graph_begin();
-  if (rc != 0) { graph_ok_ = false; return rc < 0 ? rc : 0; }
-  const int rc2 = update_amps(ampn_.p, ampn_.p + (int64_t)o_ * v_);
-  dev_tape_t t = nullptr;
-  const int rc3 = dev_tape_end(&t);
-  if (rc2 || rc3) { graph_ok_ = false; if (t) dev_tape_destroy(t); if (rc2) return rc2; return rc3 < 0 ? rc3 : 0; }
-  tape_ = t;
+  // Record straight away: a capture executes nothing, it only must not allocate -- and in the small-fragment regime update_amps works in buffers that setup() sized
+  // (slabs included).  Should a workspace have to grow after all, the capture fails on that allocation: then one eager pass into the staging buffer settles the
+  // workspaces -- it reads the amplitudes and writes only scratch -- and the recording is repeated.  (The unconditional eager pass cost every fragment of every sweep
+  // ~46 launches.)
+  static const bool dry_first = std::getenv("QEMB_TAPE_DRY_PASS") != nullptr;
+  for (int attempt = dry_first ? 1 : 0; attempt < 2; ++attempt) {
+    if (attempt == 1) { QTRY(update_amps(ampn_.p, ampn_.p + (int64_t)o_ * v_)); ++eager_iters_; }
+    const int rc = dev_graph_begin();
+    if (rc != 0) { graph_ok_ = false; return rc < 0 ? rc : 0; }
+    const int rc2 = update_amps(ampn_.p, ampn_.p + (int64_t)o_ * v_);
+    dev_tape_t t = nullptr;
+    const int rc3 = dev_tape_end(&t);
+    if (!rc2 && !rc3) { tape_ = t; return 0; }
+    if (t) dev_tape_destroy(t);
+    if (attempt == 1) { graph_ok_ = false; if (rc2) return rc2; return (rc3 < 0) ? rc3 : 0; }      // (a failed first attempt: whatever went wrong shows again in the eager pass)
+  }
   return 0;
 }
 
