@@ -61,6 +61,12 @@ static int density_from_mos(int n, int o, const double* C, double* dm) {
   return gemm(n, n, o, 2.0, C, n, true, C, n, true, 0.0, dm, n);
 }
 
+static int fock_from_jk(int64_t n2, const double* h, const double* J, const double* K, double* F) {
+  const double c[3] = {1.0, 1.0, -0.5};
+  const double* xs[3] = {h, J, K};
+  return dev_lincomb(n2, 3, c, xs, 0.0, F);
+}
+
 static int rhf_loop(int n, int o, const double* h, const double* eri, const double* eri_s4, double* dm, const ScfOptions& opt,
                     double* C, double* eps, double* J, double* K, ScfResult* res, bool c_is_guess) {
   const int64_t n2 = (int64_t)n * n;
@@ -76,8 +82,8 @@ static int rhf_loop(int n, int o, const double* h, const double* eri, const doub
   int cyc = 0;
   for (cyc = 0; cyc < opt.max_cycle; ++cyc) {
     QTRY(build_jk(n, eri, dm, J, K, eri_s4));
-    QTRY(dcopy(n2, h, F)); QTRY(axpby(n2, 1.0, J, 1.0, F)); QTRY(axpby(n2, -0.5, K, 1.0, F));
-    QTRY(dcopy(n2, h, hpf)); QTRY(axpby(n2, 1.0, F, 1.0, hpf));
+    QTRY(fock_from_jk(n2, h, J, K, F));                                   // F = h + J - K/2, one pass (small fragments are launch bound: five launches before)
+    QTRY(lincomb2(n2, 1.0, h, 1.0, F, hpf));
     QTRY(dev_dot(n2, hpf, dm, scal));                                   // 2 E = <h + F, D>
     QTRY(gemm_nn(n, n, n, 1.0, F, dm, 0.0, err));                       // FD - DF   (S = I)
     QTRY(gemm_nn(n, n, n, -1.0, dm, F, 1.0, err));
@@ -119,7 +125,7 @@ static int rhf_loop(int n, int o, const double* h, const double* eri, const doub
   // already IS the Fock matrix of dm (the loop left between the convergence test and the density update): no third J/K build.
   if (!res->converged) {
     QTRY(build_jk(n, eri, dm, J, K, eri_s4));
-    QTRY(dcopy(n2, h, F)); QTRY(axpby(n2, 1.0, J, 1.0, F)); QTRY(axpby(n2, -0.5, K, 1.0, F));
+    QTRY(fock_from_jk(n2, h, J, K, F));
   }
   if (have_prev) {
     // in the orbitals of the last cycle the converged Fock matrix is diagonal up to the SCF residual: the Jacobi sweeps need two or
