@@ -110,8 +110,8 @@ def sweep_mode(frags, nstreams=None, lockstep=None):
     Every mode returns bit-identical results."""
     frags = list(frags)
     nmax = max((int(f.nao) for f in frags), default=0)
-    if lockstep is None:
-        lockstep = len(frags) >= 5 and nmax <= 64
+    if lockstep is None:          # (an explicit nstreams is a request for that many streams, not for the lock step)
+        lockstep = nstreams is None and len(frags) >= 5 and nmax <= 64
     if nstreams is None:
         nstreams = 1 if len(frags) <= 1 else (min(6, len(frags)) if nmax <= 96 else min(4 if nmax <= 256 else 2, len(frags)))
     return int(nstreams), bool(lockstep)

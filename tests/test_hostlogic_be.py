@@ -621,5 +621,6 @@ def test_sweep_mode_choice():
     assert sweep_mode([F(nao=220)] * 8) == (4, False)          # large fragments: four in flight
     assert sweep_mode([F(nao=400)] * 8) == (2, False)
     assert sweep_mode([F(nao=42)]) == (1, False)
-    assert sweep_mode([F(nao=42)] * 6, nstreams=2) == (2, True) and sweep_mode([F(nao=42)] * 6, lockstep=False) == (6, False)
+    assert sweep_mode([F(nao=42)] * 6, nstreams=2) == (2, False) and sweep_mode([F(nao=42)] * 6, lockstep=False) == (6, False)
+    assert sweep_mode([F(nao=42)] * 6, nstreams=2, lockstep=True) == (2, True)
     assert sweep_mode([]) == (1, False)
