@@ -2175,6 +2175,7 @@ int dev_batch_flush() {
   ent.swap(t_batch.entries);
   if (ent.empty()) return QEMB_OK;
   static std::once_flag once;
+  std::lock_guard<std::mutex> reg_lock(g_plan_mutex);      // the registry of groupable kernels is filled lazily, also by the first dev_tape_run of another thread
   std::call_once(once, [] {
     register_groupable<diis_push_kernel_body<false>, 256, long long, const double*, const double*, double*, double*, DiisPushK, double*, unsigned*, double*, double*, int, unsigned long long*, unsigned long long>((const void*)diis_push_kernel<false>);
     register_groupable<diis_push_kernel_body<true>, 256, long long, const double*, const double*, double*, double*, DiisPushK, double*, unsigned*, double*, double*, int, unsigned long long*, unsigned long long>((const void*)diis_push_kernel<true>);
