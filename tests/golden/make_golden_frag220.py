@@ -7,7 +7,9 @@ n^4 tensor is 18.7 GB and is not formed), assembles the MO blocks from the trans
 amplitude equations (ccsd_lean.update_amps == ccsd.update_amps, tests/test_oracle_ccsd.py): 3 plain updates from the MP2 guess (the
 number bench.py's parity field compares) and the DIIS solve to |dE| < 1e-11.  About ten minutes on 8 cores, hence stored.
 
-    python tests/golden/make_golden_frag220.py        (writes tests/golden/frag220.npz)
+    python tests/golden/make_golden_frag220.py            (writes tests/golden/frag220.npz: fragment 0)
+    python tests/golden/make_golden_frag220.py 1 2        (round 4: fragments 1 and 2 of the same sweep, seeds 20260804 / 05,
+                                                           -> tests/golden/frag220_f1.npz, frag220_f2.npz)
 """
 import sys
 import time
@@ -33,9 +35,11 @@ def bench_fragment(n, seed, scale):
     return h, B
 
 
-def main():
+def main(frag=0):
     t0 = time.time()
-    h, B = bench_fragment(N, SEED, SCALE)
+    seed = SEED + frag
+    out = "frag220.npz" if frag == 0 else f"frag220_f{frag}.npz"
+    h, B = bench_fragment(N, seed, SCALE)
     naux = B.shape[0]
     Bf = B.reshape(naux, -1)
 
@@ -60,11 +64,12 @@ def main():
     conv, ecc, t1, t2, nit = ccsd_lean.kernel(er, conv_tol=1e-11, conv_tol_normt=1e-9)
     assert conv
     r1 = rdm.make_rdm1_ccsd_t1(t1)
-    np.savez_compressed(ROOT / "tests" / "golden" / "frag220.npz", n=N, o=O, seed=SEED, scale=SCALE, e_scf=mf["e_tot"], mo_energy=mf["mo_energy"],
+    np.savez_compressed(ROOT / "tests" / "golden" / out, n=N, o=O, seed=seed, scale=SCALE, e_scf=mf["e_tot"], mo_energy=mf["mo_energy"],
                         e_mp2=e_mp2, e_corr_3_plain_updates=e3, e_corr=ecc, n_iter=nit, rdm1_emb=C @ r1 @ C.T * 0.5,
                         t1_norm=np.linalg.norm(t1), t2_norm=np.linalg.norm(t2))
-    print(f"frag220: E_corr {ecc:.12f} in {nit} iterations ({time.time() - t0:.0f} s)")
+    print(f"{out}: E_corr {ecc:.12f} in {nit} iterations ({time.time() - t0:.0f} s)", flush=True)
 
 
 if __name__ == "__main__":
-    main()
+    for f in ([int(a) for a in sys.argv[1:]] or [0]):
+        main(f)
