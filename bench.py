@@ -59,6 +59,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--frags-per-gpu", type=int, default=8)
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak (the driver's contract): --frags-per-gpu fragments on every GPU; strong: --frags-total fragments shared out over the GPUs")
+    ap.add_argument("--frags-total", type=int, default=64, help="fragments of the whole job under --scaling strong (BASELINE configs[2]: 64)")
     ap.add_argument("--cu-split", type=int, default=2, help="execution contexts on this many interleaved sets of compute units (qemb_ctx_partition; 0: whole chip each)")
     ap.add_argument("--nstreams", type=int, default=4, help="fragments in flight per GPU (separate HIP streams, be_func(..., nstreams=k)); "
                     "the roofline of the ladder kernel is measured in a separate single-stream pass after the timed region")
@@ -553,8 +556,19 @@ def main():
     if nf < 2 * N_EDGE:
         raise SystemExit(f"--n {n}: the synthetic ring needs at least {2 * N_EDGE} fragment sites (n >= {4 * N_EDGE})")
     opts = default_opts(lib)
-    F_total = F * world
+    F_total = F * world if args.scaling == "weak" else args.frags_total
+    if F_total < world:
+        raise SystemExit(f"--scaling strong: {F_total} fragments cannot occupy {world} ranks")
     owner = partition_fragments([fragment_cost(n, o)] * F_total, world)     # the product's LPT partition (equal costs: F per rank)
+    F = max(owner.count(r) for r in range(world))
+    if not args.lib:
+        # resident per fragment: the 4-fold packed ERIs; beside them the pooled work space of the fragments in flight
+        npair = n * (n + 1) // 2
+        need = F * 8.0 * npair * npair + args.nstreams * 3.5 * 8.0 * n * n * npair
+        free_b, total_b = C.c_size_t(), C.c_size_t()
+        if lib.qemb_mem_info(C.byref(free_b), C.byref(total_b)) == 0 and need > 0.97 * free_b.value:
+            raise SystemExit(f"bench.py: {F} fragments of n={n} per GPU need ~{need / 1e9:.0f} GB, {free_b.value / 1e9:.0f} GB are free "
+                             f"(--scaling {args.scaling}: lower --frags-{'per-gpu' if args.scaling == 'weak' else 'total'} or use more GPUs)")
 
     # ---- set-up (untimed): fragments resident in HBM, initial fragment SCF for dm0 (BE.initialize does the same)
     log(f"setting up {F} fragments per GPU (n={n}, n_occ={o}), {F_total} in the ring")
@@ -626,9 +640,9 @@ def main():
         res = {
             "metric": "fragment CCSD iters/sec (full BE sweep over synthetic n_occ=20 n_virt=200 fragments); corr-E error vs oracle in parity_max_abs_err_Eh / parity_n220_abs_err_Eh",
             "value": n_iter_total / dt, "unit": "CCSD iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[2]: synthetic fragment sweep, {F} fragments per GPU ({F_total} total), "
+            "config": {"workload": f"BASELINE configs[2]: synthetic fragment sweep, {F} fragments per GPU ({F_total} total, {args.scaling} scaling), "
                                    f"n_occ={o} n_virt={v} (n={n}), DF-factorised ERIs naux={3 * n}, ERI scale={args.scale} (SURVEY 8d says 0.06: the oracle's "
                                    "own RHF/CCSD diverges there for n > ~100, DESIGN.md), one be_func / be_func_parallel sweep per step "
                                    "(update_heff + fragment RHF + MO transform + RCCSD to |dE|<1e-10 + 1-RDM + energies per fragment, solve_error, 1 all-reduce)",

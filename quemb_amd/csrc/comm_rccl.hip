@@ -9,11 +9,22 @@
 // process that has already loaded an RCCL (the one bundled with PyTorch) shares that copy instead of starting a second one.
 // All calls are made by the host thread that owns the DEFAULT execution context (the sweep joins its worker threads before the exchange);
 // the collective runs on that context's stream, behind every kernel the rank has queued there.
+//
+// A lost peer is an ERROR, not a hang (round 4): the rendezvous (ncclCommInitRank blocks until every rank has joined) runs in a helper
+// thread that the caller waits for at most QEMB_COMM_TIMEOUT_S seconds (default 120); an all-reduce is enqueued and then waited for with
+// hipStreamQuery in a bounded loop that also polls ncclCommGetAsyncError.  On a timeout or an asynchronous RCCL error the communicator is
+// aborted (ncclCommAbort, from a detached thread: it may itself block on a wedged kernel), the call returns QEMB_ERR_DEVICE and every later
+// call fails at once -- the rank is expected to exit non-zero, which is what makes its launcher stop the others.
 #include <dlfcn.h>
 #include <rccl/rccl.h>
+#include <chrono>
+#include <condition_variable>
+#include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include "dev_ops.h"
 #include "hip_common.h"
 
@@ -25,12 +36,15 @@ struct RcclApi {
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;                        // optional (older RCCL): without it a broken communicator is leaked
+  ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t*) = nullptr; // optional
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 RcclApi g_api;
 std::mutex g_comm_mutex;
 ncclComm_t g_comm = nullptr;
 int g_rank = 0, g_world = 1;
+bool g_broken = false;            // a collective timed out or failed: the communicator was aborted, every later call fails
 double* g_stage = nullptr;        // device staging buffer of the all-reduce (grown on demand)
 size_t g_stage_elems = 0;
 double* g_pinned = nullptr;       // pinned host image of it: both copies of a call are asynchronous on the stream
@@ -54,6 +68,8 @@ int load_rccl() {
   a.AllReduce = (decltype(a.AllReduce))dlsym(h, "ncclAllReduce");
   a.CommDestroy = (decltype(a.CommDestroy))dlsym(h, "ncclCommDestroy");
   a.GetErrorString = (decltype(a.GetErrorString))dlsym(h, "ncclGetErrorString");
+  a.CommAbort = (decltype(a.CommAbort))dlsym(h, "ncclCommAbort");
+  a.CommGetAsyncError = (decltype(a.CommGetAsyncError))dlsym(h, "ncclCommGetAsyncError");
   if (!a.GetUniqueId || !a.CommInitRank || !a.AllReduce || !a.CommDestroy || !a.GetErrorString) {
     set_error("qemb_comm: librccl lacks one of ncclGetUniqueId / ncclCommInitRank / ncclAllReduce / ncclCommDestroy / ncclGetErrorString");
     return QEMB_ERR_DEVICE;
@@ -69,6 +85,23 @@ int load_rccl() {
       return QEMB_ERR_DEVICE;                                                                                  \
     }                                                                                                          \
   } while (0)
+double comm_timeout_s() {
+  const char* e = std::getenv("QEMB_COMM_TIMEOUT_S");
+  const double v = e ? std::atof(e) : 120.0;
+  return v > 0 ? v : 120.0;
+}
+
+// the communicator can no longer be used: abort it off-thread (the call may block while a collective kernel spins on a peer that is gone),
+// keep the staging buffers (that kernel may still touch them) and make every later call fail at once.  Caller holds g_comm_mutex.
+void abandon_comm() {
+  ncclComm_t c = g_comm;
+  g_comm = nullptr; g_broken = true;
+  g_stage = nullptr; g_stage_elems = 0; g_pinned = nullptr; g_pinned_elems = 0;      // leaked on purpose
+  if (c && g_api.CommAbort) {
+    auto abort_fn = g_api.CommAbort;
+    std::thread([c, abort_fn] { (void)abort_fn(c); }).detach();
+  }
+}
 }  // namespace
 
 static_assert(COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "qemb_comm id size follows ncclUniqueId");
@@ -89,11 +122,39 @@ int dev_comm_init(int rank, int world, const void* id128) {
   std::lock_guard<std::mutex> lock(g_comm_mutex);
   if (g_comm) { set_error("qemb_comm_init: a communicator already exists (one per process; qemb_comm_destroy first)"); return QEMB_ERR_ARG; }
   if (int rc = load_rccl()) return rc;
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  // ncclCommInitRank is collective -- it returns when every rank has joined -- so it runs in a helper thread and this one waits with a bound
+  struct Rendezvous {
+    std::mutex m; std::condition_variable cv; bool done = false;
+    ncclResult_t r = ncclSuccess; hipError_t he = hipSuccess; ncclComm_t c = nullptr;
+  };
+  auto st = std::make_shared<Rendezvous>();
   ncclUniqueId id;
   memcpy(id.internal, id128, NCCL_UNIQUE_ID_BYTES);
-  ncclComm_t c = nullptr;
-  RCCL_TRY(g_api.CommInitRank(&c, world, id, rank));     // collective: returns when every rank has joined
-  g_comm = c; g_rank = rank; g_world = world;
+  auto init_fn = g_api.CommInitRank;
+  std::thread([st, id, world, rank, dev, init_fn] {
+    ncclComm_t c = nullptr;
+    hipError_t he = hipSetDevice(dev);
+    ncclResult_t r = (he == hipSuccess) ? init_fn(&c, world, id, rank) : ncclSuccess;
+    std::lock_guard<std::mutex> lk(st->m);
+    st->c = c; st->r = r; st->he = he; st->done = true;
+    st->cv.notify_all();
+  }).detach();
+  const double lim = comm_timeout_s();
+  {
+    std::unique_lock<std::mutex> lk(st->m);
+    if (!st->cv.wait_for(lk, std::chrono::duration<double>(lim), [&] { return st->done; })) {
+      g_broken = true;          // the helper is still inside RCCL; nothing of it is touched again
+      set_error("qemb_comm_init: rank " + std::to_string(rank) + " of " + std::to_string(world) + " waited " + std::to_string((int)lim) +
+                " s for the other ranks to join (QEMB_COMM_TIMEOUT_S); a rank never started or is gone");
+      return QEMB_ERR_DEVICE;
+    }
+    if (st->he != hipSuccess) { set_error(std::string("qemb_comm_init: hipSetDevice failed: ") + hipGetErrorString(st->he)); return QEMB_ERR_DEVICE; }
+    if (st->r != ncclSuccess) { set_error(std::string("ncclCommInitRank failed: ") + g_api.GetErrorString(st->r)); return QEMB_ERR_DEVICE; }
+    g_comm = st->c;
+  }
+  g_rank = rank; g_world = world; g_broken = false;
   return QEMB_OK;
 }
 
@@ -107,6 +168,7 @@ int dev_comm_info(int* rank, int* world) {
 int dev_comm_allreduce(double* host_buf, int64_t n, int op) {
   if (n < 0 || (n > 0 && !host_buf) || (op != COMM_SUM && op != COMM_MAX)) { set_error("qemb_comm_allreduce: bad arguments"); return QEMB_ERR_ARG; }
   std::lock_guard<std::mutex> lock(g_comm_mutex);
+  if (g_broken) { set_error("qemb_comm_allreduce: the communicator was aborted after a failed or timed-out collective"); return QEMB_ERR_DEVICE; }
   if (!g_comm) { set_error("qemb_comm_allreduce: no communicator (qemb_comm_init)"); return QEMB_ERR_DEVICE; }
   if (n == 0) return QEMB_OK;
   hipStream_t s = hip_stream();
@@ -123,14 +185,44 @@ int dev_comm_allreduce(double* host_buf, int64_t n, int op) {
   HIP_TRY(hipMemcpyAsync(g_stage, g_pinned, (size_t)n * sizeof(double), hipMemcpyHostToDevice, s));
   RCCL_TRY(g_api.AllReduce(g_stage, g_stage, (size_t)n, ncclDouble, op == COMM_SUM ? ncclSum : ncclMax, g_comm, s));
   HIP_TRY(hipMemcpyAsync(g_pinned, g_stage, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
+  // bounded wait: a peer that died leaves the collective kernel spinning for ever, so never hipStreamSynchronize here
+  const double lim = comm_timeout_s();
+  const auto t0 = std::chrono::steady_clock::now();
+  for (uint64_t spins = 1;; ++spins) {
+    const hipError_t q = hipStreamQuery(s);
+    if (q == hipSuccess) break;
+    if (q != hipErrorNotReady) {
+      (void)hipGetLastError();
+      abandon_comm();
+      set_error(std::string("qemb_comm_allreduce: the stream failed while the collective was in flight: ") + hipGetErrorString(q));
+      return QEMB_ERR_DEVICE;
+    }
+    if ((spins & 63) == 0) {
+      if (g_api.CommGetAsyncError) {
+        ncclResult_t ar = ncclSuccess;
+        if (g_api.CommGetAsyncError(g_comm, &ar) == ncclSuccess && ar != ncclSuccess && ar != ncclInProgress) {
+          const std::string why = g_api.GetErrorString(ar);
+          abandon_comm();
+          set_error("qemb_comm_allreduce: RCCL reported an asynchronous error (" + why + "); the communicator was aborted");
+          return QEMB_ERR_DEVICE;
+        }
+      }
+      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > lim) {
+        abandon_comm();
+        set_error("qemb_comm_allreduce: rank " + std::to_string(g_rank) + " of " + std::to_string(g_world) + " waited " + std::to_string((int)lim) +
+                  " s for the all-reduce (QEMB_COMM_TIMEOUT_S); a rank is gone -- the communicator was aborted");
+        return QEMB_ERR_DEVICE;
+      }
+      if (spins > 20000) std::this_thread::sleep_for(std::chrono::microseconds(50));     // a few ms of pure polling first: the exchange is latency bound
+    }
+  }
   memcpy(host_buf, g_pinned, (size_t)n * sizeof(double));
   return QEMB_OK;
 }
 
 int dev_comm_destroy() {
   std::lock_guard<std::mutex> lock(g_comm_mutex);
-  if (!g_comm) return QEMB_OK;
+  if (!g_comm) { g_broken = false; return QEMB_OK; }      // an abandoned communicator has nothing left to release
   if (hip_stream()) HIP_TRY(hipStreamSynchronize(hip_stream()));
   ncclComm_t c = g_comm;
   g_comm = nullptr; g_rank = 0; g_world = 1;

@@ -14,6 +14,7 @@
 // _cpp/eri_sparse_DF.cpp:611-621), built from a 32x32 LDS diagonal-block kernel plus the MFMA GEMM.
 #include <hip/hip_runtime.h>
 #include <atomic>
+#include <mutex>
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
@@ -389,9 +390,19 @@ static int jacobi_rows(int nvec, int64_t len, double* W, int64_t ldw, double* Vt
   // one launch of a block round; the register slots per lane are a template parameter (smallest instantiation that holds a row)
   auto launch_block_round = [&](int r) -> hipError_t {
     hipError_t err = hipSuccess;
+    // the three instantiations share one function-pointer type, so a flag inside the generic lambda would be ONE flag for all of them:
+    // the dynamic-LDS ceiling is raised on all three, once, and every return code is looked at
+    static std::once_flag attr_once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(attr_once, [] {
+      const void* ks[3] = {(const void*)jacobi_block_round_kernel<16, 4>, (const void*)jacobi_block_round_kernel<16, 7>, (const void*)jacobi_block_round_kernel<16, 10>};
+      for (const void* k : ks) {
+        const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+        if (e != hipSuccess && attr_err == hipSuccess) attr_err = e;
+      }
+    });
+    if (attr_err != hipSuccess) return attr_err;
     auto go = [&](auto kern, int bw) {
-      static std::atomic<bool> attr_set{false};   // per instantiation; benign if two threads both set it once
-      if (!attr_set) { err = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024); attr_set = true; }
       if (err == hipSuccess) hipLaunchKernelGGL(kern, dim3(nbp / 2), dim3(bw * 64), blk_lds, s, W, (long long)ldw, (int)len, Vt, nvec, nb, nbp, r, tol, floor2, d_off);
     };
     if (npl_need <= 4) go(jacobi_block_round_kernel<16, 4>, 16); else if (npl_need <= 7) go(jacobi_block_round_kernel<16, 7>, 16); else go(jacobi_block_round_kernel<16, 10>, 16);

@@ -5,7 +5,7 @@
 //
 // Protocol: the 128-byte id names a segment /dev/shm/qemb_hc_<pid>_<nonce> created by dev_comm_unique_id.  An all-reduce copies each
 // rank's buffer into its slot, meets at a generation barrier, lets every rank combine the slots in rank order (so every rank gets the
-// bit-identical result, as with RCCL), and meets again before the slots are reused.  Waiting is bounded (QEMB_HC_COMM_TIMEOUT_S, 120 s):
+// bit-identical result, as with RCCL), and meets again before the slots are reused.  Waiting is bounded (QEMB_COMM_TIMEOUT_S, 120 s, as in the product):
 // a lost rank turns into an error, not a hang.
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -40,11 +40,14 @@ struct ShmComm {
   size_t bytes = 0;
 };
 ShmComm* g_comm = nullptr;
+bool g_broken = false;      // a wait timed out: like the product's aborted communicator, every later collective fails at once
 std::mutex g_mutex;
 
 double timeout_s() {
-  const char* e = std::getenv("QEMB_HC_COMM_TIMEOUT_S");
-  return e ? std::atof(e) : 120.0;
+  const char* e = std::getenv("QEMB_COMM_TIMEOUT_S");            // the product's knob (csrc/comm_rccl.hip); the older mock-only name still works
+  if (!e) e = std::getenv("QEMB_HC_COMM_TIMEOUT_S");
+  const double v = e ? std::atof(e) : 120.0;
+  return v > 0 ? v : 120.0;
 }
 size_t segment_bytes(int world) { return 4096 + (size_t)world * SLOT_ELEMS * sizeof(double); }
 
@@ -122,12 +125,13 @@ int dev_comm_info(int* rank, int* world) {
 int dev_comm_allreduce(double* buf, int64_t n, int op) {
   if (n < 0 || (n > 0 && !buf) || (op != COMM_SUM && op != COMM_MAX)) { set_error("qemb_comm_allreduce: bad arguments"); return QEMB_ERR_ARG; }
   std::lock_guard<std::mutex> lock(g_mutex);
+  if (g_broken) { set_error("qemb_comm_allreduce: the communicator was aborted after a failed or timed-out collective"); return QEMB_ERR_DEVICE; }
   if (!g_comm) { set_error("qemb_comm_allreduce: no communicator (qemb_comm_init)"); return QEMB_ERR_DEVICE; }
   ShmComm& c = *g_comm;
   for (int64_t off = 0; off < n; off += SLOT_ELEMS) {
     const int64_t m = std::min<int64_t>(SLOT_ELEMS, n - off);
     memcpy(c.slots + (size_t)c.rank * SLOT_ELEMS, buf + off, (size_t)m * sizeof(double));
-    if (int rc = barrier(c)) return rc;
+    if (int rc = barrier(c)) { g_broken = true; return rc; }
     for (int64_t i = 0; i < m; ++i) {
       double acc = c.slots[i];
       for (int r = 1; r < c.world; ++r) {
@@ -136,13 +140,14 @@ int dev_comm_allreduce(double* buf, int64_t n, int op) {
       }
       buf[off + i] = acc;
     }
-    if (int rc = barrier(c)) return rc;
+    if (int rc = barrier(c)) { g_broken = true; return rc; }
   }
   return QEMB_OK;
 }
 
 int dev_comm_destroy() {
   std::lock_guard<std::mutex> lock(g_mutex);
+  g_broken = false;
   if (!g_comm) return QEMB_OK;
   ShmComm* c = g_comm;
   g_comm = nullptr;

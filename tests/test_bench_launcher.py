@@ -143,3 +143,77 @@ def test_cpu_baseline_runs_whole_fragments_in_both_pool_settings():
     assert fs["gpu_same_fragments"]["fragments"] == fs["all_cores"]["nproc"]
     assert cb["n220_amplitude_updates"]["value"] > 0
     assert r["parity_n220_abs_err_Eh"] < 1e-10
+
+
+@pytest.mark.timeout(600)
+def test_world8_strong_scaling_matches_one_rank():
+    """`--gpus 8 --scaling strong` with BASELINE configs[2]'s 64 fragments on the mock: eight ranks of eight fragments, the sweep energy,
+    residual and iteration counts of the one-rank run of the same 64-fragment ring (world 8 is the driver's node size; it never ran before)."""
+    outs = []
+    for gpus in (1, 8):
+        p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", str(gpus), *SMALL, "--scaling", "strong", "--frags-total", "64",
+                            "--lib", _mock()], env=_env(OMP_NUM_THREADS="1"), capture_output=True, text=True, timeout=500)
+        assert p.returncode == 0, p.stderr[-2000:]
+        lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1
+        outs.append(json.loads(lines[0]))
+    a, b = outs
+    assert b["n_gpus"] == 8 and b["scaling"] == "strong" and a["scaling"] == "strong"
+    assert b["config"]["fragments_per_rank"] == [8] * 8 and a["config"]["fragments_per_rank"] == [64]
+    assert abs(a["mean_e_corr_per_sweep"] - b["mean_e_corr_per_sweep"]) < 1e-11
+    assert abs(a["residual_norm"] - b["residual_norm"]) < 1e-12
+    assert a["ccsd_iterations_per_fragment"] == b["ccsd_iterations_per_fragment"]
+    assert b["config"]["allreduce_bytes_per_sweep"] == a["config"]["residual_slots"] * 8 or b["config"]["allreduce_bytes_per_sweep"] > 0
+    # weak scaling of the same node: 8 x 2 fragments
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "8", *SMALL, "--lib", _mock()], env=_env(OMP_NUM_THREADS="1"),
+                       capture_output=True, text=True, timeout=500)
+    assert p.returncode == 0, p.stderr[-2000:]
+    w = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    assert w["scaling"] == "weak" and w["config"]["fragments_per_rank"] == [2] * 8
+
+
+_DYING_RANK_SCRIPT = r"""
+import ctypes as C, os, signal, sys, time
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from quemb_amd import _lib, comm
+lib = _lib.declare(C.CDLL(sys.argv[2]))
+_lib.check(lib.qemb_init(0), "qemb_init", lib)
+rank, world = comm.init_from_env(lib)
+comm.all_reduce(lib, np.ones(3))                 # everybody is there
+if rank == int(sys.argv[3]):
+    os.kill(os.getpid(), signal.SIGKILL)         # dies like an OOM-killed process: no exception, no goodbye
+t0 = time.monotonic()
+try:
+    comm.all_reduce(lib, np.ones(3))
+except _lib.QembError as e:
+    print(f"rank {rank}: {e} after {time.monotonic() - t0:.1f} s", flush=True)
+    try:
+        comm.all_reduce(lib, np.ones(3))          # and it stays failed, at once
+    except _lib.QembError:
+        pass
+    assert time.monotonic() - t0 < float(os.environ["QEMB_COMM_TIMEOUT_S"]) + 10.0
+    sys.exit(3)
+sys.exit(0)                                        # must not happen: a rank was gone
+"""
+
+
+@pytest.mark.timeout(180)
+def test_killed_rank_ends_the_other_seven_within_the_bound():
+    """world 8 under an EXTERNAL launcher (this test): rank 5 is killed between two collectives; the other seven must come back from the
+    all-reduce with an error inside QEMB_COMM_TIMEOUT_S and exit non-zero -- nobody hangs, nobody is re-executed."""
+    import time
+    world, victim, bound = 8, 5, 6.0
+    t0 = time.monotonic()
+    procs = [subprocess.Popen([sys.executable, "-c", _DYING_RANK_SCRIPT, str(ROOT), _mock(), str(victim)],
+                              env=_env(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT="23471",
+                                       QEMB_COMM_TIMEOUT_S=str(bound)),
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=150) for p in procs]
+    for r, (p, (so, se)) in enumerate(zip(procs, outs)):
+        if r == victim:
+            assert p.returncode == -9
+        else:
+            assert p.returncode == 3, (r, p.returncode, se[-1500:])
+            assert "a rank is gone" in so
+    assert time.monotonic() - t0 < 120

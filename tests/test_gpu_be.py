@@ -6,6 +6,8 @@ import numpy as np
 import pytest
 
 from helpers import GOLDEN
+from pathlib import Path
+ROOT = Path(__file__).resolve().parent.parent
 from qemb_oracle import eri as oeri
 from quemb_amd import _lib, eri_transform as et
 
@@ -631,6 +633,45 @@ def test_library_rccl_communicator_single_rank(qlib):
     assert comm.active() is None
     with pytest.raises(_lib.QembError):
         comm.all_reduce(qlib, np.zeros(3))                   # no communicator: loud
+
+
+_MISSING_PEER_SCRIPT = r"""
+import ctypes as C, os, sys, time
+sys.path.insert(0, sys.argv[1])
+from quemb_amd import _lib, comm
+lib = _lib.init(0)
+uid = comm.unique_id(lib)
+t0 = time.monotonic()
+try:
+    comm.init(lib, 0, 2, uid)            # world of two, the second rank never starts
+    print("JOINED", flush=True)
+except _lib.QembError as e:
+    print(f"TIMEOUT {time.monotonic() - t0:.1f} {e}", flush=True)
+try:
+    comm.all_reduce(lib, __import__("numpy").zeros(2))
+    print("REDUCED", flush=True)
+except _lib.QembError as e:
+    print(f"LOUD {e}", flush=True)
+sys.stdout.flush()
+os._exit(0)                               # the helper thread is still inside ncclCommInitRank: leave without running exit handlers
+"""
+
+
+@pytest.mark.timeout(180)
+def test_library_rccl_rendezvous_is_bounded(qlib):
+    """A peer that never joins is an error after QEMB_COMM_TIMEOUT_S, not a hang (csrc/comm_rccl.hip, round 4): rank 0 of a world of
+    two on the real RCCL, in a child process (its rendezvous thread never returns)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, QEMB_COMM_TIMEOUT_S="8", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, "-c", _MISSING_PEER_SCRIPT, str(ROOT)], env=env, capture_output=True, text=True, timeout=150)
+    out = p.stdout
+    assert "JOINED" not in out and "REDUCED" not in out, out + p.stderr[-1500:]
+    line = [ln for ln in out.splitlines() if ln.startswith("TIMEOUT")]
+    assert line, out + p.stderr[-1500:]
+    waited = float(line[0].split()[1])
+    assert 7.0 <= waited <= 30.0 and "QEMB_COMM_TIMEOUT_S" in line[0]
+    assert any(ln.startswith("LOUD") for ln in out.splitlines())
 
 
 def test_df_transform_matches_reference_integral_direct_DF(qlib):
