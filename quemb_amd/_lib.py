@@ -21,8 +21,15 @@ c_i64 = C.c_int64
 c_vp = C.c_void_p
 
 
+QEMB_ERR_ARG, QEMB_ERR_ALLOC, QEMB_ERR_DEVICE, QEMB_ERR_NOCONV, QEMB_ERR_NUMERIC = -1, -2, -3, -4, -5      # include/qemb_hip.h
+
+
 class QembError(RuntimeError):
-    """Raised when a libqemb_hip call returns a non-zero status."""
+    """Raised when a libqemb_hip call returns a non-zero status (`.status`: the QEMB_ERR_* code)."""
+
+    def __init__(self, msg="", status=None):
+        super().__init__(msg)
+        self.status = status
 
 
 class SolverOpts(C.Structure):
@@ -208,7 +215,7 @@ def check(rc: int, what: str = "", lib=None):
         warnings.warn(ConvergenceWarning(f"{what or 'libqemb_hip call'}: {msg}"), stacklevel=3)
     elif rc != 0:
         msg = (lib or load()).qemb_last_error().decode(errors="replace")
-        raise QembError(f"{what or 'libqemb_hip call'} failed (status {rc}): {msg}")
+        raise QembError(f"{what or 'libqemb_hip call'} failed (status {rc}): {msg}", status=int(rc))
 
 
 def init(device: int | None = None):

@@ -13,68 +13,80 @@ import numpy as np
 from numpy.linalg import inv, norm, pinv
 
 
+# Li-Fukushima acceptance test, constants of the reference's choice (optqn.py:25-59): shrink factor of the step, sufficient-decrease
+# fraction of the residual, and the two weights of the squared step length
+_LF_SHRINK, _LF_DECREASE, _LF_W_LOOP, _LF_W_FIRST, _LF_MAX_EVALS = 0.1, 0.9, 1e-3, 1e-3, 20
+
+
 def line_search_LF(func, xold, fold, dx, iter_, verbose=True):
-    """D.-H. Li and M. Fukushima, Optim. Methods Softw. 13, 181 (2000): accept x + dx when the residual drops
-    enough, else back-track alpha *= 0.1 (at most 20 evaluations)."""
-    beta, rho, sigma1, sigma2 = 0.1, 0.9, 1e-3, 1e-3
-    eta = (iter_ + 1) ** -2.0
-    alp = 1.0
-    xk = xold + dx
-    fk = func(xk)
-    nev = 1
-    ndx, nfk, nfo = norm(dx), norm(fk), norm(fold)
-    if nfk > rho * nfo - sigma2 * ndx ** 2.0:
-        while nfk > (1.0 + eta) * nfo - sigma1 * alp ** 2.0 * ndx ** 2.0:
-            alp *= beta
-            xk = xold + alp * dx
-            fk = func(xk)
-            nev += 1
-            nfk = norm(fk)
-            if nev == 20:
-                break
+    """Derivative-free back-tracking of D.-H. Li and M. Fukushima, Optim. Methods Softw. 13, 181 (2000).  The full quasi-Newton step is
+    taken when |f(x + dx)| <= 0.9 |f(x)| - 1e-3 |dx|^2; otherwise the step length is cut by ten until
+    |f(x + a dx)| <= (1 + (k + 1)^-2) |f(x)| - 1e-3 a^2 |dx|^2 holds or twenty residuals have been evaluated.
+    Returns (step length, x, f(x)) -- same sequence of trial points as the reference's routine of this name."""
+    slack = (iter_ + 1) ** -2.0                       # forcing term of outer iteration k: the test relaxes as 1 / (k + 1)^2
+    step_len2 = norm(dx) ** 2.0
+    res_old = norm(fold)
+    length = 1.0
+    trial = xold + dx
+    f_trial = func(trial)
+    evals = 1
+    res_new = norm(f_trial)
+    full_step_ok = not (res_new > _LF_DECREASE * res_old - _LF_W_FIRST * step_len2)
+    while not full_step_ok and evals < _LF_MAX_EVALS:
+        if not (res_new > (1.0 + slack) * res_old - _LF_W_LOOP * length ** 2.0 * step_len2):
+            break
+        length *= _LF_SHRINK
+        trial = xold + length * dx
+        f_trial = func(trial)
+        evals += 1
+        res_new = norm(f_trial)
     if verbose:
-        print(" No. of line search steps in QN opt :", nev, flush=True)
-    return alp, xk, fk
+        print(f" quasi-Newton line search: {evals} residual evaluation(s), step length {length:g}", flush=True)
+    return length, trial, f_trial
 
 
 def trustRegion(func, xold, fold, Binv, c=0.5, verbose=True):
-    """Broyden trust-region dog-leg step (reference optqn.py:62-155; IAENG IJCS 46(3) 2019, Algorithm 1)."""
-    p = 0
-    rho = 0.001
-    ratio = 0.0
-    B = inv(Binv)
-    dx_gn = -(Binv @ Binv.T) @ B.T @ fold
-    dx_sd = -B.T @ fold
-    t = norm(dx_sd) ** 2 / norm(B @ dx_sd) ** 2
-    prev = None
-    ared = 0.0
-    fnew = fold
-    while ratio < rho or ared < 0.0:
-        radius = c ** p
-        scale = max(1.0, norm(xold)) * radius
-        if norm(dx_gn) < scale:
-            kind, dx = "Gauss-Newton", dx_gn
-        elif t * norm(dx_sd) > scale:
-            kind, dx = "Steepest Descent", radius / norm(dx_sd) * dx_sd
+    """Dog-leg step inside a shrinking trust region on the Broyden model (the reference's routine of this name, optqn.py:62-155, after
+    IAENG IJCS 46(3) 2019, Algorithm 1).  Radius c^p times max(1, |x|), p = 0, 1, ...: the Gauss-Newton point if it lies inside, the scaled
+    steepest-descent direction if even the Cauchy point lies outside, else the point of the dog leg between them that reaches the radius
+    (found by walking back from the Gauss-Newton end in steps of 1/1000).  A step is accepted when the actual reduction of |f|^2 / 2 is
+    positive and at least 0.001 of the reduction the linear model predicts."""
+    accept_ratio = 0.001
+    jac = inv(Binv)
+    newton_pt = -(Binv @ Binv.T) @ jac.T @ fold
+    descent = -jac.T @ fold
+    cauchy_len = norm(descent) ** 2 / norm(jac @ descent) ** 2
+    half_res_old = 0.5 * norm(fold) ** 2
+    last_step = None
+    gain_ratio, actual = 0.0, 0.0
+    f_new = fold
+    shrinks = 0
+    while gain_ratio < accept_ratio or actual < 0.0:
+        radius = c ** shrinks
+        reach = max(1.0, norm(xold)) * radius
+        if norm(newton_pt) < reach:
+            label, step = "Gauss-Newton point", newton_pt
+        elif cauchy_len * norm(descent) > reach:
+            label, step = "steepest descent to the radius", radius / norm(descent) * descent
         else:
-            kind = "Dog Leg"
-            tdx = t * dx_sd
-            diff = dx_gn - tdx
-            s = 1
-            dx = tdx + s * diff
-            while norm(dx) > radius and s > 0:
-                s -= 0.001
-                dx = tdx + s * diff
+            label = "dog leg"
+            cauchy_pt = cauchy_len * descent
+            leg = newton_pt - cauchy_pt
+            frac = 1
+            step = cauchy_pt + frac * leg
+            while norm(step) > radius and frac > 0:
+                frac -= 0.001
+                step = cauchy_pt + frac * leg
         if verbose:
-            print("  Trust Region Optimization Step ", p, ":", kind, flush=True)
-        if prev is None or not np.all(dx == prev):
-            fnew = func(xold + dx)
-            ared = 0.5 * (norm(fold) ** 2 - norm(fnew) ** 2)
-            pred = 0.5 * (norm(fold) ** 2 - norm(fold + B @ dx) ** 2)
-        ratio = ared / pred
-        p += 1
-        prev = dx
-    return xold + dx, fnew
+            print(f"  trust region, radius {radius:g}: {label}", flush=True)
+        if last_step is None or not np.all(step == last_step):
+            f_new = func(xold + step)
+            actual = half_res_old - 0.5 * norm(f_new) ** 2
+            predicted = half_res_old - 0.5 * norm(fold + jac @ step) ** 2
+        gain_ratio = actual / predicted
+        shrinks += 1
+        last_step = step
+    return xold + step, f_new
 
 
 class FrankQN:

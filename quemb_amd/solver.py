@@ -102,10 +102,25 @@ def solve_ccsd(h, eri_s4, nsocc, dm0=None, *, n_frag=0, rdm_return=False, rdm2_r
     return out["t1"], out["t2"]
 
 
-def sweep_mode(frags, nstreams=None, lockstep=None):
+def fragment_work_bytes(n, o=None):
+    """Device memory ONE fragment in flight takes beside its resident ERIs: the two n^2 x npair buffers of the
+    embedding->MO transformation (rows at a stride of whole 128-byte lines), the (+/-) pair-packed ladder operands, the ovvv block with its
+    packed images, and ~30 tensors of the size of t2.  Without n_occ the worst split (n_occ = n / 4) is assumed."""
+    n = int(n)
+    o = max(1, n // 4) if o is None else int(o)
+    v = max(n - o, 1)
+    ld = (n + 15) // 16 * 16
+    npair = n * (n + 1) // 2
+    pv, qv = v * (v + 1) // 2, v * (v - 1) // 2
+    return 8.0 * (2.0 * n * ld * npair + pv * pv + qv * qv + 2.0 * o * v ** 3 + 30.0 * (o * v) ** 2)
+
+
+def sweep_mode(frags, nstreams=None, lockstep=None, mem_free=None):
     """How the fragments of a sweep share the GPU when the caller leaves it open (BE(..., nstreams=None, lockstep=None)):
     many small fragments (>= 5 of at most 64 embedding orbitals: launch bound) advance in lock step -- one grouped launch per operation for all of them;
-    otherwise several fragments are in flight on separate streams: up to six small ones, up to four of at most 256 orbitals, two beyond (device memory).
+    otherwise several fragments are in flight on separate streams: up to six small ones, up to four of at most 256 orbitals, two beyond --
+    and never more than the device memory that is free (`mem_free` bytes; taken from the fragments' library when they are on a device)
+    holds working sets of (fragment_work_bytes): a calculation that fits one fragment at a time keeps fitting with the default.
     Measured on octane/STO-3G: BE2 (six fragments of ~42 orbitals) 40 ms serial, 18.3 ms six streams, 16.7 ms lock step; BE3 (four of ~55) 41 / 28 / 29 ms.
     Every mode returns bit-identical results."""
     frags = list(frags)
@@ -114,7 +129,32 @@ def sweep_mode(frags, nstreams=None, lockstep=None):
         lockstep = nstreams is None and len(frags) >= 5 and nmax <= 64
     if nstreams is None:
         nstreams = 1 if len(frags) <= 1 else (min(6, len(frags)) if nmax <= 96 else min(4 if nmax <= 256 else 2, len(frags)))
+        if nstreams > 1 and nmax > 96:
+            if mem_free is None:
+                mem_free = _device_free_bytes(frags)
+            if mem_free is not None:
+                work = max(fragment_work_bytes(f.nao, getattr(f, "nsocc", None)) for f in frags)
+                nstreams = max(1, min(nstreams, int(0.9 * mem_free // work)))
     return int(nstreams), bool(lockstep)
+
+
+def _device_free_bytes(frags):
+    """free device memory as the fragments' library reports it (qemb_mem_info) plus nothing else: blocks the library has parked count as used,
+    so the bound errs on the side of fewer fragments in flight.  None when the fragments are not on a device (host-logic tests)."""
+    import ctypes as C
+    dev = next((getattr(f, "dev", None) for f in frags if getattr(f, "dev", None) is not None), None)
+    lib = getattr(dev, "lib", None)
+    if lib is None or not hasattr(lib, "qemb_mem_info"):
+        return None
+    free_b, total_b = C.c_size_t(), C.c_size_t()
+    try:
+        if hasattr(lib, "qemb_trim"):
+            lib.qemb_trim()                      # parked work space of earlier sweeps is free for this decision
+        if lib.qemb_mem_info(C.byref(free_b), C.byref(total_b)) != 0:
+            return None
+    except Exception:  # noqa: BLE001
+        return None
+    return float(free_b.value)
 
 
 def set_cu_partition(lib, parts):
@@ -150,8 +190,27 @@ def map_fragments(fn, frags, nstreams=1):
     def bind():
         from ._lib import check
         check(lib.qemb_ctx_bind(ids.get()), "qemb_ctx_bind", lib)
+    from ._lib import QEMB_ERR_ALLOC, QembError
     with ThreadPoolExecutor(max_workers=nwork, initializer=bind) as pool:
-        return list(pool.map(fn, frags))
+        futs = [pool.submit(fn, f) for f in frags]
+        res, retry = [None] * len(frags), []
+        for k, fu in enumerate(futs):
+            try:
+                res[k] = fu.result()
+            except QembError as e:
+                if getattr(e, "status", None) != QEMB_ERR_ALLOC:
+                    raise
+                retry.append(k)
+    if retry:
+        # the working sets of `nwork` fragments did not fit together: what fits one fragment at a time must keep working (the serial sweep
+        # is what nstreams = 1 runs); parked blocks of every context are released first
+        import warnings
+        warnings.warn(f"{len(retry)} fragment(s) ran out of device memory with {nwork} in flight; solving them one at a time", RuntimeWarning, stacklevel=2)
+        if hasattr(lib, "qemb_trim"):
+            lib.qemb_trim()
+        for k in retry:
+            res[k] = fn(frags[k])
+    return res
 
 
 def solve_fragments(pot, frags, only_chem=False, opts=None, eeval=False, use_cumulant=True, relax_density=False, nstreams=1, lockstep=False,

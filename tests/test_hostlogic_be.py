@@ -624,3 +624,11 @@ def test_sweep_mode_choice():
     assert sweep_mode([F(nao=42)] * 6, nstreams=2) == (2, False) and sweep_mode([F(nao=42)] * 6, lockstep=False) == (6, False)
     assert sweep_mode([F(nao=42)] * 6, nstreams=2, lockstep=True) == (2, True)
     assert sweep_mode([]) == (1, False)
+    # device memory bounds the fragments in flight (advisor, round 3): n = 400 needs ~200 GB of work space per fragment in flight
+    from quemb_amd.solver import fragment_work_bytes
+    assert 25e9 < fragment_work_bytes(220, 20) < 40e9 and fragment_work_bytes(400) > 150e9
+    assert sweep_mode([F(nao=220, nsocc=20)] * 8, mem_free=250e9) == (4, False)
+    assert sweep_mode([F(nao=220, nsocc=20)] * 8, mem_free=80e9) == (2, False)
+    assert sweep_mode([F(nao=400)] * 8, mem_free=250e9) == (1, False)       # what fitted with nstreams = 1 keeps fitting
+    assert sweep_mode([F(nao=400)] * 8, mem_free=10e9) == (1, False)
+    assert sweep_mode([F(nao=400)] * 8, nstreams=2, mem_free=10e9) == (2, False)     # an explicit request is honoured
