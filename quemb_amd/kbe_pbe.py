@@ -16,6 +16,11 @@ that is the reference's flow:
 Fragment ERIs (`BE._eri_transform`, kbe/pbe.py:502-572):
     int_transform="int-direct-DF-hip"   Gamma point only, like the reference (:233-236): `kbe_eri_onthefly.integral_direct_DF` with
                                         the integral source given as `df_source`
+    int_transform="supercell-DF-hip"    k-point sampled: the density-fitted integrals of the Born-von-Karman supercell (`df_source`, nao = N_k x
+                                        AOs per cell, cells in kbe.misc.get_phase order) rotated with the real-space image of every
+                                        fragment's TA_k by the same device transform -- what libdmet's `get_emb_eri_fast_gdf(cell, mf.with_df,
+                                        C_ao_eo=TA)` computes from the k-point GDF tensor (:529-537): fragment ERIs of BASELINE configs[4]
+                                        (polyacetylene, 1 x 1 x 3 k-points) never leave the device
     int_transform="fragment-eris"       `eri_provider(fragment) -> (npair(n), npair(n))`: the seam where the reference calls libdmet's
                                         `get_emb_eri_fast_gdf(cell, mf.with_df, C_ao_eo=TA)` (:529-537) or reads a cderi file
                                         (:877-896); no periodic integral code exists in this image, so the provider is an argument
@@ -91,8 +96,8 @@ class BE(mbe.BE):
         self.C_core = self.P_core = self.core_veff = None
         if int_transform == "int-direct-DF-hip" and np.abs(self.kpts).max() > 0:
             raise NotImplementedError("k-point sampled ERI not implemented for int-direct-DF.")          # kbe/pbe.py:233-236
-        if int_transform not in ("int-direct-DF-hip", "fragment-eris"):
-            raise ValueError(f"int_transform {int_transform!r} is not one of ('int-direct-DF-hip', 'fragment-eris')")
+        if int_transform not in ("int-direct-DF-hip", "supercell-DF-hip", "fragment-eris"):
+            raise ValueError(f"int_transform {int_transform!r} is not one of ('int-direct-DF-hip', 'supercell-DF-hip', 'fragment-eris')")
         self.pot = mbe.initialize_pot(fobj.n_frag, fobj.relAO_per_edge_per_frag)
         self.Fobjs: list[KFrags] = []
         self.stats = {}
@@ -149,6 +154,17 @@ class BE(mbe.BE):
                         raise ValueError("Gamma-point TA is not real")
                     self.TA, self.dev = np.ascontiguousarray(f.TA[0].real), f.dev
             keo.integral_direct_DF(self.df_source, [_Gamma(f) for f in frs], lib=self.lib)
+        elif self.int_transform == "supercell-DF-hip":
+            from . import kbe_eri_onthefly as keo
+            if self.df_source is None:
+                raise ValueError("`df_source` (the integral source of the Born-von-Karman supercell) has to be defined.")
+            if self.df_source.nao != self.nkpt * self.S.shape[1]:
+                raise ValueError(f"supercell-DF-hip: the source has {self.df_source.nao} AOs, the supercell {self.nkpt} x {self.S.shape[1]}")
+
+            class _Super:                     # the fragment in the supercell AO basis: real TA (N_k nao x n) and the device slot
+                def __init__(s_, f):
+                    s_.TA, s_.dev = f.real_space_TA(self.a_vec, self.kpts, self.kmesh), f.dev
+            keo.integral_direct_DF(self.df_source, [_Super(f) for f in frs], lib=self.lib)
         else:
             if self.eri_provider is None:
                 raise ValueError("`eri_provider` has to be defined for int_transform='fragment-eris'")

@@ -81,6 +81,21 @@ class KFrags(Frags):
         self.dev = DeviceFragment(self.nao, self.n_frag, lib=self.lib)
         return self.TA
 
+    def real_space_TA(self, a_vec, kpts, kmesh):
+        """The embedding orbitals in the AO basis of the Born-von-Karman supercell, rows ordered (cell R, AO mu) with the cells in the order
+        of kbe.misc.get_phase: TA_R[(R, mu), i] = N_k^-1/2 sum_k phase[R, k] TA_k[mu, i] -- the inverse of the back transform of `sd`
+        (kbe/pfrag.py:192).  Real for a time-reversal symmetric mean field (checked).  This is the rotation libdmet's
+        `get_emb_eri_fast_gdf(cell, mydf, C_ao_eo=TA)` applies to the k-point GDF tensor (kbe/pbe.py:529-537)."""
+        phase = get_phase(a_vec, kpts, kmesh)                        # (NR, nk)
+        nk, nao, neo = self.TA.shape
+        T = self.TA.reshape(nk, nao * neo)
+        re = et.matmul(phase.real, T.real, lib=self.lib) - et.matmul(phase.imag, T.imag, lib=self.lib)
+        im = et.matmul(phase.real, T.imag, lib=self.lib) + et.matmul(phase.imag, T.real, lib=self.lib)
+        scale = 1.0 / np.sqrt(nk)
+        if np.abs(im).max() * scale >= 1.0e-8:
+            raise ValueError(f"Imaginary real-space embedding orbitals {np.abs(im).max() * scale}")
+        return np.ascontiguousarray((re * scale).reshape(phase.shape[0] * nao, neo))
+
     def cons_h1(self, h1):
         """kbe/pfrag.py:218-237."""
         nk = self.TA.shape[0]

@@ -54,6 +54,29 @@ class SyntheticGammaSource:
         return self._rs[p0:p1]
 
 
+class GammaSourceFromFactor:
+    """a Gamma-point CC-GDF source whose fitted tensor is a given DF factor B (naux, N, N): unit metric, real-space blocks = B, and a
+    plane-wave part that cancels between +G and -G up to a real remainder folded into the blocks (exercises add_pw_block)"""
+
+    def __init__(self, B, seed=3):
+        rng = np.random.default_rng(seed)
+        self.naux, self.nao = B.shape[0], B.shape[1]
+        sym = lambda a: 0.5 * (a + a.transpose(0, 2, 1))
+        half = 0.1 * sym(rng.standard_normal((2, self.nao, self.nao)) + 1j * rng.standard_normal((2, self.nao, self.nao)))
+        self._pw = np.array([half[0], half[0].conj(), half[1], half[1].conj()])
+        fh = 0.2 * (rng.standard_normal((2, self.naux)) + 1j * rng.standard_normal((2, self.naux)))
+        self._ft = np.array([fh[0], fh[0].conj(), fh[1], fh[1].conj()])
+        pw_part = np.einsum("GL,Gpq->Lpq", self._ft.conj(), self._pw)
+        assert np.abs(pw_part.imag).max() < 1e-14
+        self._rs = B - pw_part.real
+        self.n_planewaves = 4
+
+    def j2c(self): return np.eye(self.naux)
+    def pw_block(self, g0, g1): return self._pw[g0:g1]
+    def ft_aux_block(self, g0, g1): return self._ft[g0:g1]
+    def rs_block(self, p0, p1): return self._rs[p0:p1]
+
+
 def fragment_TAs(nao, ns, seed):
     rng = np.random.default_rng(seed)
     out = []

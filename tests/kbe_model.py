@@ -73,6 +73,97 @@ def build(nk=4, nlo=3, nocc_cell=1, seed=5, naux_cell=4, gap=1.6, scale=0.45):
                 e_tot_cell=mf["e_tot"] / nk)
 
 
+def oracle_rhf(hs, eri_s1, nocc):
+    """the supercell mean field by the oracle (tests); bench.py passes the device fragment RHF instead"""
+    mf = oscf.rhf(hs, eri_s1, nocc, conv_tol=1e-13, conv_tol_grad=1e-10)
+    assert mf["converged"]
+    vj, vk = oscf.get_jk(eri_s1, mf["dm"])
+    return dict(mo_coeff=mf["mo_coeff"], mo_energy=mf["mo_energy"], dm=mf["dm"], e_tot=mf["e_tot"], veff=vj - 0.5 * vk)
+
+
+def build_chain(nk=3, units_per_cell=4, unit_size=6, occ_per_unit=(3, 4, 3, 4), seed=11, naux_unit=8, scale=0.12, hop=0.18, rhf=None):
+    """BASELINE configs[4] at its own dimensions (polyacetylene, tests/kbe_polyacetylene_test.py: a C4H4 cell = 24 STO-3G AOs, 28 electrons,
+    1 x 1 x 3 k-points): a chain of `nk` cells of `units_per_cell` units (a CH group: `unit_size` = 6 orbitals -- C 1s 2s 2p + H 1s) each,
+    nlo = 24 orbitals and 14 occupied per cell, N = 72 in the supercell.  Orthonormal model orbitals; one-body blocks on a unit and between
+    neighbouring units (different for the four units of a cell: only the translation by a whole cell is a symmetry), density-fitted
+    two-electron integrals whose auxiliary functions sit on three consecutive units.  Same dictionary as `build` (supercell view + Fourier
+    blocks of the converged Fock matrix as the k-point mean field) plus the DF factor `B` (naux, N, N) of the supercell.
+    `rhf(h, eri_s1, nocc) -> dict(mo_coeff, mo_energy, dm, e_tot, veff)`: who solves the supercell mean field (default: the oracle)."""
+    rng = np.random.default_rng(seed)
+    U, u = units_per_cell, unit_size
+    nlo, nun = U * u, nk * U
+    N = nk * nlo
+    a = 4.91
+    nocc_cell = int(sum(occ_per_unit))
+    # per unit type: occupied levels around -1.5, empty ones around +1.5, a symmetric perturbation; hopping to the next unit
+    h_on, h_hop = [], []
+    for t in range(U):
+        no = occ_per_unit[t]
+        lev = np.concatenate([-1.5 - 0.35 * np.arange(no)[::-1], 1.5 + 0.35 * np.arange(u - no)])
+        A = rng.standard_normal((u, u))
+        h_on.append(np.diag(lev) + 0.08 * (A + A.T))
+        h_hop.append(hop * rng.standard_normal((u, u)))
+    orb = lambda j: np.arange((j % nun) * u, (j % nun + 1) * u)
+    hs = np.zeros((N, N))
+    for j in range(nun):
+        hs[np.ix_(orb(j), orb(j))] += h_on[j % U]
+        hs[np.ix_(orb(j), orb(j + 1))] += h_hop[j % U]
+        hs[np.ix_(orb(j + 1), orb(j))] += h_hop[j % U].T
+    pats = []
+    decay = np.repeat([0.45, 1.0, 0.45], u)
+    for t in range(U):
+        pt = scale * rng.standard_normal((naux_unit, 3 * u, 3 * u))
+        pt = 0.5 * (pt + pt.transpose(0, 2, 1)) * decay[None, :, None] * decay[None, None, :]
+        pats.append(pt)
+    B = np.zeros((nun * naux_unit, N, N))
+    for j in range(nun):
+        idx = np.concatenate([orb(j - 1), orb(j), orb(j + 1)])
+        for a_ in range(naux_unit):
+            B[j * naux_unit + a_][np.ix_(idx, idx)] += pats[j % U][a_]
+    eri = np.einsum("Ppq,Prs->pqrs", B, B, optimize=True)
+    nocc = nk * nocc_cell
+    mf = (rhf or oracle_rhf)(hs, eri, nocc)
+    e_gap = mf["mo_energy"][nocc] - mf["mo_energy"][nocc - 1]
+    assert e_gap > 0.3, e_gap
+    veff = mf["veff"]
+    F = hs + veff
+    blk = lambda A, R, S: A[R * nlo:(R + 1) * nlo, S * nlo:(S + 1) * nlo]
+    for R in range(nk):
+        assert np.abs(blk(F, R, (R + 1) % nk) - blk(F, 0, 1)).max() < 1e-7, "the supercell RHF broke the translational symmetry"
+    kpts = np.array([[0.0, 0.0, 2 * np.pi * m / (nk * a)] for m in range(nk)])          # 1 x 1 x nk, like the reference's kpt = [1, 1, 3]
+    a_vec = np.diag([8.0, 8.0, a])
+    ft = lambda A: np.stack([sum(blk(A, D, 0) * np.exp(-1j * kpts[m][2] * D * a) for D in range(nk)) for m in range(nk)])
+    hk, Fk, vk_ = ft(hs), ft(F), ft(veff)
+    Ck, ek = [], []
+    for m in range(nk):
+        e, V = np.linalg.eigh(Fk[m])
+        Ck.append(V); ek.append(e)
+    ek = np.array(ek)
+    assert np.sort(ek[:, :nocc_cell].ravel()).max() < np.sort(ek[:, nocc_cell:].ravel()).min(), "aufbau is not uniform over k"
+    mf_super = dict(mo_coeff=mf["mo_coeff"], mo_energy=mf["mo_energy"], dm=mf["dm"], e_tot=mf["e_tot"])
+    return dict(nk=nk, nlo=nlo, N=N, a=a, a_vec=a_vec, kpts=kpts, kmesh=[1, 1, nk], nocc_cell=nocc_cell, nocc=nocc, kaxis=2,
+                units_per_cell=U, unit_size=u, n_units=nun,
+                h_super=hs, eri_super=eri, B=B, mf_super=mf_super, veff_super=veff, F_super=F,
+                hk=hk, Sk=np.stack([np.eye(nlo, dtype=np.complex128)] * nk), Ck=np.array(Ck), ek=ek, veffk=vk_,
+                e_tot_cell=mf["e_tot"] / nk)
+
+
+def chain_be2_lists(n_units, ncentres, unit_size):
+    """BE2 fragments of a chain of `n_units` units of `unit_size` orbitals, one per centre unit 0..ncentres-1 (the reference's autogen BE2 on
+    polyacetylene: a CH group with its two neighbour groups): fragment c = units {c, c-1, c+1}; each edge unit is matched to the centre of
+    the fragment of that unit -- for ncentres < n_units (fragments of the reference cell only) a translated copy of a fragment of the set."""
+    u = unit_size
+    orb = lambda j: [int(x) for x in range((j % n_units) * u, (j % n_units + 1) * u)]
+    rel = lambda k: list(range(k * u, (k + 1) * u))
+    return dict(AO_per_frag=[orb(c) + orb(c - 1) + orb(c + 1) for c in range(ncentres)],
+                AO_per_edge_per_frag=[[orb(c - 1), orb(c + 1)] for c in range(ncentres)],
+                ref_frag_idx_per_edge_per_frag=[[(c - 1) % ncentres, (c + 1) % ncentres] for c in range(ncentres)],
+                relAO_per_origin_per_frag=[rel(0) for _ in range(ncentres)],
+                weight_and_relAO_per_center_per_frag=[(1.0, rel(0)) for _ in range(ncentres)],
+                relAO_per_edge_per_frag=[[rel(1), rel(2)] for _ in range(ncentres)],
+                relAO_in_ref_per_edge_per_frag=[[rel(0), rel(0)] for _ in range(ncentres)], n_BE=2)
+
+
 def ring_be2_lists(nsite, ncentres):
     """BE2 fragments of a ring of `nsite` one-orbital sites, one per centre 0..ncentres-1: fragment c = {c, c-1, c+1}; the edge c+-1 is
     matched to the centre of fragment (c+-1) mod ncentres -- for ncentres < nsite (the reference cell of a periodic system) that is a
@@ -109,6 +200,6 @@ def real_space_TA(f, m):
     nk, nlo, a = m["nk"], m["nlo"], m["a"]
     TA = np.zeros((nk, nlo, f.TA.shape[-1]), dtype=np.complex128)
     for R in range(nk):
-        TA[R] = sum(np.exp(1j * m["kpts"][k][0] * R * a) * f.TA[k] for k in range(nk)) / nk
+        TA[R] = sum(np.exp(1j * m["kpts"][k][m.get("kaxis", 0)] * R * a) * f.TA[k] for k in range(nk)) / nk
     assert np.abs(TA.imag).max() < 1e-9
     return np.ascontiguousarray(TA.real.reshape(nk * nlo, -1))

@@ -464,6 +464,18 @@ def test_periodic_driver_matches_the_supercell(qlib):
     check_gamma_point_driver_with_direct_df(qlib)
 
 
+def test_c5_dimensions_kpoint_view_equals_supercell_view(qlib):
+    """BASELINE configs[4] AT ITS OWN DIMENSIONS (kbe polyacetylene BE2: 24 AOs per cell, 28 electrons, 1 x 1 x 3 k-points; the reference's
+    libdmet / PySCF-PBC integrals do not exist here, so the integrals are a density-fitted model of that size): kbe_pbe.BE with the four BE2
+    fragments of the reference cell (18 sites + 18 bath orbitals), fragment ERIs from the supercell's DF integrals through the device CC-GDF
+    transform (kbe_eri_onthefly.integral_direct_DF), against the molecular driver on the 72-orbital supercell with 12 fragments and dense
+    integrals -- HF-in-HF 1e-8, fragment ERIs 1e-10, one-shot E_corr per cell and its pieces 1e-8, density-matched E_corr per cell 5e-7 and
+    the translational symmetry of the 169 matched potentials.  kbe/pbe.py:78-316, :502-716."""
+    from test_kbe_pbe import check_c5_driver
+    m, kbe, mol = check_c5_driver(qlib, matching=True)
+    assert kbe.nstreams is not None                     # the sweep mode was chosen from the fragments' sizes (four fragments of 36 orbitals: streams)
+
+
 def test_whole_system_fragment_is_the_molecular_ccsd(qlib):
     from test_hostlogic_be import check_schmidt_svd_wide_and_empty_environment, check_whole_system_fragment
     check_whole_system_fragment(qlib)

@@ -1,0 +1,65 @@
+"""Counter bytes against algorithmic bytes for the HBM-bound kernels of one n = 220, n_occ = 20 fragment solve (tools/hbm_pmc.sh).
+
+    python tools/hbm_pmc.py <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass>  > profiles/r04_hbm_pmc.json
+
+Per kernel symbol (large calls only: within 2x of the longest): FETCH_SIZE and WRITE_SIZE in KB as rocprofv3 reports them; HBM bytes =
+2 x FETCH_SIZE + WRITE_SIZE (gfx950: FETCH_SIZE counts 128-byte requests at 64 bytes for wide streaming reads -- the guide's correction,
+calibrated for 16-byte-per-lane loads; the raw sum is kept beside it); the algorithmic bytes of tools/kernel_roofline.py; their ratio; and
+the duration under the counter pass (serialised dispatches) with the resulting rates."""
+import csv
+import glob
+import json
+import sys
+
+sys.path.insert(0, "tools")
+
+
+def load(d, counter):
+    f = glob.glob(f"{d}/*/*counter_collection.csv")[0]
+    out = {}
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] != counter:
+            continue
+        dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9 if "End_Timestamp" in r and r["End_Timestamp"] else None
+        out.setdefault(r["Kernel_Name"], []).append((float(r["Counter_Value"]), dur))
+    return out
+
+
+def main():
+    import io
+    import contextlib
+    sys.argv, argv = [sys.argv[0]], sys.argv
+    with contextlib.redirect_stdout(io.StringIO()):
+        try:
+            import kernel_roofline as kr          # only its tables (its body needs a trace file: guarded below)
+        except Exception:  # noqa: BLE001
+            kr = None
+    sys.argv = argv
+    if kr is None:
+        raise SystemExit("tools/kernel_roofline.py did not import")
+    fetch, write = load(argv[1], "FETCH_SIZE"), load(argv[2], "WRITE_SIZE")
+    rows = []
+    for key, (alg, what) in kr.bytes_of.items():
+        fv = [x for nm, xs in fetch.items() if key in nm for x in xs]
+        wv = [x for nm, xs in write.items() if key in nm for x in xs]
+        if not fv or not wv:
+            continue
+        # large calls: by the counter value itself (a symbol is shared by call sites of different sizes)
+        fbig = [x for x in fv if x[0] + 1 >= 0.5 * max(v for v, _ in fv)]
+        wbig = [x for x in wv if x[0] + 1 >= 0.5 * max(v for v, _ in wv)]
+        fkb = sum(v for v, _ in fbig) / len(fbig)
+        wkb = sum(v for v, _ in wbig) / len(wbig)
+        durs = [d for _, d in fbig if d]
+        t = sum(durs) / len(durs) if durs else None
+        hbm = (2.0 * fkb + wkb) * 1024.0
+        rows.append(dict(kernel=key, what=what, large_calls=len(fbig), FETCH_SIZE_KB=round(fkb, 1), WRITE_SIZE_KB=round(wkb, 1),
+                         hbm_GB=round(hbm / 1e9, 3), hbm_GB_uncorrected=round((fkb + wkb) * 1024.0 / 1e9, 3), algorithmic_GB=round(alg / 1e9, 3),
+                         counter_over_algorithmic=round(hbm / alg, 3), ms_under_counters=None if t is None else round(t * 1e3, 4),
+                         algorithmic_TBps=None if t is None else round(alg / t / 1e12, 2), counter_TBps=None if t is None else round(hbm / t / 1e12, 2)))
+    json.dump(dict(note="rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) on `python tools/frag_bench.py 220 20`; hbm = 2 x FETCH + WRITE "
+                        "(gfx950 correction for wide streaming reads, MI355X guide); ratio = counter bytes / algorithmic bytes of tools/kernel_roofline.py",
+                   kernels=rows), sys.stdout, indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -43,21 +43,26 @@ bytes_of = {   # kernel-name fragment -> (algorithmic bytes of one large call, w
     "small_k_update": (2 * N2, "rank-n_occ update of an o^2 v^2 tensor (r/w), MFMA"),
 }
 
-files = [f for a in sys.argv[1:] for f in glob.glob(a)]
-rows = list(csv.DictReader(open(files[0])))
-agg = {}
-for r in rows:
-    for key in list(flops_of) + list(bytes_of):
-        if key in r["Kernel_Name"]:
-            agg.setdefault(key, []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9)
-for key, ds in agg.items():
-    top = [d for d in ds if d >= 0.5 * max(ds)]
-    t = sum(top) / len(top)
-    if key in flops_of:
-        f, what = flops_of[key]
-        print(json.dumps(dict(kernel="dgemm_mfma_kernel" + key, bound="mfma", what=what, calls=len(ds), large_calls=len(top), mean_ms=round(t * 1e3, 4),
-                              executed_GFLOP=round(f / 1e9, 1), TFLOPs=round(f / t / 1e12, 2), frac_of_78_6_TFLOPs=round(f / t / PEAK_F, 3))))
-    else:
-        b, what = bytes_of[key]
-        print(json.dumps(dict(kernel=key, bound="hbm", what=what, calls=len(ds), large_calls=len(top), mean_ms=round(t * 1e3, 4),
-                              algorithmic_GB=round(b / 1e9, 3), TBps=round(b / t / 1e12, 2), frac_of_8_TBps=round(b / t / PEAK_B, 3))))
+def main():
+    files = [f for a in sys.argv[1:] for f in glob.glob(a)]
+    rows = list(csv.DictReader(open(files[0])))
+    agg = {}
+    for r in rows:
+        for key in list(flops_of) + list(bytes_of):
+            if key in r["Kernel_Name"]:
+                agg.setdefault(key, []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9)
+    for key, ds in agg.items():
+        top = [d for d in ds if d >= 0.5 * max(ds)]
+        t = sum(top) / len(top)
+        if key in flops_of:
+            f, what = flops_of[key]
+            print(json.dumps(dict(kernel="dgemm_mfma_kernel" + key, bound="mfma", what=what, calls=len(ds), large_calls=len(top), mean_ms=round(t * 1e3, 4),
+                                  executed_GFLOP=round(f / 1e9, 1), TFLOPs=round(f / t / 1e12, 2), frac_of_78_6_TFLOPs=round(f / t / PEAK_F, 3))))
+        else:
+            b, what = bytes_of[key]
+            print(json.dumps(dict(kernel=key, bound="hbm", what=what, calls=len(ds), large_calls=len(top), mean_ms=round(t * 1e3, 4),
+                                  algorithmic_GB=round(b / 1e9, 3), TBps=round(b / t / 1e12, 2), frac_of_8_TBps=round(b / t / PEAK_B, 3))))
+
+
+if __name__ == "__main__":
+    main()
