@@ -381,16 +381,19 @@ def _cpu_pool_task(args):
 def cpu_worker(d, mode, o, iters, nproc):
     """child process of cpu_baseline (never touches the GPU): runs the worker pool and prints one JSON line"""
     import multiprocessing as mp
-    task, jobs = (_cpu_full_task, [(d, i) for i in range(nproc)]) if mode == "full" else (_cpu_pool_task, [(d, o, iters)] * nproc)
+    if mode == "octane":          # `iters` carries the number of fragments: more tasks than workers, one fragment per task
+        task, jobs = _cpu_octane_task, [(d, i) for i in range(iters)]
+    else:
+        task, jobs = (_cpu_full_task, [(d, i) for i in range(nproc)]) if mode == "full" else (_cpu_pool_task, [(d, o, iters)] * nproc)
     t0 = time.perf_counter()
     if nproc <= 1:
-        res = [task(jobs[0])]
+        res = [task(j) for j in jobs]
     else:
         with mp.get_context("spawn").Pool(nproc) as pool:
             res = pool.map(task, jobs, chunksize=1)
     wall = time.perf_counter() - t0
     slowest = max(r[0] for r in res)
-    if mode == "full":
+    if mode in ("full", "octane"):
         assert all(r[4] for r in res), "a CPU fragment solve did not converge"
         print(json.dumps(dict(pool_wall_s=wall, slowest_worker_s=slowest, iterations=sum(r[1] for r in res), e_corr=[r[2] for r in res],
                               e_frag=[r[3] for r in res])), flush=True)
@@ -458,11 +461,75 @@ def roofline_pass(lib, fr, h, dm0, o, opts, iters):
     return dict(ladder_ms=lad[0] / max(lad[1], 1), ladder_count=lad[1], rings_ms=ring[0] / max(ring[1], 1), iter_ms=it[0] / max(it[1], 1))
 
 
-def octane_sweeps(lib, reps=5):
+def _stats_ms(ts):
+    """p50 / p95 / max / mean / min of a series of sweep times (ms) and the series itself"""
+    xs = sorted(ts)
+    q = lambda f: xs[min(len(xs) - 1, int(round(f * (len(xs) - 1))))]
+    return dict(p50_ms=q(0.5), p95_ms=q(0.95), max_ms=xs[-1], min_ms=xs[0], mean_ms=sum(xs) / len(xs), sweeps=len(xs), series_ms=[round(t, 2) for t in ts])
+
+
+def timed_sweeps(lib, fn, reps):
+    """`reps` sweeps, each bracketed by a device sync; Python's cyclic garbage collector is held off during the series (a generation-2
+    collection in the middle of a 15 ms sweep is a host pause of tens of ms that has nothing to do with the device path) and run once before it"""
+    import gc
+    gc.collect()
+    was = gc.isenabled()
+    gc.disable()
+    ts = []
+    try:
+        for _ in range(reps):
+            lib.qemb_device_sync(); t0 = time.perf_counter()
+            out = fn()
+            lib.qemb_device_sync()
+            ts.append((time.perf_counter() - t0) * 1e3)
+    finally:
+        if was:
+            gc.enable()
+    return ts, out
+
+
+def _cpu_octane_task(args):
+    """one worker of the octane CPU pool: the reference worker's whole job on one fragment of the octane BE2 sweep"""
+    d, i = args
+    sys.path.insert(0, str(ROOT / "oracle"))
+    from qemb_oracle import worker
+    z = np.load(os.path.join(d, f"oct{i}.npz"))
+    t0 = time.perf_counter()
+    out = worker.run_solver(z["h"], z["dm0"], z["s4"], int(z["o"]), int(z["nf"]), (float(z["w"]), [int(c) for c in z["cen"]]), z["h1"], z["veff0"], eeval=True)
+    return time.perf_counter() - t0, int(out["n_iter"]), float(out["e_corr"]), [float(x) for x in out["e_f"]], bool(out["converged"])
+
+
+def octane_cpu_baseline(be, e_gpu, ompnum=4, budget_s=120):
+    """cpu_baseline for the small-fragment regime: the SAME six octane BE2 fragments (h = fock + heff, dm0, 4-fold packed ERIs read back from
+    the device, centre weights) through the oracle's worker (oracle/qemb_oracle/worker.py = run_solver, be_parallel.py:40-307) in the
+    reference's pool shape -- `cores // ompnum` worker processes with `ompnum` BLAS threads each, one fragment per task -- one sweep timed."""
+    import shutil
+    import tempfile
+    cores = usable_cores()
+    nproc = max(1, min(len(be.Fobjs), cores // ompnum))
+    d = tempfile.mkdtemp(prefix="qemb_bench_oct_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        for i, f in enumerate(be.Fobjs):
+            w, cen = f.weight_and_relAO_per_center
+            np.savez(os.path.join(d, f"oct{i}.npz"), h=f.fock + f.heff, dm0=f.dm0, s4=f.dev.get_eri_s4(), o=f.nsocc, nf=f.n_frag, w=w, cen=np.array(cen),
+                     h1=f.h1, veff0=f.veff0)
+        r = cpu_pool_run(d, "octane", nproc, ompnum, ["--cpu-iters", str(len(be.Fobjs))], budget_s)
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    if isinstance(r, str):
+        return dict(value=None, note=r, nproc=nproc, ompnum=ompnum)
+    e_cpu = sum(sum(ef) for ef in r["e_frag"])
+    return dict(sweep_ms=r["pool_wall_s"] * 1e3, unit="ms per octane BE2 sweep", kind="port", nproc=nproc, ompnum=ompnum, cores=nproc * ompnum,
+                iterations=r["iterations"], slowest_fragment_s=r["slowest_worker_s"], e_corr=e_cpu, abs_e_corr_diff_vs_gpu_Eh=abs(e_cpu - e_gpu),
+                sample="one sweep: the six fragments of the GPU sweep (same h, dm0, ERIs read back from the device), whole fragment solves by "
+                       "oracle/qemb_oracle/worker.py, one fragment per pool task")
+
+
+def octane_sweeps(lib, reps=24, cpu=True):
     """BASELINE configs[1] beside the headline: one octane/STO-3G BE2 sweep (six fragments of ~40 embedding orbitals; integrals, RHF and
     fragmentation from the in-tree source, tests/golden/) through the product -- fragment by fragment, six fragments in flight on separate
     streams, and all fragments in ONE lock-step batched call (qemb_frag_solve_batch: one grouped launch per operation of the CCSD update
-    for all fragments).  The three sweeps return bit-identical energies."""
+    for all fragments).  The three sweeps return bit-identical energies.  Per mode: p50 / p95 / max over `reps` sweeps."""
     from quemb_amd.fragpart import FragPart
     from quemb_amd.integrals import RHF, Mole
     from quemb_amd.mbe import BE
@@ -470,20 +537,15 @@ def octane_sweeps(lib, reps=5):
     mf = RHF(Mole(G / "octane.xyz")); mf.kernel()
     out = {}
     energies = []
-    for label, kw in (("serial", dict(nstreams=1)), ("streams6", dict(nstreams=6)), ("lockstep", dict(lockstep=True))):
+    be = None
+    for label, kw, n in (("serial", dict(nstreams=1), max(5, reps // 4)), ("streams6", dict(nstreams=6), reps), ("lockstep", dict(lockstep=True), reps)):
         be = BE(mf, FragPart.from_json(G / "fragmentation.json", "test_autogen_octane_be2"), distribute=False, lib=lib, **kw)
-        be.oneshot()
+        be.oneshot(); be.oneshot()
         be.stats.clear()
-        ts = []
-        for _ in range(reps):
-            lib.qemb_device_sync(); t0 = time.perf_counter()
-            e, _ = be.oneshot()
-            lib.qemb_device_sync()
-            ts.append((time.perf_counter() - t0) * 1e3)
-        ts.sort()
-        out[label + "_ms"] = ts[len(ts) // 2]          # median sweep (a sweep now and then stalls for milliseconds in an allocation; the mean is beside it)
-        out[label + "_mean_ms"] = sum(ts) / len(ts)
-        out[label + "_min_ms"] = ts[0]
+        ts, (e, _) = timed_sweeps(lib, be.oneshot, n)
+        st = _stats_ms(ts)
+        out[label] = st
+        out[label + "_ms"] = st["p50_ms"]
         energies.append(e)
         if label == "lockstep":
             out["lockstep_launch_stats"] = {k: int(v) for k, v in be.stats.items() if k in ("merged_runs", "launches", "grouped_launches", "operations", "max_group")}
@@ -491,7 +553,62 @@ def octane_sweeps(lib, reps=5):
     out["bit_identical"] = bool(energies[0] == energies[1] == energies[2])
     out["fragments"] = 6
     out["what"] = "octane/STO-3G BE2 one-shot sweep (example/molbe_octane.py): fragment RHF + MO transformation + RCCSD + RDMs + energies for every fragment"
+    if cpu:
+        try:
+            out["cpu_baseline"] = octane_cpu_baseline(be, energies[0])
+        except Exception as e:  # noqa: BLE001
+            out["cpu_baseline"] = dict(value=None, note=f"failed: {e}")
     return out
+
+
+def kbe_c5_sweeps(lib, reps=20):
+    """BASELINE configs[4] at its own dimensions (kbe polyacetylene BE2: a C4H4 cell of 24 AOs and 28 electrons, 1 x 1 x 3 k-points) on the
+    density-fitted model of that size (tests/kbe_model.build_chain; PySCF-PBC / libdmet integrals do not exist in this image): the supercell
+    mean field by the device fragment RHF, `kbe_pbe.BE(int_transform="supercell-DF-hip")` -- k -> R Fourier step and SVD Schmidt per
+    fragment, fragment ERIs from the supercell DF integrals through the device CC-GDF transform, k-averaged Fock, fragment RHF, HF-in-HF --
+    then one-shot sweeps over the four fragments of the reference cell (36 embedding orbitals each)."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    import kbe_model
+    from kbe_df_source import GammaSourceFromFactor
+    from quemb_amd import kbe_pbe
+    from quemb_amd.fragpart import FragPart
+    from quemb_amd.fragsolver import DeviceFragment
+
+    def device_rhf(hs, eri_s1, nocc):
+        N = hs.shape[0]
+        il = np.tril_indices(N)
+        fr = DeviceFragment(N, N, lib=lib)
+        fr.set_eri_s4(np.ascontiguousarray(eri_s1[il[0], il[1]][:, il[0], il[1]]))
+        r = fr.scf(nocc, hs, None)
+        if not r["converged"]:
+            raise RuntimeError("the supercell RHF of the configs[4] model did not converge")
+        C_ = r["mo_coeff"]
+        dm = 2.0 * C_[:, :nocc] @ C_[:, :nocc].T
+        J, K = fr.jk(dm)
+        fr.free()
+        veff = J - 0.5 * K
+        return dict(mo_coeff=C_, mo_energy=r["mo_energy"], dm=dm, e_tot=0.5 * float(np.einsum("ij,ji->", 2.0 * hs + veff, dm)), veff=veff)
+
+    t0 = time.perf_counter()
+    m = kbe_model.build_chain(rhf=device_rhf)
+    t_model = time.perf_counter() - t0
+    kmf = kbe_pbe.KMeanField(a_vec=m["a_vec"], kpts=m["kpts"], kmesh=m["kmesh"], nelectron=2 * m["nocc_cell"], hcore=m["hk"], S=m["Sk"],
+                             mo_coeff=m["Ck"], mo_energy=m["ek"], hf_veff=m["veffk"], e_tot=m["e_tot_cell"])
+    src = GammaSourceFromFactor(m["B"])
+    lib.qemb_device_sync(); t0 = time.perf_counter()
+    be = kbe_pbe.BE(kmf, FragPart(**kbe_model.chain_be2_lists(m["n_units"], m["units_per_cell"], m["unit_size"])), lib=lib, distribute=False,
+                    int_transform="supercell-DF-hip", df_source=src)
+    lib.qemb_device_sync(); t_init = (time.perf_counter() - t0) * 1e3
+    be.oneshot(); be.oneshot()
+    ts, (e, _) = timed_sweeps(lib, be.oneshot, reps)
+    st = _stats_ms(ts)
+    return dict(sweep=st, sweep_ms=st["p50_ms"], fragments=len(be.Fobjs), n_emb=[int(f.nao) for f in be.Fobjs], n_occ=[int(f.nsocc) for f in be.Fobjs],
+                aos_per_cell=m["nlo"], kpts=m["nk"], electrons_per_cell=2 * m["nocc_cell"], n_supercell=m["N"], naux_supercell=int(m["B"].shape[0]),
+                initialize_ms=t_init, model_build_s=t_model, hf_in_hf_error_Eh=float(be.hf_err), e_corr_per_cell=float(e), nstreams=be.nstreams, lockstep=be.lockstep,
+                what="kbe_pbe.BE one-shot sweep at the dimensions of BASELINE configs[4] (kbe/pbe.py:78-316, :502-716): 4 BE2 fragments of the reference cell, "
+                     "fragment RHF + MO transformation + RCCSD + RDMs + energies each; initialize_ms = Schmidt (k -> R, SVD), supercell CC-GDF transform of all "
+                     "fragments, k-averaged Fock, fragment RHF, HF-in-HF; synthetic DF model integrals (tests/kbe_model.build_chain), parity in "
+                     "tests/test_gpu_be.py::test_c5_dimensions_kpoint_view_equals_supercell_view")
 
 
 # ------------------------------------------------------------------------------------------------------------ main
@@ -704,11 +821,19 @@ def main():
                         from quemb_amd.solver import set_cu_partition
                         set_cu_partition(lib, 0)          # small fragments: every context on the whole chip again
                     with contextlib.redirect_stdout(sys.stderr):      # the BE driver prints its energies: stdout carries the ONE JSON line only
-                        oc = octane_sweeps(lib)
+                        oc = octane_sweeps(lib, cpu=not args.no_cpu_baseline)
                     res["octane_be2_sweep_ms"] = min(oc["streams6_ms"], oc["lockstep_ms"])
                     res["octane_be2"] = oc
                 except Exception as e:  # noqa: BLE001
                     res["octane_be2_sweep_ms"] = f"failed: {e}"
+                log("periodic driver at the dimensions of configs[4]")
+                try:
+                    with contextlib.redirect_stdout(sys.stderr):
+                        kc = kbe_c5_sweeps(lib)
+                    res["kbe_c5_sweep_ms"] = kc["sweep_ms"]
+                    res["kbe_c5"] = kc
+                except Exception as e:  # noqa: BLE001
+                    res["kbe_c5_sweep_ms"] = f"failed: {e}"
             if not args.no_cpu_baseline:
                 info, e_dev, e_cpu = cpu_baseline(lib, fr0.dev, h0, dm00, o, opts, args.cpu_iters, args.cpu_ompnum, args.scale)
                 res["cpu_baseline"] = info

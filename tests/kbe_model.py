@@ -16,11 +16,17 @@ Per unit cell both must give the same HF-in-HF identity and the same correlation
 Test infrastructure (uses oracle/)."""
 import numpy as np
 
-from qemb_oracle import eri as oeri
-from qemb_oracle import scf as oscf
+
+def _oracle():
+    """the oracle is imported where a TEST asks for it (build, oracle_rhf, SupercellMF): bench.py uses build_chain with the device RHF and
+    must not pull the oracle in"""
+    from qemb_oracle import eri as oeri
+    from qemb_oracle import scf as oscf
+    return oeri, oscf
 
 
 def build(nk=4, nlo=3, nocc_cell=1, seed=5, naux_cell=4, gap=1.6, scale=0.45):
+    oeri, oscf = _oracle()
     rng = np.random.default_rng(seed)
     N = nk * nlo
     a = 2.5
@@ -75,6 +81,7 @@ def build(nk=4, nlo=3, nocc_cell=1, seed=5, naux_cell=4, gap=1.6, scale=0.45):
 
 def oracle_rhf(hs, eri_s1, nocc):
     """the supercell mean field by the oracle (tests); bench.py passes the device fragment RHF instead"""
+    oeri, oscf = _oracle()
     mf = oscf.rhf(hs, eri_s1, nocc, conv_tol=1e-13, conv_tol_grad=1e-10)
     assert mf["converged"]
     vj, vk = oscf.get_jk(eri_s1, mf["dm"])
@@ -186,7 +193,7 @@ class SupercellMF:
         self.m = m
         self.mol = type("Mol", (), {"nelectron": 2 * m["nocc"]})()
         self.mo_coeff, self.mo_energy, self.e_tot = m["mf_super"]["mo_coeff"], m["mf_super"]["mo_energy"], m["mf_super"]["e_tot"]
-        self._eri = oeri.pack_s4(m["eri_super"])
+        self._eri = _oracle()[0].pack_s4(m["eri_super"])
 
     def energy_nuc(self): return 0.0
     def get_hcore(self): return self.m["h_super"]

@@ -217,3 +217,29 @@ def test_killed_rank_ends_the_other_seven_within_the_bound():
             assert p.returncode == 3, (r, p.returncode, se[-1500:])
             assert "a rank is gone" in so
     assert time.monotonic() - t0 < 120
+
+
+_C5_SCRIPT = r"""
+import ctypes as C, json, sys
+sys.path.insert(0, sys.argv[1])
+from quemb_amd import _lib
+lib = _lib.declare(C.CDLL(sys.argv[2]))
+_lib.check(lib.qemb_init(0), "qemb_init", lib)
+import bench
+r = bench.kbe_c5_sweeps(lib, reps=2)
+r["oracle_imported"] = any(m.startswith("qemb_oracle") for m in sys.modules)
+print("RESULT " + json.dumps(r))
+"""
+
+
+@pytest.mark.timeout(600)
+def test_kbe_c5_bench_field_on_the_mock():
+    """bench.py's `kbe_c5` section (BASELINE configs[4] at its own dimensions) on the mock: the model's mean field comes from the device
+    RHF -- the oracle is not imported on this path --, four fragments of 36 embedding orbitals, HF-in-HF, sweep statistics."""
+    p = subprocess.run([sys.executable, "-c", _C5_SCRIPT, str(ROOT), _mock()], env=_env(), capture_output=True, text=True, timeout=560)
+    assert p.returncode == 0, p.stderr[-2000:]
+    r = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")][0][7:])
+    assert r["oracle_imported"] is False
+    assert r["fragments"] == 4 and r["n_emb"] == [36] * 4 and r["aos_per_cell"] == 24 and r["kpts"] == 3 and r["electrons_per_cell"] == 28
+    assert abs(r["hf_in_hf_error_Eh"]) < 1e-8 and r["e_corr_per_cell"] < -1e-3
+    assert r["sweep"]["sweeps"] == 2 and r["sweep"]["p50_ms"] <= r["sweep"]["max_ms"] and r["sweep_ms"] > 0

@@ -165,8 +165,10 @@ def test_fragment_at_bench_tiles(qlib):
     fr.free()
 
 
-def test_bench_fragment_n220_against_oracle(qlib):
-    """THE benchmarked fragment (BASELINE configs[2]: n = 220, n_occ = 20, n_virt = 200; fragment 0 of bench.py's sweep, ERIs built on the
+@pytest.mark.parametrize("frag", [0, 1, 2])
+def test_bench_fragment_n220_against_oracle(qlib, frag):
+    """(round 4: fragments 1 and 2 of the timed sweep as well, seeds 20260804 / 05 -> frag220_f1.npz, frag220_f2.npz)
+    THE benchmarked fragment (BASELINE configs[2]: n = 220, n_occ = 20, n_virt = 200; fragment 0 of bench.py's sweep, ERIs built on the
     device from the DF factor exactly as bench.make_device_eris does) against the oracle's stored results (tests/golden/frag220.npz, written
     by make_golden_frag220.py: ten minutes of NumPy): fragment RHF, the energy after 3 plain amplitude updates from the MP2 guess (the number
     bench.py's parity field reports), and the converged DIIS solve -- E_corr, iteration count, 1-RDM."""
@@ -177,9 +179,9 @@ def test_bench_fragment_n220_against_oracle(qlib):
     if str(GOLDEN) not in sys.path:
         sys.path.insert(0, str(GOLDEN))
     import make_golden_frag220 as mg
-    g = np.load(GOLDEN / "frag220.npz")
+    g = np.load(GOLDEN / ("frag220.npz" if frag == 0 else f"frag220_f{frag}.npz"))
     n, o = int(g["n"]), int(g["o"])
-    assert (n, o, int(g["seed"]), float(g["scale"])) == (mg.N, mg.O, mg.SEED, mg.SCALE) == (220, 20, 20260803, 0.03)
+    assert (n, o, int(g["seed"]), float(g["scale"])) == (mg.N, mg.O, mg.SEED + frag, mg.SCALE) == (220, 20, 20260803 + frag, 0.03)
     h, B = mg.bench_fragment(n, int(g["seed"]), float(g["scale"]))
     il = np.tril_indices(n)
     Bp = np.ascontiguousarray(B[:, il[0], il[1]])
@@ -204,6 +206,71 @@ def test_bench_fragment_n220_against_oracle(qlib):
     assert abs(out["n_iter"] - int(g["n_iter"])) <= 1
     assert np.abs(out["rdm1_emb"] - g["rdm1_emb"]).max() < TOL_RDM
     assert abs(np.linalg.norm(out["t1"]) - float(g["t1_norm"])) < 1e-7 and abs(np.linalg.norm(out["t2"]) - float(g["t2_norm"])) < 1e-7
+    fr.free()
+
+
+def test_relaxed_fragment_at_bench_tiles(qlib):
+    """relax_density = 1 at n_occ = 20, n_virt = 64 (the kernel instantiations of the headline workload): Lambda equations, response 1-RDM and
+    the fragment energies from the relaxed 2-RDM against the oracle's stored results (tests/golden/frag84_relaxed.npz, written by
+    make_golden_frag84_relaxed.py: minutes of NumPy).  solver.py:925-939."""
+    import sys
+    from helpers import GOLDEN
+    if str(GOLDEN) not in sys.path:
+        sys.path.insert(0, str(GOLDEN))
+    import make_golden_frag84 as mg
+    g = np.load(GOLDEN / "frag84_relaxed.npz")
+    n, o, nf, cen = int(g["n"]), int(g["o"]), int(g["nf"]), [int(c) for c in g["cen"]]
+    assert (n, o, nf, int(g["seed"])) == (mg.N, mg.O, mg.NF, mg.SEED)
+    h, e1 = synthetic_fragment(n, o, int(g["seed"]))
+    h1, veff0, veff = mg.energy_data(n, n)
+    fr = DeviceFragment(n, nf)
+    fr.set_eri_s4(eri.pack_s4(e1))
+    fr.set_energy_data(h1, veff0, veff, 1.0, cen)
+    opts = default_opts(cc_conv_tol=1e-12, cc_conv_tol_normt=1e-10, scf_conv_tol=1e-12, scf_conv_tol_grad=1e-8, relax_density=1, lambda_conv_tol=1e-10)
+    out = fr.solve(o, h, opts=opts, eeval=True)
+    assert abs(out["e_corr_mo"] - float(g["e_corr"])) < TOL_E, (out["e_corr_mo"], float(g["e_corr"]))
+    assert abs(out["lambda_iters"] - int(g["lambda_iters"])) <= 2
+    assert np.abs(out["rdm1_emb"] - g["rdm1_emb"]).max() < TOL_RDM
+    assert np.abs(np.array(out["e_frag"]) - g["e_frag"]).max() < TOL_E, (out["e_frag"], g["e_frag"])
+    fr.free()
+
+
+# randomised parity (round 4: tools/fuzz_parity.py as a test): fixed seeds, sizes 6 .. 96, random n_occ, fragment sites and centres;
+# fragment RHF -> RCCSD -> densities -> fragment energies against the oracle, unrelaxed everywhere and relaxed up to n = 48
+FUZZ_CASES = [(seed, 6, 41) for seed in range(101, 113)] + [(201, 41, 61), (202, 41, 61), (203, 61, 81), (204, 61, 81), (205, 81, 97), (206, 96, 97)]
+
+
+@pytest.mark.parametrize("seed,nmin,nmax", FUZZ_CASES)
+def test_randomised_fragment_parity(qlib, seed, nmin, nmax):
+    from qemb_oracle import ccsd_lambda
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(nmin, nmax))
+    o = int(rng.integers(1, n)) if n <= 40 else int(rng.integers(4, max(5, n // 4)))      # large cases: the benchmark's regime n_occ << n_virt (oracle cost)
+    nf = int(rng.integers(1, n + 1))
+    cen = sorted(set(int(x) for x in rng.integers(0, nf, size=min(nf, 3))))
+    h, e1 = synthetic_fragment(n, o, 1000 + seed, scale=0.05 if n <= 40 else None)
+    mf = scf.rhf(h, e1, o, conv_tol=1e-12, conv_tol_grad=1e-8)
+    assert mf["converged"]
+    h1 = rng.standard_normal((n, n)); h1 = h1 + h1.T
+    v0 = rng.standard_normal((n, n)); v0 = v0 + v0.T
+    s4 = eri.pack_s4(e1)
+    fr = DeviceFragment(n, nf); fr.set_eri_s4(s4); fr.set_energy_data(h1, v0, None, 0.7, cen)
+    eris = ccsd.Eris(e1, mf["mo_coeff"], o, mo_energy=mf["mo_energy"])
+    conv, ecc, t1, t2, _ = ccsd.kernel(eris, conv_tol=1e-12, conv_tol_normt=1e-10, max_cycle=200)
+    assert conv
+    C = mf["mo_coeff"]
+    for relax in ((0, 1) if n <= 48 else (0,)):
+        out = fr.solve(o, h, opts=default_opts(relax_density=relax, cc_conv_tol=1e-12, cc_conv_tol_normt=1e-10, scf_conv_tol=1e-12, scf_conv_tol_grad=1e-8,
+                                               lambda_conv_tol=1e-10, cc_max_cycle=200), eeval=True)
+        if relax:
+            z1, z2, _, lag = ccsd_lambda.solve_lambda(t1, t2, eris, conv_tol=1e-11)
+            dm1, _ = ccsd_lambda.response_densities(lag, z1, z2); g2 = ccsd_lambda.make_rdm2_relaxed(lag, z1, z2)
+        else:
+            dm1, g2 = rdm.make_rdm1_ccsd_t1(t1), rdm.make_rdm2_urlx(t1, t2, with_dm1=False)
+        e_ref = be.get_frag_energy(C, o, nf, (0.7, cen), np.zeros((n, n)), h1, dm1, g2, s4, v0, None, True)
+        assert abs(out["e_corr_mo"] - ecc) < TOL_E, (n, o, relax, out["e_corr_mo"], ecc)
+        assert np.abs(out["rdm1_emb"] - 0.5 * C @ dm1 @ C.T).max() < TOL_RDM, (n, o, relax)
+        assert np.abs(np.array(out["e_frag"]) - np.array(e_ref)).max() < TOL_E, (n, o, nf, cen, relax)
     fr.free()
 
 

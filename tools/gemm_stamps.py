@@ -55,3 +55,6 @@ if __name__ == "__main__":
     run("pp-ladder (+) pairs", npo, npv, npv, 313, 8, 7, 2)
     run("pp-ladder (-) pairs", nmo, nmv, nmv, 315, 8, 6, 2)
     run("ph-ring (ov)^3 NT", o * v, o * v, o * v, 304, 0, 4, 4)
+    # round 4: the short-K products of the MO transformation (K = n = 220: 14 k-tiles per 224 x 128 output tile), a quarter of the columns
+    n = 220
+    run("MO quarter transform, K = 220 (M = 220, N = 128 x 10240)", n, 128 * 10240, n, 313, 0, 7, 2)
