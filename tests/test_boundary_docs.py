@@ -66,3 +66,26 @@ def test_struct_size_mismatch_is_rejected():
     raw = SolverOpts()                                     # never initialised: zeros
     assert call(raw) == -1
     lib.qemb_frag_free(fr)
+
+
+def test_design_figures_follow_the_tracked_profile():
+    """DESIGN.md section 5 quotes ladder / ring figures 'from profiles/rNN_bench_nstreams1_kernel_stats.csv': the block between the figures
+    markers must be exactly what tools/design_figures.py derives from that tracked file (round-3 review: text and artifact had drifted)."""
+    sys.path.insert(0, str(ROOT / "tools"))
+    import design_figures
+    txt = (ROOT / "DESIGN.md").read_text()
+    m = re.search(r"<!-- figures: (\S+) -->\n```\n(.*?)\n```\n<!-- /figures -->", txt, flags=re.S)
+    assert m, "DESIGN.md carries no figures block"
+    src = m.group(1)
+    assert (ROOT / src).exists(), f"{src} is not tracked"
+    import os
+    cwd = os.getcwd()
+    os.chdir(ROOT)
+    try:
+        want = design_figures.figures(src)
+    finally:
+        os.chdir(cwd)
+    assert m.group(2).strip() == want.strip()
+    # and the prose of the section quotes the same averages
+    lad = re.search(r"ladder \(\+\) pairs: \d+ dispatches, ([0-9.]+) ms", want).group(1)
+    assert lad in txt.replace(m.group(0), ""), f"the text of DESIGN.md does not quote the ladder (+) average {lad} ms of {src}"
