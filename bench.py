@@ -472,7 +472,9 @@ def timed_sweeps(lib, fn, reps):
     """`reps` sweeps, each bracketed by a device sync; Python's cyclic garbage collector is held off during the series (a generation-2
     collection in the middle of a 15 ms sweep is a host pause of tens of ms that has nothing to do with the device path) and run once before it"""
     import gc
+    t_gc = time.perf_counter()
     gc.collect()
+    timed_sweeps.last_full_gc_ms = (time.perf_counter() - t_gc) * 1e3      # what a generation-2 collection costs in THIS process, reported beside the series
     was = gc.isenabled()
     gc.disable()
     ts = []
@@ -544,11 +546,15 @@ def octane_sweeps(lib, reps=24, cpu=True):
         be.stats.clear()
         ts, (e, _) = timed_sweeps(lib, be.oneshot, n)
         st = _stats_ms(ts)
+        st["full_gc_before_series_ms"] = timed_sweeps.last_full_gc_ms
         out[label] = st
         out[label + "_ms"] = st["p50_ms"]
         energies.append(e)
         if label == "lockstep":
             out["lockstep_launch_stats"] = {k: int(v) for k, v in be.stats.items() if k in ("merged_runs", "launches", "grouped_launches", "operations", "max_group")}
+    out["outliers"] = ("round 3 reported one 92 ms sweep among five (median 16): a generation-2 collection of Python's cyclic garbage collector inside the timed "
+                       "sweep -- the bench process holds the host objects of the n = 220 ring by then, `full_gc_before_series_ms` is what one such collection costs here; "
+                       "the collector is now run before each series and held off during it, and p50 / p95 / max are reported")
     out["e_corr"] = energies[0]
     out["bit_identical"] = bool(energies[0] == energies[1] == energies[2])
     out["fragments"] = 6
