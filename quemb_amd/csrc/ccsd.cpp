@@ -760,6 +760,9 @@ int ccsd_kernel_lockstep(const std::vector<CcsdSolver*>& s, const std::vector<Cc
     }
     const double t1 = now();
     if (stats) stats->ms_tapes += t1 - t0;
+    // QEMB_BATCH_TRACE=2: iterations that take longer than 5 ms are reported with their parts (where did a slow sweep spend its time?)
+    static const bool trace_iters = std::getenv("QEMB_BATCH_TRACE") && std::atoi(std::getenv("QEMB_BATCH_TRACE")) >= 2;
+    struct IterTrace { bool on; int it; double t0, t1; double (*now)(); ~IterTrace() { const double t = now(); if (on && t - t0 > 5.0) std::fprintf(stderr, "[qemb lockstep] iteration %d took %.2f ms: tape issue %.2f, post steps %.2f\n", it, t - t0, t1 - t0, t - t1); } } iter_trace{trace_iters, it, t0, t1, +now};
     struct PostTime { LockstepStats* st; double t1; double (*now)(); ~PostTime() { if (st) st->ms_post += now() - t1; } } post_time{stats, t1, +now};
     if (batched_post) {
       struct Flush { bool open = false; ~Flush() { if (open) (void)dev_batch_flush(); } } guard;      // (an error exit must not leave the collector open)

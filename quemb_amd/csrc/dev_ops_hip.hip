@@ -8,6 +8,7 @@
 // They are written for coalescing (16-byte lanes where the layout allows, LDS-tiled transposes when the
 // contiguous dimension changes) rather than reshaped into GEMMs.
 #include <hip/hip_runtime.h>
+#include <chrono>
 #include <atomic>
 #include <algorithm>
 #include <cstdint>
@@ -218,6 +219,14 @@ static size_t pool_cap_bytes() {
   }();
   return cap;
 }
+static std::atomic<long long> g_alloc_misses{0}, g_alloc_miss_ns{0}, g_alloc_miss_bytes{0};
+int dev_alloc_stats(long long* n, double* ms, double* gb, int reset) {
+  if (n) *n = g_alloc_misses.load();
+  if (ms) *ms = (double)g_alloc_miss_ns.load() * 1e-6;
+  if (gb) *gb = (double)g_alloc_miss_bytes.load() * 1e-9;
+  if (reset) { g_alloc_misses = 0; g_alloc_miss_ns = 0; g_alloc_miss_bytes = 0; }
+  return QEMB_OK;
+}
 int dev_alloc(void** p, size_t bytes) {
   REQUIRE_INIT();
   if (bytes == 0) bytes = 16;
@@ -232,6 +241,11 @@ int dev_alloc(void** p, size_t bytes) {
     }
   }
   if (g_capturing) { set_error("device allocation inside a captured region"); return QEMB_ERR_ALLOC; }   // pooled blocks are fine, a real hipMalloc is not
+  struct MissTimer {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(); size_t b;
+    ~MissTimer() { g_alloc_misses += 1; g_alloc_miss_bytes += (long long)b; g_alloc_miss_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); }
+  } miss_timer;
+  miss_timer.b = bytes;
   hipError_t e = hipMalloc(p, bytes);
   if (e != hipSuccess) {
     (void)hipGetLastError();

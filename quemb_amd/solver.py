@@ -173,7 +173,6 @@ def map_fragments(fn, frags, nstreams=1):
     frags = list(frags)
     if nstreams <= 1 or len(frags) <= 1:
         return [fn(f) for f in frags]
-    import queue
     from concurrent.futures import ThreadPoolExecutor
     lib = frags[0].dev.lib
     have = lib.qemb_ctx_count(int(nstreams) + 1)          # context 0 stays with the calling thread
@@ -183,24 +182,43 @@ def map_fragments(fn, frags, nstreams=1):
     nwork = min(int(nstreams), have - 1, len(frags))
     if nwork <= 1:
         return [fn(f) for f in frags]
-    ids = queue.Queue()
-    for k in range(1, nwork + 1):
-        ids.put(k)
+    # STATIC assignment of fragments to worker contexts (longest first, each to the least loaded worker; ties in fragment order): the same
+    # fragment meets the same context in every sweep.  The caching allocator of a context hands blocks back by exact size, so a context
+    # that gets a fragment of another size than last time misses its pool and goes to the driver (hipMalloc of a solve's ~10^3 buffers:
+    # tens of ms) -- with a dynamic queue that happened now and then in any sweep (the 92 ms sweep of the round-3 octane figures,
+    # tools/octane_sweep_series.py), with the static assignment only in the first one.
+    def cost(f):
+        n, o = int(getattr(f, "nao", 0) or 0), getattr(f, "nsocc", None)
+        o = n // 2 if o is None else int(o)
+        v = max(n - o, 0)
+        return float(o * o) * float(v) ** 4 + 4.0 * float(o * v) ** 3
+    order = sorted(range(len(frags)), key=lambda k: (-cost(frags[k]), k))
+    load, mine = [0.0] * nwork, [[] for _ in range(nwork)]
+    for k in order:
+        w = min(range(nwork), key=lambda j: (load[j], j))
+        mine[w].append(k); load[w] += max(cost(frags[k]), 1.0)
 
-    def bind():
-        from ._lib import check
-        check(lib.qemb_ctx_bind(ids.get()), "qemb_ctx_bind", lib)
-    from ._lib import QEMB_ERR_ALLOC, QembError
-    with ThreadPoolExecutor(max_workers=nwork, initializer=bind) as pool:
-        futs = [pool.submit(fn, f) for f in frags]
-        res, retry = [None] * len(frags), []
-        for k, fu in enumerate(futs):
+    from ._lib import QEMB_ERR_ALLOC, QembError, check
+    res, retry = [None] * len(frags), []
+
+    def work(w):
+        check(lib.qemb_ctx_bind(w + 1), "qemb_ctx_bind", lib)
+        out = []
+        for k in mine[w]:
             try:
-                res[k] = fu.result()
+                out.append((k, fn(frags[k]), None))
             except QembError as e:
                 if getattr(e, "status", None) != QEMB_ERR_ALLOC:
                     raise
-                retry.append(k)
+                out.append((k, None, e))
+        return out
+    with ThreadPoolExecutor(max_workers=nwork) as pool:
+        for part in pool.map(work, range(nwork)):
+            for k, r, err in part:
+                if err is not None:
+                    retry.append(k)
+                else:
+                    res[k] = r
     if retry:
         # the working sets of `nwork` fragments did not fit together: what fits one fragment at a time must keep working (the serial sweep
         # is what nstreams = 1 runs); parked blocks of every context are released first

@@ -1,0 +1,23 @@
+"""Repro of the slow lock-step sweep (round 4): two BE objects in lock-step mode one after the other, a few sweeps each, every sweep timed;
+QEMB_BATCH_TRACE=1 prints the phases.  Under rocprofv3 --kernel-trace (QEMB_GRAPH=1) tools/trace_gaps.py then shows what the device did."""
+import sys, time
+sys.path.insert(0, ".")
+from pathlib import Path
+from quemb_amd import _lib
+from quemb_amd.fragpart import FragPart
+from quemb_amd.integrals import RHF, Mole
+from quemb_amd.mbe import BE
+lib = _lib.init(0)
+G = Path("tests/golden")
+mf = RHF(Mole(G / "octane.xyz")); mf.kernel()
+modes = sys.argv[1:] or ["lockstep", "lockstep", "streams", "lockstep"]
+for m in modes:
+    kw = dict(lockstep=True) if m == "lockstep" else dict(nstreams=6, lockstep=False)
+    be = BE(mf, FragPart.from_json(G / "fragmentation.json", "test_autogen_octane_be2"), distribute=False, lib=lib, **kw)
+    ts = []
+    for k in range(5):
+        lib.qemb_device_sync(); t0 = time.perf_counter()
+        be.oneshot()
+        lib.qemb_device_sync(); ts.append((time.perf_counter() - t0) * 1e3)
+        print("MARK %s sweep %d done at %.3f" % (m, k, time.time()), file=sys.stderr, flush=True)
+    print("RESULT", m, " ".join("%.1f" % t for t in ts), file=sys.stderr, flush=True)
