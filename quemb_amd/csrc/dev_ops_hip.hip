@@ -25,6 +25,23 @@
 #include "grouped_launch.h"
 
 namespace qemb {
+// XCD-aware logical block index of the tiled HBM passes (round 4; profiles/r04_hbm_pmc.json).  Workgroups are dealt round-robin over the eight
+// XCDs, each with its own L2, so neighbouring 32 x 32 tiles -- whose 256-byte row pieces start at arbitrary offsets and share their first and
+// last 128-byte lines -- ran on different XCDs and every shared line was fetched from HBM twice: FETCH_SIZE showed 1.2-1.5 x the algorithmic
+// reads for the unpack, scatter and finishing passes.  Here the linear block number is mapped so that each XCD works through ONE contiguous
+// range of the logical order (x fastest): neighbours in x run on the same XCD at about the same time and meet in its L2.  A bijection of the
+// grid: placement is a matter of speed only (inside a grouped launch the member's blocks are offset and it is merely another permutation).
+__device__ __forceinline__ uint3 xcd_logical_block(const uint3 BID, const uint3 GDIM) {
+  const unsigned long long total = (unsigned long long)GDIM.x * GDIM.y * GDIM.z;
+  const unsigned long long lin = ((unsigned long long)BID.z * GDIM.y + BID.y) * GDIM.x + BID.x;
+  const unsigned long long q = total >> 3, r = total & 7ull;
+  const unsigned long long xcd = lin & 7ull, k = lin >> 3;
+  const unsigned long long base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  const unsigned long long L = base + k;
+  const unsigned long long xy = (unsigned long long)GDIM.x * GDIM.y;
+  return make_uint3((unsigned)(L % GDIM.x), (unsigned)((L % xy) / GDIM.x), (unsigned)(L / xy));
+}
+
 
 // ------------------------------------------------------------------------------------------------
 // error channel + device state
@@ -816,10 +833,11 @@ __global__ void __launch_bounds__(256) copy4_linear_kernel(Copy4K c) { copy4_lin
 __device__ __forceinline__ void copy4_transpose_kernel_body(const uint3 BID, const uint3 GDIM, Copy4K c, int tiles3) {
   __shared__ double tile[32][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
-  const long long t2 = BID.x / tiles3, t3 = BID.x % tiles3;
+  const uint3 LB = xcd_logical_block(BID, GDIM);      // neighbouring tiles of a slab on one XCD (their row pieces share 128-byte lines)
+  const long long t2 = LB.x / tiles3, t3 = LB.x % tiles3;
   const long long base2 = t2 * 32, base3 = t3 * 32;
-  for (long long i0 = BID.z; i0 < c.d0; i0 += GDIM.z) {
-    for (long long i1 = BID.y; i1 < c.d1; i1 += GDIM.y) {
+  for (long long i0 = LB.z; i0 < c.d0; i0 += GDIM.z) {
+    for (long long i1 = LB.y; i1 < c.d1; i1 += GDIM.y) {
       const long long bi = i0 * c.si0 + i1 * c.si1, bo = i0 * c.so0 + i1 * c.so1;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -973,8 +991,9 @@ __device__ __forceinline__ void ccsd_ph_layouts_kernel_body(const uint3 BID, con
                                                               double* __restrict__ Ut, double* __restrict__ Tpt, double* __restrict__ Th, int tiles) {
   __shared__ double xt[32][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
-  const long long tc = BID.x / tiles, tb = BID.x % tiles;
-  const long long k = BID.z, j = BID.y;
+  const uint3 LB = xcd_logical_block(BID, GDIM);
+  const long long tc = LB.x / tiles, tb = LB.x % tiles;
+  const long long k = LB.z, j = LB.y;
   const double* __restrict__ X = t2 + (k * o + j) * v * v;
   // The b-ranges of the tiles are shifted so that the 32-double runs written to the five [k,c,j,b] outputs start on 128-byte lines: their
   // rows start at ((k v + c) o + j) v doubles, which (when o v is a multiple of 16) is the same offset a = ((k v o + j) v) mod 16 into a line
@@ -1071,10 +1090,11 @@ __device__ __forceinline__ void small_k_update_mfma_kernel_body(const uint3 BID,
   // cache resident) and has the C values it will update in flight while the MFMAs run
   const int NT = (N + 15) >> 4, MT = (M + 31) >> 5;
   const int lane = threadIdx.x & 63, fr = lane & 15, fk = lane >> 4;
-  const int item = BID.x * 4 + (threadIdx.x >> 6);
+  const uint3 LB = xcd_logical_block(BID, GDIM);      // neighbouring column tiles of a strip (they share the lines their 128-byte row pieces straddle) on one XCD
+  const int item = LB.x * 4 + (threadIdx.x >> 6);
   if (item >= MT * NT) return;
   const int m0 = (item / NT) * 32, col = (item % NT) * 16 + fr;
-  const long long z = BID.y;
+  const long long z = LB.y;
   const double* __restrict__ Az = A + z * sA;
   const double* __restrict__ Bz = B + z * sB;
   double* __restrict__ Cz = C + z * sC;
@@ -1396,10 +1416,11 @@ __global__ void __launch_bounds__(256) pack_pm_tiled_kernel(long long rows, long
                                                             long long ldp, double* __restrict__ Om, long long ldm) {
   __shared__ double tB[32][33];       // only the mirror tile goes through LDS; the straight tile stays in the registers of the threads that write it
   const long long np = v * (v + 1) / 2, nm = v * (v - 1) / 2;
-  long long tc, td; unpair_ge((long long)blockIdx.x, tc, td);
+  const uint3 LB = xcd_logical_block(make_uint3(blockIdx.x, blockIdx.y, blockIdx.z), make_uint3(gridDim.x, gridDim.y, gridDim.z));
+  long long tc, td; unpair_ge((long long)LB.x, tc, td);
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const bool diag = (tc == td);
-  for (long long r = blockIdx.y; r < rows; r += gridDim.y) {
+  for (long long r = LB.y; r < rows; r += gridDim.y) {
     const double* t; double* tp = Op + r * ldp; double* tm;
     if (MODE == 1) {
       long long i, j; unpair_ge(r, i, j);
@@ -1437,7 +1458,7 @@ __global__ void __launch_bounds__(256) pack_pm_tiled_kernel(long long rows, long
         }
       }
     }
-    if (blockIdx.x == 0) {      // padding columns of the row (leading dimensions are rounded up to even)
+    if (LB.x == 0) {      // padding columns of the row (leading dimensions are rounded up to even)
       for (long long q = np + threadIdx.x; q < ldp; q += 256) tp[q] = 0.0;
       if (tm) for (long long q = nm + threadIdx.x; q < ldm; q += 256) tm[q] = 0.0;
     }
@@ -1583,9 +1604,10 @@ __device__ __forceinline__ void ccsd_finish_t2_rings_kernel_body(const uint3 BID
                                                                    const double* __restrict__ OV, const double* __restrict__ RS, const double* __restrict__ M,
                                                                    const double* __restrict__ eo, const double* __restrict__ ev, double* __restrict__ t1n) {
   __shared__ double tile[32][33];
-  long long i, j; unpair_ge((long long)BID.y, i, j);
+  const uint3 LB = xcd_logical_block(BID, GDIM);
+  long long i, j; unpair_ge((long long)LB.y, i, j);
   const long long nt = (v + 31) / 32;
-  const long long ta = BID.x / nt, tb = BID.x - ta * nt;
+  const long long ta = LB.x / nt, tb = LB.x - ta * nt;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const long long vv = v * v, ov = o * v;
   const double* Uij = U + (i * o + j) * vv;
@@ -1629,7 +1651,7 @@ __device__ __forceinline__ void ccsd_finish_t2_rings_kernel_body(const uint3 BID
       if (a < v && b < v) t2n[(j * o + i) * vv + b * v + a] = tile[tx][bb];
     }
   }
-  if (t1n && BID.x == 0 && BID.y == 0)
+  if (t1n && LB.x == 0 && LB.y == 0)
     for (long long t = threadIdx.x; t < ov; t += blockDim.x) t1n[t] /= eo[t / v] - ev[t % v];
 }
 __global__ void __launch_bounds__(256) ccsd_finish_t2_rings_kernel(long long o, long long v, double* __restrict__ t2n, const double* __restrict__ U, const double* __restrict__ OV,
@@ -1653,9 +1675,10 @@ __device__ __forceinline__ void ladder_scatter_pm_kernel_body(const uint3 BID, c
                                                                const double* __restrict__ Hp, const double* __restrict__ Hm, int assign,
                                                                int Sp, long long strideP, int Sm, long long strideM, long long ldhp, long long ldhm) {
   __shared__ double sp[32][33], sm[32][33];
-  const long long ij = BID.y;
+  const uint3 LB = xcd_logical_block(BID, GDIM);
+  const long long ij = LB.y;
   long long i, j; unpair_ge(ij, i, j);
-  long long t = BID.x, ta, tb; unpair_ge(t, ta, tb);            // tile row >= tile column
+  long long t = LB.x, ta, tb; unpair_ge(t, ta, tb);            // tile row >= tile column
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const double* rp = Rp + ij * ldp;
   const double* rm = (i > j) ? Rm + (i * (i - 1) / 2 + j) * ldm : nullptr;
@@ -2825,9 +2848,10 @@ __device__ __forceinline__ void unpack_tril_tiled_kernel_body(const uint3 BID, c
   __shared__ double tile[32][33];
   const long long np = n * (n + 1) / 2, n2 = n * ld;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  // BID.x = lower-triangle tile (tk >= tl), BID.y (looped) = packed row: every block moves one 32 x 32 tile
-  long long tt = BID.x, tk, tl; unpair_ge(tt, tk, tl);
-  for (long long r = BID.y; r < rows; r += GDIM.y) {
+  // LB.x = lower-triangle tile (tk >= tl), LB.y (looped) = packed row: every block moves one 32 x 32 tile
+  const uint3 LB = xcd_logical_block(BID, GDIM);
+  long long tt = LB.x, tk, tl; unpair_ge(tt, tk, tl);
+  for (long long r = LB.y; r < rows; r += GDIM.y) {
     const double* src = packed + r * np;
     double* dst0 = full + r * n2;
     double* dst1 = nullptr;
