@@ -1357,13 +1357,28 @@ __global__ void __launch_bounds__(256) ladder_pack_vvvv_pf_kernel(long long n, l
     long long a, b; unpair_ge(ab, a, b);
     double* vp = Vp + ab * ldp;
     double* vm = (a > b) ? Vm + (a * (a - 1) / 2 + b) * ldm : nullptr;
-    for (long long cd = threadIdx.x; cd < ldp; cd += blockDim.x) {
-      if (cd >= np) { vp[cd] = 0.0; continue; }
-      long long c, d; unpair_ge(cd, c, d);
-      const double x = Mp[pair_idx(o + a, o + c) * n2 + (o + b) * n + (o + d)];
-      const double y = Mp[pair_idx(o + b, o + c) * n2 + (o + a) * n + (o + d)];
-      vp[cd] = x + y;
-      if (vm && c > d) vm[c * (c - 1) / 2 + d] = x - y;
+    // four column pairs per thread and trip, all eight gathers requested before the first use: the two source runs of a (c,d) are short
+    // (c + 1 doubles) pieces of different slabs, so the pass is bound by how many of them a CU keeps in flight (round 4: 3.1 -> see DESIGN)
+    for (long long cd0 = threadIdx.x; cd0 < ldp; cd0 += 4 * (long long)blockDim.x) {
+      double x[4], y[4]; long long cc[4], dd[4]; bool in[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long long cd = cd0 + u * (long long)blockDim.x;
+        in[u] = cd < np;
+        long long c = 0, d = 0;
+        if (in[u]) unpair_ge(cd, c, d);
+        cc[u] = c; dd[u] = d;
+        x[u] = in[u] ? Mp[pair_idx(o + a, o + c) * n2 + (o + b) * n + (o + d)] : 0.0;
+        y[u] = in[u] ? Mp[pair_idx(o + b, o + c) * n2 + (o + a) * n + (o + d)] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long long cd = cd0 + u * (long long)blockDim.x;
+        if (cd >= ldp) continue;
+        if (!in[u]) { vp[cd] = 0.0; continue; }
+        vp[cd] = x[u] + y[u];
+        if (vm && cc[u] > dd[u]) vm[cc[u] * (cc[u] - 1) / 2 + dd[u]] = x[u] - y[u];
+      }
     }
     if (vm) for (long long q = nm + threadIdx.x; q < ldm; q += blockDim.x) vm[q] = 0.0;
   }
