@@ -62,6 +62,7 @@ struct GemmKArgs {
   double alpha, beta;
   long long* cyc2;         // TAG == 2: prologue stamps
   long long* cyc;          // debugging (QEMB_GEMM_TRACE): per-workgroup shader-clock ticks, or nullptr
+  int sb_m, sb_n;          // > 0: the tiles of an XCD's chunk are walked in super-blocks of sb_m x sb_n tiles (launch_cfg); 0: m-tiles fastest
   int* stagger;            // TAG == 6: per-CU arrival counters of the staggered start (never reset: two first-round arrivals per CU keep the parity)
   int stagger_cycles;      // TAG == 6: length of the delay in shader cycles
 };
@@ -285,7 +286,15 @@ __device__ __forceinline__ void dgemm_mfma_body(const uint3 BID, const uint3 GDI
 
   const int ntiles = g.tiles_m * g.tiles_n;
   const int L = xcd_remap(BID.x, ntiles);
-  const int tm = L % g.tiles_m, tn = L / g.tiles_m;
+  int tm = L % g.tiles_m, tn = L / g.tiles_m;
+  if (g.sb_m > 0) {
+    // 2-D walk inside an XCD's chunk (round 4): the 32 workgroups an XCD runs at a time form an sb_m x sb_n block of output tiles, so that
+    // they share sb_m A panels and sb_n B panels through the XCD's L2 instead of 32 A panels and one B panel -- the (ov)^3 ring products
+    // (32 x 16 tiles of 128 x 256) drew 2.4 GB per call through the fabric for 0.38 GB of operands (profiles/r04_hbm_pmc*.json, all_kernels)
+    const int per = g.sb_m * g.sb_n, sb = L / per, w = L - sb * per, nsbm = g.tiles_m / g.sb_m;
+    tm = (sb % nsbm) * g.sb_m + w % g.sb_m;
+    tn = (sb / nsbm) * g.sb_n + w / g.sb_m;
+  }
   const int m0 = tm * BM, n0 = tn * BN;
 
   const long long bz = BID.y / g.ksplit;
@@ -608,6 +617,22 @@ static int launch_cfg(const GemmDesc& d, hipStream_t s) {
   g.alpha = d.alpha; g.beta = d.beta;
   g.cyc = nullptr; g.cyc2 = nullptr;
   g.stagger = nullptr; g.stagger_cycles = 0;
+  g.sb_m = g.sb_n = 0;
+  {
+    // super-blocks of 32 tiles (the workgroups one XCD runs at a time at one workgroup per CU): the shape that moves the fewest operand bytes
+    // per k-step, sb_m x |A tile| + sb_n x |B tile|, among the shapes that divide the tile grid (QEMB_GEMM_SB=0: the m-fastest walk, for A/B runs)
+    static const bool sb_on = !(std::getenv("QEMB_GEMM_SB") && std::atoi(std::getenv("QEMB_GEMM_SB")) == 0);
+    if (sb_on && d.batch == 1 && d.ksplit <= 1 && g.tiles_m >= 8 && g.tiles_n >= 4 && ((long long)g.tiles_m * g.tiles_n) % 256 == 0) {
+      long long best = -1;
+      for (int sm = 1; sm <= 32; sm *= 2) {
+        const int sn = 32 / sm;
+        if (g.tiles_m % sm || g.tiles_n % sn) continue;
+        const long long cost = (long long)sm * BM + (long long)sn * BN;
+        if (best < 0 || cost < best) { best = cost; g.sb_m = sm; g.sb_n = sn; }
+      }
+      if (g.sb_m == 32) g.sb_m = g.sb_n = 0;      // that is the m-fastest walk already
+    }
+  }
   if constexpr (TAG == 6) {
     static int* counters = nullptr;      // 8 XCDs x 256 hardware CU keys; zeroed once (see the kernel: parity survives complete first rounds)
     static std::atomic<bool> ready{false};
