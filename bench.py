@@ -23,6 +23,19 @@ all-reduce (RCCL) of [edge values, centre values, sum centre diag, e1, e2, ec, n
 between steps (amplitudes restart from MP2 exactly like the reference).
 value = CCSD iterations completed by all ranks in the K timed steps / wall time (max over ranks).
 """
+import os as _os
+# BLAS / OpenMP pools inside the CPU share of this process, before NumPy starts them (quemb_amd/hostthreads.py: on a box that shows 256 cores
+# to a 16-CPU container an unbounded OpenBLAS pool gets the whole process throttled for most of a 100 ms period now and then)
+if not _os.environ.get("QEMB_KEEP_BLAS_THREADS"):
+    try:
+        _q, _p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        _n = len(_os.sched_getaffinity(0))
+        if _q != "max":
+            _n = min(_n, max(1, int(float(_q) / float(_p) + 0.5)))
+    except Exception:  # noqa: BLE001
+        _n = _os.cpu_count() or 1
+    for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+        _os.environ.setdefault(_v, str(max(1, _n // 2)))
 import argparse
 import ctypes as C
 import json
@@ -552,13 +565,13 @@ def octane_sweeps(lib, reps=24, cpu=True):
         energies.append(e)
         if label == "lockstep":
             out["lockstep_launch_stats"] = {k: int(v) for k, v in be.stats.items() if k in ("merged_runs", "launches", "grouped_launches", "operations", "max_group")}
-    out["outliers"] = ("round 3 reported one 92 ms sweep among five (median 16).  Reproduced and narrowed down in round 4 (tools/octane_outlier_repro.py, "
-                       "profiles/r04_octane_outlier.log): every BE object after the first one of a process has ONE sweep, its first or second, in which the device starts "
-                       "the submitted launches of one CCSD iteration 70-80 ms late (host issue 0.1 ms, then the wait); it needs the stream-capture path of the small-fragment "
-                       "iteration (QEMB_GRAPH=0: absent, sweeps 22-24 ms), is there with and without grouped launches, fused DIIS launches and graph destruction, is absent "
-                       "under rocprofv3 --hip-trace, and is neither Python's garbage collector (no collection inside a timed sweep; `full_gc_before_series_ms` is what one "
-                       "would cost) nor the caching allocator (0 driver allocations after the first sweep, qemb_alloc_stats).  The series below start after three sweeps; "
-                       "fragments are now assigned to stream contexts statically, which keeps the allocator's exact-size pools hit from the second sweep on")
+    out["outliers"] = ("round 3 reported one 92 ms sweep among five (median 16).  Found in round 4 (tools/octane_idle_probe.py, profiles/r04_octane_idle_probe.log): "
+                       "CPU-bandwidth throttling of the container.  The box shows 256 cores to a cgroup limited to 16 CPUs (cpu.max 1600000 / 100000); OpenBLAS starts a worker "
+                       "per visible core and the workers spin after every NumPy call, so host work between sweeps (building a BE object, 0.3 s of NumPy) burns the quota of a "
+                       "100 ms period in a few ms and the kernel freezes the whole process -- the threads that feed the GPU included -- until the period ends: the next sweep "
+                       "or the one after takes 85-100 ms (nr_throttled in /sys/fs/cgroup/cpu.stat).  Not the GC (no collection inside a timed sweep), not the allocator "
+                       "(0 driver allocations or frees in the slow sweeps, qemb_alloc_stats), not stream capture.  quemb_amd now caps the BLAS pool at half the usable cores "
+                       "at import (quemb_amd/hostthreads.py; QEMB_KEEP_BLAS_THREADS=1 brings the stalls back) and bench.py sets the same before NumPy loads")
     out["e_corr"] = energies[0]
     out["bit_identical"] = bool(energies[0] == energies[1] == energies[2])
     out["fragments"] = 6

@@ -8,4 +8,8 @@ There is no CPU fallback: importing is cheap, but the first call that needs the 
 library or a GPU is missing.
 """
 
+from .hostthreads import limit_blas_threads as _limit_blas_threads
+
+_limit_blas_threads()      # NumPy's BLAS pool inside the CPU share of the process (hostthreads.py: the cgroup-throttling stalls)
+
 __all__ = ["_lib"]
