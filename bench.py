@@ -34,8 +34,12 @@ if not _os.environ.get("QEMB_KEEP_BLAS_THREADS"):
             _n = min(_n, max(1, int(float(_q) / float(_p) + 0.5)))
     except Exception:  # noqa: BLE001
         _n = _os.cpu_count() or 1
+    try:
+        _lw = max(1, int(_os.environ.get("LOCAL_WORLD_SIZE", "1") or 1))      # the ranks of one node share its CPU quota
+    except ValueError:
+        _lw = 1
     for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
-        _os.environ.setdefault(_v, str(max(1, _n // 2)))
+        _os.environ.setdefault(_v, str(max(1, _n // (2 * _lw))))
 import argparse
 import ctypes as C
 import json

@@ -42,7 +42,12 @@ def limit_blas_threads(max_threads: int | None = None) -> int | None:
     global _limiter
     if os.environ.get("QEMB_KEEP_BLAS_THREADS", "0") not in ("", "0"):
         return None
-    cap = int(max_threads) if max_threads else max(1, usable_cores() // 2)
+    # several ranks on one node (one process per GPU) share the node's CPU quota: LOCAL_WORLD_SIZE (torchrun, bench.py's launcher) divides it
+    try:
+        local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1))
+    except ValueError:
+        local_world = 1
+    cap = int(max_threads) if max_threads else max(1, usable_cores() // (2 * local_world))
     for var in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):      # pools that have not started yet read these
         try:
             if int(os.environ.get(var, "0") or 0) > cap or var not in os.environ:

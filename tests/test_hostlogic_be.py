@@ -1,6 +1,7 @@
 """CPU: the host mirror (Frags / BE / be_func / ERI-transform + Schmidt drivers / QN) against the oracle and the
 reference's golden values, with the device layer replaced by the scalar mock (tests/hostcheck)."""
 import ctypes as C
+import os
 import re
 import sys
 from pathlib import Path
@@ -632,3 +633,21 @@ def test_sweep_mode_choice():
     assert sweep_mode([F(nao=400)] * 8, mem_free=250e9) == (1, False)       # what fitted with nstreams = 1 keeps fitting
     assert sweep_mode([F(nao=400)] * 8, mem_free=10e9) == (1, False)
     assert sweep_mode([F(nao=400)] * 8, nstreams=2, mem_free=10e9) == (2, False)     # an explicit request is honoured
+
+
+def test_blas_pool_is_capped_inside_the_cpu_share():
+    """quemb_amd/hostthreads.py (round 4: the cgroup-throttling stalls): importing the package caps NumPy's BLAS pool at half the usable cores,
+    divided by the ranks of the node; QEMB_KEEP_BLAS_THREADS=1 leaves it alone."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = str(Path(__file__).resolve().parent.parent)
+    code = ("import sys; sys.path.insert(0, %r); import quemb_amd; from quemb_amd import hostthreads as h; import numpy, threadpoolctl; "
+            "print(h.usable_cores(), max(p['num_threads'] for p in threadpoolctl.threadpool_info()))" % root)
+    env = {k: v for k, v in os.environ.items() if k not in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", "QEMB_KEEP_BLAS_THREADS", "LOCAL_WORLD_SIZE")}
+    cores, threads = (int(x) for x in subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout.split())
+    assert threads <= max(1, cores // 2)
+    cores2, threads2 = (int(x) for x in subprocess.run([sys.executable, "-c", code], env=dict(env, LOCAL_WORLD_SIZE="4"), capture_output=True, text=True, check=True).stdout.split())
+    assert threads2 <= max(1, cores2 // 8)
+    _, threads3 = (int(x) for x in subprocess.run([sys.executable, "-c", code], env=dict(env, QEMB_KEEP_BLAS_THREADS="1"), capture_output=True, text=True, check=True).stdout.split())
+    assert threads3 >= threads
