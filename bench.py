@@ -59,7 +59,7 @@ PEAK_FP64_MFMA_TFLOPS = 78.6     # MI355X FP64 matrix peak (AMD spec; == the FP6
                                  # lists no f64 row; see DESIGN.md "Roofline".
 SEED0 = 20260803
 N_EDGE = 6                       # matched AOs per fragment of the synthetic ring (edge [0..5] <-> centre [6..11] of the next one)
-PMC_FILE = "profiles/r03_pmc_ladder.json"
+PMC_FILE = "profiles/r04_pmc_ladder.json"
 
 T_START = time.perf_counter()
 
@@ -777,7 +777,7 @@ def main():
         flop_dense = 2.0 * o * o * float(v) ** 4                 # SURVEY 8(d) dense-equivalent figure
         achieved = flop_ladder / lad_avg / 1e12 if lad_avg > 0 else 0.0
         traffic, traffic_source = None, None                     # HBM bytes per launch from the separate --pmc passes
-        for cand in (PMC_FILE, "profiles/r02_pmc_ladder.json"):
+        for cand in (PMC_FILE, "profiles/r03_pmc_ladder.json", "profiles/r02_pmc_ladder.json"):
             pmc = ROOT / cand
             if pmc.exists():
                 try:
