@@ -473,7 +473,7 @@ def test_c5_dimensions_kpoint_view_equals_supercell_view(qlib):
     the translational symmetry of the 169 matched potentials.  kbe/pbe.py:78-316, :502-716."""
     from test_kbe_pbe import check_c5_driver
     m, kbe, mol = check_c5_driver(qlib, matching=True)
-    assert kbe.nstreams is not None                     # the sweep mode was chosen from the fragments' sizes (four fragments of 36 orbitals: streams)
+    assert kbe.nstreams is not None and kbe.lockstep is True      # the sweep mode was chosen from the fragments' sizes (four fragments of 36 orbitals: lock step)
 
 
 def test_whole_system_fragment_is_the_molecular_ccsd(qlib):

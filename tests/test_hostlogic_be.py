@@ -619,6 +619,8 @@ def test_sweep_mode_choice():
     from quemb_amd.solver import sweep_mode
     assert sweep_mode([F(nao=42)] * 6) == (6, True)            # octane BE2: lock step
     assert sweep_mode([F(nao=55)] * 4) == (4, False)           # octane BE3: four streams
+    assert sweep_mode([F(nao=36)] * 4) == (4, True)            # the periodic configs[4] cell: four small fragments, lock step (6.8 vs 9.5 ms)
+    assert sweep_mode([F(nao=36)] * 3) == (3, False)
     assert sweep_mode([F(nao=220)] * 8) == (4, False)          # large fragments: four in flight
     assert sweep_mode([F(nao=400)] * 8) == (2, False)
     assert sweep_mode([F(nao=42)]) == (1, False)
