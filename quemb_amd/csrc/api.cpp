@@ -115,7 +115,7 @@ int qemb_comm_destroy(void) { return dev_comm_destroy(); }
 int qemb_ctx_count(int n) { return dev_ctx_count(n); }
 int qemb_ctx_bind(int k) { return dev_ctx_bind(k); }
 int qemb_ctx_partition(int parts) { return dev_ctx_partition(parts); }
-int qemb_alloc_stats(long long* n, double* ms, double* gb, int reset) { return dev_alloc_stats(n, ms, gb, reset); }
+int qemb_alloc_stats(long long* n, long long* nfree, double* ms, double* gb, int reset) { return dev_alloc_stats(n, nfree, ms, gb, reset); }
 int qemb_ctx_timer_read(int ctx, int slot, double* total_ms, int64_t* count, int reset) { return dev_ctx_timer_read(ctx, slot, total_ms, count, reset); }
 int qemb_op_k_from_pairs(int64_t n, const double* H, const double* D, double* K) { return dev_k_from_pairs(n, H, D, K); }
 int qemb_op_jk_from_packed(int64_t n, const double* S4, const double* D, const double* Dp, double* Jp, double* K) { return dev_jk_from_packed(n, S4, D, Dp, Jp, K); }

@@ -46,7 +46,7 @@ int dev_d2d(void* dst, const void* src, size_t bytes);
 int dev_fill(double* x, int64_t n, double value);
 int dev_mem_info(size_t* free_b, size_t* total_b);
 // measurement hook: real driver allocations (pool misses) since the last reset -- their number, bytes and the host time spent in them
-int dev_alloc_stats(long long* n_driver_allocs, double* ms_in_driver_allocs, double* gb_allocated, int reset);
+int dev_alloc_stats(long long* n_driver_allocs, long long* n_driver_frees, double* ms_in_driver_calls, double* gb_allocated, int reset);
 const char* dev_backend_name();      // "hip-gfx950" for the product, "hostcheck" for the mock
 
 // ---- stream capture (hipGraph) of launch-bound loops ------------------------------------------------------------------

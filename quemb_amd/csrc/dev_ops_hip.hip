@@ -243,8 +243,9 @@ static size_t pool_cap_bytes() {
   }();
   return cap;
 }
-int dev_alloc_stats(long long* n, double* ms, double* gb, int reset) {
-  if (n) *n = g_alloc_misses.load() + 1000000ll * g_driver_frees.load();      // (frees in the millions digit: a measurement hook, not an API to build on)
+int dev_alloc_stats(long long* n, long long* nfree, double* ms, double* gb, int reset) {
+  if (n) *n = g_alloc_misses.load();
+  if (nfree) *nfree = g_driver_frees.load();
   if (ms) *ms = (double)(g_alloc_miss_ns.load() + g_driver_free_ns.load()) * 1e-6;
   if (gb) *gb = (double)g_alloc_miss_bytes.load() * 1e-9;
   if (reset) { g_alloc_misses = 0; g_alloc_miss_ns = 0; g_alloc_miss_bytes = 0; g_driver_frees = 0; g_driver_free_ns = 0; }

@@ -51,7 +51,7 @@ int dev_tape_destroy(dev_tape_t) { return QEMB_OK; }
 int dev_tape_last_stats(long long* a, long long* b, long long* c) { if (a) *a = 0; if (b) *b = 0; if (c) *c = 0; return QEMB_OK; }
 bool dev_capturing() { return false; }
 int dev_mem_info(size_t* f, size_t* t) { *f = *t = (size_t)1 << 34; return 0; }
-int dev_alloc_stats(long long* n, double* ms, double* gb, int) { if (n) *n = 0; if (ms) *ms = 0.0; if (gb) *gb = 0.0; return 0; }
+int dev_alloc_stats(long long* n, long long* nfree, double* ms, double* gb, int) { if (n) *n = 0; if (nfree) *nfree = 0; if (ms) *ms = 0.0; if (gb) *gb = 0.0; return 0; }
 
 static double g_tot[TIMER_NSLOTS]; static int64_t g_cnt[TIMER_NSLOTS];
 static std::chrono::steady_clock::time_point g_t0[TIMER_NSLOTS];

@@ -15,9 +15,9 @@ for m in modes:
     kw = dict(lockstep=True) if m == "lockstep" else dict(nstreams=6, lockstep=False)
     import ctypes as C
     def stats(tag):
-        nm, ms_, gb = C.c_longlong(), C.c_double(), C.c_double()
-        lib.qemb_alloc_stats(C.byref(nm), C.byref(ms_), C.byref(gb), 1)
-        print("ALLOC %-22s driver mallocs %4d  frees %4d  host ms %.1f  GB %.3f" % (tag, nm.value % 1000000, nm.value // 1000000, ms_.value, gb.value), file=sys.stderr, flush=True)
+        nm, nf, ms_, gb = C.c_longlong(), C.c_longlong(), C.c_double(), C.c_double()
+        lib.qemb_alloc_stats(C.byref(nm), C.byref(nf), C.byref(ms_), C.byref(gb), 1)
+        print("ALLOC %-22s driver mallocs %4d  frees %4d  host ms %.1f  GB %.3f" % (tag, nm.value, nf.value, ms_.value, gb.value), file=sys.stderr, flush=True)
     stats("before BE")
     be = BE(mf, FragPart.from_json(G / "fragmentation.json", "test_autogen_octane_be2"), distribute=False, lib=lib, **kw)
     stats("BE constructed")

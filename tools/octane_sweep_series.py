@@ -41,12 +41,12 @@ for kw in (dict(nstreams=6, lockstep=False), dict(lockstep=True), dict(nstreams=
     import ctypes as C
     for k in range(nsweep):
         n0 = len(pauses)
-        lib.qemb_alloc_stats(None, None, None, 1)
+        lib.qemb_alloc_stats(None, None, None, None, 1)
         lib.qemb_device_sync(); t0 = time.perf_counter()
         be.oneshot()
         lib.qemb_device_sync(); ts.append((time.perf_counter() - t0) * 1e3)
-        nm, ms_, gb = C.c_longlong(), C.c_double(), C.c_double()
-        lib.qemb_alloc_stats(C.byref(nm), C.byref(ms_), C.byref(gb), 0)
+        nm, nf, ms_, gb = C.c_longlong(), C.c_longlong(), C.c_double(), C.c_double()
+        lib.qemb_alloc_stats(C.byref(nm), C.byref(nf), C.byref(ms_), C.byref(gb), 0)
         misses.append("%d/%.1fms" % (nm.value, ms_.value))
         for g, ms in pauses[n0:]:
             hits.append((k, g, round(ms, 2)))
