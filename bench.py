@@ -680,8 +680,26 @@ def main():
     else:
         lib = _lib.init(lrank)
     if world > 1 and backend == "rccl":
-        comm.init_from_env(lib)
-        log(f"communicator up: {world} ranks ({lib.qemb_backend().decode()})")
+        try:
+            if os.environ.get("QEMB_BENCH_FAIL_COMM_INIT"):       # tests only: exercise the fallback below
+                raise RuntimeError("communicator start-up failure requested by QEMB_BENCH_FAIL_COMM_INIT")
+            comm.init_from_env(lib)
+            log(f"communicator up: {world} ranks ({lib.qemb_backend().decode()})")
+        except Exception as e:  # noqa: BLE001
+            # The library communicator did not come up (bounded: QEMB_COMM_TIMEOUT_S).  A start-up failure is global -- ncclCommInitRank is
+            # collective -- so every rank gets here; rather than lose the whole N-GPU measurement the ranks fall back to a torch.distributed
+            # gloo group for the one small all-reduce per sweep (host buffers, a few hundred bytes: latency of ~0.1 ms against a sweep of
+            # seconds), and the JSON line says so in config.transport.  (torch after libqemb_hip.so is fine for CPU tensors.)
+            print(f"bench.py rank {rank}: library communicator failed ({e}); falling back to torch.distributed gloo", file=sys.stderr, flush=True)
+            backend = "gloo-fallback"
+            try:
+                comm.destroy(lib)            # (a communicator that came up half way must not be picked up by be_parallel.all_reduce_sum)
+            except Exception:  # noqa: BLE001
+                comm._active = None
+            import datetime
+            import torch
+            import torch.distributed as dist
+            dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=float(os.environ.get("QEMB_COMM_TIMEOUT_S", "120")) + 60.0))
 
     def barrier():
         if world > 1:
@@ -798,7 +816,8 @@ def main():
                        "fragments_per_gpu": F, "n_occ": o, "n_virt": v, "fragments_in_flight_per_gpu": args.nstreams, "cu_partition": (args.cu_split if args.nstreams > 1 else 0),
                        "parallelism": f"fragments sharded over {world} GPU(s) by the LPT partition, 1 all-reduce per sweep",
                        "transport": None if world == 1 else {"rccl": "library communicator: ncclAllReduce on a persistent RCCL communicator (qemb_comm_allreduce)",
-                                                             "nccl": "torch.distributed nccl (RCCL)", "gloo": "torch.distributed gloo (rehearsal)"}[backend]
+                                                             "nccl": "torch.distributed nccl (RCCL)", "gloo": "torch.distributed gloo (rehearsal)",
+                                                             "gloo-fallback": "torch.distributed gloo -- FALLBACK: the library's RCCL communicator failed to start (stderr has the reason)"}[backend]
                                     + (" [hostcheck mock: shared-memory transport]" if args.lib else ""),
                        "fragments_per_rank": [owner.count(r) for r in range(world)],
                        "allreduce_bytes_per_sweep": stats.get("allreduce_bytes_per_sweep", 0 if world == 1 else None),
@@ -872,6 +891,9 @@ def main():
     barrier()
     if world > 1:
         comm.destroy(lib) if backend == "rccl" else dist.destroy_process_group()
+    if backend == "gloo-fallback":
+        sys.stdout.flush(); sys.stderr.flush()
+        os._exit(0)          # a rendezvous thread may still sit inside RCCL: leave without running its exit handlers
     return 0
 
 

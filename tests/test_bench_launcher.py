@@ -243,3 +243,19 @@ def test_kbe_c5_bench_field_on_the_mock():
     assert r["fragments"] == 4 and r["n_emb"] == [36] * 4 and r["aos_per_cell"] == 24 and r["kpts"] == 3 and r["electrons_per_cell"] == 28
     assert abs(r["hf_in_hf_error_Eh"]) < 1e-8 and r["e_corr_per_cell"] < -1e-3
     assert r["sweep"]["sweeps"] == 2 and r["sweep"]["p50_ms"] <= r["sweep"]["max_ms"] and r["sweep_ms"] > 0
+
+
+@pytest.mark.timeout(300)
+def test_comm_startup_failure_falls_back_to_gloo():
+    """If the library communicator does not come up (it never ran with more than one rank on real GPUs), the N-rank bench must still deliver
+    its line: the ranks fall back to a torch.distributed gloo group for the one small all-reduce per sweep and say so in config.transport."""
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", *SMALL, "--lib", _mock()], env=_env(QEMB_BENCH_FAIL_COMM_INIT="1"),
+                       capture_output=True, text=True, timeout=280)
+    assert p.returncode == 0, p.stderr[-2000:]
+    r = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    assert r["n_gpus"] == 2 and r["config"]["fragments_per_rank"] == [2, 2] and r["value"] > 0
+    assert "FALLBACK" in r["config"]["transport"] and "falling back to torch.distributed gloo" in p.stderr
+    # same sweep as the two-rank run over the library communicator
+    q = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", *SMALL, "--lib", _mock()], env=_env(), capture_output=True, text=True, timeout=280)
+    r0 = json.loads([ln for ln in q.stdout.splitlines() if ln.startswith("{")][0])
+    assert abs(r["mean_e_corr_per_sweep"] - r0["mean_e_corr_per_sweep"]) < 1e-12 and abs(r["residual_norm"] - r0["residual_norm"]) < 1e-12
