@@ -822,6 +822,9 @@ def main():
                        "fragments_per_rank": [owner.count(r) for r in range(world)],
                        "allreduce_bytes_per_sweep": stats.get("allreduce_bytes_per_sweep", 0 if world == 1 else None),
                        "residual_slots": int(2 * emap.n_match + 5)},
+            "host": {"usable_cores": usable_cores(), "os_cpu_count": os.cpu_count(), "blas_threads": os.environ.get("OPENBLAS_NUM_THREADS"),
+                     "note": "BLAS / OpenMP pools capped inside the container's CPU share (quemb_amd/hostthreads.py): an unbounded OpenBLAS pool gets the process "
+                             "throttled by the cgroup for most of a 100 ms period now and then"},
             "fragments_per_s": n_frag_total / dt,
             "ccsd_iterations_per_fragment": n_iter_total / max(n_frag_total, 1),
             "mean_e_corr_per_sweep": ecorr_sum / args.steps,
