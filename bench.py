@@ -595,6 +595,15 @@ def octane_sweeps(lib, reps=24, cpu=True):
                                             "golden -0.5499514850769742 (reference tolerance rtol 1e-5)")
     except Exception as e:  # noqa: BLE001
         out["density_matching"] = dict(seconds=None, note=f"failed: {e}")
+    try:        # the reference's "expensive" test beside it: BE3 density matching of the same molecule (tests/molbe_octane_test.py:63-68)
+        b3 = BE(mf, FragPart.from_json(G / "fragmentation.json", "test_autogen_octane_be3"), distribute=False, lib=lib)
+        lib.qemb_device_sync(); t0 = time.perf_counter()
+        b3.optimize(solver="CCSD")
+        lib.qemb_device_sync(); t_opt = time.perf_counter() - t0
+        out["be3_density_matching"] = dict(seconds=t_opt, e_corr=float(b3.e_corr), abs_diff_vs_reference_golden_Eh=abs(float(b3.e_corr) + 0.5497021857717073),
+                                           fragments=len(b3.Fobjs), n_emb=[int(f.nao) for f in b3.Fobjs], sweeps=int(b3.stats.get("fragments", 0)) // max(len(b3.Fobjs), 1))
+    except Exception as e:  # noqa: BLE001
+        out["be3_density_matching"] = dict(seconds=None, note=f"failed: {e}")
     if cpu:
         try:
             out["cpu_baseline"] = octane_cpu_baseline(be, energies[0])
