@@ -612,6 +612,25 @@ def octane_sweeps(lib, reps=24, cpu=True):
     return out
 
 
+def h8_be2(lib):
+    """BASELINE configs[0] in the line as well: linear H8 / STO-3G BE2 (the reference's plumbing case; six fragments of <= 6 orbitals): HF-in-HF, the
+    one-shot CCSD energy against the reference's golden and the density matching, timed."""
+    from quemb_amd.fragpart import FragPart
+    from quemb_amd.integrals import RHF, Mole
+    from quemb_amd.mbe import BE
+    G = ROOT / "tests" / "golden"
+    mf = RHF(Mole([["H", (0.0, 0.0, float(i))] for i in range(8)])); mf.kernel()
+    be = BE(mf, FragPart.from_json(G / "fragmentation.json", "test_autogen_h_linear_be2"), distribute=False, lib=lib)
+    e1, _ = be.oneshot(); be.oneshot()
+    ts, (e1, _) = timed_sweeps(lib, be.oneshot, 10)
+    lib.qemb_device_sync(); t0 = time.perf_counter()
+    be.optimize(solver="CCSD")
+    lib.qemb_device_sync(); t_opt = time.perf_counter() - t0
+    golden = -0.13198886164212092              # /root/reference/tests/_expected_data_for_fragmentation_test.py:983 (PySCF conv_tol 1e-7)
+    return dict(sweep_ms=_stats_ms(ts)["p50_ms"], hf_in_hf_error_Eh=float(be.hf_err), e_corr_oneshot=float(e1), abs_diff_vs_reference_golden_Eh=abs(float(e1) - golden),
+                density_matching_seconds=t_opt, e_corr_matched=float(be.e_corr), fragments=len(be.Fobjs), n_emb=[int(f.nao) for f in be.Fobjs])
+
+
 def kbe_c5_sweeps(lib, reps=20):
     """BASELINE configs[4] at its own dimensions (kbe polyacetylene BE2: a C4H4 cell of 24 AOs and 28 electrons, 1 x 1 x 3 k-points) on the
     density-fitted model of that size (tests/kbe_model.build_chain; PySCF-PBC / libdmet integrals do not exist in this image): the supercell
@@ -899,6 +918,11 @@ def main():
                     res["octane_be2"] = oc
                 except Exception as e:  # noqa: BLE001
                     res["octane_be2_sweep_ms"] = f"failed: {e}"
+                try:
+                    with contextlib.redirect_stdout(sys.stderr):
+                        res["h8_be2"] = h8_be2(lib)
+                except Exception as e:  # noqa: BLE001
+                    res["h8_be2"] = f"failed: {e}"
                 log("periodic driver at the dimensions of configs[4]")
                 try:
                     with contextlib.redirect_stdout(sys.stderr):
