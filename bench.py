@@ -631,6 +631,39 @@ def h8_be2(lib):
                 density_matching_seconds=t_opt, e_corr_matched=float(be.e_corr), fragments=len(be.Fobjs), n_emb=[int(f.nao) for f in be.Fobjs])
 
 
+def df_c4(lib, reps=5):
+    """BASELINE configs[3] in the line: the density-fitted AO -> fragment transform at N_ao = 512, n_aux = 1000, n = 220, synthetic integrals, result
+    resident in a device fragment.  Executed flops as in tools/transform_bench.py (two rotations, the product with L^-1, the block columns of bb^T bb at and below
+    the diagonal); parity at this size: tests/test_gpu_be.py::test_transforms_at_survey_sizes."""
+    from quemb_amd import eri_transform as et
+    from quemb_amd.fragsolver import DeviceFragment
+    rng = np.random.default_rng(SEED0)
+    N, naux, n = 512, 1000, 220
+    npair = N * (N + 1) // 2
+    ints = 0.06 * rng.standard_normal((naux, npair))
+    A = rng.standard_normal((naux, naux)) / np.sqrt(naux)
+    j2c = A @ A.T + np.eye(naux)
+    TA = np.linalg.qr(rng.standard_normal((N, N)))[0][:, :n].copy()
+    t0 = time.perf_counter()
+    df = et.DFContext(j2c=j2c, lib=lib); df.set_ints(ints, N, layout="packed"); lib.qemb_sync()
+    t_setup = time.perf_counter() - t0
+    fr = DeviceFragment(n, 22, lib=lib)
+    df.transform(TA, frag=fr, want_host=False); lib.qemb_sync()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter(); df.transform(TA, frag=fr, want_host=False); lib.qemb_sync(); ts.append(time.perf_counter() - t0)
+    dt = min(ts)
+    npn = n * (n + 1) // 2
+    nblk = 8 if npn >= 2048 else 1
+    w = ((npn + nblk - 1) // nblk + 127) // 128 * 128
+    syrk = sum(2.0 * (npn - c0) * min(w, npn - c0) * naux for c0 in range(0, npn, w))
+    flop = 2.0 * naux * N * N * n + 2.0 * naux * N * n * n + 2.0 * naux * naux * npn + syrk
+    df.free(); fr.free()
+    return dict(N_ao=N, n_aux=naux, n=n, transform_ms=dt * 1e3, executed_GFLOP=flop / 1e9, tflops_executed=flop / dt / 1e12,
+                frac_of_fp64_matrix_peak=flop / dt / 1e12 / PEAK_FP64_MFMA_TFLOPS, setup_s=t_setup,
+                what="qemb_df_transform: (P|mu nu) -> (P|ij), L^-1, bb^T bb into the fragment's 4-fold packed block (molbe/eri_onthefly.py:45-145)")
+
+
 def kbe_c5_sweeps(lib, reps=20):
     """BASELINE configs[4] at its own dimensions (kbe polyacetylene BE2: a C4H4 cell of 24 AOs and 28 electrons, 1 x 1 x 3 k-points) on the
     density-fitted model of that size (tests/kbe_model.build_chain; PySCF-PBC / libdmet integrals do not exist in this image): the supercell
@@ -918,6 +951,10 @@ def main():
                     res["octane_be2"] = oc
                 except Exception as e:  # noqa: BLE001
                     res["octane_be2_sweep_ms"] = f"failed: {e}"
+                try:
+                    res["df_c4"] = df_c4(lib)
+                except Exception as e:  # noqa: BLE001
+                    res["df_c4"] = f"failed: {e}"
                 try:
                     with contextlib.redirect_stdout(sys.stderr):
                         res["h8_be2"] = h8_be2(lib)
