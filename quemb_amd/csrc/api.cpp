@@ -361,12 +361,12 @@ int qemb_frag_ccsd_export(qemb_frag_t f, const char* name, double* host, int64_t
 int qemb_frag_ccsd_reset(qemb_frag_t f) { CHECK_FRAG(f); return FRAG(f)->ccsd_reset(); }
 
 // ---------------------------------------------------------------- ERI transforms ------------------
-static int deliver_s4(const DBuf& s4, int n, double* out_host, qemb_frag_t frag) {
+static int deliver_s4(DBuf& s4, int n, double* out_host, qemb_frag_t frag) {
   const int64_t np = (int64_t)n * (n + 1) / 2;
   if (out_host) { int rc = dev_d2h(out_host, s4, sizeof(double) * np * np); if (rc) return rc; }
   if (frag) {
     if (FRAG(frag)->n() != n) { set_error("fragment handle has a different n"); return QEMB_ERR_ARG; }
-    return FRAG(frag)->set_eri_s4_dev(s4);
+    return FRAG(frag)->adopt_eri_s4(std::move(s4));      // the transform's result block becomes the fragment's resident ERIs (round 4: no 4.7 GB copy)
   }
   return QEMB_OK;
 }

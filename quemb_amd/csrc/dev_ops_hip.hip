@@ -1236,8 +1236,8 @@ int dev_scale_rows(int64_t nrows, int64_t len, double* x, const double* s) {
 
 __global__ void __launch_bounds__(256) mirror_lower_kernel(long long n, double* __restrict__ A, long long lda) {
   __shared__ double tile[32][33];
-  // blockIdx.x enumerates lower-triangle 32 x 32 tiles (tr >= tc)
-  long long t = blockIdx.x;
+  // the logical block number enumerates lower-triangle 32 x 32 tiles (tr >= tc), neighbours of a tile row on one XCD (xcd_logical_block)
+  long long t = xcd_logical_block(make_uint3(blockIdx.x, 0, 0), make_uint3(gridDim.x, 1, 1)).x;
   long long tr = (long long)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
   while (tr * (tr + 1) / 2 > t) --tr;
   while ((tr + 1) * (tr + 2) / 2 <= t) ++tr;

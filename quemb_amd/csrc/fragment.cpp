@@ -26,6 +26,12 @@ int Fragment::set_eri_s4_dev(const double* s4_dev) {
   QTRY(eri_s4_.alloc(np * np));
   return dev_d2d(eri_s4_, s4_dev, sizeof(double) * np * np);
 }
+int Fragment::adopt_eri_s4(DBuf&& s4) {
+  const int64_t np = npair(n_);
+  if (s4.n != np * np || !s4.p) { set_error("adopt_eri_s4: block of the wrong size"); return QEMB_ERR_ARG; }
+  eri_s4_ = std::move(s4);
+  return 0;
+}
 void Fragment::set_energy_data(const double* h1, const double* veff0, const double* veff, double weight, const int* centers, int ncen) {
   const size_t n2 = (size_t)n_ * n_;
   if (h1) h1_.assign(h1, h1 + n2);

@@ -42,6 +42,7 @@ class Fragment {
   // ERIs: 4-fold packed (npair x npair), the layout of dataset "f{I}" (mbe.py:1039)
   int set_eri_s4_host(const double* s4);
   int set_eri_s4_dev(const double* s4_dev);     // device-to-device copy
+  int adopt_eri_s4(DBuf&& s4);                  // takes the block a transform just produced (no copy: 4.7 GB at n = 220)
   double* eri_s4() { return eri_s4_.p; }
   // static data for the energies: h1, veff0 (n x n host), centre weight/indices
   void set_energy_data(const double* h1, const double* veff0, const double* veff, double weight, const int* centers, int ncen);
