@@ -775,7 +775,7 @@ def main():
             import datetime
             import torch
             import torch.distributed as dist
-            dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=float(os.environ.get("QEMB_COMM_TIMEOUT_S", "120")) + 60.0))
+            dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=float(os.environ.get("QEMB_COMM_INIT_TIMEOUT_S") or os.environ.get("QEMB_COMM_TIMEOUT_S") or "300") + 60.0))
 
     def barrier():
         if world > 1:

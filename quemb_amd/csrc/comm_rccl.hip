@@ -90,6 +90,13 @@ double comm_timeout_s() {
   const double v = e ? std::atof(e) : 120.0;
   return v > 0 ? v : 120.0;
 }
+// the rendezvous waits for processes that are still starting (a cold container pages the image in for minutes, and not at the same pace for
+// every rank): its own bound, QEMB_COMM_INIT_TIMEOUT_S; unset, an explicit QEMB_COMM_TIMEOUT_S holds for it too, else 300 s
+double comm_init_timeout_s() {
+  if (const char* e = std::getenv("QEMB_COMM_INIT_TIMEOUT_S")) { const double v = std::atof(e); if (v > 0) return v; }
+  if (std::getenv("QEMB_COMM_TIMEOUT_S")) return comm_timeout_s();
+  return 300.0;
+}
 
 // the communicator can no longer be used: abort it off-thread (the call may block while a collective kernel spins on a peer that is gone),
 // keep the staging buffers (that kernel may still touch them) and make every later call fail at once.  Caller holds g_comm_mutex.
@@ -141,13 +148,13 @@ int dev_comm_init(int rank, int world, const void* id128) {
     st->c = c; st->r = r; st->he = he; st->done = true;
     st->cv.notify_all();
   }).detach();
-  const double lim = comm_timeout_s();
+  const double lim = comm_init_timeout_s();
   {
     std::unique_lock<std::mutex> lk(st->m);
     if (!st->cv.wait_for(lk, std::chrono::duration<double>(lim), [&] { return st->done; })) {
       g_broken = true;          // the helper is still inside RCCL; nothing of it is touched again
       set_error("qemb_comm_init: rank " + std::to_string(rank) + " of " + std::to_string(world) + " waited " + std::to_string((int)lim) +
-                " s for the other ranks to join (QEMB_COMM_TIMEOUT_S); a rank never started or is gone");
+                " s for the other ranks to join (QEMB_COMM_INIT_TIMEOUT_S / QEMB_COMM_TIMEOUT_S); a rank never started or is gone");
       return QEMB_ERR_DEVICE;
     }
     if (st->he != hipSuccess) { set_error(std::string("qemb_comm_init: hipSetDevice failed: ") + hipGetErrorString(st->he)); return QEMB_ERR_DEVICE; }
