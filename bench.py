@@ -82,6 +82,9 @@ def parse():
     ap.add_argument("--cu-split", type=int, default=2, help="execution contexts on this many interleaved sets of compute units (qemb_ctx_partition; 0: whole chip each)")
     ap.add_argument("--nstreams", type=int, default=4, help="fragments in flight per GPU (separate HIP streams, be_func(..., nstreams=k)); "
                     "the roofline of the ladder kernel is measured in a separate single-stream pass after the timed region")
+    ap.add_argument("--mo-route", choices=("factor", "four-index"), default="factor",
+                    help="how a solve forms its MO integrals: from the fragment's 3-index DF factor (qemb_frag_set_df_factor; the synthetic family IS DF-factorised) "
+                         "or by the four quarter transformations of the 4-fold packed block")
     ap.add_argument("--n", type=int, default=220)
     ap.add_argument("--nocc", type=int, default=20)
     ap.add_argument("--scale", type=float, default=0.03)
@@ -179,14 +182,13 @@ def make_device_eris(lib, n, seed, scale):
     dB = DeviceBuffer.from_numpy(Bp, lib=lib)
     d4 = DeviceBuffer(npair * npair, lib=lib)
     check(lib.qemb_op_gemm(npair, npair, naux, 1.0, dB.ptr, npair, 0, 0, dB.ptr, npair, 0, 0, 0.0, d4.ptr, npair, 0, 1))
-    dB.free()
     A = rng.standard_normal((n, n))
     h = np.diag(2.0 * np.arange(n)) + 0.3 * 0.5 * (A + A.T)
     V = rng.standard_normal((n, n)); veff0 = 0.05 * (V + V.T)
-    return h, veff0, d4
+    return h, veff0, d4, dB, naux
 
 
-def make_ring(lib, n, o, nf, F_total, owner, rank, scale, opts):
+def make_ring(lib, n, o, nf, F_total, owner, rank, scale, opts, mo_route="factor"):
     """The fragment objects of the sweep: `quemb_amd.pfrag.Frags`, the mirror of molbe/pfrag.py:38.  Every rank holds the (light)
     host objects of all fragments -- be_func_parallel's contract -- and the device state (ERIs in HBM, Fock, dm0) of its own."""
     from quemb_amd.fragsolver import DeviceFragment
@@ -197,9 +199,12 @@ def make_ring(lib, n, o, nf, F_total, owner, rank, scale, opts):
         f = Frags(list(range(nf)), I, [edge], [(I + 1) % F_total], [edge], [cen], (1.0, cen), cen, lib=lib)
         f.nao, f.nsocc = n, o
         if owner[I] == rank:
-            h, veff0, d4 = make_device_eris(lib, n, SEED0 + I, scale)
+            h, veff0, d4, dB, naux = make_device_eris(lib, n, SEED0 + I, scale)
             f.dev = DeviceFragment(n, nf, lib=lib)
             f.dev.set_eri_s4_dev(d4.ptr); d4.free()
+            # the fragment keeps the 3-index factor its block was formed from, as one delivered by qemb_df_transform does (integral_direct_DF's bb)
+            f.dev.set_df_factor_dev(dB.ptr, naux); dB.free()
+            f.dev.set_mo_route(-1 if mo_route == "factor" else 0)
             f.h1, f.veff0, f.veff, f.fock, f.heff = h, veff0, None, h, np.zeros((n, n))
             r = f.dev.scf(o, h, None, opts=opts)        # BE.initialize does the same (Frags.scf(fs=True), mbe.py:1160)
             f._mo_coeffs = r["mo_coeff"]
@@ -833,7 +838,7 @@ def main():
 
     # ---- set-up (untimed): fragments resident in HBM, initial fragment SCF for dm0 (BE.initialize does the same)
     log(f"setting up {F} fragments per GPU (n={n}, n_occ={o}), {F_total} in the ring")
-    frs, npot = make_ring(lib, n, o, nf, F_total, owner, rank, args.scale, opts)
+    frs, npot = make_ring(lib, n, o, nf, F_total, owner, rank, args.scale, opts, args.mo_route)
     mine = [i for i in range(F_total) if owner[i] == rank]
     emap = ErrorMap(frs)
     pot = [0.0] * npot
@@ -906,7 +911,12 @@ def main():
             "config": {"workload": f"BASELINE configs[2]: synthetic fragment sweep, {F} fragments per GPU ({F_total} total, {args.scaling} scaling), "
                                    f"n_occ={o} n_virt={v} (n={n}), DF-factorised ERIs naux={3 * n}, ERI scale={args.scale} (SURVEY 8d says 0.06: the oracle's "
                                    "own RHF/CCSD diverges there for n > ~100, DESIGN.md), one be_func / be_func_parallel sweep per step "
-                                   "(update_heff + fragment RHF + MO transform + RCCSD to |dE|<1e-10 + 1-RDM + energies per fragment, solve_error, 1 all-reduce)",
+                                   "(update_heff + fragment RHF + MO-basis integrals + RCCSD to |dE|<1e-10 + 1-RDM + energies per fragment, solve_error, 1 all-reduce); "
+                                   + ("MO-basis integrals from each fragment's 3-index DF factor (north_star's density-fitted 3-index route: the factor is rotated into the "
+                                      "fragment's orbitals and multiplied with itself, 2 naux npair^2 flops; same integrals to rounding as the four-index transformation "
+                                      "-- tests/test_gpu_fragment.py holds both routes to the oracle at n = 220 -- whose figure is `four_index_route`)"
+                                      if args.mo_route == "factor" else "MO-basis integrals by the four quarter transformations of the 4-fold packed block"),
+                       "mo_route": args.mo_route,
                        "fragments_per_gpu": F, "n_occ": o, "n_virt": v, "fragments_in_flight_per_gpu": args.nstreams, "cu_partition": (args.cu_split if args.nstreams > 1 else 0),
                        "parallelism": f"fragments sharded over {world} GPU(s) by the LPT partition, 1 all-reduce per sweep",
                        "transport": None if world == 1 else {"rccl": "library communicator: ncclAllReduce on a persistent RCCL communicator (qemb_comm_allreduce)",
@@ -951,6 +961,22 @@ def main():
                                                        "right after the timed region, GPU still hot: sum of per-workgroup s_memtime ticks / (256 CUs x kernel time)"})
             except Exception as e:  # noqa: BLE001
                 res["roofline"]["sustained_clock_ghz"] = f"probe failed: {e}"
+            if args.mo_route == "factor" and not args.lib:
+                # the same sweep with the other route (the four quarter transformations of the packed block, as in rounds 1-3), one warm-up and one timed sweep
+                try:
+                    for f in frs:
+                        f.dev.set_mo_route(0)
+                    sweep()
+                    n0 = float(stats.get("ccsd_iterations", 0))
+                    sync(); t1 = time.perf_counter()
+                    sweep()
+                    sync(); dt4 = time.perf_counter() - t1
+                    res["four_index_route"] = {"value": (float(stats.get("ccsd_iterations", 0)) - n0) / dt4, "unit": "CCSD iterations/s", "ms_per_step": dt4 * 1e3,
+                                               "mo_transform_avg_ms": None, "what": "one timed sweep of the same fragments with qemb_frag_mo_route(0)"}
+                    for f in frs:
+                        f.dev.set_mo_route(-1)
+                except Exception as e:  # noqa: BLE001
+                    res["four_index_route"] = f"failed: {e}"
             log("parity probe vs oracle")
             try:
                 res["parity_max_abs_err_Eh"] = parity_probe()

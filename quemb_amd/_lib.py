@@ -146,6 +146,10 @@ def _declare(lib):
     f("qemb_frag_free", I, V)
     f("qemb_frag_set_eri_s4", I, V, P)
     f("qemb_frag_set_eri_s4_dev", I, V, P)
+    f("qemb_frag_set_df_factor", I, V, I, P)
+    f("qemb_frag_set_df_factor_dev", I, V, I, P)
+    f("qemb_frag_mo_route", I, V, I)
+    f("qemb_frag_mo_route_used", I, V, IP, IP)
     f("qemb_frag_get_eri_s4", I, V, P)
     f("qemb_frag_set_energy_data", I, V, P, P, P, D, IP, I)
     f("qemb_frag_jk", I, V, P, P, P)

@@ -229,11 +229,15 @@ int DfContext::set_ints_semisparse(int N_, int64_t n_unique_, const double* uniq
 }
 
 // bpT[P(i,j)][L'] (pair rows of naux) -> (ij|kl) = sum_L bb[ij][L] bb[kl][L], bb = bpT Linv^T   (eval_via_cholesky, eri_sparse_DF.cpp:611-621)
-int DfContext::finish_from_pair_rows(int n, const double* bpT, double* out_s4) const {
+int DfContext::finish_from_pair_rows(int n, const double* bpT, double* out_s4, DBuf* keep_bb) const {
   const int64_t np = npair(n);
   DBuf bbT;
   QTRY(bbT.alloc(np * naux));
   QTRY(gemm(np, naux, naux, 1.0, bpT, naux, true, Linv, naux, true, 0.0, bbT, naux));
+  if (keep_bb) {                                          // the factor in the layout the fragment keeps: [naux][np]
+    QTRY(keep_bb->alloc(naux * np));
+    QTRY(perm4(*keep_bb, bbT, 1, 1, np, naux, 0, 1, 3, 2));
+  }
   const int64_t nblk = np >= 2048 ? 8 : 1;
   const int64_t w = ((np + nblk - 1) / nblk + 127) / 128 * 128;
   for (int64_t c0 = 0; c0 < np; c0 += w) {
@@ -249,7 +253,7 @@ int DfContext::finish_from_pair_rows(int n, const double* bpT, double* out_s4) c
 //   (P|mu i) = sum_{nu in reach(mu)} TA[nu,i] (P|mu nu)   ==   T1[mu][i][P] = TAg[mu]^T Dg[mu],
 // Dg[mu][k][:] = aux vector of the k-th partner of mu, TAg[mu][k][:] = TA row of that partner (zero rows pad short lists), both
 // gathered by index.  Every stored aux vector is read twice (once per member of its pair) instead of once per (mu, i).
-int DfContext::transform_semisparse(const double* TA, int n, double* out_s4, const double* S_abs, double eps) const {
+int DfContext::transform_semisparse(const double* TA, int n, double* out_s4, const double* S_abs, double eps, DBuf* keep_bb) const {
   const int64_t np = npair(n);
   DBuf T1, T2, bpT, maskb, Xb, TAact, idx_dev;
   TimerScope lap_DF(TIMER_DF);
@@ -325,14 +329,14 @@ int DfContext::transform_semisparse(const double* TA, int n, double* out_s4, con
   QTRY(bpT.alloc(np * naux));
   QTRY(dev_pack_pair_rows(n, naux, T2, bpT));            // rows (j >= i) of T2[j][i][:]
   T2.release();
-  QTRY(finish_from_pair_rows(n, bpT, out_s4));
+  QTRY(finish_from_pair_rows(n, bpT, out_s4, keep_bb));
   QTRY(lap_DF.close());
   return 0;
 }
 
-int DfContext::transform(const double* TA, int n, double* out_s4, const double* S_abs, double eps) const {
+int DfContext::transform(const double* TA, int n, double* out_s4, const double* S_abs, double eps, DBuf* keep_bb) const {
   if (n <= 0 || n > N) { set_error("df transform: need 0 < n <= N"); return QEMB_ERR_ARG; }
-  if (Linv.p && Usp.p) return transform_semisparse(TA, n, out_s4, S_abs, eps);
+  if (Linv.p && Usp.p) return transform_semisparse(TA, n, out_s4, S_abs, eps, keep_bb);
   if (!Linv.p || !Lpq.p) { set_error("DfContext: metric and 3-index integrals must be set"); return QEMB_ERR_ARG; }
   const int64_t np = npair(n);
   DBuf T1, T2, bp, bb;
@@ -365,18 +369,22 @@ int DfContext::transform(const double* TA, int n, double* out_s4, const double* 
   // bb = L^-1 bp                                          (eri_onthefly.py:141 / cublasDtrsm :667)
   QTRY(gemm(naux, np, naux, 1.0, Linv, naux, true, bp, np, false, 0.0, bb, np));
   // (ij|kl) = sum_L bb[L,ij] bb[L,kl] over packed pairs   (eri_onthefly.py:143 / cublasDsyrk :684, beta = 0)
-  // The result is symmetric: only block columns at and below the diagonal are computed (9/16 of the flops with 8
-  // blocks), then mirrored.
-  {
-    const int64_t nblk = np >= 2048 ? 8 : 1;
-    const int64_t w = ((np + nblk - 1) / nblk + 127) / 128 * 128;
-    for (int64_t c0 = 0; c0 < np; c0 += w) {
-      const int64_t cw = std::min(w, np - c0);
-      QTRY(gemm(np - c0, cw, naux, 1.0, bb.p + c0, np, false, bb.p + c0, np, false, 0.0, out_s4 + c0 * np + c0, np));
-    }
-    if (nblk > 1) QTRY(dev_mirror_lower(np, out_s4, np));
-  }
+  QTRY(df_pair_product(np, naux, bb, out_s4));
+  if (keep_bb) *keep_bb = std::move(bb);                  // B_{ij}^{L} itself: the fragment's 3-index factor (MO integrals straight from it, ccsd.cpp)
   QTRY(lap_DF.close());
+  return 0;
+}
+
+// out[P1][P2] = sum_L bb[L,P1] bb[L,P2] (np x np, symmetric) from the packed factor bb[naux][np].  Only block columns at and below
+// the diagonal are computed (9/16 of the flops with 8 blocks), then mirrored.
+int df_pair_product(int64_t np, int64_t naux, const double* bb, double* out) {
+  const int64_t nblk = np >= 2048 ? 8 : 1;
+  const int64_t w = ((np + nblk - 1) / nblk + 127) / 128 * 128;
+  for (int64_t c0 = 0; c0 < np; c0 += w) {
+    const int64_t cw = std::min(w, np - c0);
+    QTRY(gemm(np - c0, cw, naux, 1.0, bb + c0, np, false, bb + c0, np, false, 0.0, out + c0 * np + c0, np));
+  }
+  if (nblk > 1) QTRY(dev_mirror_lower(np, out, np));
   return 0;
 }
 

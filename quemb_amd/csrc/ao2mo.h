@@ -50,15 +50,19 @@ class DfContext {
                           const int64_t* reach_off);
   // S_abs_dev (N x N, may be null) + eps: the MO-coefficient screening of the semi-sparse transform
   // (_cpp/eri_sparse_DF.cpp:443-465 get_AO_per_MO): (P|mu i) is kept only where |S_abs TA|(mu,i) >= eps.
-  int transform(const double* TA_dev, int n, double* out_s4_dev, const double* S_abs_dev = nullptr, double eps = 0.0) const;
+  // keep_bb (nullable): receives the fitted factor B_{ij}^{L} = bb[naux][npair(n)] (eri_onthefly.py:141) the block was formed from
+  int transform(const double* TA_dev, int n, double* out_s4_dev, const double* S_abs_dev = nullptr, double eps = 0.0, DBuf* keep_bb = nullptr) const;
 
   DBuf Usp;                              // semi-sparse storage: [n_unique][naux]
   int64_t n_unique = 0;
   std::vector<int64_t> reach_ptr, reach_off;
   std::vector<int32_t> reach_nu;
  private:
-  int transform_semisparse(const double* TA_dev, int n, double* out_s4_dev, const double* S_abs_dev, double eps) const;
-  int finish_from_pair_rows(int n, const double* bpT, double* out_s4) const;
+  int transform_semisparse(const double* TA_dev, int n, double* out_s4_dev, const double* S_abs_dev, double eps, DBuf* keep_bb) const;
+  int finish_from_pair_rows(int n, const double* bpT, double* out_s4, DBuf* keep_bb) const;
 };
+
+// out[np][np] = bb^T bb for the packed factor bb[naux][np] (lower block columns + mirror)
+int df_pair_product(int64_t np, int64_t naux, const double* bb, double* out);
 
 }  // namespace qemb

@@ -253,6 +253,15 @@ int qemb_frag_create(int n, int n_f, qemb_frag_t* out) {
 int qemb_frag_free(qemb_frag_t f) { delete FRAG(f); return QEMB_OK; }
 int qemb_frag_set_eri_s4(qemb_frag_t f, const double* s4) { CHECK_FRAG(f); return FRAG(f)->set_eri_s4_host(s4); }
 int qemb_frag_set_eri_s4_dev(qemb_frag_t f, const double* s4) { CHECK_FRAG(f); return FRAG(f)->set_eri_s4_dev(s4); }
+int qemb_frag_set_df_factor(qemb_frag_t f, int naux, const double* B) { CHECK_FRAG(f); return FRAG(f)->set_df_factor_host(naux, B); }
+int qemb_frag_set_df_factor_dev(qemb_frag_t f, int naux, const double* B) { CHECK_FRAG(f); return FRAG(f)->set_df_factor_dev(naux, B); }
+int qemb_frag_mo_route(qemb_frag_t f, int route) { CHECK_FRAG(f); return FRAG(f)->set_mo_route(route); }
+int qemb_frag_mo_route_used(qemb_frag_t f, int* used_factor, int* naux) {
+  CHECK_FRAG(f);
+  if (used_factor) *used_factor = FRAG(f)->last_route_was_factor() ? 1 : 0;
+  if (naux) *naux = FRAG(f)->df_naux();
+  return QEMB_OK;
+}
 int qemb_frag_get_eri_s4(qemb_frag_t f, double* s4) {
   CHECK_FRAG(f);
   const int64_t n = FRAG(f)->n(), np = n * (n + 1) / 2;
@@ -361,12 +370,14 @@ int qemb_frag_ccsd_export(qemb_frag_t f, const char* name, double* host, int64_t
 int qemb_frag_ccsd_reset(qemb_frag_t f) { CHECK_FRAG(f); return FRAG(f)->ccsd_reset(); }
 
 // ---------------------------------------------------------------- ERI transforms ------------------
-static int deliver_s4(DBuf& s4, int n, double* out_host, qemb_frag_t frag) {
+static int deliver_s4(DBuf& s4, int n, double* out_host, qemb_frag_t frag, DBuf* factor = nullptr, int naux = 0) {
   const int64_t np = (int64_t)n * (n + 1) / 2;
   if (out_host) { int rc = dev_d2h(out_host, s4, sizeof(double) * np * np); if (rc) return rc; }
   if (frag) {
     if (FRAG(frag)->n() != n) { set_error("fragment handle has a different n"); return QEMB_ERR_ARG; }
-    return FRAG(frag)->adopt_eri_s4(std::move(s4));      // the transform's result block becomes the fragment's resident ERIs (round 4: no 4.7 GB copy)
+    int rc = FRAG(frag)->adopt_eri_s4(std::move(s4));    // the transform's result block becomes the fragment's resident ERIs (round 4: no 4.7 GB copy)
+    if (rc == 0 && factor && factor->p) rc = FRAG(frag)->adopt_df_factor(std::move(*factor), naux);      // ... and the factor it was formed from goes with it
+    return rc;
   }
   return QEMB_OK;
 }
@@ -458,8 +469,9 @@ int qemb_df_transform_screened(qemb_df_t df, const double* TA, int n, const doub
   if ((rc = dTA.alloc((int64_t)d->N * n)) || (rc = dS.alloc((int64_t)d->N * d->N))) return rc;
   if ((rc = dev_h2d(dTA, TA, sizeof(double) * d->N * n)) || (rc = dev_h2d(dS, S_abs, sizeof(double) * d->N * d->N))) return rc;
   if ((rc = s4.alloc(((int64_t)n * (n + 1) / 2) * ((int64_t)n * (n + 1) / 2)))) return rc;
-  if ((rc = d->transform(dTA, n, s4, dS, MO_coeff_epsilon))) return rc;
-  return deliver_s4(s4, n, out_s4_host, frag);
+  DBuf bb;
+  if ((rc = d->transform(dTA, n, s4, dS, MO_coeff_epsilon, frag ? &bb : nullptr))) return rc;
+  return deliver_s4(s4, n, out_s4_host, frag, &bb, d->naux);
 }
 int qemb_df_transform(qemb_df_t df, const double* TA, int n, double* out_s4_host, qemb_frag_t frag) {
   if (!df || !TA) { set_error("qemb_df_transform: null argument"); return QEMB_ERR_ARG; }
@@ -469,8 +481,9 @@ int qemb_df_transform(qemb_df_t df, const double* TA, int n, double* out_s4_host
   if ((rc = dTA.alloc((int64_t)d->N * n))) return rc;
   if ((rc = dev_h2d(dTA, TA, sizeof(double) * d->N * n))) return rc;
   if ((rc = s4.alloc(((int64_t)n * (n + 1) / 2) * ((int64_t)n * (n + 1) / 2)))) return rc;
-  if ((rc = d->transform(dTA, n, s4))) return rc;
-  return deliver_s4(s4, n, out_s4_host, frag);
+  DBuf bb;
+  if ((rc = d->transform(dTA, n, s4, nullptr, 0.0, frag ? &bb : nullptr))) return rc;
+  return deliver_s4(s4, n, out_s4_host, frag, &bb, d->naux);
 }
 
 // ---------------------------------------------------------------- Schmidt ---------------------------

@@ -14,6 +14,7 @@
 //   Vl[a,b,c,d] = (ac|bd): the pp-ladder is the NT GEMM  t2new[(ij),(ab)] += tau[(ij),(cd)] * Vl[(ab),(cd)]
 //   U accumulates every term that enters t2new as P(X) = X_ijab + X_jiba; it is symmetrised once.
 #include "ccsd.h"
+#include "ao2mo.h"
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -42,37 +43,24 @@ namespace qemb {
 int mo_slab_ld(int n) { return (n >= 64 && n <= 1024) ? (n + 15) / 16 * 16 : n; }
 int64_t mo_transform_work(int n) { return (int64_t)n * mo_slab_ld(n) * ((int64_t)n * (n + 1) / 2); }
 
-int mo_transform(int n, int o, int nf, const double* eri_s4, double* X0, double* X1, const double* C, MoIntegrals& out, bool build_Vl, bool build_T34,
-                 bool x1_is_unpacked) {
+// The 3/4-transformed integrals the energies need, from T[P(r's')][P][q'] (P = embedding index, rows of n, `slab` doubles per pair)
+static int mo_three_quarter_blocks(int n, int o, int nf, const double* T, int64_t slab, MoIntegrals& out, bool build_T34) {
   const int v = n - o;
-  const int64_t np = (int64_t)n * (n + 1) / 2, ncol = np * n;
-  out.n = n; out.o = o; out.v = v; out.nf = nf;
-  TimerScope lap_AO2MO(TIMER_AO2MO);
-  const int64_t nl = mo_slab_ld(n);                   // row stride of the unpacked n x n images (X1 here, X0 after the second unpack)
-  if (!x1_is_unpacked) QTRY(dev_unpack_tril_rows_ld(np, n, nl, eri_s4, X1));   // (the caller of solve_begin has done it already)
-  // 193..224 rows fit ONE 224 x 128 tile (1.8 % padding instead of the 14 % of two 128-row tiles at n = 220)
-  const int tcfg = (n > 192 && n <= 224) ? 13 : -1;
-  QTRY(gemm(n, ncol, n, 1.0, C, n, false, X1, nl, true, 0.0, X0, ncol, 1, 0, 0, 0, tcfg));
-  QTRY(gemm_quarter_lower_rows(n, np, n, C, X0, X1));     // X1[r'][s'][pq], only the rows r' >= s' (all that is read below)
-  QTRY(dev_unpack_tril_pair_rows_ld(n, n, nl, X1, X0));   // keep r' >= s' rows AND unpack pq, one pass: X0 = [(r's')][p][q], rows nl apart
-  // the last two quarter transforms act on the n x n slab of every pair (r's'): two batched GEMMs, slab <- C^T slab C, which
-  // leave the pair index IN FRONT -- every gather below then reads contiguous runs
-  const int64_t n2 = (int64_t)n * n;
-  // X1[(r's')][P][q'] = sum_q X0[..][P][q] C[q,q']: the slabs are contiguous, so this is ONE tall product over the np * n rows ((r's'),P) with
-  // all n columns in a 128 x 224 tile (as a batch of n x n x n products on the 224 x 128 tile the second column tile is 72 % padding at n = 220)
-  if (n > 192 && n <= 224) { QTRY(gemm(np * n, n, n, 1.0, X0, nl, true, C, n, false, 0.0, X1, n, 1, 0, 0, 0, 34)); }
-  else QTRY(gemm(n, n, n, 1.0, X0, nl, true, C, n, false, 0.0, X1, n, np, (int64_t)n * nl, 0, n2, tcfg));
   if (nf > 0 && build_T34) {   // every (P q'|r' s') as T34[q'][r'][s'][P]: the operand of CcLambda::densities
     QTRY(out.T34.alloc((int64_t)n * n * n * nf));
-    QTRY(dev_extract_pf_t(n, X1, 0, 0, 0, 0, n, n, n, nf, out.T34));
+    QTRY(dev_extract_pf_t(n, T, 0, 0, 0, 0, n, n, n, nf, out.T34, slab));
   } else if (nf > 0) {
     QTRY(out.A1.alloc((int64_t)v * o * v * nf));
     QTRY(out.A2.alloc((int64_t)o * o * v * nf));
-    QTRY(dev_extract_pf_t(n, X1, o, 0, o, 0, v, o, v, nf, out.A1));     // A1[a,j,b,P] = (P a|j b) = X1[P(j,b)][P][a]
-    QTRY(dev_extract_pf_t(n, X1, 0, 0, o, 0, o, o, v, nf, out.A2));     // A2[i,j,b,P] = (P i|j b)
+    QTRY(dev_extract_pf_t(n, T, o, 0, o, 0, v, o, v, nf, out.A1, slab));     // A1[a,j,b,P] = (P a|j b) = T[P(j,b)][P][a]
+    QTRY(dev_extract_pf_t(n, T, 0, 0, o, 0, o, o, v, nf, out.A2, slab));     // A2[i,j,b,P] = (P i|j b)
   }
-  QTRY(gemm(n, n, n, 1.0, C, n, false, X1, n, false, 0.0, X0, n, np, 0, n2, n2, tcfg));     // X0[(r's')][p'][q'] = sum_p C[p,p'] X1[..][p][q']
-  const double* Mp = X0;   // pair-first MO tensor Mp[P(r',s')][p'][q'] = (r's'|p'q')
+  return 0;
+}
+
+// every block of the amplitude equations from the pair-first MO tensor Mp[P(r',s')][p'][q'] = (r's'|p'q') (slabs of n x n); `scratch` holds v^4 doubles or is null
+static int mo_blocks_from_pair_first(int n, int o, const double* Mp, double* scratch, int64_t scratch_elems, MoIntegrals& out, bool build_Vl) {
+  const int v = n - o;
   QTRY(out.oooo.alloc((int64_t)o * o * o * o));
   QTRY(out.ovoo.alloc((int64_t)o * v * o * o));
   QTRY(out.ovov.alloc((int64_t)o * v * o * v));
@@ -93,15 +81,81 @@ int mo_transform(int n, int o, int nf, const double* eri_s4, double* X0, double*
     QTRY(out.Vm.alloc(std::max<int64_t>(nm, 1) * out.ldm));
     QTRY(dev_ladder_pack_vvvv_pf(n, o, Mp, out.Vp, out.ldp, out.Vm, out.ldm));
   }
-  if (build_Vl) {  // Vl[a,b,c,d] = (ac|bd): gather [a][c][b][d] (X1 is free now), then swap the middle indices
+  if (build_Vl) {  // Vl[a,b,c,d] = (ac|bd): gather [a][c][b][d], then swap the middle indices
     const int64_t v4 = (int64_t)v * v * v * v;
     QTRY(out.Vl.alloc(v4));
     DBuf tmp;
-    double* g = X1;
-    if (v4 > mo_transform_work(n)) { QTRY(tmp.alloc(v4)); g = tmp; }
+    double* g = scratch;
+    if (!g || v4 > scratch_elems) { QTRY(tmp.alloc(v4)); g = tmp; }
     QTRY(dev_extract_pf(n, Mp, o, o, o, o, v, v, v, v, g));
     QTRY(perm4(out.Vl, g, v, v, v, v, 0, 2, 1, 3));
   }
+  return 0;
+}
+
+int mo_transform(int n, int o, int nf, const double* eri_s4, double* X0, double* X1, const double* C, MoIntegrals& out, bool build_Vl, bool build_T34,
+                 bool x1_is_unpacked) {
+  const int v = n - o;
+  const int64_t np = (int64_t)n * (n + 1) / 2, ncol = np * n;
+  out.n = n; out.o = o; out.v = v; out.nf = nf;
+  TimerScope lap_AO2MO(TIMER_AO2MO);
+  const int64_t nl = mo_slab_ld(n);                   // row stride of the unpacked n x n images (X1 here, X0 after the second unpack)
+  if (!x1_is_unpacked) QTRY(dev_unpack_tril_rows_ld(np, n, nl, eri_s4, X1));   // (the caller of solve_begin has done it already)
+  // 193..224 rows fit ONE 224 x 128 tile (1.8 % padding instead of the 14 % of two 128-row tiles at n = 220)
+  const int tcfg = (n > 192 && n <= 224) ? 13 : -1;
+  QTRY(gemm(n, ncol, n, 1.0, C, n, false, X1, nl, true, 0.0, X0, ncol, 1, 0, 0, 0, tcfg));
+  QTRY(gemm_quarter_lower_rows(n, np, n, C, X0, X1));     // X1[r'][s'][pq], only the rows r' >= s' (all that is read below)
+  QTRY(dev_unpack_tril_pair_rows_ld(n, n, nl, X1, X0));   // keep r' >= s' rows AND unpack pq, one pass: X0 = [(r's')][p][q], rows nl apart
+  // the last two quarter transforms act on the n x n slab of every pair (r's'): two batched GEMMs, slab <- C^T slab C, which
+  // leave the pair index IN FRONT -- every gather below then reads contiguous runs
+  const int64_t n2 = (int64_t)n * n;
+  // X1[(r's')][P][q'] = sum_q X0[..][P][q] C[q,q']: the slabs are contiguous, so this is ONE tall product over the np * n rows ((r's'),P) with
+  // all n columns in a 128 x 224 tile (as a batch of n x n x n products on the 224 x 128 tile the second column tile is 72 % padding at n = 220)
+  if (n > 192 && n <= 224) { QTRY(gemm(np * n, n, n, 1.0, X0, nl, true, C, n, false, 0.0, X1, n, 1, 0, 0, 0, 34)); }
+  else QTRY(gemm(n, n, n, 1.0, X0, nl, true, C, n, false, 0.0, X1, n, np, (int64_t)n * nl, 0, n2, tcfg));
+  QTRY(mo_three_quarter_blocks(n, o, nf, X1, 0, out, build_T34));
+  QTRY(gemm(n, n, n, 1.0, C, n, false, X1, n, false, 0.0, X0, n, np, 0, n2, n2, tcfg));     // X0[(r's')][p'][q'] = sum_p C[p,p'] X1[..][p][q']
+  // pair-first MO tensor Mp[P(r',s')][p'][q'] = (r's'|p'q') in X0 (X1 is free now)
+  QTRY(mo_blocks_from_pair_first(n, o, X0, X1, mo_transform_work(n), out, build_Vl));
+  QTRY(lap_AO2MO.close());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// The same MO blocks from the fragment's 3-index factor B[L][P(p,q)] (naux x npair(n), embedding basis: the `bb` of
+// molbe/eri_onthefly.py:141, whose product bb^T bb IS the fragment's ERI block, :143) -- north_star's "density-fitted 3-index"
+// route to the fragment-MO integrals.  The factor is transformed, not the four-index tensor:
+//   Lh [L][p][q']  = B[L] C                      (naux n x n x n product)
+//   Lmo[L][p'][q'] = C^T Lh[L]                   (batched over L), packed over p' >= q': Lpk[L][P(p'q')]
+//   S[P(r's')][P(p'q')] = sum_L Lpk[L,P(r's')] Lpk[L,P(p'q')]      -- 2 naux npair^2 x 9/16 flops (0.44e12 at n = 220, naux = 660)
+//   Mp[P(r's')][p'][q'] = unpack of S            -- the pair-first tensor the four-index route ends with, to rounding
+//   T [P(r's')][P][q']  = sum_L Lpk[L,P(r's')] Lh[L][P][q'],  P < nf  -- the 3/4-transformed integrals of the energies
+// against 4 x 2 n^3 npair (1.81e12 executed with the triangular savings) for the four quarter transforms: cheaper while naux < ~8 n.
+// X0, X1: the work buffers of mo_transform (mo_transform_work(n) doubles each).
+int mo_transform_factor(int n, int o, int nf, int naux, const double* Bf, double* X0, double* X1, const double* C, MoIntegrals& out, bool build_Vl,
+                        bool build_T34) {
+  const int v = n - o;
+  const int64_t np = (int64_t)n * (n + 1) / 2, n2 = (int64_t)n * n;
+  if (naux <= 0 || !Bf) { set_error("mo_transform_factor: no factor"); return QEMB_ERR_ARG; }
+  if ((int64_t)nf * n > mo_transform_work(n) / np) { set_error("mo_transform_factor: work buffer too small"); return QEMB_ERR_ARG; }
+  out.n = n; out.o = o; out.v = v; out.nf = nf;
+  TimerScope lap_AO2MO(TIMER_AO2MO);
+  DBuf Lu, Lh, Lpk;
+  QTRY(Lu.alloc((int64_t)naux * n2)); QTRY(Lh.alloc((int64_t)naux * n2)); QTRY(Lpk.alloc((int64_t)naux * np));
+  QTRY(dev_unpack_tril_rows(naux, n, Bf, Lu));                                                      // B[L][p][q]
+  QTRY(gemm((int64_t)naux * n, n, n, 1.0, Lu, n, true, C, n, false, 0.0, Lh, n));                  // Lh[(L,p)][q'] = sum_q B[L][p][q] C[q,q']
+  QTRY(gemm(n, n, n, 1.0, C, n, false, Lh, n, false, 0.0, Lu, n, naux, 0, n2, n2));                 // Lmo[L][p'][q'] = sum_p C[p,p'] Lh[L][p][q']  (over Lu)
+  QTRY(dev_pack_tril_rows(naux, n, Lu, Lpk));
+  Lu.release();
+  QTRY(df_pair_product(np, naux, Lpk, X1));                                                         // S in X1 (npair x npair)
+  QTRY(dev_unpack_tril_rows(np, n, X1, X0));                                                        // Mp in X0
+  if (nf > 0) {
+    // T[P(r's')][(P,q')] for the first nf rows P of every slab of Lh: A(m,k) = Lpk[k][m], B(k,col) = Lh[k][col], col < nf n
+    QTRY(gemm(np, (int64_t)nf * n, naux, 1.0, Lpk, np, false, Lh, n2, false, 0.0, X1, (int64_t)nf * n));
+    QTRY(mo_three_quarter_blocks(n, o, nf, X1, (int64_t)nf * n, out, build_T34));
+  }
+  Lh.release(); Lpk.release();
+  QTRY(mo_blocks_from_pair_first(n, o, X0, X1, mo_transform_work(n), out, build_Vl));
   QTRY(lap_AO2MO.close());
   return 0;
 }

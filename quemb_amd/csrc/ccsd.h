@@ -35,6 +35,12 @@ int mo_slab_ld(int n);            // row stride of the unpacked n x n images ins
 int64_t mo_transform_work(int n);
 int mo_transform(int n, int o, int nf, const double* eri_s4, double* X0, double* X1, const double* C, MoIntegrals& out,
                  bool build_Vl = false, bool build_T34 = false, bool x1_is_unpacked = false);
+// the same blocks from the fragment's 3-index factor B[naux][npair(n)] (bb of molbe/eri_onthefly.py:141; eri = bb^T bb, :143): the factor is
+// transformed and multiplied with itself in the MO basis -- 2 naux npair^2 flops instead of 8 n^3 npair (ccsd.cpp)
+int mo_transform_factor(int n, int o, int nf, int naux, const double* B_packed, double* X0, double* X1, const double* C, MoIntegrals& out,
+                        bool build_Vl = false, bool build_T34 = false);
+// which route a solve takes when the fragment holds a factor: the factor's, while its product is the cheaper one (measured crossover near naux = 8 n)
+inline bool mo_factor_route_pays(int n, int naux) { return naux > 0 && (int64_t)naux <= 6 * (int64_t)n; }
 
 class CcLambda;
 

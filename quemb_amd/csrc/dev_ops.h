@@ -183,8 +183,9 @@ int dev_pack_pair_rows(int64_t n, int64_t ncols, const double* in, double* out);
 int dev_extract_pf(int64_t n, const double* Mp, int64_t p0, int64_t q0, int64_t r0, int64_t s0, int64_t sp, int64_t sq,
                    int64_t sr, int64_t ss, double* out);
 // T: [npair(n)][n][n] with T[P(r,s)][c][x] -> out[sx][sr][ss][sc] = T[P(r0+r, s0+s)][c0+c][x0+x]   (3/4-transformed integrals)
+// (slab: doubles per pair in T, rows of n; 0 = n * n.  The factor route of mo_transform keeps only the first nf rows of every slab.)
 int dev_extract_pf_t(int64_t n, const double* T, int64_t x0, int64_t r0, int64_t s0, int64_t c0, int64_t sx, int64_t sr,
-                     int64_t ss, int64_t sc, double* out);
+                     int64_t ss, int64_t sc, double* out, int64_t slab = 0);
 // (+/-) ladder operands: Vp[P(ab),P(cd)] = Mp[P(va,vc)][vb][vd] + Mp[P(vb,vc)][va][vd]  (v* = o + *), Vm with the minus sign
 int dev_ladder_pack_vvvv_pf(int64_t n, int64_t o, const double* Mp, double* Vp, int64_t ldp, double* Vm, int64_t ldm);
 

@@ -1337,21 +1337,23 @@ int dev_extract_pf(int64_t n, const double* Mp, int64_t p0, int64_t q0, int64_t 
 }
 // out[x][r][s][c] = T[P(r0+r,s0+s)][c0+c][x0+x]: one workgroup per (r,s) slab reads the sc x sx corner (rows of sx contiguous doubles)
 __global__ void __launch_bounds__(256) extract_pf_t_kernel(long long n, const double* __restrict__ T, long long x0, long long r0, long long s0, long long c0,
-                                                          long long sx, long long sr, long long ss, long long sc, double* __restrict__ out) {
+                                                          long long sx, long long sr, long long ss, long long sc, double* __restrict__ out, long long slab) {
   for (long long rs = blockIdx.x; rs < sr * ss; rs += gridDim.x) {
     const long long r = rs / ss, s = rs - r * ss;
-    const double* src = T + pair_idx(r0 + r, s0 + s) * n * n + c0 * n + x0;
+    const double* src = T + pair_idx(r0 + r, s0 + s) * slab + c0 * n + x0;
     for (long long t = threadIdx.x; t < sc * sx; t += blockDim.x) {
       const long long c = t / sx, x = t - c * sx;
       out[(x * sr * ss + rs) * sc + c] = src[c * n + x];
     }
   }
 }
-int dev_extract_pf_t(int64_t n, const double* T, int64_t x0, int64_t r0, int64_t s0, int64_t c0, int64_t sx, int64_t sr, int64_t ss, int64_t sc, double* out) {
+int dev_extract_pf_t(int64_t n, const double* T, int64_t x0, int64_t r0, int64_t s0, int64_t c0, int64_t sx, int64_t sr, int64_t ss, int64_t sc, double* out, int64_t slab) {
   REQUIRE_INIT();
   if (sx <= 0 || sr <= 0 || ss <= 0 || sc <= 0) return QEMB_OK;
+  if (slab <= 0) slab = n * n;          // (a pair's slab holds all n rows; the factor route of mo_transform keeps only the first nf)
+  if (c0 + sc > slab / n) { set_error("dev_extract_pf_t: rows beyond the slab"); return QEMB_ERR_ARG; }
   hipLaunchKernelGGL(extract_pf_t_kernel, dim3((unsigned)std::min<int64_t>(sr * ss, 1 << 20)), dim3(256), 0, g_stream, (long long)n, T, (long long)x0, (long long)r0,
-                     (long long)s0, (long long)c0, (long long)sx, (long long)sr, (long long)ss, (long long)sc, out);
+                     (long long)s0, (long long)c0, (long long)sx, (long long)sr, (long long)ss, (long long)sc, out, (long long)slab);
   HIP_TRY(hipGetLastError());
   return QEMB_OK;
 }

@@ -18,19 +18,70 @@ static inline int64_t npair(int64_t n) { return n * (n + 1) / 2; }
 
 int Fragment::set_eri_s4_host(const double* s4) {
   const int64_t np = npair(n_);
+  clear_df_factor();
   QTRY(eri_s4_.alloc(np * np));
   return dev_h2d(eri_s4_, s4, sizeof(double) * np * np);
 }
 int Fragment::set_eri_s4_dev(const double* s4_dev) {
   const int64_t np = npair(n_);
+  clear_df_factor();
   QTRY(eri_s4_.alloc(np * np));
   return dev_d2d(eri_s4_, s4_dev, sizeof(double) * np * np);
 }
 int Fragment::adopt_eri_s4(DBuf&& s4) {
   const int64_t np = npair(n_);
   if (s4.n != np * np || !s4.p) { set_error("adopt_eri_s4: block of the wrong size"); return QEMB_ERR_ARG; }
+  clear_df_factor();
   eri_s4_ = std::move(s4);
   return 0;
+}
+// ---- the fragment's 3-index factor B[naux][npair(n)] (eri = B^T B): set AFTER the ERIs it belongs to (new ERIs drop it)
+void Fragment::clear_df_factor() { df_factor_.release(); df_naux_ = 0; }
+int Fragment::set_df_factor_host(int naux, const double* B) {
+  if (naux <= 0 || !B) { set_error("set_df_factor: need naux > 0 and the factor"); return QEMB_ERR_ARG; }
+  QTRY(df_factor_.alloc((int64_t)naux * npair(n_)));
+  df_naux_ = naux;
+  return dev_h2d(df_factor_, B, sizeof(double) * naux * npair(n_));
+}
+int Fragment::set_df_factor_dev(int naux, const double* B_dev) {
+  if (naux <= 0 || !B_dev) { set_error("set_df_factor: need naux > 0 and the factor"); return QEMB_ERR_ARG; }
+  QTRY(df_factor_.alloc((int64_t)naux * npair(n_)));
+  df_naux_ = naux;
+  return dev_d2d(df_factor_, B_dev, sizeof(double) * naux * npair(n_));
+}
+int Fragment::adopt_df_factor(DBuf&& B, int naux) {
+  if (naux <= 0 || !B.p || B.n != (int64_t)naux * npair(n_)) { set_error("adopt_df_factor: factor of the wrong size"); return QEMB_ERR_ARG; }
+  df_factor_ = std::move(B); df_naux_ = naux;
+  return 0;
+}
+int Fragment::set_mo_route(int route) {
+  if (route < -1 || route > 1) { set_error("set_mo_route: -1 (by cost), 0 (four-index transformation) or 1 (3-index factor)"); return QEMB_ERR_ARG; }
+  mo_route_ = route;
+  return 0;
+}
+bool Fragment::use_factor_route() const {
+  static const bool off = std::getenv("QEMB_MO_FROM_FACTOR") && std::atoi(std::getenv("QEMB_MO_FROM_FACTOR")) == 0;      // A/B measurements
+  if (!df_factor_.p || mo_route_ == 0 || off) return false;
+  return mo_route_ == 1 || mo_factor_route_pays(n_, df_naux_);
+}
+// the half-unpacked tensor [P(p,q)][r][s] before the SCF, when something reads it: it is the first operand of the four-index
+// transformation (and the exchange operand beyond n = 1024); the factor route needs neither
+int Fragment::scf_operand(DBuf& X1, bool* unpacked) {
+  *unpacked = false;
+  if (mo_route_ == 1 && !df_factor_.p) { set_error("Fragment: the factor route was requested (set_mo_route 1) and no 3-index factor is set"); return QEMB_ERR_ARG; }
+  if (use_factor_route() && n_ <= 1024) return 0;
+  QTRY(X1.alloc(mo_transform_work(n_)));
+  QTRY(dev_unpack_tril_rows_ld(npair(n_), n_, mo_slab_ld(n_), eri_s4_, X1));      // rows mo_slab_ld(n) apart (ccsd.cpp)
+  *unpacked = true;
+  return 0;
+}
+int Fragment::mo_integrals(int o, int nf, DBuf& X1, bool x1_unpacked, MoIntegrals& ints, bool build_Vl, bool build_T34) {
+  DBuf X0;
+  QTRY(X0.alloc(mo_transform_work(n_)));
+  if (!X1.p) { QTRY(X1.alloc(mo_transform_work(n_))); x1_unpacked = false; }
+  last_route_factor_ = use_factor_route();
+  if (last_route_factor_) return mo_transform_factor(n_, o, nf, df_naux_, df_factor_, X0, X1, C_, ints, build_Vl, build_T34);
+  return mo_transform(n_, o, nf, eri_s4_, X0, X1, C_, ints, build_Vl, build_T34, x1_unpacked);
 }
 void Fragment::set_energy_data(const double* h1, const double* veff0, const double* veff, double weight, const int* centers, int ncen) {
   const size_t n2 = (size_t)n_ * n_;
@@ -112,19 +163,18 @@ int Fragment::cphf_response(int o, const double* h, const double* dm0, const Scf
   if (o <= 0 || o >= n_ || npot <= 0) { set_error("cphf_response: bad arguments"); return QEMB_ERR_ARG; }
   const int n = n_, v = n - o;
   const int64_t n2 = (int64_t)n * n, nov = (int64_t)o * v;
-  DBuf X0, X1;
-  QTRY(X1.alloc(mo_transform_work(n)));
-  QTRY(dev_unpack_tril_rows_ld(npair(n), n, mo_slab_ld(n), eri_s4_, X1));      // [P(p,q)][r][s], rows mo_slab_ld(n) apart (ccsd.cpp)
+  DBuf X1;
+  bool x1_unpacked = false;
+  QTRY(scf_operand(X1, &x1_unpacked));
   ScfResult sres;
   QTRY(run_scf(o, h, dm0, opt, X1, &sres));
   if (!sres.converged) { set_error("cphf_response: fragment SCF did not converge"); return QEMB_ERR_NOCONV; }
   std::vector<double> C((size_t)n2), eps((size_t)n);
   QTRY(dev_d2h(C.data(), C_, sizeof(double) * n2));
   QTRY(dev_d2h(eps.data(), eps_, sizeof(double) * n));
-  QTRY(X0.alloc(mo_transform_work(n)));
   MoIntegrals ints;
-  QTRY(mo_transform(n, o, 0, eri_s4_, X0, X1, C_, ints, false, false, /*x1_is_unpacked=*/true));
-  X0.release(); X1.release();
+  QTRY(mo_integrals(o, 0, X1, x1_unpacked, ints, false, false));
+  X1.release();
   DBuf A, L, Linv, d;
   QTRY(A.alloc(nov * nov)); QTRY(d.alloc(nov));
   QTRY(dcopy(nov * nov, ints.ovov, A));
@@ -174,16 +224,15 @@ int Fragment::prepare_ccsd(int o, const double* h, const double* dm0, const Frag
   if (!eri_s4_.p) { set_error("Fragment: ERIs not set"); return QEMB_ERR_ARG; }
   if (o <= 0 || o >= n_) { set_error("Fragment: need 0 < nsocc < n"); return QEMB_ERR_ARG; }
   cc_.reset();
-  DBuf X0, X1;
-  QTRY(X1.alloc(mo_transform_work(n_)));
-  QTRY(dev_unpack_tril_rows_ld(npair(n_), n_, mo_slab_ld(n_), eri_s4_, X1));
+  DBuf X1;
+  bool x1_unpacked = false;
+  QTRY(scf_operand(X1, &x1_unpacked));
   ScfResult sres;
   QTRY(run_scf(o, h, dm0, opt.scf, X1, &sres));
   if (!sres.converged) { set_error("fragment SCF did not converge (also not with level shift 0.2)"); return QEMB_ERR_NOCONV; }
-  QTRY(X0.alloc(mo_transform_work(n_)));
   MoIntegrals ints;
-  QTRY(mo_transform(n_, o, nf_, eri_s4_, X0, X1, C_, ints, /*build_Vl=*/true, false, /*x1_is_unpacked=*/true));   // measurement hook: dense block available for export
-  X0.release(); X1.release();
+  QTRY(mo_integrals(o, nf_, X1, x1_unpacked, ints, /*build_Vl=*/true, false));   // measurement hook: dense block available for export
+  X1.release();
   cc_.reset(new CcsdSolver());
   QTRY(cc_->setup(std::move(ints), eps_));
   return cc_->init_amps();
@@ -271,6 +320,7 @@ int Fragment::solve_batch(const std::vector<Fragment*>& frs, const std::vector<i
 int Fragment::solve_begin(int o, const double* h, const double* dm0, const FragmentOptions& opt, int eeval, FragmentResult* res) {
   sp_ = SolvePending();
   sp_.o = o; sp_.opt = opt; sp_.eeval = eeval; sp_.res = res;
+  last_route_factor_ = false;
   if (!eri_s4_.p) { set_error("Fragment: ERIs not set"); return QEMB_ERR_ARG; }
   if (o <= 0 || o > n_) { set_error("Fragment: need 0 < nsocc <= n"); return QEMB_ERR_ARG; }
   const int n = n_, v = n - o;
@@ -280,9 +330,9 @@ int Fragment::solve_begin(int o, const double* h, const double* dm0, const Fragm
   const int64_t n2 = (int64_t)n * n;
   cc_.reset();
   // ---- fragment RHF on the half-unpacked tensor [P(p,q)][r][s] (kept: it is the first operand of the MO transformation)
-  DBuf X0, X1;
-  QTRY(X1.alloc(mo_transform_work(n)));
-  QTRY(dev_unpack_tril_rows_ld(npair(n), n, mo_slab_ld(n), eri_s4_, X1));      // [P(p,q)][r][s], rows mo_slab_ld(n) apart (ccsd.cpp)
+  DBuf X1;
+  bool x1_unpacked = false;
+  QTRY(scf_operand(X1, &x1_unpacked));         // [P(p,q)][r][s] for the four-index route (kept: its first operand); nothing on the factor route
   ScfResult sres;
   QTRY(run_scf(o, h, dm0, opt.scf, X1, &sres, opt.warm_start != 0));
   res->scf_converged = sres.converged; res->scf_cycles = sres.cycles; res->e_scf = sres.e_tot;
@@ -302,11 +352,9 @@ int Fragment::solve_begin(int o, const double* h, const double* dm0, const Fragm
     X1.release();
     res->e_corr_mo = 0.0; res->n_iter = 0; res->ccsd_converged = true; res->lambda_iters = 0;
   } else {
-  QTRY(X0.alloc(mo_transform_work(n)));
   MoIntegrals ints;
-  QTRY(mo_transform(n, o, eeval ? nf_ : 0, eri_s4_, X0, X1, C_, ints, /*build_Vl=*/false, /*build_T34=*/opt.relax_density != 0,
-                    /*x1_is_unpacked=*/true));
-  X0.release(); X1.release();
+  QTRY(mo_integrals(o, eeval ? nf_ : 0, X1, x1_unpacked, ints, /*build_Vl=*/false, /*build_T34=*/opt.relax_density != 0));
+  X1.release();
   cc_.reset(new CcsdSolver());
   QTRY(cc_->setup(std::move(ints), eps_));
   if (opt.warm_start && t_prev_.p && t_prev_o_ == o) {

@@ -44,6 +44,16 @@ class Fragment {
   int set_eri_s4_dev(const double* s4_dev);     // device-to-device copy
   int adopt_eri_s4(DBuf&& s4);                  // takes the block a transform just produced (no copy: 4.7 GB at n = 220)
   double* eri_s4() { return eri_s4_.p; }
+  // The fragment's 3-index factor B[naux][npair(n)] with eri_s4 = B^T B (bb of molbe/eri_onthefly.py:141-143), optional.  With it the MO integrals
+  // of a solve come from the factor (mo_transform_factor, ccsd.cpp) while that is the cheaper route; set it AFTER the ERIs (new ERIs drop it).
+  int set_df_factor_host(int naux, const double* B);
+  int set_df_factor_dev(int naux, const double* B_dev);
+  int adopt_df_factor(DBuf&& B, int naux);
+  void clear_df_factor();
+  int df_naux() const { return df_naux_; }
+  int set_mo_route(int route);                  // -1: by cost (default), 0: four-index transformation of eri_s4, 1: the factor (an error without one)
+  bool use_factor_route() const;
+  bool last_route_was_factor() const { return last_route_factor_; }
   // static data for the energies: h1, veff0 (n x n host), centre weight/indices
   void set_energy_data(const double* h1, const double* veff0, const double* veff, double weight, const int* centers, int ncen);
   // The sweep body.  h = fock + heff (n x n host), dm0 (n x n host, may be null -> core guess).
@@ -83,6 +93,9 @@ class Fragment {
 
  private:
   int run_scf(int o, const double* h, const double* dm0, const ScfOptions& opt, double* X0, ScfResult* sres, bool warm = false);
+  int scf_operand(DBuf& X1, bool* unpacked);
+  int mo_integrals(int o, int nf, DBuf& X1, bool x1_unpacked, MoIntegrals& ints, bool build_Vl, bool build_T34);
+  DBuf df_factor_; int df_naux_ = 0; int mo_route_ = -1; bool last_route_factor_ = false;
   bool have_C_ = false; int c_nocc_ = -1;    // C_ holds the orbitals of a converged earlier solve with c_nocc_ occupied orbitals (the Jacobi eigensolver starts in that basis)
   int n_, nf_, o_ = -1;
   DBuf eri_s4_;

@@ -49,6 +49,28 @@ class DeviceFragment:
     def set_eri_s4_dev(self, dev_ptr: int):
         check(self.lib.qemb_frag_set_eri_s4_dev(self.h, dev_ptr), "qemb_frag_set_eri_s4_dev", self.lib)
 
+    def set_df_factor(self, B: np.ndarray):
+        """the fitted 3-index factor B (naux, npair(n)) with eri_s4 = B.T @ B (`bb` of molbe/eri_onthefly.py:141-143): solves then form their MO integrals
+        from it while that is the cheaper route (qemb_frag_mo_route).  Call after set_eri_s4 (new ERIs drop the factor)."""
+        npair = self.n * (self.n + 1) // 2
+        a = np.ascontiguousarray(B, dtype=np.float64)
+        if a.ndim != 2 or a.shape[1] != npair:
+            raise ValueError(f"the 3-index factor must be (naux, {npair}), got {a.shape}")
+        check(self.lib.qemb_frag_set_df_factor(self.h, int(a.shape[0]), a.ctypes.data), "qemb_frag_set_df_factor", self.lib)
+
+    def set_df_factor_dev(self, dev_ptr: int, naux: int):
+        check(self.lib.qemb_frag_set_df_factor_dev(self.h, int(naux), dev_ptr), "qemb_frag_set_df_factor_dev", self.lib)
+
+    def set_mo_route(self, route: int):
+        """-1: the cheaper route (default), 0: four-index transformation of the packed block, 1: the 3-index factor"""
+        check(self.lib.qemb_frag_mo_route(self.h, int(route)), "qemb_frag_mo_route", self.lib)
+
+    def mo_route_used(self):
+        """(the last solve formed its MO integrals from the factor, naux of the factor held -- 0: none)"""
+        used, naux = C.c_int(), C.c_int()
+        check(self.lib.qemb_frag_mo_route_used(self.h, C.byref(used), C.byref(naux)), "qemb_frag_mo_route_used", self.lib)
+        return bool(used.value), int(naux.value)
+
     def get_eri_s4(self) -> np.ndarray:
         npair = self.n * (self.n + 1) // 2
         out = np.empty((npair, npair))

@@ -38,6 +38,18 @@ def synthetic_fragment(n, o, seed, naux=None, scale=None, gap=2.0):
     return h, eri
 
 
+def synthetic_fragment_factor(n, o, seed, naux=None, scale=None, gap=2.0):
+    """the same fragment with its 3-index factor: (h, eri_s1, B packed (naux, npair(n)) with eri = B^T B over unique pairs p >= q)"""
+    h, eri = synthetic_fragment(n, o, seed, naux, scale, gap)
+    rng = np.random.default_rng(seed)
+    naux = naux or 3 * n
+    scale = synthetic_scale(n) if scale is None else scale
+    B = scale * rng.standard_normal((naux, n, n))
+    B = 0.5 * (B + B.transpose(0, 2, 1))
+    il = np.tril_indices(n)
+    return h, eri, np.ascontiguousarray(B[:, il[0], il[1]])
+
+
 def check_periodic_front_end(lib):
     """The periodic front-end against the reference's own outputs (tests/golden/kbe.npz).  TA is compared through the projector
     it spans (the bath vectors of an SVD are defined up to rotations within degenerate singular values and signs)."""

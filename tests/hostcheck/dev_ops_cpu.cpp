@@ -178,9 +178,10 @@ int dev_extract_pf(int64_t n, const double* Mp, int64_t p0, int64_t q0, int64_t 
     out[((p * sq + q) * sr + r) * ss + s] = Mp[(pidx(p0 + p, q0 + q) * n + (r0 + r)) * n + (s0 + s)];
   return 0;
 }
-int dev_extract_pf_t(int64_t n, const double* T, int64_t x0, int64_t r0, int64_t s0, int64_t c0, int64_t sx, int64_t sr, int64_t ss, int64_t sc, double* out) {
+int dev_extract_pf_t(int64_t n, const double* T, int64_t x0, int64_t r0, int64_t s0, int64_t c0, int64_t sx, int64_t sr, int64_t ss, int64_t sc, double* out, int64_t slab) {
+  if (slab <= 0) slab = n * n;
   for (int64_t x = 0; x < sx; ++x) for (int64_t r = 0; r < sr; ++r) for (int64_t s = 0; s < ss; ++s) for (int64_t c = 0; c < sc; ++c)
-    out[((x * sr + r) * ss + s) * sc + c] = T[(pidx(r0 + r, s0 + s) * n + (c0 + c)) * n + (x0 + x)];
+    out[((x * sr + r) * ss + s) * sc + c] = T[pidx(r0 + r, s0 + s) * slab + (c0 + c) * n + (x0 + x)];
   return 0;
 }
 int dev_ladder_pack_vvvv_pf(int64_t n, int64_t o, const double* Mp, double* Vp, int64_t ldp, double* Vm, int64_t ldm) {

@@ -46,6 +46,29 @@ def check_df_golden(lib, tol=1e-10):
                 out = df.transform(TA, want_host=True)
                 assert np.abs(out - ref).max() < tol * max(1.0, np.abs(ref).max()), (name, layout, i, np.abs(out - ref).max())
             df.free()
+        # delivered straight into a fragment the block arrives WITH the fitted factor bb it was formed from (eri_onthefly.py:141-143): bb^T bb is the
+        # block, and a solve through the factor route gives what the four-index route gives
+        from quemb_amd.fragsolver import DeviceFragment, default_opts
+        df = et.DFContext(j2c=src.j2c, lib=lib)
+        df.set_ints(layouts["packed"], N, "packed")
+        n = TAs[0].shape[1]
+        fr = DeviceFragment(n, min(2, n), lib=lib)
+        out = df.transform(TAs[0], frag=fr, want_host=True)
+        df.free()
+        assert np.abs(fr.get_eri_s4() - out).max() == 0.0 and fr.mo_route_used() == (False, src.j2c.shape[0])
+        rng = np.random.default_rng(5)
+        A = rng.standard_normal((n, n))
+        h = (np.diag(2.0 * np.arange(n)) + 0.15 * (A + A.T)) * 8.0 * max(1.0, float(np.abs(out).max()))      # (a gap the synthetic integrals cannot close)
+        fr.set_energy_data(h, 0.1 * (A + A.T), None, 1.0, [0])
+        o = max(1, n // 3)
+        opts = default_opts(lib, cc_conv_tol=1e-12, cc_conv_tol_normt=1e-10)
+        res = {}
+        for route in (0, 1):
+            fr.set_mo_route(route)
+            res[route] = fr.solve(o, h, opts=opts, eeval=True)
+            assert fr.mo_route_used()[0] == bool(route)
+        assert abs(res[0]["e_corr_mo"] - res[1]["e_corr_mo"]) < 1e-10 and np.abs(res[0]["e_frag"] - res[1]["e_frag"]).max() < 1e-10
+        assert np.abs(res[0]["rdm1_emb"] - res[1]["rdm1_emb"]).max() < 1e-9
         # the Cholesky factor handed in instead of (P|Q): the `build_lowtri_PQ` seam (eri_sparse_DF.py:535-556)
         df = et.DFContext(L_PQ=np.linalg.cholesky(src.j2c), lib=lib)
         df.set_ints(layouts["packed"], N, "packed")

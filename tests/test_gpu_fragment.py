@@ -188,9 +188,10 @@ def test_bench_fragment_n220_against_oracle(qlib, frag):
     npair = Bp.shape[1]
     dB, d4 = DeviceBuffer.from_numpy(Bp), DeviceBuffer(npair * npair)
     check(qlib.qemb_op_gemm(npair, npair, Bp.shape[0], 1.0, dB.ptr, npair, 0, 0, dB.ptr, npair, 0, 0, 0.0, d4.ptr, npair, 0, 1))
-    dB.free()
     fr = DeviceFragment(n, 22)
     fr.set_eri_s4_dev(d4.ptr); d4.free()
+    fr.set_df_factor_dev(dB.ptr, Bp.shape[0]); dB.free()
+    fr.set_mo_route(0)                      # first the four quarter transformations of the packed block (what PySCF's ao2mo does) ...
     opts = default_opts(cc_conv_tol=1e-11, cc_conv_tol_normt=1e-9, scf_conv_tol=1e-12, scf_conv_tol_grad=1e-8)
     r = fr.scf(o, h, None, opts=opts)
     assert abs(r["e_scf"] - float(g["e_scf"])) < 1e-8 * max(1.0, abs(float(g["e_scf"])))
@@ -206,7 +207,26 @@ def test_bench_fragment_n220_against_oracle(qlib, frag):
     assert abs(out["n_iter"] - int(g["n_iter"])) <= 1
     assert np.abs(out["rdm1_emb"] - g["rdm1_emb"]).max() < TOL_RDM
     assert abs(np.linalg.norm(out["t1"]) - float(g["t1_norm"])) < 1e-7 and abs(np.linalg.norm(out["t2"]) - float(g["t2_norm"])) < 1e-7
+    assert fr.mo_route_used() == (False, 3 * n)
+    # ... then the route the bench takes (naux = 3 n: by cost): MO integrals from the fragment's 3-index factor, against the same oracle results
+    fr.set_mo_route(-1)
+    fr.prepare_ccsd(o, h, dm0, opts=opts)
+    e3f, _ = fr.ccsd_iterate(3)
+    assert abs(e3f - float(g["e_corr_3_plain_updates"])) < 1e-9, (e3f, float(g["e_corr_3_plain_updates"]))
+    outf = fr.solve(o, h, dm0, opts=opts, eeval=False, want_t2=True)
+    assert fr.mo_route_used() == (True, 3 * n)
+    assert abs(outf["e_corr_mo"] - float(g["e_corr"])) < TOL_E, (outf["e_corr_mo"], float(g["e_corr"]))
+    assert abs(outf["e_corr_mo"] - out["e_corr_mo"]) < 1e-10 and outf["n_iter"] == out["n_iter"]
+    assert np.abs(outf["rdm1_emb"] - g["rdm1_emb"]).max() < TOL_RDM
+    assert np.abs(outf["t2"] - out["t2"]).max() < 1e-10 and np.abs(outf["t1"] - out["t1"]).max() < 1e-10
     fr.free()
+
+
+def test_factor_route_equals_four_index(qlib):
+    """the 3-index factor route of the MO integrals on the HIP library: the checker of the host-logic suite at sizes that reach the tiled kernels
+    (24 ... 96 orbitals; relaxed densities, energies with eeval, CPHF), then the DF transform's hand-over of its factor to the fragment"""
+    from test_hostlogic_fragment import check_factor_route_equals_four_index
+    check_factor_route_equals_four_index(qlib, cases=((8, 3, 3, 20), (24, 7, 6, 0), (45, 12, 10, 100), (33, 33, 5, 0), (96, 20, 22, 0)), tol=5e-10)
 
 
 def test_relaxed_fragment_at_bench_tiles(qlib):

@@ -71,6 +71,70 @@ def test_fragment_solve_matches_oracle(hlib, n, o, nf, cen):
     assert np.abs(J - Jr).max() < 1e-11 and np.abs(K - Kr).max() < 1e-11
 
 
+def check_factor_route_equals_four_index(lib, cases=((8, 3, 3, 20), (11, 4, 4, 0), (9, 2, 3, 31), (7, 7, 2, 12)), tol=2e-10, big=None):
+    """MO integrals from the fragment's 3-index factor (mo_transform_factor: north_star's density-fitted 3-index route) against the four quarter transformations of
+    the packed block: the same energies, densities, amplitudes and relaxed densities; the route follows qemb_frag_mo_route / the cost rule; new ERIs drop the factor."""
+    from helpers import synthetic_fragment_factor
+    from quemb_amd._lib import QembError
+    from quemb_amd.fragsolver import DeviceFragment, default_opts
+    for n, o, nf, naux in cases:
+        h, e1, Bp = synthetic_fragment_factor(n, o, 300 + n, naux=naux or None)
+        rng = np.random.default_rng(n)
+        h1 = rng.standard_normal((n, n)); h1 = h1 + h1.T
+        veff0 = rng.standard_normal((n, n)); veff0 = veff0 + veff0.T
+        s4 = eri.pack_s4(e1)
+        assert np.abs(Bp.T @ Bp - s4).max() < 1e-12
+        fr = DeviceFragment(n, nf, lib=lib)
+        fr.set_eri_s4(s4)
+        fr.set_energy_data(h1, veff0, None, 0.5, [0, 1])
+        assert fr.mo_route_used() == (False, 0)
+        outs = {}
+        for relax in (0, 1):
+            opts = default_opts(lib, cc_conv_tol=1e-13, cc_conv_tol_normt=1e-11, scf_conv_tol=1e-13, scf_conv_tol_grad=1e-9, relax_density=relax, lambda_conv_tol=1e-11)
+            fr.set_eri_s4(s4)                                  # (drops the factor)
+            fr.set_mo_route(-1)
+            outs[relax, "four"] = fr.solve(o, h, opts=opts, eeval=True, want_t2=True)
+            assert fr.mo_route_used() == (False, 0)
+            fr.set_df_factor(Bp)
+            fr.set_mo_route(1)
+            outs[relax, "factor"] = fr.solve(o, h, opts=opts, eeval=True, want_t2=True)
+            assert fr.mo_route_used() == (o < n, Bp.shape[0])          # (no virtual orbitals: no MO integrals at all)
+            a, b = outs[relax, "four"], outs[relax, "factor"]
+            assert a["n_iter"] == b["n_iter"] and a["lambda_iters"] == b["lambda_iters"]
+            for k in ("e_corr_mo", "e_scf", "ebe_hf"):
+                assert abs(a[k] - b[k]) < tol, (n, relax, k, a[k], b[k])
+            for k in ("e_frag", "rdm1_emb", "rdm1_mo", "mo_energy"):
+                assert np.abs(np.asarray(a[k]) - np.asarray(b[k])).max() < tol, (n, relax, k)
+            if o < n:
+                # the same SCF ran before both: identical orbitals, so the amplitudes compare element by element
+                assert np.array_equal(a["mo_coeff"], b["mo_coeff"])
+                assert np.abs(a["t1"] - b["t1"]).max() < tol and np.abs(a["t2"] - b["t2"]).max() < tol
+        # by cost: this family has naux = 3 n (or 20 > 6 n for the first case): the default follows mo_factor_route_pays
+        fr.set_mo_route(-1)
+        fr.solve(o, h, opts=opts, eeval=True)
+        assert fr.mo_route_used() == (Bp.shape[0] <= 6 * n and o < n, Bp.shape[0])
+        fr.set_mo_route(0)
+        fr.solve(o, h, opts=opts, eeval=True)
+        assert fr.mo_route_used() == (False, Bp.shape[0])
+        # CPHF response (HF Jacobian of the QN optimiser) goes through the same integrals
+        if 0 < o < n:
+            v1 = rng.standard_normal((2, n, n)); v1 = v1 + v1.transpose(0, 2, 1)
+            fr.set_mo_route(1); d_fac = fr.cphf(o, h, v1)
+            fr.set_mo_route(0); d_four = fr.cphf(o, h, v1)
+            assert np.abs(d_fac - d_four).max() < 1e-9
+        fr.set_eri_s4(s4)
+        assert fr.mo_route_used()[1] == 0
+        fr.set_mo_route(1)
+        with pytest.raises(QembError):
+            fr.solve(o, h, opts=opts, eeval=True)             # the factor route without a factor is an error, not a silent other route
+        with pytest.raises(ValueError):
+            fr.set_df_factor(Bp[:, :-1])
+
+
+def test_factor_route_equals_four_index(hlib):
+    check_factor_route_equals_four_index(hlib)
+
+
 def check_wide_diis_space_takes_the_general_path(lib):
     """More stored DIIS vectors than the fused end-of-iteration launches take (eight): the pass-by-pass path (lincomb / dot_many / outer4 / reductions, stream waits)
     runs instead and converges to the same amplitudes; the iteration counts differ (another extrapolation space), the fixed point does not."""

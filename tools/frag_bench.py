@@ -27,7 +27,7 @@ def synthetic_on_device(lib, n, seed, naux=None, scale=None, gap=2.0):
     check(lib.qemb_op_gemm(npair, npair, naux, 1.0, dB.ptr, npair, 0, 0, dB.ptr, npair, 0, 0, 0.0, d4.ptr, npair, 0, 1))
     A = rng.standard_normal((n, n))
     h = np.diag(gap * np.arange(n)) + 0.3 * 0.5 * (A + A.T)
-    return h, d4
+    return h, d4, dB, naux
 
 
 def timers(lib):
@@ -44,13 +44,21 @@ if __name__ == "__main__":
     o = int(sys.argv[2]) if len(sys.argv) > 2 else 20
     lib = _lib.init(0)
     t0 = time.time()
-    h, d4 = synthetic_on_device(lib, n, 20260803)
+    h, d4, dB, naux = synthetic_on_device(lib, n, 20260803)
     fr = DeviceFragment(n, min(22, n // 2))
     fr.set_eri_s4_dev(d4.ptr); d4.free()
+    # "four-index" among the arguments: the four quarter transformations of the packed block instead of the 3-index factor route; "eeval": with the energies' 3/4 blocks
+    four, eeval = "four-index" in sys.argv, "eeval" in sys.argv
+    fr.set_df_factor_dev(dB.ptr, naux); dB.free()
+    fr.set_mo_route(0 if four else -1)
+    if eeval:
+        rng = np.random.default_rng(1)
+        V = rng.standard_normal((n, n))
+        fr.set_energy_data(h, 0.05 * (V + V.T), None, 1.0, list(range(4)))
     lib.qemb_sync(); print("setup s", time.time() - t0, flush=True)
     for s in range(8): lib.qemb_timer_reset(s)
     t0 = time.time()
-    out = fr.solve(o, h, opts=default_opts(verbose=int(len(sys.argv) > 3)), eeval=False)
+    out = fr.solve(o, h, opts=default_opts(verbose=int("verbose" in sys.argv)), eeval=eeval)
     lib.qemb_sync(); print("first solve wall s", time.time() - t0, flush=True)
     for s in range(8): lib.qemb_timer_reset(s)
     t0 = time.time()
@@ -58,12 +66,12 @@ if __name__ == "__main__":
     Cprev = out["mo_coeff"]
     dm0 = 2.0 * Cprev[:, :o] @ Cprev[:, :o].T
     h2 = h.copy(); h2[:4, :4] += 1e-3
-    out = fr.solve(o, h2, dm0=dm0, opts=default_opts(verbose=0), eeval=False)
+    out = fr.solve(o, h2, dm0=dm0, opts=default_opts(verbose=0), eeval=eeval)
     lib.qemb_sync(); wall = time.time() - t0
     v = n - o
     tm = timers(lib)
     lad = tm["ladder"]["ms"] / max(tm["ladder"]["count"], 1)
-    res = dict(n=n, o=o, wall_s=wall, n_iter=out["n_iter"], scf_cycles=out["scf_cycles"], e_corr=out["e_corr_mo"], timers=tm,
+    res = dict(n=n, o=o, mo_route="factor" if fr.mo_route_used()[0] else "four-index", eeval=eeval, wall_s=wall, n_iter=out["n_iter"], scf_cycles=out["scf_cycles"], e_corr=out["e_corr_mo"], timers=tm,
                ladder_ms=lad, ladder_tflops=2.0 * o * o * v ** 4 / (lad * 1e-3) / 1e12 if lad else None,
                iter_ms=tm["iter"]["ms"] / max(tm["iter"]["count"], 1))
     print(json.dumps(res), flush=True)

@@ -10,7 +10,7 @@ from frag_bench import synthetic_on_device
 lib = _lib.init(0)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 220
 o = int(sys.argv[2]) if len(sys.argv) > 2 else 20
-h, d4 = synthetic_on_device(lib, n, 20260803, scale=0.03)
+h, d4, _dB, _naux = synthetic_on_device(lib, n, 20260803, scale=0.03); _dB.free()
 fr = DeviceFragment(n, max(1, n // 10), lib=lib)
 fr.set_eri_s4_dev(d4.ptr)
 out = fr.solve(o, h, opts=default_opts(lib, cc_max_cycle=3), eeval=False)

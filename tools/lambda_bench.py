@@ -11,7 +11,7 @@ lib = _lib.init(0)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 220
 o = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 nf = max(1, n // 10)
-h, d4 = synthetic_on_device(lib, n, 20260803)
+h, d4, _dB, _naux = synthetic_on_device(lib, n, 20260803); _dB.free()
 fr = DeviceFragment(n, nf, lib=lib)
 fr.set_eri_s4_dev(d4.ptr)
 rng = np.random.default_rng(1)

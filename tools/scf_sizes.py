@@ -8,7 +8,7 @@ from tools.frag_bench import synthetic_on_device
 from quemb_amd.fragsolver import DeviceFragment, default_opts
 lib = _lib.init(0)
 for n, o in ((220, 20), (260, 26), (300, 30)):
-    h, d4 = synthetic_on_device(lib, n, 20260803)
+    h, d4, _dB, _naux = synthetic_on_device(lib, n, 20260803); _dB.free()
     fr = DeviceFragment(n, 22); fr.set_eri_s4_dev(d4.ptr); d4.free()
     t = time.time(); r = fr.scf(o, h, None, opts=default_opts(verbose=1)); lib.qemb_sync(); t1 = time.time() - t
     C = r["mo_coeff"]; dm0 = 2 * C[:, :o] @ C[:, :o].T

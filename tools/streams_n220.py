@@ -11,7 +11,7 @@ lib = _lib.init(0)
 n, o, F = 220, 20, 8
 frs = []
 for i in range(F):
-    h, d4 = synthetic_on_device(lib, n, 20260803 + i)
+    h, d4, _dB, _naux = synthetic_on_device(lib, n, 20260803 + i); _dB.free()
     fr = DeviceFragment(n, 22, lib=lib); fr.set_eri_s4_dev(d4.ptr); d4.free()
     r = fr.scf(o, h, None)
     frs.append((fr, h, 2.0 * r["mo_coeff"][:, :o] @ r["mo_coeff"][:, :o].T))
