@@ -39,8 +39,9 @@ int mo_transform(int n, int o, int nf, const double* eri_s4, double* X0, double*
 // transformed and multiplied with itself in the MO basis -- 2 naux npair^2 flops instead of 8 n^3 npair (ccsd.cpp)
 int mo_transform_factor(int n, int o, int nf, int naux, const double* B_packed, double* X0, double* X1, const double* C, MoIntegrals& out,
                         bool build_Vl = false, bool build_T34 = false);
-// which route a solve takes when the fragment holds a factor: the factor's, while its product is the cheaper one (measured crossover near naux = 8 n)
-inline bool mo_factor_route_pays(int n, int naux) { return naux > 0 && (int64_t)naux <= 6 * (int64_t)n; }
+// which route a solve takes when the fragment holds a factor: the factor's, while its product is the cheaper one (n = 220: 4.8 ms + 9.6 ms per 660 auxiliary
+// functions against 41 ms for the four quarter transformations -- the times cross near naux = 11 n; 8 n leaves a margin)
+inline bool mo_factor_route_pays(int n, int naux) { return naux > 0 && (int64_t)naux <= 8 * (int64_t)n; }
 
 class CcLambda;
 

@@ -71,7 +71,7 @@ def test_fragment_solve_matches_oracle(hlib, n, o, nf, cen):
     assert np.abs(J - Jr).max() < 1e-11 and np.abs(K - Kr).max() < 1e-11
 
 
-def check_factor_route_equals_four_index(lib, cases=((8, 3, 3, 20), (11, 4, 4, 0), (9, 2, 3, 31), (7, 7, 2, 12)), tol=2e-10, big=None):
+def check_factor_route_equals_four_index(lib, cases=((8, 3, 3, 20), (11, 4, 4, 0), (9, 2, 3, 31), (7, 7, 2, 12), (6, 2, 2, 60)), tol=2e-10):
     """MO integrals from the fragment's 3-index factor (mo_transform_factor: north_star's density-fitted 3-index route) against the four quarter transformations of
     the packed block: the same energies, densities, amplitudes and relaxed densities; the route follows qemb_frag_mo_route / the cost rule; new ERIs drop the factor."""
     from helpers import synthetic_fragment_factor
@@ -109,10 +109,10 @@ def check_factor_route_equals_four_index(lib, cases=((8, 3, 3, 20), (11, 4, 4, 0
                 # the same SCF ran before both: identical orbitals, so the amplitudes compare element by element
                 assert np.array_equal(a["mo_coeff"], b["mo_coeff"])
                 assert np.abs(a["t1"] - b["t1"]).max() < tol and np.abs(a["t2"] - b["t2"]).max() < tol
-        # by cost: this family has naux = 3 n (or 20 > 6 n for the first case): the default follows mo_factor_route_pays
+        # by cost: the default follows mo_factor_route_pays (naux <= 8 n: every case but the last)
         fr.set_mo_route(-1)
         fr.solve(o, h, opts=opts, eeval=True)
-        assert fr.mo_route_used() == (Bp.shape[0] <= 6 * n and o < n, Bp.shape[0])
+        assert fr.mo_route_used() == (Bp.shape[0] <= 8 * n and o < n, Bp.shape[0])
         fr.set_mo_route(0)
         fr.solve(o, h, opts=opts, eeval=True)
         assert fr.mo_route_used() == (False, Bp.shape[0])
