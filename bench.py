@@ -627,6 +627,20 @@ def octane_sweeps(lib, reps=24, cpu=True):
                                            fragments=len(b3.Fobjs), n_emb=[int(f.nao) for f in b3.Fobjs], sweeps=int(b3.stats.get("fragments", 0)) // max(len(b3.Fobjs), 1))
     except Exception as e:  # noqa: BLE001
         out["be3_density_matching"] = dict(seconds=None, note=f"failed: {e}")
+    try:        # BE3 one-shot sweeps (four fragments of 54-57 orbitals) at the product's thresholds and at the reference's
+        from quemb_amd.fragsolver import default_opts
+        b3s = {}
+        for label, so in (("product_thresholds", None), ("reference_thresholds", default_opts(lib, cc_conv_tol=1e-7, cc_conv_tol_normt=1e-5))):
+            bb3 = BE(mf, FragPart.from_json(G / "fragmentation.json", "test_autogen_octane_be3"), distribute=False, lib=lib, solver_opts=so)
+            bb3.oneshot(); bb3.oneshot(); bb3.oneshot()
+            bb3.stats.clear()
+            ts, (e3, _) = timed_sweeps(lib, bb3.oneshot, 10)
+            st = _stats_ms(ts)
+            st.update(e_corr=float(e3), ccsd_iterations_per_sweep=int(bb3.stats.get("ccsd_iterations", 0)) // max(len(ts), 1), nstreams=int(bb3.nstreams), lockstep=bool(bb3.lockstep))
+            b3s[label] = st
+        out["be3_sweeps"] = b3s
+    except Exception as e:  # noqa: BLE001
+        out["be3_sweeps"] = dict(note=f"failed: {e}")
     if cpu:
         try:
             out["cpu_baseline"] = octane_cpu_baseline(be, energies[0])
