@@ -127,13 +127,23 @@ def test_h8_df_transform_path(qlib):
     be_df = BE(mf, fobj, int_transform="int-direct-DF-hip", df_ints=(pqL, j2c, "pqL"), distribute=False)
     be_in = BE(mf, fobj, distribute=False)
     e_in = be_in.oneshot()[0]
-    assert abs(be_df.oneshot()[0] - e_in) < 1e-6
+    e_df = be_df.oneshot()[0]
+    assert abs(e_df - e_in) < 1e-6
+    # the DF transform left its fitted factor with every fragment, and the sweep formed the MO integrals from it (36 auxiliary functions <= 8 n);
+    # the four-index transformation of the same fragments gives the same energy to rounding, the in-core fragments have no factor
+    assert all(f.dev.mo_route_used() == (True, j2c.shape[0]) for f in be_df.Fobjs)
+    assert all(f.dev.mo_route_used() == (False, 0) for f in be_in.Fobjs)
+    for f in be_df.Fobjs:
+        f.dev.set_mo_route(0)
+    assert abs(be_df.oneshot()[0] - e_df) < 1e-10
+    assert all(f.dev.mo_route_used() == (False, j2c.shape[0]) for f in be_df.Fobjs)
     # the same integrals handed over as the reference's semi-sparse tensor (every AO pair stored, no MO screening: eps = 0)
     from quemb_amd import eri_transform as et
     t = et.SemiSparseSym3DTensor.from_dense(np.ascontiguousarray(pqL.transpose(2, 0, 1)), [list(range(N))] * N)
     be_sp = BE(mf, fobj, int_transform="sparse-DF-hip", distribute=False,
                df_ints=dict(int_P_mu_nu=t, j2c=j2c, S_abs=np.abs(mf.get_ovlp()), MO_coeff_epsilon=0.0))
     assert abs(be_sp.oneshot()[0] - e_in) < 1e-6
+    assert all(f.dev.mo_route_used() == (True, j2c.shape[0]) for f in be_sp.Fobjs)      # the semi-sparse transform hands its factor over as well
 
 
 def _semisparse_case(seed=9):
