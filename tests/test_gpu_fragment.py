@@ -219,6 +219,15 @@ def test_bench_fragment_n220_against_oracle(qlib, frag):
     assert abs(outf["e_corr_mo"] - out["e_corr_mo"]) < 1e-10 and outf["n_iter"] == out["n_iter"]
     assert np.abs(outf["rdm1_emb"] - g["rdm1_emb"]).max() < TOL_RDM
     assert np.abs(outf["t2"] - out["t2"]).max() < 1e-10 and np.abs(outf["t1"] - out["t1"]).max() < 1e-10
+    if frag == 0:
+        # the fragment energies of the timed sweep (eeval: the 3/4-transformed integrals come from ONE more product on the factor route) by both routes
+        rng = np.random.default_rng(7)
+        V = rng.standard_normal((n, n))
+        fr.set_energy_data(h, 0.05 * (V + V.T), None, 1.0, list(range(4, 8)))
+        ef = fr.solve(o, h, dm0, opts=opts, eeval=True)
+        fr.set_mo_route(0)
+        e4 = fr.solve(o, h, dm0, opts=opts, eeval=True)
+        assert np.abs(ef["e_frag"] - e4["e_frag"]).max() < 1e-9 and abs(ef["ebe_hf"] - e4["ebe_hf"]) < 1e-9, (ef["e_frag"], e4["e_frag"])
     fr.free()
 
 
