@@ -362,9 +362,13 @@ def check_solve_batch_equals_one_by_one(lib, sizes=((8, 3, 3), (10, 4, 4), (7, 2
         h, e1, h1, veff0, veff = _problem(n, o, nf, 900 + k)
         fr = DeviceFragment(n, nf, lib=lib)
         fr.set_eri_s4(eri.pack_s4(e1))
+        if k % 2:       # a mixed batch: every second fragment holds its 3-index factor and forms its MO integrals from it (both ways of solving it do)
+            from helpers import synthetic_fragment_factor
+            fr.set_df_factor(synthetic_fragment_factor(n, o, 900 + k)[2])
         fr.set_energy_data(h1, veff0, veff, 1.0, list(range(nf)))
         frs.append(fr); hs.append(h)
         outs_ref.append(fr.solve(o, h, None, opts=opts, eeval=True, want_t2=True))
+        assert fr.mo_route_used()[0] == bool(k % 2 and o < n)
     stats = {}
     outs = solve_batch(frs, [s[1] for s in sizes], hs, None, opts=opts, eeval=True, want_t2=True, stats=stats)
     assert len({o["n_iter"] for o in outs_ref}) > 1          # the fragments do not all converge together
