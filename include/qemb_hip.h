@@ -101,7 +101,8 @@ int qemb_frag_get_eri_s4(qemb_frag_t f, double* eri_s4_host);
  * its MO-basis integrals from the factor -- transformed with the fragment's orbitals and multiplied with itself,
  * 2 naux npair(n)^2 flops -- instead of the four quarter transformations of the packed block (PySCF's ao2mo inside
  * cc.CCSD(...).ao2mo(), molbe/solver.py:900), while that is the cheaper route (naux <= 8 n); the results agree to
- * rounding.  Set it AFTER the ERIs it belongs to: new ERIs drop it.  qemb_df_transform(..., frag) hands it over itself.
+ * rounding.  Set it AFTER the ERIs it belongs to: new ERIs drop it, and a factor whose product differs from the resident block (leading
+ * 16 x 16 corner of B^T B, 1e-9 relative) is refused with QEMB_ERR_ARG.  qemb_df_transform(..., frag) hands it over itself.
  * qemb_frag_mo_route: -1 choose by cost (default), 0 always the four-index transformation, 1 always the factor.        */
 int qemb_frag_set_df_factor(qemb_frag_t f, int naux, const double* B_host);
 int qemb_frag_set_df_factor_dev(qemb_frag_t f, int naux, const double* B_dev);

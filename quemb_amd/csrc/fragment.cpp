@@ -37,17 +37,41 @@ int Fragment::adopt_eri_s4(DBuf&& s4) {
 }
 // ---- the fragment's 3-index factor B[naux][npair(n)] (eri = B^T B): set AFTER the ERIs it belongs to (new ERIs drop it)
 void Fragment::clear_df_factor() { df_factor_.release(); df_naux_ = 0; }
+// A factor that does not belong to the resident ERIs would give a fragment RHF (which reads the block) and amplitude equations (which would read the
+// factor) of two different Hamiltonians, silently: the leading corner of B^T B is compared with the block's when the factor is set.
+int Fragment::check_df_factor() {
+  if (!eri_s4_.p) return 0;
+  const int64_t np = npair(n_), m = std::min<int64_t>(np, 16);
+  DBuf S;
+  QTRY(S.alloc(m * m));
+  QTRY(gemm(m, m, df_naux_, 1.0, df_factor_, np, false, df_factor_, np, false, 0.0, S, m));
+  std::vector<double> got((size_t)(m * m)), want((size_t)m);
+  QTRY(dev_d2h(got.data(), S, sizeof(double) * m * m));
+  double worst = 0.0, scale = 1.0;
+  for (int64_t r = 0; r < m; ++r) {
+    QTRY(dev_d2h(want.data(), eri_s4_.p + r * np, sizeof(double) * m));
+    for (int64_t c = 0; c < m; ++c) { worst = std::max(worst, std::fabs(got[(size_t)(r * m + c)] - want[(size_t)c])); scale = std::max(scale, std::fabs(want[(size_t)c])); }
+  }
+  if (!(worst <= 1e-9 * scale)) {
+    clear_df_factor();
+    set_error("set_df_factor: B^T B differs from the fragment's ERI block by " + std::to_string(worst) + " in its leading corner: not the factor of these ERIs");
+    return QEMB_ERR_ARG;
+  }
+  return 0;
+}
 int Fragment::set_df_factor_host(int naux, const double* B) {
   if (naux <= 0 || !B) { set_error("set_df_factor: need naux > 0 and the factor"); return QEMB_ERR_ARG; }
   QTRY(df_factor_.alloc((int64_t)naux * npair(n_)));
   df_naux_ = naux;
-  return dev_h2d(df_factor_, B, sizeof(double) * naux * npair(n_));
+  QTRY(dev_h2d(df_factor_, B, sizeof(double) * naux * npair(n_)));
+  return check_df_factor();
 }
 int Fragment::set_df_factor_dev(int naux, const double* B_dev) {
   if (naux <= 0 || !B_dev) { set_error("set_df_factor: need naux > 0 and the factor"); return QEMB_ERR_ARG; }
   QTRY(df_factor_.alloc((int64_t)naux * npair(n_)));
   df_naux_ = naux;
-  return dev_d2d(df_factor_, B_dev, sizeof(double) * naux * npair(n_));
+  QTRY(dev_d2d(df_factor_, B_dev, sizeof(double) * naux * npair(n_)));
+  return check_df_factor();
 }
 int Fragment::adopt_df_factor(DBuf&& B, int naux) {
   if (naux <= 0 || !B.p || B.n != (int64_t)naux * npair(n_)) { set_error("adopt_df_factor: factor of the wrong size"); return QEMB_ERR_ARG; }

@@ -94,6 +94,7 @@ class Fragment {
  private:
   int run_scf(int o, const double* h, const double* dm0, const ScfOptions& opt, double* X0, ScfResult* sres, bool warm = false);
   int scf_operand(DBuf& X1, bool* unpacked);
+  int check_df_factor();
   int mo_integrals(int o, int nf, DBuf& X1, bool x1_unpacked, MoIntegrals& ints, bool build_Vl, bool build_T34);
   DBuf df_factor_; int df_naux_ = 0; int mo_route_ = -1; bool last_route_factor_ = false;
   bool have_C_ = false; int c_nocc_ = -1;    // C_ holds the orbitals of a converged earlier solve with c_nocc_ occupied orbitals (the Jacobi eigensolver starts in that basis)

@@ -129,6 +129,9 @@ def check_factor_route_equals_four_index(lib, cases=((8, 3, 3, 20), (11, 4, 4, 0
             fr.solve(o, h, opts=opts, eeval=True)             # the factor route without a factor is an error, not a silent other route
         with pytest.raises(ValueError):
             fr.set_df_factor(Bp[:, :-1])
+        with pytest.raises(QembError, match="not the factor of these ERIs"):
+            fr.set_df_factor(1.01 * Bp)                         # a factor of other integrals is refused, and none is kept
+        assert fr.mo_route_used()[1] == 0
 
 
 def test_factor_route_equals_four_index(hlib):
