@@ -38,8 +38,15 @@ if not _os.environ.get("QEMB_KEEP_BLAS_THREADS"):
         _lw = max(1, int(_os.environ.get("LOCAL_WORLD_SIZE", "1") or 1))      # the ranks of one node share its CPU quota
     except ValueError:
         _lw = 1
+    _cap, _auto = max(1, _n // (2 * _lw)), []
     for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
-        _os.environ.setdefault(_v, str(max(1, _n // (2 * _lw))))
+        try:
+            _have = int(_os.environ.get(_v, "0") or 0)
+        except ValueError:
+            _have = 0
+        if _have <= 0 or _have > _cap:            # unset, or larger than this process's share (a value inherited from a process with a larger share): lower it
+            _os.environ[_v] = str(_cap); _auto.append(_v)
+    _os.environ["QEMB_BENCH_AUTO_THREAD_VARS"] = ",".join(_auto)      # launch_ranks drops these from the ranks' environment: each rank derives its own share
 import argparse
 import ctypes as C
 import json
@@ -119,6 +126,10 @@ def launch_ranks(args):
     rdv_dir = tempfile.mkdtemp(prefix="qemb_rdv_")
     base = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                 QEMB_RDV_FILE=os.path.join(rdv_dir, "comm_id"), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    # thread-count variables THIS process derived for itself (whole-node share) must not reach the ranks, which share the node N ways: each rank derives its own
+    # from LOCAL_WORLD_SIZE at import (the header of this file, and quemb_amd/hostthreads.py)
+    for var in filter(None, base.pop("QEMB_BENCH_AUTO_THREAD_VARS", "").split(",")):
+        base.pop(var, None)
     cmd = [sys.executable, str(Path(__file__).resolve())] + sys.argv[1:]
     procs = []
     try:

@@ -101,12 +101,21 @@ int qemb_frag_get_eri_s4(qemb_frag_t f, double* eri_s4_host);
  * its MO-basis integrals from the factor -- transformed with the fragment's orbitals and multiplied with itself,
  * 2 naux npair(n)^2 flops -- instead of the four quarter transformations of the packed block (PySCF's ao2mo inside
  * cc.CCSD(...).ao2mo(), molbe/solver.py:900), while that is the cheaper route (naux <= 8 n); the results agree to
- * rounding.  Set it AFTER the ERIs it belongs to: new ERIs drop it, and a factor whose product differs from the resident block (leading
- * 16 x 16 corner of B^T B, 1e-9 relative) is refused with QEMB_ERR_ARG.  qemb_df_transform(..., frag) hands it over itself.
+ * rounding.  Set it AFTER the ERIs it belongs to: new ERIs drop it, and a factor whose product differs from the resident block (random probe of the
+ * WHOLE block: B^T (B x) against eri_s4 x for two vectors x, 1e-9 relative) is refused with QEMB_ERR_ARG and no factor is kept.  qemb_df_transform(..., frag) hands it over itself.
  * qemb_frag_mo_route: -1 choose by cost (default), 0 always the four-index transformation, 1 always the factor.        */
 int qemb_frag_set_df_factor(qemb_frag_t f, int naux, const double* B_host);
 int qemb_frag_set_df_factor_dev(qemb_frag_t f, int naux, const double* B_dev);
 int qemb_frag_mo_route(qemb_frag_t f, int route);
+/* A fragment that LIVES on its 3-index factor (round 5): qemb_frag_set_df_only[_dev] sets B (naux x npair(n), eri = B^T B) and drops any resident
+ * 4-fold packed block -- 8 naux npair bytes resident instead of 8 npair^2 (128 MB instead of 4.7 GB at n = 220, naux = 660).  J / K of the fragment RHF
+ * (helper.py:28-69 get_veff: J = B^T (B Dp), K = sum_L (B_L Co)(B_L Co)^T), the MO integrals, energies, relaxed densities and the CPHF response come
+ * from the factor; qemb_frag_jk and qemb_frag_get_eri_s4 keep working (the block is formed for that call: B^T B).  qemb_frag_mo_route(f, 0) still forces
+ * the four-index transformation (the block is then a transient of each solve).  Any qemb_frag_set_eri_s4 ends the mode.
+ * qemb_frag_resident_bytes: device bytes the fragment keeps between solves (ERIs and / or factor, orbitals, densities, kept amplitudes).            */
+int qemb_frag_set_df_only(qemb_frag_t f, int naux, const double* B_host);
+int qemb_frag_set_df_only_dev(qemb_frag_t f, int naux, const double* B_dev);
+int qemb_frag_resident_bytes(qemb_frag_t f, int64_t* bytes);
 int qemb_frag_mo_route_used(qemb_frag_t f, int* used_factor, int* naux);   /* what the last solve did; naux of the factor held (0: none) */
 /* h1 = TA^T hcore TA, veff0 = TA^T V_hf TA, veff (may be NULL), centre weight and indices
  * (Frags.weight_and_relAO_per_center, pfrag.py:100)                                                  */
@@ -202,6 +211,10 @@ int qemb_df_transform(qemb_df_t df, const double* TA, int n, double* out_s4_host
  * unstored (screened) AO pairs of the SemiSparseSym3DTensor are passed as zeros of the packed layout 2.              */
 int qemb_df_transform_screened(qemb_df_t df, const double* TA, int n, const double* S_abs, double MO_coeff_epsilon,
                                double* out_s4_host, qemb_frag_t frag);
+/* The same two transforms handing the FITTED FACTOR ALONE to the fragment (bb of eri_onthefly.py:141; the bb^T bb product of :143 is not formed): the
+ * fragment then lives on it (qemb_frag_set_df_only semantics) -- the a4 transform without its 2 naux npair^2 flops and without the 8 npair^2 bytes.   */
+int qemb_df_transform_factor(qemb_df_t df, const double* TA, int n, qemb_frag_t frag);
+int qemb_df_transform_screened_factor(qemb_df_t df, const double* TA, int n, const double* S_abs, double MO_coeff_epsilon, qemb_frag_t frag);
 
 /* Gamma-point periodic (CC-GDF) variant of the direct DF transform, kbe/eri_onthefly.py:48-241.
  * qemb_df_create_pbc: _j2c_cholesky_or_eig (:19-45) -- the periodic metric may be indefinite: Cholesky when it succeeds (*ischol = 1),

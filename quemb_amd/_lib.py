@@ -122,6 +122,7 @@ def _declare(lib):
     f("qemb_ctx_bind", I, I)
     f("qemb_ctx_partition", I, I)
     f("qemb_ctx_timer_read", I, I, I, C.POINTER(C.c_double), C.POINTER(c_i64), I)
+    f("qemb_gemm_flop_count", I, C.POINTER(C.c_double), I)
     f("qemb_alloc_stats", I, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_double), C.POINTER(C.c_double), I)
     f("qemb_op_unpack_tril_pair_rows", I, L, L, P, P)
     f("qemb_op_extract_pf", I, L, P, L, L, L, L, L, L, L, L, P)
@@ -149,6 +150,9 @@ def _declare(lib):
     f("qemb_frag_set_df_factor", I, V, I, P)
     f("qemb_frag_set_df_factor_dev", I, V, I, P)
     f("qemb_frag_mo_route", I, V, I)
+    f("qemb_frag_set_df_only", I, V, I, P)
+    f("qemb_frag_set_df_only_dev", I, V, I, V)
+    f("qemb_frag_resident_bytes", I, V, C.POINTER(L))
     f("qemb_frag_mo_route_used", I, V, IP, IP)
     f("qemb_frag_get_eri_s4", I, V, P)
     f("qemb_frag_set_energy_data", I, V, P, P, P, D, IP, I)
@@ -181,6 +185,8 @@ def _declare(lib):
     f("qemb_df_set_ints_semisparse", I, V, I, L, P, P, P, P)
     f("qemb_df_transform", I, V, P, I, P, V)
     f("qemb_df_transform_screened", I, V, P, I, P, D, P, V)
+    f("qemb_df_transform_factor", I, V, P, I, V)
+    f("qemb_df_transform_screened_factor", I, V, P, I, P, D, V)
     f("qemb_schmidt", I, P, I, I, I, LP, I, D, P, I, IP, IP)
     f("qemb_schmidt_subspace", I, P, I, I, I, LP, I, D, P, I, IP, IP)
     f("qemb_schmidt_svd", I, P, I, LP, I, D, P, I, IP, IP)

@@ -238,6 +238,7 @@ int DfContext::finish_from_pair_rows(int n, const double* bpT, double* out_s4, D
     QTRY(keep_bb->alloc(naux * np));
     QTRY(perm4(*keep_bb, bbT, 1, 1, np, naux, 0, 1, 3, 2));
   }
+  if (!out_s4) return 0;                                   // the factor alone (a fragment that lives on it)
   const int64_t nblk = np >= 2048 ? 8 : 1;
   const int64_t w = ((np + nblk - 1) / nblk + 127) / 128 * 128;
   for (int64_t c0 = 0; c0 < np; c0 += w) {
@@ -369,7 +370,7 @@ int DfContext::transform(const double* TA, int n, double* out_s4, const double* 
   // bb = L^-1 bp                                          (eri_onthefly.py:141 / cublasDtrsm :667)
   QTRY(gemm(naux, np, naux, 1.0, Linv, naux, true, bp, np, false, 0.0, bb, np));
   // (ij|kl) = sum_L bb[L,ij] bb[L,kl] over packed pairs   (eri_onthefly.py:143 / cublasDsyrk :684, beta = 0)
-  QTRY(df_pair_product(np, naux, bb, out_s4));
+  if (out_s4) QTRY(df_pair_product(np, naux, bb, out_s4));      // (null: the caller wants the factor alone -- a fragment that lives on it)
   if (keep_bb) *keep_bb = std::move(bb);                  // B_{ij}^{L} itself: the fragment's 3-index factor (MO integrals straight from it, ccsd.cpp)
   QTRY(lap_DF.close());
   return 0;

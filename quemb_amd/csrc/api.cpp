@@ -115,6 +115,7 @@ int qemb_comm_destroy(void) { return dev_comm_destroy(); }
 int qemb_ctx_count(int n) { return dev_ctx_count(n); }
 int qemb_ctx_bind(int k) { return dev_ctx_bind(k); }
 int qemb_ctx_partition(int parts) { return dev_ctx_partition(parts); }
+int qemb_gemm_flop_count(double* flops, int reset) { return dev_gemm_flop_count(flops, reset); }
 int qemb_alloc_stats(long long* n, long long* nfree, double* ms, double* gb, int reset) { return dev_alloc_stats(n, nfree, ms, gb, reset); }
 int qemb_ctx_timer_read(int ctx, int slot, double* total_ms, int64_t* count, int reset) { return dev_ctx_timer_read(ctx, slot, total_ms, count, reset); }
 int qemb_op_k_from_pairs(int64_t n, const double* H, const double* D, double* K) { return dev_k_from_pairs(n, H, D, K); }
@@ -255,6 +256,9 @@ int qemb_frag_set_eri_s4(qemb_frag_t f, const double* s4) { CHECK_FRAG(f); retur
 int qemb_frag_set_eri_s4_dev(qemb_frag_t f, const double* s4) { CHECK_FRAG(f); return FRAG(f)->set_eri_s4_dev(s4); }
 int qemb_frag_set_df_factor(qemb_frag_t f, int naux, const double* B) { CHECK_FRAG(f); return FRAG(f)->set_df_factor_host(naux, B); }
 int qemb_frag_set_df_factor_dev(qemb_frag_t f, int naux, const double* B) { CHECK_FRAG(f); return FRAG(f)->set_df_factor_dev(naux, B); }
+int qemb_frag_set_df_only(qemb_frag_t f, int naux, const double* B) { CHECK_FRAG(f); return FRAG(f)->set_df_only_host(naux, B); }
+int qemb_frag_set_df_only_dev(qemb_frag_t f, int naux, const double* B) { CHECK_FRAG(f); return FRAG(f)->set_df_only_dev(naux, B); }
+int qemb_frag_resident_bytes(qemb_frag_t f, int64_t* bytes) { CHECK_FRAG(f); if (!bytes) { set_error("qemb_frag_resident_bytes: null argument"); return QEMB_ERR_ARG; } *bytes = FRAG(f)->resident_bytes(); return QEMB_OK; }
 int qemb_frag_mo_route(qemb_frag_t f, int route) { CHECK_FRAG(f); return FRAG(f)->set_mo_route(route); }
 int qemb_frag_mo_route_used(qemb_frag_t f, int* used_factor, int* naux) {
   CHECK_FRAG(f);
@@ -264,9 +268,8 @@ int qemb_frag_mo_route_used(qemb_frag_t f, int* used_factor, int* naux) {
 }
 int qemb_frag_get_eri_s4(qemb_frag_t f, double* s4) {
   CHECK_FRAG(f);
-  const int64_t n = FRAG(f)->n(), np = n * (n + 1) / 2;
-  if (!FRAG(f)->eri_s4()) { set_error("fragment has no ERIs"); return QEMB_ERR_ARG; }
-  return dev_d2h(s4, FRAG(f)->eri_s4(), sizeof(double) * np * np);
+  if (!s4) { set_error("qemb_frag_get_eri_s4: null buffer"); return QEMB_ERR_ARG; }
+  return FRAG(f)->export_eri_s4(s4);      // the resident block, or B^T B of a fragment that lives on its factor (formed for this call)
 }
 int qemb_frag_set_energy_data(qemb_frag_t f, const double* h1, const double* veff0, const double* veff, double weight,
                               const int* centers, int ncenter) {
@@ -472,6 +475,27 @@ int qemb_df_transform_screened(qemb_df_t df, const double* TA, int n, const doub
   DBuf bb;
   if ((rc = d->transform(dTA, n, s4, dS, MO_coeff_epsilon, frag ? &bb : nullptr))) return rc;
   return deliver_s4(s4, n, out_s4_host, frag, &bb, d->naux);
+}
+// the fitted factor alone (no bb^T bb product): the fragment then lives on it (Fragment::adopt_df_only)
+static int df_transform_factor(qemb_df_t df, const double* TA, int n, const double* S_abs, double eps, qemb_frag_t frag) {
+  if (!df || !TA || !frag) { set_error("qemb_df_transform_factor: null argument"); return QEMB_ERR_ARG; }
+  DfContext* d = reinterpret_cast<DfContext*>(df);
+  if (FRAG(frag)->n() != n) { set_error("fragment handle has a different n"); return QEMB_ERR_ARG; }
+  DBuf dTA, dS, bb;
+  int rc;
+  if ((rc = dTA.alloc((int64_t)d->N * n))) return rc;
+  if ((rc = dev_h2d(dTA, TA, sizeof(double) * d->N * n))) return rc;
+  if (S_abs) {
+    if ((rc = dS.alloc((int64_t)d->N * d->N))) return rc;
+    if ((rc = dev_h2d(dS, S_abs, sizeof(double) * d->N * d->N))) return rc;
+  }
+  if ((rc = d->transform(dTA, n, nullptr, S_abs ? dS.p : nullptr, eps, &bb))) return rc;
+  return FRAG(frag)->adopt_df_only(std::move(bb), d->naux);
+}
+int qemb_df_transform_factor(qemb_df_t df, const double* TA, int n, qemb_frag_t frag) { return df_transform_factor(df, TA, n, nullptr, 0.0, frag); }
+int qemb_df_transform_screened_factor(qemb_df_t df, const double* TA, int n, const double* S_abs, double MO_coeff_epsilon, qemb_frag_t frag) {
+  if (!S_abs) { set_error("qemb_df_transform_screened_factor: null argument"); return QEMB_ERR_ARG; }
+  return df_transform_factor(df, TA, n, S_abs, MO_coeff_epsilon, frag);
 }
 int qemb_df_transform(qemb_df_t df, const double* TA, int n, double* out_s4_host, qemb_frag_t frag) {
   if (!df || !TA) { set_error("qemb_df_transform: null argument"); return QEMB_ERR_ARG; }

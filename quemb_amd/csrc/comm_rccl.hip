@@ -11,8 +11,8 @@
 // the collective runs on that context's stream, behind every kernel the rank has queued there.
 //
 // A lost peer is an ERROR, not a hang (round 4): the rendezvous (ncclCommInitRank blocks until every rank has joined) runs in a helper
-// thread that the caller waits for at most QEMB_COMM_TIMEOUT_S seconds (default 120); an all-reduce is enqueued and then waited for with
-// hipStreamQuery in a bounded loop that also polls ncclCommGetAsyncError.  On a timeout or an asynchronous RCCL error the communicator is
+// thread that the caller waits for at most QEMB_COMM_INIT_TIMEOUT_S seconds (default 300); an all-reduce is enqueued and then waited for with
+// hipStreamQuery in a loop that polls ncclCommGetAsyncError (a dead peer) under a wall-clock bound far above any rank-to-rank skew (6 h; QEMB_COMM_TIMEOUT_S).  On a timeout or an asynchronous RCCL error the communicator is
 // aborted (ncclCommAbort, from a detached thread: it may itself block on a wedged kernel), the call returns QEMB_ERR_DEVICE and every later
 // call fails at once -- the rank is expected to exit non-zero, which is what makes its launcher stop the others.
 #include <dlfcn.h>
@@ -85,16 +85,22 @@ int load_rccl() {
       return QEMB_ERR_DEVICE;                                                                                  \
     }                                                                                                          \
   } while (0)
+// Wall-clock bound of ONE all-reduce, timed from when THIS rank enqueues its collective -- so it also counts the time the slowest rank still needs to reach
+// the exchange (an LPT-partitioned sweep of heterogeneous fragments, a cold first sweep).  It is therefore not a peer-death detector: a dead peer shows as an
+// asynchronous RCCL error (polled below) and as a child exit in the launcher, which stops the other ranks.  Default: 6 hours, far above any sweep skew;
+// QEMB_COMM_TIMEOUT_S=<seconds> tightens it (tests), QEMB_COMM_TIMEOUT_S=0 removes it.
+constexpr double COMM_TIMEOUT_DEFAULT_S = 21600.0;
 double comm_timeout_s() {
   const char* e = std::getenv("QEMB_COMM_TIMEOUT_S");
-  const double v = e ? std::atof(e) : 120.0;
-  return v > 0 ? v : 120.0;
+  if (!e) return COMM_TIMEOUT_DEFAULT_S;
+  const double v = std::atof(e);
+  return v > 0 ? v : 0.0;      // 0: no wall-clock bound
 }
 // the rendezvous waits for processes that are still starting (a cold container pages the image in for minutes, and not at the same pace for
 // every rank): its own bound, QEMB_COMM_INIT_TIMEOUT_S; unset, an explicit QEMB_COMM_TIMEOUT_S holds for it too, else 300 s
 double comm_init_timeout_s() {
   if (const char* e = std::getenv("QEMB_COMM_INIT_TIMEOUT_S")) { const double v = std::atof(e); if (v > 0) return v; }
-  if (std::getenv("QEMB_COMM_TIMEOUT_S")) return comm_timeout_s();
+  if (std::getenv("QEMB_COMM_TIMEOUT_S") && comm_timeout_s() > 0) return comm_timeout_s();
   return 300.0;
 }
 
@@ -214,7 +220,7 @@ int dev_comm_allreduce(double* host_buf, int64_t n, int op) {
           return QEMB_ERR_DEVICE;
         }
       }
-      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > lim) {
+      if (lim > 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > lim) {
         abandon_comm();
         set_error("qemb_comm_allreduce: rank " + std::to_string(g_rank) + " of " + std::to_string(g_world) + " waited " + std::to_string((int)lim) +
                   " s for the all-reduce (QEMB_COMM_TIMEOUT_S); a rank is gone -- the communicator was aborted");

@@ -119,6 +119,9 @@ inline int gemm_slab_count(int64_t K, int ksplit) {      // the K slices dev_gem
   return S > 1 ? (int)S : 1;
 }
 int dev_gemm(const GemmDesc& g);
+// measurement hook: 2 M N K batch of every product issued (or recorded into a capture) by ANY host thread since the last reset -- the executed flops the size
+// sweep of bench.py divides by the iteration time (a captured update replayed k times counts once: read it around eager iterations)
+int dev_gemm_flop_count(double* flops, int reset);
 // test / tuning hooks of the calling host thread: force a tile configuration (-1: automatic), switch the automatic split-K off
 void dev_gemm_set_force_cfg(int cfg);
 void dev_gemm_set_auto_splitk(int enabled);

@@ -4,6 +4,7 @@
 // with the fragment ERIs resident in HBM between sweeps (the reference re-reads them from HDF5 every call:
 // helper.py:182-189, :303-304).
 #include "fragment.h"
+#include "ao2mo.h"
 #include <string>
 #include <chrono>
 #include <cstdio>
@@ -18,7 +19,7 @@ static inline int64_t npair(int64_t n) { return n * (n + 1) / 2; }
 
 int Fragment::set_eri_s4_host(const double* s4) {
   const int64_t np = npair(n_);
-  clear_df_factor();
+  clear_df_factor(); s4_transient_.release();
   QTRY(eri_s4_.alloc(np * np));
   return dev_h2d(eri_s4_, s4, sizeof(double) * np * np);
 }
@@ -38,43 +39,96 @@ int Fragment::adopt_eri_s4(DBuf&& s4) {
 // ---- the fragment's 3-index factor B[naux][npair(n)] (eri = B^T B): set AFTER the ERIs it belongs to (new ERIs drop it)
 void Fragment::clear_df_factor() { df_factor_.release(); df_naux_ = 0; }
 // A factor that does not belong to the resident ERIs would give a fragment RHF (which reads the block) and amplitude equations (which would read the
-// factor) of two different Hamiltonians, silently: the leading corner of B^T B is compared with the block's when the factor is set.
+// factor) of two different Hamiltonians, silently.  When the factor is set the WHOLE block is probed: for two fixed pseudo-random vectors x the products
+// B^T (B x) and eri_s4 x must agree (two gemv-sized passes; round 4 compared the leading 16 x 16 corner only, which a factor that is stale, truncated or
+// of a fragment sharing its first pairs passes).  Any failure on the way leaves the fragment WITHOUT a factor.
 int Fragment::check_df_factor() {
   if (!eri_s4_.p) return 0;
-  const int64_t np = npair(n_), m = std::min<int64_t>(np, 16);
-  DBuf S;
-  QTRY(S.alloc(m * m));
-  QTRY(gemm(m, m, df_naux_, 1.0, df_factor_, np, false, df_factor_, np, false, 0.0, S, m));
-  std::vector<double> got((size_t)(m * m)), want((size_t)m);
-  QTRY(dev_d2h(got.data(), S, sizeof(double) * m * m));
+  const int64_t np = npair(n_);
+  constexpr int NV = 2;
+  std::vector<double> x((size_t)(np * NV));
+  uint64_t st = 0x9E3779B97F4A7C15ull ^ (uint64_t)np;
+  for (double& e : x) { st = st * 6364136223846793005ull + 1442695040888963407ull; e = (double)((st >> 11) & ((1ull << 53) - 1)) / (double)(1ull << 52) - 1.0; }
+  DBuf X, Z, Y1, Y2;
+  QTRY(X.alloc(np * NV)); QTRY(Z.alloc((int64_t)df_naux_ * NV)); QTRY(Y1.alloc(np * NV)); QTRY(Y2.alloc(np * NV));
+  QTRY(dev_h2d(X, x.data(), sizeof(double) * np * NV));
+  QTRY(gemm((int64_t)df_naux_, NV, np, 1.0, df_factor_, np, true, X, NV, false, 0.0, Z, NV));        // Z = B X
+  QTRY(gemm(np, NV, (int64_t)df_naux_, 1.0, df_factor_, np, false, Z, NV, false, 0.0, Y1, NV));       // Y1 = B^T Z
+  QTRY(gemm(np, NV, np, 1.0, eri_s4_, np, true, X, NV, false, 0.0, Y2, NV));                          // Y2 = eri_s4 X
+  std::vector<double> y1((size_t)(np * NV)), y2((size_t)(np * NV));
+  QTRY(dev_d2h(y1.data(), Y1, sizeof(double) * np * NV));
+  QTRY(dev_d2h(y2.data(), Y2, sizeof(double) * np * NV));
   double worst = 0.0, scale = 1.0;
-  for (int64_t r = 0; r < m; ++r) {
-    QTRY(dev_d2h(want.data(), eri_s4_.p + r * np, sizeof(double) * m));
-    for (int64_t c = 0; c < m; ++c) { worst = std::max(worst, std::fabs(got[(size_t)(r * m + c)] - want[(size_t)c])); scale = std::max(scale, std::fabs(want[(size_t)c])); }
-  }
+  for (size_t k = 0; k < y1.size(); ++k) { worst = std::max(worst, std::fabs(y1[k] - y2[k])); scale = std::max(scale, std::fabs(y2[k])); }
   if (!(worst <= 1e-9 * scale)) {
-    clear_df_factor();
-    set_error("set_df_factor: B^T B differs from the fragment's ERI block by " + std::to_string(worst) + " in its leading corner: not the factor of these ERIs");
+    set_error("set_df_factor: B^T B x differs from the fragment's ERI block applied to x by " + std::to_string(worst) + " (random probe of the whole block): not the factor of these ERIs");
     return QEMB_ERR_ARG;
   }
   return 0;
 }
 int Fragment::set_df_factor_host(int naux, const double* B) {
   if (naux <= 0 || !B) { set_error("set_df_factor: need naux > 0 and the factor"); return QEMB_ERR_ARG; }
-  QTRY(df_factor_.alloc((int64_t)naux * npair(n_)));
-  df_naux_ = naux;
-  QTRY(dev_h2d(df_factor_, B, sizeof(double) * naux * npair(n_)));
-  return check_df_factor();
+  clear_df_factor();
+  int rc = df_factor_.alloc((int64_t)naux * npair(n_));
+  if (rc == 0) { df_naux_ = naux; rc = dev_h2d(df_factor_, B, sizeof(double) * naux * npair(n_)); }
+  if (rc == 0) rc = check_df_factor();
+  if (rc != 0) clear_df_factor();      // a half-set or refused factor is not kept
+  return rc;
 }
 int Fragment::set_df_factor_dev(int naux, const double* B_dev) {
   if (naux <= 0 || !B_dev) { set_error("set_df_factor: need naux > 0 and the factor"); return QEMB_ERR_ARG; }
-  QTRY(df_factor_.alloc((int64_t)naux * npair(n_)));
-  df_naux_ = naux;
-  QTRY(dev_d2d(df_factor_, B_dev, sizeof(double) * naux * npair(n_)));
-  return check_df_factor();
+  clear_df_factor();
+  int rc = df_factor_.alloc((int64_t)naux * npair(n_));
+  if (rc == 0) { df_naux_ = naux; rc = dev_d2d(df_factor_, B_dev, sizeof(double) * naux * npair(n_)); }
+  if (rc == 0) rc = check_df_factor();
+  if (rc != 0) clear_df_factor();
+  return rc;
+}
+int Fragment::set_df_only_host(int naux, const double* B) {
+  if (naux <= 0 || !B) { set_error("set_df_only: need naux > 0 and the factor"); return QEMB_ERR_ARG; }
+  eri_s4_.release(); s4_transient_.release(); clear_df_factor();
+  int rc = df_factor_.alloc((int64_t)naux * npair(n_));
+  if (rc == 0) { df_naux_ = naux; rc = dev_h2d(df_factor_, B, sizeof(double) * naux * npair(n_)); }
+  if (rc != 0) clear_df_factor();
+  return rc;
+}
+int Fragment::set_df_only_dev(int naux, const double* B_dev) {
+  if (naux <= 0 || !B_dev) { set_error("set_df_only: need naux > 0 and the factor"); return QEMB_ERR_ARG; }
+  eri_s4_.release(); s4_transient_.release(); clear_df_factor();
+  int rc = df_factor_.alloc((int64_t)naux * npair(n_));
+  if (rc == 0) { df_naux_ = naux; rc = dev_d2d(df_factor_, B_dev, sizeof(double) * naux * npair(n_)); }
+  if (rc != 0) clear_df_factor();
+  return rc;
+}
+int Fragment::adopt_df_only(DBuf&& B, int naux) {
+  if (naux <= 0 || !B.p || B.n != (int64_t)naux * npair(n_)) { set_error("adopt_df_only: factor of the wrong size"); return QEMB_ERR_ARG; }
+  eri_s4_.release(); s4_transient_.release();
+  df_factor_ = std::move(B); df_naux_ = naux;
+  return 0;
+}
+int Fragment::materialize_s4(DBuf& out) {
+  if (!df_factor_.p) { set_error("Fragment: no factor to form the ERI block from"); return QEMB_ERR_ARG; }
+  const int64_t np = npair(n_);
+  QTRY(out.alloc(np * np));
+  return df_pair_product(np, df_naux_, df_factor_, out);
+}
+int Fragment::export_eri_s4(double* s4_host) {
+  const int64_t np = npair(n_);
+  if (eri_s4_.p) return dev_d2h(s4_host, eri_s4_, sizeof(double) * np * np);
+  if (!df_factor_.p) { set_error("fragment has no ERIs"); return QEMB_ERR_ARG; }
+  DBuf tmp;
+  QTRY(materialize_s4(tmp));
+  return dev_d2h(s4_host, tmp, sizeof(double) * np * np);
+}
+int64_t Fragment::resident_bytes() const {
+  int64_t words = eri_s4_.n + df_factor_.n + C_.n + eps_.n + dm_.n + J_.n + K_.n + t_prev_.n + z_prev_.n;
+  return 8 * words;
 }
 int Fragment::adopt_df_factor(DBuf&& B, int naux) {
   if (naux <= 0 || !B.p || B.n != (int64_t)naux * npair(n_)) { set_error("adopt_df_factor: factor of the wrong size"); return QEMB_ERR_ARG; }
+  // beside a resident block the factor is only read while its route is the cheaper one (or forced): a large auxiliary set with the route left to the cost
+  // rule would keep 8 naux npair bytes that nothing reads (~1 GB per n = 220 fragment at naux = 5000) -- not kept
+  if (eri_s4_.p && mo_route_ == -1 && !mo_factor_route_pays(n_, naux)) { B.release(); clear_df_factor(); return 0; }
   df_factor_ = std::move(B); df_naux_ = naux;
   return 0;
 }
@@ -86,6 +140,7 @@ int Fragment::set_mo_route(int route) {
 bool Fragment::use_factor_route() const {
   static const bool off = std::getenv("QEMB_MO_FROM_FACTOR") && std::atoi(std::getenv("QEMB_MO_FROM_FACTOR")) == 0;      // A/B measurements
   if (!df_factor_.p || mo_route_ == 0 || off) return false;
+  if (!eri_s4_.p) return true;      // a fragment that lives on its factor: forming the block first would cost what the factor's own product costs
   return mo_route_ == 1 || mo_factor_route_pays(n_, df_naux_);
 }
 // the half-unpacked tensor [P(p,q)][r][s] before the SCF, when something reads it: it is the first operand of the four-index
@@ -93,9 +148,10 @@ bool Fragment::use_factor_route() const {
 int Fragment::scf_operand(DBuf& X1, bool* unpacked) {
   *unpacked = false;
   if (mo_route_ == 1 && !df_factor_.p) { set_error("Fragment: the factor route was requested (set_mo_route 1) and no 3-index factor is set"); return QEMB_ERR_ARG; }
-  if (use_factor_route() && n_ <= 1024) return 0;
+  if (use_factor_route() && (n_ <= 1024 || !eri_s4_.p)) return 0;
+  if (!eri_s4_.p) QTRY(materialize_s4(s4_transient_));      // factor-only fragment with the four-index route forced (A/B runs): the block lives for this solve
   QTRY(X1.alloc(mo_transform_work(n_)));
-  QTRY(dev_unpack_tril_rows_ld(npair(n_), n_, mo_slab_ld(n_), eri_s4_, X1));      // rows mo_slab_ld(n) apart (ccsd.cpp)
+  QTRY(dev_unpack_tril_rows_ld(npair(n_), n_, mo_slab_ld(n_), s4_ptr(), X1));      // rows mo_slab_ld(n) apart (ccsd.cpp)
   *unpacked = true;
   return 0;
 }
@@ -105,7 +161,9 @@ int Fragment::mo_integrals(int o, int nf, DBuf& X1, bool x1_unpacked, MoIntegral
   if (!X1.p) { QTRY(X1.alloc(mo_transform_work(n_))); x1_unpacked = false; }
   last_route_factor_ = use_factor_route();
   if (last_route_factor_) return mo_transform_factor(n_, o, nf, df_naux_, df_factor_, X0, X1, C_, ints, build_Vl, build_T34);
-  return mo_transform(n_, o, nf, eri_s4_, X0, X1, C_, ints, build_Vl, build_T34, x1_unpacked);
+  const int rc = mo_transform(n_, o, nf, s4_ptr(), X0, X1, C_, ints, build_Vl, build_T34, x1_unpacked);
+  s4_transient_.release();
+  return rc;
 }
 void Fragment::set_energy_data(const double* h1, const double* veff0, const double* veff, double weight, const int* centers, int ncen) {
   const size_t n2 = (size_t)n_ * n_;
@@ -137,23 +195,37 @@ int Fragment::run_scf(int o, const double* h, const double* dm0, const ScfOption
     QTRY(dev_jacobi_eigh(n_, tmp, eps_, C_, nullptr));
     QTRY(gemm(n_, n_, o, 2.0, C_, n_, true, C_, n_, true, 0.0, dm_, n_));
   }
-  const int rc = rhf_device(n_, o, hd, X0, dm_, opt, C_, eps_, J_, K_, sres, eri_s4_, c_guess);
+  JkSource src;
+  DBuf Bfull;
+  if (s4_ptr()) { src.eri_s1 = X0; src.eri_s4 = s4_ptr(); }
+  else {        // the fragment lives on its factor: J / K from B (scf.cpp build_jk_factor)
+    QTRY(Bfull.alloc((int64_t)df_naux_ * n2));
+    QTRY(unpack_df_factor(n_, df_naux_, df_factor_, Bfull));
+    src.Bp = df_factor_; src.Bfull = Bfull; src.naux = df_naux_;
+  }
+  const int rc = rhf_device_from(n_, o, hd, src, dm_, opt, C_, eps_, J_, K_, sres, c_guess);
   have_C_ = (rc == 0 && sres->converged);
   c_nocc_ = o;
   return rc;
 }
 
 int Fragment::hf_veff_from_dm(const double* P_host, double* J_host, double* K_host) {
-  if (!eri_s4_.p) { set_error("Fragment: ERIs not set"); return QEMB_ERR_ARG; }
+  if (!has_eris()) { set_error("Fragment: ERIs not set"); return QEMB_ERR_ARG; }
   const int64_t n2 = (int64_t)n_ * n_;
   DBuf X0, P, J, K;
   QTRY(P.alloc(n2)); QTRY(J.alloc(n2)); QTRY(K.alloc(n2));
-  if (n_ > 1024) {      // (up to n = 1024 J and K come from the packed block in one pass: no half-unpacked tensor is needed)
-    QTRY(X0.alloc(mo_transform_work(n_)));
-    QTRY(dev_unpack_tril_rows(npair(n_), n_, eri_s4_, X0));
-  }
   QTRY(dev_h2d(P, P_host, sizeof(double) * n2));
-  QTRY(build_jk(n_, X0, P, J, K, eri_s4_));
+  if (factor_only()) {
+    QTRY(X0.alloc((int64_t)df_naux_ * n2));
+    QTRY(unpack_df_factor(n_, df_naux_, df_factor_, X0));
+    QTRY(build_jk_factor(n_, df_naux_, df_factor_, X0, P, nullptr, 0, J, K));
+  } else {
+    if (n_ > 1024) {      // (up to n = 1024 J and K come from the packed block in one pass: no half-unpacked tensor is needed)
+      QTRY(X0.alloc(mo_transform_work(n_)));
+      QTRY(dev_unpack_tril_rows(npair(n_), n_, eri_s4_, X0));
+    }
+    QTRY(build_jk(n_, X0, P, J, K, eri_s4_));
+  }
   QTRY(dev_d2h(J_host, J, sizeof(double) * n2));
   QTRY(dev_d2h(K_host, K, sizeof(double) * n2));
   return 0;
@@ -161,11 +233,11 @@ int Fragment::hf_veff_from_dm(const double* P_host, double* J_host, double* K_ho
 
 int Fragment::scf_only(int o, const double* h, const double* dm0, const ScfOptions& opt, double* mo_coeff, double* mo_energy,
                        double* J_host, double* K_host, ScfResult* sres) {
-  if (!eri_s4_.p) { set_error("Fragment: ERIs not set"); return QEMB_ERR_ARG; }
+  if (!has_eris()) { set_error("Fragment: ERIs not set"); return QEMB_ERR_ARG; }
   if (o <= 0 || o > n_) { set_error("Fragment: need 0 < nsocc <= n"); return QEMB_ERR_ARG; }
   const int64_t n2 = (int64_t)n_ * n_;
   DBuf X0;
-  if (n_ > 1024) {      // (up to n = 1024 J and K come from the packed block in one pass: no half-unpacked tensor is needed)
+  if (n_ > 1024 && eri_s4_.p) {      // (up to n = 1024 J and K come from the packed block in one pass: no half-unpacked tensor is needed)
     QTRY(X0.alloc(mo_transform_work(n_)));
     QTRY(dev_unpack_tril_rows(npair(n_), n_, eri_s4_, X0));     // half-unpacked [P(p,q)][r][s]
   }
@@ -183,7 +255,7 @@ int Fragment::scf_only(int o, const double* h, const double* dm0, const ScfOptio
 // A is the (positive definite) RHF orbital Hessian, so the solve is Cholesky + triangular inverse + two GEMMs.
 int Fragment::cphf_response(int o, const double* h, const double* dm0, const ScfOptions& opt, const double* vpots, int npot,
                             double* dPs) {
-  if (!eri_s4_.p) { set_error("Fragment: ERIs not set"); return QEMB_ERR_ARG; }
+  if (!has_eris()) { set_error("Fragment: ERIs not set"); return QEMB_ERR_ARG; }
   if (o <= 0 || o >= n_ || npot <= 0) { set_error("cphf_response: bad arguments"); return QEMB_ERR_ARG; }
   const int n = n_, v = n - o;
   const int64_t n2 = (int64_t)n * n, nov = (int64_t)o * v;
@@ -245,7 +317,7 @@ int Fragment::cphf_response(int o, const double* h, const double* dm0, const Scf
 }
 
 int Fragment::prepare_ccsd(int o, const double* h, const double* dm0, const FragmentOptions& opt) {
-  if (!eri_s4_.p) { set_error("Fragment: ERIs not set"); return QEMB_ERR_ARG; }
+  if (!has_eris()) { set_error("Fragment: ERIs not set"); return QEMB_ERR_ARG; }
   if (o <= 0 || o >= n_) { set_error("Fragment: need 0 < nsocc < n"); return QEMB_ERR_ARG; }
   cc_.reset();
   DBuf X1;
@@ -345,7 +417,7 @@ int Fragment::solve_begin(int o, const double* h, const double* dm0, const Fragm
   sp_ = SolvePending();
   sp_.o = o; sp_.opt = opt; sp_.eeval = eeval; sp_.res = res;
   last_route_factor_ = false;
-  if (!eri_s4_.p) { set_error("Fragment: ERIs not set"); return QEMB_ERR_ARG; }
+  if (!has_eris()) { set_error("Fragment: ERIs not set"); return QEMB_ERR_ARG; }
   if (o <= 0 || o > n_) { set_error("Fragment: need 0 < nsocc <= n"); return QEMB_ERR_ARG; }
   const int n = n_, v = n - o;
   // nsocc == n: an embedding space without virtual orbitals.  PySCF's CCSD then has empty amplitude arrays and returns E_corr = 0; the

@@ -50,6 +50,16 @@ class Fragment {
   int set_df_factor_dev(int naux, const double* B_dev);
   int adopt_df_factor(DBuf&& B, int naux);
   void clear_df_factor();
+  // A fragment that LIVES on its factor (round 5): no 4-fold packed block is resident -- 8 naux npair bytes instead of 8 npair^2 (128 MB instead of 4.7 GB at
+  // n = 220, naux = 660).  J / K of the fragment RHF, the MO integrals, the energies and the CPHF response all come from the factor; the block is formed on
+  // demand only (export_eri_s4, or a solve with the four-index route forced: a transient of that solve).  Any set_eri_s4 / adopt_eri_s4 ends the mode.
+  int set_df_only_host(int naux, const double* B);
+  int set_df_only_dev(int naux, const double* B_dev);
+  int adopt_df_only(DBuf&& B, int naux);
+  bool factor_only() const { return !eri_s4_.p && df_factor_.p; }
+  bool has_eris() const { return eri_s4_.p || df_factor_.p; }
+  int export_eri_s4(double* s4_host);               // the resident block, or B^T B formed for this call
+  int64_t resident_bytes() const;                   // device bytes this fragment keeps between solves (ERIs / factor, orbitals, kept amplitudes)
   int df_naux() const { return df_naux_; }
   int set_mo_route(int route);                  // -1: by cost (default), 0: four-index transformation of eri_s4, 1: the factor (an error without one)
   bool use_factor_route() const;
@@ -93,6 +103,9 @@ class Fragment {
 
  private:
   int run_scf(int o, const double* h, const double* dm0, const ScfOptions& opt, double* X0, ScfResult* sres, bool warm = false);
+  int materialize_s4(DBuf& out);                    // B^T B over packed pairs
+  const double* s4_ptr() const { return eri_s4_.p ? eri_s4_.p : s4_transient_.p; }
+  DBuf s4_transient_;                               // factor-only fragment, four-index route forced: the block for the duration of one solve
   int scf_operand(DBuf& X1, bool* unpacked);
   int check_df_factor();
   int mo_integrals(int o, int nf, DBuf& X1, bool x1_unpacked, MoIntegrals& ints, bool build_Vl, bool build_T34);

@@ -48,6 +48,8 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 static thread_local int t_gemm_force_cfg = -1;
 static thread_local int t_gemm_splitk_enabled = 1;
 static thread_local int t_gemm_peers = 1;
+static std::atomic<long long> g_gemm_flops{0};
+int dev_gemm_flop_count(double* flops, int reset) { if (flops) *flops = (double)g_gemm_flops.load(); if (reset) g_gemm_flops = 0; return QEMB_OK; }
 void dev_gemm_set_peers(int n) { t_gemm_peers = n > 1 ? n : 1; }
 int dev_gemm_peers() { return t_gemm_peers; }
 void dev_gemm_set_force_cfg(int cfg) { t_gemm_force_cfg = cfg; }
@@ -861,6 +863,7 @@ static int dev_gemm_dispatch(const GemmDesc& d) {
     set_error("dev_gemm: dimension too large"); return QEMB_ERR_ARG;
   }
   hipStream_t s = hip_stream();
+  g_gemm_flops += 2ll * d.M * d.N * d.K * d.batch;
   const bool vec2 = operand_vec2_ok(d.A, d.lda, d.strideA, d.a_kcontig ? d.K : d.M) &&
                     operand_vec2_ok(d.B, d.ldb, d.strideB, d.b_kcontig ? d.K : d.N);
   // tile choice: biggest tile that still gives the 256 CUs >= ~2 workgroups each; small problems

@@ -183,6 +183,210 @@ __global__ void __launch_bounds__(1024) jacobi_small_kernel(double* Wg, long lon
 }
 
 // ------------------------------------------------------------------------------------------------
+// Symmetric eigenproblem of a SMALL matrix (n <= JE_MAX) in ONE launch (round 5): classical two-sided cyclic Jacobi, A <- J^T A J, with A and V
+// in the LDS of one workgroup.  The one-sided kernel above needs three length-n dot products and two wave-wide reductions per pair before it
+// can rotate, and a wave per pair: 3.4 us per round at n = 42, 0.7-1.2 ms per eigensolve of a fragment Fock matrix -- a quarter of an octane BE2
+// sweep went into it.  Two-sided, the angle of a pair comes from three matrix ELEMENTS (a_pp, a_qq, a_pq; untouched by the other pairs of the
+// round), so a round is: (0) one lane per pair computes (c, s); (1) every thread applies the row rotations, all n^2 elements in parallel; (2) the
+// column rotations of A and V -- three workgroup barriers, no reductions.  Same rotation angle as the Hestenes form (jacobi_cs on the 2 x 2 block),
+// same round-robin order of pairs, a rotation only where |a_pq| > tol x (largest absolute row sum); a sweep whose largest rotated element is below
+// stop_below x that scale is the last (quadratic convergence: what is left is its square).  Eigenvalues are ranked and the eigenvector columns
+// permuted inside the kernel (ascending, ties in index order), so the whole eigensolve is one launch and one status word back: before it was
+// seven launches and four stream waits (Gershgorin shift, identity, sweeps, Rayleigh quotients, host sort, gather).
+constexpr int JE_MAX = 96;
+__global__ void __launch_bounds__(1024) jacobi_eigh_small_kernel(const double* __restrict__ Ag, int n, double* __restrict__ w_out, double* __restrict__ V_out,
+                                                                 double tol, double stop_below, int max_sweeps, int* __restrict__ status) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int ld = n + 1 + (n & 1);                  // odd row stride: column walks are conflict free
+  const int np = n + (n & 1), nh = np >> 1;
+  double* A = lds;
+  double* V = A + (size_t)n * ld;
+  double* pc = V + (size_t)n * ld;                 // per pair of the round: cos, sin
+  double* ps = pc + nh;
+  double* rsum = ps + nh;                          // n row sums (scale), later the eigenvalues
+  int* pp = (int*)(rsum + n);                      // per pair: p, q (q < 0: no rotation)
+  int* pq = pp + nh;
+  int* rank = pq + nh;
+  __shared__ unsigned long long offbits;
+  __shared__ double scale_sh;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  for (int t = tid; t < n * n; t += nt) { const int i = t / n, j = t - i * n; A[i * ld + j] = Ag[t]; V[i * ld + j] = (i == j) ? 1.0 : 0.0; }
+  if (tid == 0) offbits = 0ull;
+  __syncthreads();
+  for (int i = tid; i < n; i += nt) { double a = 0.0; for (int j = 0; j < n; ++j) a += fabs(A[i * ld + j]); rsum[i] = a; }
+  __syncthreads();
+  if (tid == 0) { double m = 0.0; for (int i = 0; i < n; ++i) m = fmax(m, rsum[i]); scale_sh = m; }
+  __syncthreads();
+  const double scale = scale_sh, thr = tol * scale;
+  int sweep = 0;
+  bool done = (scale == 0.0);
+  for (; sweep < max_sweeps && !done; ++sweep) {
+    for (int r = 0; r < np - 1; ++r) {
+      if (tid < nh) {
+        int p, q;
+        rr_pair(np, r, tid, p, q);
+        double c = 1.0, sn = 0.0;
+        int qq = -1;
+        if (q < n) {
+          const double g = A[p * ld + q];
+          if (fabs(g) > thr) {
+            jacobi_cs(A[p * ld + p], A[q * ld + q], g, c, sn);
+            qq = q;
+            atomicMax(&offbits, (unsigned long long)__double_as_longlong(fabs(g)));      // (non-negative doubles order like their bit patterns)
+          }
+        }
+        pc[tid] = c; ps[tid] = sn; pp[tid] = p; pq[tid] = qq;
+      }
+      __syncthreads();
+      for (int t = tid; t < nh * n; t += nt) {       // rows p, q of A
+        const int k = t / n, j = t - k * n, q = pq[k];
+        if (q < 0) continue;
+        const int p = pp[k];
+        const double c = pc[k], sn = ps[k];
+        const double x = A[p * ld + j], y = A[q * ld + j];
+        A[p * ld + j] = c * x - sn * y; A[q * ld + j] = sn * x + c * y;
+      }
+      __syncthreads();
+      for (int t = tid; t < nh * n; t += nt) {       // columns p, q of A and of V
+        const int k = t / n, i = t - k * n, q = pq[k];
+        if (q < 0) continue;
+        const int p = pp[k];
+        const double c = pc[k], sn = ps[k];
+        double x = A[i * ld + p], y = A[i * ld + q];
+        double xn = c * x - sn * y, yn = sn * x + c * y;
+        if (i == p) yn = 0.0;                        // the annihilated element, exactly
+        if (i == q) xn = 0.0;
+        A[i * ld + p] = xn; A[i * ld + q] = yn;
+        x = V[i * ld + p]; y = V[i * ld + q];
+        V[i * ld + p] = c * x - sn * y; V[i * ld + q] = sn * x + c * y;
+      }
+      __syncthreads();
+    }
+    const double offmax = __longlong_as_double((long long)offbits);
+    __syncthreads();
+    if (tid == 0) offbits = 0ull;
+    __syncthreads();
+    if (offmax == 0.0 || offmax < stop_below * scale) { done = true; }
+  }
+  // eigenvalues ascending (ties in index order), eigenvector columns permuted accordingly
+  for (int i = tid; i < n; i += nt) rsum[i] = A[i * ld + i];
+  __syncthreads();
+  for (int i = tid; i < n; i += nt) {
+    const double wi = rsum[i];
+    int rk = 0;
+    for (int j = 0; j < n; ++j) { const double wj = rsum[j]; rk += (wj < wi || (wj == wi && j < i)) ? 1 : 0; }
+    rank[i] = rk;
+    w_out[rk] = wi;
+  }
+  __syncthreads();
+  for (int t = tid; t < n * n; t += nt) { const int i = t / n, j = t - i * n; V_out[i * n + rank[j]] = V[i * ld + j]; }
+  if (tid == 0) status[0] = done ? sweep : -1;
+}
+
+// The same sweeps with ONE barrier per round (n <= JE_DB_MAX): A is double buffered, and the thread that owns the element pair (i; p, q) of column pair
+// k = (p, q) forms dst[i][p], dst[i][q] = (J^T src J)[i][p], [i][q] in one go -- it works out both rotations it needs itself (its column pair's and the one
+// row i takes part in: six elements of src and two jacobi_cs, the same numbers in every thread that needs them) -- and rotates its two elements of V in
+// place.  The partner of index i in round r of the round-robin is (2 r - i) mod (np - 1) (np - 1 itself pairs with r).  Largest rotated element per
+// thread in a register, combined once per sweep.  Same pairs, same angles, same order of rounds as jacobi_eigh_small_kernel.
+constexpr int JE_DB_MAX = 80;
+__global__ void __launch_bounds__(1024) jacobi_eigh_small_db_kernel(const double* __restrict__ Ag, int n, double* __restrict__ w_out, double* __restrict__ V_out,
+                                                                    double tol, double stop_below, int max_sweeps, int* __restrict__ status) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int ld = n + 1 + (n & 1);
+  const int np = n + (n & 1), nh = np >> 1, m = np - 1;
+  double* A0 = lds;
+  double* A1 = A0 + (size_t)n * ld;
+  double* V = A1 + (size_t)n * ld;
+  double* rsum = V + (size_t)n * ld;
+  int* rank = (int*)(rsum + n);
+  __shared__ unsigned long long offbits;
+  __shared__ double scale_sh;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  for (int t = tid; t < n * n; t += nt) { const int i = t / n, j = t - i * n; A0[i * ld + j] = Ag[t]; V[i * ld + j] = (i == j) ? 1.0 : 0.0; }
+  if (tid == 0) offbits = 0ull;
+  __syncthreads();
+  for (int i = tid; i < n; i += nt) { double a = 0.0; for (int j = 0; j < n; ++j) a += fabs(A0[i * ld + j]); rsum[i] = a; }
+  __syncthreads();
+  if (tid == 0) { double mx = 0.0; for (int i = 0; i < n; ++i) mx = fmax(mx, rsum[i]); scale_sh = mx; }
+  __syncthreads();
+  const double scale = scale_sh, thr = tol * scale;
+  // this thread's items (i, k), fixed for the whole solve: t = k * n + i for t = tid, tid + nt, ...
+  constexpr int MAXI = 4;
+  int it_i[MAXI], it_k[MAXI];
+  const int nitems = nh * n;
+#pragma unroll
+  for (int a = 0; a < MAXI; ++a) { const int t = tid + a * nt; it_k[a] = (t < nitems) ? t / n : -1; it_i[a] = (t < nitems) ? t - (t / n) * n : 0; }
+  double* src = A0; double* dst = A1;
+  int sweep = 0;
+  bool done = (scale == 0.0);
+  for (; sweep < max_sweeps && !done; ++sweep) {
+    double off_seen = 0.0;
+    for (int r = 0; r < m; ++r) {
+#pragma unroll
+      for (int a = 0; a < MAXI; ++a) {
+        const int k = it_k[a];
+        if (k < 0) continue;
+        const int i = it_i[a];
+        // column pair k of round r
+        int p, q;
+        if (k == 0) { p = m; q = r; } else { p = r + k; if (p >= m) p -= m; q = r - k; if (q < 0) q += m; }
+        if (p > q) { const int t = p; p = q; q = t; }
+        double ck = 1.0, sk = 0.0;
+        const bool colpair = q < n;
+        if (colpair) {
+          const double g = src[p * ld + q];
+          if (fabs(g) > thr) { jacobi_cs(src[p * ld + p], src[q * ld + q], g, ck, sk); off_seen = fmax(off_seen, fabs(g)); }
+        }
+        // the pair row i belongs to
+        int ip = (i == m) ? r : ((i == r) ? m : 2 * r - i);
+        if (i != m && i != r) { if (ip < 0) ip += m; else if (ip >= m) ip -= m; }
+        double ci = 1.0, si = 0.0;
+        if (ip < n) {
+          const int lo = i < ip ? i : ip, hi = i < ip ? ip : i;
+          const double g = src[lo * ld + hi];
+          if (fabs(g) > thr) {
+            double c, sn;
+            jacobi_cs(src[lo * ld + lo], src[hi * ld + hi], g, c, sn);
+            ci = c; si = (i == lo) ? -sn : sn;          // row_lo' = c row_lo - s row_hi,  row_hi' = s row_lo + c row_hi
+          }
+        } else ip = i;
+        const double up = ci * src[i * ld + p] + si * src[ip * ld + p];
+        if (colpair) {
+          const double uq = ci * src[i * ld + q] + si * src[ip * ld + q];
+          double xn = ck * up - sk * uq, yn = sk * up + ck * uq;
+          if (sk != 0.0) { if (i == p) yn = 0.0; if (i == q) xn = 0.0; }
+          dst[i * ld + p] = xn; dst[i * ld + q] = yn;
+          if (sk != 0.0) { const double x = V[i * ld + p], y = V[i * ld + q]; V[i * ld + p] = ck * x - sk * y; V[i * ld + q] = sk * x + ck * y; }
+        } else {
+          dst[i * ld + p] = up;                          // column p sits this round out (odd n): only its row rotation
+        }
+      }
+      __syncthreads();
+      double* t = src; src = dst; dst = t;
+    }
+    if (off_seen > 0.0) atomicMax(&offbits, (unsigned long long)__double_as_longlong(off_seen));
+    __syncthreads();
+    const double offmax = __longlong_as_double((long long)offbits);
+    __syncthreads();
+    if (tid == 0) offbits = 0ull;
+    __syncthreads();
+    if (offmax == 0.0 || offmax < stop_below * scale) done = true;
+  }
+  for (int i = tid; i < n; i += nt) rsum[i] = src[i * ld + i];
+  __syncthreads();
+  for (int i = tid; i < n; i += nt) {
+    const double wi = rsum[i];
+    int rk = 0;
+    for (int j = 0; j < n; ++j) { const double wj = rsum[j]; rk += (wj < wi || (wj == wi && j < i)) ? 1 : 0; }
+    rank[i] = rk;
+    w_out[rk] = wi;
+  }
+  __syncthreads();
+  for (int t = tid; t < n * n; t += nt) { const int i = t / n, j = t - i * n; V_out[i * n + rank[j]] = V[i * ld + j]; }
+  if (tid == 0) status[0] = done ? sweep : -1;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Block rounds (round 3): the same Hestenes rotations, grouped so that a workgroup keeps TWO blocks of B vectors (W rows and their Vt rows)
 // in LDS and applies every rotation between them -- B inner rounds of B disjoint pairs, one pair per wave, separated by workgroup barriers
 // -- before the vectors go back to memory.  A sweep is then nb - 1 launches (nb = ceil(nvec / B) blocks in a round-robin tournament) instead
@@ -440,6 +644,37 @@ int dev_jacobi_eigh_until(int64_t n64, double* A, double* w, double* V, int* swe
   if (!s) { set_error("libqemb_hip: call qemb_init(device) first"); return QEMB_ERR_DEVICE; }
   const int n = (int)n64;
   if (n <= 0) return QEMB_OK;
+  // small matrices: the whole eigensolve in one launch (two-sided Jacobi in LDS; QEMB_JACOBI_TWOSIDED=0: the one-sided path below, for A/B runs)
+  static const bool two_sided = !(std::getenv("QEMB_JACOBI_TWOSIDED") && std::atoi(std::getenv("QEMB_JACOBI_TWOSIDED")) == 0);
+  if (two_sided && n <= JE_MAX) {
+    int* d_st = nullptr;
+    QTRY_ALLOC(d_st, sizeof(int));
+    const int ld = n + 1 + (n & 1), nh = (n + (n & 1)) / 2;
+    const size_t lds = sizeof(double) * ((size_t)2 * n * ld + 2 * nh + n) + sizeof(int) * ((size_t)2 * nh + n) + 16;
+    static std::atomic<bool> attr_set{false};
+    if (!attr_set) { HIP_TRY(hipFuncSetAttribute((const void*)jacobi_eigh_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64)); attr_set = true; }
+    const double tol = std::max(1.0e-15, std::sqrt((double)n) * 2.22e-16);
+    static const bool one_barrier = !(std::getenv("QEMB_JACOBI_DB") && std::atoi(std::getenv("QEMB_JACOBI_DB")) == 0);
+    if (one_barrier && n <= JE_DB_MAX) {
+      const size_t lds_db = sizeof(double) * ((size_t)3 * n * ld + n) + sizeof(int) * (size_t)n + 16;
+      static std::atomic<bool> attr_db{false};
+      if (!attr_db) { HIP_TRY(hipFuncSetAttribute((const void*)jacobi_eigh_small_db_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64)); attr_db = true; }
+      const int items = nh * n;                    // <= 4 per thread
+      const int nthreads = std::min(1024, std::max(64, (items + 63) / 64 * 64));
+      hipLaunchKernelGGL(jacobi_eigh_small_db_kernel, dim3(1), dim3(nthreads), lds_db, s, (const double*)A, n, w, V, tol, stop_below, 40, d_st);
+    } else {
+    const int nthreads = n <= 32 ? 256 : (n <= 64 ? 512 : 1024);
+    hipLaunchKernelGGL(jacobi_eigh_small_kernel, dim3(1), dim3(nthreads), lds, s, (const double*)A, n, w, V, tol, stop_below, 40, d_st);
+    }
+    HIP_TRY(hipGetLastError());
+    int st = 0;
+    HIP_TRY(hipMemcpyAsync(&st, d_st, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    (void)dev_free(d_st);
+    if (sweeps_out) *sweeps_out = st;
+    if (st < 0) { set_error("Jacobi sweeps did not converge in 40 sweeps"); return QEMB_ERR_NOCONV; }
+    return QEMB_OK;
+  }
   double *Vt = nullptr, *tmp = nullptr; int* d_perm = nullptr;
   QTRY_ALLOC(Vt, sizeof(double) * (size_t)n * n);
   QTRY_ALLOC(tmp, sizeof(double) * (size_t)n);

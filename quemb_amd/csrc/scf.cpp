@@ -56,6 +56,53 @@ int build_jk(int n, const double* eri, const double* dm, double* J, double* K, c
   return 0;
 }
 
+// packed density with doubled off-diagonals: Dp[P(r,s)] = D[r,s] + D[s,r] (r > s), D[r,r]
+static int packed_density(int n, const double* dm, DBuf& D2, DBuf& Dp) {
+  const int64_t n2 = (int64_t)n * n, np = (int64_t)n * (n + 1) / 2;
+  QTRY(D2.alloc(n2)); QTRY(Dp.alloc(np));
+  QTRY(perm4(D2, dm, 1, 1, n, n, 0, 1, 3, 2));            // D^T
+  QTRY(axpby(n2, 1.0, dm, 1.0, D2));                      // D + D^T
+  Copy4Desc c{};
+  c.dim[0] = 1; c.dim[1] = 1; c.dim[2] = 1; c.dim[3] = n;
+  c.in = dm; c.si[3] = n + 1; c.out = D2; c.so[3] = n + 1; c.alpha = 1.0; c.beta = 0.0;
+  QTRY(dev_copy4(c));                                     // diagonal back to D[r,r]
+  return dev_pack_tril_rows(1, n, D2, Dp);
+}
+
+int unpack_df_factor(int n, int naux, const double* Bp, double* Bfull) { return dev_unpack_tril_rows(naux, n, Bp, Bfull); }
+
+int build_jk_factor(int n, int naux, const double* Bp, const double* Bfull, const double* dm, const double* C, int o, double* J, double* K) {
+  const int64_t n2 = (int64_t)n * n, np = (int64_t)n * (n + 1) / 2;
+  if (naux <= 0 || !Bp || (K && !Bfull)) { set_error("build_jk_factor: no factor"); return QEMB_ERR_ARG; }
+  if (J) {
+    DBuf D2, Dp, Jp, z;
+    QTRY(packed_density(n, dm, D2, Dp));
+    QTRY(Jp.alloc(np)); QTRY(z.alloc(naux));
+    QTRY(dev_gemv_rows(naux, np, Bp, np, Dp, z, 1.0, 0.0));                 // z[L] = sum_P B[L,P] Dp[P]
+    QTRY(dev_contract_mid(1, naux, np, Bp, z, Jp, np, 1.0, 0.0));            // Jp[P] = sum_L z[L] B[L,P]
+    QTRY(dev_unpack_tril_rows(1, n, Jp, J));
+  }
+  if (K && C && o > 0) {
+    // Y[L][i][p] = sum_q C[q,i] B_L[q,p] (batched over L: M = o, N = n, K = n), then K = 2 Y^T Y over the joint index (L,i)
+    DBuf Y;
+    QTRY(Y.alloc((int64_t)naux * o * n));
+    QTRY(gemm(o, n, n, 1.0, C, n, false, Bfull, n, false, 0.0, Y, n, naux, 0, n2, (int64_t)o * n));
+    QTRY(gemm(n, n, (int64_t)naux * o, 2.0, Y, n, false, Y, n, false, 0.0, K, n));
+  } else if (K) {
+    // X[L][s][p] = sum_q D[q,s] B_L[q,p] (batched over L), then K[p,r] = sum_{(L,s)} X[(L,s)][p] B[(L,s)][r]
+    DBuf X;
+    QTRY(X.alloc((int64_t)naux * n2));
+    QTRY(gemm(n, n, n, 1.0, dm, n, false, Bfull, n, false, 0.0, X, n, naux, 0, n2, n2));
+    QTRY(gemm(n, n, (int64_t)naux * n, 1.0, X, n, false, Bfull, n, false, 0.0, K, n));
+  }
+  return 0;
+}
+
+int build_jk_from(int n, const JkSource& src, const double* dm, const double* C, int o, double* J, double* K) {
+  if (src.Bp && !src.eri_s4 && !src.eri_s1) return build_jk_factor(n, src.naux, src.Bp, src.Bfull, dm, C, o, J, K);
+  return build_jk(n, src.eri_s1, dm, J, K, src.eri_s4);
+}
+
 static int density_from_mos(int n, int o, const double* C, double* dm) {
   // dm = 2 C_occ C_occ^T : A(m,k) = C[m*n + k] (k < o), B(k,nn) = C[nn*n + k]
   return gemm(n, n, o, 2.0, C, n, true, C, n, true, 0.0, dm, n);
@@ -67,7 +114,7 @@ static int fock_from_jk(int64_t n2, const double* h, const double* J, const doub
   return dev_lincomb(n2, 3, c, xs, 0.0, F);
 }
 
-static int rhf_loop(int n, int o, const double* h, const double* eri, const double* eri_s4, double* dm, const ScfOptions& opt,
+static int rhf_loop(int n, int o, const double* h, const JkSource& src, double* dm, const ScfOptions& opt,
                     double* C, double* eps, double* J, double* K, ScfResult* res, bool c_is_guess) {
   const int64_t n2 = (int64_t)n * n;
   DBuf F, Fd, err, tmp, scal, hpf, Cprev, V;
@@ -80,8 +127,9 @@ static int rhf_loop(int n, int o, const double* h, const double* eri, const doub
   double e_old = 0.0;
   res->converged = false;
   int cyc = 0;
+  bool dm_from_C = false;      // dm = 2 Co Co^T of the orbitals in C (every cycle after the first): the exchange matrix of a factor-resident fragment then needs o columns only
   for (cyc = 0; cyc < opt.max_cycle; ++cyc) {
-    QTRY(build_jk(n, eri, dm, J, K, eri_s4));
+    QTRY(build_jk_from(n, src, dm, dm_from_C ? C : nullptr, o, J, K));
     QTRY(fock_from_jk(n2, h, J, K, F));                                   // F = h + J - K/2, one pass (small fragments are launch bound: five launches before)
     QTRY(lincomb2(n2, 1.0, h, 1.0, F, hpf));
     QTRY(dev_dot(n2, hpf, dm, scal));                                   // 2 E = <h + F, D>
@@ -119,12 +167,13 @@ static int rhf_loop(int n, int o, const double* h, const double* eri, const doub
     QTRY(dcopy(n2, C, Cprev));
     have_prev = true;
     QTRY(density_from_mos(n, o, C, dm));
+    dm_from_C = true;
   }
   res->cycles = cyc + (res->converged ? 1 : 0);
   // canonical orbitals of the Fock matrix of the final density (PySCF does the same extra diagonalisation).  On the converged exit F
   // already IS the Fock matrix of dm (the loop left between the convergence test and the density update): no third J/K build.
   if (!res->converged) {
-    QTRY(build_jk(n, eri, dm, J, K, eri_s4));
+    QTRY(build_jk_from(n, src, dm, dm_from_C ? C : nullptr, o, J, K));
     QTRY(fock_from_jk(n2, h, J, K, F));
   }
   if (have_prev) {
@@ -144,6 +193,12 @@ static int rhf_loop(int n, int o, const double* h, const double* eri, const doub
 
 int rhf_device(int n, int o, const double* h, const double* eri, double* dm, const ScfOptions& opt, double* C, double* eps,
                double* J_out, double* K_out, ScfResult* res, const double* eri_s4, bool c_is_guess) {
+  JkSource src;
+  src.eri_s1 = eri; src.eri_s4 = eri_s4;
+  return rhf_device_from(n, o, h, src, dm, opt, C, eps, J_out, K_out, res, c_is_guess);
+}
+int rhf_device_from(int n, int o, const double* h, const JkSource& src, double* dm, const ScfOptions& opt, double* C, double* eps,
+                    double* J_out, double* K_out, ScfResult* res, bool c_is_guess) {
   if (n <= 0 || o <= 0 || o > n) { set_error("rhf_device: bad dimensions"); return QEMB_ERR_ARG; }
   const int64_t n2 = (int64_t)n * n;
   DBuf Jb, Kb;
@@ -155,14 +210,14 @@ int rhf_device(int n, int o, const double* h, const double* eri, double* dm, con
   QTRY(dm_start.alloc(n2)); QTRY(dcopy(n2, dm, dm_start));
   DBuf c_start;
   if (c_is_guess) { QTRY(c_start.alloc(n2)); QTRY(dcopy(n2, C, c_start)); }
-  QTRY(rhf_loop(n, o, h, eri, eri_s4, dm, opt, C, eps, J, K, res, c_is_guess));
+  QTRY(rhf_loop(n, o, h, src, dm, opt, C, eps, J, K, res, c_is_guess));
   if (!res->converged) {
     // molbe/helper.py:128-149: retry with level_shift = 0.2 and a 25-vector DIIS space
     ScfOptions o2 = opt;
     o2.level_shift = 0.2; o2.diis_space = 25;
     QTRY(dcopy(n2, dm_start, dm));
     if (c_is_guess) QTRY(dcopy(n2, c_start, C));
-    QTRY(rhf_loop(n, o, h, eri, eri_s4, dm, o2, C, eps, J, K, res, c_is_guess));
+    QTRY(rhf_loop(n, o, h, src, dm, o2, C, eps, J, K, res, c_is_guess));
   }
   QTRY(lap_SCF.close());
   return 0;

@@ -88,7 +88,7 @@ def get_sparse_P_mu_nu(mol: Mole, auxmol: Mole, exch_reachable) -> et.SemiSparse
 
 
 def transform_sparse_DF_integral_hip(mf, Fobjs, auxbasis, AO_coeff_epsilon: float = 1e-10, MO_coeff_epsilon: float = 1e-5,
-                                     precompute_P_mu_nu: bool = True, lib=None, stats=None):
+                                     precompute_P_mu_nu: bool = True, lib=None, stats=None, factor_only: bool = False):
     """`_run_sparse_df_driver` (eri_sparse_DF.py:535-656) with the device transform injected, as `transform_sparse_DF_integral_gpu`
     (:686-706) does with its cuBLAS one.  The fragment ERIs go straight into each fragment's device handle (the reference writes dataset
     `f{I}` of eri_file.h5).  Defaults as BE.__init__ (mbe.py:188-189)."""
@@ -106,13 +106,13 @@ def transform_sparse_DF_integral_hip(mf, Fobjs, auxbasis, AO_coeff_epsilon: floa
             if not precompute_P_mu_nu:                                   # "on-fly-sparse-DF": only what this fragment reaches
                 P_mu_nu = get_sparse_P_mu_nu(mol, auxmol, _get_AO_per_AO(S_abs, AO_coeff_epsilon, f.TA, lib=lib))
                 df.set_ints_semisparse(P_mu_nu)
-            df.transform(f.TA, frag=f.dev, want_host=False, S_abs=S_abs, MO_coeff_epsilon=MO_coeff_epsilon)
+            df.transform(f.TA, frag=f.dev, want_host=False, S_abs=S_abs, MO_coeff_epsilon=MO_coeff_epsilon, factor_only=factor_only)
     finally:
         df.free()
     return S_abs
 
 
-def integral_direct_DF_hip(mf, Fobjs, auxbasis, lib=None):
+def integral_direct_DF_hip(mf, Fobjs, auxbasis, lib=None, factor_only: bool = False):
     """molbe/eri_onthefly.py:45-145 (`int-direct-DF`): dense (mu nu|P), fragment transform, fit with the Cholesky factor of (P|Q).  No
     auxiliary-index blocking: the blocks of :18-42 exist to stay inside host RAM; naux N^2 doubles fit in HBM."""
     mol = mf.mol
@@ -121,6 +121,6 @@ def integral_direct_DF_hip(mf, Fobjs, auxbasis, lib=None):
     try:
         df.set_ints(aux_e2(mol, auxmol), mol.nao, "pqL")
         for f in Fobjs:
-            df.transform(f.TA, frag=f.dev, want_host=False)
+            df.transform(f.TA, frag=f.dev, want_host=False, factor_only=factor_only)
     finally:
         df.free()

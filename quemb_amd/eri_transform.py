@@ -237,13 +237,26 @@ class DFContext:
                                                    off.ctypes.data), "qemb_df_set_ints_semisparse", self.lib)
         self.nao = nao
 
-    def transform(self, TA, frag=None, want_host=True, S_abs=None, MO_coeff_epsilon=None):
+    def transform(self, TA, frag=None, want_host=True, S_abs=None, MO_coeff_epsilon=None, factor_only=False):
         """(ij|kl) 4-fold packed.  With `S_abs` and `MO_coeff_epsilon` the reference's semi-sparse screening is applied
-        (transform_integral(int_P_mu_nu, TA, S_abs, L_PQ, MO_coeff_epsilon), molbe/eri_sparse_DF.py:677-678)."""
+        (transform_integral(int_P_mu_nu, TA, S_abs, L_PQ, MO_coeff_epsilon), molbe/eri_sparse_DF.py:677-678).
+        factor_only (needs `frag`, no host copy): the fragment receives the fitted factor bb alone (eri_onthefly.py:141) and lives on it --
+        the bb^T bb product of :143 is not formed (qemb_df_transform_factor); returns None."""
         TA = _arr(TA)
         if self.nao is None or TA.shape[0] != self.nao:
             raise ValueError("DFContext.transform: set_ints first / TA has the wrong number of rows")
         n = TA.shape[1]
+        if factor_only:
+            if frag is None or want_host:
+                raise ValueError("DFContext.transform(factor_only=True) delivers into a fragment handle (frag=..., want_host=False)")
+            if S_abs is not None:
+                eps = 1e-5 if MO_coeff_epsilon is None else float(MO_coeff_epsilon)
+                S_abs = _arr(S_abs)
+                check(self.lib.qemb_df_transform_screened_factor(self.h, TA.ctypes.data, n, S_abs.ctypes.data, eps, frag.h),
+                      "qemb_df_transform_screened_factor", self.lib)
+            else:
+                check(self.lib.qemb_df_transform_factor(self.h, TA.ctypes.data, n, frag.h), "qemb_df_transform_factor", self.lib)
+            return None
         npair = n * (n + 1) // 2
         out = np.empty((npair, npair)) if want_host else None
         op = None if out is None else out.ctypes.data

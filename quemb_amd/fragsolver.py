@@ -61,6 +61,23 @@ class DeviceFragment:
     def set_df_factor_dev(self, dev_ptr: int, naux: int):
         check(self.lib.qemb_frag_set_df_factor_dev(self.h, int(naux), dev_ptr), "qemb_frag_set_df_factor_dev", self.lib)
 
+    def set_df_only(self, B: np.ndarray):
+        """the fragment lives on its 3-index factor B (naux, npair(n)) alone -- no 4-fold packed block resident (qemb_frag_set_df_only): J / K, MO integrals,
+        energies and responses come from B; `get_eri_s4` forms B.T @ B on demand"""
+        npair = self.n * (self.n + 1) // 2
+        a = np.ascontiguousarray(B, dtype=np.float64)
+        if a.ndim != 2 or a.shape[1] != npair:
+            raise ValueError(f"the 3-index factor must be (naux, {npair}), got {a.shape}")
+        check(self.lib.qemb_frag_set_df_only(self.h, int(a.shape[0]), a.ctypes.data), "qemb_frag_set_df_only", self.lib)
+
+    def set_df_only_dev(self, dev_ptr: int, naux: int):
+        check(self.lib.qemb_frag_set_df_only_dev(self.h, int(naux), dev_ptr), "qemb_frag_set_df_only_dev", self.lib)
+
+    def resident_bytes(self) -> int:
+        b = C.c_int64()
+        check(self.lib.qemb_frag_resident_bytes(self.h, C.byref(b)), "qemb_frag_resident_bytes", self.lib)
+        return int(b.value)
+
     def set_mo_route(self, route: int):
         """-1: the cheaper route (default), 0: four-index transformation of the packed block, 1: the 3-index factor"""
         check(self.lib.qemb_frag_mo_route(self.h, int(route)), "qemb_frag_mo_route", self.lib)

@@ -32,7 +32,7 @@ def initialize_pot(n_frag, relAO_per_edge):
 class BE:
     def __init__(self, mf, fobj, *, lo_method="lowdin", thr_bath=1.0e-10, int_transform="in-core-hip", auxbasis=None,
                  df_ints=None, nproc=1, ompnum=1, initialize_fragment_idx=None, solver_opts=None, lib=None, distribute=True, nstreams=None, lockstep=None,
-                 eri_file=None, scratch_dir=None, restart=False, schmidt_method="subspace", MO_coeff_epsilon=1e-5, AO_coeff_epsilon=1e-10):
+                 eri_file=None, scratch_dir=None, restart=False, schmidt_method="subspace", MO_coeff_epsilon=1e-5, AO_coeff_epsilon=1e-10, df_resident="factor"):
         if lo_method != "lowdin":
             raise NotImplementedError("only lo_method='lowdin' is mirrored (localisation is upstream of the hot path)")
         if restart:
@@ -41,6 +41,11 @@ class BE:
         self.thr_bath = thr_bath
         self.schmidt_method = schmidt_method      # 'eigh' = reference formulation, 'subspace' = same bath, O(N_env n_f nocc)
         self.int_transform = int_transform
+        # what a density-fitted fragment keeps resident: "factor" = the fitted 3-index factor bb alone (eri_onthefly.py:141; 8 naux npair bytes -- J / K, MO
+        # integrals and energies come from it, the 4-fold block of dataset `f{I}` is formed on demand only), "block" = the block bb^T bb and the factor (round 4)
+        if df_resident not in ("factor", "block"):
+            raise ValueError("df_resident must be 'factor' or 'block'")
+        self.df_resident = df_resident
         self.auxbasis = auxbasis
         self.MO_coeff_epsilon, self.AO_coeff_epsilon = float(MO_coeff_epsilon), float(AO_coeff_epsilon)      # mbe.py:191-192
         self.opts = solver_opts
@@ -147,12 +152,13 @@ class BE:
                 raise ValueError("`auxbasis` has to be defined.")                # mbe.py:1050
             frs = [self.Fobjs[I] for I in idx]
             if it == "int-direct-DF-hip":
-                sdf.integral_direct_DF_hip(self.mf, frs, self.auxbasis, lib=self.lib)
+                sdf.integral_direct_DF_hip(self.mf, frs, self.auxbasis, lib=self.lib, factor_only=self.df_resident == "factor")
             else:
                 self.df_stats = {}
                 self.S_abs = sdf.transform_sparse_DF_integral_hip(self.mf, frs, self.auxbasis, AO_coeff_epsilon=self.AO_coeff_epsilon,
                                                                   MO_coeff_epsilon=self.MO_coeff_epsilon, lib=self.lib,
-                                                                  precompute_P_mu_nu=(it == "sparse-DF-hip"), stats=self.df_stats)
+                                                                  precompute_P_mu_nu=(it == "sparse-DF-hip"), stats=self.df_stats,
+                                                                  factor_only=self.df_resident == "factor")
         elif it in ("int-direct-DF-hip", "sparse-DF-hip"):
             # df_ints: (ints, j2c, layout) or a dict(ints=, layout= | int_P_mu_nu=, j2c= | L_PQ=, S_abs=, MO_coeff_epsilon=).
             # "sparse-DF-hip" applies the MO-coefficient screening of the reference's semi-sparse transform
@@ -171,7 +177,7 @@ class BE:
             S_abs = d.get("S_abs") if it == "sparse-DF-hip" else None
             for I in idx:
                 df.transform(self.Fobjs[I].TA, frag=self.Fobjs[I].dev, want_host=False, S_abs=S_abs,
-                             MO_coeff_epsilon=d.get("MO_coeff_epsilon"))
+                             MO_coeff_epsilon=d.get("MO_coeff_epsilon"), factor_only=self.df_resident == "factor")
             df.free()
         else:
             raise ValueError(f"int_transform {it!r} is not one of {et.HIP_INT_TRANSFORMS}")

@@ -5,7 +5,7 @@
 //
 // Protocol: the 128-byte id names a segment /dev/shm/qemb_hc_<pid>_<nonce> created by dev_comm_unique_id.  An all-reduce copies each
 // rank's buffer into its slot, meets at a generation barrier, lets every rank combine the slots in rank order (so every rank gets the
-// bit-identical result, as with RCCL), and meets again before the slots are reused.  Waiting is bounded (QEMB_COMM_TIMEOUT_S, 120 s, as in the product):
+// bit-identical result, as with RCCL), and meets again before the slots are reused.  Waiting is bounded (QEMB_COMM_TIMEOUT_S, 6 h unless set, as in the product):
 // a lost rank turns into an error, not a hang.
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -46,8 +46,8 @@ std::mutex g_mutex;
 double timeout_s() {
   const char* e = std::getenv("QEMB_COMM_TIMEOUT_S");            // the product's knob (csrc/comm_rccl.hip); the older mock-only name still works
   if (!e) e = std::getenv("QEMB_HC_COMM_TIMEOUT_S");
-  const double v = e ? std::atof(e) : 120.0;
-  return v > 0 ? v : 120.0;
+  const double v = e ? std::atof(e) : 21600.0;      // the product's default: far above any rank-to-rank skew of a sweep
+  return v > 0 ? v : 1e18;                            // 0: no wall-clock bound
 }
 size_t segment_bytes(int world) { return 4096 + (size_t)world * SLOT_ELEMS * sizeof(double); }
 

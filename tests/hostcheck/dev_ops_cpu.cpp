@@ -1,3 +1,4 @@
+#include <atomic>
 // dev_ops_cpu.cpp -- TEST-ONLY scalar mock of quemb_amd/csrc/dev_ops.h.
 //
 // Purpose: let the GPU-less build container exercise the HOST LOGIC of the drivers (ccsd.cpp, scf.cpp,
@@ -62,7 +63,10 @@ int dev_timer_reset(int s) { g_tot[s] = 0; g_cnt[s] = 0; return 0; }
 int dev_timer_live_events(int) { return 0; }
 
 int dev_gemm_probe(const GemmDesc&, double*, double*, long long*) { set_error("dev_gemm_probe: not available in the hostcheck build"); return QEMB_ERR_DEVICE; }
+static std::atomic<long long> g_gemm_flops{0};
+int dev_gemm_flop_count(double* flops, int reset) { if (flops) *flops = (double)g_gemm_flops.load(); if (reset) g_gemm_flops = 0; return QEMB_OK; }
 int dev_gemm(const GemmDesc& g0) {
+  g_gemm_flops += 2ll * g0.M * g0.N * g0.K * g0.batch;
   GemmDesc g = g0;
   if (g.keep_slabs) {      // slab form: the first slab receives the whole product, the others zeros (their sum is what the consumer forms)
     if (g.ksplit <= 1 || g.alpha != 1.0 || g.beta != 0.0 || g.batch != 1) { set_error("dev_gemm: keep_slabs needs ksplit > 1, alpha = 1, beta = 0, batch = 1"); return QEMB_ERR_ARG; }

@@ -190,7 +190,10 @@ def test_bench_fragment_n220_against_oracle(qlib, frag):
     check(qlib.qemb_op_gemm(npair, npair, Bp.shape[0], 1.0, dB.ptr, npair, 0, 0, dB.ptr, npair, 0, 0, 0.0, d4.ptr, npair, 0, 1))
     fr = DeviceFragment(n, 22)
     fr.set_eri_s4_dev(d4.ptr); d4.free()
-    fr.set_df_factor_dev(dB.ptr, Bp.shape[0]); dB.free()
+    fr.set_df_factor_dev(dB.ptr, Bp.shape[0])
+    frd = DeviceFragment(n, 22)             # the same fragment living on its factor alone (round 5: no 4.7 GB block resident, J / K from the factor)
+    frd.set_df_only_dev(dB.ptr, Bp.shape[0]); dB.free()
+    assert frd.resident_bytes() == 8 * Bp.size
     fr.set_mo_route(0)                      # first the four quarter transformations of the packed block (what PySCF's ao2mo does) ...
     opts = default_opts(cc_conv_tol=1e-11, cc_conv_tol_normt=1e-9, scf_conv_tol=1e-12, scf_conv_tol_grad=1e-8)
     r = fr.scf(o, h, None, opts=opts)
@@ -219,6 +222,20 @@ def test_bench_fragment_n220_against_oracle(qlib, frag):
     assert abs(outf["e_corr_mo"] - out["e_corr_mo"]) < 1e-10 and outf["n_iter"] == out["n_iter"]
     assert np.abs(outf["rdm1_emb"] - g["rdm1_emb"]).max() < TOL_RDM
     assert np.abs(outf["t2"] - out["t2"]).max() < 1e-10 and np.abs(outf["t1"] - out["t1"]).max() < 1e-10
+    # ... and the fragment that holds nothing but the factor: its own fragment RHF (J / K from the factor), the plain updates and the converged solve
+    rd = frd.scf(o, h, None, opts=opts)
+    assert abs(rd["e_scf"] - float(g["e_scf"])) < 1e-8 * max(1.0, abs(float(g["e_scf"])))
+    assert np.abs(rd["mo_energy"] - g["mo_energy"]).max() < 1e-8
+    assert np.abs(rd["J"] - r["J"]).max() < 1e-10 and np.abs(rd["K"] - r["K"]).max() < 1e-10
+    frd.prepare_ccsd(o, h, dm0, opts=opts)
+    e3d, _ = frd.ccsd_iterate(3)
+    assert abs(e3d - float(g["e_corr_3_plain_updates"])) < 1e-9, (e3d, float(g["e_corr_3_plain_updates"]))
+    outd = frd.solve(o, h, dm0, opts=opts, eeval=False, want_t2=False)
+    assert frd.mo_route_used() == (True, 3 * n)
+    assert abs(outd["e_corr_mo"] - float(g["e_corr"])) < TOL_E and abs(outd["n_iter"] - int(g["n_iter"])) <= 1
+    assert np.abs(outd["rdm1_emb"] - g["rdm1_emb"]).max() < TOL_RDM
+    assert frd.resident_bytes() < 8 * Bp.size + 64 * n * n + 8 * (o * (n - o) + (o * (n - o)) ** 2) + 4096      # factor + orbitals / densities + kept amplitudes: no block
+    frd.free()
     if frag == 0:
         # the fragment energies of the timed sweep (eeval: the 3/4-transformed integrals come from ONE more product on the factor route) by both routes
         rng = np.random.default_rng(7)
@@ -236,6 +253,12 @@ def test_factor_route_equals_four_index(qlib):
     (24 ... 96 orbitals; relaxed densities, energies with eeval, CPHF), then the DF transform's hand-over of its factor to the fragment"""
     from test_hostlogic_fragment import check_factor_route_equals_four_index
     check_factor_route_equals_four_index(qlib, cases=((8, 3, 3, 20), (24, 7, 6, 0), (45, 12, 10, 100), (33, 33, 5, 0), (96, 20, 22, 0)), tol=5e-10)
+
+
+def test_fragment_living_on_its_factor(qlib):
+    """qemb_frag_set_df_only on the device (J / K from the factor through the MFMA products, no resident block), incl. sizes on the large tiles"""
+    from test_hostlogic_fragment import check_fragment_living_on_its_factor
+    check_fragment_living_on_its_factor(qlib, cases=((8, 3, 3, 20), (24, 7, 6, 0), (45, 12, 10, 100), (33, 33, 5, 0), (96, 20, 22, 0)), tol=5e-10, jk_tol=1e-11)
 
 
 def test_relaxed_fragment_at_bench_tiles(qlib):
