@@ -92,6 +92,10 @@ def parse():
     ap.add_argument("--mo-route", choices=("factor", "four-index"), default="factor",
                     help="how a solve forms its MO integrals: from the fragment's 3-index DF factor (qemb_frag_set_df_factor; the synthetic family IS DF-factorised) "
                          "or by the four quarter transformations of the 4-fold packed block")
+    ap.add_argument("--resident", choices=("factor", "block"), default="factor",
+                    help="what each fragment keeps in HBM between sweeps: 'factor' = its 3-index DF factor alone (8 naux npair bytes; J / K, MO integrals and energies from it), "
+                         "'block' = the 4-fold packed ERI block and the factor (rounds 1-4: 8 npair^2 bytes more)")
+    ap.add_argument("--no-size-sweep", action="store_true", help="skip the fragment-size sweep (n = 42 ... 300) beside the headline")
     ap.add_argument("--n", type=int, default=220)
     ap.add_argument("--nocc", type=int, default=20)
     ap.add_argument("--scale", type=float, default=0.03)
@@ -180,8 +184,8 @@ def launch_ranks(args):
 
 
 # ------------------------------------------------------------------------------------------------------------ workload
-def make_device_eris(lib, n, seed, scale):
-    """h (host) and the 4-fold packed ERIs built ON THE DEVICE from the DF factor of the synthetic family."""
+def make_device_eris(lib, n, seed, scale, block=True):
+    """h (host), the DF factor of the synthetic family on the device and -- unless block is False -- the 4-fold packed ERIs built from it ON THE DEVICE."""
     from quemb_amd._lib import DeviceBuffer, check
     rng = np.random.default_rng(seed)
     naux = 3 * n
@@ -191,15 +195,17 @@ def make_device_eris(lib, n, seed, scale):
     Bp = np.ascontiguousarray(B[:, il[0], il[1]])
     npair = Bp.shape[1]
     dB = DeviceBuffer.from_numpy(Bp, lib=lib)
-    d4 = DeviceBuffer(npair * npair, lib=lib)
-    check(lib.qemb_op_gemm(npair, npair, naux, 1.0, dB.ptr, npair, 0, 0, dB.ptr, npair, 0, 0, 0.0, d4.ptr, npair, 0, 1))
+    d4 = None
+    if block:
+        d4 = DeviceBuffer(npair * npair, lib=lib)
+        check(lib.qemb_op_gemm(npair, npair, naux, 1.0, dB.ptr, npair, 0, 0, dB.ptr, npair, 0, 0, 0.0, d4.ptr, npair, 0, 1))
     A = rng.standard_normal((n, n))
     h = np.diag(2.0 * np.arange(n)) + 0.3 * 0.5 * (A + A.T)
     V = rng.standard_normal((n, n)); veff0 = 0.05 * (V + V.T)
     return h, veff0, d4, dB, naux
 
 
-def make_ring(lib, n, o, nf, F_total, owner, rank, scale, opts, mo_route="factor"):
+def make_ring(lib, n, o, nf, F_total, owner, rank, scale, opts, mo_route="factor", resident="factor"):
     """The fragment objects of the sweep: `quemb_amd.pfrag.Frags`, the mirror of molbe/pfrag.py:38.  Every rank holds the (light)
     host objects of all fragments -- be_func_parallel's contract -- and the device state (ERIs in HBM, Fock, dm0) of its own."""
     from quemb_amd.fragsolver import DeviceFragment
@@ -210,11 +216,15 @@ def make_ring(lib, n, o, nf, F_total, owner, rank, scale, opts, mo_route="factor
         f = Frags(list(range(nf)), I, [edge], [(I + 1) % F_total], [edge], [cen], (1.0, cen), cen, lib=lib)
         f.nao, f.nsocc = n, o
         if owner[I] == rank:
-            h, veff0, d4, dB, naux = make_device_eris(lib, n, SEED0 + I, scale)
+            h, veff0, d4, dB, naux = make_device_eris(lib, n, SEED0 + I, scale, block=(resident == "block"))
             f.dev = DeviceFragment(n, nf, lib=lib)
-            f.dev.set_eri_s4_dev(d4.ptr); d4.free()
-            # the fragment keeps the 3-index factor its block was formed from, as one delivered by qemb_df_transform does (integral_direct_DF's bb)
-            f.dev.set_df_factor_dev(dB.ptr, naux); dB.free()
+            if resident == "block":
+                f.dev.set_eri_s4_dev(d4.ptr); d4.free()
+                # the fragment keeps the 3-index factor its block was formed from, as one delivered by qemb_df_transform does (integral_direct_DF's bb)
+                f.dev.set_df_factor_dev(dB.ptr, naux); dB.free()
+            else:
+                # the fragment lives on the factor alone, as one delivered by qemb_df_transform_factor does (round 5): no 4-fold packed block in HBM
+                f.dev.set_df_only_dev(dB.ptr, naux); dB.free()
             f.dev.set_mo_route(-1 if mo_route == "factor" else 0)
             f.h1, f.veff0, f.veff, f.fock, f.heff = h, veff0, None, h, np.zeros((n, n))
             r = f.dev.scf(o, h, None, opts=opts)        # BE.initialize does the same (Frags.scf(fs=True), mbe.py:1160)
@@ -855,7 +865,10 @@ def main():
     if not args.lib:
         # resident per fragment: the 4-fold packed ERIs; beside them the pooled work space of the fragments in flight
         npair = n * (n + 1) // 2
-        need = F * 8.0 * npair * npair + args.nstreams * 3.5 * 8.0 * n * n * npair
+        naux_syn = 3 * n
+        # resident per fragment (factor, and the block with --resident block) + the work space of the fragments in flight (two n^2 x npair transform buffers and
+        # ~1.5 more of that size in ladder operands / amplitudes, the unpacked and rotated factor images)
+        need = F * 8.0 * (naux_syn * npair + (npair * npair if args.resident == "block" else 0)) + args.nstreams * 8.0 * (3.5 * n * n * npair + 3.5 * naux_syn * n * n)
         free_b, total_b = C.c_size_t(), C.c_size_t()
         if lib.qemb_mem_info(C.byref(free_b), C.byref(total_b)) == 0 and need > 0.97 * free_b.value:
             raise SystemExit(f"bench.py: {F} fragments of n={n} per GPU need ~{need / 1e9:.0f} GB, {free_b.value / 1e9:.0f} GB are free "
@@ -863,7 +876,7 @@ def main():
 
     # ---- set-up (untimed): fragments resident in HBM, initial fragment SCF for dm0 (BE.initialize does the same)
     log(f"setting up {F} fragments per GPU (n={n}, n_occ={o}), {F_total} in the ring")
-    frs, npot = make_ring(lib, n, o, nf, F_total, owner, rank, args.scale, opts, args.mo_route)
+    frs, npot = make_ring(lib, n, o, nf, F_total, owner, rank, args.scale, opts, args.mo_route, args.resident)
     mine = [i for i in range(F_total) if owner[i] == rank]
     emap = ErrorMap(frs)
     pot = [0.0] * npot
@@ -942,6 +955,11 @@ def main():
                                       "-- tests/test_gpu_fragment.py holds both routes to the oracle at n = 220 -- whose figure is `four_index_route`)"
                                       if args.mo_route == "factor" else "MO-basis integrals by the four quarter transformations of the 4-fold packed block"),
                        "mo_route": args.mo_route,
+                       "resident": args.resident,
+                       "resident_bytes_per_fragment": (fr0.dev.resident_bytes() if hasattr(fr0.dev, "resident_bytes") and not args.lib else None),
+                       "resident_note": ("each fragment keeps its 3-index DF factor alone (qemb_frag_set_df_only: 8 naux npair bytes + orbitals, densities and kept amplitudes); "
+                                         "J / K of the fragment RHF, MO integrals and energies come from it, no 4-fold packed block (8 npair^2 = 4.7 GB at n = 220) is formed"
+                                         if args.resident == "factor" else "each fragment keeps the 4-fold packed ERI block and its 3-index factor (rounds 1-4)"),
                        "fragments_per_gpu": F, "n_occ": o, "n_virt": v, "fragments_in_flight_per_gpu": args.nstreams, "cu_partition": (args.cu_split if args.nstreams > 1 else 0),
                        "parallelism": f"fragments sharded over {world} GPU(s) by the LPT partition, 1 all-reduce per sweep",
                        "transport": None if world == 1 else {"rccl": "library communicator: ncclAllReduce on a persistent RCCL communicator (qemb_comm_allreduce)",
@@ -989,8 +1007,21 @@ def main():
             if args.mo_route == "factor" and not args.lib:
                 # the same sweep with the other route (the four quarter transformations of the packed block, as in rounds 1-3), one warm-up and one timed sweep
                 try:
+                    if args.resident == "factor":
+                        # the four quarter transformations read the 4-fold packed block: give the fragments theirs for this leg (as --resident block keeps it),
+                        # when 8 npair^2 bytes per fragment fit beside the work space; otherwise the leg is skipped (the block as a per-solve transient would be timed too)
+                        npair_ = n * (n + 1) // 2
+                        free_b, total_b = C.c_size_t(), C.c_size_t()
+                        lib.qemb_trim(); lib.qemb_mem_info(C.byref(free_b), C.byref(total_b))
+                        if len(mine) * 8.0 * npair_ * npair_ + args.nstreams * 8.0 * 3.5 * n * n * npair_ > 0.9 * free_b.value:
+                            raise RuntimeError("skipped: the 4-fold packed blocks of this many fragments do not fit")
+                        for I in mine:
+                            _, _, d4, dB, naux_ = make_device_eris(lib, n, SEED0 + I, args.scale, block=True)
+                            frs[I].dev.set_eri_s4_dev(d4.ptr); d4.free()
+                            frs[I].dev.set_df_factor_dev(dB.ptr, naux_); dB.free()
                     for f in frs:
-                        f.dev.set_mo_route(0)
+                        if getattr(f, "dev", None) is not None:
+                            f.dev.set_mo_route(0)
                     sweep()
                     n0 = float(stats.get("ccsd_iterations", 0))
                     sync(); t1 = time.perf_counter()
@@ -999,7 +1030,8 @@ def main():
                     res["four_index_route"] = {"value": (float(stats.get("ccsd_iterations", 0)) - n0) / dt4, "unit": "CCSD iterations/s", "ms_per_step": dt4 * 1e3,
                                                "mo_transform_avg_ms": None, "what": "one timed sweep of the same fragments with qemb_frag_mo_route(0)"}
                     for f in frs:
-                        f.dev.set_mo_route(-1)
+                        if getattr(f, "dev", None) is not None:
+                            f.dev.set_mo_route(-1)
                 except Exception as e:  # noqa: BLE001
                     res["four_index_route"] = f"failed: {e}"
             log("parity probe vs oracle")
@@ -1037,6 +1069,20 @@ def main():
                     res["kbe_c5"] = kc
                 except Exception as e:  # noqa: BLE001
                     res["kbe_c5_sweep_ms"] = f"failed: {e}"
+            if not args.no_size_sweep and not args.lib:
+                log("fragment-size sweep")
+                try:
+                    for f in frs:                      # the headline fragments are done: their HBM goes to the sweep's (n = 300: 16 GB of work space per fragment in flight)
+                        if getattr(f, "dev", None) is not None and f is not fr0:
+                            f.dev.free()
+                    lib.qemb_trim()
+                    sys.path.insert(0, str(ROOT / "tools"))
+                    import size_sweep
+                    import contextlib
+                    with contextlib.redirect_stdout(sys.stderr):
+                        res["size_sweep"] = size_sweep.run(lib, log=log)
+                except Exception as e:  # noqa: BLE001
+                    res["size_sweep"] = f"failed: {e}"
             if not args.no_cpu_baseline:
                 info, e_dev, e_cpu = cpu_baseline(lib, fr0.dev, h0, dm00, o, opts, args.cpu_iters, args.cpu_ompnum, args.scale)
                 res["cpu_baseline"] = info

@@ -29,6 +29,7 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <atomic>
+#include <mutex>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -65,8 +66,6 @@ struct GemmKArgs {
   long long* cyc2;         // TAG == 2: prologue stamps
   long long* cyc;          // debugging (QEMB_GEMM_TRACE): per-workgroup shader-clock ticks, or nullptr
   int sb_m, sb_n;          // > 0: the tiles of an XCD's chunk are walked in super-blocks of sb_m x sb_n tiles (launch_cfg); 0: m-tiles fastest
-  int* stagger;            // TAG == 6: per-CU arrival counters of the staggered start (never reset: two first-round arrivals per CU keep the parity)
-  int stagger_cycles;      // TAG == 6: length of the delay in shader cycles
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -241,31 +240,6 @@ __device__ __forceinline__ double lane_swap_neighbour(double x) {
 template <int WM, int WN, int WAVES_M, int WAVES_N, int BK, bool A_KC, bool B_KC, int VEC, int TAG = 0, int MODE = 0>
 __device__ __forceinline__ void dgemm_mfma_body(const uint3 BID, const uint3 GDIM, GemmKArgs g) {
   const long long t_start = g.cyc ? (long long)__builtin_amdgcn_s_memtime() : 0;
-  if constexpr (TAG == 6) {
-    // Staggered start (short-K products, round 4).  Workgroups of one launch start together and every tile takes the same time, so all of
-    // them reach their epilogue -- a burst of stores with the matrix pipe idle -- and their next prologue at the same moment.  The
-    // workgroups of the FIRST round are delayed by a fraction of a tile: with two 4-wave workgroups per CU the second one to arrive on a
-    // compute unit (a ticket from a per-CU counter) waits half a tile, so that one of the two is always in its main loop; with one
-    // workgroup per CU the delay is a per-CU fraction, which spreads the store bursts of the 256 CUs over the tile time.  Later
-    // workgroups inherit the phase of the slot they follow.  Performance only: no result depends on it.
-    if (g.stagger && BID.y == 0 && BID.x < 512u) {
-      __shared__ int s_delay;
-      if (threadIdx.x == 0) {
-        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);         // HW_REG_HW_ID: cu_id [11:8], sh_id [12], se_id [15:13]
-        const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;   // HW_REG_XCC_ID [3:0]
-        const unsigned key = xcc * 256u + ((hw >> 8) & 255u);
-        const int ticket = atomicAdd(&g.stagger[key], 1);
-        s_delay = (WAVES_M * WAVES_N <= 4) ? ((ticket & 1) ? g.stagger_cycles : 0)
-                                           : (int)(((key * 2654435761u) >> 29) * (unsigned)g.stagger_cycles / 8u);
-      }
-      __syncthreads();
-      const int delay = s_delay;
-      if (delay > 0) {
-        const long long t0 = (long long)__builtin_amdgcn_s_memtime();
-        while ((long long)__builtin_amdgcn_s_memtime() - t0 < delay) __builtin_amdgcn_s_sleep(16);
-      }
-    }
-  }
   constexpr int BM = WM * 16 * WAVES_M;
   constexpr int BN = WN * 16 * WAVES_N;
   constexpr int T = WAVES_M * WAVES_N * 64;
@@ -618,7 +592,6 @@ static int launch_cfg(const GemmDesc& d, hipStream_t s) {
   g.tiles_n = (int)((d.N + BN - 1) / BN);
   g.alpha = d.alpha; g.beta = d.beta;
   g.cyc = nullptr; g.cyc2 = nullptr;
-  g.stagger = nullptr; g.stagger_cycles = 0;
   g.sb_m = g.sb_n = 0;
   {
     // super-blocks of 32 tiles (the workgroups one XCD runs at a time at one workgroup per CU): the shape that moves the fewest operand bytes
@@ -634,22 +607,6 @@ static int launch_cfg(const GemmDesc& d, hipStream_t s) {
       }
       if (g.sb_m == 32) g.sb_m = g.sb_n = 0;      // that is the m-fastest walk already
     }
-  }
-  if constexpr (TAG == 6) {
-    static int* counters = nullptr;      // 8 XCDs x 256 hardware CU keys; zeroed once (see the kernel: parity survives complete first rounds)
-    static std::atomic<bool> ready{false};
-    if (!ready) {
-      int* p = nullptr;
-      HIP_TRY(hipMalloc((void**)&p, sizeof(int) * 2048));
-      HIP_TRY(hipMemset(p, 0, sizeof(int) * 2048));
-      counters = p; ready = true;
-    }
-    static const int cyc_env = std::getenv("QEMB_GEMM_STAGGER_CYCLES") ? std::atoi(std::getenv("QEMB_GEMM_STAGGER_CYCLES")) : -1;
-    // half a tile of a 4-wave workgroup that shares its SIMDs with a second one: nk x (WM x WN x BK/4) MFMAs x 64 cycles
-    const long long nk_ = (d.K + BK - 1) / BK;
-    const long long tile_cycles = nk_ * (WM * WN * (BK / 4)) * 64 * ((WAVES_M * WAVES_N <= 4) ? 2 : 2);
-    g.stagger = counters;
-    g.stagger_cycles = cyc_env >= 0 ? cyc_env : (int)((WAVES_M * WAVES_N <= 4) ? tile_cycles / 2 : tile_cycles);
   }
   // split-K when the output has too few tiles to occupy 256 CUs but K is long (the o x v, o x o, v x v shaped
   // CCSD intermediates contract over o*v^2 ... v^2 indices)
@@ -864,6 +821,16 @@ static int dev_gemm_dispatch(const GemmDesc& d) {
   }
   hipStream_t s = hip_stream();
   g_gemm_flops += 2ll * d.M * d.N * d.K * d.batch;
+  {  // QEMB_GEMM_SHAPELOG=<file>: one line per product in launch order (M N K batch a_kcontig b_kcontig cfg ksplit) -- no timing, no synchronisation; a single-stream
+     // run under rocprofv3 --kernel-trace then pairs the i-th dgemm_mfma_kernel dispatch of the trace with the i-th line (tools/kernel_roofline.py: products by shape)
+    static FILE* shapelog = [] { const char* e = std::getenv("QEMB_GEMM_SHAPELOG"); return (e && e[0]) ? std::fopen(e, "w") : (FILE*)nullptr; }();
+    if (shapelog) {
+      static std::mutex mu;
+      std::lock_guard<std::mutex> lock(mu);
+      std::fprintf(shapelog, "%lld %lld %lld %lld %d %d %d %d\n", (long long)d.M, (long long)d.N, (long long)d.K, (long long)d.batch, (int)d.a_kcontig, (int)d.b_kcontig, d.cfg, d.ksplit);
+      std::fflush(shapelog);
+    }
+  }
   const bool vec2 = operand_vec2_ok(d.A, d.lda, d.strideA, d.a_kcontig ? d.K : d.M) &&
                     operand_vec2_ok(d.B, d.ldb, d.strideB, d.b_kcontig ? d.K : d.N);
   // tile choice: biggest tile that still gives the 256 CUs >= ~2 workgroups each; small problems
@@ -923,10 +890,6 @@ static int dev_gemm_dispatch(const GemmDesc& d) {
     case 413: return launch_layout<7, 2, 2, 4, 16, 3, 1>(d, s, vec2);
     case 513: return launch_layout<7, 2, 2, 4, 16, 4, 1>(d, s, vec2);
     case 613: return launch_layout<7, 2, 2, 4, 16, 5, 1>(d, s, vec2);
-    // staggered-start instantiations (TAG 6; tools/transform_stagger.py): the short-K tiles with their first round of workgroups out of phase
-    case 713: return launch_layout<7, 2, 2, 4, 16, 6, 1>(d, s, vec2);
-    case 733: return launch_layout<7, 2, 1, 4, 16, 6, 1>(d, s, vec2);
-    case 734: return launch_layout<2, 7, 4, 2, 16, 6, 1>(d, s, vec2);
     case 404: return launch_layout<4, 4, 2, 4, 16, 3, 1>(d, s, vec2);
     case 504: return launch_layout<4, 4, 2, 4, 16, 4, 1>(d, s, vec2);
     case 604: return launch_layout<4, 4, 2, 4, 16, 5, 1>(d, s, vec2);

@@ -89,3 +89,35 @@ def test_design_figures_follow_the_tracked_profile():
     # and the prose of the section quotes the same averages
     lad = re.search(r"ladder \(\+\) pairs: \d+ dispatches, ([0-9.]+) ms", want).group(1)
     assert lad in txt.replace(m.group(0), ""), f"the text of DESIGN.md does not quote the ladder (+) average {lad} ms of {src}"
+
+
+def test_no_tracked_roofline_row_exceeds_its_peak():
+    """A kernel cannot run above the roofline it is priced against: a row with frac > 1 in a tracked per-kernel roofline table is a mis-attributed
+    flop or byte count (round 4: a factor-route product priced with the four-index route's flops showed 20.7 x the FP64 matrix peak)."""
+    import json
+    files = sorted((ROOT / "profiles").glob("*kernel_roofline*.jsonl"))
+    assert files, "no per-kernel roofline table is tracked"
+    for f in files:
+        for ln in f.read_text().splitlines():
+            if not ln.strip().startswith("{"):
+                continue
+            d = json.loads(ln)
+            for k, val in d.items():
+                if k.startswith("frac_of") and isinstance(val, (int, float)):
+                    assert val <= 1.0, f"{f.name}: {d.get('kernel')} at {val} of its peak"
+
+
+def test_readme_ladder_agreement_lines_follow_their_csv():
+    """profiles/README.md quotes, per round, the rocprofv3 averages of the two ladder dispatches 'X + Y ms ... (`rNN_bench_nstreams1_kernel_stats.csv`)': the
+    quoted figures must be the ones in that tracked file (round 4 shipped 2.770 + 2.364 beside a CSV that says 2.823 + 2.409)."""
+    import csv
+    txt = (ROOT / "profiles" / "README.md").read_text()
+    hits = re.findall(r"rocprofv3\s+([0-9.]+) \+ ([0-9.]+) ms = [0-9.]+ ms per dispatch \(`(r\d\d_bench_nstreams1_kernel_stats.csv)`", txt)
+    assert hits, "no ladder agreement line with its CSV in profiles/README.md"
+    for a, b, name in hits:
+        rows = {r["Name"]: r for r in csv.DictReader(open(ROOT / "profiles" / name))}
+        def avg(frag):
+            hit = [r for nm, r in rows.items() if "dgemm_mfma_kernel<" + frag + ">" in nm]
+            assert len(hit) == 1
+            return float(hit[0]["AverageNs"]) * 1e-6
+        assert abs(avg("7, 2, 2, 4, 16, true, true, 2, 1, 1") - float(a)) < 5e-4 and abs(avg("6, 2, 2, 4, 16, true, true, 2, 1, 1") - float(b)) < 5e-4, (name, a, b)

@@ -191,7 +191,8 @@ def check_fragment_living_on_its_factor(lib, cases=((8, 3, 3, 20), (11, 4, 4, 0)
             # warm second solve from the previous density (the path of a BE sweep)
             dm0 = 2.0 * b["mo_coeff"][:, :o] @ b["mo_coeff"][:, :o].T
             b2 = fr.solve(o, h, dm0=dm0, opts=opts, eeval=True)
-            assert abs(b2["e_corr_mo"] - b["e_corr_mo"]) < tol and np.abs(b2["rdm1_emb"] - b["rdm1_emb"]).max() < tol
+            # (another starting point: the two solves agree to the convergence thresholds of the SCF / CCSD, not to rounding)
+            assert abs(b2["e_corr_mo"] - b["e_corr_mo"]) < 1e-9 and np.abs(b2["rdm1_emb"] - b["rdm1_emb"]).max() < 1e-8
         # the four-index route forced on a factor-only fragment: the block is a transient of the solve
         fr.set_mo_route(0)
         c = fr.solve(o, h, opts=default_opts(lib), eeval=True)

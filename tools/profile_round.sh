@@ -42,8 +42,8 @@ done
 python tools/pmc_lockstep_iteration.py gpurun_out/lpmc_FETCH_SIZE gpurun_out/lpmc_WRITE_SIZE > $OUT/octane_lockstep_iteration_pmc.json 2>&1 || echo "pmc_lockstep_iteration failed"
 rm -rf gpurun_out/lpmc_FETCH_SIZE gpurun_out/lpmc_WRITE_SIZE
 python tools/gemm_stamps.py > $OUT/gemm_stamps.jsonl 2>&1
-python tools/transform_stagger.py > $OUT/transform_products.jsonl 2>&1
-python tools/octane_sweep_series.py 2> $OUT/octane_sweep_series.log > /dev/null
+python tools/transform_products.py > $OUT/transform_products.jsonl 2>&1
+
 # 4. HBM traffic of the ladder dispatches (FETCH_SIZE / WRITE_SIZE, separate passes)
 bash tools/pmc_ladder.sh > $OUT/pmc_ladder.log 2>&1
 cp gpurun_out/pmc_ladder.json $OUT/pmc_ladder.json
