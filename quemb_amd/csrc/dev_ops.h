@@ -54,7 +54,12 @@ const char* dev_backend_name();      // "hip-gfx950" for the product, "hostcheck
 // with one host call.  Only pure launch sequences may be captured (no allocation, no host transfer, no timers).
 // dev_graph_begin returns 1 (not an error) when the backend cannot capture; the caller then simply runs eagerly.
 typedef void* dev_graph_t;
-int dev_graph_begin();
+int dev_graph_begin(int for_tape = 0);       // for_tape: the capture will end as a tape (dev_tape_end): parallel regions leave their markers
+// Parallel regions inside a tape capture: chains of operations that do not depend on each other (dev_ops_hip.hip has the contract).  No-ops when the calls are
+// executed or captured for an executable graph: program order is always a valid order.
+int dev_region_begin();
+int dev_region_chain();
+int dev_region_end();
 int dev_graph_end(dev_graph_t* out);
 int dev_graph_launch(dev_graph_t g);
 int dev_graph_destroy(dev_graph_t g);

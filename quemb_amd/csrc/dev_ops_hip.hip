@@ -70,6 +70,11 @@ struct DevCtx {
   size_t ws_bytes = 0;
   double* gws = nullptr;             // split-K partial-sum workspace of the GEMM
   size_t gws_bytes = 0;
+  // parallel regions of a tape capture (dev_region_*): marker byte whose memsets delimit regions / chains in the captured graph, and a bump offset so that
+  // every split-K product recorded inside a region gets its own slice of gws (the chains of a region may run side by side)
+  unsigned char* marker = nullptr;
+  bool tape_capture = false, in_region = false;
+  size_t gws_bump = 0;
   TimerSlot timers[TIMER_NSLOTS];
   std::map<size_t, std::vector<void*>> pool;   // caching allocator (see below)
   size_t pool_bytes = 0;
@@ -363,6 +368,13 @@ int dev_d2d(void* dst, const void* src, size_t bytes) {
 int dev_mem_info(size_t* free_b, size_t* total_b) { REQUIRE_INIT(); HIP_TRY(hipMemGetInfo(free_b, total_b)); return QEMB_OK; }
 
 double* gemm_workspace(size_t bytes) {
+  if (ctx().in_region) {      // recorded inside a parallel region: a slice of its own (the region's chains do not share scratch)
+    const size_t need = (bytes + 255) / 256 * 256;
+    if (!g_gws || ctx().gws_bump + need > g_gws_bytes) { set_error("split-K workspace too small for a parallel region"); return nullptr; }
+    double* p = (double*)((unsigned char*)g_gws + ctx().gws_bump);
+    ctx().gws_bump += need;
+    return p;
+  }
   if (bytes <= g_gws_bytes) return g_gws;
   if (g_capturing) { set_error("split-K workspace growth inside a captured region"); return nullptr; }
   if (g_gws) { (void)hipStreamSynchronize(g_stream); (void)timed_hip_free(g_gws); g_gws = nullptr; g_gws_bytes = 0; }
@@ -384,17 +396,36 @@ static int ensure_ws(size_t bytes) {
 
 // ---- stream capture ---------------------------------------------------------------------------------
 bool dev_capturing() { return g_capturing; }
-int dev_graph_begin() {
+int dev_graph_begin(int for_tape) {
   REQUIRE_INIT();
   if (g_capturing) { set_error("dev_graph_begin: already capturing"); return QEMB_ERR_ARG; }
+  if (for_tape && !ctx().marker) HIP_TRY(hipMalloc((void**)&ctx().marker, 256));
+  if (for_tape && !g_gws) { if (!gemm_workspace(1)) return QEMB_ERR_ALLOC; }      // regions slice the workspace: it must exist before the capture
   HIP_TRY(hipStreamBeginCapture(g_stream, hipStreamCaptureModeThreadLocal));
   g_capturing = true;
+  ctx().tape_capture = for_tape != 0; ctx().in_region = false; ctx().gws_bump = 0;
   return QEMB_OK;
 }
+// Parallel regions (round 5).  Between dev_region_begin and dev_region_end the caller declares CHAINS of operations -- dev_region_chain starts the next one --
+// that do not depend on each other (no chain reads what another chain of the region writes, no two write the same place): inside a chain the order of the
+// calls is kept, across chains it is free.  Executed eagerly, or captured into an executable graph, the calls simply run in program order and the three
+// functions do nothing.  Captured for a TAPE they leave markers (one-byte memsets of a per-context marker) from which dev_tape_end recovers the structure, and
+// dev_tape_run issues level k of a region -- the k-th operation of every chain, of every fragment of the run -- together: the same kernel of several chains
+// and fragments in ONE grouped launch (device-table variant, up to 64 members).  The small-fragment CCSD update is ~46 dependent launches; its data flow is
+// ~16 levels deep.  The assertion of independence is the caller's; the lock-step tests compare bit for bit with the one-by-one solves.
+enum { MARK_REGION_BEGIN = 0xA1, MARK_CHAIN = 0xA2, MARK_REGION_END = 0xA3 };
+static int region_mark(int value) {
+  if (!g_capturing || !ctx().tape_capture || !ctx().marker) return QEMB_OK;
+  HIP_TRY(hipMemsetAsync(ctx().marker, value, 1, g_stream));
+  return QEMB_OK;
+}
+int dev_region_begin() { if (g_capturing && ctx().tape_capture) { ctx().in_region = true; } { const int rc_ = region_mark(MARK_REGION_BEGIN); if (rc_) return rc_; } return region_mark(MARK_CHAIN); }
+int dev_region_chain() { return region_mark(MARK_CHAIN); }
+int dev_region_end() { ctx().in_region = false; return region_mark(MARK_REGION_END); }
 int dev_graph_end(dev_graph_t* out) {
   REQUIRE_INIT();
   if (!g_capturing) { set_error("dev_graph_end: not capturing"); return QEMB_ERR_ARG; }
-  g_capturing = false;
+  g_capturing = false; ctx().tape_capture = false; ctx().in_region = false;
   hipGraph_t graph = nullptr;
   HIP_TRY(hipStreamEndCapture(g_stream, &graph));
   hipGraphExec_t exec = nullptr;
@@ -424,6 +455,7 @@ struct TapeNode {
   hipKernelNodeParams k;        // type == Kernel
   hipMemcpy3DParms cpy;         // type == Memcpy
   hipMemsetParams set;          // type == Memset
+  int region = -1, chain = -1;  // inside a parallel region (dev_region_*): which region of the tape, which chain of the region
 };
 struct Tape {
   hipGraph_t graph = nullptr;
@@ -434,7 +466,8 @@ static thread_local long long t_tape_launches = 0, t_tape_grouped = 0, t_tape_op
 int dev_tape_end(dev_tape_t* out) {
   REQUIRE_INIT();
   if (!g_capturing) { set_error("dev_tape_end: not capturing"); return QEMB_ERR_ARG; }
-  g_capturing = false;
+  g_capturing = false; ctx().tape_capture = false; ctx().in_region = false;
+  const void* marker = ctx().marker;
   hipGraph_t graph = nullptr;
   HIP_TRY(hipStreamEndCapture(g_stream, &graph));
   auto fail = [&](const std::string& why) { (void)hipGraphDestroy(graph); set_error("dev_tape_end: " + why); return 1; };     // 1: cannot tape (not an error)
@@ -458,6 +491,7 @@ int dev_tape_end(dev_tape_t* out) {
   for (hipGraphNode_t x : nodes) if (indeg[x] == 0) { if (cur) return fail("the captured sequence has several roots"); cur = x; }
   Tape* t = new Tape();
   t->graph = graph;
+  int cur_region = -1, cur_chain = -1, n_regions = 0;
   for (size_t visited = 0; cur && visited < nn; ++visited) {
     TapeNode tn{};
     if (hipGraphNodeGetType(cur, &tn.type) != hipSuccess) { delete t; return fail("hipGraphNodeGetType"); }
@@ -470,7 +504,15 @@ int dev_tape_end(dev_tape_t* out) {
     } else if (tn.type != hipGraphNodeTypeEmpty) {
       delete t; return fail("node type " + std::to_string((int)tn.type) + " cannot be taped");
     }
-    if (tn.type != hipGraphNodeTypeEmpty) t->nodes.push_back(tn);
+    bool is_marker = false;
+    if (tn.type == hipGraphNodeTypeMemset && marker && tn.set.dst == marker) {      // a region marker: structure, not work
+      is_marker = true;
+      const unsigned v = tn.set.value & 0xffu;
+      if (v == MARK_REGION_BEGIN) { cur_region = n_regions++; cur_chain = -1; }
+      else if (v == MARK_CHAIN) { if (cur_region >= 0) ++cur_chain; }
+      else if (v == MARK_REGION_END) { cur_region = -1; cur_chain = -1; }
+    }
+    if (!is_marker && tn.type != hipGraphNodeTypeEmpty) { tn.region = cur_region; tn.chain = cur_region >= 0 ? cur_chain : -1; t->nodes.push_back(tn); }
     auto it = next.find(cur);
     cur = (it == next.end()) ? nullptr : it->second;
   }
@@ -506,64 +548,141 @@ struct PlanStep {
   bool grouped;
   const TapeNode* single;       // !grouped
   const GroupInfo* gi; size_t args_off; unsigned blocks; dim3 block; size_t lds;     // grouped: its argument block inside TapePlan::args
+  bool tab = false;             // grouped through a member table in device memory (more than GROUP_MAX members): args_off is the offset inside TapePlan::dev_tabs
 };
 struct TapePlan {
   std::vector<const void*> key;
   std::vector<PlanStep> steps;
   std::vector<unsigned char> args;      // argument blocks of the grouped launches (host memory: they are passed by value)
+  std::vector<unsigned char> tabs;      // host image of the device member tables
+  unsigned char* dev_tabs = nullptr;    // ... and their device copy (pooled block, uploaded once)
   long long ops = 0, grouped = 0;
+  ~TapePlan() { if (dev_tabs) (void)dev_free(dev_tabs); }
 };
 static std::mutex g_plan_mutex;
 static std::vector<TapePlan*> g_plans;        // small: one per distinct set of tapes that ran together
+
+// one step of the plan from the nodes that may run together (same position of a plain segment, or one level of a parallel region): launches of the same
+// kernel and block shape become grouped launches -- by value up to GROUP_MAX members, through a device table up to GROUP_TAB_MAX -- the rest is issued singly
+static void plan_emit(TapePlan* plan, const std::vector<const TapeNode*>& here, bool grouping, bool allow_tab) {
+  std::vector<unsigned char>& host = plan->args;
+  auto reserve = [&](std::vector<unsigned char>& v, size_t bytes) { const size_t off = (v.size() + 255) / 256 * 256; v.resize(off + bytes); return off; };
+  plan->ops += (long long)here.size();
+  std::vector<bool> done(here.size(), false);
+  for (size_t a = 0; a < here.size(); ++a) {
+    if (done[a]) continue;
+    const TapeNode* na = here[a];
+    std::vector<const TapeNode*> grp{na};
+    const GroupInfo* gi = nullptr;
+    const int cap = allow_tab ? GROUP_TAB_MAX : GROUP_MAX;
+    if (grouping && na->type == hipGraphNodeTypeKernel) {
+      auto it = groupable().find(na->k.func);
+      if (it != groupable().end()) {
+        gi = &it->second;
+        for (size_t b = a + 1; b < here.size() && (int)grp.size() < cap; ++b) {
+          const TapeNode* nb = here[b];
+          if (!done[b] && nb->type == hipGraphNodeTypeKernel && nb->k.func == na->k.func && nb->k.blockDim.x == na->k.blockDim.x &&
+              nb->k.blockDim.y == na->k.blockDim.y && nb->k.blockDim.z == na->k.blockDim.z) { grp.push_back(nb); done[b] = true; }
+        }
+      }
+    }
+    done[a] = true;
+    PlanStep st{};
+    if (gi && grp.size() >= 2) {
+      st.grouped = true; st.gi = gi; st.block = na->k.blockDim; st.lds = 0;
+      std::vector<GroupMember> mem;
+      for (const TapeNode* x : grp) {
+        mem.push_back(GroupMember{x->k.kernelParams, x->k.gridDim.x, x->k.gridDim.y, x->k.gridDim.z});
+        st.lds = std::max<size_t>(st.lds, x->k.sharedMemBytes);
+      }
+      if ((int)grp.size() <= GROUP_MAX) {
+        st.args_off = reserve(host, gi->args_bytes);
+        st.blocks = gi->build(host.data() + st.args_off, mem.data(), (int)mem.size());
+      } else {
+        st.tab = true;
+        st.args_off = reserve(plan->tabs, gi->tab_bytes);
+        st.blocks = gi->build_tab(plan->tabs.data() + st.args_off, mem.data(), (int)mem.size());
+      }
+      plan->grouped += 1;
+      plan->steps.push_back(st);
+    } else {
+      for (const TapeNode* x : grp) { PlanStep s1{}; s1.grouped = false; s1.single = x; plan->steps.push_back(s1); }
+    }
+  }
+}
+
+// A tape as a sequence of segments: runs of plain nodes, and parallel regions (their chains).  Tapes of one run are merged segment by segment when their
+// segment structure agrees (same code path for every fragment); otherwise position by position as if there were no regions.
+struct TapeSegment { int region; size_t begin, end; std::vector<std::vector<const TapeNode*>> chains; };
+static std::vector<TapeSegment> tape_segments(const Tape* t) {
+  std::vector<TapeSegment> out;
+  for (size_t i = 0; i < t->nodes.size(); ++i) {
+    const TapeNode& nd = t->nodes[i];
+    if (out.empty() || out.back().region != nd.region) out.push_back(TapeSegment{nd.region, i, i, {}});
+    TapeSegment& sg = out.back();
+    sg.end = i + 1;
+    if (nd.region >= 0) {
+      if ((int)sg.chains.size() <= nd.chain) sg.chains.resize((size_t)nd.chain + 1);
+      sg.chains[(size_t)nd.chain].push_back(&nd);
+    }
+  }
+  return out;
+}
 
 static int build_plan(const dev_tape_t* tapes, int n, TapePlan** out) {
   static std::once_flag once;
   std::call_once(once, [] { register_groupable_kernels(); register_groupable_gemm(); });
   static const bool grouping = !(std::getenv("QEMB_TAPE_GROUP") && std::atoi(std::getenv("QEMB_TAPE_GROUP")) == 0);
+  static const bool regions_on = !(std::getenv("QEMB_TAPE_REGIONS") && std::atoi(std::getenv("QEMB_TAPE_REGIONS")) == 0);      // 0: ignore the regions (A/B runs)
   TapePlan* plan = new TapePlan();
   for (int f = 0; f < n; ++f) plan->key.push_back(tapes[f]);
-  std::vector<unsigned char>& host = plan->args;
-  auto reserve = [&](size_t bytes) { const size_t off = (host.size() + 15) / 16 * 16; host.resize(off + bytes); return off; };
-  size_t longest = 0;
-  for (int f = 0; f < n; ++f) longest = std::max(longest, ((const Tape*)tapes[f])->nodes.size());
-  for (size_t i = 0; i < longest; ++i) {
-    std::vector<const TapeNode*> here;
-    for (int f = 0; f < n; ++f) { const Tape* t = (const Tape*)tapes[f]; if (i < t->nodes.size()) here.push_back(&t->nodes[i]); }
-    plan->ops += (long long)here.size();
-    std::vector<bool> done(here.size(), false);
-    for (size_t a = 0; a < here.size(); ++a) {
-      if (done[a]) continue;
-      const TapeNode* na = here[a];
-      std::vector<const TapeNode*> grp{na};
-      const GroupInfo* gi = nullptr;
-      if (grouping && na->type == hipGraphNodeTypeKernel) {
-        auto it = groupable().find(na->k.func);
-        if (it != groupable().end()) {
-          gi = &it->second;
-          for (size_t b = a + 1; b < here.size() && (int)grp.size() < GROUP_MAX; ++b) {
-            const TapeNode* nb = here[b];
-            if (!done[b] && nb->type == hipGraphNodeTypeKernel && nb->k.func == na->k.func && nb->k.blockDim.x == na->k.blockDim.x &&
-                nb->k.blockDim.y == na->k.blockDim.y && nb->k.blockDim.z == na->k.blockDim.z) { grp.push_back(nb); done[b] = true; }
-          }
+  std::vector<std::vector<TapeSegment>> segs;
+  bool same_structure = regions_on;
+  for (int f = 0; f < n && same_structure; ++f) {
+    segs.push_back(tape_segments((const Tape*)tapes[f]));
+    if (f > 0) {
+      same_structure = segs[f].size() == segs[0].size();
+      for (size_t k = 0; same_structure && k < segs[0].size(); ++k)
+        same_structure = (segs[f][k].region >= 0) == (segs[0][k].region >= 0) && segs[f][k].chains.size() == segs[0][k].chains.size();
+    }
+  }
+  if (same_structure && !segs.empty()) {
+    for (size_t k = 0; k < segs[0].size(); ++k) {
+      if (segs[0][k].region < 0) {      // plain segment: position by position
+        size_t longest = 0;
+        for (int f = 0; f < n; ++f) longest = std::max(longest, segs[f][k].end - segs[f][k].begin);
+        for (size_t i = 0; i < longest; ++i) {
+          std::vector<const TapeNode*> here;
+          for (int f = 0; f < n; ++f) { const Tape* t = (const Tape*)tapes[f]; const size_t j = segs[f][k].begin + i; if (j < segs[f][k].end) here.push_back(&t->nodes[j]); }
+          plan_emit(plan, here, grouping, false);
         }
-      }
-      done[a] = true;
-      PlanStep st{};
-      if (gi && grp.size() >= 2) {
-        st.grouped = true; st.gi = gi; st.block = na->k.blockDim; st.lds = 0;
-        st.args_off = reserve(gi->args_bytes);
-        std::vector<GroupMember> mem;
-        for (const TapeNode* x : grp) {
-          mem.push_back(GroupMember{x->k.kernelParams, x->k.gridDim.x, x->k.gridDim.y, x->k.gridDim.z});
-          st.lds = std::max<size_t>(st.lds, x->k.sharedMemBytes);
+      } else {                          // parallel region: level by level over every chain of every tape
+        size_t depth = 0;
+        for (int f = 0; f < n; ++f) for (const auto& c : segs[f][k].chains) depth = std::max(depth, c.size());
+        for (size_t lev = 0; lev < depth; ++lev) {
+          std::vector<const TapeNode*> here;
+          for (int f = 0; f < n; ++f) for (const auto& c : segs[f][k].chains) if (lev < c.size()) here.push_back(c[lev]);
+          plan_emit(plan, here, grouping, true);
         }
-        st.blocks = gi->build(host.data() + st.args_off, mem.data(), (int)mem.size());
-        plan->grouped += 1;
-        plan->steps.push_back(st);
-      } else {
-        for (const TapeNode* x : grp) { PlanStep s1{}; s1.grouped = false; s1.single = x; plan->steps.push_back(s1); }
       }
     }
+  } else {
+    size_t longest = 0;
+    for (int f = 0; f < n; ++f) longest = std::max(longest, ((const Tape*)tapes[f])->nodes.size());
+    for (size_t i = 0; i < longest; ++i) {
+      std::vector<const TapeNode*> here;
+      for (int f = 0; f < n; ++f) { const Tape* t = (const Tape*)tapes[f]; if (i < t->nodes.size()) here.push_back(&t->nodes[i]); }
+      plan_emit(plan, here, grouping, false);
+    }
+  }
+  if (!plan->tabs.empty()) {      // member tables to the device, once
+    void* q = nullptr;
+    int rc = dev_alloc(&q, plan->tabs.size());
+    if (rc) { delete plan; return rc; }
+    plan->dev_tabs = (unsigned char*)q;
+    hipError_t e = hipMemcpyAsync(plan->dev_tabs, plan->tabs.data(), plan->tabs.size(), hipMemcpyHostToDevice, g_stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(g_stream);      // (pageable source: complete before the vector can move; once per plan)
+    if (e != hipSuccess) { set_error(std::string("dev_tape_run: table upload failed: ") + hipGetErrorString(e)); delete plan; return QEMB_ERR_DEVICE; }
   }
   *out = plan;
   return QEMB_OK;
@@ -589,7 +708,10 @@ int dev_tape_run(const dev_tape_t* tapes, int n) {
   }
   t_tape_launches = 0; t_tape_grouped = plan->grouped; t_tape_ops = plan->ops;
   for (const PlanStep& st : plan->steps) {
-    if (st.grouped) {
+    if (st.grouped && st.tab) {
+      st.gi->launch_tab(plan->dev_tabs + st.args_off, st.blocks, st.block, st.lds, g_stream);
+      t_tape_launches += 1;
+    } else if (st.grouped) {
       st.gi->launch(plan->args.data() + st.args_off, st.blocks, st.block, st.lds, g_stream);
       t_tape_launches += 1;
     } else {

@@ -874,6 +874,10 @@ static int dev_gemm_dispatch(const GemmDesc& d) {
     case 33: return launch_layout<7, 2, 1, 4, 16, 0, 1>(d, s, vec2);  // 112 x 128, 4 waves, TWO workgroups per CU (66 KB of LDS each): short-K products
     case 34: return launch_layout<2, 7, 4, 2, 16, 0, 1>(d, s, vec2);  // 128 x 224, 8 waves as 4 x 2 (2 x 7 MFMA tiles per wave): tall products with 192 < N <= 224
     case 35: return launch_layout<5, 2, 2, 4, 16, 0, 1>(d, s, vec2);  // 160 x 128, 8 waves as 2 x 4 (5 x 2 MFMA tiles per wave): pair-row counts that 160 divides well (465 = npair(30))
+    case 36: return launch_layout<5, 2, 1, 4, 16, 0, 1>(d, s, vec2);  //  80 x 128, 4 waves as 1 x 4 (5 x 2 per wave), two workgroups per CU: the 66-80 packed pair rows of n_occ = 12 (mid-size fragments, round 5)
+    case 37: return launch_layout<3, 3, 2, 2, 16, 0, 1>(d, s, vec2);  //  96 x  96, 4 waves as 2 x 2 (3 x 3 per wave): square products of 1000-2000 rows and columns (the rings of mid-size fragments: 15 x 15 tiles at o v = 1440 fill 225 of 256 CUs in one round)
+    case 236: return launch_layout<5, 2, 1, 4, 16>(d, s, vec2);
+    case 237: return launch_layout<3, 3, 2, 2, 16>(d, s, vec2);
     case 20: return launch_layout<4, 1, 2, 2, 16>(d, s, vec2);   // 128 x  32, 4 waves: tall products with N = n_occ (the t1 contractions of ovvv)
     case 21: return launch_layout<1, 4, 2, 2, 16>(d, s, vec2);   //  32 x 128, 4 waves: the same with M = n_occ
     case 23: return launch_layout<7, 2, 2, 4, 16, 1, 1>(d, s, vec2);   // = 13 under its own kernel symbol (pp-ladder, + pairs)

@@ -42,7 +42,10 @@ int dev_pinned_alloc(void** p, size_t b) { *p = std::malloc(b ? b : 16); return 
 int dev_pinned_free(void* p) { std::free(p); return 0; }
 int dev_d2d(void* d, const void* s, size_t b) { std::memmove(d, s, b); return 0; }
 int dev_fill(double* x, int64_t n, double v) { std::fill(x, x + n, v); return 0; }
-int dev_graph_begin() { return 1; }   // the mock cannot capture: drivers run eagerly
+int dev_graph_begin(int) { return 1; }
+int dev_region_begin() { return 0; }
+int dev_region_chain() { return 0; }
+int dev_region_end() { return 0; }   // the mock cannot capture: drivers run eagerly
 int dev_graph_end(dev_graph_t*) { return QEMB_ERR_DEVICE; }
 int dev_graph_launch(dev_graph_t) { return QEMB_ERR_DEVICE; }
 int dev_graph_destroy(dev_graph_t) { return 0; }

@@ -32,7 +32,7 @@ def _gemm(lib, A, B, Cm, alpha, beta, a_kc, b_kc, batch=1, cfg=-1):
     return dC.numpy(Cm.shape)
 
 
-@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 4, 10, 11, 12, 33, 34, 35, 200, 204])
+@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 4, 10, 11, 12, 33, 34, 35, 36, 37, 200, 204, 236, 237])
 @pytest.mark.parametrize("a_kc,b_kc", [(1, 1), (1, 0), (0, 1), (0, 0)])
 @pytest.mark.parametrize("shape", [(128, 128, 64), (400, 300, 200), (37, 53, 29), (441, 441, 441), (1, 220, 96), (130, 258, 18),
                                    (66, 130, 6), (64, 64, 16), (50, 70, 5)])      # the last three: a single k-tile (no second LDS buffer is ever filled)
@@ -781,7 +781,7 @@ def test_gather_and_scale_rows(qlib):
 # cfg 15 / 25: 192 x 128 tile (6 x 2 per wave) -- the (-) pair block (M = 190);
 # cfg 20 / 21: 128 x 32 / 32 x 128 tiles -- the products with an n_occ-sized side (ccsd.cpp:249).
 # 23 / 25 are 13 / 15 under the ladder's own kernel symbol (ccsd.cpp:217), i.e. separately compiled instantiations.
-@pytest.mark.parametrize("cfg,M", [(13, 210), (23, 210), (13, 224), (13, 220), (15, 190), (25, 190), (15, 192), (23, 97), (213, 210), (215, 190), (33, 220), (33, 112), (33, 113), (35, 160), (35, 465), (35, 161), (35, 153), (35, 136), (4, 120), (4, 128), (11, 105), (12, 45)])
+@pytest.mark.parametrize("cfg,M", [(13, 210), (23, 210), (13, 224), (13, 220), (15, 190), (25, 190), (15, 192), (23, 97), (213, 210), (215, 190), (33, 220), (33, 112), (33, 113), (35, 160), (35, 465), (35, 161), (35, 153), (35, 136), (4, 120), (4, 128), (11, 105), (12, 45), (36, 78), (36, 66), (36, 80), (36, 81), (37, 96), (37, 100), (37, 190)])
 @pytest.mark.parametrize("a_kc,b_kc", [(1, 1), (1, 0), (0, 1), (0, 0)])
 @pytest.mark.parametrize("ks", [0, 8])
 def test_gemm_ladder_tile_configs(qlib, cfg, M, a_kc, b_kc, ks):
@@ -941,7 +941,7 @@ def test_device_timers_hold_a_bounded_number_of_events(qlib):
 # classic loop of the same tile (cfg + 200; 23 / 25 are 13 / 15 under the ladder's kernel symbol): same summation order, so the results
 # must be IDENTICAL -- a compiler that moves a fragment register between the asm read and its wait would show up here first.
 @pytest.mark.parametrize("cfg,classic,M,N", [(0, 200, 256, 384), (1, 201, 192, 192), (4, 204, 128, 512), (13, 213, 210, 2304), (23, 213, 210, 2304),
-                                             (15, 215, 190, 2304), (25, 215, 190, 2304), (33, 233, 220, 512), (34, 234, 640, 220), (35, 235, 465, 512)])
+                                             (15, 215, 190, 2304), (25, 215, 190, 2304), (33, 233, 220, 512), (34, 234, 640, 220), (35, 235, 465, 512), (36, 236, 78, 1440), (37, 237, 480, 384)])
 @pytest.mark.parametrize("a_kc,b_kc", [(1, 1), (1, 0), (0, 1), (0, 0)])
 def test_gemm_mode1_equals_classic_loop(qlib, cfg, classic, M, N, a_kc, b_kc):
     rng = np.random.default_rng(7 * cfg + a_kc + 2 * b_kc)
