@@ -38,6 +38,11 @@ int qemb_timer_live_events(int slot);      /* event pairs held by the calling co
 int qemb_op_gemm(int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t lda, int a_kcontig,
                  int64_t strideA, const double* B, int64_t ldb, int b_kcontig, int64_t strideB, double beta,
                  double* C, int64_t ldc, int64_t strideC, int64_t batch);
+/* C = A B with the rows of A (stored K x M, i.e. !a_kcontig) read through the slab-aware loader: A(m,k) = A[k*lda + m + (m / a_slab) * a_slab_skip].  With
+ * lda = a_slab = n and a_slab_skip = n^2 - n the rows (pair, q) of a stack of n x n slabs X[pair][k][q] form ONE tall operand: the last quarter transform
+ * of the embedding -> MO transformation (C^T . slab for every pair, csrc/ccsd.cpp mo_transform) as a flat product on the tall tile.  cfg as qemb_set_gemm_config. */
+int qemb_op_gemm_slab_rows(int64_t M, int64_t N, int64_t K, const double* A, int64_t lda, int64_t a_slab, int64_t a_slab_skip, const double* B, int64_t ldb,
+                           int b_kcontig, double* C, int64_t ldc, int cfg);
 /* -1 = automatic tile choice; 0..99 force a tile configuration (calling host thread only); 2xx = the round-1 main loop of the same tiles
  * (A/B measurements); 3xx = diagnostic instantiations that stamp s_memtime (qemb_op_gemm_stamps); 4xx / 5xx / 6xx = ABLATION instantiations
  * that leave memory traffic out and return WRONG products by construction (tools/gemm_ablation.py) -- measurement aids, reachable through

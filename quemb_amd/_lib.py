@@ -70,6 +70,7 @@ def _declare(lib):
     f("qemb_timer_reset", I, I)
     f("qemb_timer_live_events", I, I)
     f("qemb_op_gemm", I, L, L, L, D, P, L, I, L, P, L, I, L, D, P, L, L, L)
+    f("qemb_op_gemm_slab_rows", I, L, L, L, P, L, L, L, P, L, I, P, L, I)
     f("qemb_op_gemm_probe", I, L, L, L, P, L, I, P, L, I, P, L, I, I, C.POINTER(D), C.POINTER(D), C.POINTER(L))
     f("qemb_op_gemm_stamps", I, L, L, L, P, L, P, L, P, L, I, I, C.POINTER(D))
     f("qemb_set_gemm_config", I, I)

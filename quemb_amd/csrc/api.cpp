@@ -115,6 +115,15 @@ int qemb_comm_destroy(void) { return dev_comm_destroy(); }
 int qemb_ctx_count(int n) { return dev_ctx_count(n); }
 int qemb_ctx_bind(int k) { return dev_ctx_bind(k); }
 int qemb_ctx_partition(int parts) { return dev_ctx_partition(parts); }
+int qemb_op_gemm_slab_rows(int64_t M, int64_t N, int64_t K, const double* A, int64_t lda, int64_t a_slab, int64_t a_slab_skip, const double* B, int64_t ldb,
+                           int b_kcontig, double* C, int64_t ldc, int cfg) {
+  GemmDesc g{};
+  g.M = M; g.N = N; g.K = K; g.alpha = 1.0; g.beta = 0.0;
+  g.A = A; g.lda = lda; g.a_kcontig = 0; g.strideA = 0; g.a_slab = a_slab; g.a_slab_skip = a_slab_skip;
+  g.B = B; g.ldb = ldb; g.b_kcontig = b_kcontig; g.strideB = 0;
+  g.C = C; g.ldc = ldc; g.strideC = 0; g.batch = 1; g.cfg = cfg; g.ksplit = 0;
+  return dev_gemm(g);
+}
 int qemb_gemm_flop_count(double* flops, int reset) { return dev_gemm_flop_count(flops, reset); }
 int qemb_alloc_stats(long long* n, long long* nfree, double* ms, double* gb, int reset) { return dev_alloc_stats(n, nfree, ms, gb, reset); }
 int qemb_ctx_timer_read(int ctx, int slot, double* total_ms, int64_t* count, int reset) { return dev_ctx_timer_read(ctx, slot, total_ms, count, reset); }

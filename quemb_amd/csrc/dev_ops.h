@@ -115,6 +115,10 @@ struct GemmDesc {
   // keep_slabs (needs ksplit > 1, alpha = 1, beta = 0, batch = 1): the K slices' partial products stay where they are -- C receives
   // gemm_slab_count(K, ksplit) slabs [M][N] (ld = N, ldc ignored) and the consumer adds them up in slab order (what the reduction pass would do)
   int keep_slabs = 0;
+  // Slab-aware rows of a !a_kcontig A operand (round 5): row m sits a_slab_skip * (m / a_slab) elements further on, A(m,k) = A[k*lda + m + (m / a_slab) * a_slab_skip].
+  // With a_slab = lda = n and a_slab_skip = n^2 - n the rows (pair, q) of a stack of n x n slabs X[pair][k][q] are ONE tall operand: the batched product
+  // C^T . slab of the MO transformation runs flat on the tall tile.  0: plain rows.  (a_slab even when the operand is loaded 16 bytes at a time.)
+  int64_t a_slab = 0, a_slab_skip = 0;
 };
 inline int gemm_slab_count(int64_t K, int ksplit) {      // the K slices dev_gemm cuts for an explicit ksplit (32-aligned chunks)
   if (ksplit <= 1) return 1;

@@ -66,6 +66,7 @@ struct GemmKArgs {
   long long* cyc2;         // TAG == 2: prologue stamps
   long long* cyc;          // debugging (QEMB_GEMM_TRACE): per-workgroup shader-clock ticks, or nullptr
   int sb_m, sb_n;          // > 0: the tiles of an XCD's chunk are walked in super-blocks of sb_m x sb_n tiles (launch_cfg); 0: m-tiles fastest
+  int a_slab; long long a_slab_skip;      // slab-aware rows of a !A_KC operand (GemmDesc::a_slab): row m is a_slab_skip * (m / a_slab) elements further on; 0: plain
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -91,7 +92,7 @@ struct LdsImage {
 // Stage one operand tile global -> registers (zero filled outside the matrix).
 template <int BMN, int BK, bool KCONTIG, int VEC, int T, int NCH>
 __device__ __forceinline__ void stage_load(double (&reg)[NCH][VEC], const double* __restrict__ P,
-                                           long long ld, int mn0, int k0, int MN, int K, int tid) {
+                                           long long ld, int mn0, int k0, int MN, int K, int tid, int slab = 0, long long slab_skip = 0) {
   constexpr int CPR = (KCONTIG ? BK : BMN) / VEC;  // chunks per contiguous row of the tile
   constexpr int TOTAL = BMN * BK / VEC;
 #pragma unroll
@@ -103,7 +104,8 @@ __device__ __forceinline__ void stage_load(double (&reg)[NCH][VEC], const double
     const int mn = KCONTIG ? r : cc;
     const int k = KCONTIG ? cc : r;
     const int gmn = mn0 + mn, gk = k0 + k;
-    const long long g = KCONTIG ? (long long)gmn * ld + gk : (long long)gk * ld + gmn;
+    long long g = KCONTIG ? (long long)gmn * ld + gk : (long long)gk * ld + gmn;
+    if (!KCONTIG && slab > 0) g += (long long)(gmn / slab) * slab_skip;
     if constexpr (VEC == 2) {
       // dispatch guarantees even extents/ld/alignment, so a chunk is entirely in or out
       const bool ok = (gmn < MN) && (gk < K);
@@ -123,7 +125,8 @@ __device__ __forceinline__ void stage_load(double (&reg)[NCH][VEC], const double
 // matrix are clamped to its last row (their products land in rows / columns of the tile that are never stored); only a k-tail needs
 // zeros, so the LAST tile of a slice still goes through stage_load.
 template <int BMN, int BK, bool KCONTIG, int VEC, int T, int NCH>
-__device__ __forceinline__ void stage_ptrs(const double* (&ptr)[NCH], const double* __restrict__ P, long long ld, int mn0, int k0, int MN, int tid) {
+__device__ __forceinline__ void stage_ptrs(const double* (&ptr)[NCH], const double* __restrict__ P, long long ld, int mn0, int k0, int MN, int tid, int slab = 0,
+                                           long long slab_skip = 0) {
   constexpr int CPR = (KCONTIG ? BK : BMN) / VEC;
   constexpr int TOTAL = BMN * BK / VEC;
 #pragma unroll
@@ -136,6 +139,7 @@ __device__ __forceinline__ void stage_ptrs(const double* (&ptr)[NCH], const doub
     const int last = KCONTIG ? MN - 1 : MN - VEC;    // last addressable row / (VEC == 2, mn contiguous: MN and gmn are even) last chunk start
     gmn = gmn < last ? gmn : (last > 0 ? last : 0);
     ptr[c] = KCONTIG ? P + (long long)gmn * ld + (k0 + k) : P + (long long)(k0 + k) * ld + gmn;
+    if (!KCONTIG && slab > 0) ptr[c] += (long long)(gmn / slab) * slab_skip;
   }
 }
 template <int BMN, int BK, bool KCONTIG, int VEC, int T, int NCH>
@@ -299,7 +303,7 @@ __device__ __forceinline__ void dgemm_mfma_body(const uint3 BID, const uint3 GDI
 
   const double* pa[NCH_A];
   const double* pb[NCH_B];
-  stage_ptrs<BM, BK, A_KC, VEC, T, NCH_A>(pa, A, g.lda, m0, kbeg + BK, g.M, tid);   // tile 1 is the first one the pointer-bump loader fetches
+  stage_ptrs<BM, BK, A_KC, VEC, T, NCH_A>(pa, A, g.lda, m0, kbeg + BK, g.M, tid, g.a_slab, g.a_slab_skip);   // tile 1 is the first one the pointer-bump loader fetches
   stage_ptrs<BN, BK, B_KC, VEC, T, NCH_B>(pb, B, g.ldb, n0, kbeg + BK, g.N, tid);
   const long long step_a = A_KC ? (long long)BK : (long long)BK * g.lda;
   const long long step_b = B_KC ? (long long)BK : (long long)BK * g.ldb;
@@ -308,7 +312,7 @@ __device__ __forceinline__ void dgemm_mfma_body(const uint3 BID, const uint3 GDI
   constexpr bool FAST = (VEC == 2);
   auto fetch_a = [&](double (&r)[NCH_A][VEC], int tt) {
     if (FAST && tt + 1 < nk) stage_load_fast<BM, BK, A_KC, VEC, T, NCH_A>(r, pa, step_a, tid);
-    else if (tt < nk) stage_load<BM, BK, A_KC, VEC, T, NCH_A>(r, A, g.lda, m0, kbeg + tt * BK, g.M, kend, tid);
+    else if (tt < nk) stage_load<BM, BK, A_KC, VEC, T, NCH_A>(r, A, g.lda, m0, kbeg + tt * BK, g.M, kend, tid, g.a_slab, g.a_slab_skip);
   };
   auto fetch_b = [&](double (&r)[NCH_B][VEC], int tt) {
     if (FAST && tt + 1 < nk) stage_load_fast<BN, BK, B_KC, VEC, T, NCH_B>(r, pb, step_b, tid);
@@ -318,7 +322,7 @@ __device__ __forceinline__ void dgemm_mfma_body(const uint3 BID, const uint3 GDI
   // prologue: tile 0 -> LDS buffer 0; with a two-deep operand, tile 1 is already requested
   long long pst[4] = {0, 0, 0, 0};     // TAG == 2: prologue stamps
   if constexpr (TAG == 2) pst[0] = __builtin_amdgcn_s_memtime();
-  stage_load<BM, BK, A_KC, VEC, T, NCH_A>(ra[0], A, g.lda, m0, kbeg, g.M, kend, tid);
+  stage_load<BM, BK, A_KC, VEC, T, NCH_A>(ra[0], A, g.lda, m0, kbeg, g.M, kend, tid, g.a_slab, g.a_slab_skip);
   stage_load<BN, BK, B_KC, VEC, T, NCH_B>(rb[0], B, g.ldb, n0, kbeg, g.N, kend, tid);
   stage_store<BM, BK, A_KC, VEC, T, NCH_A>(ra[0], sA0, tid);
   stage_store<BN, BK, B_KC, VEC, T, NCH_B>(rb[0], sB0, tid);
@@ -593,6 +597,11 @@ static int launch_cfg(const GemmDesc& d, hipStream_t s) {
   g.alpha = d.alpha; g.beta = d.beta;
   g.cyc = nullptr; g.cyc2 = nullptr;
   g.sb_m = g.sb_n = 0;
+  g.a_slab = 0; g.a_slab_skip = 0;
+  if (d.a_slab > 0) {
+    if (A_KC || d.batch != 1 || d.a_slab > 0x3fffffff || (VEC == 2 && (d.a_slab % 2 || d.a_slab_skip % 2))) { set_error("dev_gemm: a_slab needs a !a_kcontig A operand, batch = 1 and (16-byte loads) an even slab"); return QEMB_ERR_ARG; }
+    g.a_slab = (int)d.a_slab; g.a_slab_skip = d.a_slab_skip;
+  }
   {
     // super-blocks of 32 tiles (the workgroups one XCD runs at a time at one workgroup per CU): the shape that moves the fewest operand bytes
     // per k-step, sb_m x |A tile| + sb_n x |B tile|, among the shapes that divide the tile grid (QEMB_GEMM_SB=0: the m-fastest walk, for A/B runs)

@@ -10,6 +10,8 @@ number bench.py's parity field compares) and the DIIS solve to |dE| < 1e-11.  Ab
     python tests/golden/make_golden_frag220.py            (writes tests/golden/frag220.npz: fragment 0)
     python tests/golden/make_golden_frag220.py 1 2        (round 4: fragments 1 and 2 of the same sweep, seeds 20260804 / 05,
                                                            -> tests/golden/frag220_f1.npz, frag220_f2.npz)
+    python tests/golden/make_golden_frag220.py 132:12     (round 5: the mid-size point of bench.py's size sweep, n = 132, n_occ = 12, same family and seed,
+                                                           ERI scale 0.06 (55 / n)^(1/2) as tools/size_sweep.py -> tests/golden/frag132.npz; a minute)
 """
 import sys
 import time
@@ -35,10 +37,11 @@ def bench_fragment(n, seed, scale):
     return h, B
 
 
-def main(frag=0):
+def main(frag=0, n=N, o=O, scale=SCALE):
+    N, O, SCALE = n, o, scale          # (shadow the module constants: the body below is written in their terms)
     t0 = time.time()
     seed = SEED + frag
-    out = "frag220.npz" if frag == 0 else f"frag220_f{frag}.npz"
+    out = ("frag220.npz" if frag == 0 else f"frag220_f{frag}.npz") if n == 220 else f"frag{n}.npz"
     h, B = bench_fragment(N, seed, SCALE)
     naux = B.shape[0]
     Bf = B.reshape(naux, -1)
@@ -71,5 +74,9 @@ def main(frag=0):
 
 
 if __name__ == "__main__":
-    for f in ([int(a) for a in sys.argv[1:]] or [0]):
-        main(f)
+    for a in (sys.argv[1:] or ["0"]):
+        if ":" in a:
+            nn, oo = (int(x) for x in a.split(":"))
+            main(0, nn, oo, 0.06 * min(1.0, (55.0 / nn) ** 0.5))
+        else:
+            main(int(a))

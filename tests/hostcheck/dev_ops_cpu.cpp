@@ -81,7 +81,9 @@ int dev_gemm(const GemmDesc& g0) {
     const double* A = g.A + b * g.strideA; const double* B = g.B + b * g.strideB; double* C = g.C + b * g.strideC;
     // pack to contiguous row-major A(MxK), B(KxN) for a cache-friendly triple loop
     std::vector<double> a((size_t)g.M * g.K), bb((size_t)g.K * g.N);
-    for (int64_t m = 0; m < g.M; ++m) for (int64_t k = 0; k < g.K; ++k) a[m * g.K + k] = g.a_kcontig ? A[m * g.lda + k] : A[k * g.lda + m];
+    if (g.a_slab > 0 && (g.a_kcontig || g.batch != 1)) { set_error("dev_gemm: a_slab needs a !a_kcontig A operand and batch = 1"); return QEMB_ERR_ARG; }
+    for (int64_t m = 0; m < g.M; ++m) for (int64_t k = 0; k < g.K; ++k)
+      a[m * g.K + k] = g.a_kcontig ? A[m * g.lda + k] : A[k * g.lda + m + (g.a_slab > 0 ? (m / g.a_slab) * g.a_slab_skip : 0)];
     for (int64_t k = 0; k < g.K; ++k) for (int64_t n = 0; n < g.N; ++n) bb[k * g.N + n] = g.b_kcontig ? B[n * g.ldb + k] : B[k * g.ldb + n];
     std::vector<double> row((size_t)g.N);
     for (int64_t m = 0; m < g.M; ++m) {

@@ -248,6 +248,45 @@ def test_bench_fragment_n220_against_oracle(qlib, frag):
     fr.free()
 
 
+def test_mid_size_fragment_n132_against_oracle(qlib):
+    """The mid-size point of bench.py's size sweep (n = 132, n_occ = 12: rings on 64 x 64 tiles, ladder on the 80 x 128 tile of round 5, graph-replayed update)
+    against the oracle's stored results (tests/golden/frag132.npz, make_golden_frag220.py 132:12): fragment RHF, three plain updates, the converged solve --
+    with the fragment living on its factor and with the 4-fold block resident (four-index route)."""
+    import sys
+    from helpers import GOLDEN
+    from quemb_amd._lib import DeviceBuffer, check
+    if str(GOLDEN) not in sys.path:
+        sys.path.insert(0, str(GOLDEN))
+    import make_golden_frag220 as mg
+    g = np.load(GOLDEN / "frag132.npz")
+    n, o = int(g["n"]), int(g["o"])
+    assert (n, o) == (132, 12)
+    h, B = mg.bench_fragment(n, int(g["seed"]), float(g["scale"]))
+    il = np.tril_indices(n)
+    Bp = np.ascontiguousarray(B[:, il[0], il[1]])
+    opts = default_opts(cc_conv_tol=1e-11, cc_conv_tol_normt=1e-9, scf_conv_tol=1e-12, scf_conv_tol_grad=1e-8)
+    for mode in ("factor", "block"):
+        fr = DeviceFragment(n, 22)
+        if mode == "factor":
+            fr.set_df_only(Bp)
+        else:
+            fr.set_eri_s4(Bp.T @ Bp); fr.set_mo_route(0)
+        r = fr.scf(o, h, None, opts=opts)
+        assert abs(r["e_scf"] - float(g["e_scf"])) < 1e-8 * max(1.0, abs(float(g["e_scf"])))
+        assert np.abs(r["mo_energy"] - g["mo_energy"]).max() < 1e-8
+        dm0 = 2.0 * r["mo_coeff"][:, :o] @ r["mo_coeff"][:, :o].T
+        fr.prepare_ccsd(o, h, dm0, opts=opts)
+        e3, _ = fr.ccsd_iterate(3)
+        assert abs(e3 - float(g["e_corr_3_plain_updates"])) < 1e-9, (mode, e3, float(g["e_corr_3_plain_updates"]))
+        out = fr.solve(o, h, dm0, opts=opts, eeval=False, want_t2=True)
+        assert fr.mo_route_used()[0] == (mode == "factor")
+        assert abs(out["e_corr_mo"] - float(g["e_corr"])) < TOL_E, (mode, out["e_corr_mo"], float(g["e_corr"]))
+        assert abs(out["n_iter"] - int(g["n_iter"])) <= 1
+        assert np.abs(out["rdm1_emb"] - g["rdm1_emb"]).max() < TOL_RDM
+        assert abs(np.linalg.norm(out["t1"]) - float(g["t1_norm"])) < 1e-7 and abs(np.linalg.norm(out["t2"]) - float(g["t2_norm"])) < 1e-7
+        fr.free()
+
+
 def test_factor_route_equals_four_index(qlib):
     """the 3-index factor route of the MO integrals on the HIP library: the checker of the host-logic suite at sizes that reach the tiled kernels
     (24 ... 96 orbitals; relaxed densities, energies with eeval, CPHF), then the DF transform's hand-over of its factor to the fragment"""

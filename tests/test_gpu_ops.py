@@ -966,3 +966,17 @@ def test_diagnostic_gemm_configs_are_not_reachable(qlib):
     for cfg in (313, 413, 513, 613, 304, 404):
         with pytest.raises(Exception, match="diagnostic"):
             _gemm(qlib, A, B, C0, 1.0, 0.0, 1, 1, cfg=cfg)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,npairs,cfg", [(220, 37, 34), (220, 5, -1), (222, 9, 34), (96, 40, -1), (45, 7, -1), (10, 3, 2), (64, 50, 1)])
+def test_gemm_slab_rows_is_the_batched_transposed_product(qlib, n, npairs, cfg):
+    """GemmDesc::a_slab (round 5): the rows (pair, q) of a stack of n x n slabs X[pair][k][q] read as ONE tall !a_kcontig operand --
+    Out[(pair, q)][p'] = sum_k X[pair][k][q] C[k][p'], i.e. (C^T X[pair])^T slab by slab: the last quarter transform of mo_transform as a flat product."""
+    rng = np.random.default_rng(n + npairs)
+    X = rng.standard_normal((npairs, n, n)); Cm = rng.standard_normal((n, n))
+    dX, dC, dO = DeviceBuffer.from_numpy(X), DeviceBuffer.from_numpy(Cm), DeviceBuffer(npairs * n * n)
+    check(qlib.qemb_op_gemm_slab_rows(npairs * n, n, n, dX.ptr, n, n, n * n - n, dC.ptr, n, 0, dO.ptr, n, cfg))
+    got = dO.numpy((npairs, n, n))
+    ref = np.einsum("Pkq,kp->Pqp", X, Cm)
+    assert np.abs(got - ref).max() < 1e-12 * n
