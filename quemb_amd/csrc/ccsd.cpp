@@ -593,6 +593,8 @@ int CcsdSolver::update_amps(double* t1n, double* t2n) {
   const int64_t ring_tiles96 = ((nov + 95) / 96) * ((nov + 95) / 96);
   static const bool ring96_on = std::getenv("QEMB_RING96") && std::atoi(std::getenv("QEMB_RING96")) != 0;
   const bool ring96 = ring96_on && nov >= 1024 && nov < 2048 && (nov % 2) == 0 && ring_tiles96 >= 200 && ring_tiles96 <= 256;
+  // (measured and not kept, round 5: eight n = 132 fragments in lock step with their ring products grouped on 128 x 128 tiles -- 10.8 ms per lock-step
+  //  iteration against 10.4 ms on the 64 x 64 tile, and four streams beat both)
   const int cfg_ring = (nov >= 2048) ? 4 : ring96 ? 37 : (nov >= 256 && ring_tiles64 >= 200) ? 1 : -1;
   auto ring = [&](double al, const double* A, const double* Bsym, double be, double* C) {
     return gemm(nov, nov, nov, al, A, nov, true, Bsym, nov, true, be, C, nov, 1, 0, 0, 0, cfg_ring);

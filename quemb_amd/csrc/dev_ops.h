@@ -111,7 +111,7 @@ struct GemmDesc {
   double* C; int64_t ldc; int64_t strideC;
   int64_t batch;
   int cfg = -1;        // tile configuration override (-1: automatic)
-  int ksplit = 0;      // split-K override (0: automatic)
+  int ksplit = 0;      // split-K override (0: automatic, < 0: never)
   // keep_slabs (needs ksplit > 1, alpha = 1, beta = 0, batch = 1): the K slices' partial products stay where they are -- C receives
   // gemm_slab_count(K, ksplit) slabs [M][N] (ld = N, ldc ignored) and the consumer adds them up in slab order (what the reduction pass would do)
   int keep_slabs = 0;

@@ -627,7 +627,7 @@ static int launch_cfg(const GemmDesc& d, hipStream_t s) {
     chunk = (chunk + 31) / 32 * 32;
     const long long S = (d.K + chunk - 1) / chunk;
     if (S > 1 && S * d.batch <= 65535) { g.ksplit = (int)S; g.kchunk = (int)chunk; }
-  } else if (t_gemm_splitk_enabled && tiles < 256 && d.K >= 1024) {
+  } else if (d.ksplit == 0 && t_gemm_splitk_enabled && tiles < 256 && d.K >= 1024) {      // (ksplit < 0: the caller wants NO split -- its product runs beside others that fill the chip)
     long long S = (768 + tiles - 1) / tiles;
     if (S > d.K / 256) S = d.K / 256;
     if (S > 1) {

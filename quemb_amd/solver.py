@@ -117,7 +117,7 @@ def fragment_work_bytes(n, o=None):
 
 def sweep_mode(frags, nstreams=None, lockstep=None, mem_free=None):
     """How the fragments of a sweep share the GPU when the caller leaves it open (BE(..., nstreams=None, lockstep=None)):
-    many small fragments (>= 5 of at most 64 embedding orbitals, or >= 4 of at most 48: launch bound) advance in lock step -- one grouped launch per
+    many small fragments (>= 4 of at most 64 embedding orbitals: launch bound) advance in lock step -- one grouped launch per
     operation for all of them;
     otherwise several fragments are in flight on separate streams: up to six small ones, up to four of at most 256 orbitals, two beyond --
     and never more than the device memory that is free (`mem_free` bytes; taken from the fragments' library when they are on a device)
@@ -129,7 +129,8 @@ def sweep_mode(frags, nstreams=None, lockstep=None, mem_free=None):
     if lockstep is None:          # (an explicit nstreams is a request for that many streams, not for the lock step)
         # (round 4: four fragments of 36 orbitals -- the periodic configs[4] cell -- run 6.8 ms in lock step against 9.5 ms on four streams;
         #  four of ~55, octane BE3, tie at 28-29 ms)
-        lockstep = nstreams is None and ((len(frags) >= 5 and nmax <= 64) or (len(frags) >= 4 and nmax <= 48))
+        # (round 5: with the update's parallel regions four fragments of ~55 orbitals -- octane BE3 -- run 26.5 ms in lock step against 28.7 ms on four streams)
+        lockstep = nstreams is None and len(frags) >= 4 and nmax <= 64
     if nstreams is None:
         nstreams = 1 if len(frags) <= 1 else (min(6, len(frags)) if nmax <= 96 else min(4 if nmax <= 256 else 2, len(frags)))
         if nstreams > 1 and nmax > 96:

@@ -235,7 +235,7 @@ def test_pair_packed_transform_helpers(qlib):
         assert np.array_equal(dVm.numpy((nmv, ldm)), dVm2.numpy((nmv, ldm)))
 
 
-@pytest.mark.parametrize("n", [2, 7, 42, 131, 220])
+@pytest.mark.parametrize("n", [2, 7, 42, 57, 80, 81, 90, 96, 97, 131, 220])
 def test_jacobi_eigh(qlib, n):
     rng = np.random.default_rng(13 + n)
     A = rng.standard_normal((n, n)); A = A + A.T

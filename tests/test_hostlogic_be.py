@@ -618,7 +618,7 @@ def test_sweep_mode_choice():
     from types import SimpleNamespace as F
     from quemb_amd.solver import sweep_mode
     assert sweep_mode([F(nao=42)] * 6) == (6, True)            # octane BE2: lock step
-    assert sweep_mode([F(nao=55)] * 4) == (4, False)           # octane BE3: four streams
+    assert sweep_mode([F(nao=55)] * 4) == (4, True)            # octane BE3: lock step since round 5 (26.5 vs 28.7 ms on four streams)
     assert sweep_mode([F(nao=36)] * 4) == (4, True)            # the periodic configs[4] cell: four small fragments, lock step (6.8 vs 9.5 ms)
     assert sweep_mode([F(nao=36)] * 3) == (3, False)
     assert sweep_mode([F(nao=220)] * 8) == (4, False)          # large fragments: four in flight

@@ -154,7 +154,7 @@ def run(lib, sizes=SIZES, log=None):
     return dict(peak_tflops=PEAK, rows=rows,
                 what="synthetic family of SURVEY 8d per fragment size: single_stream = one fragment, one stream (iteration_ms = HIP-event bracket of a whole CCSD iteration, "
                      "tflops_iteration = executed FP64 product flops of one amplitude update / iteration_ms; iterations_per_s over whole warm solves incl. fragment RHF, MO integrals, "
-                     "RDMs and energies); best_mode = several fragments of that size at once (lock step up to n = 64, separate streams beyond), "
+                     "RDMs and energies); best_mode = several fragments of that size at once (lock step up to n = 64, separate streams beyond -- eight n = 96 / 132 fragments in lock step were measured no better than four streams; the single-stream figure when that is the better one), "
                      "tflops_whole_solve = iterations x executed flop per iteration / wall time of the whole solves")
 
 
