@@ -276,26 +276,27 @@ int CcsdSolver::energy(const double* t1, const double* t2, double* e) {
   // E = sum (2 ovov[iajb] - ovov[ibja]) tau[ijab] = <Loovv, tau>   (f_ov = 0)
   QTRY(make_tau(t1, t2, tau_));
   QTRY(dev_dot((int64_t)o_ * o_ * v_ * v_, Loovv_, tau_, scal_));
-  QTRY(dev_d2h(e, scal_, sizeof(double)));
+  if (e) QTRY(dev_d2h(e, scal_, sizeof(double)));      // (null: the value stays in scal_[0] -- fetch_energy)
   return 0;
 }
+int CcsdSolver::fetch_energy() { return dev_d2h(&ecc_, scal_, sizeof(double)); }
 
-int CcsdSolver::init_amps() {
+int CcsdSolver::init_amps(bool defer_energy) {
   const int64_t o = o_, v = v_;
   QTRY(dev_fill(t1(), o * v, 0.0));                                      // t1 = f_ov / e_ia = 0
   QTRY(dcopy(o * o * v * v, OVoovv_, t2()));                             // t2 = ovov[i,a,j,b] / e_ijab
   QTRY(dev_div_denom(t2(), o, o, v, v, eo_, eo_, ev_, ev_));
   first_ = true;
   diis_.clear();
-  return energy(t1(), t2(), &ecc_);
+  return energy(t1(), t2(), defer_energy ? nullptr : &ecc_);
 }
 
-int CcsdSolver::set_amps(const double* t1d, const double* t2d) {
+int CcsdSolver::set_amps(const double* t1d, const double* t2d, bool defer_energy) {
   QTRY(dev_d2d(t1(), t1d, sizeof(double) * o_ * v_));
   QTRY(dev_d2d(t2(), t2d, sizeof(double) * (int64_t)o_ * o_ * v_ * v_));
   first_ = true;
   diis_.clear();
-  return energy(t1(), t2(), &ecc_);
+  return energy(t1(), t2(), defer_energy ? nullptr : &ecc_);
 }
 
 // tile configuration and K split for the "few packed pair rows x many columns" GEMMs (ladder, tau-side dressing)

@@ -56,8 +56,10 @@ class CcsdSolver {
                                   std::vector<double>&, std::vector<int>&, std::vector<char>&, LockstepStats*);
  public:
   int setup(MoIntegrals&& ints, const double* mo_energy_dev);
-  int init_amps();                                  // MP2 guess (t1 = 0 for the diagonal Fock)
-  int set_amps(const double* t1_dev, const double* t2_dev);   // warm start
+  // defer_energy: the energy of the guess stays on the device (the launches may be captured for a tape); fetch_energy() reads it back afterwards
+  int init_amps(bool defer_energy = false);         // MP2 guess (t1 = 0 for the diagonal Fock)
+  int set_amps(const double* t1_dev, const double* t2_dev, bool defer_energy = false);   // warm start
+  int fetch_energy();
   int iterate(double* e_corr, double* normt);       // one update_amps + DIIS + energy
   int iterate_update(bool prefer_tape, bool defer_tape, bool* deferred);   // the two halves of iterate(), for the lock-step sweep
   int iterate_post(double* e_corr, double* normt);

@@ -360,8 +360,19 @@ int dev_pinned_free(void* p) {
   g_pinned_live.erase(it);
   return QEMB_OK;
 }
+// (inside a capture a device-to-device copy is issued as a KERNEL: a captured hipMemcpyAsync becomes a memcpy node whose parameters this runtime hands back in a
+//  form neither hipMemcpy3DAsync nor a linear replay accepts, and tapes replay node by node)
+__global__ void __launch_bounds__(256) copy_words_kernel(double* __restrict__ dst, const double* __restrict__ src, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) dst[i] = src[i];
+}
 int dev_d2d(void* dst, const void* src, size_t bytes) {
   REQUIRE_INIT();
+  if (g_capturing && bytes % 8 == 0 && ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 7) == 0) {
+    const long long n = (long long)(bytes / 8);
+    if (n > 0) hipLaunchKernelGGL(copy_words_kernel, dim3((unsigned)std::min<long long>((n + 255) / 256, 4096)), dim3(256), 0, g_stream, (double*)dst, (const double*)src, n);
+    HIP_TRY(hipGetLastError());
+    return QEMB_OK;
+  }
   HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, g_stream));
   return QEMB_OK;
 }
@@ -531,7 +542,12 @@ static int tape_issue_single(const TapeNode& n, hipStream_t s) {
   if (n.type == hipGraphNodeTypeKernel) {
     HIP_TRY(hipLaunchKernel(n.k.func, n.k.gridDim, n.k.blockDim, n.k.kernelParams, n.k.sharedMemBytes, s));
   } else if (n.type == hipGraphNodeTypeMemcpy) {
-    HIP_TRY(hipMemcpy3DAsync(&n.cpy, s));
+    // (a captured 1-D hipMemcpyAsync comes back as 3-D parameters with extent {bytes, 1, 1}; hipMemcpy3DAsync refuses them -- invalid argument -- so the
+    //  linear case is replayed as the linear copy it was)
+    const hipMemcpy3DParms& c = n.cpy;
+    if (c.extent.height <= 1 && c.extent.depth <= 1 && !c.srcArray && !c.dstArray && c.dstPtr.ptr && c.srcPtr.ptr && c.extent.width > 0)
+      HIP_TRY(hipMemcpyAsync((char*)c.dstPtr.ptr + c.dstPos.x, (const char*)c.srcPtr.ptr + c.srcPos.x, c.extent.width, c.kind, s));
+    else HIP_TRY(hipMemcpy3DAsync(&n.cpy, s));
   } else if (n.type == hipGraphNodeTypeMemset) {
     if (n.set.height <= 1) {
       if (n.set.elementSize == 1) HIP_TRY(hipMemsetAsync(n.set.dst, (int)n.set.value, n.set.width, s));

@@ -385,12 +385,40 @@ int Fragment::solve_batch(const std::vector<Fragment*>& frs, const std::vector<i
     for (int f = 0; f < F; ++f) if (rc[f] < 0 && worst == 0) { worst = rc[f]; set_error("fragment " + std::to_string(f) + ": " + msg[f]); }
     return worst;
   };
+  // Before the iterations: the fragment RHF per fragment (host round trips inside), then MO integrals + CCSD set-up + starting amplitudes.  The latter is a pure
+  // launch sequence (~60 launches per small fragment) and CAN be recorded as a tape per fragment and run merged on the home stream like the iterations
+  // (QEMB_TAPE_PREPHASE=1).  Measured in round 5 and left off: recording the sequence anew every sweep (stream capture + node queries) and running the merged
+  // sequence serially costs more than six streams issuing it side by side -- octane BE2 begin phase 3.1 -> 3.9 ms, BE3 sweep 26.9 -> 27.8 ms.
+  static const bool tape_pre = std::getenv("QEMB_TAPE_PREPHASE") && std::atoi(std::getenv("QEMB_TAPE_PREPHASE")) != 0;
+  QTRY(per_fragment([&](int f) { return frs[f]->solve_begin_scf(o[f], h[f], dm0[f], opt, eeval, &res[f]); }));
+  std::vector<dev_tape_t> pre(F, nullptr);
+  std::vector<char> taped(F, 0);
+  struct PreTapes { std::vector<dev_tape_t>& t; ~PreTapes() { for (dev_tape_t x : t) if (x) (void)dev_tape_destroy(x); } } pre_guard{pre};
+  const bool small_all = [&] { for (int f = 0; f < F; ++f) { const int64_t oo = o[f], vv = frs[f]->n_ - o[f]; if (oo * oo * vv * vv > ((int64_t)1 << 22)) return false; } return true; }();
+  const bool try_tape = tape_pre && threaded && small_all && opt.relax_density == 0;
   QTRY(per_fragment([&](int f) {
-    int r = frs[f]->solve_begin(o[f], h[f], dm0[f], opt, eeval, &res[f]);
+    int r = 0;
+    if (try_tape && !frs[f]->sp_.no_virtuals && dev_graph_begin(1) == 0) {
+      const int rc_cc = frs[f]->solve_begin_cc(true);
+      dev_tape_t t = nullptr;
+      const int rc_end = dev_tape_end(&t);
+      if (rc_cc == 0 && rc_end == 0 && t) { pre[f] = t; taped[f] = 1; }
+      else { if (t) (void)dev_tape_destroy(t); frs[f]->cc_.reset(); }      // (what failed shows again in the eager pass below)
+    }
+    if (!taped[f]) r = frs[f]->solve_begin_cc(false);
     if (r == 0 && frs[f]->cc_ && F > 1) r = frs[f]->cc_->prepare_tape(F);      // recorded side by side; a lone fragment keeps its executable graph
     if (r == 0) r = dev_sync();                                               // the lock-step loop reads this fragment's buffers from another stream
     return r;
   }));
+  {
+    std::vector<dev_tape_t> run;
+    for (int f = 0; f < F; ++f) if (taped[f]) run.push_back(pre[f]);
+    if (!run.empty()) {
+      QTRY(dev_tape_run(run.data(), (int)run.size()));      // on the calling thread's (home) stream
+      QTRY(dev_sync());
+      for (int f = 0; f < F; ++f) if (taped[f]) QTRY(frs[f]->cc_->fetch_energy());
+    }
+  }
   const double t_begin_done = now();
   std::vector<CcsdSolver*> solvers; std::vector<int> idx, ctx; std::vector<CcsdOptions> copt;
   for (int f = 0; f < F; ++f) if (!frs[f]->sp_.no_virtuals) { solvers.push_back(frs[f]->cc_.get()); idx.push_back(f); ctx.push_back(threaded ? f + 1 : 0); copt.push_back(opt.cc); }
@@ -414,6 +442,10 @@ int Fragment::solve_batch(const std::vector<Fragment*>& frs, const std::vector<i
 }
 
 int Fragment::solve_begin(int o, const double* h, const double* dm0, const FragmentOptions& opt, int eeval, FragmentResult* res) {
+  QTRY(solve_begin_scf(o, h, dm0, opt, eeval, res));
+  return solve_begin_cc(false);
+}
+int Fragment::solve_begin_scf(int o, const double* h, const double* dm0, const FragmentOptions& opt, int eeval, FragmentResult* res) {
   sp_ = SolvePending();
   sp_.o = o; sp_.opt = opt; sp_.eeval = eeval; sp_.res = res;
   last_route_factor_ = false;
@@ -422,42 +454,43 @@ int Fragment::solve_begin(int o, const double* h, const double* dm0, const Fragm
   const int n = n_, v = n - o;
   // nsocc == n: an embedding space without virtual orbitals.  PySCF's CCSD then has empty amplitude arrays and returns E_corr = 0; the
   // sweep body needs the mean-field results only (density = 2 I in any orthonormal basis, no correlation contribution to the energies).
-  const bool no_virtuals = (v == 0);
   const int64_t n2 = (int64_t)n * n;
   cc_.reset();
   // ---- fragment RHF on the half-unpacked tensor [P(p,q)][r][s] (kept: it is the first operand of the MO transformation)
-  DBuf X1;
-  bool x1_unpacked = false;
-  QTRY(scf_operand(X1, &x1_unpacked));         // [P(p,q)][r][s] for the four-index route (kept: its first operand); nothing on the factor route
+  QTRY(scf_operand(sp_.X1, &sp_.x1_unpacked));         // [P(p,q)][r][s] for the four-index route (kept: its first operand); nothing on the factor route
   ScfResult sres;
-  QTRY(run_scf(o, h, dm0, opt.scf, X1, &sres, opt.warm_start != 0));
+  QTRY(run_scf(o, h, dm0, opt.scf, sp_.X1, &sres, opt.warm_start != 0));
   res->scf_converged = sres.converged; res->scf_cycles = sres.cycles; res->e_scf = sres.e_tot;
-  bool& unconverged = sp_.unconverged;
-  sp_.no_virtuals = no_virtuals;
+  sp_.no_virtuals = (v == 0);
   if (!sres.converged) {
     set_error("fragment SCF did not converge (also not with level shift 0.2)");
     if (opt.strict) return QEMB_ERR_NOCONV;
-    unconverged = true;
+    sp_.unconverged = true;
   }
-  std::vector<double>& C = sp_.C; std::vector<double>& eps = sp_.eps;
-  C.assign((size_t)n2, 0.0); eps.assign((size_t)n, 0.0);
-  QTRY(dev_d2h(C.data(), C_, sizeof(double) * n2));
-  QTRY(dev_d2h(eps.data(), eps_, sizeof(double) * n));
-  // ---- integrals + CCSD
-  if (no_virtuals) {
-    X1.release();
+  sp_.C.assign((size_t)n2, 0.0); sp_.eps.assign((size_t)n, 0.0);
+  QTRY(dev_d2h(sp_.C.data(), C_, sizeof(double) * n2));
+  QTRY(dev_d2h(sp_.eps.data(), eps_, sizeof(double) * n));
+  return 0;
+}
+// ---- integrals + CCSD set-up + starting amplitudes: launches only (allocations come from the context's pool once a sweep has run)
+int Fragment::solve_begin_cc(bool defer_energy) {
+  const int o = sp_.o, v = n_ - o;
+  const FragmentOptions& opt = sp_.opt;
+  FragmentResult* res = sp_.res;
+  if (sp_.no_virtuals) {
+    sp_.X1.release();
     res->e_corr_mo = 0.0; res->n_iter = 0; res->ccsd_converged = true; res->lambda_iters = 0;
-  } else {
+    return 0;
+  }
   MoIntegrals ints;
-  QTRY(mo_integrals(o, eeval ? nf_ : 0, X1, x1_unpacked, ints, /*build_Vl=*/false, /*build_T34=*/opt.relax_density != 0));
-  X1.release();
+  QTRY(mo_integrals(o, sp_.eeval ? nf_ : 0, sp_.X1, sp_.x1_unpacked, ints, /*build_Vl=*/false, /*build_T34=*/opt.relax_density != 0));
+  sp_.X1.release();
   cc_.reset(new CcsdSolver());
   QTRY(cc_->setup(std::move(ints), eps_));
   if (opt.warm_start && t_prev_.p && t_prev_o_ == o) {
-    QTRY(cc_->set_amps(t_prev_.p, t_prev_.p + (int64_t)o * v));
+    QTRY(cc_->set_amps(t_prev_.p, t_prev_.p + (int64_t)o * v, defer_energy));
   } else {
-    QTRY(cc_->init_amps());
-  }
+    QTRY(cc_->init_amps(defer_energy));
   }
   return 0;
 }

@@ -73,6 +73,10 @@ class Fragment {
   // The same in three steps -- everything before the CCSD iterations, (the iterations: cc_->kernel or the lock-step loop of solve_batch),
   // everything after -- so that several fragments can share the middle step.
   int solve_begin(int o, const double* h, const double* dm0, const FragmentOptions& opt, int eeval, FragmentResult* res);
+  // ... and solve_begin itself in two halves: the fragment RHF (host round trips inside), then MO integrals + CCSD set-up + starting amplitudes -- a pure launch
+  // sequence, which solve_batch records as a tape per fragment and runs merged for all fragments (defer_energy: the guess's energy is fetched afterwards)
+  int solve_begin_scf(int o, const double* h, const double* dm0, const FragmentOptions& opt, int eeval, FragmentResult* res);
+  int solve_begin_cc(bool defer_energy);
   int solve_end(double* mo_coeff, double* mo_energy, double* rdm1_emb, double* rdm1_mo, double* t1, double* t2);
   struct BatchOutputs { double *mo_coeff = nullptr, *mo_energy = nullptr, *rdm1_emb = nullptr, *rdm1_mo = nullptr, *t1 = nullptr, *t2 = nullptr; };
   // every fragment of a sweep in one call: solve_begin / solve_end per fragment on its own execution context (host thread + stream),
@@ -121,6 +125,7 @@ class Fragment {
     int o = 0, eeval = 0; FragmentOptions opt; FragmentResult* res = nullptr;
     bool unconverged = false, no_virtuals = false;
     std::vector<double> C, eps;
+    DBuf X1; bool x1_unpacked = false;      // the half-unpacked tensor between the two halves of solve_begin (four-index route)
   } sp_;
   // state of the last solve
   DBuf C_, eps_, dm_, J_, K_;

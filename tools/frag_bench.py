@@ -46,10 +46,15 @@ if __name__ == "__main__":
     t0 = time.time()
     h, d4, dB, naux = synthetic_on_device(lib, n, 20260803)
     fr = DeviceFragment(n, min(22, n // 2))
-    fr.set_eri_s4_dev(d4.ptr); d4.free()
-    # "four-index" among the arguments: the four quarter transformations of the packed block instead of the 3-index factor route; "eeval": with the energies' 3/4 blocks
+    # "four-index" among the arguments: the four quarter transformations of the packed block instead of the 3-index factor route; "eeval": with the energies' 3/4 blocks;
+    # "block": keep the 4-fold packed block resident beside the factor (rounds 1-4) -- the default since round 5 is bench.py's: the fragment lives on its factor alone
     four, eeval = "four-index" in sys.argv, "eeval" in sys.argv
-    fr.set_df_factor_dev(dB.ptr, naux); dB.free()
+    if four or "block" in sys.argv:
+        fr.set_eri_s4_dev(d4.ptr)
+        fr.set_df_factor_dev(dB.ptr, naux)
+    else:
+        fr.set_df_only_dev(dB.ptr, naux)
+    d4.free(); dB.free()
     fr.set_mo_route(0 if four else -1)
     if eeval:
         rng = np.random.default_rng(1)
@@ -71,7 +76,7 @@ if __name__ == "__main__":
     v = n - o
     tm = timers(lib)
     lad = tm["ladder"]["ms"] / max(tm["ladder"]["count"], 1)
-    res = dict(n=n, o=o, mo_route="factor" if fr.mo_route_used()[0] else "four-index", eeval=eeval, wall_s=wall, n_iter=out["n_iter"], scf_cycles=out["scf_cycles"], e_corr=out["e_corr_mo"], timers=tm,
+    res = dict(n=n, o=o, mo_route="factor" if fr.mo_route_used()[0] else "four-index", resident_bytes=fr.resident_bytes(), eeval=eeval, wall_s=wall, n_iter=out["n_iter"], scf_cycles=out["scf_cycles"], e_corr=out["e_corr_mo"], timers=tm,
                ladder_ms=lad, ladder_tflops=2.0 * o * o * v ** 4 / (lad * 1e-3) / 1e12 if lad else None,
                iter_ms=tm["iter"]["ms"] / max(tm["iter"]["count"], 1))
     print(json.dumps(res), flush=True)

@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 mkdir -p gpurun_out
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf gpurun_out/hpmc_$c
-  timeout -k 10 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/hpmc_$c -- python tools/frag_bench.py 220 20 > gpurun_out/hpmc_$c.log 2>&1 || echo "rocprofv3 $c left with status $?"
+  timeout -k 10 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/hpmc_$c -- python tools/frag_bench.py 220 20 block > gpurun_out/hpmc_$c.log 2>&1 || echo "rocprofv3 $c left with status $?"
 done
 python tools/hbm_pmc.py gpurun_out/hpmc_FETCH_SIZE gpurun_out/hpmc_WRITE_SIZE > gpurun_out/hbm_pmc.json
 rm -rf gpurun_out/hpmc_FETCH_SIZE gpurun_out/hpmc_WRITE_SIZE

@@ -55,11 +55,8 @@ def nf_cols(n):
     return min(22, n // 2) * n
 
 
-def main():
-    args = [a for a in sys.argv[1:]]
-    files = [f for f in glob.glob(args[0])]
-    shapes = [tuple(int(x) for x in ln.split()) for ln in open(args[1])] if len(args) > 1 else None
-    n, o, naux = (int(args[2]), int(args[3]), int(args[4])) if len(args) > 4 else (220, 20, 660)
+def bytes_table(n, o):
+    """kernel-name fragment -> (algorithmic bytes of one large call, what) at fragment size (n, n_occ)"""
     v = n - o
     npn, npo, nmo, npv, nmv = n * (n + 1) // 2, o * (o + 1) // 2, o * (o - 1) // 2, v * (v + 1) // 2, v * (v - 1) // 2
     N2 = o * o * v * v * 8
@@ -77,6 +74,18 @@ def main():
         "small_k_update": (2 * N2, "rank-n_occ update of an o^2 v^2 tensor (r/w), MFMA"),
         "mirror_lower_kernel": (npn * npn * 8, "mirror of the lower block columns of the pair product (r/w of half the block each)"),
     }
+    return bytes_of
+
+
+bytes_of = bytes_table(220, 20)      # (tools/hbm_pmc.py reads the table of the benchmarked size)
+
+
+def main():
+    args = [a for a in sys.argv[1:]]
+    files = [f for f in glob.glob(args[0])]
+    shapes = [tuple(int(x) for x in ln.split()) for ln in open(args[1])] if len(args) > 1 else None
+    n, o, naux = (int(args[2]), int(args[3]), int(args[4])) if len(args) > 4 else (220, 20, 660)
+    bytes_of = bytes_table(n, o)
     rows = list(csv.DictReader(open(files[0])))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     gemm_rows = [r for r in rows if "dgemm_mfma_kernel<" in r["Kernel_Name"]]
