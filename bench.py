@@ -790,6 +790,10 @@ def kbe_c5_sweeps(lib, reps=20):
 def main():
     global FULL_N, FULL_O, FULL_NF
     args = parse()
+    if os.environ.get("QEMB_BENCH_WATCHDOG_S"):      # diagnostics: the Python stacks of all threads to stderr every so many seconds (where does a silent run sit?)
+        import faulthandler
+        faulthandler.enable(file=sys.stderr, all_threads=True)
+        faulthandler.dump_traceback_later(float(os.environ["QEMB_BENCH_WATCHDOG_S"]), repeat=True, file=sys.stderr)
     FULL_N, FULL_O = args.full_n, args.full_nocc
     FULL_NF = min(FULL_NF, FULL_N // 2)
     if args.cpu_worker:
@@ -1027,7 +1031,7 @@ def main():
                         # when 8 npair^2 bytes per fragment fit beside the work space; otherwise the leg is skipped (the block as a per-solve transient would be timed too)
                         npair_ = n * (n + 1) // 2
                         free_b, total_b = C.c_size_t(), C.c_size_t()
-                        lib.qemb_trim(); lib.qemb_mem_info(C.byref(free_b), C.byref(total_b))
+                        lib.qemb_trim_all(); lib.qemb_mem_info(C.byref(free_b), C.byref(total_b))
                         # (the work space of the fragments in flight is parked in the contexts' pools and is reused: only the blocks are new)
                         if len(mine) * 8.0 * npair_ * npair_ > 0.85 * free_b.value:
                             raise RuntimeError("skipped: the 4-fold packed blocks of this many fragments do not fit")
@@ -1091,7 +1095,7 @@ def main():
                     for f in frs:                      # the headline fragments are done: their HBM goes to the sweep's (n = 300: 16 GB of work space per fragment in flight)
                         if getattr(f, "dev", None) is not None and f is not fr0:
                             f.dev.free()
-                    lib.qemb_trim()
+                    lib.qemb_trim_all()                # (every context's parked work space: ~200 GB after the sections above)
                     sys.path.insert(0, str(ROOT / "tools"))
                     import size_sweep
                     import contextlib

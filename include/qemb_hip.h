@@ -42,6 +42,7 @@ int qemb_mem_info(size_t* free_bytes, size_t* total_bytes);
 int qemb_malloc(void** dptr, size_t bytes);
 int qemb_free(void* dptr);                 /* parks the block for reuse (caching allocator)       */
 int qemb_trim(void);                       /* hand every parked block back to the driver          */
+int qemb_trim_all(void);              /* the same for EVERY execution context (their streams are drained first): between phases with very different working sets */
 int qemb_h2d(void* dptr, const void* host, size_t bytes);
 int qemb_d2h(void* host, const void* dptr, size_t bytes);
 int qemb_d2d(void* dst, const void* src, size_t bytes);

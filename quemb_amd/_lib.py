@@ -61,6 +61,7 @@ def _declare(lib):
     f("qemb_malloc", I, C.POINTER(c_vp), C.c_size_t)
     f("qemb_free", I, V)
     f("qemb_trim", I)
+    f("qemb_trim_all", I)
     f("qemb_h2d", I, V, V, C.c_size_t)
     f("qemb_d2h", I, V, V, C.c_size_t)
     f("qemb_d2d", I, V, V, C.c_size_t)

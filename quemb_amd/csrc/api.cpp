@@ -2,7 +2,11 @@
 // Thin argument marshalling only; the work is in the drivers (ccsd.cpp, scf.cpp, ao2mo.cpp, schmidt.cpp)
 // and the device layer (dev_ops.h).
 #include <cstring>
+#include <cstdlib>
 #include <vector>
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
 #include "../../include/qemb_hip_ops.h"
 #include "dev_ops.h"
 #include "ccsd.h"
@@ -25,7 +29,21 @@ static thread_local int g_test_ksplit = 0;   // qemb_set_gemm_ksplit: split-K ov
 
 extern "C" {
 
-int qemb_init(int device) { return dev_init(device); }
+// QEMB_BACKTRACE=1: native frames to stderr on SIGSEGV / SIGABRT (a debugging aid: where inside the library did a host fault happen?)
+static void qemb_fault_handler(int sig) {
+  void* frames[64];
+  const int nfr = backtrace(frames, 64);
+  const char msg[] = "[qemb] fatal signal; native backtrace:\n";
+  (void)!write(2, msg, sizeof(msg) - 1);
+  backtrace_symbols_fd(frames, nfr, 2);
+  signal(sig, SIG_DFL);
+  raise(sig);
+}
+int qemb_init(int device) {
+  static const bool bt = [] { const char* e = std::getenv("QEMB_BACKTRACE"); if (e && e[0] != '0') { signal(SIGSEGV, qemb_fault_handler); signal(SIGABRT, qemb_fault_handler); } return true; }();
+  (void)bt;
+  return dev_init(device);
+}
 const char* qemb_last_error(void) { return last_error(); }
 const char* qemb_backend(void) { return dev_backend_name(); }
 int qemb_sync(void) { return dev_sync(); }
@@ -34,6 +52,7 @@ int qemb_mem_info(size_t* f, size_t* t) { return dev_mem_info(f, t); }
 int qemb_malloc(void** p, size_t bytes) { return dev_alloc(p, bytes); }
 int qemb_free(void* p) { return dev_free(p); }
 int qemb_trim(void) { return dev_trim(); }
+int qemb_trim_all(void) { return dev_trim_all(); }
 int qemb_h2d(void* d, const void* h, size_t b) { return dev_h2d(d, h, b); }
 int qemb_d2h(void* h, const void* d, size_t b) { return dev_d2h(h, d, b); }
 int qemb_d2d(void* d, const void* s, size_t b) { return dev_d2d(d, s, b); }

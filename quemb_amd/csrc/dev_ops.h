@@ -34,7 +34,8 @@ int dev_ctx_bind(int k);
 int dev_ctx_partition(int parts);
 int dev_alloc(void** p, size_t bytes);
 int dev_free(void* p);                // parks the block in a free list (see dev_trim)
-int dev_trim();                       // release every parked block back to the driver
+int dev_trim();                       // release every parked block back to the driver (the calling context's)
+int dev_trim_all();                   // ... of EVERY context (each context's stream is drained first): between phases of very different working sets
 int dev_h2d(void* dst, const void* src_host, size_t bytes);
 int dev_d2h(void* dst_host, const void* src, size_t bytes);
 // device -> PINNED host memory without waiting: the data are there after the next dev_sync of the calling context (lock-step sweeps read

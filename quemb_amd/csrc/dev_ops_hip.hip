@@ -214,6 +214,8 @@ static void trim_ctx_locked(DevCtx& c) {      // g_alloc_mutex held; the context
   for (auto& kv : c.pool) for (void* q : kv.second) (void)timed_hip_free(q);
   c.pool.clear(); c.pool_bytes = 0;
 }
+static int trim_all_contexts();
+int dev_trim_all() { REQUIRE_INIT(); return trim_all_contexts(); }
 int dev_trim() {
   if (!g_stream) return QEMB_OK;
   HIP_TRY(hipStreamSynchronize(g_stream));
@@ -275,6 +277,16 @@ int dev_alloc(void** p, size_t bytes) {
     ~MissTimer() { g_alloc_misses += 1; g_alloc_miss_bytes += (long long)b; g_alloc_miss_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); }
   } miss_timer;
   miss_timer.b = bytes;
+  {
+    // Do not walk INTO an out-of-memory condition: on this runtime a hipMalloc beyond what is free has been seen to crash inside the HSA allocator (or to hang)
+    // instead of failing (round 5: bench.py's size sweep after the other sections, ~200 GB parked in the pools of seven contexts).  When the request does not fit
+    // what the driver reports free, the parked blocks of every context go back first.
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && bytes + ((size_t)512 << 20) > free_b) {
+      const int rc = trim_all_contexts();
+      if (rc) return rc;
+    }
+  }
   hipError_t e = hipMalloc(p, bytes);
   if (e != hipSuccess) {
     (void)hipGetLastError();

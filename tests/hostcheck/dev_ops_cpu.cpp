@@ -35,6 +35,7 @@ int dev_sync_device() { return QEMB_OK; }
 int dev_alloc(void** p, size_t bytes) { *p = std::malloc(bytes ? bytes : 16); if (!*p) { set_error("malloc failed"); return QEMB_ERR_ALLOC; } return 0; }
 int dev_free(void* p) { std::free(p); return 0; }
 int dev_trim() { return 0; }
+int dev_trim_all() { return dev_trim(); }
 int dev_h2d(void* d, const void* s, size_t b) { std::memcpy(d, s, b); return 0; }
 int dev_d2h(void* d, const void* s, size_t b) { std::memcpy(d, s, b); return 0; }
 int dev_d2h_async(void* d, const void* s, size_t b) { std::memcpy(d, s, b); return 0; }

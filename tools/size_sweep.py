@@ -134,7 +134,7 @@ def one_size(lib, n, o, nbest=None, lockstep_upto=None):
                     sweep_ms=single["solve_ms"], tflops_whole_solve=single["tflops_whole_solve"], frac_of_peak=single["tflops_whole_solve"] / PEAK)
     for f, _ in frs:
         f.free()
-    lib.qemb_trim()
+    lib.qemb_trim_all()      # the next size has other block sizes: nothing parked here is reused
     row = dict(n=n, n_occ=o, n_virt=v, executed_flop_per_iteration=flop_iter, single_stream=single, best_mode=best)
     if skipped:
         row["seeds_skipped_not_converging"] = skipped
