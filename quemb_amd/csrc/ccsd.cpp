@@ -380,12 +380,15 @@ int CcsdSolver::apply_ladder(const double* x, double* out, bool rows_packed, boo
     SlabGemm sp, sm;
     pick_pair_gemm(npo, npv, cfg, ks);
     if (cfg == 13 || cfg == 15) cfg += 10;      // same tiles under the ladder's own kernel symbol (profiles)
+    QTRY(dev_region_begin());
     QTRY(gemm_slabs(npo, npv, ldp, LTp_, ldp, I_.Vp, ldp, LRp_, ldp, cfg, ks, sp));
+    QTRY(dev_region_chain());
     if (nmo > 0 && nmv > 0) {
       pick_pair_gemm(nmo, nmv, cfg, ks);
       if (cfg == 13 || cfg == 15) cfg += 10;
       QTRY(gemm_slabs(nmo, nmv, ldm, LTm_, ldm, I_.Vm, ldm, LRm_, ldm, cfg, ks, sm));
     }
+    QTRY(dev_region_end());
     QTRY(lap_LADDER.close());
     if (hh) {
       // hole-hole ladder on the same packed rows, now as the RIGHT operand (K = packed occupied pairs):
@@ -394,8 +397,11 @@ int CcsdSolver::apply_ladder(const double* x, double* out, bool rows_packed, boo
       // columns of HR+: LTp carries 1/2 there) and writes the sum as the first contribution to `out`
       static const struct { int rows, cfg; } cand[] = {{224, 13}, {192, 15}, {160, 35}, {128, 0}, {64, 1}};
       auto tile_for = [&](int64_t rows) { int best = -1; int64_t pad = -1; for (const auto& c : cand) { const int64_t q = (rows + c.rows - 1) / c.rows * c.rows; if (pad < 0 || q < pad) { pad = q; best = c.cfg; } } return best; };
+      QTRY(dev_region_begin());
       QTRY(gemm(npo, npv, npo, 1.0, WAp_, lwp_, true, LTp_, ldp, false, 0.0, HRp_, ldp, 1, 0, 0, 0, npv >= 2048 ? tile_for(npo) : -1));
+      QTRY(dev_region_chain());
       if (nmo > 0 && nmv > 0) QTRY(gemm(nmo, nmv, nmo, 1.0, WAm_, lwm_, true, LTm_, ldm, false, 0.0, HRm_, ldm, 1, 0, 0, 0, nmv >= 2048 ? tile_for(nmo) : -1));
+      QTRY(dev_region_end());
       QTRY(dev_ladder_scatter_pm2(o, v, LRp_, sp.ld, LRm_, sm.ld, HRp_, (nmo > 0 && nmv > 0) ? HRm_.p : nullptr, 1, out, sp.S, sp.stride, sm.S, sm.stride, ldp, ldm));
     } else {
       QTRY(dev_ladder_scatter_pm2(o, v, LRp_, sp.ld, LRm_, sm.ld, nullptr, nullptr, 0, out, sp.S, sp.stride, sm.S, sm.stride));
@@ -406,80 +412,85 @@ int CcsdSolver::apply_ladder(const double* x, double* out, bool rows_packed, boo
 
 int CcsdSolver::update_amps(double* t1n, double* t2n) {
   const int64_t o = o_, v = v_, nov = o * v, oo = o * o, vv = v * v;
-  const int64_t npo = o * (o + 1) / 2, nmo = o * (o - 1) / 2, npv = v * (v + 1) / 2, nmv = v * (v - 1) / 2;
-  const int64_t ldp = I_.ldp, ldm = I_.ldm;
   const double* t1 = this->t1();
   const double* t2 = this->t2();
-  // The update is written as a sequence of PARALLEL REGIONS (dev_region_*, round 5): inside a region every chain reads only what earlier regions (or the
-  // chain itself) wrote.  Executed eagerly the calls run in program order; in a lock-step sweep of small fragments level k of a region -- the k-th call of every
-  // chain, of every fragment -- is issued together, the same kernel of several chains and fragments in one grouped launch (46 dependent launches -> ~17 levels).
-  // tau_ already holds tau(t1, t2): every change of the amplitudes (init_amps, set_amps, iterate) ends with energy(), which builds it.
-  const int cfg_tall = (o <= 32) ? 20 : -1, cfg_wide = (o <= 32) ? 21 : -1;      // n_occ <= 32 columns / rows: 128 x 32 and 32 x 128 tiles (a 64-wide tile made these HBM-bound passes MFMA-bound)
-  SlabGemm sfvv, swp, swm, spa, spb, slp, slm, sxp, sxm;
-  double fvv_scale = -1.0;
-  double* PA = T1P_.p;
-  double* PB = nullptr;
-
-  // ---- region A: everything that reads the amplitudes and the integrals only
-  QTRY(dev_region_begin());
+  // Parallel regions (dev_region_begin / chain / end, round 5): operations that stand NEXT to each other here and do not depend on each other are
+  // marked as the chains of a region; the lock step of small fragments (dev_tape_run) then issues the same kernel of both chains and of all fragments as
+  // one launch.  Outside a tape capture the calls do nothing.  The order of the operations is the producer-next-to-consumer order of rounds 1-4: a version that
+  // reordered the update into seven wide regions was 0.5-0.8 ms per octane BE2 sweep slower on the same box (operands left the L2 between producer and
+  // consumer) and was withdrawn; marking only neighbours costs nothing on BE2 and gains ~0.7 ms per BE3 sweep.
+  // ---- amplitude layouts.  tau_ already holds tau(t1, t2): every change of the amplitudes (init_amps, set_amps, iterate) ends
+  // with energy(), which builds it.
   // T [k,c,j,b] = t2[k,j,c,b], Tp[k,c,j,b] = t2[k,j,b,c], S = u = 2T - Tp (Theta_ph), and the t1-dressed ring operands
   // u~ = u - 2 t1(x)t1 (W12_), Tp~ = Tp + 2 t1(x)t1 (W12b_), t1(x)t1[(ia),(ld)] = t1[id] t1[la] -- one pass over t2
+  QTRY(dev_region_begin());
   QTRY(dev_ccsd_ph_layouts(o, v, t2, t1, T_, Tp_, S_, W12_, W12b_, R_));   // R_: Th[i,k,d,c] = 2 t2[ikcd] - t2[ikdc], scratch until the rings
   QTRY(dev_region_chain());
-  QTRY(dev_ladder_pack_tau(o, v, tau_, LTp_, ldp, LTm_, ldm));            // the packed tau rows: read by the Woooo build, the ladder and the tau-side dressing
-  QTRY(dev_region_chain());
-  // Fvv'[a,c] = -sum tau[klxa] Loovv[klxc]  (64 x 64 tiles: split-K supplies the blocks; the slabs are added up -- with the sign -- by the pass that forms Lvv')
+  QTRY(dev_ladder_pack_tau(o, v, tau_, LTp_, I_.ldp, LTm_, I_.ldm));     // the packed tau rows: also read by the ladder and by the tau-side dressing below
+  QTRY(dev_region_end());
+
+  // ---- one- and two-index intermediates (energy-shifted: Foo - eps, Fvv - eps, ...)
+  {  // Xw[i,j,k,l] = ovov[kcld] tau[ijcd] (the quadratic part of Woooo, added to it below) over the (+/-) packed (c,d) pairs:  X[ij] = Xp + Xm, X[ji] = Xp - Xm (i > j),
+     //   Xp[P(ij),(kl)] = sum_{c>=d} LTp[P(ij),P(cd)] G+[(kl),P(cd)],  Xm[Q(ij),(kl)] = sum_{c>d} LTm G-   (LTp carries 1/2 on c = d, G+ is doubled there)
+    const int64_t npo = o * (o + 1) / 2, nmo = o * (o - 1) / 2, nmv = v * (v - 1) / 2;
+    auto split = [&](int64_t rows, int64_t K, int& cfg, int& ks) { pick_xw_split(rows, oo, K, cfg, ks); };
+    int cfg, ks;
+    SlabGemm sp, sm;
+    split(npo, I_.ldp, cfg, ks);
+    QTRY(dev_region_begin());
+    QTRY(gemm_slabs(npo, oo, I_.ldp, LTp_, I_.ldp, Gp_, I_.ldp, Xwp_, oo, cfg, ks, sp));
+    QTRY(dev_region_chain());
+    if (nmo > 0) {
+      if (nmv > 0) { split(nmo, I_.ldm, cfg, ks); QTRY(gemm_slabs(nmo, oo, I_.ldm, LTm_, I_.ldm, Gm_, I_.ldm, Xwm_, oo, cfg, ks, sm)); }
+      else QTRY(dev_fill(Xwm_, nmo * oo, 0.0));
+    }
+    QTRY(dev_region_end());
+    QTRY(dev_scatter_pm_rows(o, oo, Xwp_, Xwm_, Xw_, nullptr, sp.S, sp.stride, sm.S, sm.stride));      // Xw[i,j,k,l] (the K slices' slabs added on the way)
+  }
   // (Foo' and Z only ever enter as Loo' = Foo' + Z, Fvv' and Y as Lvv' = Fvv' + Y: each pair is accumulated in place)
+  // Foo'[k,i] = sum_{lcd} (2 ovov[kcld] - ovov[kdlc]) tau[ilcd] = sum_l (2 Xw[i,l,k,l] - Xw[l,i,k,l]): a partial trace of Xw instead of
+  // a pass over two o^2 v^2 tensors
+  QTRY(dev_foo_from_x(o, Xw_, Loo_));
+  // Fvv'[a,c] = -sum tau[klxa] Loovv[klxc]  (64 x 64 tiles: split-K supplies the blocks; the slabs are added up -- with the sign -- by the pass that forms Lvv' below)
+  SlabGemm sfvv;
+  double fvv_scale = -1.0;
   {
     int cfg, ks;
     pick_long_k(v, v, oo * v, 64, 64, (v <= 256) ? 1 : -1, cfg, ks);
     if (ks > 1) QTRY(gemm_slabs(v, v, oo * v, tau_, v, Loovv_, v, Fvv_, v, cfg, ks, sfvv, false, false));
     else { QTRY(gemm(v, v, oo * v, -1.0, tau_, v, false, Loovv_, v, false, 0.0, Fvv_, v, 1, 0, 0, 0, cfg)); fvv_scale = 1.0; }
   }
-  QTRY(dev_region_chain());
-  // The two t1-contractions of ovvv are formed ONCE per iteration (each is one pass over the 1.28 GB block at n = 220) and serve the ring intermediates, the X1
-  // term and -- through their k = i traces -- the Y intermediate
+  // Fov[k,c] = Lovov[(kc),:] . t1  and  Loo' = Foo' + Z[k,i], Z = LovooT[(ki),:] . t1: two matrix-vector passes, one launch
+  QTRY(dev_gemv_rows_two(nov, nov, Lovov_, nov, t1, Fov_, 1.0, 0.0, oo, nov, LovooT_, nov, t1, Loo_, 1.0, 1.0));
+  // The two t1-contractions of ovvv are formed ONCE per iteration (each is one pass over the 1.28 GB block) and serve the
+  // ring intermediates, the X1 term and -- through their k = i traces -- the Y intermediate:
+  // (n_occ <= 32 columns / rows: 128 x 32 and 32 x 128 tiles instead of padding n_occ to a 64-wide tile, which made these
+  //  HBM-bound passes MFMA-bound)
+  const int cfg_tall = (o <= 32) ? 20 : -1, cfg_wide = (o <= 32) ? 21 : -1;
+  QTRY(dev_region_begin());
   QTRY(gemm(o * vv, o, v, 1.0, I_.ovvv, v, true, t1, v, true, 0.0, ZB_, o, 1, 0, 0, 0, cfg_tall));     // ZB[k,c,a,i] = ovvv[kcad] t1[id]
   QTRY(dev_region_chain());
   {  // ZC[k,i,a,c] = t1[id] ovvv[kdac], symmetric in (a,c): on the pair-packed block, then unpacked
+    const int64_t npv = v * (v + 1) / 2;
     const bool vec_ok = (npv % 2) == 0;     // (the 32 x 128 tile wants 16-byte aligned rows; odd npair(v): the dispatcher's choice)
     QTRY(gemm(o, npv, v, 1.0, t1, v, true, ovvv_pk_, npv, false, 0.0, ZCp_, npv, o, 0, v * npv, o * npv, vec_ok ? cfg_wide : -1));
     QTRY(dev_unpack_tril_rows(oo, v, ZCp_, ZC_));
   }
-  QTRY(dev_region_chain());
-  // Woooo[k,l,i,j] = oooo[kilj] + ovov[kcld] tau[ijcd] (Xw[i,j,k,l]) + ovoo[lcki] t1[jc] (O1[l,j,k,i]) + ovoo[kclj] t1[ic] (O1[k,i,l,j]) is never stored:
-  // its (+/-) pair-packed images are formed from the four terms (region D)
-  QTRY(gemm(o, oo, v, 1.0, t1, v, true, I_.ovoo, oo, false, 0.0, O1_, oo, o, 0, v * oo, o * oo));   // O1[l,j,k,i]
-  QTRY(dev_region_chain());
-  // Every t1-dressing term of the T2 equation but one has the form U[i,j,a,b] -= sum_k A[i,j,k,a] t1[k,b] (the oovv one through its P-partner), with
-  // A only o^3 v large: the A's are summed first and ONE rank-n_occ update passes over U.
-  //   A = X[i,j,k,a] + ovoo[i,a,j,k] + (oovv[(k,j,a),c] t1[i,c]) + (t1[j,c] ovvo[k,c,a,i])
-  QTRY(gemm(oo * v, o, v, 1.0, I_.oovv, v, true, t1, v, true, 0.0, G2_, o, 1, 0, 0, 0, cfg_tall));                                   // G2[k,j,a,i] = oovv[(kja),c] t1[ic]
-  QTRY(gemm(o, v * o, v, 1.0, t1, v, true, I_.ovvo, v * o, false, 1.0, G2_, v * o, o, 0, v * v * o, o * v * o, cfg_wide));          //          += t1[jc] ovvo[k,c,a,i]
   QTRY(dev_region_end());
+  QTRY(dev_ccsd_y_traces(o, v, ZC_, ZB_, Lvv_, Fvv_, sfvv.S, sfvv.stride, fvv_scale));                               // Lvv' = Fvv' + Y,  Y[a,c] = 2 sum_k ZC[k,k,a,c] - sum_k ZB[k,c,a,k]
 
-  // ---- region B: the products on the packed tau rows and on the ph layouts; Lvv'
+  // ---- T1 equation
+  // The two long-K terms first, as the slabs their K slices leave:  PA[i,a] = (2 ovvv[kdac] - ovvv[kcad]) t2[ikcd],  PB[i,a] = (2 ovoo[lcki] - ovoo[kcli]) t2[klac]
+  SlabGemm spa, spb;
+  double* PA = T1P_.p;
   QTRY(dev_region_begin());
-  {  // Xw[i,j,k,l] = ovov[kcld] tau[ijcd] (the quadratic part of Woooo) over the (+/-) packed (c,d) pairs:  X[ij] = Xp + Xm, X[ji] = Xp - Xm (i > j),
-     //   Xp[P(ij),(kl)] = sum_{c>=d} LTp[P(ij),P(cd)] G+[(kl),P(cd)],  Xm[Q(ij),(kl)] = sum_{c>d} LTm G-   (LTp carries 1/2 on c = d, G+ is doubled there)
-    int cfg, ks;
-    pick_xw_split(npo, oo, ldp, cfg, ks);
-    QTRY(gemm_slabs(npo, oo, ldp, LTp_, ldp, Gp_, ldp, Xwp_, oo, cfg, ks, swp));
-    QTRY(dev_region_chain());
-    if (nmo > 0) {
-      if (nmv > 0) { pick_xw_split(nmo, oo, ldm, cfg, ks); QTRY(gemm_slabs(nmo, oo, ldm, LTm_, ldm, Gm_, ldm, Xwm_, oo, cfg, ks, swm)); }
-      else QTRY(dev_fill(Xwm_, nmo * oo, 0.0));
-    }
-  }
-  QTRY(dev_region_chain());
-  // The two long-K terms of the T1 equation, as the slabs their K slices leave:  PA[i,a] = (2 ovvv[kdac] - ovvv[kcad]) t2[ikcd],  PB[i,a] = (2 ovoo[lcki] - ovoo[kcli]) t2[klac]
   {
     int cfg, ks;
     pick_long_k(o, v, o * vv, 32, 128, cfg_wide, cfg, ks, true);
     if (ks > 1) QTRY(gemm_slabs(o, v, o * vv, R_, o * vv, I_.ovvv, v, PA, v, cfg, ks, spa, true, false));
     else { QTRY(gemm(o, v, o * vv, 1.0, R_, o * vv, true, I_.ovvv, v, false, 0.0, PA, v, 1, 0, 0, 0, cfg)); spa.S = 1; }
   }
-  PB = PA + (int64_t)spa.S * nov;
+  double* PB = PA + (int64_t)spa.S * nov;
   QTRY(dev_region_chain());
   {
     int cfg, ks;
@@ -487,101 +498,72 @@ int CcsdSolver::update_amps(double* t1n, double* t2n) {
     if (ks > 1) QTRY(gemm_slabs(o, v, o * v * o, Lovoo_, o, T_, v, PB, v, cfg, ks, spb, false, false));
     else { QTRY(gemm(o, v, o * v * o, 1.0, Lovoo_, o, false, T_, v, false, 0.0, PB, v, 1, 0, 0, 0, cfg)); spb.S = 1; }
   }
-  QTRY(dev_region_chain());
-  {
-    // pp-ladder (the dominant kernel of large fragments)
-    // R_ijab = sum_cd (ac|bd) tau_ijcd through pair-packed symmetric / antisymmetric combinations:
-    //   R = R+ + R-,  R+[P(ij),P(ab)] = sum_{c>=d} Vp[P(ab),P(cd)] Tp[P(ij),P(cd)],  R-[Q(ij),Q(ab)] = sum_{c>d} Vm Tm,
-    // using tau[j,i,d,c] = tau[i,j,c,d] and (ac|bd) = (bd|ac): only i >= j rows, a >= b columns and c >= d contractions
-    // are computed -- 2 npair(o) npair(v)^2 + 2 npair'(o) npair'(v)^2 flops = 1/4 of the dense 2 o^2 v^4 -- and the
-    // operands Vp, Vm (6.4 GB together at v = 200) are each streamed ONCE through a tile that holds every packed (ij) row
-    // (224 x 128, 8 waves), K split over workgroups to fill whole rounds of the 256 CUs; the slices' partial products stay in slabs that the scatter adds up.
-    int cfg, ks;
-    TimerScope lap_LADDER(TIMER_LADDER);
-    pick_pair_gemm(npo, npv, cfg, ks);
-    if (cfg == 13 || cfg == 15) cfg += 10;      // same tiles under the ladder's own kernel symbol (profiles)
-    QTRY(gemm_slabs(npo, npv, ldp, LTp_, ldp, I_.Vp, ldp, LRp_, ldp, cfg, ks, slp));
-    QTRY(dev_region_chain());
-    if (nmo > 0 && nmv > 0) {
-      pick_pair_gemm(nmo, nmv, cfg, ks);
-      if (cfg == 13 || cfg == 15) cfg += 10;
-      QTRY(gemm_slabs(nmo, nmv, ldm, LTm_, ldm, I_.Vm, ldm, LRm_, ldm, cfg, ks, slm));
-    }
-    QTRY(lap_LADDER.close());
-  }
-  QTRY(dev_region_chain());
-  {  // t1-dressing of Wvvvv folded on the tau side: X[i,j,k,a] = tau[ijcd] OVl[k,a,c,d] from the packed tau rows:
-     //   X[ij] = Xp + Xm, X[ji] = Xp - Xm (i > j),  Xp = LTp OVp^T (c >= d),  Xm = LTm OVm^T (c > d)
-    int cfg, ks;
-    pick_pair_gemm(npo, nov, cfg, ks);
-    QTRY(gemm_slabs(npo, nov, ldp, LTp_, ldp, OVp_, ldp, Xp_, nov, cfg, ks, sxp));
-    QTRY(dev_region_chain());
-    if (nmo > 0) {
-      pick_pair_gemm(nmo, nov, cfg, ks);
-      QTRY(gemm_slabs(nmo, nov, ldm, LTm_, ldm, OVm_, ldm, Xm_, nov, cfg, ks, sxm));
-    }
-  }
-  QTRY(dev_region_chain());
-  QTRY(dev_ccsd_y_traces(o, v, ZC_, ZB_, Lvv_, Fvv_, sfvv.S, sfvv.stride, fvv_scale));      // Lvv' = Fvv' + Y,  Y[a,c] = 2 sum_k ZC[k,k,a,c] - sum_k ZB[k,c,a,k]
-  // T2 equation, terms that enter as P(X) accumulate in U: Lvv'[a,c] t2[ijcb] enters as its P-partner t2[ijac] Lvv'[b,c] (U is only used as U + U^T(ji,ba)):
-  // ONE (o^2 v) x v x v product
-  QTRY(gemm(oo * v, v, v, 1.0, t2, v, true, Lvv_, v, true, 0.0, U_, v));
   QTRY(dev_region_end());
-
-  // ---- region C: the results of the packed products back in their index order; Foo' and Fov
-  QTRY(dev_region_begin());
-  QTRY(dev_scatter_pm_rows(o, oo, Xwp_, Xwm_, Xw_, nullptr, swp.S, swp.stride, swm.S, swm.stride));      // Xw[i,j,k,l] (the K slices' slabs added on the way)
-  // Foo'[k,i] = sum_{lcd} (2 ovov[kcld] - ovov[kdlc]) tau[ilcd] = sum_l (2 Xw[i,l,k,l] - Xw[l,i,k,l]): a partial trace of Xw instead of a pass over two o^2 v^2 tensors
-  QTRY(dev_foo_from_x(o, Xw_, Loo_));
-  // Fov[k,c] = Lovov[(kc),:] . t1  and  Loo' = Foo' + Z[k,i], Z = LovooT[(ki),:] . t1: two matrix-vector passes, one launch
-  QTRY(dev_gemv_rows_two(nov, nov, Lovov_, nov, t1, Fov_, 1.0, 0.0, oo, nov, LovooT_, nov, t1, Loo_, 1.0, 1.0));
-  QTRY(dev_region_chain());
-  QTRY(dev_scatter_pm_rows(o, nov, Xp_, Xm_, X_, ovoo_ijka_, sxp.S, sxp.stride, sxm.S, sxm.stride));   // X[i,j,k,a] + ovoo[i,a,j,k]: the second term of A, added on the way
-  QTRY(perm4(X_, G2_, o, o, v, o, 3, 1, 0, 2, 1.0, 1.0));                                              // A[i,j,k,a] += G2[k,j,a,i]
-  QTRY(dev_region_end());
-
-  // ---- region D: T1 equation; (+/-) images of Woooo; the t1-dressing terms of U
-  QTRY(dev_region_begin());
   // t1n = (Fvv'+Y)_ac t1[ic] - (Foo'+Z)_ki t1[ka] + Fov_kc t1[ic] t1[ka] + Fov_kc (2 t2[kica] - t2[ikca]) + (2 ovvo[kcai] - oovv[kiac]) t1[kc] + PA - PB:
   // the small products, the two passes over o^2 v^2 operands and the slab sums in one launch (a workgroup per element)
   QTRY(dev_ccsd_t1_assemble(o, v, t1, Lvv_, Loo_, Fov_, S_, Lph1_, PA, spa.S, nov, PB, spb.S, nov, t1n));
-  QTRY(dev_region_chain());
+
+  // ---- T2 equation: direct (unsymmetrised) part
+  // (the bare ovov[i,a,j,b] term is added by the finishing kernel)
+  // Woooo[k,l,i,j]
+  //   = oooo[kilj] + ovov[kcld] tau[ijcd] (Xw[i,j,k,l], formed at the top) + ovoo[lcki] t1[jc] (O1[l,j,k,i]) + ovoo[kclj] t1[ic] (O1[k,i,l,j])
+  // is never stored: its (+/-) pair-packed images -- Woooo[klij] tau[klab] goes with the ladder below, through packed pairs -- are formed from the four terms
+  QTRY(gemm(o, oo, v, 1.0, t1, v, true, I_.ovoo, oo, false, 0.0, O1_, oo, o, 0, v * oo, o * oo));   // O1[l,j,k,i]
   QTRY(dev_pack_w_pm_sum(o, oooo_p_, Xw_, O1_, WAp_, lwp_, WAm_, lwm_));
-  QTRY(dev_region_chain());
-  QTRY(gemm(o, o * vv, o, -1.0, Loo_, o, false, t2, o * vv, false, 1.0, U_, o * vv, 1, 0, 0, 0, cfg_wide));   // U -= Loo'[k,i] t2[kjab]
-  //   X1 = (ovvv[iacb] - oovv[kibc] t1[ka]) t1[jc],   X2 = (ovvo[kcai] t1[jc] + ovoo[iajk]) t1[kb] (enters with a minus sign)
-  QTRY(perm4(U_, ZB_, o, v, v, o, 0, 3, 1, 2, 1.0, 1.0));                          // U[i,j,a,b] += t1[jc] ovvv[i,a,b,c] = ZB[i,a,b,j]
-  QTRY(dev_small_k_update(oo, v, v, o, -1.0, X_, nov, t1, 0, U_, vv));             // U[ij][a][b] -= sum_k A[ij][k][a] t1[k][b]
-  QTRY(dev_region_chain());
-  // the rank-n_occ piece -t1[la] ovoo[lcki] of Wvovo is subtracted from ZC in place (its last reader -- the Y traces -- is done)
-  QTRY(dev_small_k_update(oo, v, v, o, -1.0, t1, 0, ovoo_kilc_, nov, ZC_, vv));    // ZC[k,i,a,c] -= sum_l t1[l,a] ovoo[l,c,k,i]
-  QTRY(dev_region_end());
+  // pp-ladder (the dominant kernel)
+  // R_ijab = sum_cd (ac|bd) tau_ijcd through pair-packed symmetric / antisymmetric combinations:
+  //   R = R+ + R-,  R+[P(ij),P(ab)] = sum_{c>=d} Vp[P(ab),P(cd)] Tp[P(ij),P(cd)],  R-[Q(ij),Q(ab)] = sum_{c>d} Vm Tm,
+  // using tau[j,i,d,c] = tau[i,j,c,d] and (ac|bd) = (bd|ac): only i >= j rows, a >= b columns and c >= d contractions
+  // are computed -- 2 npair(o) npair(v)^2 + 2 npair'(o) npair'(v)^2 flops = 1/4 of the dense 2 o^2 v^4 -- and the
+  // operands Vp, Vm (6.4 GB together at v = 200) are each streamed ONCE through a tile that holds every packed (ij) row
+  // (224 x 128, 8 waves), K split over workgroups to fill whole rounds of the 256 CUs.
+  QTRY(apply_ladder(tau_, t2n, /*rows_packed=*/true, /*hh=*/true));               // (first writer of t2n)
 
-  // ---- region E: hole-hole ladder on the same packed rows; Wvoov without its t2-dependent part
-  QTRY(dev_region_begin());
-  {
-    // hole-hole ladder, the packed tau rows now as the RIGHT operand (K = packed occupied pairs):
-    //   HR+[P(ij),P(ab)] = sum_{k>=l} WA+[P(ij),P(kl)] LTp[P(kl),P(ab)],   HR-[Q(ij),Q(ab)] = sum_{k>l} WA-[Q(ij),Q(kl)] LTm[Q(kl),Q(ab)]
-    // -- a quarter of the flops of the dense o^2 x v^2 x o^2 product; the scatter adds them to the pp-ladder rows (doubling the a = b
-    // columns of HR+: LTp carries 1/2 there) and writes the sum as the first contribution to t2n
-    static const struct { int rows, cfg; } cand[] = {{224, 13}, {192, 15}, {160, 35}, {128, 0}, {64, 1}};
-    auto tile_for = [&](int64_t rows) { int best = -1; int64_t pad = -1; for (const auto& c : cand) { const int64_t q = (rows + c.rows - 1) / c.rows * c.rows; if (pad < 0 || q < pad) { pad = q; best = c.cfg; } } return best; };
-    QTRY(gemm(npo, npv, npo, 1.0, WAp_, lwp_, true, LTp_, ldp, false, 0.0, HRp_, ldp, 1, 0, 0, 0, npv >= 2048 ? tile_for(npo) : -1));
+  // ---- T2 equation: terms that enter as P(X) accumulate in U
+  // Lvv'[a,c] t2[ijcb] enters as its P-partner t2[ijac] Lvv'[b,c] (U is only used as U + U^T(ji,ba)): ONE (o^2 v) x v x v product
+  QTRY(gemm(oo * v, v, v, 1.0, t2, v, true, Lvv_, v, true, 0.0, U_, v));
+  QTRY(gemm(o, o * vv, o, -1.0, Loo_, o, false, t2, o * vv, false, 1.0, U_, o * vv, 1, 0, 0, 0, cfg_wide));   // -Loo'[k,i] t2[kjab]
+  //   t1-dressing of Wvvvv folded on the tau side: -t1[kb] (tau[ijcd] ovvv[kdac])
+  {  // X[i,j,k,a] = tau[ijcd] OVl[k,a,c,d] from the packed tau rows LTp/LTm that apply_ladder just built:
+     //   X[ij] = Xp + Xm, X[ji] = Xp - Xm (i > j),  Xp = LTp OVp^T (c >= d),  Xm = LTm OVm^T (c > d)
+    const int64_t npo = o * (o + 1) / 2, nmo = o * (o - 1) / 2;
+    int cfg, ks;
+    SlabGemm sp, sm;
+    pick_pair_gemm(npo, nov, cfg, ks);
+    QTRY(dev_region_begin());
+    QTRY(gemm_slabs(npo, nov, I_.ldp, LTp_, I_.ldp, OVp_, I_.ldp, Xp_, nov, cfg, ks, sp));
     QTRY(dev_region_chain());
-    if (nmo > 0 && nmv > 0) QTRY(gemm(nmo, nmv, nmo, 1.0, WAm_, lwm_, true, LTm_, ldm, false, 0.0, HRm_, ldm, 1, 0, 0, 0, nmv >= 2048 ? tile_for(nmo) : -1));
+    if (nmo > 0) {
+      pick_pair_gemm(nmo, nov, cfg, ks);
+      QTRY(gemm_slabs(nmo, nov, I_.ldm, LTm_, I_.ldm, OVm_, I_.ldm, Xm_, nov, cfg, ks, sm));
+    }
+    QTRY(dev_region_end());
+    QTRY(dev_scatter_pm_rows(o, nov, Xp_, Xm_, X_, ovoo_ijka_, sp.S, sp.stride, sm.S, sm.stride));   // ... + ovoo[i,a,j,k]: the second term of A below, added on the way
   }
+  //   X1 = (ovvv[iacb] - oovv[kibc] t1[ka]) t1[jc],   X2 = (ovvo[kcai] t1[jc] + ovoo[iajk]) t1[kb] (enters with a minus sign)
+  QTRY(dev_region_begin());
+  QTRY(perm4(U_, ZB_, o, v, v, o, 0, 3, 1, 2, 1.0, 1.0));                          // U[i,j,a,b] += t1[jc] ovvv[i,a,b,c] = ZB[i,a,b,j]
   QTRY(dev_region_chain());
-  // the rank-n_occ piece -ovoo[kcli] t1[la] of Wvoov is subtracted from ZB in place (its last readers -- the Y traces and the X1 term -- are done), so ONE
-  // transposing pass carries both pieces
-  QTRY(dev_small_k_update(nov, v, o, o, -1.0, t1, 0, I_.ovoo, oo, ZB_, v * o));    // ZB[k,c,a,i] -= sum_l t1[l,a] ovoo[k,c,l,i]
-  QTRY(perm4(W1_, ZB_, o, v, v, o, 3, 2, 0, 1, 1.0, 1.0, W1base_));                // W1 = W1base + ovvv[kcad] t1[id] - ovoo[kcli] t1[la]
+  // Every other t1-dressing term has the form U[i,j,a,b] -= sum_k A[i,j,k,a] t1[k,b] (the oovv one through its P-partner), with
+  // A only o^3 v large: the A's are summed first and ONE rank-n_occ update passes over U.
+  //   A = X[i,j,k,a] + ovoo[i,a,j,k] + (oovv[(k,j,a),c] t1[i,c]) + (t1[j,c] ovvo[k,c,a,i])
+  QTRY(gemm(oo * v, o, v, 1.0, I_.oovv, v, true, t1, v, true, 0.0, G2_, o, 1, 0, 0, 0, cfg_tall));                                   // G2[k,j,a,i] = oovv[(kja),c] t1[ic]
+  QTRY(gemm(o, v * o, v, 1.0, t1, v, true, I_.ovvo, v * o, false, 1.0, G2_, v * o, o, 0, v * v * o, o * v * o, cfg_wide));          //          += t1[jc] ovvo[k,c,a,i]
   QTRY(dev_region_end());
-
-  // ---- ph rings.  The t2-dependent parts of both ring intermediates come from TWO (ov)^3 products instead of three: with
+  QTRY(perm4(X_, G2_, o, o, v, o, 3, 1, 0, 2, 1.0, 1.0));                          // A[i,j,k,a] += G2[k,j,a,i]
+  QTRY(dev_small_k_update(oo, v, v, o, -1.0, X_, nov, t1, 0, U_, vv));                 // U[ij][a][b] -= sum_k A[ij][k][a] t1[k][b]
+  // ---- ph rings
+  TimerScope lap_RINGS(TIMER_RINGS);
+  // The t2-dependent parts of both ring intermediates come from TWO (ov)^3 products instead of three: with
   //   u~ = 2T - Tp - 2 t1(x)t1,  Tp~ = Tp + 2 t1(x)t1   (t1(x)t1[(ia),(ld)] = t1[id] t1[la]),  L = 2 ovov - ovov_t,
   //   Wvoov += 1/4 u~ L - 1/4 Tp~ ovov_t,      Wvovo -= 1/2 Tp~ ovov_t
   // (expand: 1/4 (2T - Tp)(2 ovov - ovov_t) = (T - Tp/2) ovov - T ovov_t / 2 + Tp ovov_t / 4, and the t1(x)t1 pieces
   // reproduce -ovov[ldkc] t1[id] t1[la] and -ovov[lckd] t1[id] t1[la]).
+  // (S = u, W12_ = u~ and W12b_ = Tp~ were formed by dev_ccsd_ph_layouts at the top of the update)
+  // the rank-n_occ pieces -ovoo[kcli] t1[la] (Wvoov) and -t1[la] ovoo[lcki] (Wvovo) are subtracted from ZB / ZC in place (their last
+  // readers -- the Y traces and the X1 term -- are done), so ONE transposing pass per intermediate carries both pieces
+  QTRY(dev_small_k_update(nov, v, o, o, -1.0, t1, 0, I_.ovoo, oo, ZB_, v * o));    // ZB[k,c,a,i] -= sum_l t1[l,a] ovoo[k,c,l,i]
+  QTRY(perm4(W1_, ZB_, o, v, v, o, 3, 2, 0, 1, 1.0, 1.0, W1base_));                // W1 = W1base + ovvv[kcad] t1[id] - ovoo[kcli] t1[la]
   // The right-hand operands of all four (ov)^3 products are symmetric matrices over (kc),(ld) -- L and ovov_t by the integral symmetry
   // (kc|ld) = (ld|kc), T' and u by t2[k,j,c,b] = t2[j,k,b,c] -- so each is passed in its K-contiguous (transposed) reading: both operands
   // of the GEMM are then staged through the conflict-free [row][BK+2] LDS image, on the 128 x 256 tile (512 tiles at ov = 4000: two per CU).
@@ -589,26 +571,15 @@ int CcsdSolver::update_amps(double* t1n, double* t2n) {
   //  64 x 64 tiles.  Measured on six octane fragments, o v = 441: 294 such workgroups on 256 CUs are SLOWER than the 1176 of the 32 x 32 tile the
   //  dispatcher picks for a lone product -- 11.3 against 11.0 ms per sweep -- so the hint stays off.)
   const int64_t ring_tiles64 = ((nov + 63) / 64) * ((nov + 63) / 64) * dev_gemm_peers();
-  // (1024 <= o v < 2048, mid-size fragments: 96 x 96 tiles -- 15 x 15 of them at o v = 1440 fill 225 of the 256 CUs in ONE round with 2/3 of the LDS
-  //  fragment reads per MFMA of the 64 x 64 tile, which needs 529 workgroups there)
-  const int64_t ring_tiles96 = ((nov + 95) / 96) * ((nov + 95) / 96);
-  static const bool ring96_on = std::getenv("QEMB_RING96") && std::atoi(std::getenv("QEMB_RING96")) != 0;
-  const bool ring96 = ring96_on && nov >= 1024 && nov < 2048 && (nov % 2) == 0 && ring_tiles96 >= 200 && ring_tiles96 <= 256;
-  // (measured and not kept, round 5: eight n = 132 fragments in lock step with their ring products grouped on 128 x 128 tiles -- 10.8 ms per lock-step
-  //  iteration against 10.4 ms on the 64 x 64 tile, and four streams beat both)
-  const int cfg_ring = (nov >= 2048) ? 4 : ring96 ? 37 : (nov >= 256 && ring_tiles64 >= 200) ? 1 : -1;
+  const int cfg_ring = (nov >= 2048) ? 4 : (nov >= 256 && ring_tiles64 >= 200) ? 1 : -1;
   auto ring = [&](double al, const double* A, const double* Bsym, double be, double* C) {
     return gemm(nov, nov, nov, al, A, nov, true, Bsym, nov, true, be, C, nov, 1, 0, 0, 0, cfg_ring);
   };
-  // ---- region F: the ladder results into t2n; the first ring product
-  QTRY(dev_region_begin());
-  QTRY(dev_ladder_scatter_pm2(o, v, LRp_, slp.ld, LRm_, slm.ld, HRp_, (nmo > 0 && nmv > 0) ? HRm_.p : nullptr, 1, t2n, slp.S, slp.stride, slm.S, slm.stride, ldp, ldm));   // (first writer of t2n)
-  QTRY(dev_region_chain());
-  TimerScope lap_RINGS(TIMER_RINGS);
   QTRY(ring(0.25, W12_, Lovov_, 1.0, W1_));                                        // + 1/4 u~ L
-  QTRY(dev_region_end());
-  // W2[(ia),(kc)] = Wvovo[a,k,c,i] = W2base + t1[id] ovvv[kdac] - t1[la] ovoo[lcki].  The Tp~ ovov_t product enters Wvoov with -1/4 and Wvovo with -1/2, so it
-  // cancels in Wvoov - Wvovo/2: that combination (R) is formed first -- as a second output of the pass that writes W2 -- then the GEMM accumulates the product
+  //   W2[(ia),(kc)] = Wvovo[a,k,c,i]
+  QTRY(dev_small_k_update(oo, v, v, o, -1.0, t1, 0, ovoo_kilc_, nov, ZC_, vv));     // ZC[k,i,a,c] -= sum_l t1[l,a] ovoo[l,c,k,i]
+  // W2 = W2base + t1[id] ovvv[kdac] - t1[la] ovoo[lcki].  The Tp~ ovov_t product enters Wvoov with -1/4 and Wvovo with -1/2, so it cancels in
+  // Wvoov - Wvovo/2: that combination (R) is formed first -- as a second output of the pass that writes W2 -- then the GEMM accumulates the product
   // straight into Wvovo.
   {
     Copy4Desc c{};
@@ -623,10 +594,10 @@ int CcsdSolver::update_amps(double* t1n, double* t2n) {
     c.out2 = R_; c.in2 = W1_; c.c2a = 1.0; c.c2b = -0.5;                            // R = Wvoov - Wvovo/2
     QTRY(dev_copy4(c));
   }
-  // ---- region G: the other three ring products.  Update, two products:  (2 Wvoov - Wvovo) T - Wvoov Tp = (Wvoov - Wvovo/2) u - (Wvovo Tp)/2  with T = (u + Tp)/2
+  QTRY(ring(-0.5, W12b_, ovov_t_, 1.0, W2_));                                       // Wvovo -= 1/2 Tp~ ovov_t
+  // Update, also two products:  (2 Wvoov - Wvovo) T - Wvoov Tp = (Wvoov - Wvovo/2) u - (Wvovo Tp)/2  with T = (u + Tp)/2
   // The two products stay where the GEMMs leave them ([i,a,j,b]); the finishing pass takes U[i,j,a,b] += RS[i,a,j,b] - A3[i,a,j,b] / 2 - A3[i,b,j,a] from there
   QTRY(dev_region_begin());
-  QTRY(ring(-0.5, W12b_, ovov_t_, 1.0, W2_));                                       // Wvovo -= 1/2 Tp~ ovov_t
   QTRY(ring(1.0, W2_, Tp_, 0.0, W1_));                                             // A3 = Wvovo[bkci] t2[kjac] at W1[i,b,j,a]
   QTRY(dev_region_chain());
   QTRY(ring(1.0, R_, S_, 0.0, W12_));                                              // RS = (Wvoov - Wvovo/2) u   (W12_: its last reader was the first product)

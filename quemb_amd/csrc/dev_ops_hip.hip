@@ -70,9 +70,9 @@ struct DevCtx {
   size_t ws_bytes = 0;
   double* gws = nullptr;             // split-K partial-sum workspace of the GEMM
   size_t gws_bytes = 0;
-  // parallel regions of a tape capture (dev_region_*): marker byte whose memsets delimit regions / chains in the captured graph, and a bump offset so that
+  // parallel regions of a tape capture (dev_region_*): the marks that delimit regions / chains in the captured chain of nodes, and a bump offset so that
   // every split-K product recorded inside a region gets its own slice of gws (the chains of a region may run side by side)
-  unsigned char* marker = nullptr;
+  std::vector<std::pair<hipGraphNode_t, int>> marks;      // (last captured node at the time of the mark, mark)
   bool tape_capture = false, in_region = false;
   size_t gws_bump = 0;
   TimerSlot timers[TIMER_NSLOTS];
@@ -422,27 +422,38 @@ bool dev_capturing() { return g_capturing; }
 int dev_graph_begin(int for_tape) {
   REQUIRE_INIT();
   if (g_capturing) { set_error("dev_graph_begin: already capturing"); return QEMB_ERR_ARG; }
-  if (for_tape && !ctx().marker) HIP_TRY(hipMalloc((void**)&ctx().marker, 256));
   if (for_tape && !g_gws) { if (!gemm_workspace(1)) return QEMB_ERR_ALLOC; }      // regions slice the workspace: it must exist before the capture
   HIP_TRY(hipStreamBeginCapture(g_stream, hipStreamCaptureModeThreadLocal));
   g_capturing = true;
-  ctx().tape_capture = for_tape != 0; ctx().in_region = false; ctx().gws_bump = 0;
+  ctx().tape_capture = for_tape != 0; ctx().in_region = false; ctx().gws_bump = 0; ctx().marks.clear();
   return QEMB_OK;
 }
 // Parallel regions (round 5).  Between dev_region_begin and dev_region_end the caller declares CHAINS of operations -- dev_region_chain starts the next one --
 // that do not depend on each other (no chain reads what another chain of the region writes, no two write the same place): inside a chain the order of the
 // calls is kept, across chains it is free.  Executed eagerly, or captured into an executable graph, the calls simply run in program order and the three
-// functions do nothing.  Captured for a TAPE they leave markers (one-byte memsets of a per-context marker) from which dev_tape_end recovers the structure, and
+// functions do nothing.  Captured for a TAPE they note which node was the newest of the capture at that moment (hipStreamGetCaptureInfo_v2: no node is added --
+// markers as captured one-byte memsets cost 0.7 ms of capture per octane BE2 sweep, more than the merged launches gain), from which dev_tape_end recovers the structure, and
 // dev_tape_run issues level k of a region -- the k-th operation of every chain, of every fragment of the run -- together: the same kernel of several chains
-// and fragments in ONE grouped launch (device-table variant, up to 64 members).  The small-fragment CCSD update is ~46 dependent launches; its data flow is
+// and fragments in ONE grouped launch (up to GROUP_MAX members).  The small-fragment CCSD update is ~46 dependent launches; its data flow is
 // ~16 levels deep.  The assertion of independence is the caller's; the lock-step tests compare bit for bit with the one-by-one solves.
 enum { MARK_REGION_BEGIN = 0xA1, MARK_CHAIN = 0xA2, MARK_REGION_END = 0xA3 };
+static bool regions_enabled() {      // QEMB_TAPE_REGIONS=0: no markers are recorded, the tape is the plain sequence (A/B runs)
+  static const bool on = !(std::getenv("QEMB_TAPE_REGIONS") && std::atoi(std::getenv("QEMB_TAPE_REGIONS")) == 0);
+  return on;
+}
 static int region_mark(int value) {
-  if (!g_capturing || !ctx().tape_capture || !ctx().marker) return QEMB_OK;
-  HIP_TRY(hipMemsetAsync(ctx().marker, value, 1, g_stream));
+  if (!g_capturing || !ctx().tape_capture || !regions_enabled()) return QEMB_OK;
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  unsigned long long id = 0;
+  hipGraph_t graph = nullptr;
+  const hipGraphNode_t* deps = nullptr;
+  size_t ndeps = 0;
+  HIP_TRY(hipStreamGetCaptureInfo_v2(g_stream, &st, &id, &graph, &deps, &ndeps));
+  if (st != hipStreamCaptureStatusActive || ndeps > 1) { set_error("dev_region_*: the capture is not a single chain"); return QEMB_ERR_DEVICE; }
+  ctx().marks.emplace_back(ndeps ? deps[0] : nullptr, value);
   return QEMB_OK;
 }
-int dev_region_begin() { if (g_capturing && ctx().tape_capture) { ctx().in_region = true; } { const int rc_ = region_mark(MARK_REGION_BEGIN); if (rc_) return rc_; } return region_mark(MARK_CHAIN); }
+int dev_region_begin() { if (g_capturing && ctx().tape_capture && regions_enabled()) { ctx().in_region = true; } { const int rc_ = region_mark(MARK_REGION_BEGIN); if (rc_) return rc_; } return region_mark(MARK_CHAIN); }
 int dev_region_chain() { return region_mark(MARK_CHAIN); }
 int dev_region_end() { ctx().in_region = false; return region_mark(MARK_REGION_END); }
 int dev_graph_end(dev_graph_t* out) {
@@ -490,7 +501,8 @@ int dev_tape_end(dev_tape_t* out) {
   REQUIRE_INIT();
   if (!g_capturing) { set_error("dev_tape_end: not capturing"); return QEMB_ERR_ARG; }
   g_capturing = false; ctx().tape_capture = false; ctx().in_region = false;
-  const void* marker = ctx().marker;
+  std::vector<std::pair<hipGraphNode_t, int>> marks;
+  marks.swap(ctx().marks);
   hipGraph_t graph = nullptr;
   HIP_TRY(hipStreamEndCapture(g_stream, &graph));
   auto fail = [&](const std::string& why) { (void)hipGraphDestroy(graph); set_error("dev_tape_end: " + why); return 1; };     // 1: cannot tape (not an error)
@@ -515,6 +527,16 @@ int dev_tape_end(dev_tape_t* out) {
   Tape* t = new Tape();
   t->graph = graph;
   int cur_region = -1, cur_chain = -1, n_regions = 0;
+  size_t mi = 0;
+  auto apply_marks = [&](hipGraphNode_t last) {      // the marks recorded while `last` was the newest node of the capture
+    for (; mi < marks.size() && marks[mi].first == last; ++mi) {
+      const int v = marks[mi].second;
+      if (v == MARK_REGION_BEGIN) { cur_region = n_regions++; cur_chain = -1; }
+      else if (v == MARK_CHAIN) { if (cur_region >= 0) ++cur_chain; }
+      else if (v == MARK_REGION_END) { cur_region = -1; cur_chain = -1; }
+    }
+  };
+  apply_marks(nullptr);
   for (size_t visited = 0; cur && visited < nn; ++visited) {
     TapeNode tn{};
     if (hipGraphNodeGetType(cur, &tn.type) != hipSuccess) { delete t; return fail("hipGraphNodeGetType"); }
@@ -527,18 +549,12 @@ int dev_tape_end(dev_tape_t* out) {
     } else if (tn.type != hipGraphNodeTypeEmpty) {
       delete t; return fail("node type " + std::to_string((int)tn.type) + " cannot be taped");
     }
-    bool is_marker = false;
-    if (tn.type == hipGraphNodeTypeMemset && marker && tn.set.dst == marker) {      // a region marker: structure, not work
-      is_marker = true;
-      const unsigned v = tn.set.value & 0xffu;
-      if (v == MARK_REGION_BEGIN) { cur_region = n_regions++; cur_chain = -1; }
-      else if (v == MARK_CHAIN) { if (cur_region >= 0) ++cur_chain; }
-      else if (v == MARK_REGION_END) { cur_region = -1; cur_chain = -1; }
-    }
-    if (!is_marker && tn.type != hipGraphNodeTypeEmpty) { tn.region = cur_region; tn.chain = cur_region >= 0 ? cur_chain : -1; t->nodes.push_back(tn); }
+    if (tn.type != hipGraphNodeTypeEmpty) { tn.region = cur_region; tn.chain = cur_region >= 0 ? cur_chain : -1; t->nodes.push_back(tn); }
+    apply_marks(cur);
     auto it = next.find(cur);
     cur = (it == next.end()) ? nullptr : it->second;
   }
+  if (mi != marks.size()) { delete t; return fail("a region mark does not lie on the captured chain"); }
   if (t->nodes.size() > nn) { delete t; return fail("node walk did not terminate"); }
   *out = t;
   return QEMB_OK;
@@ -576,23 +592,21 @@ struct PlanStep {
   bool grouped;
   const TapeNode* single;       // !grouped
   const GroupInfo* gi; size_t args_off; unsigned blocks; dim3 block; size_t lds;     // grouped: its argument block inside TapePlan::args
-  bool tab = false;             // grouped through a member table in device memory (more than GROUP_MAX members): args_off is the offset inside TapePlan::dev_tabs
 };
 struct TapePlan {
   std::vector<const void*> key;
   std::vector<PlanStep> steps;
   std::vector<unsigned char> args;      // argument blocks of the grouped launches (host memory: they are passed by value)
-  std::vector<unsigned char> tabs;      // host image of the device member tables
-  unsigned char* dev_tabs = nullptr;    // ... and their device copy (pooled block, uploaded once)
   long long ops = 0, grouped = 0;
-  ~TapePlan() { if (dev_tabs) (void)dev_free(dev_tabs); }
 };
 static std::mutex g_plan_mutex;
 static std::vector<TapePlan*> g_plans;        // small: one per distinct set of tapes that ran together
 
 // one step of the plan from the nodes that may run together (same position of a plain segment, or one level of a parallel region): launches of the same
-// kernel and block shape become grouped launches -- by value up to GROUP_MAX members, through a device table up to GROUP_TAB_MAX -- the rest is issued singly
-static void plan_emit(TapePlan* plan, const std::vector<const TapeNode*>& here, bool grouping, bool allow_tab) {
+// kernel and block shape become grouped launches of up to GROUP_MAX members (arguments by value), the rest is issued singly.  (A member table in device
+// memory with up to 64 members per launch was measured in round 5: six fragments x two chains in one launch were 0.5 ms per octane BE2 sweep SLOWER than two
+// launches of six -- the table is chased through memory by every workgroup where the by-value arguments are scalar loads.)
+static void plan_emit(TapePlan* plan, const std::vector<const TapeNode*>& here, bool grouping) {
   std::vector<unsigned char>& host = plan->args;
   auto reserve = [&](std::vector<unsigned char>& v, size_t bytes) { const size_t off = (v.size() + 255) / 256 * 256; v.resize(off + bytes); return off; };
   plan->ops += (long long)here.size();
@@ -602,7 +616,7 @@ static void plan_emit(TapePlan* plan, const std::vector<const TapeNode*>& here, 
     const TapeNode* na = here[a];
     std::vector<const TapeNode*> grp{na};
     const GroupInfo* gi = nullptr;
-    const int cap = allow_tab ? GROUP_TAB_MAX : GROUP_MAX;
+    const int cap = GROUP_MAX;
     if (grouping && na->type == hipGraphNodeTypeKernel) {
       auto it = groupable().find(na->k.func);
       if (it != groupable().end()) {
@@ -623,14 +637,8 @@ static void plan_emit(TapePlan* plan, const std::vector<const TapeNode*>& here, 
         mem.push_back(GroupMember{x->k.kernelParams, x->k.gridDim.x, x->k.gridDim.y, x->k.gridDim.z});
         st.lds = std::max<size_t>(st.lds, x->k.sharedMemBytes);
       }
-      if ((int)grp.size() <= GROUP_MAX) {
-        st.args_off = reserve(host, gi->args_bytes);
-        st.blocks = gi->build(host.data() + st.args_off, mem.data(), (int)mem.size());
-      } else {
-        st.tab = true;
-        st.args_off = reserve(plan->tabs, gi->tab_bytes);
-        st.blocks = gi->build_tab(plan->tabs.data() + st.args_off, mem.data(), (int)mem.size());
-      }
+      st.args_off = reserve(host, gi->args_bytes);
+      st.blocks = gi->build(host.data() + st.args_off, mem.data(), (int)mem.size());
       plan->grouped += 1;
       plan->steps.push_back(st);
     } else {
@@ -661,7 +669,7 @@ static int build_plan(const dev_tape_t* tapes, int n, TapePlan** out) {
   static std::once_flag once;
   std::call_once(once, [] { register_groupable_kernels(); register_groupable_gemm(); });
   static const bool grouping = !(std::getenv("QEMB_TAPE_GROUP") && std::atoi(std::getenv("QEMB_TAPE_GROUP")) == 0);
-  static const bool regions_on = !(std::getenv("QEMB_TAPE_REGIONS") && std::atoi(std::getenv("QEMB_TAPE_REGIONS")) == 0);      // 0: ignore the regions (A/B runs)
+  const bool regions_on = regions_enabled();
   TapePlan* plan = new TapePlan();
   for (int f = 0; f < n; ++f) plan->key.push_back(tapes[f]);
   std::vector<std::vector<TapeSegment>> segs;
@@ -682,7 +690,7 @@ static int build_plan(const dev_tape_t* tapes, int n, TapePlan** out) {
         for (size_t i = 0; i < longest; ++i) {
           std::vector<const TapeNode*> here;
           for (int f = 0; f < n; ++f) { const Tape* t = (const Tape*)tapes[f]; const size_t j = segs[f][k].begin + i; if (j < segs[f][k].end) here.push_back(&t->nodes[j]); }
-          plan_emit(plan, here, grouping, false);
+          plan_emit(plan, here, grouping);
         }
       } else {                          // parallel region: level by level over every chain of every tape
         size_t depth = 0;
@@ -690,7 +698,7 @@ static int build_plan(const dev_tape_t* tapes, int n, TapePlan** out) {
         for (size_t lev = 0; lev < depth; ++lev) {
           std::vector<const TapeNode*> here;
           for (int f = 0; f < n; ++f) for (const auto& c : segs[f][k].chains) if (lev < c.size()) here.push_back(c[lev]);
-          plan_emit(plan, here, grouping, true);
+          plan_emit(plan, here, grouping);
         }
       }
     }
@@ -700,17 +708,8 @@ static int build_plan(const dev_tape_t* tapes, int n, TapePlan** out) {
     for (size_t i = 0; i < longest; ++i) {
       std::vector<const TapeNode*> here;
       for (int f = 0; f < n; ++f) { const Tape* t = (const Tape*)tapes[f]; if (i < t->nodes.size()) here.push_back(&t->nodes[i]); }
-      plan_emit(plan, here, grouping, false);
+      plan_emit(plan, here, grouping);
     }
-  }
-  if (!plan->tabs.empty()) {      // member tables to the device, once
-    void* q = nullptr;
-    int rc = dev_alloc(&q, plan->tabs.size());
-    if (rc) { delete plan; return rc; }
-    plan->dev_tabs = (unsigned char*)q;
-    hipError_t e = hipMemcpyAsync(plan->dev_tabs, plan->tabs.data(), plan->tabs.size(), hipMemcpyHostToDevice, g_stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(g_stream);      // (pageable source: complete before the vector can move; once per plan)
-    if (e != hipSuccess) { set_error(std::string("dev_tape_run: table upload failed: ") + hipGetErrorString(e)); delete plan; return QEMB_ERR_DEVICE; }
   }
   *out = plan;
   return QEMB_OK;
@@ -736,10 +735,7 @@ int dev_tape_run(const dev_tape_t* tapes, int n) {
   }
   t_tape_launches = 0; t_tape_grouped = plan->grouped; t_tape_ops = plan->ops;
   for (const PlanStep& st : plan->steps) {
-    if (st.grouped && st.tab) {
-      st.gi->launch_tab(plan->dev_tabs + st.args_off, st.blocks, st.block, st.lds, g_stream);
-      t_tape_launches += 1;
-    } else if (st.grouped) {
+    if (st.grouped) {
       st.gi->launch(plan->args.data() + st.args_off, st.blocks, st.block, st.lds, g_stream);
       t_tape_launches += 1;
     } else {

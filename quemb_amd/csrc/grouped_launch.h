@@ -1,4 +1,5 @@
-// grouped_launch.h -- one launch for the same kernel of several fragments (see dev_ops_hip.hip "grouped launches" and dev_ops.h dev_tape_run).
+// grouped_launch.h -- one launch for the same kernel of several fragments, or of several independent operations of one fragment (the chains of a
+// parallel region, dev_region_*) (see dev_ops_hip.hip "grouped launches" and dev_ops.h dev_tape_run).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstring>
@@ -46,37 +47,12 @@ __global__ void __launch_bounds__(MAXT) grouped_kernel(const GroupArgs<Pack<A...
   const uint3 gdim = make_uint3(gx, gy, a.gz[f]);
   a.tab[f].call([&](const A&... x) { Body(bid, gdim, x...); });
 }
-// The same with the member table in DEVICE memory (round 5): up to GROUP_TAB_MAX members per launch -- the same kernel of several fragments AND of several
-// independent operations of one fragment (the chains of a parallel region, dev_region_*).  The table is written once per plan; a workgroup finds its member by
-// bisection over the first-block prefix.
-constexpr int GROUP_TAB_MAX = 64;
-template <class P> struct GroupTab {
-  int n, pad;
-  unsigned first[GROUP_TAB_MAX + 1], gx[GROUP_TAB_MAX], gy[GROUP_TAB_MAX], gz[GROUP_TAB_MAX];
-  P tab[GROUP_TAB_MAX];
-};
-template <auto Body, int MAXT, class... A>
-__global__ void __launch_bounds__(MAXT) grouped_tab_kernel(const GroupTab<Pack<A...>>* __restrict__ t) {
-  const unsigned b = blockIdx.x;
-  int lo = 0, hi = t->n;                 // first[lo] <= b < first[hi]
-  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (b >= t->first[mid]) lo = mid; else hi = mid; }
-  const int f = lo;
-  const unsigned lb = b - t->first[f];
-  const unsigned gx = t->gx[f], gy = t->gy[f];
-  const uint3 bid = make_uint3(lb % gx, (lb / gx) % gy, lb / (gx * gy));
-  const uint3 gdim = make_uint3(gx, gy, t->gz[f]);
-  t->tab[f].call([&](const A&... x) { Body(bid, gdim, x...); });
-}
 struct GroupMember { void** kernel_params; unsigned gx, gy, gz; };
 struct GroupInfo {
   size_t args_bytes;
   // fill the argument block of a grouped launch of n <= GROUP_MAX members; returns the number of blocks of the concatenated grid
   unsigned (*build)(void* dst, const GroupMember* members, int n);
   void (*launch)(const void* args, unsigned blocks, dim3 block, size_t lds, hipStream_t s);
-  // device-table variant: n <= GROUP_TAB_MAX members; build_tab fills a HOST image of the table (tab_bytes), which the plan copies to the device once
-  size_t tab_bytes;
-  unsigned (*build_tab)(void* dst_host, const GroupMember* members, int n);
-  void (*launch_tab)(const void* dev_tab, unsigned blocks, dim3 block, size_t lds, hipStream_t s);
 };
 std::map<const void*, GroupInfo>& groupable();      // dev_ops_hip.hip
 bool group_xcd_mode();                                // dev_ops_hip.hip (QEMB_GROUP_XCD)
@@ -101,22 +77,6 @@ static void register_groupable(const void* wrapper) {
   };
   gi.launch = [](const void* args, unsigned blocks, dim3 block, size_t lds, hipStream_t s) {
     hipLaunchKernelGGL((grouped_kernel<Body, MAXT, A...>), dim3(blocks), block, lds, s, *reinterpret_cast<const GA*>(args));
-  };
-  using GT = GroupTab<P>;
-  gi.tab_bytes = sizeof(GT);
-  gi.build_tab = [](void* dst, const GroupMember* m, int n) -> unsigned {
-    GT* a = new (dst) GT();
-    a->n = n; a->pad = 0;
-    unsigned first = 0;
-    for (int k = 0; k < GROUP_TAB_MAX; ++k) {
-      if (k < n) { a->first[k] = first; a->gx[k] = m[k].gx; a->gy[k] = m[k].gy; a->gz[k] = m[k].gz; a->tab[k].load(m[k].kernel_params); first += m[k].gx * m[k].gy * m[k].gz; }
-      else { a->first[k] = 0xffffffffu; a->gx[k] = a->gy[k] = a->gz[k] = 1; a->tab[k] = a->tab[0]; }
-    }
-    a->first[n] = first;
-    return first;
-  };
-  gi.launch_tab = [](const void* dev_tab, unsigned blocks, dim3 block, size_t lds, hipStream_t s) {
-    hipLaunchKernelGGL((grouped_tab_kernel<Body, MAXT, A...>), dim3(blocks), block, lds, s, reinterpret_cast<const GT*>(dev_tab));
   };
   groupable()[wrapper] = gi;
 }
