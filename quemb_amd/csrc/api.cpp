@@ -175,8 +175,8 @@ int qemb_op_copy4_two(const int64_t dim[4], const double* in, const int64_t si[4
 }
 int qemb_op_scatter_pm_rows_add(int64_t o, int64_t ncols, const double* Xp, const double* Xm, double* out, const double* add) { return dev_scatter_pm_rows(o, ncols, Xp, Xm, out, add); }
 int qemb_op_ccsd_y_traces_add(int64_t o, int64_t v, const double* ZC, const double* ZB, double* Y, const double* add) { return dev_ccsd_y_traces(o, v, ZC, ZB, Y, add); }
-int qemb_op_pack_w_pm_sum(int64_t o, const double* Wp, const double* X, const double* O1, double* Ap, int64_t lda_p, double* Am, int64_t lda_m) {
-  return dev_pack_w_pm_sum(o, Wp, X, O1, Ap, lda_p, Am, lda_m);
+int qemb_op_pack_w_pm_sum(int64_t o, const double* Wt, const double* X, const double* At, double* Ap, int64_t lda_p, double* Am, int64_t lda_m) {
+  return dev_pack_w_pm_sum(o, Wt, X, At, Ap, lda_p, Am, lda_m);
 }
 int qemb_op_ccsd_t1_small(int64_t o, int64_t v, const double* t1, const double* Lvv, const double* Loo, const double* Fov, double* t1n) { return dev_ccsd_t1_small(o, v, t1, Lvv, Loo, Fov, t1n); }
 int qemb_op_ccsd_t1_assemble(int64_t o, int64_t v, const double* t1, const double* Lvv, const double* Loo, const double* Fov, const double* S, const double* Lph1,

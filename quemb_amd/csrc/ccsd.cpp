@@ -222,7 +222,9 @@ int CcsdSolver::setup(MoIntegrals&& ints, const double* mo_energy_dev) {
   // packed tau rows the ladder builds anyway -- half the flops of the dense (oo) x (oo) x (vv) product
   QTRY(Gp_.alloc(oo * I_.ldp)); QTRY(Gm_.alloc(oo * I_.ldm));
   QTRY(dev_pack_pm_cols(oo, v, OVoovv_, Gp_, I_.ldp, Gm_, I_.ldm));
-  QTRY(perm4(oooo_p_, I_.oooo, o, o, o, o, 0, 2, 1, 3));                 // oooo_p[k,l,i,j] = oooo[k,i,l,j]
+  QTRY(perm4(oooo_p_, I_.oooo, o, o, o, o, 1, 3, 0, 2));                 // oooo_p[i,j,k,l] = oooo[k,i,l,j]: the bare term of Woooo[k,l,i,j], row pair (i,j) first (pack_w_pm_sum)
+  QTRY(ovoo_cikl_.alloc(v * oo * o));
+  QTRY(perm4(ovoo_cikl_, I_.ovoo, o, v, o, o, 1, 3, 2, 0));              // ovoo[l,c,k,i] at [c,i,k,l]: O1 = t1 . ovoo then comes out as [j,(i,k,l)], one product
   // (ovvo / oovv stay resident: 2 x 128 MB at n = 220 buy two permutation passes per iteration)
   // ---- amplitudes and work space
   const int64_t na = nov + N2;
@@ -506,9 +508,9 @@ int CcsdSolver::update_amps(double* t1n, double* t2n) {
   // ---- T2 equation: direct (unsymmetrised) part
   // (the bare ovov[i,a,j,b] term is added by the finishing kernel)
   // Woooo[k,l,i,j]
-  //   = oooo[kilj] + ovov[kcld] tau[ijcd] (Xw[i,j,k,l], formed at the top) + ovoo[lcki] t1[jc] (O1[l,j,k,i]) + ovoo[kclj] t1[ic] (O1[k,i,l,j])
+  //   = oooo[kilj] + ovov[kcld] tau[ijcd] (Xw[i,j,k,l], formed at the top) + ovoo[lcki] t1[jc] (O1[j,i,k,l]) + ovoo[kclj] t1[ic] (O1[i,j,l,k])
   // is never stored: its (+/-) pair-packed images -- Woooo[klij] tau[klab] goes with the ladder below, through packed pairs -- are formed from the four terms
-  QTRY(gemm(o, oo, v, 1.0, t1, v, true, I_.ovoo, oo, false, 0.0, O1_, oo, o, 0, v * oo, o * oo));   // O1[l,j,k,i]
+  QTRY(gemm(o, oo * o, v, 1.0, t1, v, true, ovoo_cikl_, oo * o, false, 0.0, O1_, oo * o));          // O1[j,i,k,l] = sum_c t1[j,c] ovoo[l,c,k,i]
   QTRY(dev_pack_w_pm_sum(o, oooo_p_, Xw_, O1_, WAp_, lwp_, WAm_, lwm_));
   // pp-ladder (the dominant kernel)
   // R_ijab = sum_cd (ac|bd) tau_ijcd through pair-packed symmetric / antisymmetric combinations:

@@ -94,7 +94,7 @@ class CcsdSolver {
   MoIntegrals I_;
   DBuf eo_, ev_;
   // derived constant tensors
-  DBuf ovov_t_, Lovov_, Loovv_, OVoovv_, Lovoo_, ovoo_ijka_, ovoo_kilc_, W1base_, W2base_, Lph1_, OVp_, OVm_, oooo_p_;   // OVp/OVm: (+/-) pair-packed OVl[k,a,c,d] = ovvv[k,d,a,c] over (c,d)
+  DBuf ovov_t_, Lovov_, Loovv_, OVoovv_, Lovoo_, ovoo_ijka_, ovoo_kilc_, W1base_, W2base_, Lph1_, OVp_, OVm_, oooo_p_, ovoo_cikl_;   // OVp/OVm: (+/-) pair-packed OVl[k,a,c,d] = ovvv[k,d,a,c] over (c,d)
   // amplitudes (t1 then t2, one contiguous vector) and per-iteration work space
   DBuf amp_, ampn_, diff_;
   DBuf tau_, T_, Tp_, S_, W1_, W2_, W12_, W12b_, R_, U_, G2_, T1P_;      // T1P_: slabs of the two long-K products of the T1 equation

@@ -237,8 +237,9 @@ int dev_ladder_scatter_pm2(int64_t o, int64_t v, const double* Rp, int64_t ldp, 
 //   Ap[P(ij)][P(kl)] = W[klij] + W[klji] (k > l), W[kkij] (k = l), i >= j;   Am[Q(ij)][Q(kl)] = W[klij] - W[klji], k > l, i > j
 // (row-major with leading dimensions lda_p >= npair(o), lda_m >= npair'(o); padding columns zeroed)
 int dev_pack_w_pm(int64_t o, const double* W, double* Ap, int64_t lda_p, double* Am, int64_t lda_m);
-// the same for W[k,l,i,j] = Wp[k,l,i,j] + X[i,j,k,l] + O1[l,j,k,i] + O1[k,i,l,j] formed on the fly (the Woooo intermediate of the CCSD update: never stored)
-int dev_pack_w_pm_sum(int64_t o, const double* Wp, const double* X, const double* O1, double* Ap, int64_t lda_p, double* Am, int64_t lda_m);
+// the same for W[k,l,i,j] = Wt[i,j,k,l] + X[i,j,k,l] + At[j,i,k,l] + At[i,j,l,k] formed on the fly (the Woooo intermediate of the CCSD update: never stored; every
+// operand with the row pair (i,j) of the packed images as its slow indices, so that a row of the images reads contiguous blocks)
+int dev_pack_w_pm_sum(int64_t o, const double* Wt, const double* X, const double* At, double* Ap, int64_t lda_p, double* Am, int64_t lda_m);
 // t1n[i,a] = sum_c t1[i,c] Lvv[a,c] - sum_k Loo[k,i] t1[k,a] + sum_k Q[i,k] t1[k,a],  Q[i,k] = sum_c t1[i,c] Fov[k,c]   (the four small products of the T1 equation)
 int dev_ccsd_t1_small(int64_t o, int64_t v, const double* t1, const double* Lvv, const double* Loo, const double* Fov, double* t1n);
 // The whole right-hand side of the T1 equation in one launch, one workgroup per element (i,a):

@@ -1910,7 +1910,7 @@ int dev_ladder_scatter_pm(int64_t o, int64_t v, const double* Rp, int64_t ldp, c
   return dev_ladder_scatter_pm2(o, v, Rp, ldp, Rm, ldm, nullptr, nullptr, 0, t2);
 }
 // one thread per (P(ij), P(kl)) / (Q(ij), Q(kl)) entry of the packed images of W[k,l,i,j]; W(k,l,i,j) is a functor: a stored tensor (pack_w_pm) or the
-// four-term sum that IS the Woooo intermediate (pack_w_pm_sum: oooo_p[k,l,i,j] + X[i,j,k,l] + O1[l,j,k,i] + O1[k,i,l,j], added in that order)
+// four-term sum that IS the Woooo intermediate (pack_w_pm_sum: Wt[i,j,k,l] + X[i,j,k,l] + At[j,i,k,l] + At[i,j,l,k], added in that order)
 // grid (ceil(lda_p / 256), npair(o)): row P(ij) per BID.y, one thread per column P(kl).  W(k,l,i,j) and W(k,l,j,i) are read once and serve both images
 // (the (-) entry Q(ij),Q(kl) exists when i > j and k > l); the padding columns are zeroed by the threads past npair(o) / by the first thread of the row.
 template <class WF>
@@ -1936,10 +1936,12 @@ __device__ __forceinline__ void pack_w_pm_kernel_body(const uint3 BID, const uin
 }
 __global__ void __launch_bounds__(256) pack_w_pm_kernel(long long o, const double* __restrict__ W, double* __restrict__ Ap, long long lda_p,
                                                         double* __restrict__ Am, long long lda_m) { pack_w_pm_kernel_body(make_uint3(blockIdx.x, blockIdx.y, blockIdx.z), make_uint3(gridDim.x, gridDim.y, gridDim.z), o, W, Ap, lda_p, Am, lda_m); }
-__device__ __forceinline__ void pack_w_pm_sum_kernel_body(const uint3 BID, const uint3 GDIM, long long o, const double* __restrict__ Wp, const double* __restrict__ X, const double* __restrict__ O1,
+__device__ __forceinline__ void pack_w_pm_sum_kernel_body(const uint3 BID, const uint3 GDIM, long long o, const double* __restrict__ Wp, const double* __restrict__ X, const double* __restrict__ O1,      // (Wp = Wt, O1 = At of dev_ops.h)
                                                             double* __restrict__ Ap, long long lda_p, double* __restrict__ Am, long long lda_m) {
+  // every operand is addressed [row pair][column pair]: a row of the packed images reads the (i,j) and (j,i) blocks of o^2 contiguous doubles of each (round 5:
+  // with W stored [k,l,i,j] and O1 stored [l,j,k,i] neighbouring threads read o^2 doubles apart -- 0.25 TB/s on the n_occ ~ 28 fragments of octane BE3)
   pack_w_pm_any(BID, o, [=](long long k, long long l, long long i, long long j) {
-    return ((Wp[((k * o + l) * o + i) * o + j] + X[((i * o + j) * o + k) * o + l]) + O1[((l * o + j) * o + k) * o + i]) + O1[((k * o + i) * o + l) * o + j]; }, Ap, lda_p, Am, lda_m);
+    return ((Wp[((i * o + j) * o + k) * o + l] + X[((i * o + j) * o + k) * o + l]) + O1[((j * o + i) * o + k) * o + l]) + O1[((i * o + j) * o + l) * o + k]; }, Ap, lda_p, Am, lda_m);
 }
 __global__ void __launch_bounds__(256) pack_w_pm_sum_kernel(long long o, const double* __restrict__ Wp, const double* __restrict__ X, const double* __restrict__ O1,
                                                             double* __restrict__ Ap, long long lda_p, double* __restrict__ Am, long long lda_m) {

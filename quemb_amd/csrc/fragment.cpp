@@ -391,6 +391,8 @@ int Fragment::solve_batch(const std::vector<Fragment*>& frs, const std::vector<i
   // sequence serially costs more than six streams issuing it side by side -- octane BE2 begin phase 3.1 -> 3.9 ms, BE3 sweep 26.9 -> 27.8 ms.
   static const bool tape_pre = std::getenv("QEMB_TAPE_PREPHASE") && std::atoi(std::getenv("QEMB_TAPE_PREPHASE")) != 0;
   QTRY(per_fragment([&](int f) { return frs[f]->solve_begin_scf(o[f], h[f], dm0[f], opt, eeval, &res[f]); }));
+  const double t_scf_done = now();
+  std::vector<double> ms_cc(F, 0.0), ms_capture(F, 0.0);      // (trace: the slowest fragment's share of the second half of the begin phase)
   std::vector<dev_tape_t> pre(F, nullptr);
   std::vector<char> taped(F, 0);
   struct PreTapes { std::vector<dev_tape_t>& t; ~PreTapes() { for (dev_tape_t x : t) if (x) (void)dev_tape_destroy(x); } } pre_guard{pre};
@@ -405,9 +407,13 @@ int Fragment::solve_batch(const std::vector<Fragment*>& frs, const std::vector<i
       if (rc_cc == 0 && rc_end == 0 && t) { pre[f] = t; taped[f] = 1; }
       else { if (t) (void)dev_tape_destroy(t); frs[f]->cc_.reset(); }      // (what failed shows again in the eager pass below)
     }
+    const double t0 = now();
     if (!taped[f]) r = frs[f]->solve_begin_cc(false);
+    const double t1 = now();
     if (r == 0 && frs[f]->cc_ && F > 1) r = frs[f]->cc_->prepare_tape(F);      // recorded side by side; a lone fragment keeps its executable graph
+    const double t2 = now();
     if (r == 0) r = dev_sync();                                               // the lock-step loop reads this fragment's buffers from another stream
+    ms_cc[f] = (t1 - t0) + (now() - t2); ms_capture[f] = t2 - t1;
     return r;
   }));
   {
@@ -434,8 +440,9 @@ int Fragment::solve_batch(const std::vector<Fragment*>& frs, const std::vector<i
     rc_end[f] = frs[f]->solve_end(outs[f].mo_coeff, outs[f].mo_energy, outs[f].rdm1_emb, outs[f].rdm1_mo, outs[f].t1, outs[f].t2);
     return rc_end[f];
   });
-  if (trace) std::fprintf(stderr, "[qemb batch] %d fragments: begin %.2f ms, lock-step iterations %.2f ms (tapes %.2f, post %.2f), end %.2f ms\n", F,
-                          t_begin_done - t_start, t_lock_done - t_begin_done, stats ? stats->ms_tapes : 0.0, stats ? stats->ms_post : 0.0, now() - t_lock_done);
+  if (trace) std::fprintf(stderr, "[qemb batch] %d fragments: begin %.2f ms (RHF %.2f, integrals + set-up <= %.2f, recording <= %.2f), lock-step iterations %.2f ms (tapes %.2f, post %.2f), end %.2f ms\n", F,
+                          t_begin_done - t_start, t_scf_done - t_start, *std::max_element(ms_cc.begin(), ms_cc.end()), *std::max_element(ms_capture.begin(), ms_capture.end()),
+                          t_lock_done - t_begin_done, stats ? stats->ms_tapes : 0.0, stats ? stats->ms_post : 0.0, now() - t_lock_done);
   if (worst) return worst;
   for (int f = 0; f < F; ++f) if (rc_end[f] > 0) { warn = rc_end[f]; set_error("fragment " + std::to_string(f) + ": " + msg[f]); }
   return warn;

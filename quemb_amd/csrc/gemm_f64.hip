@@ -43,6 +43,7 @@ namespace qemb {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
+typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));      // a pair read from global memory at 8-byte alignment (rows of an odd leading dimension)
 
 // Test / tuning hooks (qemb_set_gemm_config, qemb_set_gemm_splitk).  Per calling HOST THREAD: a thread drives one execution context
 // (stream), so a setter cannot change the tile choice of GEMMs dispatched -- or being captured into a hipGraph -- by another thread.
@@ -107,10 +108,14 @@ __device__ __forceinline__ void stage_load(double (&reg)[NCH][VEC], const double
     long long g = KCONTIG ? (long long)gmn * ld + gk : (long long)gk * ld + gmn;
     if (!KCONTIG && slab > 0) g += (long long)(gmn / slab) * slab_skip;
     if constexpr (VEC == 2) {
-      // dispatch guarantees even extents/ld/alignment, so a chunk is entirely in or out
+      // M/N-contiguous operands: the dispatch guarantees even extents / ld / alignment, so a chunk is entirely in or out.  K-contiguous operands may have an odd
+      // K (and an odd ld: pairs at 8-byte alignment): the last pair of a row is then its last element alone
       const bool ok = (gmn < MN) && (gk < K);
       d2 v = {0.0, 0.0};
-      if (ok) v = *reinterpret_cast<const d2*>(P + g);
+      if (KCONTIG) {
+        if (ok && gk + 1 < K) { const d2u u = *reinterpret_cast<const d2u*>(P + g); v[0] = u[0]; v[1] = u[1]; }
+        else if (ok) v[0] = P[g];
+      } else if (ok) v = *reinterpret_cast<const d2*>(P + g);
       reg[c][0] = v[0];
       reg[c][VEC - 1] = v[1];
     } else {
@@ -149,9 +154,8 @@ __device__ __forceinline__ void stage_load_fast(double (&reg)[NCH][VEC], const d
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
     if constexpr (VEC == 2) {
-      const d2 v = *reinterpret_cast<const d2*>(ptr[c]);
-      reg[c][0] = v[0];
-      reg[c][VEC - 1] = v[1];
+      if constexpr (KCONTIG) { const d2u v = *reinterpret_cast<const d2u*>(ptr[c]); reg[c][0] = v[0]; reg[c][VEC - 1] = v[1]; }
+      else { const d2 v = *reinterpret_cast<const d2*>(ptr[c]); reg[c][0] = v[0]; reg[c][VEC - 1] = v[1]; }
     } else {
       reg[c][0] = *ptr[c];
     }
@@ -688,7 +692,12 @@ static int launch_layout(const GemmDesc& d, hipStream_t s, bool vec2) {
   return QEMB_ERR_ARG;
 }
 
-static bool operand_vec2_ok(const double* p, int64_t ld, int64_t stride, int64_t contig_extent) {
+// 16-byte loads of an operand tile: an M/N-contiguous operand needs pairs that are entirely inside or outside the matrix and 16-byte aligned (even extent, ld,
+// batch stride; aligned base); a K-contiguous one takes any K and ld -- its pairs are read at 8-byte alignment and the odd last element of a row alone (round 5:
+// fragments with an odd n_occ n_virt ran the 8-byte kernels, and could not share a grouped launch with their even neighbours of a lock-step sweep)
+static bool operand_vec2_ok(const double* p, int64_t ld, int64_t stride, int64_t contig_extent, bool kcontig) {
+  static const bool relaxed = !(std::getenv("QEMB_GEMM_VEC2_ODD") && std::atoi(std::getenv("QEMB_GEMM_VEC2_ODD")) == 0);      // (0: the round-4 rule, for A/B runs)
+  if (kcontig && relaxed) return (reinterpret_cast<uintptr_t>(p) & 7) == 0;
   return ((reinterpret_cast<uintptr_t>(p) & 15) == 0) && (ld % 2 == 0) && (stride % 2 == 0) &&
          (contig_extent % 2 == 0);
 }
@@ -840,8 +849,8 @@ static int dev_gemm_dispatch(const GemmDesc& d) {
       std::fflush(shapelog);
     }
   }
-  const bool vec2 = operand_vec2_ok(d.A, d.lda, d.strideA, d.a_kcontig ? d.K : d.M) &&
-                    operand_vec2_ok(d.B, d.ldb, d.strideB, d.b_kcontig ? d.K : d.N);
+  const bool vec2 = operand_vec2_ok(d.A, d.lda, d.strideA, d.a_kcontig ? d.K : d.M, d.a_kcontig != 0) &&
+                    operand_vec2_ok(d.B, d.ldb, d.strideB, d.b_kcontig ? d.K : d.N, d.b_kcontig != 0);
   // tile choice: biggest tile that still gives the 256 CUs >= ~2 workgroups each; small problems
   // fall to 64x64 / 32x32 tiles so the grid is not a handful of blocks.
   const int64_t t128 = ((d.M + 127) / 128) * ((d.N + 127) / 128) * d.batch;

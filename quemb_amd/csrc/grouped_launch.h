@@ -8,7 +8,7 @@
 #include <type_traits>
 
 namespace qemb {
-constexpr int GROUP_MAX = 8;      // members of one grouped launch (more fragments: several launches)
+constexpr int GROUP_MAX = 12;     // members of one grouped launch (more: several launches) -- six fragments x the two chains of a parallel region
 template <class... A> struct Pack;
 template <> struct Pack<> {
   void load(void**) {}
@@ -67,7 +67,7 @@ static void register_groupable(const void* wrapper) {
   gi.build = [](void* dst, const GroupMember* m, int n) -> unsigned {
     GA* a = new (dst) GA();
     a->n = n;
-    a->xcd = (group_xcd_mode() && n >= 3) ? 1 : 0;      // (one or two members: an XCD each would leave most of the chip idle)
+    a->xcd = (group_xcd_mode() && n >= 3 && n <= 8) ? 1 : 0;      // (one or two members: an XCD each would leave most of the chip idle; more than eight: no XCD each)
     unsigned first = 0, most = 0;
     for (int k = 0; k < GROUP_MAX; ++k) {
       if (k < n) { a->first[k] = first; a->gx[k] = m[k].gx; a->gy[k] = m[k].gy; a->gz[k] = m[k].gz; a->tab[k].load(m[k].kernel_params); first += m[k].gx * m[k].gy * m[k].gz; most = m[k].gx * m[k].gy * m[k].gz > most ? m[k].gx * m[k].gy * m[k].gz : most; }

@@ -646,7 +646,8 @@ int dev_jacobi_eigh_until(int64_t n64, double* A, double* w, double* V, int* swe
   if (n <= 0) return QEMB_OK;
   // small matrices: the whole eigensolve in one launch (two-sided Jacobi in LDS; QEMB_JACOBI_TWOSIDED=0: the one-sided path below, for A/B runs)
   static const bool two_sided = !(std::getenv("QEMB_JACOBI_TWOSIDED") && std::atoi(std::getenv("QEMB_JACOBI_TWOSIDED")) == 0);
-  if (two_sided && n <= JE_MAX) {
+  static const int small_max = [] { const char* e = std::getenv("QEMB_JACOBI_SMALL_MAX"); return e ? std::min(std::atoi(e), JE_MAX) : JE_MAX; }();      // (A/B runs: the block path from a smaller n on)
+  if (two_sided && n <= small_max) {
     int* d_st = nullptr;
     QTRY_ALLOC(d_st, sizeof(int));
     const int ld = n + 1 + (n & 1), nh = (n + (n & 1)) / 2;
