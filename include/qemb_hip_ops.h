@@ -120,7 +120,7 @@ int qemb_op_ccsd_y_traces(int64_t o, int64_t v, const double* ZC, const double* 
 /* Fused passes of the CCSD amplitude update (csrc/ccsd.cpp update_amps), device pointers:
  *   copy4_two: qemb_op_copy4 with base (NULL: out) and a second output of the same pass, addressed like out: out2 = c2a in2 + c2b (value written to out)
  *   scatter_pm_rows_add / ccsd_y_traces_add: the plain ops with an addend laid out like the result
- *   pack_w_pm_sum: pack_w_pm of W[k,l,i,j] = Wp[k,l,i,j] + X[i,j,k,l] + O1[l,j,k,i] + O1[k,i,l,j], W never stored
+ *   pack_w_pm_sum: pack_w_pm of W[k,l,i,j] = Wt[i,j,k,l] + X[i,j,k,l] + At[j,i,k,l] + At[i,j,l,k], W never stored
  *   ccsd_t1_small: t1n[i,a] = sum_c t1[i,c] Lvv[a,c] - sum_k Loo[k,i] t1[k,a] + sum_k (sum_c t1[i,c] Fov[k,c]) t1[k,a]
  *   gemv_rows2: y = alpha (T1 x1 + T2 x2) + beta y
  *   ccsd_finish_t2_rings: F[ijab] = U[ijab] + RS[iajb] - M[iajb] / 2 - M[ibja];  t2n[ijab] = t2n[jiba] = (t2n[ijab] + OV[ijab] + F[ijab] + F[jiba]) / D (i >= j);
@@ -129,7 +129,7 @@ int qemb_op_copy4_two(const int64_t dim[4], const double* in, const int64_t si[4
                       double* out2, const double* in2, double c2a, double c2b);
 int qemb_op_scatter_pm_rows_add(int64_t o, int64_t ncols, const double* Xp, const double* Xm, double* out, const double* add);
 int qemb_op_ccsd_y_traces_add(int64_t o, int64_t v, const double* ZC, const double* ZB, double* Y, const double* add);
-int qemb_op_pack_w_pm_sum(int64_t o, const double* Wp, const double* X, const double* O1, double* Ap, int64_t lda_p, double* Am, int64_t lda_m);
+int qemb_op_pack_w_pm_sum(int64_t o, const double* Wt, const double* X, const double* At, double* Ap, int64_t lda_p, double* Am, int64_t lda_m);
 int qemb_op_ccsd_t1_small(int64_t o, int64_t v, const double* t1, const double* Lvv, const double* Loo, const double* Fov, double* t1n);
 /*   ccsd_t1_assemble: t1n = [ccsd_t1_small] + S[(ia),:] . Fov + Lph1[(ia),:] . t1 + sum_s PA[s] - sum_s PB[s]  (PA / PB: SA / SB slabs of o v doubles, strideA / strideB apart)
  *   gemv_rows_two: two independent matrix-vector passes in one launch;  ccsd_y_traces_slabs: Y = traces + scale * sum of S slabs of `add` */

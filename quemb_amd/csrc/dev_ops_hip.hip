@@ -1319,27 +1319,33 @@ __device__ __forceinline__ double slab_sum(const double* __restrict__ p, int S, 
 }
 __device__ __forceinline__ void ccsd_y_traces_kernel_body(const uint3 BID, const uint3 GDIM, long long o, long long v, const double* __restrict__ ZC, const double* __restrict__ ZB,
                                                             double* __restrict__ Y, const double* __restrict__ add, int S, long long stride, double scale) {
-  const long long idx = (long long)BID.x * blockDim.x + threadIdx.x;
-  if (idx >= v * v) return;
-  const long long a = idx / v, c = idx % v;
+  // eight lanes per output (a, c), lane q takes k = q, q + 8, ...: the ZB addresses of one output are v^2 o doubles apart (every load its own line), so the
+  // pass is a matter of loads in flight -- a thread per output kept 3-4 workgroups per fragment busy walking n_occ dependent rounds
+  const long long idx = ((long long)BID.x * blockDim.x + threadIdx.x) >> 3;
+  const int q = threadIdx.x & 7;
+  const bool in = idx < v * v;
+  const long long a = in ? idx / v : 0, c = in ? idx % v : 0;
   double s = 0.0;
-  long long k = 0;
-  for (; k + 4 <= o; k += 4) {      // four terms' loads in flight, added in order
+  if (in) {
     double zc[4], zb[4];
+    long long k = q;
+    for (; k + 24 < o; k += 32) {      // four terms' loads in flight
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { zc[q] = ZC[(((k + q) * o + (k + q)) * v + a) * v + c]; zb[q] = ZB[(((k + q) * v + c) * v + a) * o + (k + q)]; }
+      for (int u = 0; u < 4; ++u) { const long long kk = k + 8 * u; zc[u] = ZC[((kk * o + kk) * v + a) * v + c]; zb[u] = ZB[((kk * v + c) * v + a) * o + kk]; }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) s += 2.0 * zc[q] - zb[q];
+      for (int u = 0; u < 4; ++u) s += 2.0 * zc[u] - zb[u];
+    }
+    for (; k < o; k += 8) s += 2.0 * ZC[((k * o + k) * v + a) * v + c] - ZB[((k * v + c) * v + a) * o + k];
   }
-  for (; k < o; ++k) s += 2.0 * ZC[((k * o + k) * v + a) * v + c] - ZB[((k * v + c) * v + a) * o + k];
-  Y[idx] = add ? s + scale * slab_sum(add + idx, S, stride) : s;
+  s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+  if (in && q == 0) Y[idx] = add ? s + scale * slab_sum(add + idx, S, stride) : s;
 }
 __global__ void __launch_bounds__(256) ccsd_y_traces_kernel(long long o, long long v, const double* __restrict__ ZC, const double* __restrict__ ZB,
                                                             double* __restrict__ Y, const double* __restrict__ add, int S, long long stride, double scale) { ccsd_y_traces_kernel_body(make_uint3(blockIdx.x, blockIdx.y, blockIdx.z), make_uint3(gridDim.x, gridDim.y, gridDim.z), o, v, ZC, ZB, Y, add, S, stride, scale); }
 int dev_ccsd_y_traces(int64_t o, int64_t v, const double* ZC, const double* ZB, double* Y, const double* add, int S, int64_t stride, double scale) {
   REQUIRE_INIT();
   if (v <= 0) return QEMB_OK;
-  hipLaunchKernelGGL(ccsd_y_traces_kernel, dim3((unsigned)((v * v + 255) / 256)), dim3(256), 0, g_stream, (long long)o, (long long)v, ZC, ZB, Y, add, std::max(S, 1), (long long)stride, scale);
+  hipLaunchKernelGGL(ccsd_y_traces_kernel, dim3((unsigned)((v * v * 8 + 255) / 256)), dim3(256), 0, g_stream, (long long)o, (long long)v, ZC, ZB, Y, add, std::max(S, 1), (long long)stride, scale);
   HIP_TRY(hipGetLastError());
   return QEMB_OK;
 }
@@ -2549,16 +2555,17 @@ __device__ __forceinline__ void ccsd_t1_assemble_kernel_body(const uint3 BID, co
                                                                const double* __restrict__ PB, int SB, long long strideB, double* __restrict__ t1n) {
   __shared__ double w[1024];              // Q[i,k] - Loo[k,i], k < o <= 1024
   __shared__ double sh[4];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const long long nov = (long long)o * v;
   for (long long r = BID.x; r < nov; r += GDIM.x) {
     const int i = (int)(r / v), a = (int)(r - (long long)i * v);
     const double* ti = t1 + (long long)i * v;
-    for (int k = wave; k < o; k += nw) {
+    // Q[i,k] = sum_c t1[i,c] Fov[k,c]: eight lanes per k, 32 values of k at a time (a wave per k walked n_occ / 4 dependent rounds of loads: 7 us of the
+    // 23 us this pass takes on the n_occ ~ 21 fragments of octane BE2)
+    for (int k = threadIdx.x >> 3; k < o; k += blockDim.x >> 3) {
       double acc = 0.0;
-      for (int c = lane; c < v; c += 64) acc += ti[c] * Fov[(long long)k * v + c];
-      acc = wave_sum(acc);
-      if (lane == 0) w[k] = acc - Loo[(long long)k * o + i];
+      for (int c = threadIdx.x & 7; c < v; c += 8) acc += ti[c] * Fov[(long long)k * v + c];
+      acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 4);
+      if ((threadIdx.x & 7) == 0) w[k] = acc - Loo[(long long)k * o + i];
     }
     const double* rs = Sm + r * nov;
     const double* rl = Lph1 + r * nov;

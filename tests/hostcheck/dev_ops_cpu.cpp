@@ -283,10 +283,10 @@ int dev_pack_w_pm(int64_t o, const double* W, double* Ap, int64_t lda_p, double*
   }
   return 0;
 }
-int dev_pack_w_pm_sum(int64_t o, const double* Wp, const double* X, const double* O1, double* Ap, int64_t lda_p, double* Am, int64_t lda_m) {
+int dev_pack_w_pm_sum(int64_t o, const double* Wt, const double* X, const double* At, double* Ap, int64_t lda_p, double* Am, int64_t lda_m) {
   std::vector<double> W((size_t)(o * o * o * o));
   for (int64_t k = 0; k < o; ++k) for (int64_t l = 0; l < o; ++l) for (int64_t i = 0; i < o; ++i) for (int64_t j = 0; j < o; ++j)
-    W[(size_t)(((k * o + l) * o + i) * o + j)] = ((Wp[((k * o + l) * o + i) * o + j] + X[((i * o + j) * o + k) * o + l]) + O1[((l * o + j) * o + k) * o + i]) + O1[((k * o + i) * o + l) * o + j];
+    W[(size_t)(((k * o + l) * o + i) * o + j)] = ((Wt[((i * o + j) * o + k) * o + l] + X[((i * o + j) * o + k) * o + l]) + At[((j * o + i) * o + k) * o + l]) + At[((i * o + j) * o + l) * o + k];
   return dev_pack_w_pm(o, W.data(), Ap, lda_p, Am, lda_m);
 }
 int dev_ccsd_t1_small(int64_t o, int64_t v, const double* t1, const double* Lvv, const double* Loo, const double* Fov, double* t1n) {

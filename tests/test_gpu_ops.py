@@ -475,10 +475,11 @@ def test_pm_pair_packing_roundtrip_and_lincomb(qlib):
     assert np.abs(dz.numpy() - (2.0 * x - 0.5 * y + 3.0 * z)).max() < 1e-14
 
 
-@pytest.mark.parametrize("o,v", [(1, 1), (3, 5), (4, 33), (7, 70), (4, 36), (8, 50), (2, 200)])
+@pytest.mark.parametrize("o,v", [(1, 1), (3, 5), (4, 33), (7, 70), (4, 36), (8, 50), (2, 200), (6, 40), (3, 34), (5, 96)])
 def test_ccsd_single_pass_kernels(qlib, o, v):
     """The fused element-wise kernels of the amplitude update against NumPy, at sizes that are not multiples of the 32 x 32 tiles; the last
-    three have o v a multiple of 16, where ph_layouts shifts its tile columns onto 128-byte lines (a different shift per (k, j))."""
+    three of the first seven have o v a multiple of 16, where ph_layouts shifts its tile columns onto 128-byte lines (a different shift per (k, j)); even
+    n_virt >= 32 takes the 16-byte-access kernel (32 x 64 tiles)."""
     rng = np.random.default_rng(100 * o + v)
     t2 = rng.standard_normal((o, o, v, v)); t1 = rng.standard_normal((o, v))
     d2, d1 = DeviceBuffer.from_numpy(t2), DeviceBuffer.from_numpy(t1)
@@ -565,7 +566,7 @@ def test_ccsd_update_fused_passes(qlib, o, v):
     nov = o * v
     # --- pack_w_pm_sum == pack_w_pm of the summed tensor
     Wp, X, O1 = (rng.standard_normal((o, o, o, o)) for _ in range(3))
-    W = Wp + X.transpose(2, 3, 0, 1) + O1.transpose(2, 0, 3, 1) + O1.transpose(0, 2, 1, 3)      # W[k,l,i,j] = Wp[klij] + X[ijkl] + O1[ljki] + O1[kilj]
+    W = Wp.transpose(2, 3, 0, 1) + X.transpose(2, 3, 0, 1) + O1.transpose(2, 3, 1, 0) + O1.transpose(3, 2, 0, 1)      # W[k,l,i,j] = Wt[ijkl] + X[ijkl] + At[jikl] + At[ijlk]
     npo, nmo = o * (o + 1) // 2, o * (o - 1) // 2
     lwp, lwm = npo + (npo & 1), max(2, nmo + (nmo & 1))
     bufs = [DeviceBuffer.from_numpy(a) for a in (Wp, X, O1, W)]

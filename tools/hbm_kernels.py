@@ -98,3 +98,28 @@ if not want or "smallk" in want:
     report("small_k_update (ZB)", "ZB[k,c,a,i] -= sum_l t1[l,a] ovoo[k,c,l,i]: r/w o^2 v^2, N = n_occ columns", (2 * oo * vv + nov * oo) * 8, t)
     for b in (dC, dA, dt1, dZ, dB):
         b.free()
+
+if not want or "layouts" in want:
+    oo, vv = o * o, v * v
+    N2 = oo * vv
+    d2 = rand_dev(N2)
+    dt1 = DeviceBuffer.from_numpy(rng.standard_normal((o, v)))
+    outs = [DeviceBuffer(N2) for _ in range(6)]
+    t = timed(lambda: check(lib.qemb_op_ccsd_ph_layouts(o, v, d2.ptr, dt1.ptr, *[b.ptr for b in outs])), reps=30)
+    report("ccsd_ph_layouts", "t2 -> T, T', u, u~, T'~, Theta in one pass (7 o^2 v^2)", 7 * N2 * 8, t)
+    for b in [d2, dt1] + outs:
+        b.free()
+
+if not want or "copy4" in want:
+    oo, vv = o * o, v * v
+    N2 = oo * vv
+    L = C.c_int64 * 4
+    dZB, dU = rand_dev(N2), rand_dev(N2)
+    # U[i,j,a,b] += ZB[i,a,b,j]: dims (i, j, a, b), input strides of ZB[i][a][b][j], output strides of U
+    t = timed(lambda: check(lib.qemb_op_copy4(L(o, o, v, v), dZB.ptr, L(v * v * o, 1, v * o, o), dU.ptr, L(o * vv, vv, v, 1), 1.0, 1.0)), reps=30)
+    report("copy4 (U += ZB)", "U[i,j,a,b] += ZB[i,a,b,j]: the n_occ-long index is the contiguous one of the input (3 o^2 v^2)", 3 * N2 * 8, t)
+    # W1[i,a,k,c] = ZB[k,c,a,i] (+ base in the solve): dims (i, a, k, c)
+    t = timed(lambda: check(lib.qemb_op_copy4(L(o, v, o, v), dZB.ptr, L(1, o, vv * o, v * o), dU.ptr, L(v * o * v, o * v, v, 1), 1.0, 1.0)), reps=30)
+    report("copy4 (W1 += ZB)", "W1[i,a,k,c] += ZB[k,c,a,i] (3 o^2 v^2)", 3 * N2 * 8, t)
+    for b in (dZB, dU):
+        b.free()

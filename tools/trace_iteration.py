@@ -1,5 +1,5 @@
 """From a rocprofv3 --kernel-trace CSV of tools/frag_bench.py: the ordered kernel list of the LAST CCSD iteration (from one
-pp-ladder launch to the next), with durations and the idle gaps between kernels.
+amplitude-layout pass -- the first kernel of update_amps -- to the next), with durations and the idle gaps between kernels.
 
     rocprofv3 --kernel-trace --output-format csv -d gpurun_out/kt -- python tools/frag_bench.py 220 20
     python tools/trace_iteration.py gpurun_out/kt
@@ -9,7 +9,7 @@ import csv, glob, sys
 files = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)
 rows = list(csv.DictReader(open(files[0])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-lad = [i for i, r in enumerate(rows) if "<7, 2, 2, 4, 16, true, true, 2, 1" in r["Kernel_Name"]]
+lad = [i for i, r in enumerate(rows) if "ccsd_ph_layouts_kernel" in r["Kernel_Name"]]
 a, b = lad[-2], lad[-1]
 t_prev = None
 tot = busy = 0.0
