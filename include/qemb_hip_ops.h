@@ -27,6 +27,7 @@ int qemb_timer_read(int slot, double* total_ms, int64_t* count);
 int qemb_timer_reset(int slot);
 int qemb_alloc_stats(long long* n_driver_allocs, long long* n_driver_frees, double* ms_in_driver_calls, double* gb_allocated, int reset);   /* pool misses (real hipMalloc calls) and real hipFree calls since the last reset */
 int qemb_gemm_flop_count(double* flops, int reset);   /* 2 M N K batch summed over every FP64 MFMA product issued since the last reset (executed flops of a region; measurement hook) */
+int qemb_tape_cache_counters(int64_t* reused, int64_t* recorded, int reset);   /* lock-step sweeps: recorded amplitude updates kept from the last solve of a fragment / recorded anew, since the last reset (measurement hook) */
 int qemb_ctx_timer_read(int ctx, int slot, double* total_ms, int64_t* count, int reset);   /* timers of an idle execution context */
 int qemb_timer_live_events(int slot);      /* event pairs held by the calling context's slot (bounded by recycling)   */
 

@@ -125,6 +125,7 @@ def _declare(lib):
     f("qemb_ctx_partition", I, I)
     f("qemb_ctx_timer_read", I, I, I, C.POINTER(C.c_double), C.POINTER(c_i64), I)
     f("qemb_gemm_flop_count", I, C.POINTER(C.c_double), I)
+    f("qemb_tape_cache_counters", I, C.POINTER(L), C.POINTER(L), I)
     f("qemb_alloc_stats", I, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_double), C.POINTER(C.c_double), I)
     f("qemb_op_unpack_tril_pair_rows", I, L, L, P, P)
     f("qemb_op_extract_pf", I, L, P, L, L, L, L, L, L, L, L, P)

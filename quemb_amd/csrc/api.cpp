@@ -144,6 +144,13 @@ int qemb_op_gemm_slab_rows(int64_t M, int64_t N, int64_t K, const double* A, int
   return dev_gemm(g);
 }
 int qemb_gemm_flop_count(double* flops, int reset) { return dev_gemm_flop_count(flops, reset); }
+int qemb_tape_cache_counters(int64_t* reused, int64_t* recorded, int reset) {
+  long long a = 0, b = 0;
+  tape_cache_counters(&a, &b, reset);
+  if (reused) *reused = a;
+  if (recorded) *recorded = b;
+  return QEMB_OK;
+}
 int qemb_alloc_stats(long long* n, long long* nfree, double* ms, double* gb, int reset) { return dev_alloc_stats(n, nfree, ms, gb, reset); }
 int qemb_ctx_timer_read(int ctx, int slot, double* total_ms, int64_t* count, int reset) { return dev_ctx_timer_read(ctx, slot, total_ms, count, reset); }
 int qemb_op_k_from_pairs(int64_t n, const double* H, const double* D, double* K) { return dev_k_from_pairs(n, H, D, K); }

@@ -128,6 +128,11 @@ class CcsdSolver {
     if (host_scal_) { if (post_pending_) (void)dev_sync_device(); dev_pinned_free(host_scal_); }
   }
   CcsdSolver() = default;
+  // the recorded update of a lock-step sweep changes hands: a fragment keeps it from one solve to the next when the next solver's buffers are where this one's
+  // were (Fragment::tape_for_lockstep)
+  dev_tape_t release_tape() { dev_tape_t t = tape_; tape_ = nullptr; return t; }
+  void adopt_tape(dev_tape_t t) { if (tape_) dev_tape_destroy(tape_); tape_ = t; }
+  dev_tape_t tape() const { return tape_; }
   CcsdSolver(const CcsdSolver&) = delete;
   CcsdSolver& operator=(const CcsdSolver&) = delete;
  private:

@@ -74,6 +74,14 @@ typedef void* dev_tape_t;
 int dev_tape_end(dev_tape_t* out);
 int dev_tape_run(const dev_tape_t* tapes, int n);          // on the calling thread's stream; the tapes stay valid and may be run again
 int dev_tape_destroy(dev_tape_t t);
+// 1 when two tapes are the same launch sequence (kernels, grids and every argument byte of the kernels the grouped launches know; 0 otherwise) -- the check of
+// the tape cache (fragment.cpp, QEMB_TAPE_CACHE_CHECK)
+int dev_tape_equal(dev_tape_t a, dev_tape_t b);
+// A tape is valid as long as every buffer its launches name is where it was.  The caller brackets the allocations of a solve with these two: the value returned
+// is a hash of every block dev_alloc handed out on the calling thread's context in between (size and address, in order) and of the context's scratch blocks --
+// equal values on two solves mean the same buffers at the same places (round 5: a fragment's tape is kept from sweep to sweep under that key)
+void dev_alloc_trace_begin();
+unsigned long long dev_alloc_trace_end();
 // counters of the calling thread's last dev_tape_run: launches issued, of which grouped, recorded operations covered
 int dev_tape_last_stats(long long* launches, long long* grouped, long long* operations);
 

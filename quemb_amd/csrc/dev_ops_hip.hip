@@ -74,6 +74,7 @@ struct DevCtx {
   // every split-K product recorded inside a region gets its own slice of gws (the chains of a region may run side by side)
   std::vector<std::pair<hipGraphNode_t, int>> marks;      // (last captured node at the time of the mark, mark)
   bool tape_capture = false, in_region = false;
+  bool alloc_trace = false; unsigned long long alloc_hash = 0;      // dev_alloc_trace_*
   size_t gws_bump = 0;
   TimerSlot timers[TIMER_NSLOTS];
   std::map<size_t, std::vector<void*>> pool;   // caching allocator (see below)
@@ -258,6 +259,12 @@ int dev_alloc_stats(long long* n, long long* nfree, double* ms, double* gb, int 
   if (reset) { g_alloc_misses = 0; g_alloc_miss_ns = 0; g_alloc_miss_bytes = 0; g_driver_frees = 0; g_driver_free_ns = 0; }
   return QEMB_OK;
 }
+static inline unsigned long long hash_mix(unsigned long long h, unsigned long long x) {      // (splitmix64 step over h ^ x)
+  unsigned long long z = (h ^ x) + 0x9e3779b97f4a7c15ull;
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+  return z ^ (z >> 31);
+}
 int dev_alloc(void** p, size_t bytes) {
   REQUIRE_INIT();
   if (bytes == 0) bytes = 16;
@@ -268,6 +275,7 @@ int dev_alloc(void** p, size_t bytes) {
     if (it != g_pool.end() && !it->second.empty()) {
       *p = it->second.back(); it->second.pop_back(); g_pool_bytes -= bytes;
       g_live_blocks[*p] = LiveBlock{bytes, &ctx()};
+      if (ctx().alloc_trace) ctx().alloc_hash = hash_mix(hash_mix(ctx().alloc_hash, (unsigned long long)bytes), (unsigned long long)reinterpret_cast<uintptr_t>(*p));
       return QEMB_OK;
     }
   }
@@ -297,7 +305,17 @@ int dev_alloc(void** p, size_t bytes) {
   if (e != hipSuccess) { set_error("hipMalloc of " + std::to_string(bytes) + " bytes failed: " + hipGetErrorString(e)); return QEMB_ERR_ALLOC; }
   std::lock_guard<std::mutex> lock(g_alloc_mutex);
   g_live_blocks[*p] = LiveBlock{bytes, &ctx()};
+  if (ctx().alloc_trace) ctx().alloc_hash = hash_mix(hash_mix(ctx().alloc_hash, (unsigned long long)bytes), (unsigned long long)reinterpret_cast<uintptr_t>(*p));
   return QEMB_OK;
+}
+void dev_alloc_trace_begin() { ctx().alloc_trace = true; ctx().alloc_hash = 0x9e3779b97f4a7c15ull; }
+unsigned long long dev_alloc_trace_end() {
+  ctx().alloc_trace = false;
+  unsigned long long h = ctx().alloc_hash;
+  h = hash_mix(h, (unsigned long long)reinterpret_cast<uintptr_t>(ctx().partials));
+  h = hash_mix(h, (unsigned long long)reinterpret_cast<uintptr_t>(ctx().ws));
+  h = hash_mix(h, (unsigned long long)reinterpret_cast<uintptr_t>(ctx().gws));
+  return hash_mix(h, (unsigned long long)reinterpret_cast<uintptr_t>(&ctx()));
 }
 int dev_free(void* p) {
   if (!p) return QEMB_OK;
@@ -314,7 +332,12 @@ int dev_free(void* p) {
   {
     std::lock_guard<std::mutex> lock(g_alloc_mutex);
     if (blk.owner->pool_bytes + blk.bytes <= pool_cap_bytes()) {
-      blk.owner->pool[blk.bytes].push_back(p); blk.owner->pool_bytes += blk.bytes;
+      // kept sorted by descending address: dev_alloc takes the back, the LOWEST address of the size class.  Which block a request gets then depends on the set of
+      // parked blocks only, not on the order they came back in -- a solve that allocates what the last one did finds its buffers at the same addresses (with a
+      // stack the buffers of one size class traded places from solve to solve), which is what lets a fragment keep its recorded update (dev_alloc_trace_*)
+      std::vector<void*>& parked = blk.owner->pool[blk.bytes];
+      parked.insert(std::upper_bound(parked.begin(), parked.end(), p, std::greater<void*>()), p);
+      blk.owner->pool_bytes += blk.bytes;
       return QEMB_OK;
     }
   }
@@ -481,6 +504,10 @@ std::map<const void*, GroupInfo>& groupable() { static std::map<const void*, Gro
 bool group_xcd_mode() { static const bool on = [] { const char* e = std::getenv("QEMB_GROUP_XCD"); return e && e[0] != '0'; }(); return on; }
 void register_groupable_gemm();         // gemm_f64.hip
 static void register_groupable_kernels();   // end of this file (after the kernels)
+static void ensure_groupable_registered() {
+  static std::once_flag once;
+  std::call_once(once, [] { register_groupable_kernels(); register_groupable_gemm(); });
+}
 
 // ---- tapes: captured launch sequences executed together -------------------------------------------------------------------------------
 // A tape keeps the captured hipGraph alive (it owns the argument storage of its nodes) and lists the nodes in execution order.
@@ -565,6 +592,36 @@ int dev_tape_destroy(dev_tape_t tp) {
   Tape* t = (Tape*)tp;
   if (t) { drop_plans_with(t); if (t->graph) (void)hipGraphDestroy(t->graph); delete t; }
   return QEMB_OK;
+}
+int dev_tape_equal(dev_tape_t ap, dev_tape_t bp) {
+  const Tape* a = (const Tape*)ap; const Tape* b = (const Tape*)bp;
+  auto differ = [&](size_t i, const char* what) { set_error("tapes differ at operation " + std::to_string(i) + ": " + what); return 0; };
+  if (!a || !b) return differ(0, "no tape");
+  if (a->nodes.size() != b->nodes.size()) return differ(0, "number of operations");
+  ensure_groupable_registered();
+  std::vector<unsigned char> xa, xb;
+  for (size_t i = 0; i < a->nodes.size(); ++i) {
+    const TapeNode& x = a->nodes[i]; const TapeNode& y = b->nodes[i];
+    if (x.type != y.type) return differ(i, "kind of operation");
+    if (x.region != y.region || x.chain != y.chain) return differ(i, "region / chain");
+    if (x.type == hipGraphNodeTypeKernel) {
+      if (x.k.func != y.k.func) return differ(i, "kernel");
+      if (x.k.gridDim.x != y.k.gridDim.x || x.k.gridDim.y != y.k.gridDim.y || x.k.gridDim.z != y.k.gridDim.z ||
+          x.k.blockDim.x != y.k.blockDim.x || x.k.blockDim.y != y.k.blockDim.y || x.k.blockDim.z != y.k.blockDim.z || x.k.sharedMemBytes != y.k.sharedMemBytes) return differ(i, "launch geometry");
+      auto it = groupable().find(x.k.func);
+      if (it == groupable().end()) return differ(i, "a kernel whose argument list is not known to the grouped launches (not comparable)");
+      const GroupInfo& gi = it->second;
+      xa.assign(gi.args_bytes, 0); xb.assign(gi.args_bytes, 0);
+      GroupMember ma{x.k.kernelParams, x.k.gridDim.x, x.k.gridDim.y, x.k.gridDim.z}, mb{y.k.kernelParams, y.k.gridDim.x, y.k.gridDim.y, y.k.gridDim.z};
+      (void)gi.build(xa.data(), &ma, 1); (void)gi.build(xb.data(), &mb, 1);
+      for (size_t q = 0; q < gi.args_bytes; ++q) if (xa[q] != xb[q]) return differ(i, ("kernel argument byte " + std::to_string(q) + " of " + std::to_string(gi.args_bytes)).c_str());
+    } else if (x.type == hipGraphNodeTypeMemset) {
+      if (x.set.dst != y.set.dst || x.set.value != y.set.value || x.set.width != y.set.width || x.set.height != y.set.height || x.set.elementSize != y.set.elementSize) return differ(i, "memset");
+    } else if (x.type == hipGraphNodeTypeMemcpy) {
+      if (std::memcmp(&x.cpy, &y.cpy, sizeof(x.cpy)) != 0) return differ(i, "copy");
+    }
+  }
+  return 1;
 }
 static int tape_issue_single(const TapeNode& n, hipStream_t s) {
   if (n.type == hipGraphNodeTypeKernel) {
@@ -666,8 +723,7 @@ static std::vector<TapeSegment> tape_segments(const Tape* t) {
 }
 
 static int build_plan(const dev_tape_t* tapes, int n, TapePlan** out) {
-  static std::once_flag once;
-  std::call_once(once, [] { register_groupable_kernels(); register_groupable_gemm(); });
+  ensure_groupable_registered();
   static const bool grouping = !(std::getenv("QEMB_TAPE_GROUP") && std::atoi(std::getenv("QEMB_TAPE_GROUP")) == 0);
   const bool regions_on = regions_enabled();
   TapePlan* plan = new TapePlan();
@@ -1031,7 +1087,7 @@ int dev_copy4(const Copy4Desc& cd) {
     if (transpose) { for (int k = 0; k < 4; ++k) if (k != a && k != b) rest.push_back(k); order[0] = rest[0]; order[1] = rest[1]; order[2] = b; order[3] = a; }
     else { for (int k = 0; k < 4; ++k) if (k != a) rest.push_back(k); order[0] = rest[0]; order[1] = rest[1]; order[2] = rest[2]; order[3] = a; }
   }
-  Copy4K c;
+  Copy4K c{};
   long long d[4], si[4], so[4];
   for (int k = 0; k < 4; ++k) { d[k] = cd.dim[order[k]]; si[k] = cd.si[order[k]]; so[k] = cd.so[order[k]]; }
   c.d0 = d[0]; c.d1 = d[1]; c.d2 = d[2]; c.d3 = d[3];

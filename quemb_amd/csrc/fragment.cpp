@@ -1,3 +1,4 @@
+#include <atomic>
 // fragment.cpp -- the per-fragment pipeline on the device:
 //   fragment RHF (helper.py:73-151) -> embedding->MO integrals (solver.py:900) -> RCCSD (solver.py:907)
 //   -> unrelaxed 1-RDM (ccsd_rdm.py:10-20) back-rotated (solver.py:496-505) -> fragment energy (helper.py:220-339)
@@ -319,7 +320,7 @@ int Fragment::cphf_response(int o, const double* h, const double* dm0, const Scf
 int Fragment::prepare_ccsd(int o, const double* h, const double* dm0, const FragmentOptions& opt) {
   if (!has_eris()) { set_error("Fragment: ERIs not set"); return QEMB_ERR_ARG; }
   if (o <= 0 || o >= n_) { set_error("Fragment: need 0 < nsocc < n"); return QEMB_ERR_ARG; }
-  cc_.reset();
+  retire_solver();
   DBuf X1;
   bool x1_unpacked = false;
   QTRY(scf_operand(X1, &x1_unpacked));
@@ -405,12 +406,12 @@ int Fragment::solve_batch(const std::vector<Fragment*>& frs, const std::vector<i
       dev_tape_t t = nullptr;
       const int rc_end = dev_tape_end(&t);
       if (rc_cc == 0 && rc_end == 0 && t) { pre[f] = t; taped[f] = 1; }
-      else { if (t) (void)dev_tape_destroy(t); frs[f]->cc_.reset(); }      // (what failed shows again in the eager pass below)
+      else { if (t) (void)dev_tape_destroy(t); frs[f]->retire_solver(); }      // (what failed shows again in the eager pass below)
     }
     const double t0 = now();
     if (!taped[f]) r = frs[f]->solve_begin_cc(false);
     const double t1 = now();
-    if (r == 0 && frs[f]->cc_ && F > 1) r = frs[f]->cc_->prepare_tape(F);      // recorded side by side; a lone fragment keeps its executable graph
+    if (r == 0 && frs[f]->cc_ && F > 1) r = frs[f]->tape_for_lockstep(F);      // recorded side by side (or kept from the last sweep); a lone fragment keeps its executable graph
     const double t2 = now();
     if (r == 0) r = dev_sync();                                               // the lock-step loop reads this fragment's buffers from another stream
     ms_cc[f] = (t1 - t0) + (now() - t2); ms_capture[f] = t2 - t1;
@@ -462,7 +463,7 @@ int Fragment::solve_begin_scf(int o, const double* h, const double* dm0, const F
   // nsocc == n: an embedding space without virtual orbitals.  PySCF's CCSD then has empty amplitude arrays and returns E_corr = 0; the
   // sweep body needs the mean-field results only (density = 2 I in any orthonormal basis, no correlation contribution to the energies).
   const int64_t n2 = (int64_t)n * n;
-  cc_.reset();
+  retire_solver();
   // ---- fragment RHF on the half-unpacked tensor [P(p,q)][r][s] (kept: it is the first operand of the MO transformation)
   QTRY(scf_operand(sp_.X1, &sp_.x1_unpacked));         // [P(p,q)][r][s] for the four-index route (kept: its first operand); nothing on the factor route
   ScfResult sres;
@@ -489,9 +490,11 @@ int Fragment::solve_begin_cc(bool defer_energy) {
     res->e_corr_mo = 0.0; res->n_iter = 0; res->ccsd_converged = true; res->lambda_iters = 0;
     return 0;
   }
+  dev_alloc_trace_begin();
   MoIntegrals ints;
   QTRY(mo_integrals(o, sp_.eeval ? nf_ : 0, sp_.X1, sp_.x1_unpacked, ints, /*build_Vl=*/false, /*build_T34=*/opt.relax_density != 0));
   sp_.X1.release();
+  retire_solver();
   cc_.reset(new CcsdSolver());
   QTRY(cc_->setup(std::move(ints), eps_));
   if (opt.warm_start && t_prev_.p && t_prev_o_ == o) {
@@ -499,7 +502,50 @@ int Fragment::solve_begin_cc(bool defer_energy) {
   } else {
     QTRY(cc_->init_amps(defer_energy));
   }
+  sp_.alloc_hash = dev_alloc_trace_end();
   return 0;
+}
+
+// The recorded update of a lock-step sweep.  Recording costs a stream capture and ~50 node queries per fragment and sweep (0.4-0.5 ms of the begin phase of an
+// octane sweep, the six host threads queueing on the runtime's capture lock), and a new tape means a new merge plan in dev_tape_run.  The tape only names
+// buffers and sizes: when this solve's allocations landed where the last solve's did (the pool hands blocks back in the order they came -- sp_.alloc_hash), the
+// last tape IS this solve's tape.  QEMB_TAPE_CACHE=0: record every time; QEMB_TAPE_CACHE_CHECK=1: record anyway and compare with the kept tape (tests).
+static std::atomic<long long> g_tape_reused{0}, g_tape_recorded{0};
+void tape_cache_counters(long long* reused, long long* recorded, int reset) {
+  if (reused) *reused = g_tape_reused.load();
+  if (recorded) *recorded = g_tape_recorded.load();
+  if (reset) { g_tape_reused = 0; g_tape_recorded = 0; }
+}
+int Fragment::tape_for_lockstep(int peers) {
+  static const bool cache_on = !(std::getenv("QEMB_TAPE_CACHE") && std::atoi(std::getenv("QEMB_TAPE_CACHE")) == 0);
+  const bool check = std::getenv("QEMB_TAPE_CACHE_CHECK") && std::atoi(std::getenv("QEMB_TAPE_CACHE_CHECK")) != 0;
+  unsigned long long key = sp_.alloc_hash ^ (0x9e3779b97f4a7c15ull * (unsigned long long)(peers + 1)) ^ ((unsigned long long)sp_.o << 40) ^ ((unsigned long long)n_ << 20);
+  if (key == 0) key = 1;
+  tape_key_ = key;
+  if (std::getenv("QEMB_TAPE_CACHE_TRACE")) std::fprintf(stderr, "[qemb tape cache] fragment %p n %d: key %016llx, kept %016llx\n", (void*)this, n_, key, tape_cache_.tape ? tape_cache_.key : 0ull);
+  if (cache_on && tape_cache_.tape && tape_cache_.key == key) {
+    if (check) {
+      QTRY(cc_->prepare_tape(peers));
+      if (cc_->tape() && !dev_tape_equal(cc_->tape(), tape_cache_.tape)) { set_error(std::string("the kept tape differs from a fresh recording at the same buffer layout: ") + last_error()); return QEMB_ERR_DEVICE; }
+    }
+    cc_->adopt_tape(tape_cache_.tape);
+    tape_cache_.tape = nullptr;
+    g_tape_reused += 1;
+    return 0;
+  }
+  g_tape_recorded += 1;
+  return cc_->prepare_tape(peers);
+}
+void Fragment::retire_solver() {
+  if (cc_) {
+    dev_tape_t t = cc_->release_tape();
+    if (t) {
+      if (tape_key_ != 0) { if (tape_cache_.tape) (void)dev_tape_destroy(tape_cache_.tape); tape_cache_.tape = t; tape_cache_.key = tape_key_; }
+      else (void)dev_tape_destroy(t);
+    }
+  }
+  tape_key_ = 0;
+  cc_.reset();
 }
 
 int Fragment::solve_end(double* mo_coeff, double* mo_energy, double* rdm1_emb, double* rdm1_mo, double* t1_out, double* t2_out) {
@@ -624,7 +670,7 @@ int Fragment::solve_end(double* mo_coeff, double* mo_energy, double* rdm1_emb, d
   // the next sweep may drive this fragment from a host thread bound to ANOTHER execution context (stream): the kept amplitudes,
   // multipliers and orbitals must be complete before this call returns (no inter-stream ordering exists otherwise)
   QTRY(dev_sync());
-  cc_.reset();
+  retire_solver();
   return unconverged ? QEMB_WARN_NOCONV : 0;
 }
 

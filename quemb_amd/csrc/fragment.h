@@ -126,7 +126,13 @@ class Fragment {
     bool unconverged = false, no_virtuals = false;
     std::vector<double> C, eps;
     DBuf X1; bool x1_unpacked = false;      // the half-unpacked tensor between the two halves of solve_begin (four-index route)
+    unsigned long long alloc_hash = 0;      // dev_alloc_trace_end over integrals + set-up + starting amplitudes of this solve
   } sp_;
+  // the recorded amplitude update of the last lock-step solve and the buffer layout it is valid for (tape_for_lockstep / retire_solver)
+  struct TapeCache { dev_tape_t tape = nullptr; unsigned long long key = 0; ~TapeCache() { if (tape) (void)dev_tape_destroy(tape); } } tape_cache_;
+  unsigned long long tape_key_ = 0;
+  int tape_for_lockstep(int peers);
+  void retire_solver();
   // state of the last solve
   DBuf C_, eps_, dm_, J_, K_;
   std::unique_ptr<CcsdSolver> cc_;
@@ -135,5 +141,8 @@ class Fragment {
   int z_prev_o_ = -1;
   int t_prev_o_ = -1;
 };
+
+// lock-step tapes kept from an earlier solve / recorded anew since the last reset (all fragments of the process)
+void tape_cache_counters(long long* reused, long long* recorded, int reset);
 
 }  // namespace qemb

@@ -591,7 +591,7 @@ static int launch_cfg(const GemmDesc& d, hipStream_t s) {
   constexpr int BM = WM * 16 * WAVES_M, BN = WN * 16 * WAVES_N;
   using ImgA = LdsImage<BM, BK, A_KC>;
   using ImgB = LdsImage<BN, BK, B_KC>;
-  GemmKArgs g;
+  GemmKArgs g{};      // (padding zeroed: recorded launches are compared byte by byte, dev_tape_equal)
   g.A = d.A; g.B = d.B; g.C = d.C;
   g.lda = d.lda; g.ldb = d.ldb; g.ldc = d.ldc;
   g.strideA = d.strideA; g.strideB = d.strideB; g.strideC = d.strideC;

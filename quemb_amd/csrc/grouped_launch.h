@@ -16,7 +16,7 @@ template <> struct Pack<> {
 };
 template <class H, class... T> struct Pack<H, T...> {
   H h; Pack<T...> t;
-  void load(void** kp) { h = *reinterpret_cast<const H*>(kp[0]); t.load(kp + 1); }
+  void load(void** kp) { std::memcpy(&h, kp[0], sizeof(H)); t.load(kp + 1); }      // (bytes as recorded, padding included)
   template <class F, class... X> __device__ __forceinline__ void call(F&& f, const X&... x) const { t.call(f, x..., h); }
 };
 // Everything a grouped launch needs travels in the kernel-argument segment (scalar loads, no table in device memory to chase): the first

@@ -51,6 +51,9 @@ int dev_graph_end(dev_graph_t*) { return QEMB_ERR_DEVICE; }
 int dev_graph_launch(dev_graph_t) { return QEMB_ERR_DEVICE; }
 int dev_graph_destroy(dev_graph_t) { return 0; }
 int dev_tape_end(dev_tape_t*) { return 1; }            // the mock executes eagerly: nothing to tape
+int dev_tape_equal(dev_tape_t, dev_tape_t) { return 0; }
+void dev_alloc_trace_begin() {}
+unsigned long long dev_alloc_trace_end() { return 0; }
 int dev_tape_run(const dev_tape_t*, int) { set_error("hostcheck: no tapes"); return QEMB_ERR_DEVICE; }
 int dev_tape_destroy(dev_tape_t) { return QEMB_OK; }
 int dev_tape_last_stats(long long* a, long long* b, long long* c) { if (a) *a = 0; if (b) *b = 0; if (c) *c = 0; return QEMB_OK; }

@@ -702,6 +702,39 @@ def test_df_transform_matches_reference_integral_direct_DF(qlib):
     check_df_golden(qlib)
 
 
+def test_lockstep_tapes_are_kept_between_sweeps_and_equal_fresh_recordings(qlib, monkeypatch):
+    """A fragment keeps the recorded amplitude update of a lock-step sweep for its next solve when that solve's buffers land where the last one's did
+    (same allocation trace).  With QEMB_TAPE_CACHE_CHECK=1 every kept tape is compared, launch by launch and argument byte by argument byte, with a fresh
+    recording; the sweeps give the numbers of the first one; a sweep at a different potential (other numbers in the same buffers) those of a serial sweep of a fresh BE object."""
+    import ctypes as C
+    from quemb_amd.solver import be_func
+    monkeypatch.setenv("QEMB_TAPE_CACHE_CHECK", "1")
+    mfl, bel = _be("octane", lockstep=True)
+    reused, recorded = C.c_int64(), C.c_int64()
+    qlib.qemb_tape_cache_counters(C.byref(reused), C.byref(recorded), 1)
+    first = None
+    for sweep in range(4):
+        r = be_func(None, bel.Fobjs, bel.Nocc, "CCSD", bel.enuc, eeval=True, return_vec=True, opts=bel.opts, lockstep=True)
+        if first is None:
+            first = (r[0], np.asarray(r[1]).copy(), [f._rdm1.copy() for f in bel.Fobjs])
+        else:
+            # (not bit for bit: from the second sweep on the fragment RHF starts in the orbitals of the sweep before)
+            assert abs(r[0] - first[0]) < 1e-12 and np.abs(np.asarray(r[1]) - first[1]).max() < 1e-11
+            assert all(np.abs(f._rdm1 - d).max() < 1e-10 for f, d in zip(bel.Fobjs, first[2]))
+    qlib.qemb_tape_cache_counters(C.byref(reused), C.byref(recorded), 0)
+    nfr = len(bel.Fobjs)
+    assert recorded.value >= nfr and reused.value >= nfr, (reused.value, recorded.value)      # the buffer layout settles after a sweep or two; from then on no recording
+    assert reused.value + recorded.value == 4 * nfr
+    # other numbers in the same buffers: a kept tape must serve a sweep at another potential exactly like a fresh recording
+    monkeypatch.setenv("QEMB_TAPE_CACHE_CHECK", "0")
+    pot = np.array([0.01 * (k % 3 - 1) for k in range(len(first[1]))])
+    ra = be_func(pot, bel.Fobjs, bel.Nocc, "CCSD", bel.enuc, eeval=True, return_vec=True, opts=bel.opts, lockstep=True)
+    mf1, be1 = _be("octane")
+    rb = be_func(pot, be1.Fobjs, be1.Nocc, "CCSD", be1.enuc, eeval=True, return_vec=True, opts=be1.opts)
+    assert abs(ra[0] - rb[0]) < 1e-12 and np.abs(np.asarray(ra[1]) - np.asarray(rb[1])).max() < 1e-11
+    assert np.abs(np.asarray(ra[1]) - first[1]).max() > 1e-4      # (and it IS another sweep)
+
+
 def test_lockstep_sweep_gives_identical_results(qlib):
     """lockstep=True: every fragment of the octane BE2 sweep in ONE library call (qemb_frag_solve_batch) -- fragment phases per stream,
     CCSD iterations of all six fragments in lock step with one grouped launch per operation.  Bit for bit the serial sweep; the density
