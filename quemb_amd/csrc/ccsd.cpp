@@ -250,11 +250,11 @@ int CcsdSolver::setup(MoIntegrals&& ints, const double* mo_energy_dev) {
     const int64_t npo = o * (o + 1) / 2, nmo = std::max<int64_t>(o * (o - 1) / 2, 1);
     // (results of the split-K products keep one slab per K slice: the consumers add them up)
     const int64_t npv = v * (v + 1) / 2, nmv = v * (v - 1) / 2;
-    auto slabs_pair = [&](int64_t rows, int64_t cols, int64_t K) { int cfg, ks; pick_pair_gemm(rows, cols, cfg, ks); return (int64_t)gemm_slab_count(K, ks); };
+    auto slabs_pair = [&](int64_t rows, int64_t cols, int64_t K, bool k_aware = false) { int cfg, ks; pick_pair_gemm(rows, cols, cfg, ks, k_aware ? K : 0); return (int64_t)gemm_slab_count(K, ks); };
     auto slabs_xw = [&](int64_t rows, int64_t K) { int cfg, ks; pick_xw_split(rows, oo, K, cfg, ks); return (int64_t)gemm_slab_count(K, ks); };
     QTRY(LTp_.alloc(npo * I_.ldp)); QTRY(LRp_.alloc(std::max(npo * I_.ldp, slabs_pair(npo, npv, I_.ldp) * npo * npv)));
     QTRY(LTm_.alloc(nmo * I_.ldm)); QTRY(LRm_.alloc(std::max(nmo * I_.ldm, slabs_pair(nmo, std::max<int64_t>(nmv, 1), I_.ldm) * nmo * std::max<int64_t>(nmv, 1))));
-    QTRY(Xp_.alloc(slabs_pair(npo, nov, I_.ldp) * npo * nov)); QTRY(Xm_.alloc(slabs_pair(nmo, nov, I_.ldm) * nmo * nov));
+    QTRY(Xp_.alloc(slabs_pair(npo, nov, I_.ldp, true) * npo * nov)); QTRY(Xm_.alloc(slabs_pair(nmo, nov, I_.ldm, true) * nmo * nov));
     QTRY(Xwp_.alloc(slabs_xw(npo, I_.ldp) * npo * oo)); QTRY(Xwm_.alloc(slabs_xw(nmo, I_.ldm) * nmo * oo)); QTRY(Xw_.alloc(oo * oo));
     lwp_ = npo + (npo & 1); lwm_ = std::max<int64_t>(2, nmo + (nmo & 1));
     QTRY(WAp_.alloc(npo * lwp_)); QTRY(WAm_.alloc(nmo * lwm_)); QTRY(HRp_.alloc(npo * I_.ldp)); QTRY(HRm_.alloc(nmo * I_.ldm));
@@ -302,7 +302,7 @@ int CcsdSolver::set_amps(const double* t1d, const double* t2d, bool defer_energy
 }
 
 // tile configuration and K split for the "few packed pair rows x many columns" GEMMs (ladder, tau-side dressing)
-void pick_pair_gemm(int64_t rows, int64_t cols, int& cfg, int& ks) {
+void pick_pair_gemm(int64_t rows, int64_t cols, int& cfg, int& ks, int64_t K) {
   cfg = -1; ks = 0;
   if (cols < 1024) return;
   // the row-tile height with the least ESTIMATED TIME among the configurations that exist: padded rows weighted by what a row costs on
@@ -312,11 +312,12 @@ void pick_pair_gemm(int64_t rows, int64_t cols, int& cfg, int& ks) {
   // n_occ = 40 (820 rows) four 224-row tiles, not thirteen 64-row ones.  (The dispatcher's own choice for "few tiles" would be the
   // 64 x 64 tile, a quarter of the rate.)
   static const struct { int rows, cfg, cols; double cost; } cand[] = {{224, 13, 128, 1.0}, {192, 15, 128, 1.0}, {160, 35, 128, 1.03}, {128, 4, 256, 1.0},
-                                                                      {112, 11, 128, 1.25}, {80, 36, 128, 1.08}, {64, 12, 128, 1.6}};
+                                                                      {112, 11, 128, 1.25}, {80, 36, 128, 1.08}, {64, 12, 128, 1.6}, {48, 38, 128, 1.12}};
   double best_cost = -1.0;
   int64_t tiles = 0;
   for (const auto& c : cand) {
     const int64_t mt = (rows + c.rows - 1) / c.rows;
+    if (c.cfg == 38 && mt > 1) continue;      // (the 48-row tile only where it holds all rows: n_occ <= 9)
     const double cost = (double)(mt * c.rows) * c.cost;
     if (best_cost < 0 || cost < best_cost - 1e-9) { best_cost = cost; cfg = c.cfg; tiles = mt * ((cols + c.cols - 1) / c.cols); }
   }
@@ -327,6 +328,9 @@ void pick_pair_gemm(int64_t rows, int64_t cols, int& cfg, int& ks) {
     if (units >= 512 && eff > best + 1e-9) { best = eff; ks = c; }
   }
   if (ks == 0) ks = (int)std::max<int64_t>(1, std::min<int64_t>(8, (1024 + tiles - 1) / tiles));
+  // a product whose eight slices still leave most CUs without a workgroup and whose K is long (the tau-side dressing of mid-size fragments: 12 column tiles x 8 at
+  // n = 132, K = 7260 -- 85 us at 19 TFLOP/s): more, shorter slices, down to ~256 k each (K = 0: the caller did not say, the rule above stands)
+  if (K > 0 && tiles * ks < 256) ks = (int)std::max<int64_t>(ks, std::min<int64_t>(std::min<int64_t>(32, K / 256), (512 + tiles - 1) / tiles));
 }
 
 // C = A B^T (both operands K-contiguous) whose consumer adds the split-K slabs itself: with ks > 1 the slices' partial products stay in slabs
@@ -531,12 +535,12 @@ int CcsdSolver::update_amps(double* t1n, double* t2n) {
     const int64_t npo = o * (o + 1) / 2, nmo = o * (o - 1) / 2;
     int cfg, ks;
     SlabGemm sp, sm;
-    pick_pair_gemm(npo, nov, cfg, ks);
+    pick_pair_gemm(npo, nov, cfg, ks, I_.ldp);
     QTRY(dev_region_begin());
     QTRY(gemm_slabs(npo, nov, I_.ldp, LTp_, I_.ldp, OVp_, I_.ldp, Xp_, nov, cfg, ks, sp));
     QTRY(dev_region_chain());
     if (nmo > 0) {
-      pick_pair_gemm(nmo, nov, cfg, ks);
+      pick_pair_gemm(nmo, nov, cfg, ks, I_.ldm);
       QTRY(gemm_slabs(nmo, nov, I_.ldm, LTm_, I_.ldm, OVm_, I_.ldm, Xm_, nov, cfg, ks, sm));
     }
     QTRY(dev_region_end());
@@ -573,9 +577,13 @@ int CcsdSolver::update_amps(double* t1n, double* t2n) {
   //  64 x 64 tiles.  Measured on six octane fragments, o v = 441: 294 such workgroups on 256 CUs are SLOWER than the 1176 of the 32 x 32 tile the
   //  dispatcher picks for a lone product -- 11.3 against 11.0 ms per sweep -- so the hint stays off.)
   const int64_t ring_tiles64 = ((nov + 63) / 64) * ((nov + 63) / 64) * dev_gemm_peers();
-  const int cfg_ring = (nov >= 2048) ? 4 : (nov >= 256 && ring_tiles64 >= 200) ? 1 : -1;
+  // (1024 <= o v < 2048, one mid-size fragment on the chip: 96 x 96 tiles with K in two slices -- 15 x 15 x 2 workgroups at o v = 1440, 119 us against the 151 us
+  //  of 23 x 23 tiles of 64 x 64; tools/mid_gemm_bench.py.  QEMB_RING96=0: the 64 x 64 tiles, for A/B runs)
+  static const bool ring96 = !(std::getenv("QEMB_RING96") && std::getenv("QEMB_RING96")[0] == '0');
+  const bool mid_ring = ring96 && nov >= 1024 && nov < 2048 && dev_gemm_peers() == 1;
+  const int cfg_ring = (nov >= 2048) ? 4 : mid_ring ? 37 : (nov >= 256 && ring_tiles64 >= 200) ? 1 : -1;
   auto ring = [&](double al, const double* A, const double* Bsym, double be, double* C) {
-    return gemm(nov, nov, nov, al, A, nov, true, Bsym, nov, true, be, C, nov, 1, 0, 0, 0, cfg_ring);
+    return gemm(nov, nov, nov, al, A, nov, true, Bsym, nov, true, be, C, nov, 1, 0, 0, 0, cfg_ring, mid_ring ? 2 : 0);
   };
   QTRY(ring(0.25, W12_, Lovov_, 1.0, W1_));                                        // + 1/4 u~ L
   //   W2[(ia),(kc)] = Wvovo[a,k,c,i]

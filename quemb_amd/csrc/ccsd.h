@@ -140,5 +140,5 @@ class CcsdSolver {
 };
 
 // tile configuration and split-K factor CcsdSolver picks for a "few packed pair rows x many columns" product (introspection for tests / tools)
-void pick_pair_gemm(int64_t rows, int64_t cols, int& cfg, int& ks);
+void pick_pair_gemm(int64_t rows, int64_t cols, int& cfg, int& ks, int64_t K = 0);
 }  // namespace qemb

@@ -894,6 +894,7 @@ static int dev_gemm_dispatch(const GemmDesc& d) {
     case 35: return launch_layout<5, 2, 2, 4, 16, 0, 1>(d, s, vec2);  // 160 x 128, 8 waves as 2 x 4 (5 x 2 MFMA tiles per wave): pair-row counts that 160 divides well (465 = npair(30))
     case 36: return launch_layout<5, 2, 1, 4, 16, 0, 1>(d, s, vec2);  //  80 x 128, 4 waves as 1 x 4 (5 x 2 per wave), two workgroups per CU: the 66-80 packed pair rows of n_occ = 12 (mid-size fragments, round 5)
     case 37: return launch_layout<3, 3, 2, 2, 16, 0, 1>(d, s, vec2);  //  96 x  96, 4 waves as 2 x 2 (3 x 3 per wave): square products of 1000-2000 rows and columns (the rings of mid-size fragments: 15 x 15 tiles at o v = 1440 fill 225 of 256 CUs in one round)
+    case 38: return launch_layout<3, 2, 1, 4, 16, 0, 1>(d, s, vec2);  //  48 x 128, 4 waves as 1 x 4 (3 x 2 per wave): the 36-45 packed pair rows of n_occ = 9 (round 5: the 80-row tile spent 44 % of its MFMAs on padding there)
     case 236: return launch_layout<5, 2, 1, 4, 16>(d, s, vec2);
     case 237: return launch_layout<3, 3, 2, 2, 16>(d, s, vec2);
     case 20: return launch_layout<4, 1, 2, 2, 16>(d, s, vec2);   // 128 x  32, 4 waves: tall products with N = n_occ (the t1 contractions of ovvv)

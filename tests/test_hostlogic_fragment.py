@@ -423,7 +423,8 @@ def test_pair_gemm_tile_choice(hlib):
     assert choice(npair(30))[0] == 35                                      # 465 rows: three 160-row tiles
     assert choice(npair(40))[0] in (13, 4)                                 # 820 rows: 896 padded rows on a fast tile, NOT thirteen 64-row tiles
     assert choice(npair(40) - 40)[0] in (13, 15, 35, 4)                    # 780 antisymmetric rows
-    assert choice(36)[0] in (12, 36) and choice(100)[0] in (4, 11)             # small fragments keep the small tiles (36: the 80 x 128 tile of round 5)
+    assert choice(36)[0] == 38 and choice(45)[0] == 38 and choice(100)[0] in (4, 11)      # n_occ = 9: 45 / 36 pair rows on the 48 x 128 tile (round 5), not on 80 rows
+    assert choice(49)[0] in (12, 36)
     assert choice(78)[0] == 36 and choice(66)[0] == 36                         # n_occ = 12 (mid-size fragments): 78 / 66 pair rows on the 80-row tile, not on 128 rows
     assert choice(210, cols=1000) == (-1, 0)                               # few columns: the dispatcher's own choice
     for rows in (28, 105, 190, 210, 465, 820, 1275):
