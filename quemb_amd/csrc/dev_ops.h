@@ -37,6 +37,7 @@ int dev_free(void* p);                // parks the block in a free list (see dev
 int dev_trim();                       // release every parked block back to the driver (the calling context's)
 int dev_trim_all();                   // ... of EVERY context (each context's stream is drained first): between phases of very different working sets
 int dev_h2d(void* dst, const void* src_host, size_t bytes);
+int dev_h2d_async(void* dst, const void* src, size_t bytes);      // ordered on the calling context's stream only (the source is free on return)
 int dev_d2h(void* dst_host, const void* src, size_t bytes);
 // device -> PINNED host memory without waiting: the data are there after the next dev_sync of the calling context (lock-step sweeps read
 // the scalars of several fragments' streams with one wait each instead of one per transfer)
@@ -363,6 +364,17 @@ int dev_jacobi_eigh(int64_t n, double* A, double* w, double* V, int* sweeps_out)
 int dev_jacobi_eigh_until(int64_t n, double* A, double* w, double* V, int* sweeps_out, double stop_below);
 // One-sided Jacobi SVD of G (m x n row-major, m >= n), overwritten by U*diag(s) columns;
 // s[n] descending, V (n x n) right vectors in columns, U (m x n) left vectors in columns.
+// ---- fused steps of the fragment RHF of SMALL fragments (n <= dev_scf_fused_max(); 0: not available / switched off): see linalg_f64.hip
+int dev_scf_fused_max();
+// eigenproblem of F in the basis Cp (nullptr: as given): w ascending, C_out = Cp V (columns in that order), the same to C2_out (nullable; may be Cp), dm_out (nullable) =
+// 2 C_occ C_occ^T of the lowest nocc columns.  Asynchronous: *status_dev (device) receives the number of sweeps, or -1 when 40 sweeps did not converge -- read it at the
+// caller's next transfer.
+int dev_jacobi_eigh_in_basis(int64_t n, const double* F, const double* Cp, double* w, double* C_out, double* C2_out, int nocc, double* dm_out, double stop_below,
+                             int* status_dev);
+// F = h + J - K/2, err = F D - D F, scal2[0] = sum (h + F) o D, scal2[1] = sum err^2 (device)
+int dev_scf_fock_small(int64_t n, const double* h, const double* J, const double* K, const double* D, double* F, double* err, double* scal2);
+// Dp[P(r,s)] = D[r,s] + D[s,r] (r > s), D[r,r]
+int dev_pack_density_sym(int64_t n, const double* D, double* Dp);
 int dev_jacobi_svd(int64_t m, int64_t n, double* G, double* s, double* U, double* V, int* sweeps_out);
 
 // ---- the one exchange of the sharded sweep: a persistent communicator, one process per GPU ----------------

@@ -79,6 +79,11 @@ struct DevCtx {
   TimerSlot timers[TIMER_NSLOTS];
   std::map<size_t, std::vector<void*>> pool;   // caching allocator (see below)
   size_t pool_bytes = 0;
+  // pinned staging of small host <-> device copies (dev_h2d / dev_d2h): a ring of slots, each with the event of its last upload
+  unsigned char* stage = nullptr;
+  hipEvent_t stage_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  bool stage_busy[8] = {false, false, false, false, false, false, false, false};
+  int stage_next = 0;
 };
 struct LiveBlock { size_t bytes; DevCtx* owner; };
 static std::map<void*, LiveBlock> g_live_blocks;   // every block handed out by dev_alloc, any context
@@ -345,14 +350,57 @@ int dev_free(void* p) {
   HIP_TRY(timed_hip_free(p));
   return QEMB_OK;
 }
-int dev_h2d(void* dst, const void* src, size_t bytes) {
+// Small copies between PAGEABLE host memory and the device go through pinned slots of the calling context (round 5).  The runtime stages a pageable copy itself,
+// synchronously and under locks that the host threads of a batched sweep queue on (six fragments x ~8 small copies in the RHF phase of an octane sweep: the phase took
+// 3 x the time of one fragment alone).  Upload: the bytes are copied into the next slot of a ring and leave from there asynchronously -- no wait at all (the caller's
+// buffer is free on return, the stream orders the copy before later launches; a slot is reused only after the event of its last upload).  Download: device -> slot,
+// one stream wait, slot -> destination.  QEMB_STAGED_COPIES=0: the plain calls, for A/B runs.
+static constexpr size_t STAGE_SLOT = 256 * 1024;      // (n x n doubles up to n = 181)
+static bool stage_ready(DevCtx& c) {
+  static const bool on = !(std::getenv("QEMB_STAGED_COPIES") && std::atoi(std::getenv("QEMB_STAGED_COPIES")) == 0);
+  if (!on || c.capturing) return false;
+  if (c.stage) return true;
+  void* q = nullptr;
+  if (hipHostMalloc(&q, 8 * STAGE_SLOT, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return false; }
+  for (int k = 0; k < 8; ++k) if (hipEventCreateWithFlags(&c.stage_ev[k], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(q); return false; }
+  c.stage = (unsigned char*)q;
+  return true;
+}
+static int h2d_impl(void* dst, const void* src, size_t bytes, bool wait);
+// dev_h2d returns when the bytes are on the device (any stream may read them); dev_h2d_async only orders the copy on the calling context's stream -- for data that
+// the same context consumes (the source buffer is free on return either way)
+int dev_h2d(void* dst, const void* src, size_t bytes) { return h2d_impl(dst, src, bytes, true); }
+int dev_h2d_async(void* dst, const void* src, size_t bytes) { return h2d_impl(dst, src, bytes, false); }
+static int h2d_impl(void* dst, const void* src, size_t bytes, bool wait) {
   REQUIRE_INIT();
+  DevCtx& c = ctx();
+  if (bytes > 0 && bytes <= STAGE_SLOT && stage_ready(c)) {
+    const int k = c.stage_next; c.stage_next = (k + 1) & 7;
+    if (c.stage_busy[k]) { HIP_TRY(hipEventSynchronize(c.stage_ev[k])); c.stage_busy[k] = false; }
+    unsigned char* slot = c.stage + (size_t)k * STAGE_SLOT;
+    std::memcpy(slot, src, bytes);
+    HIP_TRY(hipMemcpyAsync(dst, slot, bytes, hipMemcpyHostToDevice, c.stream));
+    if (wait) { HIP_TRY(hipStreamSynchronize(c.stream)); return QEMB_OK; }
+    HIP_TRY(hipEventRecord(c.stage_ev[k], c.stream));
+    c.stage_busy[k] = true;
+    return QEMB_OK;
+  }
   HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, g_stream));
   HIP_TRY(hipStreamSynchronize(g_stream));   // pageable host memory: keep the contract simple
   return QEMB_OK;
 }
 int dev_d2h(void* dst, const void* src, size_t bytes) {
   REQUIRE_INIT();
+  DevCtx& c = ctx();
+  if (bytes > 0 && bytes <= STAGE_SLOT && stage_ready(c)) {
+    const int k = c.stage_next; c.stage_next = (k + 1) & 7;
+    if (c.stage_busy[k]) { HIP_TRY(hipEventSynchronize(c.stage_ev[k])); c.stage_busy[k] = false; }
+    unsigned char* slot = c.stage + (size_t)k * STAGE_SLOT;
+    HIP_TRY(hipMemcpyAsync(slot, src, bytes, hipMemcpyDeviceToHost, c.stream));
+    HIP_TRY(hipStreamSynchronize(c.stream));
+    std::memcpy(dst, slot, bytes);
+    return QEMB_OK;
+  }
   HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, g_stream));
   HIP_TRY(hipStreamSynchronize(g_stream));
   return QEMB_OK;

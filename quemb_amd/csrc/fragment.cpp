@@ -13,6 +13,10 @@
 #include <thread>
 #include <cmath>
 #include <cstring>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <unistd.h>
 
 namespace qemb {
 
@@ -188,9 +192,9 @@ int Fragment::run_scf(int o, const double* h, const double* dm0, const ScfOption
   QTRY(eps_.alloc(n_)); QTRY(dm_.alloc(n2)); QTRY(J_.alloc(n2)); QTRY(K_.alloc(n2));
   DBuf hd;
   QTRY(hd.alloc(n2));
-  QTRY(dev_h2d(hd, h, sizeof(double) * n2));
+  QTRY(dev_h2d_async(hd, h, sizeof(double) * n2));        // (consumed on this context's stream)
   if (dm0) {
-    QTRY(dev_h2d(dm_, dm0, sizeof(double) * n2));
+    QTRY(dev_h2d_async(dm_, dm0, sizeof(double) * n2));
   } else {   // core guess
     DBuf tmp; QTRY(tmp.alloc(n2)); QTRY(dcopy(n2, hd, tmp));
     QTRY(dev_jacobi_eigh(n_, tmp, eps_, C_, nullptr));
@@ -355,6 +359,68 @@ int Fragment::solve(int o, const double* h, const double* dm0, const FragmentOpt
 // Several fragments in one call: the phases around the CCSD iterations (fragment RHF + MO transformation + set-up; amplitudes -> 1-RDM ->
 // energies) run per fragment on one host thread and execution context each, as solver.map_fragments does; the CCSD iterations of all
 // fragments run in LOCK STEP on the calling thread (ccsd_kernel_lockstep: one grouped launch per operation for all fragments).
+// The per-fragment phases of a batched sweep run on PERSISTENT host threads (round 5): worker f serves fragment f of every phase of every sweep.  Starting six
+// std::threads three times per sweep cost ~0.1 ms per phase on the sweep's critical path (the last thread starts ~100 us after the first) -- 0.3 ms of an octane BE2
+// sweep of 14 ms.  The pool is never destroyed (its threads sleep on a condition variable; a fork()ed child makes its own); a second caller that finds it busy starts
+// plain threads as before.
+namespace {
+class PhasePool {
+ public:
+  static PhasePool* acquire(int F) {
+    static std::mutex guard;
+    static PhasePool* pool = nullptr;
+    std::lock_guard<std::mutex> lk(guard);
+    if (!pool || pool->pid_ != getpid()) pool = new PhasePool();      // (first use, or the child of a fork: the parent's workers do not exist here)
+    if (!pool->busy_.try_lock()) return nullptr;
+    pool->grow(F);
+    return pool;
+  }
+  void release() { busy_.unlock(); }
+  // fn(f) for f in [0, F) on workers 0 .. F-1; returns when every call has returned
+  void run(int F, const std::function<void(int)>& fn) {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      fn_ = &fn; active_ = F; pending_ = F; ++gen_;
+    }
+    cv_work_.notify_all();
+    std::unique_lock<std::mutex> lk(mu_);
+    cv_done_.wait(lk, [&] { return pending_ == 0; });
+    fn_ = nullptr;
+  }
+ private:
+  PhasePool() : pid_(getpid()) {}
+  void grow(int F) {
+    while ((int)nworkers_ < F) {
+      const int id = nworkers_++;
+      std::thread([this, id] { loop(id); }).detach();
+    }
+  }
+  void loop(int id) {
+    unsigned long long seen = 0;
+    for (;;) {
+      const std::function<void(int)>* fn = nullptr;
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_work_.wait(lk, [&] { return gen_ != seen; });
+        seen = gen_;
+        if (id < active_) fn = fn_;
+      }
+      if (!fn) continue;
+      (*fn)(id);
+      bool last;
+      { std::lock_guard<std::mutex> lk(mu_); last = (--pending_ == 0); }
+      if (last) cv_done_.notify_one();
+    }
+  }
+  pid_t pid_;
+  std::mutex busy_, mu_;
+  std::condition_variable cv_work_, cv_done_;
+  const std::function<void(int)>* fn_ = nullptr;
+  int active_ = 0, pending_ = 0, nworkers_ = 0;
+  unsigned long long gen_ = 0;
+};
+}  // namespace
+
 int Fragment::solve_batch(const std::vector<Fragment*>& frs, const std::vector<int>& o, const std::vector<const double*>& h,
                           const std::vector<const double*>& dm0, const FragmentOptions& opt, int eeval, std::vector<FragmentResult>& res,
                           const std::vector<BatchOutputs>& outs, LockstepStats* stats) {
@@ -370,15 +436,22 @@ int Fragment::solve_batch(const std::vector<Fragment*>& frs, const std::vector<i
   const bool threaded = have >= F + 1 && F > 1;
   std::vector<int> rc(F, 0);
   std::vector<std::string> msg(F);
+  static const bool pool_on = !(std::getenv("QEMB_PHASE_POOL") && std::atoi(std::getenv("QEMB_PHASE_POOL")) == 0);      // (0: a std::thread per fragment and phase, for A/B runs)
+  PhasePool* pool = (threaded && pool_on) ? PhasePool::acquire(F) : nullptr;
+  struct PoolRelease { PhasePool* p; ~PoolRelease() { if (p) p->release(); } } pool_guard{pool};
   auto per_fragment = [&](auto fn) {
     if (threaded) {
-      std::vector<std::thread> th;
-      for (int f = 0; f < F; ++f) th.emplace_back([&, f] {
+      auto body = [&](int f) {
         rc[f] = dev_ctx_bind(f + 1);
         if (rc[f] == 0) rc[f] = fn(f);
         if (rc[f] != 0) msg[f] = last_error();
-      });
-      for (auto& t : th) t.join();
+      };
+      if (pool) pool->run(F, body);
+      else {
+        std::vector<std::thread> th;
+        for (int f = 0; f < F; ++f) th.emplace_back([&, f] { body(f); });
+        for (auto& t : th) t.join();
+      }
     } else {
       for (int f = 0; f < F; ++f) { rc[f] = fn(f); if (rc[f] != 0) msg[f] = last_error(); }
     }
@@ -463,11 +536,17 @@ int Fragment::solve_begin_scf(int o, const double* h, const double* dm0, const F
   // nsocc == n: an embedding space without virtual orbitals.  PySCF's CCSD then has empty amplitude arrays and returns E_corr = 0; the
   // sweep body needs the mean-field results only (density = 2 I in any orthonormal basis, no correlation contribution to the energies).
   const int64_t n2 = (int64_t)n * n;
+  static const bool trace = std::getenv("QEMB_SCF_TRACE") != nullptr;      // host time of the steps of this phase on stderr (a measuring aid)
+  auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t0 = trace ? now() : 0.0;
   retire_solver();
+  const double t1 = trace ? now() : 0.0;
   // ---- fragment RHF on the half-unpacked tensor [P(p,q)][r][s] (kept: it is the first operand of the MO transformation)
   QTRY(scf_operand(sp_.X1, &sp_.x1_unpacked));         // [P(p,q)][r][s] for the four-index route (kept: its first operand); nothing on the factor route
+  const double t2 = trace ? now() : 0.0;
   ScfResult sres;
   QTRY(run_scf(o, h, dm0, opt.scf, sp_.X1, &sres, opt.warm_start != 0));
+  if (trace) std::fprintf(stderr, "[qemb scf trace] n=%d retire %.0f us, operand %.0f us, run_scf %.0f us (%d cycles)\n", n, t1 - t0, t2 - t1, now() - t2, sres.cycles);
   res->scf_converged = sres.converged; res->scf_cycles = sres.cycles; res->e_scf = sres.e_tot;
   sp_.no_virtuals = (v == 0);
   if (!sres.converged) {

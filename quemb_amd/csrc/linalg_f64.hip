@@ -289,8 +289,13 @@ __global__ void __launch_bounds__(1024) jacobi_eigh_small_kernel(const double* _
 // place.  The partner of index i in round r of the round-robin is (2 r - i) mod (np - 1) (np - 1 itself pairs with r).  Largest rotated element per
 // thread in a register, combined once per sweep.  Same pairs, same angles, same order of rounds as jacobi_eigh_small_kernel.
 constexpr int JE_DB_MAX = 80;
-__global__ void __launch_bounds__(1024) jacobi_eigh_small_db_kernel(const double* __restrict__ Ag, int n, double* __restrict__ w_out, double* __restrict__ V_out,
-                                                                    double tol, double stop_below, int max_sweeps, int* __restrict__ status) {
+// Fused form for the fragment RHF (round 5; Cp != nullptr or dm_out != nullptr): the matrix is first rotated into the basis Cp (A = Cp^T F Cp, the orbitals of the last
+// SCF cycle, in which F is nearly diagonal), the eigenvectors are rotated back (C = Cp V, columns in ascending order of the eigenvalues), written to V_out and --
+// when asked -- a second time to C2_out (which may be Cp itself: the next cycle's basis), and dm_out = 2 C_occ C_occ^T of the lowest `nocc` columns.  One launch
+// where the SCF cycle of a small fragment made seven (two products in, the eigensolve, one product out, a copy, the density product).
+__global__ void __launch_bounds__(1024) jacobi_eigh_small_db_kernel(const double* __restrict__ Ag, int n, double* __restrict__ w_out, double* V_out,
+                                                                    double tol, double stop_below, int max_sweeps, int* __restrict__ status,
+                                                                    const double* Cp, double* C2_out, int nocc, double* __restrict__ dm_out) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int ld = n + 1 + (n & 1);
   const int np = n + (n & 1), nh = np >> 1, m = np - 1;
@@ -302,7 +307,19 @@ __global__ void __launch_bounds__(1024) jacobi_eigh_small_db_kernel(const double
   __shared__ unsigned long long offbits;
   __shared__ double scale_sh;
   const int tid = threadIdx.x, nt = blockDim.x;
-  for (int t = tid; t < n * n; t += nt) { const int i = t / n, j = t - i * n; A0[i * ld + j] = Ag[t]; V[i * ld + j] = (i == j) ? 1.0 : 0.0; }
+  if (Cp) {
+    // A0 = Cp^T (F Cp): F in A1, Cp in V, the half product in A0, the result back in A1 -- then A1 moves to A0 and V becomes the identity
+    for (int t = tid; t < n * n; t += nt) { const int i = t / n, j = t - i * n; A1[i * ld + j] = Ag[t]; V[i * ld + j] = Cp[t]; }
+    __syncthreads();
+    for (int t = tid; t < n * n; t += nt) { const int i = t / n, j = t - i * n; double a = 0.0; for (int k = 0; k < n; ++k) a += A1[i * ld + k] * V[k * ld + j]; A0[i * ld + j] = a; }
+    __syncthreads();
+    for (int t = tid; t < n * n; t += nt) { const int i = t / n, j = t - i * n; double a = 0.0; for (int k = 0; k < n; ++k) a += V[k * ld + i] * A0[k * ld + j]; A1[i * ld + j] = a; }
+    __syncthreads();
+    // (the product is symmetric up to rounding; the sweeps read the upper triangle for the angles and keep both halves: make it exactly symmetric)
+    for (int t = tid; t < n * n; t += nt) { const int i = t / n, j = t - i * n; A0[i * ld + j] = (i <= j) ? A1[i * ld + j] : A1[j * ld + i]; V[i * ld + j] = (i == j) ? 1.0 : 0.0; }
+  } else {
+    for (int t = tid; t < n * n; t += nt) { const int i = t / n, j = t - i * n; A0[i * ld + j] = Ag[t]; V[i * ld + j] = (i == j) ? 1.0 : 0.0; }
+  }
   if (tid == 0) offbits = 0ull;
   __syncthreads();
   for (int i = tid; i < n; i += nt) { double a = 0.0; for (int j = 0; j < n; ++j) a += fabs(A0[i * ld + j]); rsum[i] = a; }
@@ -382,8 +399,76 @@ __global__ void __launch_bounds__(1024) jacobi_eigh_small_db_kernel(const double
     w_out[rk] = wi;
   }
   __syncthreads();
-  for (int t = tid; t < n * n; t += nt) { const int i = t / n, j = t - i * n; V_out[i * n + rank[j]] = V[i * ld + j]; }
+  if (!Cp && !dm_out && !C2_out) {
+    for (int t = tid; t < n * n; t += nt) { const int i = t / n, j = t - i * n; V_out[i * n + rank[j]] = V[i * ld + j]; }
+  } else {
+    // C = Cp V (or V itself), columns ranked, staged in the buffer the sweeps no longer need -- C2_out may be Cp, which every thread still reads here
+    double* Cs = dst;
+    for (int t = tid; t < n * n; t += nt) {
+      const int i = t / n, j = t - i * n;
+      double a;
+      if (Cp) { a = 0.0; for (int k = 0; k < n; ++k) a += Cp[i * n + k] * V[k * ld + j]; }
+      else a = V[i * ld + j];
+      Cs[i * ld + rank[j]] = a;
+    }
+    __syncthreads();
+    for (int t = tid; t < n * n; t += nt) {
+      const int i = t / n, j = t - i * n;
+      const double c = Cs[i * ld + j];
+      V_out[t] = c;
+      if (C2_out) C2_out[t] = c;
+      if (dm_out) { double a = 0.0; for (int k = 0; k < nocc; ++k) a += Cs[i * ld + k] * Cs[j * ld + k]; dm_out[t] = 2.0 * a; }
+    }
+  }
   if (tid == 0) status[0] = done ? sweep : -1;
+}
+
+// F = h + J - K/2, err = F D - D F, scal[0] = sum (h + F) o D (twice the SCF energy), scal[1] = sum err^2: the bookkeeping of one SCF cycle of a SMALL fragment
+// (n <= JE_MAX; F and D in the LDS of one workgroup) in one launch -- it was eight (the Fock combination, h + F, two reductions of two launches each, two n^3 products).
+// The two sums are formed in a fixed order (per thread over its elements, then a tree over the threads): the same numbers on every run.
+__global__ void __launch_bounds__(1024) scf_fock_small_kernel(int n, const double* __restrict__ h, const double* __restrict__ J, const double* __restrict__ K,
+                                                              const double* __restrict__ D, double* __restrict__ F_out, double* __restrict__ err_out,
+                                                              double* __restrict__ scal) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int ld = n + 1 + (n & 1);
+  double* F = lds;
+  double* Dm = F + (size_t)n * ld;
+  double* red = Dm + (size_t)n * ld;      // 2 x blockDim.x
+  const int tid = threadIdx.x, nt = blockDim.x;
+  double e2 = 0.0, g2 = 0.0;
+  for (int t = tid; t < n * n; t += nt) {
+    const int i = t / n, j = t - i * n;
+    const double hh = h[t], f = hh + J[t] - 0.5 * K[t], d = D[t];
+    F[i * ld + j] = f; Dm[i * ld + j] = d; F_out[t] = f;
+    e2 += (hh + f) * d;
+  }
+  __syncthreads();
+  for (int t = tid; t < n * n; t += nt) {
+    const int i = t / n, j = t - i * n;
+    double a = 0.0;
+    for (int k = 0; k < n; ++k) a += F[i * ld + k] * Dm[k * ld + j] - Dm[i * ld + k] * F[k * ld + j];
+    err_out[t] = a;
+    g2 += a * a;
+  }
+  red[tid] = e2; red[nt + tid] = g2;
+  __syncthreads();
+  for (int s = nt >> 1; s > 0; s >>= 1) {
+    if (tid < s) { red[tid] += red[tid + s]; red[nt + tid] += red[nt + tid + s]; }
+    __syncthreads();
+  }
+  if (tid == 0) { scal[0] = red[0]; scal[1] = red[nt]; }
+}
+// Dp[P(r,s)] = D[r,s] + D[s,r] (r > s), D[r,r]: the packed density of the Coulomb pass over the 4-fold packed block (four launches before: transpose, sum, diagonal, pack)
+__global__ void __launch_bounds__(256) pack_density_sym_kernel(int n, const double* __restrict__ D, double* __restrict__ Dp) {
+  const long long np = (long long)n * (n + 1) / 2;
+  for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < np; p += (long long)gridDim.x * blockDim.x) {
+    // row r of the lower triangle that holds p: r (r + 1) / 2 <= p
+    long long r = (long long)((sqrt(8.0 * (double)p + 1.0) - 1.0) * 0.5);
+    while (r * (r + 1) / 2 > p) --r;
+    while ((r + 1) * (r + 2) / 2 <= p) ++r;
+    const long long c = p - r * (r + 1) / 2;
+    Dp[p] = (r == c) ? D[r * n + r] : D[r * n + c] + D[c * n + r];
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -662,7 +747,8 @@ int dev_jacobi_eigh_until(int64_t n64, double* A, double* w, double* V, int* swe
       if (!attr_db) { HIP_TRY(hipFuncSetAttribute((const void*)jacobi_eigh_small_db_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64)); attr_db = true; }
       const int items = nh * n;                    // <= 4 per thread
       const int nthreads = std::min(1024, std::max(64, (items + 63) / 64 * 64));
-      hipLaunchKernelGGL(jacobi_eigh_small_db_kernel, dim3(1), dim3(nthreads), lds_db, s, (const double*)A, n, w, V, tol, stop_below, 40, d_st);
+      hipLaunchKernelGGL(jacobi_eigh_small_db_kernel, dim3(1), dim3(nthreads), lds_db, s, (const double*)A, n, w, V, tol, stop_below, 40, d_st,
+                         (const double*)nullptr, (double*)nullptr, 0, (double*)nullptr);
     } else {
     const int nthreads = n <= 32 ? 256 : (n <= 64 ? 512 : 1024);
     hipLaunchKernelGGL(jacobi_eigh_small_kernel, dim3(1), dim3(nthreads), lds, s, (const double*)A, n, w, V, tol, stop_below, 40, d_st);
@@ -709,6 +795,53 @@ int dev_jacobi_eigh_until(int64_t n64, double* A, double* w, double* V, int* swe
   }
   (void)dev_free(Vt); (void)dev_free(tmp); (void)dev_free(d_perm);
   return rc;
+}
+
+// ---- fused steps of the fragment RHF of small fragments (scf.cpp)
+int dev_scf_fused_max() {
+  static const int m = [] { const char* e = std::getenv("QEMB_SCF_FUSED"); return (e && std::atoi(e) == 0) ? 0 : JE_DB_MAX; }();      // (QEMB_SCF_FUSED=0: the launch-by-launch cycle, for A/B runs)
+  return m;
+}
+int dev_jacobi_eigh_in_basis(int64_t n64, const double* F, const double* Cp, double* w, double* C_out, double* C2_out, int nocc, double* dm_out, double stop_below,
+                             int* status_dev) {
+  hipStream_t s = hip_stream();
+  if (!s) { set_error("libqemb_hip: call qemb_init(device) first"); return QEMB_ERR_DEVICE; }
+  const int n = (int)n64;
+  if (n <= 0 || n > JE_DB_MAX || nocc < 0 || nocc > n || !status_dev) { set_error("dev_jacobi_eigh_in_basis: 0 < n <= 80, 0 <= nocc <= n, a status word"); return QEMB_ERR_ARG; }
+  const int ld = n + 1 + (n & 1), nh = (n + (n & 1)) / 2;
+  const size_t lds_db = sizeof(double) * ((size_t)3 * n * ld + n) + sizeof(int) * (size_t)n + 16;
+  static std::atomic<bool> attr_db{false};
+  if (!attr_db) { HIP_TRY(hipFuncSetAttribute((const void*)jacobi_eigh_small_db_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64)); attr_db = true; }
+  const double tol = std::max(1.0e-15, std::sqrt((double)n) * 2.22e-16);
+  const int items = nh * n;
+  const int nthreads = std::min(1024, std::max(64, (items + 63) / 64 * 64));
+  hipLaunchKernelGGL(jacobi_eigh_small_db_kernel, dim3(1), dim3(nthreads), lds_db, s, F, n, w, C_out, tol, stop_below, 40, status_dev, Cp, C2_out, nocc, dm_out);
+  HIP_TRY(hipGetLastError());
+  return QEMB_OK;
+}
+int dev_scf_fock_small(int64_t n64, const double* h, const double* J, const double* K, const double* D, double* F, double* err, double* scal2) {
+  hipStream_t s = hip_stream();
+  if (!s) { set_error("libqemb_hip: call qemb_init(device) first"); return QEMB_ERR_DEVICE; }
+  const int n = (int)n64;
+  if (n <= 0 || n > JE_DB_MAX) { set_error("dev_scf_fock_small: 0 < n <= 80"); return QEMB_ERR_ARG; }
+  const int ld = n + 1 + (n & 1);
+  const int nthreads = n <= 24 ? 256 : (n <= 40 ? 512 : 1024);
+  const size_t lds = sizeof(double) * ((size_t)2 * n * ld + 2 * nthreads);
+  static std::atomic<bool> attr{false};
+  if (!attr) { HIP_TRY(hipFuncSetAttribute((const void*)scf_fock_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64)); attr = true; }
+  hipLaunchKernelGGL(scf_fock_small_kernel, dim3(1), dim3(nthreads), lds, s, n, h, J, K, D, F, err, scal2);
+  HIP_TRY(hipGetLastError());
+  return QEMB_OK;
+}
+int dev_pack_density_sym(int64_t n64, const double* D, double* Dp) {
+  hipStream_t s = hip_stream();
+  if (!s) { set_error("libqemb_hip: call qemb_init(device) first"); return QEMB_ERR_DEVICE; }
+  const int n = (int)n64;
+  if (n <= 0) return QEMB_OK;
+  const long long np = (long long)n * (n + 1) / 2;
+  hipLaunchKernelGGL(pack_density_sym_kernel, dim3((unsigned)std::min<long long>((np + 255) / 256, 4096)), dim3(256), 0, s, n, D, Dp);
+  HIP_TRY(hipGetLastError());
+  return QEMB_OK;
 }
 
 int dev_jacobi_svd(int64_t m64, int64_t n64, double* G, double* sv, double* U, double* V, int* sweeps_out) {

@@ -5,28 +5,25 @@
 // molbe/helper.py:28-69 `get_veff` (J/K through `scf.hf.dot_eri_dm` :64).  The J/K contractions stream the
 // n^4 tensor once each (HBM bound); the Fock eigenproblem goes through the wavefront Jacobi solver.
 #include "scf.h"
+#include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstring>
 #include <vector>
 
 namespace qemb {
 
+static int packed_density(int n, const double* dm, DBuf& Dp);
 int build_jk(int n, const double* eri, const double* dm, double* J, double* K, const double* eri_s4) {
   const int64_t n2 = (int64_t)n * n;
   if (eri_s4 && n <= 1024 && (J || K)) {
     // J and K in ONE pass over the 4-fold packed block (4.7 GB at n = 220; the Coulomb product over it plus the exchange build over
     // the 9.4 GB pair-row tensor were two passes, 3.1 ms -> 1.1 ms per build)
     const int64_t np = (int64_t)n * (n + 1) / 2;
-    DBuf D2, Dp, Jp;
+    DBuf Dp, Jp;
     if (J) {
-      QTRY(D2.alloc(n2)); QTRY(Dp.alloc(np)); QTRY(Jp.alloc(np));
-      QTRY(perm4(D2, dm, 1, 1, n, n, 0, 1, 3, 2));            // D^T
-      QTRY(axpby(n2, 1.0, dm, 1.0, D2));                      // D + D^T
-      Copy4Desc c{};
-      c.dim[0] = 1; c.dim[1] = 1; c.dim[2] = 1; c.dim[3] = n;
-      c.in = dm; c.si[3] = n + 1; c.out = D2; c.so[3] = n + 1; c.alpha = 1.0; c.beta = 0.0;
-      QTRY(dev_copy4(c));                                     // diagonal back to D[r,r]
-      QTRY(dev_pack_tril_rows(1, n, D2, Dp));
+      QTRY(Jp.alloc(np));
+      QTRY(packed_density(n, dm, Dp));                        // Dp[rs] = D[r,s] + D[s,r] (r > s), D[r,r]
     }
     QTRY(dev_jk_from_packed(n, eri_s4, dm, J ? Dp.p : nullptr, J ? Jp.p : nullptr, K));
     if (J) QTRY(dev_unpack_tril_rows(1, n, Jp, J));
@@ -35,15 +32,9 @@ int build_jk(int n, const double* eri, const double* dm, double* J, double* K, c
   if (J && eri_s4) {
     // J from the 4-fold packed block (a quarter of the bytes): Jp = eri_s4 . Dp, Dp[rs] = D[r,s] + D[s,r] (r > s), D[r,r]
     const int64_t np = (int64_t)n * (n + 1) / 2;
-    DBuf D2, Dp, Jp;
-    QTRY(D2.alloc(n2)); QTRY(Dp.alloc(np)); QTRY(Jp.alloc(np));
-    QTRY(perm4(D2, dm, 1, 1, n, n, 0, 1, 3, 2));            // D^T
-    QTRY(axpby(n2, 1.0, dm, 1.0, D2));                      // D + D^T
-    Copy4Desc c{};
-    c.dim[0] = 1; c.dim[1] = 1; c.dim[2] = 1; c.dim[3] = n;
-    c.in = dm; c.si[3] = n + 1; c.out = D2; c.so[3] = n + 1; c.alpha = 1.0; c.beta = 0.0;
-    QTRY(dev_copy4(c));                                     // diagonal back to D[r,r]
-    QTRY(dev_pack_tril_rows(1, n, D2, Dp));
+    DBuf Dp, Jp;
+    QTRY(Jp.alloc(np));
+    QTRY(packed_density(n, dm, Dp));
     QTRY(dev_gemv_rows(np, np, eri_s4, np, Dp, Jp, 1.0, 0.0));
     QTRY(dev_unpack_tril_rows(1, n, Jp, J));
   } else if (J) {
@@ -57,16 +48,9 @@ int build_jk(int n, const double* eri, const double* dm, double* J, double* K, c
 }
 
 // packed density with doubled off-diagonals: Dp[P(r,s)] = D[r,s] + D[s,r] (r > s), D[r,r]
-static int packed_density(int n, const double* dm, DBuf& D2, DBuf& Dp) {
-  const int64_t n2 = (int64_t)n * n, np = (int64_t)n * (n + 1) / 2;
-  QTRY(D2.alloc(n2)); QTRY(Dp.alloc(np));
-  QTRY(perm4(D2, dm, 1, 1, n, n, 0, 1, 3, 2));            // D^T
-  QTRY(axpby(n2, 1.0, dm, 1.0, D2));                      // D + D^T
-  Copy4Desc c{};
-  c.dim[0] = 1; c.dim[1] = 1; c.dim[2] = 1; c.dim[3] = n;
-  c.in = dm; c.si[3] = n + 1; c.out = D2; c.so[3] = n + 1; c.alpha = 1.0; c.beta = 0.0;
-  QTRY(dev_copy4(c));                                     // diagonal back to D[r,r]
-  return dev_pack_tril_rows(1, n, D2, Dp);
+static int packed_density(int n, const double* dm, DBuf& Dp) {
+  QTRY(Dp.alloc((int64_t)n * (n + 1) / 2));
+  return dev_pack_density_sym(n, dm, Dp);                 // (one launch; it was four: transpose, sum, diagonal, pack)
 }
 
 int unpack_df_factor(int n, int naux, const double* Bp, double* Bfull) { return dev_unpack_tril_rows(naux, n, Bp, Bfull); }
@@ -75,8 +59,8 @@ int build_jk_factor(int n, int naux, const double* Bp, const double* Bfull, cons
   const int64_t n2 = (int64_t)n * n, np = (int64_t)n * (n + 1) / 2;
   if (naux <= 0 || !Bp || (K && !Bfull)) { set_error("build_jk_factor: no factor"); return QEMB_ERR_ARG; }
   if (J) {
-    DBuf D2, Dp, Jp, z;
-    QTRY(packed_density(n, dm, D2, Dp));
+    DBuf Dp, Jp, z;
+    QTRY(packed_density(n, dm, Dp));
     QTRY(Jp.alloc(np)); QTRY(z.alloc(naux));
     QTRY(dev_gemv_rows(naux, np, Bp, np, Dp, z, 1.0, 0.0));                 // z[L] = sum_P B[L,P] Dp[P]
     QTRY(dev_contract_mid(1, naux, np, Bp, z, Jp, np, 1.0, 0.0));            // Jp[P] = sum_L z[L] B[L,P]
@@ -128,16 +112,37 @@ static int rhf_loop(int n, int o, const double* h, const JkSource& src, double* 
   res->converged = false;
   int cyc = 0;
   bool dm_from_C = false;      // dm = 2 Co Co^T of the orbitals in C (every cycle after the first): the exchange matrix of a factor-resident fragment then needs o columns only
+  // Small fragments (n <= dev_scf_fused_max(), round 5): the cycle is launch bound -- ~28 launches and three waits -- so its two ends are single launches each: Fock
+  // matrix + energy + commutator + its norm (dev_scf_fock_small), and rotation into the last orbitals + Jacobi + rotation back + copy + density
+  // (dev_jacobi_eigh_in_basis, asynchronous: its status word travels with the next cycle's scalars).
+  const bool fused = n <= dev_scf_fused_max();
+  int* jac_status = reinterpret_cast<int*>(scal.p + 2);
+  bool status_pending = false;
+  auto check_status = [&](const double* word) {
+    int st; std::memcpy(&st, word, sizeof(int));
+    if (st < 0) { set_error("Jacobi sweeps did not converge in 40 sweeps"); return (int)QEMB_ERR_NOCONV; }
+    return 0;
+  };
+  static const bool trace = std::getenv("QEMB_SCF_TRACE") != nullptr;
+  auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   for (cyc = 0; cyc < opt.max_cycle; ++cyc) {
+    const double tc0 = trace ? now() : 0.0;
     QTRY(build_jk_from(n, src, dm, dm_from_C ? C : nullptr, o, J, K));
+    if (trace) { (void)dev_sync(); std::fprintf(stderr, "[qemb scf trace]   cycle %d: J/K issued + done %.0f us\n", cyc, now() - tc0); }
+    if (fused) {
+      QTRY(dev_scf_fock_small(n, h, J, K, dm, F, err, scal));
+    } else {
     QTRY(fock_from_jk(n2, h, J, K, F));                                   // F = h + J - K/2, one pass (small fragments are launch bound: five launches before)
     QTRY(lincomb2(n2, 1.0, h, 1.0, F, hpf));
     QTRY(dev_dot(n2, hpf, dm, scal));                                   // 2 E = <h + F, D>
     QTRY(gemm_nn(n, n, n, 1.0, F, dm, 0.0, err));                       // FD - DF   (S = I)
     QTRY(gemm_nn(n, n, n, -1.0, dm, F, 1.0, err));
     QTRY(dev_dot(n2, err, err, scal.p + 1));
-    double hs[2];
-    QTRY(dev_d2h(hs, scal, sizeof(double) * 2));
+    }
+    double hs[3] = {0.0, 0.0, 0.0};
+    QTRY(dev_d2h(hs, scal, sizeof(double) * (status_pending ? 3 : 2)));
+    if (status_pending) { status_pending = false; QTRY(check_status(hs + 2)); }
+    if (trace) std::fprintf(stderr, "[qemb scf trace]   cycle %d: scalars on the host %.0f us after the cycle began\n", cyc, now() - tc0);
     const double e_tot = 0.5 * hs[0], gnorm = std::sqrt(hs[1]);
     if (opt.verbose > 0) std::fprintf(stderr, "[qemb scf] cycle %2d  E = %.12f  dE = %.3e  |FD-DF| = %.3e\n", cyc, e_tot, e_tot - e_old, gnorm);
     res->e_tot = e_tot;
@@ -152,6 +157,12 @@ static int rhf_loop(int n, int o, const double* h, const JkSource& src, double* 
       for (int i = 0; i < n; ++i) ident[(size_t)i * n + i] = opt.level_shift;
       QTRY(dev_h2d(tmp, ident.data(), sizeof(double) * n2));
       QTRY(axpby(n2, 1.0, tmp, 1.0, Fd));
+    }
+    if (fused) {
+      QTRY(dev_jacobi_eigh_in_basis(n, Fd, have_prev ? Cprev.p : nullptr, eps, C, Cprev, o, dm, 1.0e-7, jac_status));
+      status_pending = true; have_prev = true; dm_from_C = true;
+      if (trace) { (void)dev_sync(); std::fprintf(stderr, "[qemb scf trace]   cycle %d: DIIS + eigensolve done %.0f us after the cycle began\n", cyc, now() - tc0); }
+      continue;
     }
     if (have_prev) {
       // rotate into the previous cycle's orbitals first: the Jacobi sweeps start from a nearly diagonal matrix
@@ -175,6 +186,12 @@ static int rhf_loop(int n, int o, const double* h, const JkSource& src, double* 
   if (!res->converged) {
     QTRY(build_jk_from(n, src, dm, dm_from_C ? C : nullptr, o, J, K));
     QTRY(fock_from_jk(n2, h, J, K, F));
+  }
+  if (fused) {
+    QTRY(dev_jacobi_eigh_in_basis(n, F, have_prev ? Cprev.p : nullptr, eps, C, nullptr, o, dm, 1.0e-10, jac_status));
+    double word = 0.0;
+    QTRY(dev_d2h(&word, scal.p + 2, sizeof(double)));
+    return check_status(&word);
   }
   if (have_prev) {
     // in the orbitals of the last cycle the converged Fock matrix is diagonal up to the SCF residual: the Jacobi sweeps need two or

@@ -37,6 +37,7 @@ int dev_free(void* p) { std::free(p); return 0; }
 int dev_trim() { return 0; }
 int dev_trim_all() { return dev_trim(); }
 int dev_h2d(void* d, const void* s, size_t b) { std::memcpy(d, s, b); return 0; }
+int dev_h2d_async(void* d, const void* s, size_t b) { std::memcpy(d, s, b); return 0; }
 int dev_d2h(void* d, const void* s, size_t b) { std::memcpy(d, s, b); return 0; }
 int dev_d2h_async(void* d, const void* s, size_t b) { std::memcpy(d, s, b); return 0; }
 int dev_pinned_alloc(void** p, size_t b) { *p = std::malloc(b ? b : 16); return *p ? 0 : QEMB_ERR_ALLOC; }
@@ -508,6 +509,47 @@ int dev_jacobi_eigh(int64_t n64, double* A, double* w, double* V, int* sweeps_ou
   std::stable_sort(perm.begin(), perm.end(), [&](int x, int y) { return a[(size_t)x * n + x] < a[(size_t)y * n + y]; });
   for (int i = 0; i < n; ++i) { w[i] = a[(size_t)perm[i] * n + perm[i]]; for (int k = 0; k < n; ++k) V[(size_t)k * n + i] = v[(size_t)k * n + perm[i]]; }
   if (sweeps_out) *sweeps_out = sweep;
+  return 0;
+}
+// fused steps of the fragment RHF of small fragments (linalg_f64.hip), restated with plain loops
+int dev_scf_fused_max() { return 80; }
+int dev_jacobi_eigh_in_basis(int64_t n64, const double* F, const double* Cp, double* w, double* C_out, double* C2_out, int nocc, double* dm_out, double, int* status_dev) {
+  const int n = (int)n64;
+  std::vector<double> a((size_t)n * n), v((size_t)n * n), c((size_t)n * n);
+  for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) {
+    double t = 0;
+    if (Cp) { for (int k = 0; k < n; ++k) for (int l = 0; l < n; ++l) t += Cp[(size_t)k * n + i] * F[(size_t)k * n + l] * Cp[(size_t)l * n + j]; }
+    else t = F[(size_t)i * n + j];
+    a[(size_t)i * n + j] = t;
+  }
+  for (int i = 0; i < n; ++i) for (int j = 0; j < i; ++j) a[(size_t)i * n + j] = a[(size_t)j * n + i];
+  int sweeps = 0;
+  dev_jacobi_eigh(n, a.data(), w, v.data(), &sweeps);
+  for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) {
+    double t = 0;
+    if (Cp) { for (int k = 0; k < n; ++k) t += Cp[(size_t)i * n + k] * v[(size_t)k * n + j]; } else t = v[(size_t)i * n + j];
+    c[(size_t)i * n + j] = t;
+  }
+  for (size_t t = 0; t < (size_t)n * n; ++t) { C_out[t] = c[t]; if (C2_out) C2_out[t] = c[t]; }
+  if (dm_out) for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) { double t = 0; for (int k = 0; k < nocc; ++k) t += c[(size_t)i * n + k] * c[(size_t)j * n + k]; dm_out[(size_t)i * n + j] = 2.0 * t; }
+  *status_dev = sweeps;
+  return 0;
+}
+int dev_scf_fock_small(int64_t n64, const double* h, const double* J, const double* K, const double* D, double* F, double* err, double* scal2) {
+  const int n = (int)n64;
+  long double e2 = 0, g2 = 0;
+  for (size_t t = 0; t < (size_t)n * n; ++t) { F[t] = h[t] + J[t] - 0.5 * K[t]; e2 += (long double)(h[t] + F[t]) * D[t]; }
+  for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) {
+    double a = 0;
+    for (int k = 0; k < n; ++k) a += F[(size_t)i * n + k] * D[(size_t)k * n + j] - D[(size_t)i * n + k] * F[(size_t)k * n + j];
+    err[(size_t)i * n + j] = a; g2 += (long double)a * a;
+  }
+  scal2[0] = (double)e2; scal2[1] = (double)g2;
+  return 0;
+}
+int dev_pack_density_sym(int64_t n64, const double* D, double* Dp) {
+  const int64_t n = n64;
+  for (int64_t r = 0; r < n; ++r) for (int64_t c = 0; c <= r; ++c) Dp[pidx(r, c)] = (r == c) ? D[r * n + r] : D[r * n + c] + D[c * n + r];
   return 0;
 }
 int dev_jacobi_svd(int64_t m64, int64_t n64, double* G, double* s, double* U, double* V, int* sweeps_out) {
