@@ -644,7 +644,10 @@ static int jacobi_rows(int nvec, int64_t len, double* W, int64_t ldw, double* Vt
   hipStream_t s = hip_stream();
   if (nvec < 2) { if (sweeps_out) *sweeps_out = 0; return QEMB_OK; }
   const int np = (nvec % 2 == 0) ? nvec : nvec + 1;
-  if (Vt && nvec <= JS_MAX && len <= JS_MAX) {   // LDS-resident single-workgroup path
+  // (64 < nvec <= 96 take the block rounds below since round 5: n = 96 cold 3.2-3.4 -> 1.35 ms, warm 1.28 -> 0.60 ms; n = 80 2.1 -> 1.34 / 0.89 -> 0.60 ms -- one
+  //  workgroup is bound by the LDS bandwidth of its CU there; at n = 57 the single workgroup is still the faster one, 0.86 vs 0.92 ms.  QEMB_JACOBI_ROWS_SMALL_MAX=96: as before)
+  static const int rows_small_max = [] { const char* e = std::getenv("QEMB_JACOBI_ROWS_SMALL_MAX"); return e ? std::atoi(e) : 64; }();
+  if (Vt && nvec <= JS_MAX && len <= JS_MAX && nvec <= rows_small_max) {   // LDS-resident single-workgroup path
     int* d_sw = nullptr;
     QTRY_ALLOC(d_sw, sizeof(int));
     const double tol_s = std::max(1.0e-15, std::sqrt((double)len) * 2.22e-16);
@@ -731,7 +734,9 @@ int dev_jacobi_eigh_until(int64_t n64, double* A, double* w, double* V, int* swe
   if (n <= 0) return QEMB_OK;
   // small matrices: the whole eigensolve in one launch (two-sided Jacobi in LDS; QEMB_JACOBI_TWOSIDED=0: the one-sided path below, for A/B runs)
   static const bool two_sided = !(std::getenv("QEMB_JACOBI_TWOSIDED") && std::atoi(std::getenv("QEMB_JACOBI_TWOSIDED")) == 0);
-  static const int small_max = [] { const char* e = std::getenv("QEMB_JACOBI_SMALL_MAX"); return e ? std::min(std::atoi(e), JE_MAX) : JE_MAX; }();      // (A/B runs: the block path from a smaller n on)
+  // (n <= 80: the one-barrier kernel; 80 < n <= 96 went through the three-barrier kernel until round 5 -- 1.28 ms warm, bound by the LDS bandwidth of its one CU -- and take
+  //  the block rounds of jacobi_rows now, 0.60 ms; QEMB_JACOBI_SMALL_MAX=96: as before)
+  static const int small_max = [] { const char* e = std::getenv("QEMB_JACOBI_SMALL_MAX"); return e ? std::min(std::atoi(e), JE_MAX) : JE_DB_MAX; }();
   if (two_sided && n <= small_max) {
     int* d_st = nullptr;
     QTRY_ALLOC(d_st, sizeof(int));
