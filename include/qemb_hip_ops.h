@@ -163,6 +163,14 @@ int qemb_op_ladder_pack_vvvv_pf(int64_t n, int64_t o, const double* Mp, double* 
 int qemb_op_unpack_tril_rows(int64_t rows, int64_t n, const double* packed, double* full);
 int qemb_op_pack_tril_rows(int64_t rows, int64_t n, const double* full, double* packed);
 int qemb_op_jacobi_eigh(int64_t n, double* A, double* w, double* V, int* sweeps);
+/* The SCF cycle of a SMALL fragment in two fused launches (round 5; n <= qemb_op_scf_fused_max(), 80 on the device; reference: molbe/helper.py:73-151, PySCF scf.hf.kernel):
+ * qemb_op_scf_fock_small: F = h + J - K/2, err = F D - D F, scal2 = [sum (h + F) o D, sum err^2] (device);
+ * qemb_op_jacobi_eigh_in_basis: eigenproblem of F in the orthonormal basis Cp (NULL: as given) -- w ascending, C_out = Cp V, the same to C2_out (NULL or any buffer, Cp itself
+ * allowed), dm_out (NULL or) 2 C_occ C_occ^T of the lowest nocc columns;  qemb_op_pack_density_sym: Dp[P(r,s)] = D[r,s] + D[s,r] (r > s), D[r,r]. */
+int qemb_op_scf_fused_max(void);
+int qemb_op_jacobi_eigh_in_basis(int64_t n, const double* F, const double* Cp, double* w, double* C_out, double* C2_out, int nocc, double* dm_out, double stop_below, int* sweeps);
+int qemb_op_scf_fock_small(int64_t n, const double* h, const double* J, const double* K, const double* D, double* F, double* err, double* scal2);
+int qemb_op_pack_density_sym(int64_t n, const double* D, double* Dp);
 int qemb_op_jacobi_svd(int64_t m, int64_t n, double* G, double* s, double* U, double* V, int* sweeps);
 int qemb_op_cholesky_lower(int64_t n, double* A);
 int qemb_op_tri_inverse_lower(int64_t n, const double* L, double* Linv);

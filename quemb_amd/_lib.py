@@ -133,6 +133,10 @@ def _declare(lib):
     f("qemb_op_ladder_pack_vvvv_pf", I, L, L, P, P, L, P, L)
     f("qemb_op_pack_tril_rows", I, L, L, P, P)
     f("qemb_op_jacobi_eigh", I, L, P, P, P, C.POINTER(I))
+    f("qemb_op_scf_fused_max", I)
+    f("qemb_op_jacobi_eigh_in_basis", I, L, P, P, P, P, P, I, P, D, C.POINTER(I))
+    f("qemb_op_scf_fock_small", I, L, P, P, P, P, P, P, P)
+    f("qemb_op_pack_density_sym", I, L, P, P)
     f("qemb_op_jacobi_svd", I, L, L, P, P, P, P, C.POINTER(I))
     f("qemb_op_cholesky_lower", I, L, P)
     f("qemb_op_tri_inverse_lower", I, L, P, P)

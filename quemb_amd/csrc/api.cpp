@@ -238,6 +238,21 @@ int qemb_op_unpack_tril_pair_rows(int64_t nr, int64_t n, const double* in, doubl
 int qemb_op_unpack_tril_rows(int64_t rows, int64_t n, const double* p, double* f) { return dev_unpack_tril_rows(rows, n, p, f); }
 int qemb_op_pack_tril_rows(int64_t rows, int64_t n, const double* f, double* p) { return dev_pack_tril_rows(rows, n, f, p); }
 int qemb_op_jacobi_eigh(int64_t n, double* A, double* w, double* V, int* sweeps) { return dev_jacobi_eigh(n, A, w, V, sweeps); }
+// the fused steps of the fragment RHF of small fragments (scf.cpp), each on its own
+int qemb_op_scf_fused_max(void) { return dev_scf_fused_max(); }
+int qemb_op_jacobi_eigh_in_basis(int64_t n, const double* F, const double* Cp, double* w, double* C_out, double* C2_out, int nocc, double* dm_out, double stop_below, int* sweeps) {
+  DBuf st;
+  QTRY(st.alloc(1));
+  QTRY(dev_jacobi_eigh_in_basis(n, F, Cp, w, C_out, C2_out, nocc, dm_out, stop_below, reinterpret_cast<int*>(st.p)));
+  double word = 0.0;
+  QTRY(dev_d2h(&word, st.p, sizeof(double)));
+  int sw; std::memcpy(&sw, &word, sizeof(int));
+  if (sweeps) *sweeps = sw;
+  if (sw < 0) { set_error("Jacobi sweeps did not converge in 40 sweeps"); return QEMB_ERR_NOCONV; }
+  return QEMB_OK;
+}
+int qemb_op_scf_fock_small(int64_t n, const double* h, const double* J, const double* K, const double* D, double* F, double* err, double* scal2) { return dev_scf_fock_small(n, h, J, K, D, F, err, scal2); }
+int qemb_op_pack_density_sym(int64_t n, const double* D, double* Dp) { return dev_pack_density_sym(n, D, Dp); }
 int qemb_op_jacobi_svd(int64_t m, int64_t n, double* G, double* s, double* U, double* V, int* sweeps) { return dev_jacobi_svd(m, n, G, s, U, V, sweeps); }
 int qemb_op_cholesky_lower(int64_t n, double* A) { return dev_cholesky_lower(n, A); }
 int qemb_op_tri_inverse_lower(int64_t n, const double* L, double* Linv) { return dev_tri_inverse_lower(n, L, Linv); }

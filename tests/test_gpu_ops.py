@@ -254,6 +254,60 @@ def test_jacobi_eigh(qlib, n):
     assert np.abs(A @ V - V * w).max() < 1e-11 * scale
 
 
+def check_fused_scf_ops(lib, sizes):
+    """The fused steps of the SCF cycle of small fragments (linalg_f64.hip; reference molbe/helper.py:73-151) against NumPy: packed density, Fock + energy + commutator,
+    eigenproblem in a rotated basis with back-rotation, copy and density."""
+    nmax = lib.qemb_op_scf_fused_max()
+    for n in sizes:
+        if n > nmax:
+            continue
+        rng = np.random.default_rng(100 + n)
+        sym = lambda a: 0.5 * (a + a.T)
+        h, J, K = (sym(rng.standard_normal((n, n))) for _ in range(3))
+        nocc = max(1, n // 3)
+        Q = np.linalg.qr(rng.standard_normal((n, n)))[0]
+        D = 2.0 * Q[:, :nocc] @ Q[:, :nocc].T + 1e-3 * rng.standard_normal((n, n))      # (not exactly symmetric: the packed density must add both halves)
+        dh, dJ, dK, dD = (DeviceBuffer.from_numpy(x, lib=lib) for x in (h, J, K, D))
+        dF, dE, dS = DeviceBuffer(n * n, lib=lib), DeviceBuffer(n * n, lib=lib), DeviceBuffer(2, lib=lib)
+        check(lib.qemb_op_scf_fock_small(n, dh.ptr, dJ.ptr, dK.ptr, dD.ptr, dF.ptr, dE.ptr, dS.ptr), lib=lib)
+        F = h + J - 0.5 * K
+        err = F @ D - D @ F
+        assert np.abs(dF.numpy((n, n)) - F).max() < 1e-14 * max(1.0, np.abs(F).max())
+        assert np.abs(dE.numpy((n, n)) - err).max() < 1e-12 * max(1.0, np.abs(err).max())
+        sc = dS.numpy()
+        assert abs(sc[0] - ((h + F) * D).sum()) < 1e-11 * max(1.0, abs(((h + F) * D).sum())) and abs(sc[1] - (err * err).sum()) < 1e-11 * (err * err).sum()
+        # packed density
+        dP = DeviceBuffer(n * (n + 1) // 2, lib=lib)
+        check(lib.qemb_op_pack_density_sym(n, dD.ptr, dP.ptr), lib=lib)
+        il = np.tril_indices(n)
+        want = np.where(il[0] == il[1], D[il], D[il] + D.T[il])
+        assert np.abs(dP.numpy() - want).max() == 0.0
+        # eigenproblem in the basis Cp, with and without a basis, C2 aliasing Cp, density of the lowest nocc
+        for with_basis in (True, False):
+            Cp = np.linalg.qr(rng.standard_normal((n, n)))[0]
+            Fd = sym(rng.standard_normal((n, n))) + np.diag(3.0 * np.arange(n))
+            dFd, dCp = DeviceBuffer.from_numpy(Fd, lib=lib), DeviceBuffer.from_numpy(Cp, lib=lib)
+            dw, dC, dDm = DeviceBuffer(n, lib=lib), DeviceBuffer(n * n, lib=lib), DeviceBuffer(n * n, lib=lib)
+            sw = C.c_int(0)
+            check(lib.qemb_op_jacobi_eigh_in_basis(n, dFd.ptr, dCp.ptr if with_basis else None, dw.ptr, dC.ptr, dCp.ptr, nocc, dDm.ptr, 1e-10, C.byref(sw)), lib=lib)
+            w, Cm, C2, Dm = dw.numpy(), dC.numpy((n, n)), dCp.numpy((n, n)), dDm.numpy((n, n))
+            wr = np.linalg.eigvalsh(Fd)
+            scale = np.abs(wr).max()
+            assert np.abs(w - wr).max() < 1e-12 * scale and sw.value >= 1
+            assert np.abs(Cm.T @ Cm - np.eye(n)).max() < 1e-12
+            assert np.abs(Fd @ Cm - Cm * w).max() < 1e-11 * scale
+            assert np.array_equal(C2, Cm)                                                   # the copy (written over Cp)
+            assert np.abs(Dm - 2.0 * Cm[:, :nocc] @ Cm[:, :nocc].T).max() < 1e-13
+            for b in (dFd, dCp, dw, dC, dDm):
+                b.free()
+        for b in (dh, dJ, dK, dD, dF, dE, dS, dP):
+            b.free()
+
+
+def test_fused_scf_ops(qlib):
+    check_fused_scf_ops(qlib, (2, 7, 24, 41, 42, 57, 64, 79, 80))
+
+
 def test_jacobi_eigh_projector_spectrum(qlib):
     """The Schmidt case: environment block of an idempotent 1-RDM (eigenvalues 0, 1 and a few in between)."""
     rng = np.random.default_rng(14)

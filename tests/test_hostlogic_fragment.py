@@ -478,3 +478,9 @@ def check_solve_batch_equals_one_by_one(lib, sizes=((8, 3, 3), (10, 4, 4), (7, 2
 
 def test_solve_batch_equals_one_by_one(hlib):
     check_solve_batch_equals_one_by_one(hlib)
+
+
+def test_fused_scf_ops_on_the_mock(hlib):
+    """the fused steps of the SCF cycle of small fragments through the C ABI of the mock build (the GPU test of the same name runs the HIP kernels)"""
+    from test_gpu_ops import check_fused_scf_ops
+    check_fused_scf_ops(hlib, (2, 7, 24, 41))
