@@ -464,8 +464,9 @@ int Fragment::solve_batch(const std::vector<Fragment*>& frs, const std::vector<i
   // (QEMB_TAPE_PREPHASE=1).  Measured in round 5 and left off: recording the sequence anew every sweep (stream capture + node queries) and running the merged
   // sequence serially costs more than six streams issuing it side by side -- octane BE2 begin phase 3.1 -> 3.9 ms, BE3 sweep 26.9 -> 27.8 ms.
   static const bool tape_pre = std::getenv("QEMB_TAPE_PREPHASE") && std::atoi(std::getenv("QEMB_TAPE_PREPHASE")) != 0;
-  QTRY(per_fragment([&](int f) { return frs[f]->solve_begin_scf(o[f], h[f], dm0[f], opt, eeval, &res[f]); }));
-  const double t_scf_done = now();
+  // (one pass of the host threads for both halves of the begin phase since round 5: a fragment goes on to its integrals as soon as ITS RHF is through instead of
+  //  waiting for the slowest RHF of the sweep)
+  std::vector<double> ms_scf(F, 0.0);
   std::vector<double> ms_cc(F, 0.0), ms_capture(F, 0.0);      // (trace: the slowest fragment's share of the second half of the begin phase)
   std::vector<dev_tape_t> pre(F, nullptr);
   std::vector<char> taped(F, 0);
@@ -474,6 +475,12 @@ int Fragment::solve_batch(const std::vector<Fragment*>& frs, const std::vector<i
   const bool try_tape = tape_pre && threaded && small_all && opt.relax_density == 0;
   QTRY(per_fragment([&](int f) {
     int r = 0;
+    {
+      const double ts = now();
+      r = frs[f]->solve_begin_scf(o[f], h[f], dm0[f], opt, eeval, &res[f]);
+      ms_scf[f] = now() - ts;
+      if (r != 0) return r;
+    }
     if (try_tape && !frs[f]->sp_.no_virtuals && dev_graph_begin(1) == 0) {
       const int rc_cc = frs[f]->solve_begin_cc(true);
       dev_tape_t t = nullptr;
@@ -514,8 +521,8 @@ int Fragment::solve_batch(const std::vector<Fragment*>& frs, const std::vector<i
     rc_end[f] = frs[f]->solve_end(outs[f].mo_coeff, outs[f].mo_energy, outs[f].rdm1_emb, outs[f].rdm1_mo, outs[f].t1, outs[f].t2);
     return rc_end[f];
   });
-  if (trace) std::fprintf(stderr, "[qemb batch] %d fragments: begin %.2f ms (RHF %.2f, integrals + set-up <= %.2f, recording <= %.2f), lock-step iterations %.2f ms (tapes %.2f, post %.2f), end %.2f ms\n", F,
-                          t_begin_done - t_start, t_scf_done - t_start, *std::max_element(ms_cc.begin(), ms_cc.end()), *std::max_element(ms_capture.begin(), ms_capture.end()),
+  if (trace) std::fprintf(stderr, "[qemb batch] %d fragments: begin %.2f ms (RHF <= %.2f, integrals + set-up <= %.2f, recording <= %.2f), lock-step iterations %.2f ms (tapes %.2f, post %.2f), end %.2f ms\n", F,
+                          t_begin_done - t_start, *std::max_element(ms_scf.begin(), ms_scf.end()), *std::max_element(ms_cc.begin(), ms_cc.end()), *std::max_element(ms_capture.begin(), ms_capture.end()),
                           t_lock_done - t_begin_done, stats ? stats->ms_tapes : 0.0, stats ? stats->ms_post : 0.0, now() - t_lock_done);
   if (worst) return worst;
   for (int f = 0; f < F; ++f) if (rc_end[f] > 0) { warn = rc_end[f]; set_error("fragment " + std::to_string(f) + ": " + msg[f]); }
