@@ -45,6 +45,10 @@ int qemb_trim(void);                       /* hand every parked block back to th
 int qemb_trim_all(void);              /* the same for EVERY execution context (their streams are drained first): between phases with very different working sets */
 int qemb_h2d(void* dptr, const void* host, size_t bytes);
 int qemb_d2h(void* host, const void* dptr, size_t bytes);
+/* upload that only ORDERS the copy on the calling context's stream (for data that context consumes; qemb_sync or any later download of the context completes it).  The host
+ * buffer is free on return: copies of up to 256 KB leave from pinned slots of the context (round 5 -- the runtime's pageable path serialised the host threads of a
+ * batched sweep), larger ones fall back to the waiting path of qemb_h2d. */
+int qemb_h2d_async(void* dptr, const void* host, size_t bytes);
 int qemb_d2d(void* dst, const void* src, size_t bytes);
 
 /* Execution contexts (one HIP stream + workspaces + block cache each; no reference counterpart -- the reference overlaps

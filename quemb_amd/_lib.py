@@ -64,6 +64,7 @@ def _declare(lib):
     f("qemb_trim_all", I)
     f("qemb_h2d", I, V, V, C.c_size_t)
     f("qemb_d2h", I, V, V, C.c_size_t)
+    f("qemb_h2d_async", I, V, V, C.c_size_t)
     f("qemb_d2d", I, V, V, C.c_size_t)
     f("qemb_timer_begin", I, I)
     f("qemb_timer_end", I, I)

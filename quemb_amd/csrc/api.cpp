@@ -55,6 +55,7 @@ int qemb_trim(void) { return dev_trim(); }
 int qemb_trim_all(void) { return dev_trim_all(); }
 int qemb_h2d(void* d, const void* h, size_t b) { return dev_h2d(d, h, b); }
 int qemb_d2h(void* h, const void* d, size_t b) { return dev_d2h(h, d, b); }
+int qemb_h2d_async(void* d, const void* h, size_t b) { return dev_h2d_async(d, h, b); }
 int qemb_d2d(void* d, const void* s, size_t b) { return dev_d2d(d, s, b); }
 int qemb_timer_begin(int s) { return dev_timer_begin(s); }
 int qemb_timer_end(int s) { return dev_timer_end(s); }

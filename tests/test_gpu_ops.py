@@ -254,6 +254,41 @@ def test_jacobi_eigh(qlib, n):
     assert np.abs(A @ V - V * w).max() < 1e-11 * scale
 
 
+def check_small_copies(lib):
+    """host <-> device copies around the size of the pinned slots (256 KB) and more asynchronous uploads in a row than there are slots: every byte arrives, a host
+    buffer may be overwritten as soon as the upload call has returned"""
+    rng = np.random.default_rng(5)
+    slot = 256 * 1024 // 8
+    sizes = [1, 7, 1000, slot - 1, slot, slot + 1, 3 * slot]
+    for n in sizes:                                   # the waiting pair
+        a = rng.standard_normal(n)
+        d = DeviceBuffer.from_numpy(a, lib=lib)
+        assert np.array_equal(d.numpy(), a)
+        d.free()
+    bufs, want = [], []
+    scratch = np.empty(slot)
+    for k in range(28):                               # > 3 x the ring of eight slots, mixed sizes, ONE host buffer reused for all of them
+        n = [5, 4096, slot, slot - 3][k % 4]
+        scratch[:n] = rng.standard_normal(n)
+        want.append(scratch[:n].copy())
+        d = DeviceBuffer(n, lib=lib)
+        check(lib.qemb_h2d_async(d.ptr, scratch.ctypes.data, n * 8), "qemb_h2d_async", lib)
+        scratch[:n] = -1.0                            # the source is free on return
+        bufs.append(d)
+    big = rng.standard_normal(2 * slot + 5)           # beyond a slot: the waiting path behind the same call
+    dbig = DeviceBuffer(big.size, lib=lib)
+    check(lib.qemb_h2d_async(dbig.ptr, big.ctypes.data, big.size * 8), "qemb_h2d_async", lib)
+    for d, w in zip(bufs, want):
+        assert np.array_equal(d.numpy(), w)
+        d.free()
+    assert np.array_equal(dbig.numpy(), big)
+    dbig.free()
+
+
+def test_small_copies_through_pinned_slots(qlib):
+    check_small_copies(qlib)
+
+
 def check_fused_scf_ops(lib, sizes):
     """The fused steps of the SCF cycle of small fragments (linalg_f64.hip; reference molbe/helper.py:73-151) against NumPy: packed density, Fock + energy + commutator,
     eigenproblem in a rotated basis with back-rotation, copy and density."""

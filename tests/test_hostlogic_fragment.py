@@ -484,3 +484,8 @@ def test_fused_scf_ops_on_the_mock(hlib):
     """the fused steps of the SCF cycle of small fragments through the C ABI of the mock build (the GPU test of the same name runs the HIP kernels)"""
     from test_gpu_ops import check_fused_scf_ops
     check_fused_scf_ops(hlib, (2, 7, 24, 41))
+
+
+def test_small_copies_on_the_mock(hlib):
+    from test_gpu_ops import check_small_copies
+    check_small_copies(hlib)
